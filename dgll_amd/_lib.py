@@ -1,0 +1,79 @@
+"""ctypes binding of libdgll_hip.so (the C ABI declared in include/dgll_hip.h).
+
+There is no fallback: if the library is missing and cannot be built, importing dgll_amd raises.  The
+in-tree location (dgll_amd/lib/libdgll_hip.so) is deliberate -- the driver records which in-tree .so
+files the test processes mapped.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdgll_hip.so")
+
+OK = 0
+F32, BF16 = 0, 1
+REDUCE_SUM, REDUCE_MEAN = 0, 1
+EPI_NONE, EPI_BIAS, EPI_RELU = 0, 1, 2
+
+
+class DgllHipError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        # Source checkout without a built library: build it now (hipcc cross-compiles without a GPU).
+        from . import build as _build
+
+        _build.build()
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libdgll_hip.so is missing (expected at %s); run `python -m dgll_amd.build`" % LIB_PATH)
+    return C.CDLL(LIB_PATH)
+
+
+lib = _load()
+
+_vp, _i32, _i64, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/dgll_hip.h one to one (tests/test_abi.py checks the header)
+SIGNATURES = {
+    "dgll_hip_abi_version": (_i32, []),
+    "dgll_hip_last_error": (C.c_char_p, []),
+    "dgll_hip_device_info": (_i32, [_i32, C.c_char_p, _i32, C.POINTER(_i32), C.POINTER(_i64)]),
+    "dgll_hip_csr_plan_create": (_i32, [_vp, _vp, _i64, _i64, _i32, C.POINTER(_vp)]),
+    "dgll_hip_csr_plan_destroy": (None, [_vp]),
+    "dgll_hip_csr_plan_workspace_bytes": (_sz, [_vp, _i32]),
+    "dgll_hip_csr_plan_num_long_rows": (_i64, [_vp]),
+    "dgll_hip_csr_plan_num_chunks": (_i64, [_vp]),
+    "dgll_hip_spmm_csr": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _i64, _i32, _i64, _i64, _i32, _i32,
+                                 _i32, _vp, _vp, _sz]),
+    "dgll_hip_sddmm_csr": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i32, _vp, _i64, _i32]),
+    "dgll_hip_gat_fwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i64, _i32, _i32,
+                                C.c_float, _i32, _i32]),
+    "dgll_hip_gat_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i32,
+                                _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32, C.c_float, _i32,
+                                _i32]),
+    "dgll_hip_segment_max": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i32, _i64, _i32]),
+}
+
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(lib, _name)  # AttributeError here == the library does not export a declared symbol
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+def last_error():
+    msg = lib.dgll_hip_last_error()
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+def check(code, what):
+    if code != OK:
+        raise DgllHipError("%s failed (code %d): %s" % (what, code, last_error()))
+
+
+def device_info(device=0):
+    name = C.create_string_buffer(64)
+    cus, mem = _i32(0), _i64(0)
+    check(lib.dgll_hip_device_info(device, name, 64, C.byref(cus), C.byref(mem)), "dgll_hip_device_info")
+    return {"arch": name.value.decode(), "compute_units": cus.value, "global_mem_bytes": mem.value}

@@ -1,0 +1,81 @@
+"""Build libdgll_hip.so (hand-written HIP for gfx950) in-tree with hipcc.
+
+    python -m dgll_amd.build [--force] [--verbose]
+
+The shared library lands in dgll_amd/lib/ (git-ignored, but it travels with the gpurun snapshot).  hipcc
+cross-compiles for gfx950 without a GPU, so this also runs in the CPU-only build container.
+"""
+import concurrent.futures as cf
+import glob
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+OBJDIR = os.path.join(LIBDIR, "obj")
+LIB = os.path.join(LIBDIR, "libdgll_hip.so")
+ARCH = "gfx950"
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
+         "-ffp-contract=fast"]
+
+
+def _hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: libdgll_hip.so cannot be built")
+    return exe
+
+
+def _newest(paths):
+    return max(os.path.getmtime(p) for p in paths)
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def headers():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hpp"))) + [os.path.join(HERE, "..", "include", "dgll_hip.h")]
+
+
+def build(force=False, verbose=False):
+    srcs, hdrs = sources(), headers()
+    if not srcs:
+        raise RuntimeError("no HIP sources under " + CSRC)
+    os.makedirs(OBJDIR, exist_ok=True)
+    hipcc = _hipcc()
+    hdr_time = _newest(hdrs)
+
+    def compile_one(src):
+        obj = os.path.join(OBJDIR, os.path.basename(src)[:-4] + ".o")
+        if (not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), hdr_time)):
+            return obj, False
+        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, res.stdout, res.stderr))
+        if verbose and res.stderr.strip():
+            print(res.stderr, file=sys.stderr)
+        return obj, True
+
+    with cf.ThreadPoolExecutor(max_workers=min(6, len(srcs))) as ex:
+        results = list(ex.map(compile_one, srcs))
+    objs = [o for o, _ in results]
+    if force or any(ch for _, ch in results) or not os.path.exists(LIB) or os.path.getmtime(LIB) < _newest(objs):
+        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError("link failed:\n%s\n%s" % (res.stdout, res.stderr))
+    return LIB
+
+
+if __name__ == "__main__":
+    path = build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv)
+    print(path)

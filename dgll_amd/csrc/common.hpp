@@ -1,0 +1,128 @@
+// common.hpp -- shared device/host helpers of libdgll_hip.so (gfx950 only, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/dgll_hip.h"
+
+#define DGLL_API extern "C" __attribute__((visibility("default")))
+
+namespace dgll {
+
+constexpr int kWave = 64;           // CDNA4 wavefront width
+constexpr int kBlock = 256;         // 4 waves per workgroup, one per SIMD
+constexpr int kWavesPerBlock = kBlock / kWave;
+constexpr int kXcds = 8;            // MI355X: 8 XCDs, block b is dispatched to XCD b % 8
+
+typedef uint16_t bf16_t;            // raw bfloat16 bits
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+
+// ---- error plumbing (thread-local text, negative return codes; never exit()) -----------------------
+void set_error(const std::string& msg);
+int hip_fail(hipError_t e, const char* what);
+
+#define DGLL_HIP_TRY(expr)                                          \
+    do {                                                            \
+        hipError_t _e = (expr);                                     \
+        if (_e != hipSuccess) return ::dgll::hip_fail(_e, #expr);   \
+    } while (0)
+
+#define DGLL_REQUIRE(cond, msg)                                     \
+    do {                                                            \
+        if (!(cond)) { ::dgll::set_error(std::string(msg) + " [" #cond "]"); return DGLL_ERR_INVALID; } \
+    } while (0)
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ---- bf16 <-> f32 ------------------------------------------------------------------------------------
+__device__ __forceinline__ float bf16_lo(uint32_t packed) { return __uint_as_float(packed << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t packed) { return __uint_as_float(packed & 0xffff0000u); }
+__device__ __forceinline__ float bf16_to_f32(bf16_t b) { return __uint_as_float((uint32_t)b << 16); }
+// round-to-nearest-even pack of two floats: one v_cvt_pk_bf16_f32 on gfx950
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(pack_bf16x2(f, 0.0f) & 0xffffu); }
+
+// make a wave-uniform 64-bit value provably uniform (SGPR pair) for the compiler
+__device__ __forceinline__ int64_t uniform64(int64_t v) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)v >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & (kWave - 1)); }
+
+// XCD-aware block remap: give every XCD (private 4 MiB L2) a CONTIGUOUS range of logical blocks, so rows
+// that are close in the graph (and tend to share neighbours) share an L2.  Bijective for any grid size.
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t nblocks) {
+    const uint32_t q = nblocks / kXcds, r = nblocks % kXcds;   // XCD x owns q (+1 if x < r) logical blocks
+    const uint32_t xcd = bid % kXcds, idx = bid / kXcds;
+    const uint32_t start = xcd * q + (xcd < r ? xcd : r);
+    return start + idx;
+}
+
+// ---- typed 16-byte / scalar row-vector access ----------------------------------------------------------
+// VecIO<T, EPV>: EPV elements of storage type T handled by one lane.  EPV * sizeof(T) is 16 bytes on the
+// fast path (global_load_dwordx4) and sizeof(T) on the any-alignment path.
+template <typename T, int EPV> struct VecIO;
+
+template <> struct VecIO<float, 4> {
+    typedef uint4 raw_t;
+    static __device__ __forceinline__ raw_t zero() { return make_uint4(0, 0, 0, 0); }
+    static __device__ __forceinline__ raw_t load(const float* p) { return *reinterpret_cast<const uint4*>(p); }
+    static __device__ __forceinline__ void unpack(const raw_t& r, float (&f)[4]) {
+        f[0] = __uint_as_float(r.x); f[1] = __uint_as_float(r.y); f[2] = __uint_as_float(r.z); f[3] = __uint_as_float(r.w);
+    }
+    static __device__ __forceinline__ void store(float* p, const float (&f)[4]) {
+        *reinterpret_cast<float4*>(p) = make_float4(f[0], f[1], f[2], f[3]);
+    }
+};
+template <> struct VecIO<float, 1> {
+    typedef float raw_t;
+    static __device__ __forceinline__ raw_t zero() { return 0.0f; }
+    static __device__ __forceinline__ raw_t load(const float* p) { return *p; }
+    static __device__ __forceinline__ void unpack(const raw_t& r, float (&f)[1]) { f[0] = r; }
+    static __device__ __forceinline__ void store(float* p, const float (&f)[1]) { *p = f[0]; }
+};
+template <> struct VecIO<bf16_t, 8> {
+    typedef uint4 raw_t;
+    static __device__ __forceinline__ raw_t zero() { return make_uint4(0, 0, 0, 0); }
+    static __device__ __forceinline__ raw_t load(const bf16_t* p) { return *reinterpret_cast<const uint4*>(p); }
+    static __device__ __forceinline__ void unpack(const raw_t& r, float (&f)[8]) {
+        f[0] = bf16_lo(r.x); f[1] = bf16_hi(r.x); f[2] = bf16_lo(r.y); f[3] = bf16_hi(r.y);
+        f[4] = bf16_lo(r.z); f[5] = bf16_hi(r.z); f[6] = bf16_lo(r.w); f[7] = bf16_hi(r.w);
+    }
+    static __device__ __forceinline__ void store(bf16_t* p, const float (&f)[8]) {
+        *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]),
+                                                  pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7]));
+    }
+};
+template <> struct VecIO<bf16_t, 1> {
+    typedef bf16_t raw_t;
+    static __device__ __forceinline__ raw_t zero() { return 0; }
+    static __device__ __forceinline__ raw_t load(const bf16_t* p) { return *p; }
+    static __device__ __forceinline__ void unpack(const raw_t& r, float (&f)[1]) { f[0] = bf16_to_f32(r); }
+    static __device__ __forceinline__ void store(bf16_t* p, const float (&f)[1]) { *p = f32_to_bf16(f[0]); }
+};
+// wide stores used when the output type differs from the gather type
+template <> struct VecIO<float, 8> {
+    static __device__ __forceinline__ void store(float* p, const float (&f)[8]) {
+        reinterpret_cast<float4*>(p)[0] = make_float4(f[0], f[1], f[2], f[3]);
+        reinterpret_cast<float4*>(p)[1] = make_float4(f[4], f[5], f[6], f[7]);
+    }
+};
+template <> struct VecIO<bf16_t, 4> {
+    static __device__ __forceinline__ void store(bf16_t* p, const float (&f)[4]) {
+        *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]));
+    }
+};
+
+template <typename T> __device__ __forceinline__ void store_one(T* p, float v);
+template <> __device__ __forceinline__ void store_one<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void store_one<bf16_t>(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+
+}  // namespace dgll

@@ -1,0 +1,602 @@
+// edge.hip -- per-edge kernels of the GAT / SpecialSpmm path for gfx950: SDDMM, fused edge-softmax + SpMM
+// (forward), its two backward gather passes, and the max-reduce of the SAGE aggregator.
+//
+// Reference semantics (all under /root/reference/dgll/nn/Convolution/):
+//   sparseGatConv.forward  gatconv.py:111-148   e_ij = exp(-leakyrelu(a1.h_i + a2.h_j)); out_i = sum_j e_ij h_j / sum_j e_ij; elu
+//   gatConv.forward        gatconv.py:30-54     att = softmax_j(+leakyrelu(.)) over the adjacency's nonzeros; out = att.Wh; elu
+//   SpecialSpmmFunction    gatconv.py:60-81     backward: grad_values[e] = <g[row_e,:], b[col_e,:]>  (SDDMM), grad_b = A^T.g
+//   SpGAT / GAT            gatconv.py:154-199   `nheads` independent heads, concatenated (one python call per head)
+// Here all heads of a layer run in ONE launch: H is [N, heads*fo] (fo = per-head width, padded by the host to a
+// power-of-two number of 16-byte vectors), S[i,k] = a1_k.h_i^k and T[j,k] = a2_k.h_j^k are [N, heads] fp32.
+//
+// Same skeleton as spmm.hip: one wavefront per row, LPR lanes x 16 bytes per gathered feature row, 64/LPR
+// neighbour slots, U gathers in flight per lane, a coalesced 64-edge index batch handed out with ds_bpermute,
+// fp32 accumulation, no atomics (fixed reduction order, bit-reproducible).  Nothing per-edge is ever stored:
+// the backward passes recompute e_ij from S and T.
+#include "common.hpp"
+
+namespace dgll {
+
+struct EdgeArgs {
+    const int64_t* rowptr;
+    const int32_t* col;
+    const int64_t* perm;        // A^T edge slot -> A edge slot (only to index edge_scale from the transposed pass)
+    const void* H;              // gathered matrix [n_cols, ld]
+    int64_t ldh;
+    const void* G;              // row-side matrix [n_rows, ld] (sddmm: grad_out; gat_bwd_rows: grad_out)
+    int64_t ldg;
+    const void* O;              // forward output [n_rows, ld] (gat_bwd_rows)
+    int64_t ldo;
+    void* Y;                    // main output matrix
+    int64_t ldy;
+    const float* S;             // [*, heads] row-side scores
+    const float* T;             // [*, heads] gathered-side scores
+    const float* M;             // [*, heads] row maxima (mode 1) or NULL
+    const float* DEN;           // [*, heads] denominators
+    const float* DD;            // [*, heads] d(denominator)
+    const float* edge_scale;    // [nnz, heads] dropout multipliers or NULL
+    float* out_a;               // fp32 [*, heads] output (rowsum / ds / dt)
+    float* out_b;               // fp32 [*, heads] output (rowmax / dden)
+    float* edge_out;            // fp32 [nnz] (sddmm)
+    int64_t n_rows;
+    int heads, fo, feat;        // feat = heads * fo
+    float alpha, sign;          // leaky-relu slope; -1: exp(-lrelu) (sparseGatConv), +1: softmax(+lrelu) (gatConv)
+    int apply_elu, use_max;
+    int32_t* arg_out;           // segment_max: int32 [n_rows, ld] source row of the maximum
+};
+
+__device__ __forceinline__ float lrelu(float z, float alpha) { return z > 0.0f ? z : alpha * z; }
+
+// sum over the `lph` adjacent lanes that hold one head's columns (lph is a power of two <= 64)
+__device__ __forceinline__ float head_sum(float v, int lph) {
+    for (int off = 1; off < lph; off <<= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+template <int LPR>
+__device__ __forceinline__ float slot_sum(float v) {
+#pragma unroll
+    for (int off = LPR; off < kWave; off <<= 1) v += __shfl_xor(v, off);
+    return v;
+}
+template <int LPR>
+__device__ __forceinline__ float slot_max(float v) {
+#pragma unroll
+    for (int off = LPR; off < kWave; off <<= 1) v = fmaxf(v, __shfl_xor(v, off));
+    return v;
+}
+
+// Iterates the edges [b, e) of one row in coalesced batches of 64; `body(j0, nb, cur_col, k0)` is called once
+// per batch with the lane-distributed column ids (lane l holds edge k0 + l).
+template <typename Body>
+__device__ __forceinline__ void for_each_batch(const int32_t* __restrict__ col, int64_t b, int64_t e, int lane, Body body) {
+    int my_col = 0;
+    if (b + lane < e) my_col = col[b + lane];
+    for (int64_t k0 = b; k0 < e; k0 += kWave) {
+        const int64_t left = e - k0;
+        const int nb = left < kWave ? (int)left : kWave;
+        const int cur_col = my_col;
+        const int64_t kn = k0 + kWave + lane;
+        if (kn < e) my_col = col[kn];
+        body(nb, cur_col, k0);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ SDDMM
+// edge_out[k] = sum_f G[row(k), f] * H[col[k], f]            (gatconv.py:76-78)
+template <typename XT, int EPV, int LPR, int U>
+__global__ __launch_bounds__(kBlock) void sddmm_kernel(const EdgeArgs a) {
+    typedef VecIO<XT, EPV> IO;
+    constexpr int SLOTS = kWave / LPR;
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int sub = lane % LPR, slot = lane / LPR;
+    const int c0 = sub * EPV;
+    const bool col_ok = c0 < a.feat;
+    const int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+    if (row >= a.n_rows) return;
+    const int64_t b = uniform64(a.rowptr[row]), e = uniform64(a.rowptr[row + 1]);
+    float g[EPV];
+    {
+        typename IO::raw_t r = col_ok ? IO::load(static_cast<const XT*>(a.G) + row * a.ldg + c0) : IO::zero();
+        IO::unpack(r, g);
+    }
+    const XT* hcol = static_cast<const XT*>(a.H) + (col_ok ? c0 : 0);
+    for_each_batch(a.col, b, e, lane, [&](int nb, int cur_col, int64_t k0) {
+        for (int j = 0; j < nb; j += SLOTS * U) {
+            int idx[U];
+            typename IO::raw_t v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                idx[u] = j + u * SLOTS + slot;
+                const int c = __shfl(cur_col, idx[u] < nb ? idx[u] : nb - 1);
+                v[u] = IO::load(hcol + (int64_t)c * a.ldh);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float f[EPV];
+                IO::unpack(v[u], f);
+                float d = 0.0f;
+#pragma unroll
+                for (int i = 0; i < EPV; ++i) d = fmaf(g[i], f[i], d);
+                d = head_sum(d, LPR);
+                if (sub == 0 && idx[u] < nb) a.edge_out[k0 + idx[u]] = d;
+            }
+        }
+    });
+}
+
+// ------------------------------------------------------------------------------------------------ GAT forward
+// out[i, head cols] = act( sum_j w_ij * scale_ij * H[j, cols] / sum_j w_ij ),  w_ij = exp(sign*lrelu(S[i]+T[j]) - M[i])
+template <typename XT, typename YT, int EPV, int LPR, int U>
+__global__ __launch_bounds__(kBlock) void gat_fwd_kernel(const EdgeArgs a, int lph) {
+    typedef VecIO<XT, EPV> IO;
+    constexpr int SLOTS = kWave / LPR;
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int sub = lane % LPR, slot = lane / LPR;
+    const int c0 = ((int)blockIdx.y * LPR + sub) * EPV;
+    const bool col_ok = c0 < a.feat;
+    const int head = col_ok ? c0 / a.fo : 0;
+    const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int64_t row = (int64_t)bid * kWavesPerBlock + wave;
+    if (row >= a.n_rows) return;
+    const int64_t b = uniform64(a.rowptr[row]), e = uniform64(a.rowptr[row + 1]);
+    const float s_i = a.S[row * a.heads + head];
+    const XT* hcol = static_cast<const XT*>(a.H) + (col_ok ? c0 : 0);
+
+    float m_i = 0.0f;
+    if (a.use_max) {  // gatConv semantics: subtract the row maximum of the scores (softmax), gatconv.py:36
+        float mx = -INFINITY;
+        for_each_batch(a.col, b, e, lane, [&](int nb, int cur_col, int64_t) {
+            for (int j = 0; j < nb; j += SLOTS) {  // uniform trip count: every lane takes part in the shuffle
+                const int idx = j + slot;
+                const int c = __shfl(cur_col, idx < nb ? idx : nb - 1);
+                mx = fmaxf(mx, a.sign * lrelu(s_i + a.T[(int64_t)c * a.heads + head], a.alpha));
+            }
+        });
+        m_i = slot_max<LPR>(mx);
+    }
+
+    float acc[EPV];
+#pragma unroll
+    for (int i = 0; i < EPV; ++i) acc[i] = 0.0f;
+    float den = 0.0f;
+    for_each_batch(a.col, b, e, lane, [&](int nb, int cur_col, int64_t k0) {
+        for (int j = 0; j < nb; j += SLOTS * U) {
+            bool ok[U];
+            int idx[U];
+            float t[U], sc[U];
+            typename IO::raw_t v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                idx[u] = j + u * SLOTS + slot;
+                ok[u] = idx[u] < nb;
+                if (!ok[u]) idx[u] = nb - 1;
+                const int c = __shfl(cur_col, idx[u]);
+                t[u] = a.T[(int64_t)c * a.heads + head];
+                sc[u] = a.edge_scale ? a.edge_scale[(k0 + idx[u]) * a.heads + head] : 1.0f;
+                v[u] = IO::load(hcol + (int64_t)c * a.ldh);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float w = __expf(a.sign * lrelu(s_i + t[u], a.alpha) - m_i);
+                w = ok[u] ? w : 0.0f;
+                den += w;
+                const float wn = w * sc[u];
+                float f[EPV];
+                IO::unpack(ok[u] ? v[u] : IO::zero(), f);
+#pragma unroll
+                for (int i = 0; i < EPV; ++i) acc[i] = fmaf(wn, f[i], acc[i]);
+            }
+        }
+    });
+#pragma unroll
+    for (int i = 0; i < EPV; ++i) acc[i] = slot_sum<LPR>(acc[i]);
+    den = slot_sum<LPR>(den);
+    if (slot == 0 && col_ok) {
+        const float inv = 1.0f / den;  // 0/0 -> NaN for edgeless rows, as gatconv.py:139
+#pragma unroll
+        for (int i = 0; i < EPV; ++i) {
+            float v = acc[i] * inv;
+            if (a.apply_elu) v = v > 0.0f ? v : expm1f(v);
+            acc[i] = v;
+        }
+        VecIO<YT, EPV>::store(static_cast<YT*>(a.Y) + row * a.ldy + c0, acc);
+        if ((sub % lph) == 0) {
+            a.out_a[row * a.heads + head] = den;
+            if (a.out_b) a.out_b[row * a.heads + head] = m_i;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ GAT backward, pass 1 (rows of A)
+// Per row i:  dhp = g * elu'(hp);  DN[i,:] = dhp / den_i;  DD[i,k] = -sum_{f in k} dhp*hp / den_i;
+//             ds[i,k] = sum_j dz_ij,   dz_ij = (scale_ij * <DN_i, h_j>_k + DD[i,k]) * w_ij * sign * lrelu'(S_i+T_j)
+template <typename XT, int EPV, int LPR, int U>
+__global__ __launch_bounds__(kBlock) void gat_bwd_rows_kernel(const EdgeArgs a, int lph) {
+    typedef VecIO<XT, EPV> IO;
+    constexpr int SLOTS = kWave / LPR;
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int sub = lane % LPR, slot = lane / LPR;
+    const int c0 = ((int)blockIdx.y * LPR + sub) * EPV;
+    const bool col_ok = c0 < a.feat;
+    const int head = col_ok ? c0 / a.fo : 0;
+    const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int64_t row = (int64_t)bid * kWavesPerBlock + wave;
+    if (row >= a.n_rows) return;
+    const int64_t b = uniform64(a.rowptr[row]), e = uniform64(a.rowptr[row + 1]);
+    const float s_i = a.S[row * a.heads + head];
+    const float m_i = a.M ? a.M[row * a.heads + head] : 0.0f;
+    const float inv_den = 1.0f / a.DEN[row * a.heads + head];
+
+    float dn[EPV];
+    float dd;
+    {
+        float g[EPV], o[EPV];
+        IO::unpack(col_ok ? IO::load(static_cast<const XT*>(a.G) + row * a.ldg + c0) : IO::zero(), g);
+        IO::unpack(col_ok ? IO::load(static_cast<const XT*>(a.O) + row * a.ldo + c0) : IO::zero(), o);
+        float part = 0.0f;
+#pragma unroll
+        for (int i = 0; i < EPV; ++i) {
+            float dhp = g[i], hp = o[i];
+            if (a.apply_elu && o[i] <= 0.0f) {  // out = expm1(hp): elu'(hp) = out + 1, hp = log1p(out)
+                dhp = g[i] * (o[i] + 1.0f);
+                hp = log1pf(o[i]);
+            }
+            part = fmaf(dhp, hp, part);
+            dn[i] = dhp * inv_den;
+        }
+        dd = -head_sum(part, lph) * inv_den;
+        if (slot == 0 && col_ok) {
+            VecIO<XT, EPV>::store(static_cast<XT*>(a.Y) + row * a.ldy + c0, dn);
+            if ((sub % lph) == 0) a.out_b[row * a.heads + head] = dd;
+        }
+        if (sizeof(XT) == 2) {  // the transposed pass re-reads DN in storage precision: use the same rounded values here
+#pragma unroll
+            for (int i = 0; i < EPV; ++i) dn[i] = bf16_to_f32(f32_to_bf16(dn[i]));
+        }
+    }
+
+    const XT* hcol = static_cast<const XT*>(a.H) + (col_ok ? c0 : 0);
+    float ds = 0.0f;
+    for_each_batch(a.col, b, e, lane, [&](int nb, int cur_col, int64_t k0) {
+        for (int j = 0; j < nb; j += SLOTS * U) {
+            bool ok[U];
+            int idx[U];
+            float t[U], sc[U];
+            typename IO::raw_t v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                idx[u] = j + u * SLOTS + slot;
+                ok[u] = idx[u] < nb;
+                if (!ok[u]) idx[u] = nb - 1;
+                const int c = __shfl(cur_col, idx[u]);
+                t[u] = a.T[(int64_t)c * a.heads + head];
+                sc[u] = a.edge_scale ? a.edge_scale[(k0 + idx[u]) * a.heads + head] : 1.0f;
+                v[u] = IO::load(hcol + (int64_t)c * a.ldh);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float f[EPV];
+                IO::unpack(v[u], f);
+                float dot = 0.0f;
+#pragma unroll
+                for (int i = 0; i < EPV; ++i) dot = fmaf(dn[i], f[i], dot);
+                dot = head_sum(dot, lph);
+                const float z = s_i + t[u];
+                const float w = __expf(a.sign * lrelu(z, a.alpha) - m_i);
+                const float dz = (sc[u] * dot + dd) * w * a.sign * (z > 0.0f ? 1.0f : a.alpha);
+                ds += ok[u] ? dz : 0.0f;
+            }
+        }
+    });
+    ds = slot_sum<LPR>(ds);
+    if (slot == 0 && col_ok && (sub % lph) == 0) a.out_a[row * a.heads + head] = ds;
+}
+
+// ------------------------------------------------------------------------------------------------ GAT backward, pass 2 (rows of A^T)
+// Per source node j:  dH[j,:] = sum_i w_ij * scale_ij * DN[i,:];   dt[j,k] = sum_i dz_ij   (dz recomputed, see pass 1)
+// Here rowptr/col describe A^T (rows = j, columns = i); H is DN (gathered by i); G is the node's own h_j row;
+// S holds the per-node score of the ROW side of this pass (T of the forward), T the gathered side (S of the forward).
+template <typename XT, typename YT, int EPV, int LPR, int U>
+__global__ __launch_bounds__(kBlock) void gat_bwd_cols_kernel(const EdgeArgs a, int lph) {
+    typedef VecIO<XT, EPV> IO;
+    constexpr int SLOTS = kWave / LPR;
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int sub = lane % LPR, slot = lane / LPR;
+    const int c0 = ((int)blockIdx.y * LPR + sub) * EPV;
+    const bool col_ok = c0 < a.feat;
+    const int head = col_ok ? c0 / a.fo : 0;
+    const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int64_t row = (int64_t)bid * kWavesPerBlock + wave;
+    if (row >= a.n_rows) return;
+    const int64_t b = uniform64(a.rowptr[row]), e = uniform64(a.rowptr[row + 1]);
+    const float t_j = a.S[row * a.heads + head];
+    float hj[EPV];
+    IO::unpack(col_ok ? IO::load(static_cast<const XT*>(a.G) + row * a.ldg + c0) : IO::zero(), hj);
+    const XT* dncol = static_cast<const XT*>(a.H) + (col_ok ? c0 : 0);
+
+    float acc[EPV];
+#pragma unroll
+    for (int i = 0; i < EPV; ++i) acc[i] = 0.0f;
+    float dt = 0.0f;
+    for_each_batch(a.col, b, e, lane, [&](int nb, int cur_col, int64_t k0) {
+        for (int j = 0; j < nb; j += SLOTS * U) {
+            bool ok[U];
+            int idx[U];
+            float s[U], m[U], dd[U], sc[U];
+            typename IO::raw_t v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                idx[u] = j + u * SLOTS + slot;
+                ok[u] = idx[u] < nb;
+                if (!ok[u]) idx[u] = nb - 1;
+                const int64_t c = __shfl(cur_col, idx[u]);
+                s[u] = a.T[c * a.heads + head];
+                m[u] = a.M ? a.M[c * a.heads + head] : 0.0f;
+                dd[u] = a.DD[c * a.heads + head];
+                sc[u] = a.edge_scale ? a.edge_scale[a.perm[k0 + idx[u]] * a.heads + head] : 1.0f;
+                v[u] = IO::load(dncol + c * a.ldh);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float f[EPV];
+                IO::unpack(ok[u] ? v[u] : IO::zero(), f);
+                float dot = 0.0f;
+#pragma unroll
+                for (int i = 0; i < EPV; ++i) dot = fmaf(f[i], hj[i], dot);
+                dot = head_sum(dot, lph);
+                const float z = s[u] + t_j;
+                float w = __expf(a.sign * lrelu(z, a.alpha) - m[u]);
+                w = ok[u] ? w : 0.0f;
+                dt += (sc[u] * dot + dd[u]) * w * a.sign * (z > 0.0f ? 1.0f : a.alpha);
+                const float wn = w * sc[u];
+#pragma unroll
+                for (int i = 0; i < EPV; ++i) acc[i] = fmaf(wn, f[i], acc[i]);
+            }
+        }
+    });
+#pragma unroll
+    for (int i = 0; i < EPV; ++i) acc[i] = slot_sum<LPR>(acc[i]);
+    dt = slot_sum<LPR>(dt);
+    if (slot == 0 && col_ok) {
+        VecIO<YT, EPV>::store(static_cast<YT*>(a.Y) + row * a.ldy + c0, acc);
+        if ((sub % lph) == 0) a.out_a[row * a.heads + head] = dt;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ segment max
+// Y[i,f] = max_k X[col[k], f], arg[i,f] = col of the (first) maximum; empty rows give 0 / -1.   (sageconv.py:37-38)
+template <typename XT, int EPV, int LPR, int U>
+__global__ __launch_bounds__(kBlock) void segment_max_kernel(const EdgeArgs a) {
+    typedef VecIO<XT, EPV> IO;
+    constexpr int SLOTS = kWave / LPR;
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int sub = lane % LPR, slot = lane / LPR;
+    const int c0 = ((int)blockIdx.y * LPR + sub) * EPV;
+    const bool col_ok = c0 < a.feat;
+    const int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+    if (row >= a.n_rows) return;
+    const int64_t b = uniform64(a.rowptr[row]), e = uniform64(a.rowptr[row + 1]);
+    const XT* hcol = static_cast<const XT*>(a.H) + (col_ok ? c0 : 0);
+    float best[EPV];
+    int arg[EPV];
+#pragma unroll
+    for (int i = 0; i < EPV; ++i) { best[i] = -INFINITY; arg[i] = -1; }
+    for_each_batch(a.col, b, e, lane, [&](int nb, int cur_col, int64_t) {
+        for (int j = 0; j < nb; j += SLOTS * U) {
+            bool ok[U];
+            int c[U];
+            typename IO::raw_t v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = j + u * SLOTS + slot;
+                ok[u] = idx < nb;
+                c[u] = __shfl(cur_col, ok[u] ? idx : nb - 1);
+                v[u] = IO::load(hcol + (int64_t)c[u] * a.ldh);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float f[EPV];
+                IO::unpack(v[u], f);
+#pragma unroll
+                for (int i = 0; i < EPV; ++i)
+                    if (ok[u] && (f[i] > best[i] || (f[i] == best[i] && c[u] < arg[i]) || arg[i] < 0)) { best[i] = f[i]; arg[i] = c[u]; }
+            }
+        }
+    });
+#pragma unroll
+    for (int off = LPR; off < kWave; off <<= 1) {
+#pragma unroll
+        for (int i = 0; i < EPV; ++i) {
+            const float ob = __shfl_xor(best[i], off);
+            const int oa = __shfl_xor(arg[i], off);
+            if (oa >= 0 && (arg[i] < 0 || ob > best[i] || (ob == best[i] && oa < arg[i]))) { best[i] = ob; arg[i] = oa; }
+        }
+    }
+    if (slot == 0 && col_ok) {
+#pragma unroll
+        for (int i = 0; i < EPV; ++i)
+            if (arg[i] < 0) best[i] = 0.0f;
+        VecIO<XT, EPV>::store(static_cast<XT*>(a.Y) + row * a.ldy + c0, best);
+#pragma unroll
+        for (int i = 0; i < EPV; ++i) a.arg_out[row * a.ldy + c0 + i] = arg[i];
+    }
+}
+
+// ---- host-side dispatch helpers --------------------------------------------------------------------------
+static int pick_lpr(int vecs) {
+    int lpr = 4;
+    while (lpr < 64 && lpr < vecs) lpr <<= 1;
+    return lpr;
+}
+
+static bool vec_ok(const void* p, int64_t ld, int esz) { return aligned16(p) && (ld * esz) % 16 == 0; }
+
+#define DGLL_LPR_SWITCH(lpr, CALL)   \
+    switch (lpr) {                   \
+        case 4: { CALL(4); } break;  \
+        case 8: { CALL(8); } break;  \
+        case 16: { CALL(16); } break;\
+        case 32: { CALL(32); } break;\
+        default: { CALL(64); } break;\
+    }
+
+}  // namespace dgll
+
+using namespace dgll;
+
+static int check_heads(int heads, int fo, int epv, int* lph_out) {
+    DGLL_REQUIRE(heads > 0 && fo > 0, "heads/fo must be positive");
+    DGLL_REQUIRE(fo % epv == 0, "per-head width must be a multiple of the 16-byte vector (pad on the host)");
+    const int lph = fo / epv;
+    DGLL_REQUIRE((lph & (lph - 1)) == 0 && lph <= 64, "per-head width / vector must be a power of two <= 64 (pad on the host)");
+    *lph_out = lph;
+    return DGLL_OK;
+}
+
+DGLL_API int dgll_hip_sddmm_csr(void* stream, const int64_t* rowptr, const int32_t* col, const void* G, int64_t ldg,
+                                const void* B, int64_t ldb, int dtype, float* edge_out, int64_t n_rows, int feat) {
+    if (n_rows <= 0) return DGLL_OK;
+    DGLL_REQUIRE(rowptr && col && G && B && edge_out, "NULL argument");
+    DGLL_REQUIRE(dtype == DGLL_F32 || dtype == DGLL_BF16, "dtype");
+    const int esz = dtype == DGLL_BF16 ? 2 : 4, epv = 16 / esz;
+    DGLL_REQUIRE(feat > 0 && feat <= 64 * epv, "sddmm handles up to 64 vectors per row in one launch (split columns on the host)");
+    DGLL_REQUIRE(vec_ok(G, ldg, esz) && vec_ok(B, ldb, esz) && ldg >= ((feat + epv - 1) / epv) * epv && ldb >= ((feat + epv - 1) / epv) * epv,
+                 "sddmm operands must be 16-byte aligned with padded leading dimensions");
+    EdgeArgs a{};
+    a.rowptr = rowptr; a.col = col; a.G = G; a.ldg = ldg; a.H = B; a.ldh = ldb; a.edge_out = edge_out;
+    a.n_rows = n_rows; a.feat = feat;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int lpr = pick_lpr((feat + epv - 1) / epv);
+    dim3 grid((uint32_t)((n_rows + kWavesPerBlock - 1) / kWavesPerBlock));
+#define CALL(L)                                                                                                       \
+    if (dtype == DGLL_F32) hipLaunchKernelGGL((sddmm_kernel<float, 4, L, 4>), grid, dim3(kBlock), 0, s, a);           \
+    else hipLaunchKernelGGL((sddmm_kernel<bf16_t, 8, L, 4>), grid, dim3(kBlock), 0, s, a);
+    DGLL_LPR_SWITCH(lpr, CALL)
+#undef CALL
+    DGLL_HIP_TRY(hipGetLastError());
+    return DGLL_OK;
+}
+
+static int gat_common(EdgeArgs& a, const int64_t* rowptr, const int32_t* col, int64_t n_rows, int heads, int fo, int dtype,
+                      float alpha, int mode, int apply_elu, int* lph, int* lpr, dim3* grid) {
+    DGLL_REQUIRE(rowptr && col, "NULL CSR");
+    DGLL_REQUIRE(dtype == DGLL_F32 || dtype == DGLL_BF16, "dtype");
+    DGLL_REQUIRE(mode == 0 || mode == 1, "mode");
+    const int epv = dtype == DGLL_BF16 ? 8 : 4;
+    int rc = check_heads(heads, fo, epv, lph);
+    if (rc != DGLL_OK) return rc;
+    a.rowptr = rowptr; a.col = col; a.n_rows = n_rows; a.heads = heads; a.fo = fo; a.feat = heads * fo;
+    a.alpha = alpha; a.sign = mode == 0 ? -1.0f : 1.0f; a.use_max = mode; a.apply_elu = apply_elu;
+    const int vecs = a.feat / epv;
+    *lpr = pick_lpr(vecs);
+    if (*lpr < *lph) *lpr = *lph;
+    *grid = dim3((uint32_t)((n_rows + kWavesPerBlock - 1) / kWavesPerBlock), (uint32_t)((vecs + *lpr - 1) / *lpr));
+    return DGLL_OK;
+}
+
+DGLL_API int dgll_hip_gat_fwd(void* stream, const int64_t* rowptr, const int32_t* col, const void* H, int64_t ldh,
+                              const float* S, const float* T, const float* edge_scale, void* out, int64_t ldo, int dtype,
+                              float* rowsum, float* rowmax, int64_t n_rows, int heads, int fo, float alpha, int apply_elu,
+                              int mode) {
+    if (n_rows <= 0) return DGLL_OK;
+    EdgeArgs a{};
+    int lph, lpr;
+    dim3 grid;
+    int rc = gat_common(a, rowptr, col, n_rows, heads, fo, dtype, alpha, mode, apply_elu, &lph, &lpr, &grid);
+    if (rc != DGLL_OK) return rc;
+    DGLL_REQUIRE(H && S && T && out && rowsum, "NULL argument");
+    DGLL_REQUIRE(mode == 0 || rowmax, "mode 1 needs a rowmax output");
+    const int esz = dtype == DGLL_BF16 ? 2 : 4;
+    DGLL_REQUIRE(vec_ok(H, ldh, esz) && vec_ok(out, ldo, esz) && ldh >= a.feat && ldo >= a.feat, "H/out must be 16-byte aligned");
+    a.H = H; a.ldh = ldh; a.S = S; a.T = T; a.edge_scale = edge_scale; a.Y = out; a.ldy = ldo;
+    a.out_a = rowsum; a.out_b = mode == 1 ? rowmax : nullptr;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+#define CALL(L)                                                                                                                \
+    if (dtype == DGLL_F32) hipLaunchKernelGGL((gat_fwd_kernel<float, float, 4, L, 4>), grid, dim3(kBlock), 0, s, a, lph);      \
+    else hipLaunchKernelGGL((gat_fwd_kernel<bf16_t, bf16_t, 8, L, 4>), grid, dim3(kBlock), 0, s, a, lph);
+    DGLL_LPR_SWITCH(lpr, CALL)
+#undef CALL
+    DGLL_HIP_TRY(hipGetLastError());
+    return DGLL_OK;
+}
+
+DGLL_API int dgll_hip_gat_bwd(void* stream,
+                              const int64_t* rowptr, const int32_t* col,          /* A   */
+                              const int64_t* t_rowptr, const int32_t* t_col, const int64_t* t_perm, /* A^T */
+                              const void* H, int64_t ldh, const float* S, const float* T, const float* edge_scale,
+                              const void* out, int64_t ldo, const void* grad_out, int64_t ldg, int dtype,
+                              const float* rowsum, const float* rowmax,
+                              void* dn_scratch, int64_t ldn, float* dd_scratch,
+                              void* grad_H, int64_t ldgh, float* grad_S, float* grad_T,
+                              int64_t n_rows, int64_t n_cols, int heads, int fo, float alpha, int apply_elu, int mode) {
+    if (n_rows <= 0 && n_cols <= 0) return DGLL_OK;
+    EdgeArgs a{};
+    int lph, lpr;
+    dim3 grid;
+    int rc = gat_common(a, rowptr, col, n_rows, heads, fo, dtype, alpha, mode, apply_elu, &lph, &lpr, &grid);
+    if (rc != DGLL_OK) return rc;
+    DGLL_REQUIRE(t_rowptr && t_col && H && S && T && out && grad_out && rowsum && dn_scratch && dd_scratch && grad_H && grad_S && grad_T,
+                 "NULL argument");
+    DGLL_REQUIRE(mode == 0 || rowmax, "mode 1 needs the forward's rowmax");
+    DGLL_REQUIRE(!edge_scale || t_perm, "edge_scale needs the transpose permutation");
+    const int esz = dtype == DGLL_BF16 ? 2 : 4;
+    DGLL_REQUIRE(vec_ok(H, ldh, esz) && vec_ok(out, ldo, esz) && vec_ok(grad_out, ldg, esz) && vec_ok(dn_scratch, ldn, esz) &&
+                 vec_ok(grad_H, ldgh, esz), "matrices must be 16-byte aligned with padded leading dimensions");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // pass 1: rows of A
+    a.H = H; a.ldh = ldh; a.S = S; a.T = T; a.M = mode == 1 ? rowmax : nullptr; a.DEN = rowsum; a.edge_scale = edge_scale;
+    a.G = grad_out; a.ldg = ldg; a.O = out; a.ldo = ldo; a.Y = dn_scratch; a.ldy = ldn; a.out_a = grad_S; a.out_b = dd_scratch;
+    if (n_rows > 0) {
+#define CALL(L)                                                                                                              \
+    if (dtype == DGLL_F32) hipLaunchKernelGGL((gat_bwd_rows_kernel<float, 4, L, 4>), grid, dim3(kBlock), 0, s, a, lph);      \
+    else hipLaunchKernelGGL((gat_bwd_rows_kernel<bf16_t, 8, L, 4>), grid, dim3(kBlock), 0, s, a, lph);
+        DGLL_LPR_SWITCH(lpr, CALL)
+#undef CALL
+        DGLL_HIP_TRY(hipGetLastError());
+    }
+    // pass 2: rows of A^T
+    EdgeArgs t = a;
+    t.rowptr = t_rowptr; t.col = t_col; t.perm = t_perm; t.n_rows = n_cols;
+    t.H = dn_scratch; t.ldh = ldn; t.G = H; t.ldg = ldh; t.S = T; t.T = S; t.DD = dd_scratch;
+    t.Y = grad_H; t.ldy = ldgh; t.out_a = grad_T; t.out_b = nullptr;
+    if (n_cols > 0) {
+        dim3 tgrid((uint32_t)((n_cols + kWavesPerBlock - 1) / kWavesPerBlock), grid.y);
+#define CALL(L)                                                                                                                   \
+    if (dtype == DGLL_F32) hipLaunchKernelGGL((gat_bwd_cols_kernel<float, float, 4, L, 4>), tgrid, dim3(kBlock), 0, s, t, lph);   \
+    else hipLaunchKernelGGL((gat_bwd_cols_kernel<bf16_t, bf16_t, 8, L, 4>), tgrid, dim3(kBlock), 0, s, t, lph);
+        DGLL_LPR_SWITCH(lpr, CALL)
+#undef CALL
+        DGLL_HIP_TRY(hipGetLastError());
+    }
+    return DGLL_OK;
+}
+
+DGLL_API int dgll_hip_segment_max(void* stream, const int64_t* rowptr, const int32_t* col, const void* X, int64_t ldx,
+                                  void* Y, int32_t* arg, int64_t ldy, int dtype, int64_t n_rows, int feat) {
+    if (n_rows <= 0 || feat <= 0) return DGLL_OK;
+    DGLL_REQUIRE(rowptr && col && X && Y && arg, "NULL argument");
+    DGLL_REQUIRE(dtype == DGLL_F32 || dtype == DGLL_BF16, "dtype");
+    const int esz = dtype == DGLL_BF16 ? 2 : 4, epv = 16 / esz;
+    const int vecs = (feat + epv - 1) / epv;
+    DGLL_REQUIRE(vec_ok(X, ldx, esz) && vec_ok(Y, ldy, esz) && ldx >= vecs * epv && ldy >= vecs * epv,
+                 "segment_max operands must be 16-byte aligned with padded leading dimensions");
+    EdgeArgs a{};
+    a.rowptr = rowptr; a.col = col; a.H = X; a.ldh = ldx; a.Y = Y; a.ldy = ldy; a.arg_out = arg; a.n_rows = n_rows;
+    a.feat = vecs * epv;  // padded columns are computed too (they live inside the padded leading dimension)
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int lpr = pick_lpr(vecs);
+    dim3 grid((uint32_t)((n_rows + kWavesPerBlock - 1) / kWavesPerBlock), (uint32_t)((vecs + lpr - 1) / lpr));
+#define CALL(L)                                                                                                          \
+    if (dtype == DGLL_F32) hipLaunchKernelGGL((segment_max_kernel<float, 4, L, 4>), grid, dim3(kBlock), 0, s, a);        \
+    else hipLaunchKernelGGL((segment_max_kernel<bf16_t, 8, L, 4>), grid, dim3(kBlock), 0, s, a);
+    DGLL_LPR_SWITCH(lpr, CALL)
+#undef CALL
+    DGLL_HIP_TRY(hipGetLastError());
+    return DGLL_OK;
+}

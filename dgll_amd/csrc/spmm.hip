@@ -1,0 +1,420 @@
+// spmm.hip -- CSR SpMM neighbour aggregation for gfx950 (MI355X), the kernel the whole engine is judged on.
+//
+//   Y[i, :] = epilogue( reduce_{k in row i} val[k] * X[col[k], :] )
+//
+// Serves F.spmm / torch.sparse.mm of the reference (dgll/nn/Convolution/gcnconv.py:31,
+// Evaluation/PPI/gcn_model.py:76), the K-axis mean of NeighborAggregator (sageconv.py:33-36) and, on the
+// transposed structure, every grad_X = A^T.g.
+//
+// Design: the op is an HBM-bound gather -- no MFMA.
+//   * one wavefront (64 lanes) owns one output row at a time; a feature row of the gathered matrix is read
+//     by LPR adjacent lanes with one 16-byte load each (global_load_dwordx4), so a 256-wide bf16 row is one
+//     512-byte fully coalesced request; the 64/LPR lane groups ("slots") of the wave gather different
+//     neighbours concurrently and U loads are kept in flight per lane;
+//   * column indices / edge weights of up to 64 edges are fetched with ONE coalesced load per batch and handed
+//     to the slots with ds_bpermute (__shfl), so the dependent chain is rowptr -> col batch -> gathers, with
+//     the next batch prefetched while the current one is consumed;
+//   * fp32 accumulation in registers, cross-slot tree reduction with wave shuffles, fused epilogue
+//     (mean scale, bias, ReLU, bf16 down-convert) and one vector store per lane;
+//   * rows longer than the plan's threshold are cut into chunks that run as ordinary work items (scheduled
+//     FIRST, longest-processing-time style) and write fp32 partials that a tiny second kernel reduces in a
+//     fixed order -- no atomics anywhere, results are bit-reproducible;
+//   * logical row blocks are remapped so each XCD's L2 serves a contiguous row range (xcd_remap).
+#include <algorithm>
+#include <vector>
+
+#include "common.hpp"
+
+struct dgll_csr_plan {
+    int device = 0;
+    int64_t n_rows = 0, nnz = 0;
+    int threshold = 512;
+    int64_t n_long = 0, n_chunks = 0;
+    int64_t* d_long_row = nullptr;    // [n_long]      row id of each long row (ascending)
+    int32_t* d_long_chunk0 = nullptr; // [n_long + 1]  first chunk of each long row
+    int64_t* d_chunk_begin = nullptr; // [n_chunks]    first edge of the chunk
+    int64_t* d_chunk_end = nullptr;   // [n_chunks]    one past its last edge
+};
+
+namespace dgll {
+
+struct LongRow { int64_t row, begin, end; };
+
+__global__ void find_long_rows_kernel(const int64_t* __restrict__ rowptr, int64_t n_rows, int threshold,
+                                      LongRow* __restrict__ out, unsigned long long* __restrict__ count,
+                                      unsigned long long capacity) {
+    for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n_rows; r += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = rowptr[r], e = rowptr[r + 1];
+        if (e - b > threshold) {
+            const unsigned long long at = atomicAdd(count, 1ull);
+            if (at < capacity) out[at] = LongRow{r, b, e};
+        }
+    }
+}
+
+struct SpmmArgs {
+    const int64_t* rowptr;
+    const int32_t* col;
+    const float* val;
+    const void* X;
+    void* Y;
+    int64_t ldx, ldy, n_rows;
+    int feat, reduce, epilogue;
+    const float* bias;
+    // long-row schedule (threshold == 0: none)
+    int threshold;
+    int64_t n_chunks;
+    const int64_t* chunk_begin;
+    const int64_t* chunk_end;
+    float* ws;
+    int ws_ld;
+    uint32_t chunk_blocks, row_blocks;
+    int rows_per_wave;
+};
+
+// Accumulate edges [b, e) of one row into acc (this lane's EPV columns starting at xcol).
+template <typename XT, int EPV, int LPR, bool HAS_VAL, int U>
+__device__ __forceinline__ void gather_edges(const int32_t* __restrict__ col, const float* __restrict__ val,
+                                             const XT* __restrict__ xcol, int64_t ldx, int64_t b, int64_t e,
+                                             int lane, float (&acc)[EPV]) {
+    typedef VecIO<XT, EPV> IO;
+    constexpr int SLOTS = kWave / LPR;
+    const int slot = lane / LPR;
+
+    int my_col = 0;
+    float my_val = 0.0f;
+    if (b + lane < e) {
+        my_col = col[b + lane];
+        if (HAS_VAL) my_val = val[b + lane];
+    }
+    for (int64_t k0 = b; k0 < e; k0 += kWave) {
+        const int64_t left = e - k0;
+        const int nb = left < kWave ? (int)left : kWave;
+        const int cur_col = my_col;
+        const float cur_val = my_val;
+        // prefetch the next batch of indices while this one is consumed
+        const int64_t kn = k0 + kWave + lane;
+        if (kn < e) {
+            my_col = col[kn];
+            if (HAS_VAL) my_val = val[kn];
+        }
+        for (int j = 0; j < nb; j += SLOTS * U) {
+            // All U gathers are issued back to back with no branch in between: an out-of-range slot re-reads the
+            // batch's last valid edge (same cache lines as a live request) and is zeroed after the load.
+            int c[U];
+            float w[U];
+            bool ok[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = j + u * SLOTS + slot;
+                ok[u] = idx < nb;
+                const int src = ok[u] ? idx : nb - 1;
+                c[u] = __shfl(cur_col, src);
+                w[u] = HAS_VAL ? __shfl(cur_val, src) : 1.0f;
+            }
+            typename IO::raw_t v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = IO::load(xcol + (int64_t)c[u] * ldx);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float f[EPV];
+                IO::unpack(ok[u] ? v[u] : IO::zero(), f);
+#pragma unroll
+                for (int i = 0; i < EPV; ++i) acc[i] = HAS_VAL ? fmaf(w[u], f[i], acc[i]) : acc[i] + f[i];
+            }
+        }
+    }
+    // combine the slots: lanes that differ only in the slot bits hold the same columns
+#pragma unroll
+    for (int off = LPR; off < kWave; off <<= 1) {
+#pragma unroll
+        for (int i = 0; i < EPV; ++i) acc[i] += __shfl_xor(acc[i], off);
+    }
+}
+
+template <typename YT, int EPV>
+__device__ __forceinline__ void finish_row(YT* __restrict__ y, int c0, int feat, float scale, int epilogue,
+                                           const float* __restrict__ bias, float (&acc)[EPV]) {
+#pragma unroll
+    for (int i = 0; i < EPV; ++i) {
+        float v = acc[i] * scale;
+        if ((epilogue & DGLL_EPI_BIAS) && c0 + i < feat) v += bias[c0 + i];
+        if (epilogue & DGLL_EPI_RELU) v = fmaxf(v, 0.0f);
+        acc[i] = v;
+    }
+    if (c0 + EPV <= feat) {
+        VecIO<YT, EPV>::store(y + c0, acc);
+    } else {
+#pragma unroll
+        for (int i = 0; i < EPV; ++i)
+            if (c0 + i < feat) store_one<YT>(y + c0 + i, acc[i]);
+    }
+}
+
+template <typename XT, typename YT, int EPV, int LPR, bool HAS_VAL, int U>
+__global__ __launch_bounds__(kBlock) void spmm_csr_kernel(const SpmmArgs a) {
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int sub = lane % LPR;
+    const int c0 = ((int)blockIdx.y * LPR + sub) * EPV;
+    const bool col_ok = c0 < a.feat;
+    const XT* xcol = static_cast<const XT*>(a.X) + (col_ok ? c0 : 0);  // idle lanes re-read column 0, never store
+    uint32_t bid = blockIdx.x;
+
+    if (bid < a.chunk_blocks) {  // ---- a chunk of a long row: fp32 partial into the workspace
+        const int64_t chunk = __builtin_amdgcn_readfirstlane((int)(bid * kWavesPerBlock + wave));
+        if (chunk >= a.n_chunks) return;
+        float acc[EPV];
+#pragma unroll
+        for (int i = 0; i < EPV; ++i) acc[i] = 0.0f;
+        gather_edges<XT, EPV, LPR, HAS_VAL, U>(a.col, a.val, xcol, a.ldx, uniform64(a.chunk_begin[chunk]),
+                                               uniform64(a.chunk_end[chunk]), lane, acc);
+        if (lane < LPR && col_ok) {
+            float* w = a.ws + chunk * a.ws_ld + c0;
+#pragma unroll
+            for (int i = 0; i < EPV; ++i) w[i] = acc[i];
+        }
+        return;
+    }
+
+    bid = xcd_remap(bid - a.chunk_blocks, a.row_blocks);
+    const int64_t row0 = ((int64_t)bid * kWavesPerBlock + wave) * a.rows_per_wave;
+    for (int r = 0; r < a.rows_per_wave; ++r) {
+        const int64_t row = row0 + r;
+        if (row >= a.n_rows) return;
+        const int64_t b = uniform64(a.rowptr[row]), e = uniform64(a.rowptr[row + 1]);
+        if (a.threshold > 0 && e - b > a.threshold) continue;  // handled as chunks
+        float acc[EPV];
+#pragma unroll
+        for (int i = 0; i < EPV; ++i) acc[i] = 0.0f;
+        gather_edges<XT, EPV, LPR, HAS_VAL, U>(a.col, a.val, xcol, a.ldx, b, e, lane, acc);
+        if (lane < LPR && col_ok) {
+            const float scale = (a.reduce == DGLL_REDUCE_MEAN && e > b) ? 1.0f / (float)(e - b) : 1.0f;
+            finish_row<YT, EPV>(static_cast<YT*>(a.Y) + row * a.ldy, c0, a.feat, scale, a.epilogue, a.bias, acc);
+        }
+    }
+}
+
+// Second pass for long rows: sum the chunk partials in chunk order, then the same epilogue.
+template <typename YT>
+__global__ __launch_bounds__(kBlock) void spmm_long_finalize_kernel(const SpmmArgs a, const int64_t* __restrict__ long_row,
+                                                                    const int32_t* __restrict__ long_chunk0) {
+    const int64_t li = blockIdx.x;
+    const int64_t row = long_row[li];
+    const int cb = long_chunk0[li], ce = long_chunk0[li + 1];
+    const int f = (int)(blockIdx.y * kBlock + threadIdx.x);
+    if (f >= a.feat) return;
+    float s = 0.0f;
+    for (int c = cb; c < ce; ++c) s += a.ws[(int64_t)c * a.ws_ld + f];
+    if (a.reduce == DGLL_REDUCE_MEAN) s *= 1.0f / (float)(a.rowptr[row + 1] - a.rowptr[row]);
+    if (a.epilogue & DGLL_EPI_BIAS) s += a.bias[f];
+    if (a.epilogue & DGLL_EPI_RELU) s = fmaxf(s, 0.0f);
+    store_one<YT>(static_cast<YT*>(a.Y) + row * a.ldy + f, s);
+}
+
+static int ws_ld_for(int feat) { return (feat + 7) & ~7; }
+
+template <typename XT, typename YT, int EPV, int LPR>
+static hipError_t launch_variant(const SpmmArgs& a, dim3 grid, hipStream_t s) {
+    constexpr int U = 4;
+    if (a.val)
+        hipLaunchKernelGGL((spmm_csr_kernel<XT, YT, EPV, LPR, true, U>), grid, dim3(kBlock), 0, s, a);
+    else
+        hipLaunchKernelGGL((spmm_csr_kernel<XT, YT, EPV, LPR, false, U>), grid, dim3(kBlock), 0, s, a);
+    return hipGetLastError();
+}
+
+template <typename XT, typename YT, int EPV>
+static hipError_t launch_lpr(const SpmmArgs& a, int lpr, dim3 grid, hipStream_t s) {
+    switch (lpr) {
+        case 4: return launch_variant<XT, YT, EPV, 4>(a, grid, s);
+        case 8: return launch_variant<XT, YT, EPV, 8>(a, grid, s);
+        case 16: return launch_variant<XT, YT, EPV, 16>(a, grid, s);
+        case 32: return launch_variant<XT, YT, EPV, 32>(a, grid, s);
+        default: return launch_variant<XT, YT, EPV, 64>(a, grid, s);
+    }
+}
+
+}  // namespace dgll
+
+using namespace dgll;
+
+DGLL_API int dgll_hip_csr_plan_create(void* stream, const int64_t* rowptr, int64_t n_rows, int64_t nnz,
+                                      int long_row_threshold, dgll_csr_plan** out_plan) {
+    DGLL_REQUIRE(out_plan != nullptr, "out_plan is NULL");
+    DGLL_REQUIRE(rowptr != nullptr && n_rows >= 0 && nnz >= 0, "bad CSR arguments");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    dgll_csr_plan* p = new dgll_csr_plan();
+    p->n_rows = n_rows;
+    p->nnz = nnz;
+    p->threshold = long_row_threshold > 0 ? long_row_threshold : 512;
+    hipError_t e = hipGetDevice(&p->device);
+    if (e != hipSuccess) { delete p; return hip_fail(e, "hipGetDevice"); }
+
+    const unsigned long long capacity = (unsigned long long)(nnz / p->threshold) + 1;
+    LongRow* d_list = nullptr;
+    unsigned long long* d_count = nullptr;
+    std::vector<LongRow> h_list;
+    unsigned long long h_count = 0;
+    auto cleanup = [&]() { if (d_list) (void)hipFree(d_list); if (d_count) (void)hipFree(d_count); };
+#define PLAN_TRY(expr)                                                                   \
+    do {                                                                                 \
+        hipError_t _e = (expr);                                                          \
+        if (_e != hipSuccess) { cleanup(); dgll_hip_csr_plan_destroy(p); return hip_fail(_e, #expr); } \
+    } while (0)
+    PLAN_TRY(hipMalloc(&d_list, capacity * sizeof(LongRow)));
+    PLAN_TRY(hipMalloc(&d_count, sizeof(unsigned long long)));
+    PLAN_TRY(hipMemsetAsync(d_count, 0, sizeof(unsigned long long), s));
+    if (n_rows > 0) {
+        const int blocks = (int)std::min<int64_t>((n_rows + kBlock - 1) / kBlock, 2048);
+        hipLaunchKernelGGL(find_long_rows_kernel, dim3(blocks), dim3(kBlock), 0, s, rowptr, n_rows, p->threshold,
+                           d_list, d_count, capacity);
+        PLAN_TRY(hipGetLastError());
+    }
+    PLAN_TRY(hipMemcpyAsync(&h_count, d_count, sizeof(h_count), hipMemcpyDeviceToHost, s));
+    PLAN_TRY(hipStreamSynchronize(s));
+    if (h_count > capacity) {
+        cleanup();
+        dgll_hip_csr_plan_destroy(p);
+        set_error("rowptr is inconsistent with nnz (more long rows than nnz allows)");
+        return DGLL_ERR_INVALID;
+    }
+    h_list.resize(h_count);
+    if (h_count) {
+        PLAN_TRY(hipMemcpyAsync(h_list.data(), d_list, h_count * sizeof(LongRow), hipMemcpyDeviceToHost, s));
+        PLAN_TRY(hipStreamSynchronize(s));
+    }
+    std::sort(h_list.begin(), h_list.end(), [](const LongRow& x, const LongRow& y) { return x.row < y.row; });
+
+    std::vector<int64_t> long_row(h_count), chunk_begin, chunk_end;
+    std::vector<int32_t> chunk0(h_count + 1, 0);
+    for (size_t i = 0; i < h_count; ++i) {
+        long_row[i] = h_list[i].row;
+        chunk0[i] = (int32_t)chunk_begin.size();
+        for (int64_t b = h_list[i].begin; b < h_list[i].end; b += p->threshold) {
+            chunk_begin.push_back(b);
+            chunk_end.push_back(std::min<int64_t>(b + p->threshold, h_list[i].end));
+        }
+    }
+    chunk0[h_count] = (int32_t)chunk_begin.size();
+    p->n_long = (int64_t)h_count;
+    p->n_chunks = (int64_t)chunk_begin.size();
+    if (p->n_long > 0) {
+        PLAN_TRY(hipMalloc(&p->d_long_row, sizeof(int64_t) * h_count));
+        PLAN_TRY(hipMalloc(&p->d_long_chunk0, sizeof(int32_t) * (h_count + 1)));
+        PLAN_TRY(hipMalloc(&p->d_chunk_begin, sizeof(int64_t) * chunk_begin.size()));
+        PLAN_TRY(hipMalloc(&p->d_chunk_end, sizeof(int64_t) * chunk_end.size()));
+        PLAN_TRY(hipMemcpyAsync(p->d_long_row, long_row.data(), sizeof(int64_t) * h_count, hipMemcpyHostToDevice, s));
+        PLAN_TRY(hipMemcpyAsync(p->d_long_chunk0, chunk0.data(), sizeof(int32_t) * (h_count + 1), hipMemcpyHostToDevice, s));
+        PLAN_TRY(hipMemcpyAsync(p->d_chunk_begin, chunk_begin.data(), sizeof(int64_t) * chunk_begin.size(), hipMemcpyHostToDevice, s));
+        PLAN_TRY(hipMemcpyAsync(p->d_chunk_end, chunk_end.data(), sizeof(int64_t) * chunk_end.size(), hipMemcpyHostToDevice, s));
+        PLAN_TRY(hipStreamSynchronize(s));
+    }
+#undef PLAN_TRY
+    cleanup();
+    *out_plan = p;
+    return DGLL_OK;
+}
+
+DGLL_API void dgll_hip_csr_plan_destroy(dgll_csr_plan* p) {
+    if (!p) return;
+    if (p->d_long_row) (void)hipFree(p->d_long_row);
+    if (p->d_long_chunk0) (void)hipFree(p->d_long_chunk0);
+    if (p->d_chunk_begin) (void)hipFree(p->d_chunk_begin);
+    if (p->d_chunk_end) (void)hipFree(p->d_chunk_end);
+    delete p;
+}
+
+DGLL_API size_t dgll_hip_csr_plan_workspace_bytes(const dgll_csr_plan* p, int feat) {
+    if (!p || p->n_chunks == 0 || feat <= 0) return 0;
+    return (size_t)p->n_chunks * (size_t)ws_ld_for(feat) * sizeof(float);
+}
+
+DGLL_API int64_t dgll_hip_csr_plan_num_long_rows(const dgll_csr_plan* p) { return p ? p->n_long : 0; }
+DGLL_API int64_t dgll_hip_csr_plan_num_chunks(const dgll_csr_plan* p) { return p ? p->n_chunks : 0; }
+
+DGLL_API int dgll_hip_spmm_csr(void* stream, const dgll_csr_plan* plan, const int64_t* rowptr, const int32_t* col,
+                               const float* val, const void* X, int64_t ldx, int x_dtype, void* Y, int64_t ldy,
+                               int y_dtype, int64_t n_rows, int64_t n_cols, int feat, int reduce, int epilogue,
+                               const float* bias, void* workspace, size_t workspace_bytes) {
+    DGLL_REQUIRE(n_rows >= 0 && n_cols >= 0 && feat >= 0, "negative size");
+    if (n_rows == 0 || feat == 0) return DGLL_OK;
+    DGLL_REQUIRE(rowptr && X && Y, "NULL rowptr/X/Y");
+    DGLL_REQUIRE(ldx >= feat && ldy >= feat, "leading dimension smaller than feat");
+    DGLL_REQUIRE(x_dtype == DGLL_F32 || x_dtype == DGLL_BF16, "x_dtype");
+    DGLL_REQUIRE(y_dtype == DGLL_F32 || y_dtype == DGLL_BF16, "y_dtype");
+    DGLL_REQUIRE(reduce == DGLL_REDUCE_SUM || reduce == DGLL_REDUCE_MEAN, "reduce");
+    DGLL_REQUIRE((epilogue & ~(DGLL_EPI_BIAS | DGLL_EPI_RELU)) == 0, "epilogue");
+    DGLL_REQUIRE(!(epilogue & DGLL_EPI_BIAS) || bias, "DGLL_EPI_BIAS needs bias");
+    if (x_dtype == DGLL_F32 && y_dtype == DGLL_BF16) {
+        set_error("fp32 input with bf16 output is not supported");
+        return DGLL_ERR_UNSUPPORTED;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+
+    SpmmArgs a{};
+    a.rowptr = rowptr; a.col = col; a.val = val; a.X = X; a.Y = Y;
+    a.ldx = ldx; a.ldy = ldy; a.n_rows = n_rows; a.feat = feat; a.reduce = reduce; a.epilogue = epilogue; a.bias = bias;
+    a.ws_ld = ws_ld_for(feat);
+    a.rows_per_wave = 1;
+    if (plan) {
+        DGLL_REQUIRE(plan->n_rows == n_rows, "plan was built for a different CSR");
+        a.threshold = plan->threshold;
+        a.n_chunks = plan->n_chunks;
+        a.chunk_begin = plan->d_chunk_begin;
+        a.chunk_end = plan->d_chunk_end;
+        if (plan->n_chunks > 0) {
+            const size_t need = dgll_hip_csr_plan_workspace_bytes(plan, feat);
+            if (!workspace || workspace_bytes < need) {
+                set_error("workspace too small for the plan's long-row partials");
+                return DGLL_ERR_WORKSPACE;
+            }
+            a.ws = static_cast<float*>(workspace);
+        }
+        // amortise wave start-up when rows are tiny: aim for >= 8 KiB of gathered bytes per wave
+        const double row_bytes = (double)plan->nnz / (double)std::max<int64_t>(n_rows, 1) * feat *
+                                 (x_dtype == DGLL_BF16 ? 2.0 : 4.0);
+        int rpw = row_bytes > 0 ? (int)(8192.0 / row_bytes) : 8;
+        a.rows_per_wave = std::min(std::max(rpw, 1), 8);
+    }
+    const int64_t waves = (n_rows + a.rows_per_wave - 1) / a.rows_per_wave;
+    const int64_t row_blocks = (waves + kWavesPerBlock - 1) / kWavesPerBlock;
+    int64_t chunk_blocks = (a.n_chunks + kWavesPerBlock - 1) / kWavesPerBlock;
+    chunk_blocks = (chunk_blocks + kXcds - 1) / kXcds * kXcds;  // keep (block % 8) == XCD for the row blocks
+    DGLL_REQUIRE(row_blocks + chunk_blocks < (int64_t)0x7fffffff, "grid too large");
+    a.row_blocks = (uint32_t)row_blocks;
+    a.chunk_blocks = (uint32_t)chunk_blocks;
+
+    const int esz = x_dtype == DGLL_BF16 ? 2 : 4;
+    const int ysz = y_dtype == DGLL_BF16 ? 2 : 4;
+    const int epv = 16 / esz;
+    const bool fast = aligned16(X) && aligned16(Y) && (ldx * esz) % 16 == 0 && (ldy * ysz) % 16 == 0 &&
+                      ((int64_t)epv * ysz) % 16 == 0;
+    hipError_t err;
+    if (fast) {
+        const int vecs = (feat + epv - 1) / epv;
+        int lpr = 4;
+        while (lpr < 64 && lpr < vecs) lpr <<= 1;
+        dim3 grid((uint32_t)(row_blocks + chunk_blocks), (uint32_t)((vecs + lpr - 1) / lpr));
+        if (x_dtype == DGLL_F32) err = launch_lpr<float, float, 4>(a, lpr, grid, s);
+        else if (y_dtype == DGLL_BF16) err = launch_lpr<bf16_t, bf16_t, 8>(a, lpr, grid, s);
+        else err = launch_lpr<bf16_t, float, 8>(a, lpr, grid, s);
+    } else {
+        dim3 grid((uint32_t)(row_blocks + chunk_blocks), (uint32_t)((feat + 63) / 64));
+        if (x_dtype == DGLL_F32) err = launch_variant<float, float, 1, 64>(a, grid, s);
+        else if (y_dtype == DGLL_BF16) err = launch_variant<bf16_t, bf16_t, 1, 64>(a, grid, s);
+        else err = launch_variant<bf16_t, float, 1, 64>(a, grid, s);
+    }
+    if (err != hipSuccess) return hip_fail(err, "spmm_csr_kernel launch");
+
+    if (plan && plan->n_long > 0) {
+        dim3 grid((uint32_t)plan->n_long, (uint32_t)((feat + kBlock - 1) / kBlock));
+        if (y_dtype == DGLL_F32)
+            hipLaunchKernelGGL(spmm_long_finalize_kernel<float>, grid, dim3(kBlock), 0, s, a, plan->d_long_row, plan->d_long_chunk0);
+        else
+            hipLaunchKernelGGL(spmm_long_finalize_kernel<bf16_t>, grid, dim3(kBlock), 0, s, a, plan->d_long_row, plan->d_long_chunk0);
+        err = hipGetLastError();
+        if (err != hipSuccess) return hip_fail(err, "spmm_long_finalize_kernel launch");
+    }
+    return DGLL_OK;
+}

@@ -1,0 +1,233 @@
+"""GAT layers on the gfx950 aggregation engine.
+
+Interface mirror of /root/reference/dgll/nn/Convolution/gatconv.py:
+  gatConv(in_features, out_features, dropout, alpha, concat=True)          dense-adjacency GAT   gatconv.py:10-57
+  SpecialSpmmFunction / SpecialSpmm                                        sparse A.b with grads gatconv.py:60-86
+  sparseGatConv(in_features, out_features, dropout, alpha, concat=True)    sparse GAT            gatconv.py:89-151
+  GAT / SpGAT(nfeat, nhid, nclass, dropout, alpha, nheads)                 8-head models         gatconv.py:154-199
+with identical parameter names (`W`, `a`, `attention_%d`, `out_att`) and initialisers.
+
+On the GPU each layer is ONE fused kernel (dgll_hip_gat_fwd): edge scores are formed from two per-node dot
+products s_i = a[:fo].h_i, t_j = a[fo:].h_j instead of the reference's materialised [2*fo, E] edge_h
+(gatconv.py:122), all heads of SpGAT/GAT run in the same launch (the reference calls heads one by one,
+gatconv.py:168,196), and the backward pass is two more gather passes instead of a dense N x N matmul
+(gatconv.py:76).  The adjacency may be the reference's dense 0/1 matrix (its nonzero pattern is converted to
+CSR once and cached), a torch sparse tensor or a CSRGraph.
+
+Not reproduced: the host-synchronising `assert not isnan(...)` checks (gatconv.py:119,126,136,141; set
+DGLL_CHECK_NAN=1 to get them back), and gatConv's behaviour for rows with no edge (the reference's dense
+softmax then attends uniformly to ALL nodes; here, as in sparseGatConv, such rows are NaN -- add self-loops).
+"""
+import os
+
+from ... import backend as F
+from ... import ops
+from ...graph import CSRGraph, as_csr_graph
+
+_CHECK_NAN = os.environ.get("DGLL_CHECK_NAN", "0") == "1"
+
+
+def _pad_heads(h, heads, fo, fo_pad):
+    """[N, heads*fo] -> [N, heads*fo_pad] with zero columns appended to every head."""
+    if fo_pad == fo:
+        return h
+    return F.nn.functional.pad(h.view(h.shape[0], heads, fo), (0, fo_pad - fo)).reshape(h.shape[0], heads * fo_pad)
+
+
+def _unpad_heads(out, heads, fo, fo_pad):
+    if fo_pad == fo:
+        return out
+    return out.view(out.shape[0], heads, fo_pad)[:, :, :fo].reshape(out.shape[0], heads * fo)
+
+
+def _attention_dropout(graph, heads, p, training, device):
+    """Per-edge, per-head multipliers of F.dropout on the attention weights (gatconv.py:37,132)."""
+    if not training or p <= 0.0:
+        return None
+    return F.dropout(F.ones(graph.nnz, heads, device=device), p, training=True)
+
+
+def _fused_heads(x, adj, Ws, a1s, a2s, alpha, concat, mode, dropout, training):
+    """Shared GPU path: Ws [heads][Fin, fo], a1s/a2s [heads][fo] -> [N, heads*fo]."""
+    heads, fo = len(Ws), Ws[0].shape[1]
+    graph = as_csr_graph(adj)
+    h = F.mm(x, Ws[0] if heads == 1 else F.cat(Ws, dim=1))                     # gatconv.py:31,117 for every head at once
+    hv = h.view(h.shape[0], heads, fo)
+    s = (hv * F.stack(a1s).to(h.dtype)).sum(-1)                                # a[:fo] . h_i
+    t = (hv * F.stack(a2s).to(h.dtype)).sum(-1)                                # a[fo:] . h_j
+    fo_pad = ops.head_width_padded(fo, h.dtype)
+    out = ops.gat_aggregate(graph, _pad_heads(h, heads, fo, fo_pad), s, t, heads, alpha, apply_elu=concat, mode=mode,
+                            edge_scale=_attention_dropout(graph, heads, dropout, training, h.device))
+    out = _unpad_heads(out, heads, fo, fo_pad)
+    if _CHECK_NAN:
+        assert not F.isnan(out).any()
+    return out
+
+
+class gatConv(F.nn.Module):
+    """Dense-adjacency GAT layer: softmax_j(leakyrelu(a1.Wh_i + a2.Wh_j)) over adj > 0 (gatconv.py:30-54)."""
+
+    def __init__(self, in_features, out_features, dropout, alpha, concat=True):
+        super().__init__()
+        self.dropout, self.in_features, self.out_features = dropout, in_features, out_features
+        self.alpha, self.concat = alpha, concat
+        self.W = F.Parameter(F.empty(in_features, out_features))
+        F.init.xavier_uniform_(self.W.data, gain=1.414)
+        self.a = F.Parameter(F.empty(2 * out_features, 1))
+        F.init.xavier_uniform_(self.a.data, gain=1.414)
+        self.leakyrelu = F.LeakyReLU(self.alpha)
+
+    def _split_a(self):
+        return self.a[:self.out_features, 0], self.a[self.out_features:, 0]
+
+    def forward(self, h, adj):
+        if h.is_cuda:
+            a1, a2 = self._split_a()
+            return _fused_heads(h, adj, [self.W], [a1], [a2], self.alpha, self.concat, 1, self.dropout, self.training)
+        # CPU tensors: the reference's dense formulation with torch's own ops
+        Wh = F.mm(h, self.W)
+        e = self.leakyrelu(F.matmul(Wh, self.a[:self.out_features, :]) + F.matmul(Wh, self.a[self.out_features:, :]).T)
+        attention = F.softmax(F.where(adj > 0, e, -9e15 * F.ones_like(e)), dim=1)
+        attention = F.dropout(attention, self.dropout, training=self.training)
+        h_prime = F.matmul(attention, Wh)
+        return F.elu(h_prime) if self.concat else h_prime
+
+    def extra_repr(self):
+        return "%d -> %d" % (self.in_features, self.out_features)
+
+
+def _graph_of_indices(indices, shape):
+    """CSRGraph for a [2, E] index tensor plus the permutation that sorts its edges row-major (None if sorted)."""
+    row, col = indices[0], indices[1]
+    key = row * int(shape[1]) + col
+    if key.numel() > 1 and not bool((key[1:] >= key[:-1]).all()):
+        order = F.argsort(key, stable=True)
+        row, col = row[order], col[order]
+    else:
+        order = None
+    return CSRGraph.from_coo(row, col, None, shape, coalesce=False), order
+
+
+class SpecialSpmmFunction(F.autograd.Function):
+    """sparse(indices, values, shape) @ b with gradients for `values` and `b` only (gatconv.py:60-81)."""
+
+    @staticmethod
+    def forward(ctx, indices, values, shape, b):
+        assert indices.requires_grad == False  # noqa: E712  (gatconv.py:65)
+        if not b.is_cuda:
+            a = F.sparse_coo_tensor(indices, values, shape)
+            ctx.save_for_backward(a, b)
+            ctx.N, ctx.gpu = shape[0], False
+            return F.matmul(a, b)
+        graph, order = _graph_of_indices(indices, shape)
+        vals = values.detach().to(F.float32)
+        vals = vals if order is None else vals[order]
+        ctx.graph, ctx.order, ctx.gpu = graph, order, True
+        ctx.save_for_backward(vals, b)
+        return ops.spmm_raw(graph, b, val=vals)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        grad_values = grad_b = None
+        if not ctx.gpu:
+            a, b = ctx.saved_tensors
+            if ctx.needs_input_grad[1]:
+                grad_a_dense = grad_output.matmul(b.t())
+                edge_idx = a._indices()[0, :] * ctx.N + a._indices()[1, :]
+                grad_values = grad_a_dense.view(-1)[edge_idx]
+            if ctx.needs_input_grad[3]:
+                grad_b = a.t().matmul(grad_output)
+            return None, grad_values, None, grad_b
+        vals, b = ctx.saved_tensors
+        graph = ctx.graph
+        if ctx.needs_input_grad[1]:
+            grad_values = ops.sddmm_raw(graph, grad_output, b)             # gatconv.py:76-78 without the dense N x N
+            if ctx.order is not None:
+                unsorted = F.empty_like(grad_values)
+                unsorted[ctx.order] = grad_values
+                grad_values = unsorted
+        if ctx.needs_input_grad[3]:
+            gt, perm = graph.transpose()
+            grad_b = ops.spmm_raw(gt, grad_output, val=vals[perm])         # a.t() @ grad_output, gatconv.py:80
+        return None, grad_values, None, grad_b
+
+
+class SpecialSpmm(F.nn.Module):
+    def forward(self, indices, values, shape, b):
+        return SpecialSpmmFunction.apply(indices, values, shape, b)
+
+
+class sparseGatConv(F.nn.Module):
+    """Sparse GAT layer: e_ij = exp(-leakyrelu(a.[h_i || h_j])), h'_i = sum_j e_ij h_j / sum_j e_ij (gatconv.py:111-148)."""
+
+    def __init__(self, in_features, out_features, dropout, alpha, concat=True):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.alpha, self.concat = alpha, concat
+        self.W = F.Parameter(F.zeros(in_features, out_features))
+        F.init.xavier_normal_(self.W.data, gain=1.414)
+        self.a = F.Parameter(F.zeros(1, 2 * out_features))
+        F.init.xavier_normal_(self.a.data, gain=1.414)
+        self.dropout = F.Dropout(dropout)
+        self.leakyrelu = F.LeakyReLU(self.alpha)
+        self.special_spmm = SpecialSpmm()
+
+    def _split_a(self):
+        return self.a[0, :self.out_features], self.a[0, self.out_features:]
+
+    def forward(self, input, adj):
+        if input.is_cuda:
+            a1, a2 = self._split_a()
+            return _fused_heads(input, adj, [self.W], [a1], [a2], self.alpha, self.concat, 0, self.dropout.p, self.training)
+        # CPU tensors: the reference's op sequence with torch's own ops
+        N = input.size(0)
+        edge = adj.nonzero().t()
+        h = F.mm(input, self.W)
+        edge_h = F.cat((h[edge[0, :], :], h[edge[1, :], :]), dim=1).t()
+        edge_e = F.exp(-self.leakyrelu(self.a.mm(edge_h).squeeze()))
+        e_rowsum = self.special_spmm(edge, edge_e, F.Size([N, N]), F.ones(N, 1))
+        h_prime = self.special_spmm(edge, self.dropout(edge_e), F.Size([N, N]), h).div(e_rowsum)
+        assert not F.isnan(h_prime).any()
+        return F.elu(h_prime) if self.concat else h_prime
+
+    def extra_repr(self):
+        return "%d -> %d" % (self.in_features, self.out_features)
+
+
+class _MultiHead(F.nn.Module):
+    """dropout -> concat(heads) -> dropout -> elu(out head) -> log_softmax (gatconv.py:166-171, :194-199)."""
+    layer_cls = None
+    mode = 0
+
+    def __init__(self, nfeat, nhid, nclass, dropout, alpha, nheads):
+        super().__init__()
+        self.dropout = dropout
+        self.attentions = [self.layer_cls(nfeat, nhid, dropout=dropout, alpha=alpha, concat=True) for _ in range(nheads)]
+        for i, attention in enumerate(self.attentions):
+            self.add_module("attention_{}".format(i), attention)
+        self.out_att = self.layer_cls(nhid * nheads, nclass, dropout=dropout, alpha=alpha, concat=False)
+
+    def forward(self, x, adj):
+        x = F.dropout(x, self.dropout, training=self.training)
+        if x.is_cuda:   # every head in one launch
+            first = self.attentions[0]
+            halves = [att._split_a() for att in self.attentions]
+            x = _fused_heads(x, adj, [att.W for att in self.attentions], [h[0] for h in halves], [h[1] for h in halves],
+                             first.alpha, True, self.mode, self.dropout, self.training)
+        else:
+            x = F.cat([att(x, adj) for att in self.attentions], dim=1)
+        x = F.dropout(x, self.dropout, training=self.training)
+        x = F.elu(self.out_att(x, adj))
+        return F.log_softmax(x, dim=1)
+
+
+class GAT(_MultiHead):
+    """Dense version of GAT (gatconv.py:154-171)."""
+    layer_cls = gatConv
+    mode = 1
+
+
+class SpGAT(_MultiHead):
+    """Sparse version of GAT (gatconv.py:174-199)."""
+    layer_cls = sparseGatConv
+    mode = 0

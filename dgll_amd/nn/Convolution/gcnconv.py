@@ -1,0 +1,60 @@
+"""GCN layer on the gfx950 aggregation engine.
+
+Interface mirror of /root/reference/dgll/nn/Convolution/gcnconv.py: `gcnConv(in_features, out_features,
+bias=True)` with parameters `weight` [in, out] and `bias` [out] initialised U(-1/sqrt(out), 1/sqrt(out))
+(gcnconv.py:23-27), `forward(x, adj)` = adj . (x . weight) + bias (gcnconv.py:29-35), and the two-layer
+`GCN(in_features, nhid, nclass, dropout)` example (gcnconv.py:43-58).  state_dicts interchange.
+
+On GPU tensors the product with `adj` runs in dgll_hip_spmm_csr with the bias add fused into the kernel's
+epilogue; `adj` may be the reference's torch sparse COO tensor (converted to CSR once and cached) or a
+dgll_amd.CSRGraph.
+"""
+import math
+
+from ... import backend as F
+from ... import ops
+from ...graph import as_csr_graph
+
+
+class gcnConv(F.nn.Module):
+    def __init__(self, in_features, out_features, bias=True):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.weight = F.Parameter(F.empty(in_features, out_features))
+        if bias:
+            self.bias = F.Parameter(F.empty(out_features))
+        else:
+            self.register_parameter("bias", None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        bound = 1.0 / math.sqrt(self.out_features)  # gcnconv.py:24: 1/sqrt(weight.size(1))
+        with F.no_grad():
+            self.weight.uniform_(-bound, bound)
+            if self.bias is not None:
+                self.bias.uniform_(-bound, bound)
+
+    def forward(self, x, adj):
+        support = F.mm(x, self.weight)                       # transform first (gcnconv.py:30)
+        if support.is_cuda:
+            return ops.spmm(as_csr_graph(adj), support, bias=self.bias)   # aggregate + fused bias (gcnconv.py:31-33)
+        out = F.spmm(adj, support)
+        return out if self.bias is None else out + self.bias
+
+    def extra_repr(self):
+        return "%d -> %d" % (self.in_features, self.out_features)
+
+
+class GCN(F.nn.Module):
+    """log_softmax(gcn2(dropout(relu(gcn1(x, A))), A)) -- gcnconv.py:53-58."""
+
+    def __init__(self, in_features, nhid, nclass, dropout):
+        super().__init__()
+        self.in_features, self.nhid, self.nclass, self.dropout = in_features, nhid, nclass, dropout
+        self.gcn1 = gcnConv(in_features, nhid)
+        self.gcn2 = gcnConv(nhid, nclass)
+
+    def forward(self, x, adj):
+        hidden = F.relu(self.gcn1(x, adj))
+        hidden = F.dropout(hidden, self.dropout, training=self.training)
+        return F.log_softmax(self.gcn2(hidden, adj), dim=1)

@@ -1,0 +1,151 @@
+"""GraphSAGE layer on the gfx950 aggregation engine.
+
+Interface mirror of /root/reference/dgll/nn/Convolution/sageconv.py:
+  NeighborAggregator(input_dim, output_dim, use_bias=False, aggr_method="mean")      sageconv.py:10-45
+  sageConv(input_dim, hidden_dim, activation=relu, aggr_neighbor_method="mean",
+           aggr_hid_method="sum")                                                    sageconv.py:48-83
+  GraphSage(input_dim, hidden_dim=[64, 64], num_neighbors_list=[10, 10])             sageconv.py:86-114
+with the same parameter names (`weight`, `neighborAgg.weight`, `neighborAgg.bias`, `gcn1`, `gcn2`, ...).
+
+Reference defects deliberately NOT reproduced: the K-axis reduction result is
+assigned (sageconv.py:33-38 discards it), `max` takes the values of torch.max, sageConv.weight is
+initialised (reset_parameters() is never called at sageconv.py:63-68), GraphSage accepts any number of
+layers and indexes fan-outs by hop (sageconv.py:111 indexes by layer, which only works for equal fan-outs).
+
+On the GPU the K-axis reduce over the dense [N, K, D] neighbour tensor is the CSR SpMM kernel on a
+constant-degree structure (rowptr = arange(0, N*K+1, K), col = arange(N*K)); `forward_block` takes a sampled
+CSR block and gathers straight from the source feature matrix without materialising [N, K, D].
+"""
+from ... import backend as F
+from ... import ops
+from ...graph import CSRGraph
+
+_fanout_graphs = {}
+
+
+def _fanout_graph(n, k, device):
+    key = (n, k, str(device))
+    g = _fanout_graphs.get(key)
+    if g is None:
+        if len(_fanout_graphs) > 64:
+            _fanout_graphs.clear()
+        g = _fanout_graphs[key] = CSRGraph.fixed_fanout(n, k, device)
+    return g
+
+
+def _check_method(name, allowed, what):
+    if name not in allowed:
+        raise ValueError("Unsupported %s, expected %s, but got %s" % (what, ", ".join(allowed), name))
+
+
+class NeighborAggregator(F.nn.Module):
+    """reduce_K(neighbours) . weight (+ bias)."""
+
+    def __init__(self, input_dim, output_dim, use_bias=False, aggr_method="mean"):
+        super().__init__()
+        self.input_dim, self.output_dim = input_dim, output_dim
+        self.use_bias, self.aggr_method = use_bias, aggr_method
+        self.weight = F.Parameter(F.empty(input_dim, output_dim))
+        if use_bias:
+            self.bias = F.Parameter(F.empty(output_dim))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        F.init.kaiming_uniform_(self.weight)        # sageconv.py:28
+        if self.use_bias:
+            F.init.zeros_(self.bias)                # sageconv.py:30
+
+    def reduce(self, neighbor_feature):
+        """[N, K, D] -> [N, D] over the K axis (sageconv.py:33-38, with the result kept)."""
+        _check_method(self.aggr_method, ("mean", "sum", "max"), "aggr_method")
+        if not neighbor_feature.is_cuda:             # CPU tensors: torch's own reduction, as in the reference
+            if self.aggr_method == "max":
+                return neighbor_feature.max(dim=1)[0]
+            return getattr(neighbor_feature, self.aggr_method)(dim=1)
+        n, k, d = neighbor_feature.shape
+        flat = neighbor_feature.reshape(n * k, d)
+        graph = _fanout_graph(n, k, neighbor_feature.device)
+        if self.aggr_method == "max":
+            return ops.segment_max(graph, flat)
+        return ops.spmm(graph, flat, reduce=self.aggr_method)
+
+    def reduce_block(self, block, x_src):
+        """Same reduction driven by a CSR block (rows = destination nodes, columns index x_src)."""
+        _check_method(self.aggr_method, ("mean", "sum", "max"), "aggr_method")
+        if self.aggr_method == "max":
+            return ops.segment_max(block, x_src)
+        return ops.spmm(block, x_src, reduce=self.aggr_method)
+
+    def transform(self, reduced):
+        hidden = F.matmul(reduced, self.weight)     # sageconv.py:41
+        if self.use_bias:
+            hidden = hidden + self.bias
+        return hidden
+
+    def forward(self, neighbor_feature):
+        return self.transform(self.reduce(neighbor_feature))
+
+
+class sageConv(F.nn.Module):
+    """act( src . weight  (+ | ++)  NeighborAggregator(neighbours) ) -- sageconv.py:70-83."""
+
+    def __init__(self, input_dim, hidden_dim, activation=F.relu, aggr_neighbor_method="mean", aggr_hid_method="sum"):
+        super().__init__()
+        self.input_dim, self.hidden_dim = input_dim, hidden_dim
+        self.activation = activation
+        self.aggr_neighbor_method, self.aggr_hid_method = aggr_neighbor_method, aggr_hid_method
+        self.weight = F.Parameter(F.empty(input_dim, hidden_dim))
+        self.neighborAgg = NeighborAggregator(input_dim, hidden_dim, aggr_method=aggr_neighbor_method)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        F.init.kaiming_uniform_(self.weight)        # sageconv.py:68
+
+    def _combine(self, self_hidden, neighbor_hidden):
+        _check_method(self.aggr_hid_method, ("sum", "concat"), "aggr_hid_method")
+        if self.aggr_hid_method == "sum":
+            hidden = self_hidden + neighbor_hidden
+        else:
+            hidden = F.cat([self_hidden, neighbor_hidden], dim=1)   # self first (sageconv.py:77)
+        return self.activation(hidden) if self.activation else hidden
+
+    def forward(self, src_node_features, neighbor_node_features):
+        neighbor_hidden = self.neighborAgg(neighbor_node_features)
+        self_hidden = F.matmul(src_node_features, self.weight)
+        return self._combine(self_hidden, neighbor_hidden)
+
+    def forward_block(self, block, x_src, x_dst=None):
+        """Sampled-block / full-graph form: `block` is a CSRGraph whose rows are the destination nodes and whose
+        columns index `x_src`; `x_dst` are the destination nodes' own features (default: the first n_rows rows
+        of x_src, the usual block convention)."""
+        if x_dst is None:
+            x_dst = x_src[:block.n_rows]
+        neighbor_hidden = self.neighborAgg.transform(self.neighborAgg.reduce_block(block, x_src))
+        return self._combine(F.matmul(x_dst, self.weight), neighbor_hidden)
+
+
+class GraphSage(F.nn.Module):
+    """Hop-pyramid GraphSAGE (sageconv.py:103-114): layer l is applied to hops 0 .. L-l-1, hop h taking its
+    neighbours from hop h+1 viewed as [n_h, K_h, -1]."""
+
+    def __init__(self, input_dim, hidden_dim=[64, 64], num_neighbors_list=[10, 10]):
+        super().__init__()
+        self.input_dim, self.hidden_dim = input_dim, list(hidden_dim)
+        self.num_neighbors_list = list(num_neighbors_list)
+        self.num_layers = len(self.num_neighbors_list)
+        if len(self.hidden_dim) != self.num_layers:
+            raise ValueError("hidden_dim and num_neighbors_list must have one entry per layer")
+        dims = [input_dim] + self.hidden_dim
+        self.gcn = []
+        for l in range(self.num_layers):
+            layer = sageConv(dims[l], dims[l + 1])
+            setattr(self, "gcn%d" % (l + 1), layer)   # registered as gcn1, gcn2, ... (sageconv.py:96-97)
+            self.gcn.append(layer)
+
+    def forward(self, node_feature_list):
+        hidden = node_feature_list
+        for l in range(self.num_layers):
+            layer = self.gcn[l]
+            hidden = [layer(hidden[hop], hidden[hop + 1].view(len(hidden[hop]), self.num_neighbors_list[hop], -1))
+                      for hop in range(self.num_layers - l)]
+        return hidden[0]

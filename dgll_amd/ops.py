@@ -1,0 +1,127 @@
+"""Operators of the aggregation hot path: thin autograd wrappers over the C ABI (include/dgll_hip.h).
+
+Every function here takes CUDA (= HIP on torch-ROCm) tensors and launches hand-written gfx950 kernels on the
+current torch stream.  There is no CPU implementation in this module and no fallback: a CPU tensor raises.
+"""
+import torch
+
+from . import _lib
+from .graph import CSRGraph
+
+_DT = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16}
+_REDUCE = {"sum": _lib.REDUCE_SUM, "mean": _lib.REDUCE_MEAN}
+
+
+def _require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("dgll_amd.ops run on the GPU only (got a %s tensor); there is no CPU fallback" % t.device)
+
+
+def _dtype_code(t):
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError("dgll_amd kernels take float32 or bfloat16 matrices, got %s" % t.dtype)
+
+
+def _row_major(x):
+    """2-D tensor with unit column stride (any row stride >= ncols is passed through as the leading dimension)."""
+    if x.dim() != 2:
+        raise ValueError("expected a 2-D matrix")
+    if x.stride(1) != 1 or x.stride(0) < x.shape[1]:
+        x = x.contiguous()
+    return x
+
+
+def alloc_features(n_rows, feat, dtype, device, pad_to=8):
+    """[n_rows, feat] view of a buffer whose leading dimension is padded to 16 bytes, so any feature width
+    takes the vectorised (global_load_dwordx4) path of the kernels."""
+    ld = (feat + pad_to - 1) // pad_to * pad_to
+    buf = torch.empty((n_rows, ld), dtype=dtype, device=device)
+    return buf[:, :feat] if ld != feat else buf
+
+
+def spmm_raw(graph, x, val=None, reduce="sum", bias=None, relu=False, out_dtype=None, out=None):
+    """Y = epilogue(reduce_j A[i,j] X[j,:]) with no autograd.  `val` overrides graph.val (None = unweighted
+    unless graph.val is set)."""
+    _require_cuda(x, graph.rowptr)
+    x = _row_major(x)
+    if x.shape[0] != graph.n_cols:
+        raise ValueError("X has %d rows but the adjacency gathers from %d" % (x.shape[0], graph.n_cols))
+    feat = x.shape[1]
+    val = graph.val if val is None else val
+    if val is not None:
+        if val.dtype != torch.float32 or val.numel() != graph.nnz:
+            raise ValueError("edge values must be fp32 with one entry per nonzero")
+        val = val.contiguous()
+    out_dtype = x.dtype if out_dtype is None else out_dtype
+    if out is None:
+        out = alloc_features(graph.n_rows, feat, out_dtype, x.device, pad_to=8 if out_dtype == torch.bfloat16 else 4)
+    epi = (_lib.EPI_BIAS if bias is not None else 0) | (_lib.EPI_RELU if relu else 0)
+    if bias is not None:
+        bias = bias.detach().to(torch.float32).contiguous()
+    plan = graph.plan()
+    ws_bytes = graph.workspace_bytes(feat)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes else None
+    with torch.cuda.device(x.device):
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        code = _lib.lib.dgll_hip_spmm_csr(
+            stream, plan, graph.rowptr.data_ptr(), graph.col.data_ptr(), val.data_ptr() if val is not None else None,
+            x.data_ptr(), x.stride(0), _dtype_code(x), out.data_ptr(), out.stride(0), _dtype_code(out),
+            graph.n_rows, graph.n_cols, feat, _REDUCE[reduce], epi, bias.data_ptr() if bias is not None else None,
+            ws.data_ptr() if ws is not None else None, ws_bytes)
+    _lib.check(code, "dgll_hip_spmm_csr")
+    return out
+
+
+class _Spmm(torch.autograd.Function):
+    """Y = A.X (+bias, ReLU) -- F.spmm of gcnconv.py:31 / SpecialSpmmFunction of gatconv.py:60-81.
+    backward: grad_X = A^T.g through the cached transposed CSR (gatconv.py:80), grad_val = SDDMM(g, X)
+    (gatconv.py:76-78), grad_bias = column sums."""
+
+    @staticmethod
+    def forward(ctx, x, val, bias, graph, reduce, relu):
+        y = spmm_raw(graph, x, val=val, reduce=reduce, bias=bias, relu=relu)
+        ctx.graph, ctx.reduce, ctx.relu = graph, reduce, relu
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x if (val is not None and val.requires_grad) else None, val, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, val, y = ctx.saved_tensors
+        graph = ctx.graph
+        if ctx.relu:
+            g = g * (y > 0)
+        g = _row_major(g)
+        grad_x = grad_val = grad_bias = None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            grad_bias = g.sum(0, dtype=torch.float32)
+        if ctx.needs_input_grad[0]:
+            gt, perm = graph.transpose()
+            tval = gt.val if val is None else val.detach()[perm]  # gt.val is the cached permuted graph.val
+            if ctx.reduce == "mean":
+                scale = graph.mean_scale_transposed()  # A^T edge (j <- i) carries 1/deg(i)
+                tval = scale if tval is None else tval * scale
+            grad_x = spmm_raw(gt, g, val=tval, reduce="sum")
+        if val is not None and ctx.needs_input_grad[1]:
+            from .ops_edge import sddmm_raw
+
+            grad_val = sddmm_raw(graph, g, x)
+            if ctx.reduce == "mean":
+                grad_val = grad_val / graph.degrees().clamp(min=1).to(torch.float32)[graph.row_index()]
+        return grad_x, grad_val, grad_bias, None, None, None
+
+
+def spmm(graph, x, val=None, reduce="sum", bias=None, relu=False):
+    """Differentiable CSR SpMM on the GPU.  `graph` is a CSRGraph; `val` optional per-edge fp32 weights
+    (defaults to graph.val); `reduce` 'sum' or 'mean'; optional fused bias / ReLU epilogue."""
+    if not isinstance(graph, CSRGraph):
+        raise TypeError("spmm expects a CSRGraph (use dgll_amd.graph.as_csr_graph for torch sparse tensors)")
+    if val is None and graph.val is not None and graph.val.requires_grad:
+        val = graph.val
+    return _Spmm.apply(x, val, bias, graph, reduce, relu)
+
+
+from .ops_edge import gat_aggregate, head_width_padded, sddmm_raw, segment_max  # noqa: E402,F401

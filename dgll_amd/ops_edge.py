@@ -1,0 +1,170 @@
+"""Per-edge operators of the GAT / SpecialSpmm path (C ABI: dgll_hip_sddmm_csr, dgll_hip_gat_fwd/bwd,
+dgll_hip_segment_max).  GPU only; no fallback."""
+import torch
+
+from . import _lib
+from .graph import CSRGraph
+from .ops import _dtype_code, _require_cuda
+
+
+def _stream(device):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _epv(dtype):
+    return 8 if dtype == torch.bfloat16 else 4
+
+
+def _vec_ready(x):
+    """16-byte aligned rows: unit column stride, leading dimension a multiple of one vector."""
+    esz = x.element_size()
+    return (x.dim() == 2 and x.stride(1) == 1 and x.stride(0) >= x.shape[1] and (x.stride(0) * esz) % 16 == 0
+            and x.data_ptr() % 16 == 0 and x.stride(0) >= -(-x.shape[1] // (16 // esz)) * (16 // esz))
+
+
+def _padded_copy(x, width=None):
+    """Copy of x whose leading dimension (and optionally logical width, zero filled) is vector aligned."""
+    epv = _epv(x.dtype)
+    width = x.shape[1] if width is None else width
+    ld = -(-width // epv) * epv
+    buf = torch.zeros((x.shape[0], ld), dtype=x.dtype, device=x.device)
+    buf[:, :x.shape[1]] = x
+    return buf[:, :width] if ld != width else buf
+
+
+def _ready(x):
+    return x if _vec_ready(x) else _padded_copy(x)
+
+
+def _empty_padded(n, width, dtype, device):
+    epv = _epv(dtype)
+    ld = -(-width // epv) * epv
+    buf = torch.empty((n, ld), dtype=dtype, device=device)
+    return buf[:, :width] if ld != width else buf
+
+
+# ------------------------------------------------------------------------------------------------ SDDMM
+def sddmm_raw(graph, g, b):
+    """edge_out[k] = <g[row(k)], b[col[k]]> -- SpecialSpmmFunction.backward's grad_values (gatconv.py:76-78)."""
+    _require_cuda(g, b, graph.rowptr)
+    if g.dtype != b.dtype:
+        b = b.to(g.dtype)
+    feat = g.shape[1]
+    tile = 64 * _epv(g.dtype)
+    out = torch.empty(graph.nnz, dtype=torch.float32, device=g.device)
+    total = None
+    for c0 in range(0, feat, tile):  # > 64 vectors per row: column blocks, summed
+        gs, bs = _ready(g[:, c0:c0 + tile]), _ready(b[:, c0:c0 + tile])
+        with torch.cuda.device(g.device):
+            code = _lib.lib.dgll_hip_sddmm_csr(_stream(g.device), graph.rowptr.data_ptr(), graph.col.data_ptr(),
+                                               gs.data_ptr(), gs.stride(0), bs.data_ptr(), bs.stride(0), _dtype_code(gs),
+                                               out.data_ptr(), graph.n_rows, gs.shape[1])
+        _lib.check(code, "dgll_hip_sddmm_csr")
+        if feat > tile:
+            total = out.clone() if total is None else total + out
+    return out if total is None else total
+
+
+# ------------------------------------------------------------------------------------------------ segment max
+class _SegmentMax(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, graph):
+        _require_cuda(x, graph.rowptr)
+        xs = _ready(x)
+        feat = x.shape[1]
+        y = _empty_padded(graph.n_rows, feat, x.dtype, x.device)
+        arg = torch.empty((graph.n_rows, y.stride(0)), dtype=torch.int32, device=x.device)
+        with torch.cuda.device(x.device):
+            code = _lib.lib.dgll_hip_segment_max(_stream(x.device), graph.rowptr.data_ptr(), graph.col.data_ptr(),
+                                                 xs.data_ptr(), xs.stride(0), y.data_ptr(), arg.data_ptr(), y.stride(0),
+                                                 _dtype_code(xs), graph.n_rows, feat)
+        _lib.check(code, "dgll_hip_segment_max")
+        ctx.save_for_backward(arg[:, :feat])
+        ctx.n_src = x.shape[0]
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (arg,) = ctx.saved_tensors
+        grad = torch.zeros((ctx.n_src, g.shape[1]), dtype=g.dtype, device=g.device)
+        valid = arg >= 0
+        grad.scatter_add_(0, arg.clamp(min=0).long(), g * valid)   # the gradient goes to the arg-max row only
+        return grad, None
+
+
+def segment_max(graph, x):
+    """max over each row's neighbours -- NeighborAggregator 'max' (sageconv.py:37-38); empty rows give 0."""
+    return _SegmentMax.apply(x, graph)
+
+
+# ------------------------------------------------------------------------------------------------ fused GAT
+def head_width_padded(fo, dtype):
+    """Per-head column count the kernels need: a power-of-two number of 16-byte vectors."""
+    epv = _epv(dtype)
+    vecs = -(-fo // epv)
+    p = 1
+    while p < vecs:
+        p <<= 1
+    return p * epv
+
+
+class _GatAggregate(torch.autograd.Function):
+    """out = act( sum_j w_ij scale_ij h_j / sum_j w_ij ) for all heads at once; see include/dgll_hip.h."""
+
+    @staticmethod
+    def forward(ctx, h, s, t, edge_scale, graph, heads, fo, alpha, apply_elu, mode):
+        _require_cuda(h, s, t, graph.rowptr)
+        dev = h.device
+        h = _ready(h)
+        s = s.to(torch.float32).contiguous()
+        t = t.to(torch.float32).contiguous()
+        out = _empty_padded(graph.n_rows, heads * fo, h.dtype, dev)
+        rowsum = torch.empty((graph.n_rows, heads), dtype=torch.float32, device=dev)
+        rowmax = torch.empty((graph.n_rows, heads), dtype=torch.float32, device=dev) if mode == 1 else None
+        if edge_scale is not None:
+            edge_scale = edge_scale.to(torch.float32).contiguous()
+        with torch.cuda.device(dev):
+            code = _lib.lib.dgll_hip_gat_fwd(
+                _stream(dev), graph.rowptr.data_ptr(), graph.col.data_ptr(), h.data_ptr(), h.stride(0), s.data_ptr(),
+                t.data_ptr(), edge_scale.data_ptr() if edge_scale is not None else None, out.data_ptr(), out.stride(0),
+                _dtype_code(h), rowsum.data_ptr(), rowmax.data_ptr() if rowmax is not None else None, graph.n_rows, heads,
+                fo, float(alpha), int(apply_elu), int(mode))
+        _lib.check(code, "dgll_hip_gat_fwd")
+        ctx.graph, ctx.cfg = graph, (heads, fo, float(alpha), int(apply_elu), int(mode))
+        ctx.save_for_backward(h, s, t, edge_scale, out, rowsum, rowmax)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        h, s, t, edge_scale, out, rowsum, rowmax = ctx.saved_tensors
+        graph = ctx.graph
+        heads, fo, alpha, apply_elu, mode = ctx.cfg
+        dev = h.device
+        g = _ready(g.to(h.dtype))
+        gt, perm = graph.transpose()
+        dn = _empty_padded(graph.n_rows, heads * fo, h.dtype, dev)
+        dd = torch.empty((graph.n_rows, heads), dtype=torch.float32, device=dev)
+        grad_h = _empty_padded(graph.n_cols, heads * fo, h.dtype, dev)
+        grad_s = torch.empty((graph.n_rows, heads), dtype=torch.float32, device=dev)
+        grad_t = torch.empty((graph.n_cols, heads), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            code = _lib.lib.dgll_hip_gat_bwd(
+                _stream(dev), graph.rowptr.data_ptr(), graph.col.data_ptr(), gt.rowptr.data_ptr(), gt.col.data_ptr(),
+                perm.data_ptr(), h.data_ptr(), h.stride(0), s.data_ptr(), t.data_ptr(),
+                edge_scale.data_ptr() if edge_scale is not None else None, out.data_ptr(), out.stride(0), g.data_ptr(),
+                g.stride(0), _dtype_code(h), rowsum.data_ptr(), rowmax.data_ptr() if rowmax is not None else None,
+                dn.data_ptr(), dn.stride(0), dd.data_ptr(), grad_h.data_ptr(), grad_h.stride(0), grad_s.data_ptr(),
+                grad_t.data_ptr(), graph.n_rows, graph.n_cols, heads, fo, alpha, apply_elu, mode)
+        _lib.check(code, "dgll_hip_gat_bwd")
+        return grad_h, grad_s, grad_t, None, None, None, None, None, None, None
+
+
+def gat_aggregate(graph, h, s, t, heads, alpha, apply_elu=True, mode=0, edge_scale=None):
+    """Fused multi-head edge-softmax + aggregation.  h: [N, heads*fo] with fo already padded per
+    `head_width_padded`; s, t: [N, heads]."""
+    if not isinstance(graph, CSRGraph):
+        raise TypeError("gat_aggregate expects a CSRGraph")
+    fo = h.shape[1] // heads
+    if fo * heads != h.shape[1] or head_width_padded(fo, h.dtype) != fo:
+        raise ValueError("per-head width %d is not padded for the kernels (need %d)" % (fo, head_width_padded(fo, h.dtype)))
+    return _GatAggregate.apply(h, s, t, edge_scale, graph, heads, fo, alpha, apply_elu, mode)

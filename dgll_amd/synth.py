@@ -1,0 +1,94 @@
+"""Synthetic power-law graphs for the benchmarks and the parity tests.
+
+RMAT (a=.57 b=.19 c=.19 d=.05), one random draw per level deciding the (src, dst) bit pair.  Two generators
+with the same recursion: numpy (`rmat_edges_np`, bit-reproducible everywhere, used by the tests and the golden
+generator) and torch on the device (`rmat_edges_torch`, used for bench-size graphs that are built in HBM).
+"""
+import numpy as np
+import torch
+
+from .graph import CSRGraph
+
+A, B, C = 0.57, 0.19, 0.19
+
+
+def rmat_edges_np(scale, n_edges, seed, a=A, b=B, c=C):
+    rng = np.random.default_rng(seed)
+    src = np.zeros(n_edges, dtype=np.int64)
+    dst = np.zeros(n_edges, dtype=np.int64)
+    for _ in range(scale):
+        r = rng.random(n_edges)
+        src = (src << 1) | (r >= a + b)
+        dst = (dst << 1) | (((r >= a) & (r < a + b)) | (r >= a + b + c))
+    return src, dst
+
+
+def rmat_edges_torch(scale, n_edges, seed, device, a=A, b=B, c=C, chunk=1 << 26):
+    """Same recursion on the device, generated in chunks to bound temporary memory."""
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    srcs, dsts = [], []
+    for start in range(0, n_edges, chunk):
+        m = min(chunk, n_edges - start)
+        src = torch.zeros(m, dtype=torch.int64, device=device)
+        dst = torch.zeros(m, dtype=torch.int64, device=device)
+        for _ in range(scale):
+            r = torch.rand(m, generator=gen, device=device)
+            src = (src << 1) | (r >= a + b)
+            dst = (dst << 1) | (((r >= a) & (r < a + b)) | (r >= a + b + c))
+        srcs.append(src)
+        dsts.append(dst)
+    return torch.cat(srcs), torch.cat(dsts)
+
+
+def build_graph(src, dst, n, symmetric=False, self_loops=True, normalise="row", weighted=True):
+    """Coalesced CSRGraph from an edge list (torch tensors on any device).
+
+    symmetric: add the reverse of every edge; self_loops: add (i, i); normalise: 'row' gives D^-1 A fp32 weights
+    (nn/utils/utils.py:240-247), None gives all-ones; weighted=False drops the value array (SAGE mean/sum)."""
+    if symmetric:
+        src, dst = torch.cat([src, dst]), torch.cat([dst, src])
+    if self_loops:
+        loops = torch.arange(n, dtype=torch.int64, device=src.device)
+        src, dst = torch.cat([src, loops]), torch.cat([dst, loops])
+    key = torch.unique(src * n + dst)            # sorted + coalesced (duplicates dropped, weight 1)
+    row = torch.div(key, n, rounding_mode="floor")
+    col = (key - row * n).to(torch.int32)
+    del key
+    counts = torch.bincount(row, minlength=n)
+    rowptr = torch.zeros(n + 1, dtype=torch.int64, device=src.device)
+    torch.cumsum(counts, 0, out=rowptr[1:])
+    val = None
+    if weighted:
+        if normalise == "row":
+            val = (1.0 / counts.clamp(min=1).to(torch.float32))[row]
+        else:
+            val = torch.ones(col.numel(), dtype=torch.float32, device=src.device)
+    return CSRGraph(rowptr, col, val, n, n, check=False)
+
+
+def rmat_graph(scale, edge_factor=16, seed=0, device="cpu", **kw):
+    n = 1 << scale
+    if torch.device(device).type == "cpu":
+        s, d = rmat_edges_np(scale, edge_factor << scale, seed)
+        src, dst = torch.from_numpy(s), torch.from_numpy(d)
+    else:
+        src, dst = rmat_edges_torch(scale, edge_factor << scale, seed, device)
+    return build_graph(src, dst, n, **kw)
+
+
+PRODUCTS_NODES = 2_449_029          # ogbn-products (C3/C4)
+PRODUCTS_UNDIRECTED_EDGES = 61_859_140
+
+
+def products_like_graph(device, seed=0, n=PRODUCTS_NODES, n_undirected=PRODUCTS_UNDIRECTED_EDGES, weighted=False,
+                        self_loops=False):
+    """ogbn-products-shaped synthetic graph: N = 2 449 029 nodes, ~61.86 M undirected RMAT edges symmetrised to
+    ~123.7 M directed ones (duplicates coalesce, so nnz lands slightly below 123 718 280).  RMAT ids are drawn at
+    scale ceil(log2 N) and folded into [0, N) with a modulo."""
+    scale = int(np.ceil(np.log2(n)))
+    src, dst = rmat_edges_torch(scale, n_undirected, seed, device) if torch.device(device).type != "cpu" else \
+        tuple(torch.from_numpy(x) for x in rmat_edges_np(scale, n_undirected, seed))
+    src, dst = src % n, dst % n
+    keep = src != dst
+    return build_graph(src[keep], dst[keep], n, symmetric=True, self_loops=self_loops, weighted=weighted)

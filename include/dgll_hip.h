@@ -1,0 +1,123 @@
+/*
+ * dgll_hip.h -- C ABI of libdgll_hip.so, the MI355X (gfx950) sparse GNN aggregation engine that sits
+ * behind the dgll.nn conv-layer API.
+ *
+ * This is the drop-in boundary of the hot path.  The reference's own native
+ * boundary has the same shape -- two extern "C" launchers taking borrowed device pointers and plain
+ * ints (/root/reference/dgll/FusedKernel/gcn_fused_kernel.cu:190-195 and :238-244, bound from Python by
+ * gcn_extension.cpp:5-18,46-55).  Each entry point below cites the reference call site it serves.
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a DEVICE pointer owned by the caller and borrowed for the duration of the launch
+ *     (as gcn_extension.cpp:46-55 borrows tensor.data_ptr()); nothing is allocated or freed on the data
+ *     path; scratch memory is passed in by the caller (`workspace`);
+ *   - `stream` is a hipStream_t passed as void*; launches are ASYNCHRONOUS on it (the reference launcher
+ *     synchronises the whole device, gcn_fused_kernel.cu:229 -- deliberately not reproduced);
+ *   - return value: 0 on success, negative DGLL_ERR_* otherwise; dgll_hip_last_error() gives the text
+ *     (the reference calls exit(1), gcn_fused_kernel.cu:224-227 -- deliberately not reproduced);
+ *   - CSR: int64 rowptr[n_rows+1], int32 col[nnz], optional fp32 val[nnz] (NULL = all ones);
+ *     dense matrices are row-major with an explicit leading dimension in ELEMENTS;
+ *   - dtypes: DGLL_F32 or DGLL_BF16 storage, fp32 accumulation always;
+ *   - re-entrant and thread-safe: no global mutable state besides the thread-local error string.
+ */
+#ifndef DGLL_HIP_H
+#define DGLL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DGLL_HIP_ABI_VERSION 1
+
+enum { DGLL_OK = 0, DGLL_ERR_INVALID = -1, DGLL_ERR_HIP = -2, DGLL_ERR_UNSUPPORTED = -3, DGLL_ERR_WORKSPACE = -4 };
+enum { DGLL_F32 = 0, DGLL_BF16 = 1 };
+enum { DGLL_REDUCE_SUM = 0, DGLL_REDUCE_MEAN = 1 };
+/* epilogue bit-mask applied to a finished output row: y = act(scale*acc + bias) */
+enum { DGLL_EPI_NONE = 0, DGLL_EPI_BIAS = 1, DGLL_EPI_RELU = 2 };
+
+typedef struct dgll_csr_plan dgll_csr_plan; /* opaque: load-balancing schedule of one CSR structure */
+
+/* ---- library -------------------------------------------------------------------------------------- */
+int dgll_hip_abi_version(void);
+const char* dgll_hip_last_error(void);
+/* Fills name (<= name_len bytes), compute-unit count and total global memory of `device`. */
+int dgll_hip_device_info(int device, char* name, int name_len, int* compute_units, int64_t* global_mem_bytes);
+
+/* ---- CSR schedule ----------------------------------------------------------------------------------
+ * Built once per adjacency structure (the reference builds its adjacency once per graph,
+ * nn/utils/utils.py:171,179).  Rows longer than `long_row_threshold` nonzeros (<= 0 selects the default,
+ * 512) are split into chunks that are reduced in a fixed order, so results are bit-reproducible and
+ * power-law rows do not serialise the launch.  Synchronises `stream` (it reads a count back).          */
+int dgll_hip_csr_plan_create(void* stream, const int64_t* rowptr, int64_t n_rows, int64_t nnz,
+                             int long_row_threshold, dgll_csr_plan** out_plan);
+void dgll_hip_csr_plan_destroy(dgll_csr_plan* plan);
+/* Scratch bytes dgll_hip_spmm_csr / dgll_hip_gat_* need for `feat` output columns with this plan. */
+size_t dgll_hip_csr_plan_workspace_bytes(const dgll_csr_plan* plan, int feat);
+int64_t dgll_hip_csr_plan_num_long_rows(const dgll_csr_plan* plan);
+int64_t dgll_hip_csr_plan_num_chunks(const dgll_csr_plan* plan);
+
+/* ---- a1 / a3 / a7-forward: Y[n_rows, feat] = epilogue( reduce_j A[i,j] * X[j, :] ) -------------------
+ * Serves F.spmm(adj, support) (dgll/nn/Convolution/gcnconv.py:31, gcn.py:39), torch.sparse.mm
+ * (Evaluation/PPI/gcn_model.py:76), the K-axis mean/sum of NeighborAggregator (sageconv.py:33-36, a
+ * constant-degree CSR) and SpecialSpmmFunction.forward (gatconv.py:66-69).  With the transposed CSR it is
+ * also every grad_X = A^T.g (autograd of the above; gatconv.py:80).
+ * `plan` may be NULL (every row is then handled by one wavefront).  `val` may be NULL (unweighted).
+ * `bias` is fp32[feat] and only read when epilogue has DGLL_EPI_BIAS.                                   */
+int dgll_hip_spmm_csr(void* stream, const dgll_csr_plan* plan,
+                      const int64_t* rowptr, const int32_t* col, const float* val,
+                      const void* X, int64_t ldx, int x_dtype,
+                      void* Y, int64_t ldy, int y_dtype,
+                      int64_t n_rows, int64_t n_cols, int feat,
+                      int reduce, int epilogue, const float* bias,
+                      void* workspace, size_t workspace_bytes);
+
+/* ---- a7 backward: edge_out[k] = <G[row(k), :], B[col[k], :]> ------------------------------------------
+ * The sampled dense-dense product SpecialSpmmFunction.backward computes through a dense N x N matmul
+ * (gatconv.py:76-78).  G and B share `dtype`; both must be 16-byte aligned with leading dimensions padded to
+ * a multiple of 16 bytes; feat <= 64 vectors of 16 bytes (256 fp32 / 512 bf16 columns).                      */
+int dgll_hip_sddmm_csr(void* stream, const int64_t* rowptr, const int32_t* col,
+                       const void* G, int64_t ldg, const void* B, int64_t ldb, int dtype,
+                       float* edge_out, int64_t n_rows, int feat);
+
+/* ---- a6 / a8 / a9: fused multi-head edge-softmax + aggregation ------------------------------------------
+ * All `heads` attention heads of one layer in one launch (the reference loops heads in Python,
+ * gatconv.py:168,196).  H is [n_cols, heads*fo] (the concatenated per-head X.W of gatconv.py:117), S and T are
+ * fp32 [n, heads] with S[i,k] = a_k[:fo].h_i^k, T[j,k] = a_k[fo:].h_j^k (gatconv.py:122-125 without
+ * materialising edge_h).  mode 0 = sparseGatConv: w_ij = exp(-leakyrelu_alpha(S_i+T_j)) (gatconv.py:125);
+ * mode 1 = gatConv restricted to the adjacency's nonzeros: softmax_j(+leakyrelu) with the row maximum
+ * subtracted (gatconv.py:34-36,53-54).  out_i = act(sum_j w_ij*scale_ij*h_j / sum_j w_ij), act = ELU when
+ * apply_elu (gatconv.py:143-145); `edge_scale` (fp32 [nnz, heads] or NULL) carries attention-dropout
+ * multipliers, applied after the row sum exactly as gatconv.py:129-135 orders them.  rowsum (and rowmax in
+ * mode 1) are fp32 [n_rows, heads] outputs kept for the backward pass.  `fo` must make fo*sizeof(dtype)/16 a
+ * power of two (the host pads each head with zero columns).                                                */
+int dgll_hip_gat_fwd(void* stream, const int64_t* rowptr, const int32_t* col,
+                     const void* H, int64_t ldh, const float* S, const float* T, const float* edge_scale,
+                     void* out, int64_t ldo, int dtype, float* rowsum, float* rowmax,
+                     int64_t n_rows, int heads, int fo, float alpha, int apply_elu, int mode);
+
+/* Backward of dgll_hip_gat_fwd: two gather passes (rows of A, then rows of A^T given by t_rowptr/t_col with
+ * t_perm[k] = A's edge slot of A^T's k-th edge), nothing stored per edge.  Scratch: dn_scratch
+ * [n_rows, ldn] in `dtype`, dd_scratch fp32 [n_rows, heads].  Outputs: grad_H [n_cols, ldgh] in `dtype`,
+ * grad_S fp32 [n_rows, heads], grad_T fp32 [n_cols, heads].                                                 */
+int dgll_hip_gat_bwd(void* stream, const int64_t* rowptr, const int32_t* col,
+                     const int64_t* t_rowptr, const int32_t* t_col, const int64_t* t_perm,
+                     const void* H, int64_t ldh, const float* S, const float* T, const float* edge_scale,
+                     const void* out, int64_t ldo, const void* grad_out, int64_t ldg, int dtype,
+                     const float* rowsum, const float* rowmax,
+                     void* dn_scratch, int64_t ldn, float* dd_scratch,
+                     void* grad_H, int64_t ldgh, float* grad_S, float* grad_T,
+                     int64_t n_rows, int64_t n_cols, int heads, int fo, float alpha, int apply_elu, int mode);
+
+/* ---- a3 (max): Y[i,f] = max_k X[col[k], f], arg[i,f] = the source row holding it (-1 / 0.0 for empty rows) --
+ * NeighborAggregator's "max" (sageconv.py:37-38).  Y and arg share the leading dimension ldy; X/Y 16-byte
+ * aligned with padded leading dimensions.                                                                   */
+int dgll_hip_segment_max(void* stream, const int64_t* rowptr, const int32_t* col, const void* X, int64_t ldx,
+                         void* Y, int32_t* arg, int64_t ldy, int dtype, int64_t n_rows, int feat);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DGLL_HIP_H */

@@ -1,0 +1,93 @@
+"""Restatement of the reference layers' op sequences with torch on CPU tensors (TEST INFRASTRUCTURE ONLY).
+
+The reference's backend is torch itself (/root/reference/dgll/__init__.py:1), so the faithful CPU restatement of
+its arithmetic issues the same ATen ops; autograd of these restatements gives the reference gradients at sizes the
+fixtures do not cover.  Each function cites the lines it follows; each is pinned against tests/golden/*.npz in
+tests/test_oracle_golden.py.  Works on CSR arrays (rowptr, col) so no dense N x N is needed.
+"""
+import torch
+
+
+def _rows(rowptr):
+    deg = rowptr[1:] - rowptr[:-1]
+    return torch.repeat_interleave(torch.arange(rowptr.numel() - 1), deg)
+
+
+def spmm_coo(row, col, val, x, n_rows):
+    """The reference's exact call: torch.spmm(sparse_coo, dense) -- gcnconv.py:31."""
+    adj = torch.sparse_coo_tensor(torch.stack([row, col]), val, (n_rows, x.shape[0]))
+    return torch.spmm(adj, x)
+
+
+def gcn_conv(rowptr, col, val, x, weight, bias=None):
+    """gcnconv.py:29-35: support = x.W; output = spmm(adj, support) (+ bias)."""
+    out = spmm_coo(_rows(rowptr), col.long(), val, torch.mm(x, weight), rowptr.numel() - 1)
+    return out if bias is None else out + bias
+
+
+def gcn_model(rowptr, col, val, x, w1, b1, w2, b2):
+    """gcnconv.py:53-58 in eval mode (dropout inactive)."""
+    h = torch.relu(gcn_conv(rowptr, col, val, x, w1, b1))
+    return torch.log_softmax(gcn_conv(rowptr, col, val, h, w2, b2), dim=1)
+
+
+def sage_conv(src, nbr, weight, nbr_weight, aggr="mean", hid="sum", act=True):
+    """sageconv.py:32-45,70-83 with the documented fix (reduction result assigned)."""
+    red = nbr.mean(1) if aggr == "mean" else nbr.sum(1) if aggr == "sum" else nbr.max(1)[0]
+    nh = red @ nbr_weight
+    sh = src @ weight
+    out = sh + nh if hid == "sum" else torch.cat([sh, nh], 1)
+    return torch.relu(out) if act else out
+
+
+def spgat_conv(rowptr, col, x, W, a, alpha, concat=True, heads=1):
+    """sparseGatConv.forward, gatconv.py:111-148 (dropout inactive); multi-head when W is [heads, Fin, Fo] and a is
+    [heads, 1, 2*Fo] (the torch.cat over heads of SpGAT.forward, gatconv.py:196)."""
+    if W.dim() == 2:
+        W, a = W[None], a[None]
+    row, colv = _rows(rowptr), col.long()
+    n = rowptr.numel() - 1
+    outs = []
+    for k in range(W.shape[0]):
+        fo = W.shape[2]
+        h = x @ W[k]
+        z = (h @ a[k, 0, :fo])[row] + (h @ a[k, 0, fo:])[colv]
+        e = torch.exp(-torch.nn.functional.leaky_relu(z, alpha))
+        den = torch.zeros(n, dtype=h.dtype).index_add_(0, row, e)
+        num = torch.zeros(n, fo, dtype=h.dtype).index_add_(0, row, e[:, None] * h[colv])
+        hp = num / den[:, None]
+        outs.append(torch.nn.functional.elu(hp) if concat else hp)
+    return torch.cat(outs, 1)
+
+
+def gat_conv(rowptr, col, x, W, a, alpha, concat=True):
+    """gatConv.forward restricted to the adjacency's nonzeros, gatconv.py:30-54: softmax_j(+leakyrelu) with the
+    row maximum subtracted; valid when every row has an edge.  W [heads, Fin, Fo] / a [heads, 2*Fo, 1] for heads."""
+    if W.dim() == 2:
+        W, a = W[None], a[None]
+    row, colv = _rows(rowptr), col.long()
+    n = rowptr.numel() - 1
+    outs = []
+    for k in range(W.shape[0]):
+        fo = W.shape[2]
+        h = x @ W[k]
+        z = torch.nn.functional.leaky_relu((h @ a[k, :fo, 0])[row] + (h @ a[k, fo:, 0])[colv], alpha)
+        mx = torch.full((n,), -float("inf"), dtype=h.dtype).scatter_reduce(0, row, z, "amax")
+        e = torch.exp(z - mx[row])
+        den = torch.zeros(n, dtype=h.dtype).index_add_(0, row, e)
+        hp = torch.zeros(n, fo, dtype=h.dtype).index_add_(0, row, (e / den[row])[:, None] * h[colv])
+        outs.append(torch.nn.functional.elu(hp) if concat else hp)
+    return torch.cat(outs, 1)
+
+
+def multihead_model(kind, rowptr, col, x, W, a, W_out, a_out, alpha):
+    """GAT / SpGAT forward in eval mode, gatconv.py:166-171 / :194-199."""
+    conv = spgat_conv if kind == "spgat" else gat_conv
+    h = conv(rowptr, col, x, W, a, alpha, True)
+    o = torch.nn.functional.elu(conv(rowptr, col, h, W_out, a_out, alpha, False))
+    return torch.log_softmax(o, dim=1)
+
+
+def special_spmm(rowptr, col, values, b):
+    """SpecialSpmmFunction.forward, gatconv.py:66-69 (autograd gives the :72-81 gradients)."""
+    return spmm_coo(_rows(rowptr), col.long(), values, b, rowptr.numel() - 1)

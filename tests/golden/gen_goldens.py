@@ -1,0 +1,426 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by IMPORTING the reference.
+
+Runs only where /root/reference exists (the build container); the GPU box only sees the .npz files
+this script wrote.  Recipe:
+
+  1. ``import dgll`` from /root/reference, then replace ``dgll.backend`` (which is literally ``torch``,
+     dgll/__init__.py:1) by a module that forwards to torch and adds the six names the layers use but
+     torch lacks: Parameter, init, LeakyReLU, Dropout, elu, dropout.
+  2. Load dgll/nn/Convolution/{gcnconv,sageconv,gatconv}.py, dgll/nn/utils/utils.py,
+     dgll/data/dgraph.py, dgll/sampling/*.py and Evaluation/PPI/gcn_model.py BY FILE PATH (the package
+     __init__ files are broken, Convolution/__init__.py:1-5).
+  3. sageconv.py:33-38 discards its reduction result; the documented one-line fix ("assign the
+     result") is applied in memory by replacing NeighborAggregator.forward, and sageConv.weight (left
+     uninitialised, sageconv.py:63,67-68) is initialised by calling reset_parameters().
+  4. Run each layer on small seeded inputs and store inputs, parameters, outputs and gradients.
+
+Only data is written: no reference source text is stored in the fixtures.
+
+Usage:  python tests/golden/gen_goldens.py            (writes next to this file)
+"""
+import contextlib
+import importlib.util
+import io
+import json
+import os
+import random
+import sys
+import types
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+SAGE_FIX = ("NeighborAggregator.forward: assign the reduction result "
+            "(mean(dim=1) / sum(dim=1) / max(dim=1)[0]) before F.matmul; "
+            "sageConv.reset_parameters() called after construction")
+
+
+# ---------------------------------------------------------------------------------- reference import
+def load_reference():
+    assert os.path.isdir(REF), "reference not mounted; goldens can only be regenerated in the build container"
+    sys.path.insert(0, REF)
+    for k in [k for k in sys.modules if k == "dgll" or k.startswith("dgll.")]:
+        del sys.modules[k]
+    import dgll  # the reference package: `import torch as backend`
+
+    assert dgll.__file__.startswith(REF), dgll.__file__
+
+    shim = types.ModuleType("dgll.backend")
+    shim.__getattr__ = lambda name: getattr(torch, name)
+    shim.Parameter = torch.nn.Parameter
+    shim.init = torch.nn.init
+    shim.LeakyReLU = torch.nn.LeakyReLU
+    shim.Dropout = torch.nn.Dropout
+    shim.elu = torch.nn.functional.elu
+    shim.dropout = torch.nn.functional.dropout
+    dgll.backend = shim
+    sys.modules["dgll.backend"] = shim
+
+    def by_path(name, rel, package=None):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(REF, rel))
+        mod = importlib.util.module_from_spec(spec)
+        if package:
+            mod.__package__ = package
+        sys.modules[name] = mod
+        spec.loader.exec_module(mod)
+        return mod
+
+    ref = types.SimpleNamespace()
+    ref.gcnconv = by_path("ref_gcnconv", "dgll/nn/Convolution/gcnconv.py")
+    ref.sageconv = by_path("ref_sageconv", "dgll/nn/Convolution/sageconv.py")
+    ref.gatconv = by_path("ref_gatconv", "dgll/nn/Convolution/gatconv.py")
+    ref.utils = by_path("ref_nn_utils", "dgll/nn/utils/utils.py")
+    ref.ppi_model = by_path("ref_ppi_gcn_model", "Evaluation/PPI/gcn_model.py")
+    # dgll.data / dgll.sampling use relative imports of the backend: give them a package home.
+    pkg_data = types.ModuleType("dgll.data")
+    pkg_data.__path__ = [os.path.join(REF, "dgll/data")]
+    sys.modules["dgll.data"] = pkg_data
+    ref.dgraph = by_path("dgll.data.dgraph", "dgll/data/dgraph.py", package="dgll.data")
+    pkg_s = types.ModuleType("dgll.sampling")
+    pkg_s.__path__ = [os.path.join(REF, "dgll/sampling")]
+    sys.modules["dgll.sampling"] = pkg_s
+    ref.base_sampler = by_path("dgll.sampling.base_sampler", "dgll/sampling/base_sampler.py", package="dgll.sampling")
+    ref.dgllsampler = by_path("dgll.sampling.dgllsampler", "dgll/sampling/dgllsampler.py", package="dgll.sampling")
+
+    # --- the documented SAGE fix (in memory only) ---
+    F = shim
+
+    def fixed_forward(self, neighbor_feature):
+        if self.aggr_method == "mean":
+            neighbor_feature = neighbor_feature.mean(dim=1)
+        elif self.aggr_method == "sum":
+            neighbor_feature = neighbor_feature.sum(dim=1)
+        elif self.aggr_method == "max":
+            neighbor_feature = neighbor_feature.max(dim=1)[0]
+        else:
+            raise ValueError("Unsupported aggr_method, expected mean, sum, max, but got {}".format(self.aggr_method))
+        neighbor_hidden = F.matmul(neighbor_feature, self.weight)
+        if self.use_bias:
+            neighbor_hidden += self.bias
+        return neighbor_hidden
+
+    ref.sageconv.NeighborAggregator.forward = fixed_forward
+    return ref
+
+
+# ---------------------------------------------------------------------------------- inputs
+def rmat_edges(scale, edge_factor, seed, a=0.57, b=0.19, c=0.19):
+    """Bit-per-level RMAT, numpy default_rng(seed); directed, with duplicates."""
+    rng = np.random.default_rng(seed)
+    n_edges = edge_factor << scale
+    src = np.zeros(n_edges, dtype=np.int64)
+    dst = np.zeros(n_edges, dtype=np.int64)
+    for _ in range(scale):
+        r = rng.random(n_edges)
+        src = (src << 1) | (r >= a + b)
+        dst = (dst << 1) | (((r >= a) & (r < a + b)) | (r >= a + b + c))
+    return src, dst
+
+
+def ref_normalised_adj(ref, src, dst, n, self_loops=True):
+    """adjacency prep exactly as nn/utils/utils.py:163-171,240-257 does it (a11)."""
+    adj = sp.coo_matrix((np.ones(src.shape[0]), (src, dst)), shape=(n, n), dtype=np.float32)
+    adj.sum_duplicates()
+    adj.data[:] = 1.0
+    adj = adj + adj.T.multiply(adj.T > adj) - adj.multiply(adj.T > adj)  # utils.py:164
+    if self_loops:
+        adj = adj + sp.eye(adj.shape[0])
+    adj = ref.utils.normalize(adj)  # utils.py:171 / :240-247
+    return ref.utils.sparse_mx_to_torch_sparse_tensor(adj)  # utils.py:250-257
+
+
+def save(name, meta, **arrays):
+    meta = dict(meta)
+    meta.update(torch=torch.__version__, numpy=np.__version__, python=sys.version.split()[0])
+    out = {}
+    for k, v in arrays.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    out["meta"] = np.array(json.dumps(meta))
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote %-34s %8.1f KB" % (name + ".npz", os.path.getsize(path) / 1024))
+
+
+def grads_of(out, gout, tensors):
+    loss = (out * gout).sum()
+    gs = torch.autograd.grad(loss, tensors, allow_unused=True)
+    return [torch.zeros_like(t) if g is None else g for g, t in zip(gs, tensors)]
+
+
+# ---------------------------------------------------------------------------------- cases
+def gen_gcn(ref):
+    cases = [
+        # name, scale, ef, F, H, bias, self_loops/normalised
+        ("gcn_conv_s8_f7_h16", 8, 8, 7, 16, True, True),
+        ("gcn_conv_s10_f64_h47", 10, 16, 64, 47, True, True),
+        ("gcn_conv_s9_f33_h16_raw", 9, 4, 33, 16, False, False),
+        ("gcn_conv_s9_f128_h256", 9, 16, 128, 256, True, True),
+    ]
+    for name, scale, ef, Fi, H, bias, norm in cases:
+        torch.manual_seed(1)
+        n = 1 << scale
+        src, dst = rmat_edges(scale, ef, seed=scale)
+        if norm:
+            adj = ref_normalised_adj(ref, src, dst, n)
+        else:
+            # raw power-law adjacency, random weights, rows with no entries stay empty (no self-loops)
+            m = sp.coo_matrix((np.ones(src.shape[0], np.float32), (src, dst)), shape=(n, n))
+            m.sum_duplicates()
+            m = m.tocsr().tocoo()
+            rng = np.random.default_rng(7)
+            vals = rng.standard_normal(m.nnz).astype(np.float32)
+            adj = torch.sparse_coo_tensor(np.vstack((m.row, m.col)).astype(np.int64), vals, (n, n))
+        layer = ref.gcnconv.gcnConv(Fi, H, bias=bias)
+        x = torch.randn(n, Fi, requires_grad=True)
+        y = layer(x, adj)
+        gout = torch.randn_like(y)
+        params = [x, layer.weight] + ([layer.bias] if bias else [])
+        gs = grads_of(y, gout, params)
+        ind = adj._indices()
+        arrays = dict(adj_row=ind[0], adj_col=ind[1], adj_val=adj._values(), x=x, weight=layer.weight,
+                      y=y, gout=gout, grad_x=gs[0], grad_weight=gs[1])
+        if bias:
+            arrays.update(bias=layer.bias, grad_bias=gs[2])
+        deg = np.bincount(ind[0].numpy(), minlength=n)
+        save(name, dict(row="a1", ref="dgll/nn/Convolution/gcnconv.py:29-35", n=n, F=Fi, H=H, nnz=int(ind.shape[1]),
+                        zero_degree_rows=int((deg == 0).sum()), max_degree=int(deg.max()), normalised=norm,
+                        adj_prep="nn/utils/utils.py:164,171,240-257" if norm else "raw"), **arrays)
+
+    # a2: the 2-layer GCN model, eval mode (dropout inactive) and its log_softmax output
+    torch.manual_seed(2)
+    scale, n, Fi, nhid, ncls = 9, 512, 50, 64, 7
+    src, dst = rmat_edges(scale, 8, seed=21)
+    adj = ref_normalised_adj(ref, src, dst, n)
+    model = ref.gcnconv.GCN(Fi, nhid, ncls, dropout=0.5).eval()
+    x = torch.randn(n, Fi, requires_grad=True)
+    y = model(x, adj)
+    gout = torch.randn_like(y)
+    ps = [x, model.gcn1.weight, model.gcn1.bias, model.gcn2.weight, model.gcn2.bias]
+    gs = grads_of(y, gout, ps)
+    ind = adj._indices()
+    save("gcn_model_s9", dict(row="a2", ref="dgll/nn/Convolution/gcnconv.py:43-58", n=n, F=Fi, nhid=nhid, nclass=ncls,
+                              mode="eval"),
+         adj_row=ind[0], adj_col=ind[1], adj_val=adj._values(), x=x, y=y, gout=gout,
+         w1=ps[1], b1=ps[2], w2=ps[3], b2=ps[4], grad_x=gs[0], grad_w1=gs[1], grad_b1=gs[2], grad_w2=gs[3],
+         grad_b2=gs[4])
+
+
+def gen_sage(ref):
+    cases = [
+        ("sage_conv_mean_sum", 50, 10, 7, 16, "mean", "sum"),
+        ("sage_conv_mean_concat", 33, 25, 64, 47, "mean", "concat"),
+        ("sage_conv_sum_k1", 20, 1, 5, 8, "sum", "sum"),
+        ("sage_conv_max_sum", 40, 10, 16, 16, "max", "sum"),
+        ("sage_conv_mean_f100_h256", 64, 10, 100, 256, "mean", "sum"),
+    ]
+    for name, N, K, D, H, aggr, hid in cases:
+        torch.manual_seed(3)
+        layer = ref.sageconv.sageConv(D, H, aggr_neighbor_method=aggr, aggr_hid_method=hid)
+        layer.reset_parameters()
+        src = torch.randn(N, D, requires_grad=True)
+        nbr = torch.randn(N, K, D, requires_grad=True)
+        y = layer(src, nbr)
+        gout = torch.randn_like(y)
+        ps = [src, nbr, layer.weight, layer.neighborAgg.weight]
+        gs = grads_of(y, gout, ps)
+        save(name, dict(row="a3+a4", ref="dgll/nn/Convolution/sageconv.py:32-45,70-83", N=N, K=K, D=D, H=H,
+                        aggr=aggr, hid=hid, fix=SAGE_FIX),
+             src=src, nbr=nbr, weight=layer.weight, nbr_weight=layer.neighborAgg.weight, y=y, gout=gout,
+             grad_src=gs[0], grad_nbr=gs[1], grad_weight=gs[2], grad_nbr_weight=gs[3])
+
+    # a5: the 2-layer GraphSage hop pyramid (equal fan-outs are the only shapes the reference accepts)
+    torch.manual_seed(4)
+    D, hidden, K, n0 = 12, [16, 8], [3, 3], 10
+    model = ref.sageconv.GraphSage(D, hidden, K)
+    model.gcn1.reset_parameters()
+    model.gcn2.reset_parameters()
+    feats = [torch.randn(n0, D), torch.randn(n0 * 3, D), torch.randn(n0 * 9, D)]
+    y = model(feats)
+    save("sage_model_k3", dict(row="a5", ref="dgll/nn/Convolution/sageconv.py:86-114", D=D, hidden=hidden,
+                               num_neighbors=K, fix=SAGE_FIX),
+         h0=feats[0], h1=feats[1], h2=feats[2], y=y,
+         w1=model.gcn1.weight, wn1=model.gcn1.neighborAgg.weight,
+         w2=model.gcn2.weight, wn2=model.gcn2.neighborAgg.weight)
+
+
+def dense_adj(n, density, seed, self_loops=True):
+    rng = np.random.default_rng(seed)
+    a = (rng.random((n, n)) < density).astype(np.float32)
+    if self_loops:
+        np.fill_diagonal(a, 1.0)
+    return torch.from_numpy(a)
+
+
+def gen_gat(ref):
+    # a6: sparseGatConv
+    for name, n, Fi, Fo, concat, dens in [
+        ("spgat_conv_n200_f19_o32", 200, 19, 32, True, 0.05),
+        ("spgat_conv_n150_f64_o8_noconcat", 150, 64, 8, False, 0.1),
+        ("spgat_conv_n97_f5_o3", 97, 5, 3, True, 0.3),
+    ]:
+        torch.manual_seed(5)
+        adj = dense_adj(n, dens, seed=n)
+        layer = ref.gatconv.sparseGatConv(Fi, Fo, dropout=0.0, alpha=0.2, concat=concat)
+        x = torch.randn(n, Fi, requires_grad=True)
+        y = layer(x, adj)
+        gout = torch.randn_like(y)
+        gs = grads_of(y, gout, [x, layer.W, layer.a])
+        save(name, dict(row="a6", ref="dgll/nn/Convolution/gatconv.py:89-151", n=n, Fin=Fi, Fout=Fo, alpha=0.2,
+                        concat=concat, dropout=0.0),
+             adj=adj.to(torch.uint8), x=x, W=layer.W, a=layer.a, y=y, gout=gout,
+             grad_x=gs[0], grad_W=gs[1], grad_a=gs[2])
+
+    # a7: SpecialSpmmFunction forward/backward
+    torch.manual_seed(6)
+    n, Fo = 120, 24
+    adj = dense_adj(n, 0.08, seed=77)
+    edge = adj.nonzero().t()
+    values = torch.rand(edge.shape[1], requires_grad=True)
+    b = torch.randn(n, Fo, requires_grad=True)
+    y = ref.gatconv.SpecialSpmm()(edge, values, torch.Size([n, n]), b)
+    gout = torch.randn_like(y)
+    gs = grads_of(y, gout, [values, b])
+    save("special_spmm_n120", dict(row="a7", ref="dgll/nn/Convolution/gatconv.py:60-86", n=n, Fout=Fo),
+         edge=edge, values=values, b=b, y=y, gout=gout, grad_values=gs[0], grad_b=gs[1])
+
+    # a8: dense gatConv
+    for name, n, Fi, Fo, concat in [("gat_conv_n200_f19_o32", 200, 19, 32, True),
+                                    ("gat_conv_n64_f8_o7_noconcat", 64, 8, 7, False)]:
+        torch.manual_seed(7)
+        adj = dense_adj(n, 0.05, seed=n + 1)
+        layer = ref.gatconv.gatConv(Fi, Fo, dropout=0.0, alpha=0.2, concat=concat)
+        x = torch.randn(n, Fi, requires_grad=True)
+        y = layer(x, adj)
+        gout = torch.randn_like(y)
+        gs = grads_of(y, gout, [x, layer.W, layer.a])
+        save(name, dict(row="a8", ref="dgll/nn/Convolution/gatconv.py:10-57", n=n, Fin=Fi, Fout=Fo, alpha=0.2,
+                        concat=concat, dropout=0.0),
+             adj=adj.to(torch.uint8), x=x, W=layer.W, a=layer.a, y=y, gout=gout,
+             grad_x=gs[0], grad_W=gs[1], grad_a=gs[2])
+
+    # a9: 8-head models in eval mode
+    for kind, cls in [("spgat", ref.gatconv.SpGAT), ("gat", ref.gatconv.GAT)]:
+        torch.manual_seed(8)
+        n, nfeat, nhid, ncls, heads = 160, 19, 8, 7, 8
+        adj = dense_adj(n, 0.06, seed=99)
+        model = cls(nfeat, nhid, ncls, dropout=0.6, alpha=0.2, nheads=heads).eval()
+        x = torch.randn(n, nfeat, requires_grad=True)
+        y = model(x, adj)
+        gout = torch.randn_like(y)
+        ps = [x] + [p for att in model.attentions for p in (att.W, att.a)] + [model.out_att.W, model.out_att.a]
+        gs = grads_of(y, gout, ps)
+        arrays = dict(adj=adj.to(torch.uint8), x=x, y=y, gout=gout, grad_x=gs[0],
+                      W=torch.stack([att.W for att in model.attentions]),
+                      a=torch.stack([att.a for att in model.attentions]),
+                      grad_W=torch.stack(gs[1:1 + 2 * heads:2]), grad_a=torch.stack(gs[2:2 + 2 * heads:2]),
+                      W_out=model.out_att.W, a_out=model.out_att.a, grad_W_out=gs[-2], grad_a_out=gs[-1])
+        save(kind + "_model_h8", dict(row="a9", ref="dgll/nn/Convolution/gatconv.py:154-199", n=n, nfeat=nfeat,
+                                      nhid=nhid, nclass=ncls, nheads=heads, alpha=0.2, mode="eval"), **arrays)
+
+
+def gen_ppi(ref):
+    """Config 1 plumbing: Evaluation/PPI/gcn_model.py GCN on a PPI-shaped graph (duplicated directed edges,
+    all-ones uncoalesced COO rebuilt per layer, gcn_model.py:56,73)."""
+    torch.manual_seed(9)
+    n, Fi, Hd, ncls = 300, 50, 64, 121
+    src, dst = rmat_edges(8, 12, seed=5)
+    src, dst = src % n, dst % n
+    keep = src != dst
+    edge_index = torch.from_numpy(np.vstack((src[keep], dst[keep])))
+    model = ref.ppi_model.GCN(Fi, Hd, ncls, num_layers=3)
+    with torch.no_grad():  # the reference's randn init gives activations ~1e4; scale to keep fp32 comparisons meaningful
+        for layer in model.layers:
+            layer.weight.mul_(0.1)
+    x = torch.randn(n, Fi, requires_grad=True)
+    y = model(edge_index, x)
+    gout = torch.randn_like(y)
+    ps = [x] + [l.weight for l in model.layers] + [model.out_layer.weight, model.out_layer.bias]
+    gs = grads_of(y, gout, ps)
+    save("ppi_gcn_3layer", dict(row="a1 (config 1)", ref="Evaluation/PPI/gcn_model.py:63-94", n=n, F=Fi, hidden=Hd,
+                                nclass=ncls, duplicate_edges=True),
+         edge_index=edge_index, x=x, y=y, gout=gout, w0=ps[1], w1=ps[2], w2=ps[3], w_out=ps[4], b_out=ps[5],
+         grad_x=gs[0], grad_w0=gs[1], grad_w1=gs[2], grad_w2=gs[3], grad_w_out=gs[4], grad_b_out=gs[5])
+
+
+def gen_sampler(ref):
+    """Neighbour sampler IDs under random.seed(s): dgll/sampling/base_sampler.py:30-58, dgllsampler.py:10-21."""
+    rng = np.random.default_rng(11)
+    n = 400
+    edges = []
+    for v in range(n):
+        deg = int(min(n - 1, rng.zipf(1.6))) if v % 17 else 0  # power-law degrees, some isolated nodes
+        edges.append(sorted(rng.choice(n, size=deg, replace=False).tolist()))
+    g = ref.dgraph.DGraph(nodes=torch.arange(n), edges=edges, labels=torch.arange(n) % 7,
+                          features=torch.arange(n * 3, dtype=torch.float32).view(n, 3))
+    flat = np.concatenate([np.asarray(e, dtype=np.int64) for e in edges] + [np.zeros(0, np.int64)])
+    ptr = np.cumsum([0] + [len(e) for e in edges])
+    arrays = dict(adj_ptr=ptr, adj_idx=flat)
+    metas = []
+    for ci, (seed, fanouts, seeds) in enumerate([
+        (0, [3, 2], [0, 1, 2, 5, 17, 34, 399]),
+        (1, [10, 25], list(range(100, 164))),
+        (2, [25, 10, 10], [7, 8, 9, 10, 11]),
+        (3, [1], [3, 3, 3]),
+        (4, [], [1, 2, 3]),
+    ]):
+        sampler = ref.dgllsampler.DGLLNeighborSampler(fanouts)
+        random.seed(seed)
+        with contextlib.redirect_stdout(io.StringIO()):  # dgllsampler.py:13 has a stray print
+            if fanouts:
+                inp, outp, subgs = sampler.sample(g, torch.tensor(seeds))
+            else:
+                # empty fan-out list: the loop body never runs and `input_nodes` is unbound (dgllsampler.py:21)
+                try:
+                    sampler.sample(g, torch.tensor(seeds))
+                    raised = False
+                except UnboundLocalError:
+                    raised = True
+                metas.append(dict(seed=seed, fanouts=fanouts, seeds=seeds, raises_unbound_local=raised))
+                continue
+        arrays["c%d_input_nodes" % ci] = inp
+        arrays["c%d_output_nodes" % ci] = outp
+        for li, sg in enumerate(subgs):
+            arrays["c%d_l%d_src" % (ci, li)] = sg.src_nodes()
+            arrays["c%d_l%d_dst" % (ci, li)] = sg.dst_nodes()
+            arrays["c%d_l%d_nodes" % (ci, li)] = sg.nodes()
+        metas.append(dict(seed=seed, fanouts=fanouts, seeds=seeds, n_layers=len(subgs)))
+    # DGraph queries (example.py:22-41)
+    q = torch.tensor([0, 2, 5, 6, 9, 23])
+    arrays["q_nodes"] = q
+    arrays["q_induced"] = g.get_induced_subgraph(q)
+    arrays["q_features"] = g.get_features(q)
+    arrays["q_labels"] = g.get_labels(q)
+    save("sampler_n400", dict(row="f1", ref="dgll/sampling/base_sampler.py:30-58; dgllsampler.py:10-21; "
+                                            "data/dgraph.py:49-105", n=n, cases=metas), **arrays)
+
+
+def gen_adj_prep(ref):
+    """a11: D^-1 (A + I) and the COO hand-over, nn/utils/utils.py:164,171,240-257."""
+    src, dst = rmat_edges(7, 6, seed=3)
+    n = 128
+    adj = ref_normalised_adj(ref, src, dst, n)
+    ind = adj._indices()
+    save("adj_prep_s7", dict(row="a11", ref="dgll/nn/utils/utils.py:164,171,240-257", n=n,
+                             is_coalesced=bool(adj.is_coalesced())),
+         src=src, dst=dst, adj_row=ind[0], adj_col=ind[1], adj_val=adj._values())
+
+
+def main():
+    ref = load_reference()
+    gen_gcn(ref)
+    gen_sage(ref)
+    gen_gat(ref)
+    gen_ppi(ref)
+    gen_sampler(ref)
+    gen_adj_prep(ref)
+
+
+if __name__ == "__main__":
+    main()

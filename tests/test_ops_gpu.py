@@ -1,0 +1,272 @@
+"""HIP kernels (through the C ABI) vs the CPU oracle on seeded random graphs.  GPU box only (-m gpu)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cref
+
+pytestmark = pytest.mark.gpu
+
+
+def np_graph(n, avg_deg, seed, heavy_rows=(), empty_rows=(), weighted=True, n_cols=None):
+    """Random CSR with optional very long rows (> the 512-edge chunk threshold) and forced-empty rows."""
+    rng = np.random.default_rng(seed)
+    n_cols = n if n_cols is None else n_cols
+    deg = rng.poisson(avg_deg, n)
+    for r, d in heavy_rows:
+        deg[r] = d
+    for r in empty_rows:
+        deg[r] = 0
+    deg = np.minimum(deg, n_cols)
+    rowptr = np.zeros(n + 1, np.int64)
+    np.cumsum(deg, out=rowptr[1:])
+    col = np.concatenate([np.sort(rng.choice(n_cols, d, replace=False)) for d in deg] + [np.zeros(0, np.int64)]).astype(np.int32)
+    val = rng.standard_normal(col.shape[0]).astype(np.float32) if weighted else None
+    return rowptr, col, val
+
+
+def to_dev(rowptr, col, val, n_cols, device):
+    import dgll_amd
+
+    return dgll_amd.CSRGraph(torch.from_numpy(rowptr).to(device), torch.from_numpy(col).to(device),
+                             None if val is None else torch.from_numpy(val).to(device), len(rowptr) - 1, n_cols)
+
+
+def bf16_round(x):
+    return torch.from_numpy(x).to(torch.bfloat16).to(torch.float32).numpy()
+
+
+@pytest.mark.parametrize("feat", [1, 7, 16, 47, 64, 100, 128, 256, 300, 602])
+@pytest.mark.parametrize("weighted", [True, False])
+def test_spmm_f32_vs_oracle(cuda_device, feat, weighted):
+    from dgll_amd import ops
+
+    n = 700
+    rowptr, col, val = np_graph(n, 9, seed=feat, heavy_rows=[(3, 650), (500, 699)], empty_rows=[0, 17, n - 1], weighted=weighted)
+    x = np.random.default_rng(1).standard_normal((n, feat)).astype(np.float32)
+    g = to_dev(rowptr, col, val, n, cuda_device)
+    assert g.num_long_rows() == 2
+    y = ops.spmm(g, torch.from_numpy(x).to(cuda_device))
+    np.testing.assert_allclose(y.cpu().numpy(), cref.spmm_csr(rowptr, col, val, x), rtol=1e-4, atol=1e-4)
+    ym = ops.spmm(g, torch.from_numpy(x).to(cuda_device), reduce="mean")
+    np.testing.assert_allclose(ym.cpu().numpy(), cref.spmm_csr(rowptr, col, val, x, reduce="mean"), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("feat", [8, 47, 100, 128, 256, 520])
+def test_spmm_bf16_vs_oracle(cuda_device, feat):
+    """bf16 storage, fp32 accumulation: compare with the fp32 oracle fed the same bf16-rounded inputs; the only
+    extra error is the final round-to-bf16 of the output (rel 2^-8)."""
+    from dgll_amd import ops
+
+    n = 600
+    rowptr, col, val = np_graph(n, 12, seed=feat + 1, heavy_rows=[(9, 590)], empty_rows=[5])
+    x = bf16_round(np.random.default_rng(2).standard_normal((n, feat)).astype(np.float32))
+    g = to_dev(rowptr, col, val, n, cuda_device)
+    xd = torch.from_numpy(x).to(cuda_device).to(torch.bfloat16)
+    ref = cref.spmm_csr(rowptr, col, val, x)
+    y = ops.spmm(g, xd)
+    assert y.dtype == torch.bfloat16
+    np.testing.assert_allclose(y.float().cpu().numpy(), ref, rtol=8e-3, atol=8e-3)
+    y32 = ops.spmm_raw(g, xd, out_dtype=torch.float32)      # bf16 gather, fp32 output: no output rounding
+    np.testing.assert_allclose(y32.cpu().numpy(), ref, rtol=1e-4, atol=1e-4)
+
+
+def test_spmm_epilogue_and_backward(cuda_device):
+    from dgll_amd import ops
+
+    n, feat = 300, 40
+    rowptr, col, val = np_graph(n, 6, seed=3, heavy_rows=[(1, 290)], empty_rows=[2])
+    g = to_dev(rowptr, col, val, n, cuda_device)
+    rng = np.random.default_rng(4)
+    x = torch.from_numpy(rng.standard_normal((n, feat)).astype(np.float32)).to(cuda_device).requires_grad_()
+    bias = torch.from_numpy(rng.standard_normal(feat).astype(np.float32)).to(cuda_device).requires_grad_()
+    gout = torch.from_numpy(rng.standard_normal((n, feat)).astype(np.float32)).to(cuda_device)
+    y = ops.spmm(g, x, bias=bias, relu=True)
+    ref_pre = cref.spmm_csr(rowptr, col, val, x.detach().cpu().numpy()) + bias.detach().cpu().numpy()
+    np.testing.assert_allclose(y.detach().cpu().numpy(), np.maximum(ref_pre, 0), rtol=1e-4, atol=1e-4)
+    (y * gout).sum().backward()
+    gm = gout.cpu().numpy() * (ref_pre > 0)
+    r, c = np.repeat(np.arange(n), np.diff(rowptr)), col
+    t_rowptr, t_col, t_val = cref.coo_to_csr(c, r, val, n)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), cref.spmm_csr(t_rowptr, t_col, t_val, gm), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(bias.grad.cpu().numpy(), gm.sum(0), rtol=1e-4, atol=1e-3)
+
+
+def test_spmm_mean_backward_and_edge_value_grad(cuda_device):
+    from dgll_amd import ops
+
+    n, feat = 200, 24
+    rowptr, col, val = np_graph(n, 5, seed=8, empty_rows=[7])
+    g = to_dev(rowptr, col, None, n, cuda_device)
+    rng = np.random.default_rng(5)
+    xn = rng.standard_normal((n, feat)).astype(np.float32)
+    gn = rng.standard_normal((n, feat)).astype(np.float32)
+    x = torch.from_numpy(xn).to(cuda_device).requires_grad_()
+    v = torch.from_numpy(val).to(cuda_device).requires_grad_()
+    y = ops.spmm(g, x, val=v, reduce="mean")
+    (y * torch.from_numpy(gn).to(cuda_device)).sum().backward()
+    # torch CPU autograd of the same formula as the reference oracle
+    xt = torch.from_numpy(xn).requires_grad_()
+    vt = torch.from_numpy(val).requires_grad_()
+    row = torch.from_numpy(np.repeat(np.arange(n), np.diff(rowptr)))
+    deg = torch.from_numpy(np.diff(rowptr)).clamp(min=1).float()
+    yt = torch.zeros(n, feat).index_add_(0, row, vt[:, None] * xt[torch.from_numpy(col).long()]) / deg[:, None]
+    (yt * torch.from_numpy(gn)).sum().backward()
+    np.testing.assert_allclose(y.detach().cpu().numpy(), yt.detach().numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), xt.grad.numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(v.grad.cpu().numpy(), vt.grad.numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_spmm_unaligned_leading_dimension_takes_generic_path(cuda_device):
+    from dgll_amd import ops
+
+    n, feat = 150, 37
+    rowptr, col, val = np_graph(n, 4, seed=11, heavy_rows=[(0, 140)])
+    g = to_dev(rowptr, col, val, n, cuda_device)
+    x = np.random.default_rng(6).standard_normal((n, feat)).astype(np.float32)
+    big = torch.zeros(n, feat + 1, device=cuda_device)
+    xd = big[:, 1:]                          # data pointer 4 bytes off 16-byte alignment, ld = 38
+    xd.copy_(torch.from_numpy(x))
+    out = torch.empty(n, feat, device=cuda_device)
+    y = ops.spmm_raw(g, xd, out=out)
+    np.testing.assert_allclose(y.cpu().numpy(), cref.spmm_csr(rowptr, col, val, x), rtol=1e-4, atol=1e-4)
+
+
+def test_spmm_is_bit_reproducible_and_handles_empty_graph(cuda_device):
+    import dgll_amd
+    from dgll_amd import ops
+
+    n, feat = 2000, 256
+    rowptr, col, val = np_graph(n, 30, seed=12, heavy_rows=[(5, 1900), (6, 1500)])
+    g = to_dev(rowptr, col, val, n, cuda_device)
+    x = torch.randn(n, feat, device=cuda_device, dtype=torch.bfloat16)
+    a, b = ops.spmm_raw(g, x), ops.spmm_raw(g, x)
+    assert torch.equal(a, b)
+    empty = dgll_amd.CSRGraph(torch.zeros(n + 1, dtype=torch.int64, device=cuda_device),
+                              torch.zeros(0, dtype=torch.int32, device=cuda_device), None, n, n)
+    assert float(ops.spmm_raw(empty, x).float().abs().max()) == 0.0
+
+
+def test_rectangular_block_and_fixed_fanout(cuda_device):
+    """Sampled-block shape: fewer destination rows than source rows; and the [N, K, D] mean of sageconv.py:33-34."""
+    import dgll_amd
+    from dgll_amd import ops
+
+    n_dst, n_src, feat = 64, 500, 100
+    rowptr, col, _ = np_graph(n_dst, 10, seed=13, weighted=False, n_cols=n_src)
+    g = to_dev(rowptr, col, None, n_src, cuda_device)
+    x = np.random.default_rng(7).standard_normal((n_src, feat)).astype(np.float32)
+    y = ops.spmm(g, torch.from_numpy(x).to(cuda_device), reduce="mean")
+    np.testing.assert_allclose(y.cpu().numpy(), cref.spmm_csr(rowptr, col, None, x, reduce="mean"), rtol=1e-4, atol=1e-5)
+    N, K, D = 33, 25, 64
+    nbr = np.random.default_rng(8).standard_normal((N, K, D)).astype(np.float32)
+    fg = dgll_amd.CSRGraph.fixed_fanout(N, K, cuda_device)
+    ym = ops.spmm(fg, torch.from_numpy(nbr).to(cuda_device).view(N * K, D), reduce="mean")
+    np.testing.assert_allclose(ym.cpu().numpy(), nbr.mean(1), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("feat", [24, 100, 256, 700])
+def test_sddmm_vs_oracle(cuda_device, dtype, feat):
+    from dgll_amd import ops
+
+    n = 300
+    rowptr, col, _ = np_graph(n, 8, seed=feat, heavy_rows=[(4, 280)], empty_rows=[0], weighted=False)
+    rng = np.random.default_rng(9)
+    gn = rng.standard_normal((n, feat)).astype(np.float32)
+    bn = rng.standard_normal((n, feat)).astype(np.float32)
+    if dtype == torch.bfloat16:
+        gn, bn = bf16_round(gn), bf16_round(bn)
+    g = to_dev(rowptr, col, None, n, cuda_device)
+    out = ops.sddmm_raw(g, torch.from_numpy(gn).to(cuda_device).to(dtype), torch.from_numpy(bn).to(cuda_device).to(dtype))
+    np.testing.assert_allclose(out.cpu().numpy(), cref.sddmm_csr(rowptr, col, gn, bn), rtol=1e-4, atol=1e-4 * np.sqrt(feat))
+
+
+@pytest.mark.parametrize("heads,fo", [(1, 32), (8, 8), (8, 32), (3, 5), (1, 47), (2, 128)])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_gat_forward_vs_oracle(cuda_device, heads, fo, mode):
+    from dgll_amd import ops
+
+    n = 400
+    rowptr, col, _ = np_graph(n, 7, seed=heads * 100 + fo, heavy_rows=[(2, 390)], weighted=False)
+    # every row needs an edge (gatconv.py:139-141): add self loops
+    dense = np.zeros((n, n), bool)
+    dense[np.repeat(np.arange(n), np.diff(rowptr)), col] = True
+    np.fill_diagonal(dense, True)
+    r, c = np.nonzero(dense)
+    rowptr, col, _ = cref.coo_to_csr(r, c, None, n)
+    rng = np.random.default_rng(10)
+    h = (0.5 * rng.standard_normal((n, heads * fo))).astype(np.float32)
+    s = rng.standard_normal((n, heads)).astype(np.float32)
+    t = rng.standard_normal((n, heads)).astype(np.float32)
+    ref = cref.gat_fwd(rowptr, col, h, s, t, heads, 0.2, apply_elu=True, mode=mode)
+    g = to_dev(rowptr, col, None, n, cuda_device)
+    fo_pad = ops.head_width_padded(fo, torch.float32)
+    hp = np.zeros((n, heads, fo_pad), np.float32)
+    hp[:, :, :fo] = h.reshape(n, heads, fo)
+    out = ops.gat_aggregate(g, torch.from_numpy(hp.reshape(n, -1)).to(cuda_device), torch.from_numpy(s).to(cuda_device),
+                            torch.from_numpy(t).to(cuda_device), heads, 0.2, apply_elu=True, mode=mode)
+    out = out.cpu().numpy().reshape(n, heads, fo_pad)[:, :, :fo].reshape(n, heads * fo)
+    np.testing.assert_allclose(out, ref, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("heads,fo", [(4, 8), (1, 20)])
+def test_gat_backward_vs_torch_autograd(cuda_device, mode, heads, fo):
+    """Gradients of the fused kernel vs CPU autograd of the oracle's restated formula (oracle/torch_ref.py)."""
+    from dgll_amd import ops
+    from oracle import torch_ref
+
+    n, fin = 250, 13
+    rowptr, col, _ = np_graph(n, 6, seed=77 + heads, heavy_rows=[(1, 240)], weighted=False)
+    dense = np.zeros((n, n), bool)
+    dense[np.repeat(np.arange(n), np.diff(rowptr)), col] = True
+    np.fill_diagonal(dense, True)
+    r, c = np.nonzero(dense)
+    rowptr, col, _ = cref.coo_to_csr(r, c, None, n)
+    rng = np.random.default_rng(21)
+    xn = rng.standard_normal((n, fin)).astype(np.float32)
+    Wn = (0.3 * rng.standard_normal((heads, fin, fo))).astype(np.float32)
+    an = (0.3 * rng.standard_normal((heads, 2 * fo))).astype(np.float32)
+    gn = rng.standard_normal((n, heads * fo)).astype(np.float32)
+    # oracle side
+    xt, Wt, at = (torch.from_numpy(v).requires_grad_() for v in (xn, Wn, an))
+    if mode == 0:
+        yt = torch_ref.spgat_conv(torch.from_numpy(rowptr), torch.from_numpy(col), xt, Wt, at[:, None, :], 0.2, True)
+    else:
+        yt = torch_ref.gat_conv(torch.from_numpy(rowptr), torch.from_numpy(col), xt, Wt, at[:, :, None], 0.2, True)
+    (yt * torch.from_numpy(gn)).sum().backward()
+    # device side
+    dev = cuda_device
+    xd, Wd, ad = (torch.from_numpy(v).to(dev).requires_grad_() for v in (xn, Wn, an))
+    g = to_dev(rowptr, col, None, n, dev)
+    h = torch.mm(xd, torch.cat(list(Wd), dim=1))
+    hv = h.view(n, heads, fo)
+    s = (hv * ad[:, :fo]).sum(-1)
+    t = (hv * ad[:, fo:]).sum(-1)
+    fo_pad = ops.head_width_padded(fo, torch.float32)
+    hp = torch.nn.functional.pad(hv, (0, fo_pad - fo)).reshape(n, heads * fo_pad)
+    out = ops.gat_aggregate(g, hp, s, t, heads, 0.2, apply_elu=True, mode=mode)
+    out = out.view(n, heads, fo_pad)[:, :, :fo].reshape(n, heads * fo)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), yt.detach().numpy(), rtol=1e-4, atol=1e-5)
+    (out * torch.from_numpy(gn).to(dev)).sum().backward()
+    np.testing.assert_allclose(xd.grad.cpu().numpy(), xt.grad.numpy(), rtol=2e-3, atol=2e-4)
+    np.testing.assert_allclose(Wd.grad.cpu().numpy(), Wt.grad.numpy(), rtol=2e-3, atol=2e-4)
+    np.testing.assert_allclose(ad.grad.cpu().numpy(), at.grad.numpy(), rtol=2e-3, atol=2e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_segment_max_vs_oracle(cuda_device, dtype):
+    from dgll_amd import ops
+
+    n, feat = 300, 50
+    rowptr, col, _ = np_graph(n, 8, seed=31, heavy_rows=[(3, 280)], empty_rows=[1], weighted=False)
+    x = np.random.default_rng(12).standard_normal((n, feat)).astype(np.float32)
+    if dtype == torch.bfloat16:
+        x = bf16_round(x)
+    g = to_dev(rowptr, col, None, n, cuda_device)
+    xd = torch.from_numpy(x).to(cuda_device).to(dtype).requires_grad_()
+    y = ops.segment_max(g, xd)
+    np.testing.assert_array_equal(y.detach().float().cpu().numpy(), cref.spmm_csr_max(rowptr, col, x))
+    y.float().sum().backward()
+    assert float(xd.grad.float().sum()) == float((np.diff(rowptr) > 0).sum() * feat)
