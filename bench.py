@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""Headline benchmark: aggregated edges/s (+ epoch time) of full-graph 3-layer GraphSAGE training on an
+ogbn-products-shaped synthetic graph, hidden = 256, bf16 storage / fp32 accumulation (BASELINE.json `metric`).
+
+    python bench.py --gpus 1 --steps K --warmup W                (single MI355X)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W                (one rank per GPU, RCCL)
+
+A step = one pass of the hot path over the whole graph: forward through three sageConv layers (mean neighbour
+aggregation = CSR SpMM in libdgll_hip.so, then the dense transforms), cross-entropy over all nodes, backward
+(SpMM on the transposed CSR for every layer whose input needs a gradient), Adam update.  One step is one epoch.
+"aggregated edges" counts nnz once per SpMM-type launch (3 forward + 2 backward per step).
+
+Rank 0 prints ONE JSON line; see DESIGN.md section 6 for the fields (`roofline`, `cpu_baseline`).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--nodes", type=int, default=2_449_029, help="ogbn-products node count")
+    ap.add_argument("--undirected-edges", type=int, default=61_859_140, help="ogbn-products undirected edge count")
+    ap.add_argument("--in-feats", type=int, default=100)
+    ap.add_argument("--hidden", type=int, default=256)
+    ap.add_argument("--classes", type=int, default=47)
+    ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16")
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-rows", type=int, default=200_000)
+    ap.add_argument("--spmm-only", action="store_true", help="also print the per-shape SpMM table to stderr")
+    return ap.parse_args()
+
+
+def alg_bytes(nnz, n_rows, feat, x_bytes, y_bytes, weighted):
+    """every edge is charged one full feature-row read."""
+    return nnz * (feat * x_bytes + 4 + (4 if weighted else 0)) + n_rows * (feat * y_bytes + 8)
+
+
+def cpu_baseline(graph, feat, sample_rows, seed):
+    """The oracle's CSR SpMM (oracle/oracle.c, OpenMP) on the host cores, on a bounded sample of the same workload:
+    the first `sample_rows` rows of the same adjacency, fp32, same feature width.  Also times the reference's own op,
+    torch.spmm on a COO tensor (gcnconv.py:31), on the same sample."""
+    import numpy as np
+
+    from oracle import cref
+
+    rows = min(sample_rows, graph.n_rows)
+    rowptr = graph.rowptr[:rows + 1].cpu().numpy()
+    nnz = int(rowptr[-1])
+    col = graph.col[:nnz].cpu().numpy()
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((graph.n_cols, feat), dtype=np.float32)
+    cores = os.cpu_count() or 1
+    cref.set_num_threads(cores)
+    cref.spmm_csr(rowptr, col, None, x[:, :8].copy(), reduce="mean")  # warm the thread pool
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        cref.spmm_csr(rowptr, col, None, x, reduce="mean")
+        times.append(time.perf_counter() - t0)
+    t_port = sorted(times)[1]
+    # the reference's exact call on the same sample (unit weights; mean = values 1/deg)
+    torch.set_num_threads(cores)
+    deg = np.diff(rowptr)
+    row = np.repeat(np.arange(rows), deg)
+    val = (1.0 / np.maximum(deg, 1)).astype(np.float32)[row]
+    adj = torch.sparse_coo_tensor(torch.from_numpy(np.stack([row, col.astype(np.int64)])), torch.from_numpy(val),
+                                  (rows, graph.n_cols))
+    xt = torch.from_numpy(x)
+    t0 = time.perf_counter()
+    torch.spmm(adj, xt)
+    t_coo = time.perf_counter() - t0
+    return {
+        "value": nnz / t_port, "unit": "edges/s", "cores": cores, "kind": "port",
+        "sample": "CSR mean-SpMM of the first %d rows (%d edges) of the same graph, F=%d fp32, oracle/oracle.c + OpenMP, "
+                  "median of 3" % (rows, nnz, feat),
+        "torch_spmm_coo_edges_per_s": nnz / t_coo,
+        "torch_spmm_coo_note": "the reference's own call torch.spmm(adj_coo, X) (gcnconv.py:31), torch %s, %d threads, "
+                               "one run on the same sample" % (torch.__version__, cores),
+    }
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl")   # RCCL on ROCm
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    import dgll_amd
+    from dgll_amd import nn as dnn
+    from dgll_amd import ops, synth
+
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    esz = 2 if dtype == torch.bfloat16 else 4
+    torch.manual_seed(args.seed)
+
+    # ---- workload: the same seeded graph on every rank -------------------------------------------------
+    full = synth.products_like_graph(dev, seed=args.seed, n=args.nodes, n_undirected=args.undirected_edges)
+    n, nnz = full.n_rows, full.nnz
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(args.seed + 1)
+    model = dnn.GraphSage(args.in_feats, [args.hidden, args.hidden, args.classes], None).to(dev)
+    labels_all = torch.randint(0, args.classes, (n,), generator=gen, device=dev)
+
+    if world > 1:
+        from dgll_amd import dist as ddist
+
+        part = ddist.partition_contiguous(full, world, rank)
+        engine = ddist.DistGraph(part, dev)
+        x_local = ops.alloc_features(part.n_own, args.in_feats, dtype, dev)
+        feats = torch.randn(n, args.in_feats, generator=gen, device=dev)
+        x_local.copy_(feats[part.own_begin:part.own_end].to(dtype))
+        del feats
+        labels = labels_all[part.own_begin:part.own_end]
+        del full
+        graph_for_cpu = None
+        racom = ddist.RaCoM(model.parameters(), dev)
+    else:
+        engine = None
+        x_local = ops.alloc_features(n, args.in_feats, dtype, dev)
+        x_local.copy_(torch.randn(n, args.in_feats, generator=gen, device=dev).to(dtype))
+        labels = labels_all
+        graph_for_cpu = full
+        racom = None
+        full.plan()
+        full.transpose()[0].plan()
+        full.mean_scale_transposed()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    spmm_launches_per_step = 3 + 2   # forward: 3 layers; backward: layers 2 and 3 (the input features need no gradient)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        if engine is None:
+            out = model.forward_graph(full, x_local)
+        else:
+            out = engine.sage_forward(model, x_local)
+        loss = torch.nn.functional.cross_entropy(out.float(), labels, reduction="sum") / n
+        loss.backward()
+        if racom is not None:
+            racom.all_reduce_and_wait()
+        opt.step()
+        return loss
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    with ops.LaunchTimer() as timer:
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = spmm_launches_per_step * nnz * args.steps / elapsed
+
+    if rank != 0:
+        return
+    # ---- roofline of the dominant kernel: forward mean-SpMM at hidden width, timed with HIP events in the timed region
+    launches = timer.summary()
+    dom_tag = None
+    for tag, (cnt, avg_ms) in launches.items():
+        if tag[0] == "spmm" and tag[1] == args.hidden and not tag[3]:
+            dom_tag = tag
+    roofline = None
+    if dom_tag is not None:
+        cnt, avg_ms = launches[dom_tag]
+        local_rows = n if engine is None else engine.part.n_own
+        b_alg = alg_bytes(dom_tag[4], local_rows, args.hidden, esz, esz, weighted=False)
+        achieved = b_alg / (avg_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBPS, "traffic": load_traffic(args),
+                    "kernel": "spmm_csr_kernel<bf16,bf16,8,32,unweighted> (forward mean aggregation, F=%d)" % args.hidden,
+                    "launches_timed": cnt, "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": b_alg,
+                    "edges_per_s_this_kernel": dom_tag[4] / (avg_ms * 1e-3)}
+    result = {
+        "metric": "aggregated edges/sec + epoch time, 3-layer GraphSAGE ogbn-products, 1/2/4/8 GPU",
+        "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "full-graph 3-layer GraphSAGE (mean aggr, %d-%d-%d-%d) training step on an "
+                               "ogbn-products-shaped RMAT graph" % (args.in_feats, args.hidden, args.hidden, args.classes),
+                   "nodes": n, "nnz": nnz, "hidden": args.hidden, "parallelism": "1-D row partition x%d" % world,
+                   "spmm_launches_per_step": spmm_launches_per_step},
+        "epoch_time_s": ms_per_step / 1e3, "loss": float(loss),
+        "roofline": roofline,
+        "spmm_launch_table": {"%s F=%d %s %s" % (t[0], t[1], t[2].replace("torch.", ""), "weighted" if t[3] else "unweighted"):
+                              {"count": c, "avg_ms": a, "G_edges_per_s": t[4] / (a * 1e-3) / 1e9}
+                              for t, (c, a) in launches.items()},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(graph_for_cpu, args.hidden, args.cpu_sample_rows, args.seed)
+    print(json.dumps(result))
+
+
+def load_traffic(args):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/), or null."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        key = "spmm_f%d_%s" % (args.hidden, args.dtype)
+        return t.get(key, {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
+if __name__ == "__main__":
+    main()

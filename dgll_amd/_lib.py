@@ -7,6 +7,11 @@ files the test processes mapped.
 import ctypes as C
 import os
 
+# torch bundles its own HIP runtime (torch/lib/libamdhip64.so, SONAME libamdhip64.so.7).  It must be mapped BEFORE
+# libdgll_hip.so so that the library's NEEDED libamdhip64.so.7 binds to that same runtime; loaded the other way
+# round the process ends up with two HIP runtimes and the second one sees no device.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdgll_hip.so")
 

@@ -35,7 +35,7 @@ class gcnConv(F.nn.Module):
                 self.bias.uniform_(-bound, bound)
 
     def forward(self, x, adj):
-        support = F.mm(x, self.weight)                       # transform first (gcnconv.py:30)
+        support = F.mm(x, self.weight.to(x.dtype))           # transform first (gcnconv.py:30)
         if support.is_cuda:
             return ops.spmm(as_csr_graph(adj), support, bias=self.bias)   # aggregate + fused bias (gcnconv.py:31-33)
         out = F.spmm(adj, support)

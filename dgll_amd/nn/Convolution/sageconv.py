@@ -77,9 +77,9 @@ class NeighborAggregator(F.nn.Module):
         return ops.spmm(block, x_src, reduce=self.aggr_method)
 
     def transform(self, reduced):
-        hidden = F.matmul(reduced, self.weight)     # sageconv.py:41
+        hidden = F.matmul(reduced, self.weight.to(reduced.dtype))     # sageconv.py:41
         if self.use_bias:
-            hidden = hidden + self.bias
+            hidden = hidden + self.bias.to(hidden.dtype)
         return hidden
 
     def forward(self, neighbor_feature):
@@ -111,7 +111,7 @@ class sageConv(F.nn.Module):
 
     def forward(self, src_node_features, neighbor_node_features):
         neighbor_hidden = self.neighborAgg(neighbor_node_features)
-        self_hidden = F.matmul(src_node_features, self.weight)
+        self_hidden = F.matmul(src_node_features, self.weight.to(src_node_features.dtype))
         return self._combine(self_hidden, neighbor_hidden)
 
     def forward_block(self, block, x_src, x_dst=None):
@@ -121,7 +121,7 @@ class sageConv(F.nn.Module):
         if x_dst is None:
             x_dst = x_src[:block.n_rows]
         neighbor_hidden = self.neighborAgg.transform(self.neighborAgg.reduce_block(block, x_src))
-        return self._combine(F.matmul(x_dst, self.weight), neighbor_hidden)
+        return self._combine(F.matmul(x_dst, self.weight.to(x_dst.dtype)), neighbor_hidden)
 
 
 class GraphSage(F.nn.Module):
@@ -131,7 +131,8 @@ class GraphSage(F.nn.Module):
     def __init__(self, input_dim, hidden_dim=[64, 64], num_neighbors_list=[10, 10]):
         super().__init__()
         self.input_dim, self.hidden_dim = input_dim, list(hidden_dim)
-        self.num_neighbors_list = list(num_neighbors_list)
+        # None: full-graph use only (forward_graph), one layer per hidden_dim entry
+        self.num_neighbors_list = [None] * len(self.hidden_dim) if num_neighbors_list is None else list(num_neighbors_list)
         self.num_layers = len(self.num_neighbors_list)
         if len(self.hidden_dim) != self.num_layers:
             raise ValueError("hidden_dim and num_neighbors_list must have one entry per layer")
@@ -149,3 +150,11 @@ class GraphSage(F.nn.Module):
             hidden = [layer(hidden[hop], hidden[hop + 1].view(len(hidden[hop]), self.num_neighbors_list[hop], -1))
                       for hop in range(self.num_layers - l)]
         return hidden[0]
+
+    def forward_graph(self, graph, x):
+        """Full-graph form (BASELINE configs 3 and 5): every layer aggregates over the whole adjacency `graph`
+        (a CSRGraph), h <- layer(h_self = h, neighbours of each node gathered from h)."""
+        h = x
+        for layer in self.gcn:
+            h = layer.forward_block(graph, h, h)
+        return h

@@ -42,6 +42,36 @@ def alloc_features(n_rows, feat, dtype, device, pad_to=8):
     return buf[:, :feat] if ld != feat else buf
 
 
+class LaunchTimer:
+    """HIP-event timing of individual kernel launches on the stream they are issued on (bench.py's roofline leg).
+    Usage: `with LaunchTimer() as t: ...steps...` then t.summary() -> {tag: (count, avg_ms)}."""
+    active = None
+
+    def __init__(self):
+        self.records = []
+
+    def __enter__(self):
+        LaunchTimer.active = self
+        return self
+
+    def __exit__(self, *exc):
+        LaunchTimer.active = None
+
+    def start(self, tag, device):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(torch.cuda.current_stream(device))
+        self.records.append((tag, a, b))
+        return b
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for tag, a, b in self.records:
+            n, tot = out.get(tag, (0, 0.0))
+            out[tag] = (n + 1, tot + a.elapsed_time(b))
+        return {k: (n, tot / n) for k, (n, tot) in out.items()}
+
+
 def spmm_raw(graph, x, val=None, reduce="sum", bias=None, relu=False, out_dtype=None, out=None):
     """Y = epilogue(reduce_j A[i,j] X[j,:]) with no autograd.  `val` overrides graph.val (None = unweighted
     unless graph.val is set)."""
@@ -64,6 +94,8 @@ def spmm_raw(graph, x, val=None, reduce="sum", bias=None, relu=False, out_dtype=
     plan = graph.plan()
     ws_bytes = graph.workspace_bytes(feat)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes else None
+    timer = LaunchTimer.active
+    end = timer.start(("spmm", feat, str(x.dtype), val is not None, graph.nnz), x.device) if timer is not None else None
     with torch.cuda.device(x.device):
         stream = torch.cuda.current_stream(x.device).cuda_stream
         code = _lib.lib.dgll_hip_spmm_csr(
@@ -71,6 +103,8 @@ def spmm_raw(graph, x, val=None, reduce="sum", bias=None, relu=False, out_dtype=
             x.data_ptr(), x.stride(0), _dtype_code(x), out.data_ptr(), out.stride(0), _dtype_code(out),
             graph.n_rows, graph.n_cols, feat, _REDUCE[reduce], epi, bias.data_ptr() if bias is not None else None,
             ws.data_ptr() if ws is not None else None, ws_bytes)
+    if end is not None:
+        end.record(torch.cuda.current_stream(x.device))
     _lib.check(code, "dgll_hip_spmm_csr")
     return out
 
