@@ -131,9 +131,9 @@ def main():
         engine = ddist.DistGraph(part, dev)
         x_local = ops.alloc_features(part.n_own, args.in_feats, dtype, dev)
         feats = torch.randn(n, args.in_feats, generator=gen, device=dev)
-        x_local.copy_(feats[part.own_begin:part.own_end].to(dtype))
+        x_local.copy_(engine.permute_to_local(feats[part.own_begin:part.own_end]).to(dtype))
         del feats
-        labels = labels_all[part.own_begin:part.own_end]
+        labels = engine.permute_to_local(labels_all[part.own_begin:part.own_end])
         del full
         graph_for_cpu = None
         racom = ddist.RaCoM(model.parameters(), dev)
@@ -156,7 +156,9 @@ def main():
             out = model.forward_graph(full, x_local)
         else:
             out = engine.sage_forward(model, x_local)
-        loss = torch.nn.functional.cross_entropy(out.float(), labels, reduction="sum") / n
+        # cross-entropy summed over this rank's nodes / global node count (x world: RaCoM averages over ranks)
+        logp = torch.log_softmax(out.float(), dim=1)
+        loss = -logp.gather(1, labels.unsqueeze(1)).sum() * (world / n)
         loss.backward()
         if racom is not None:
             racom.all_reduce_and_wait()
@@ -212,7 +214,7 @@ def main():
                                "ogbn-products-shaped RMAT graph" % (args.in_feats, args.hidden, args.hidden, args.classes),
                    "nodes": n, "nnz": nnz, "hidden": args.hidden, "parallelism": "1-D row partition x%d" % world,
                    "spmm_launches_per_step": spmm_launches_per_step},
-        "epoch_time_s": ms_per_step / 1e3, "loss": float(loss),
+        "epoch_time_s": ms_per_step / 1e3, "loss": float(loss.detach()) / world,
         "roofline": roofline,
         "spmm_launch_table": {"%s F=%d %s %s" % (t[0], t[1], t[2].replace("torch.", ""), "weighted" if t[3] else "unweighted"):
                               {"count": c, "avg_ms": a, "G_edges_per_s": t[4] / (a * 1e-3) / 1e9}

@@ -1,0 +1,353 @@
+"""Multi-GPU execution of the aggregation path: 1-D row partition + halo feature exchange + RaCoM gradient sharing.
+
+One process per GPU (`torch.distributed`, backend "nccl" = RCCL over xGMI on ROCm; "gloo" on CPU for the tests).
+The reference has no graph-partition parallelism at all ("Halo / remote-feature exchange:
+not present anywhere"); what it does have is data-parallel DDP plus the RaCoM gradient queue
+(/root/reference/dgll/GPU Accelerator/MQGCN.py:55-79, buffer_queues.py:74-110, README.md:27-37).  This module
+supplies the partitioned full-graph path BASELINE.json's configs 3 and 5 name:
+
+  * `partition_contiguous`: every rank owns a contiguous block of destination rows of A, their CSR rows and their
+    feature rows.  Local column ids are relabelled [owned | halo], the halo ordered by owner rank, so a received
+    message is already in place.  Owned rows are reordered [interior | boundary]: interior rows have no remote
+    neighbour and can be aggregated while the halo is still in flight.
+  * `DistAggregate`: one autograd node per layer.  forward = pack send rows -> grouped point-to-point send/recv
+    (xGMI is point-to-point: all peers are driven concurrently, not a ring) on a communication stream, overlapped
+    with the SpMM over interior rows; then the SpMM over boundary rows.  backward = the transposed exchange
+    (halo gradients return to their owners and are reduced in a fixed order -- no atomics).
+  * `RaCoM`: all parameter gradients flattened into ONE bucket, all-reduced on a dedicated stream, averaged
+    (MQGCN.py:63-64: sum / world_size), and applied when ready; `sync_every` = 1 reproduces DDP exactly.
+"""
+import torch
+import torch.distributed as dist
+
+from . import ops
+from .graph import CSRGraph
+
+
+class Partition:
+    """This rank's share of a row-partitioned graph (all tensors on one device)."""
+
+    def __init__(self):
+        self.rank = self.world = 0
+        self.own_begin = self.own_end = 0
+        self.n_own = self.n_halo = self.n_interior = 0
+        self.order = None          # [n_own] global row id (minus own_begin) of local row i  (interior first)
+        self.interior = None       # CSRGraph [n_interior, n_own]
+        self.boundary = None       # CSRGraph [n_own - n_interior, n_own + n_halo]
+        self.send_idx = None       # [sum(send_counts)] local row ids to pack, grouped by destination rank
+        self.send_counts = None    # python list, rows sent to each rank
+        self.recv_counts = None    # python list, halo rows received from each rank
+        self.send_reduce = None    # CSRGraph [n_own, sum(send_counts)]: owner-side deterministic reduction of returned grads
+        self.nnz = 0
+
+
+def _csr_rows(rowptr, col, val, rows):
+    """Sub-CSR made of `rows` (int64 indices) in the given order."""
+    deg = rowptr[rows + 1] - rowptr[rows]
+    new_ptr = torch.zeros(rows.numel() + 1, dtype=torch.int64, device=rowptr.device)
+    torch.cumsum(deg, 0, out=new_ptr[1:])
+    total = int(new_ptr[-1])
+    if total == 0:
+        empty = torch.zeros(0, dtype=col.dtype, device=col.device)
+        return new_ptr, empty, (None if val is None else val[:0])
+    # edge positions: start of each row repeated + offset within the row
+    starts = torch.repeat_interleave(rowptr[rows] - new_ptr[:-1], deg)
+    pos = starts + torch.arange(total, device=rowptr.device)
+    return new_ptr, col[pos], (None if val is None else val[pos])
+
+
+def partition_contiguous(graph, world, rank, bounds=None):
+    """Row-partition `graph` (the SAME full CSRGraph on every rank) into `world` contiguous blocks and build this
+    rank's Partition.  `bounds` (len world+1) overrides the equal-rows split (e.g. METIS part boundaries after a
+    community relabelling, or an nnz-balanced split)."""
+    n = graph.n_rows
+    dev = graph.device
+    if bounds is None:
+        bounds = [(n * r) // world for r in range(world + 1)]
+    bounds_t = torch.tensor(bounds, dtype=torch.int64, device=dev)
+    p = Partition()
+    p.rank, p.world = rank, world
+    p.own_begin, p.own_end = bounds[rank], bounds[rank + 1]
+    p.n_own = p.own_end - p.own_begin
+    rp = graph.rowptr
+    e0, e1 = int(rp[p.own_begin]), int(rp[p.own_end])
+    col = graph.col[e0:e1].to(torch.int64)
+    val = None if graph.val is None else graph.val[e0:e1]
+    rowptr = rp[p.own_begin:p.own_end + 1] - e0
+    p.nnz = e1 - e0
+
+    owned = (col >= p.own_begin) & (col < p.own_end)
+    halo_ids = torch.unique(col[~owned])                       # sorted by global id == grouped by owner rank
+    p.n_halo = int(halo_ids.numel())
+    owner = torch.bucketize(halo_ids, bounds_t[1:], right=True)
+    p.recv_counts = torch.bincount(owner, minlength=world).tolist()
+
+    # rows with a remote neighbour are boundary rows
+    row_of_edge = torch.repeat_interleave(torch.arange(p.n_own, device=dev), rowptr[1:] - rowptr[:-1])
+    has_remote = torch.zeros(p.n_own, dtype=torch.bool, device=dev)
+    has_remote[row_of_edge[~owned]] = True
+    interior_rows = torch.nonzero(~has_remote).flatten()
+    boundary_rows = torch.nonzero(has_remote).flatten()
+    p.n_interior = int(interior_rows.numel())
+    p.order = torch.cat([interior_rows, boundary_rows])
+    inv = torch.empty(p.n_own, dtype=torch.int64, device=dev)
+    inv[p.order] = torch.arange(p.n_own, device=dev)            # old local row -> new local row
+
+    # local column ids: owned -> permuted local row, halo -> n_own + rank in the sorted halo list
+    local_col = torch.empty_like(col)
+    local_col[owned] = inv[col[owned] - p.own_begin]
+    local_col[~owned] = p.n_own + torch.searchsorted(halo_ids, col[~owned])
+    local_col = local_col.to(torch.int32)
+
+    ip, ic, iv = _csr_rows(rowptr, local_col, val, interior_rows)
+    bp, bc, bv = _csr_rows(rowptr, local_col, val, boundary_rows)
+    p.interior = CSRGraph(ip, ic, iv, p.n_interior, p.n_own, check=False)
+    p.boundary = CSRGraph(bp, bc, bv, p.n_own - p.n_interior, p.n_own + p.n_halo, check=False)
+
+    # what each peer needs from me: the unique columns of ITS rows that fall in my range (every rank derives this
+    # from the same full graph, so it equals the peer's halo list restricted to my block -- no setup communication)
+    send, counts = [], []
+    for q in range(world):
+        if q == rank:
+            counts.append(0)
+            continue
+        q0, q1 = int(rp[bounds[q]]), int(rp[bounds[q + 1]])
+        qc = graph.col[q0:q1].to(torch.int64)
+        mine = torch.unique(qc[(qc >= p.own_begin) & (qc < p.own_end)])
+        send.append(inv[mine - p.own_begin])
+        counts.append(int(mine.numel()))
+    p.send_counts = counts
+    p.send_idx = torch.cat(send) if send else torch.zeros(0, dtype=torch.int64, device=dev)
+    # deterministic owner-side reduction of returned halo gradients: row r sums the slots of send_idx equal to r
+    n_send = int(p.send_idx.numel())
+    if n_send:
+        order = torch.argsort(p.send_idx, stable=True)
+        cnt = torch.bincount(p.send_idx, minlength=p.n_own)
+        sptr = torch.zeros(p.n_own + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(cnt, 0, out=sptr[1:])
+        p.send_reduce = CSRGraph(sptr, order.to(torch.int32), None, p.n_own, n_send, check=False)
+    return p
+
+
+def nnz_balanced_bounds(graph, world):
+    """Row boundaries giving every rank about the same number of nonzeros (power-law rows make equal-row splits
+    uneven)."""
+    targets = torch.arange(1, world, device=graph.device, dtype=torch.int64) * (graph.nnz // world)
+    cuts = torch.searchsorted(graph.rowptr, targets).tolist()
+    return [0] + cuts + [graph.n_rows]
+
+
+# ----------------------------------------------------------------------------------------------------------------
+class _Exchange:
+    """Grouped point-to-point halo exchange (works on RCCL and gloo)."""
+
+    def __init__(self, part, group=None):
+        self.part, self.group = part, group
+
+    def start(self, send_buf, recv_buf, reverse=False):
+        p = self.part
+        s_counts, r_counts = (p.recv_counts, p.send_counts) if reverse else (p.send_counts, p.recv_counts)
+        opsl, so, ro = [], 0, 0
+        for q in range(p.world):
+            if s_counts[q]:
+                opsl.append(dist.P2POp(dist.isend, send_buf[so:so + s_counts[q]], q, self.group))
+            if r_counts[q]:
+                opsl.append(dist.P2POp(dist.irecv, recv_buf[ro:ro + r_counts[q]], q, self.group))
+            so += s_counts[q]
+            ro += r_counts[q]
+        return dist.batch_isend_irecv(opsl) if opsl else []
+
+    @staticmethod
+    def wait(reqs):
+        for r in reqs:
+            r.wait()
+
+
+class DistAggregate(torch.autograd.Function):
+    """Neighbour aggregation over the distributed adjacency: out[local row] = reduce_j A[row, j] h[j], with h
+    partitioned by owner.  forward(h_own [n_own, F]) -> [n_own, F] (local row order); reduce 'sum' or 'mean'."""
+
+    @staticmethod
+    def forward(ctx, h_own, engine, reduce):
+        p = engine.part
+        feat = h_own.shape[1]
+        # exchange buffers hold whole (16-byte padded) rows so that every message is one contiguous block
+        x_store, x_full = engine.alloc_rows(p.n_own + p.n_halo, feat, h_own.dtype)
+        x_full[:p.n_own] = h_own
+        send_store = x_store.index_select(0, p.send_idx) if p.send_idx.numel() else x_store[:0]
+        _, out = engine.alloc_rows(p.n_own, feat, h_own.dtype)
+        with engine.comm_scope():
+            reqs = engine.exchange.start(send_store, x_store[p.n_own:])
+        if p.n_interior:
+            engine.spmm(p.interior, x_full[:p.n_own], out[:p.n_interior], reduce)     # overlaps the exchange
+        with engine.comm_scope():
+            engine.exchange.wait(reqs)
+        engine.join_comm()
+        if p.n_own - p.n_interior:
+            engine.spmm(p.boundary, x_full, out[p.n_interior:], reduce)
+        ctx.engine, ctx.reduce = engine, reduce
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        engine, reduce = ctx.engine, ctx.reduce
+        p = engine.part
+        feat = g.shape[1]
+        g_store, g_full = engine.alloc_rows(p.n_own + p.n_halo, feat, g.dtype)
+        # boundary rows first: they produce the halo gradients that have to travel
+        if p.n_own - p.n_interior:
+            engine.spmm_t(p.boundary, g[p.n_interior:], g_full, reduce)
+        else:
+            g_store.zero_()
+        n_send = int(p.send_idx.numel())
+        recv_store, recv_g = engine.alloc_rows(n_send, feat, g.dtype)
+        with engine.comm_scope():
+            reqs = engine.exchange.start(g_store[p.n_own:], recv_store, reverse=True)
+        g_own = g_full[:p.n_own]
+        if p.n_interior:
+            g_own = g_own + engine.spmm_t(p.interior, g[:p.n_interior], None, reduce)    # overlaps the exchange
+        with engine.comm_scope():
+            engine.exchange.wait(reqs)
+        engine.join_comm()
+        if n_send:
+            g_own = g_own + engine.spmm(p.send_reduce, recv_g, None, "sum")     # fixed-order reduction, no atomics
+        return g_own, None, None
+
+
+class DistGraph:
+    """Per-rank engine: owns the Partition, the communication stream and the kernels' scratch."""
+
+    def __init__(self, part, device, group=None, spmm_fn=None):
+        self.part = part
+        self.device = torch.device(device)
+        self.exchange = _Exchange(part, group)
+        self._spmm_fn = spmm_fn
+        self.comm_stream = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
+        if self.device.type == "cuda":   # build the schedules up front, not inside the first timed step
+            for g in (part.interior, part.boundary):
+                g.plan()
+                self.transposed(g).plan()
+                g.mean_scale_transposed()
+            if part.send_reduce is not None:
+                part.send_reduce.plan()
+
+    # ---- helpers used by DistAggregate
+    def alloc_rows(self, n, feat, dtype):
+        """(storage [n, feat padded to 16 bytes] contiguous, view [n, feat])."""
+        epv = 8 if dtype == torch.bfloat16 else 4
+        ld = -(-feat // epv) * epv
+        store = torch.empty((n, ld), dtype=dtype, device=self.device)
+        if ld != feat:
+            store[:, feat:].zero_()
+        return store, (store[:, :feat] if ld != feat else store)
+
+    def spmm(self, graph, x, out, reduce, val=None):
+        if self._spmm_fn is not None:
+            y = self._spmm_fn(graph, x, reduce, val)
+            if out is None:
+                return y
+            out.copy_(y)
+            return out
+        return ops.spmm_raw(graph, x, val=val, reduce=reduce, out=out)
+
+    def spmm_t(self, graph, g, out, reduce):
+        """A^T . g for the forward's `reduce` (mean: every edge carries 1/deg of its destination row)."""
+        gt = self.transposed(graph)
+        val = graph.mean_scale_transposed() if reduce == "mean" else None
+        if val is not None and gt.val is not None:
+            val = val * gt.val
+        return self.spmm(gt, g, out, "sum", val)
+
+    def transposed(self, graph):
+        return graph.transpose()[0]
+
+    class _Scope:
+        def __init__(self, engine):
+            self.engine = engine
+            self.ctx = None
+
+        def __enter__(self):
+            e = self.engine
+            if e.comm_stream is not None:
+                e.comm_stream.wait_stream(torch.cuda.current_stream(e.device))
+                self.ctx = torch.cuda.stream(e.comm_stream)
+                self.ctx.__enter__()
+
+        def __exit__(self, *exc):
+            if self.ctx is not None:
+                self.ctx.__exit__(*exc)
+
+    def comm_scope(self):
+        """Work issued inside runs on the communication stream, ordered after everything already queued."""
+        return DistGraph._Scope(self)
+
+    def join_comm(self):
+        if self.comm_stream is not None:
+            torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
+
+    # ---- layer-level API
+    def aggregate(self, h_own, reduce="mean"):
+        return DistAggregate.apply(h_own, self, reduce)
+
+    def permute_to_local(self, x_block):
+        """Rows of this rank's block in global order -> local (interior-first) order."""
+        return x_block[self.part.order]
+
+    def sage_forward(self, model, x_local):
+        """Full-graph GraphSage forward on this rank's rows (x_local in local row order)."""
+        h = x_local
+        for layer in model.gcn:
+            h = layer.transform_block(h, self.aggregate(h, reduce=layer.aggr_neighbor_method))
+        return h
+
+
+# ----------------------------------------------------------------------------------------------------------------
+class RaCoM:
+    """Gradient sharing in the spirit of the reference's RaCoM queue (README.md:27-37; MQGCN.py:55-79 all-reduces
+    every parameter separately and divides by world_size).  Here: ONE flattened bucket, one all-reduce on a dedicated
+    stream, averaged and copied back into .grad; `all_reduce_and_wait` is the synchronous form (identical to DDP),
+    `launch` / `wait` let the caller overlap the reduction with other work."""
+
+    def __init__(self, params, device, group=None):
+        self.params = [p for p in params if p.requires_grad]
+        self.device = torch.device(device)
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        total = sum(p.numel() for p in self.params)
+        self.bucket = torch.zeros(total, dtype=torch.float32, device=self.device)
+        self.stream = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
+        self._work = None
+
+    def launch(self):
+        views, off = [], 0
+        for p in self.params:
+            n = p.numel()
+            g = p.grad if p.grad is not None else torch.zeros_like(p)
+            views.append((p, off, n))
+            self.bucket[off:off + n].copy_(g.reshape(-1))
+            off += n
+        self._views = views
+        if self.world > 1:
+            if self.stream is not None:
+                self.stream.wait_stream(torch.cuda.current_stream(self.device))
+                with torch.cuda.stream(self.stream):
+                    self._work = dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            else:
+                self._work = dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def wait(self):
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        if self.stream is not None:
+            torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        if self.world > 1:
+            self.bucket.div_(self.world)                      # MQGCN.py:64
+        for p, off, n in self._views:
+            if p.grad is None:
+                p.grad = torch.empty_like(p)
+            p.grad.copy_(self.bucket[off:off + n].view_as(p))
+
+    def all_reduce_and_wait(self):
+        self.launch()
+        self.wait()

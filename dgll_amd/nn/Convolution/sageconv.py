@@ -17,7 +17,7 @@ constant-degree structure (rowptr = arange(0, N*K+1, K), col = arange(N*K)); `fo
 CSR block and gathers straight from the source feature matrix without materialising [N, K, D].
 """
 from ... import backend as F
-from ... import ops
+from ... import dense, ops
 from ...graph import CSRGraph
 
 _fanout_graphs = {}
@@ -120,8 +120,14 @@ class sageConv(F.nn.Module):
         of x_src, the usual block convention)."""
         if x_dst is None:
             x_dst = x_src[:block.n_rows]
-        neighbor_hidden = self.neighborAgg.transform(self.neighborAgg.reduce_block(block, x_src))
-        return self._combine(F.matmul(x_dst, self.weight.to(x_dst.dtype)), neighbor_hidden)
+        return self.transform_block(x_dst, self.neighborAgg.reduce_block(block, x_src))
+
+    def transform_block(self, x_dst, reduced):
+        """act(x_dst . weight (+|++) reduced . neighborAgg.weight) given the already aggregated neighbours."""
+        if (x_dst.is_cuda and self.aggr_hid_method == "sum" and not self.neighborAgg.use_bias
+                and self.activation in (None, F.relu)):
+            return dense.sage_transform(x_dst, reduced, self.weight, self.neighborAgg.weight, self.activation is not None)
+        return self._combine(F.matmul(x_dst, self.weight.to(x_dst.dtype)), self.neighborAgg.transform(reduced))
 
 
 class GraphSage(F.nn.Module):
