@@ -26,10 +26,11 @@ class DgllHipError(RuntimeError):
 
 
 def _load():
-    if not os.path.exists(LIB_PATH):
-        # Source checkout without a built library: build it now (hipcc cross-compiles without a GPU).
-        from . import build as _build
+    # Build when the library is missing or was built from different sources (content hash, not mtimes); hipcc
+    # cross-compiles without a GPU.  A failed build raises: there is nothing to fall back to.
+    from . import build as _build
 
+    if not _build.is_current():
         _build.build()
     if not os.path.exists(LIB_PATH):
         raise ImportError("libdgll_hip.so is missing (expected at %s); run `python -m dgll_amd.build`" % LIB_PATH)
@@ -45,6 +46,7 @@ SIGNATURES = {
     "dgll_hip_abi_version": (_i32, []),
     "dgll_hip_last_error": (C.c_char_p, []),
     "dgll_hip_device_info": (_i32, [_i32, C.c_char_p, _i32, C.POINTER(_i32), C.POINTER(_i64)]),
+    "dgll_hip_debug_tune": (_i32, [_i32, _i32]),
     "dgll_hip_csr_plan_create": (_i32, [_vp, _vp, _i64, _i64, _i32, C.POINTER(_vp)]),
     "dgll_hip_csr_plan_destroy": (None, [_vp]),
     "dgll_hip_csr_plan_workspace_bytes": (_sz, [_vp, _i32]),
@@ -58,6 +60,10 @@ SIGNATURES = {
     "dgll_hip_gat_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i32,
                                 _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32, C.c_float, _i32,
                                 _i32]),
+    "dgll_hip_gemm_f32": (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _i32]),
+    "launch_gcn_fused_kernel": (None, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32]),
+    "dgll_hip_gcn_fused_forward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _sz]),
+    "dgll_hip_gcn_fused_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "dgll_hip_segment_max": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i32, _i64, _i32]),
 }
 

@@ -41,8 +41,33 @@ def headers():
     return sorted(glob.glob(os.path.join(CSRC, "*.hpp"))) + [os.path.join(HERE, "..", "include", "dgll_hip.h")]
 
 
+STAMP = os.path.join(LIBDIR, "build_stamp.txt")
+
+
+def source_digest():
+    """sha256 over every kernel source and header (and the flags): identifies what the .so was built from."""
+    import hashlib
+
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for path in sources() + headers():
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def is_current():
+    try:
+        with open(STAMP) as f:
+            return os.path.exists(LIB) and f.read().strip() == source_digest()
+    except OSError:
+        return False
+
+
 def build(force=False, verbose=False):
     srcs, hdrs = sources(), headers()
+    if not force and is_current():
+        return LIB
     if not srcs:
         raise RuntimeError("no HIP sources under " + CSRC)
     os.makedirs(OBJDIR, exist_ok=True)
@@ -73,6 +98,8 @@ def build(force=False, verbose=False):
         res = subprocess.run(cmd, capture_output=True, text=True)
         if res.returncode != 0:
             raise RuntimeError("link failed:\n%s\n%s" % (res.stdout, res.stderr))
+    with open(STAMP, "w") as f:
+        f.write(source_digest())
     return LIB
 
 

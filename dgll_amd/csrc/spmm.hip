@@ -19,7 +19,8 @@
 //   * rows longer than the plan's threshold are cut into chunks that run as ordinary work items (scheduled
 //     FIRST, longest-processing-time style) and write fp32 partials that a tiny second kernel reduces in a
 //     fixed order -- no atomics anywhere, results are bit-reproducible;
-//   * logical row blocks are remapped so each XCD's L2 serves a contiguous row range (xcd_remap).
+//   * optional XCD-contiguous row mapping (xcd_remap) for graphs whose neighbours are close in id space; off by
+//     default: on RMAT-like inputs (degree correlated with id) it unbalances the XCDs (measured -4 % .. -45 %).
 #include <algorithm>
 #include <vector>
 
@@ -28,7 +29,7 @@
 struct dgll_csr_plan {
     int device = 0;
     int64_t n_rows = 0, nnz = 0;
-    int threshold = 512;
+    int threshold = 256;
     int64_t n_long = 0, n_chunks = 0;
     int64_t* d_long_row = nullptr;    // [n_long]      row id of each long row (ascending)
     int32_t* d_long_chunk0 = nullptr; // [n_long + 1]  first chunk of each long row
@@ -70,6 +71,7 @@ struct SpmmArgs {
     int ws_ld;
     uint32_t chunk_blocks, row_blocks;
     int rows_per_wave;
+    int flags;  // bit 0: XCD-contiguous row mapping
 };
 
 // Accumulate edges [b, e) of one row into acc (this lane's EPV columns starting at xcol).
@@ -84,8 +86,8 @@ __device__ __forceinline__ void gather_edges(const int32_t* __restrict__ col, co
     int my_col = 0;
     float my_val = 0.0f;
     if (b + lane < e) {
-        my_col = col[b + lane];
-        if (HAS_VAL) my_val = val[b + lane];
+        my_col = __builtin_nontemporal_load(col + b + lane);   // indices and weights are streamed once: keep them
+        if (HAS_VAL) my_val = __builtin_nontemporal_load(val + b + lane);   // from displacing feature rows in L2
     }
     for (int64_t k0 = b; k0 < e; k0 += kWave) {
         const int64_t left = e - k0;
@@ -95,8 +97,8 @@ __device__ __forceinline__ void gather_edges(const int32_t* __restrict__ col, co
         // prefetch the next batch of indices while this one is consumed
         const int64_t kn = k0 + kWave + lane;
         if (kn < e) {
-            my_col = col[kn];
-            if (HAS_VAL) my_val = val[kn];
+            my_col = __builtin_nontemporal_load(col + kn);
+            if (HAS_VAL) my_val = __builtin_nontemporal_load(val + kn);
         }
         for (int j = 0; j < nb; j += SLOTS * U) {
             // All U gathers are issued back to back with no branch in between: an out-of-range slot re-reads the
@@ -177,7 +179,8 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_kernel(const SpmmArgs a) {
         return;
     }
 
-    bid = xcd_remap(bid - a.chunk_blocks, a.row_blocks);
+    bid -= a.chunk_blocks;
+    if (a.flags & 1) bid = xcd_remap(bid, a.row_blocks);
     const int64_t row0 = ((int64_t)bid * kWavesPerBlock + wave) * a.rows_per_wave;
     for (int r = 0; r < a.rows_per_wave; ++r) {
         const int64_t row = row0 + r;
@@ -214,14 +217,28 @@ __global__ __launch_bounds__(kBlock) void spmm_long_finalize_kernel(const SpmmAr
 
 static int ws_ld_for(int feat) { return (feat + 7) & ~7; }
 
-template <typename XT, typename YT, int EPV, int LPR>
-static hipError_t launch_variant(const SpmmArgs& a, dim3 grid, hipStream_t s) {
-    constexpr int U = 4;
+// Tuning knobs (diagnostics; defaults are the shipped configuration).  Set through dgll_hip_debug_tune().
+static int g_tune_unroll = 4;        // gathers in flight per lane (2, 4 or 8; 8 only for the widest variants)
+static int g_tune_rows_per_wave = 0; // 0 = automatic
+static int g_tune_flags = 0;         // bit 0: XCD-contiguous row mapping (off: measured slower when degree correlates with row id)
+static int g_tune_threshold = 0;     // 0 = plan default (512)
+
+template <typename XT, typename YT, int EPV, int LPR, int U>
+static hipError_t launch_u(const SpmmArgs& a, dim3 grid, hipStream_t s) {
     if (a.val)
         hipLaunchKernelGGL((spmm_csr_kernel<XT, YT, EPV, LPR, true, U>), grid, dim3(kBlock), 0, s, a);
     else
         hipLaunchKernelGGL((spmm_csr_kernel<XT, YT, EPV, LPR, false, U>), grid, dim3(kBlock), 0, s, a);
     return hipGetLastError();
+}
+
+template <typename XT, typename YT, int EPV, int LPR>
+static hipError_t launch_variant(const SpmmArgs& a, dim3 grid, hipStream_t s) {
+    if constexpr (LPR >= 32 && EPV > 1) {  // the wide-row variants also exist with other unroll depths
+        if (g_tune_unroll == 8) return launch_u<XT, YT, EPV, LPR, 8>(a, grid, s);
+        if (g_tune_unroll == 2) return launch_u<XT, YT, EPV, LPR, 2>(a, grid, s);
+    }
+    return launch_u<XT, YT, EPV, LPR, 4>(a, grid, s);
 }
 
 template <typename XT, typename YT, int EPV>
@@ -247,7 +264,7 @@ DGLL_API int dgll_hip_csr_plan_create(void* stream, const int64_t* rowptr, int64
     dgll_csr_plan* p = new dgll_csr_plan();
     p->n_rows = n_rows;
     p->nnz = nnz;
-    p->threshold = long_row_threshold > 0 ? long_row_threshold : 512;
+    p->threshold = long_row_threshold > 0 ? long_row_threshold : (g_tune_threshold > 0 ? g_tune_threshold : 256);
     hipError_t e = hipGetDevice(&p->device);
     if (e != hipSuccess) { delete p; return hip_fail(e, "hipGetDevice"); }
 
@@ -316,6 +333,17 @@ DGLL_API int dgll_hip_csr_plan_create(void* stream, const int64_t* rowptr, int64
     return DGLL_OK;
 }
 
+DGLL_API int dgll_hip_debug_tune(int key, int value) {
+    switch (key) {
+        case 0: g_tune_unroll = value; break;
+        case 1: g_tune_rows_per_wave = value; break;
+        case 2: g_tune_flags = value; break;
+        case 3: g_tune_threshold = value; break;
+        default: set_error("unknown tuning key"); return DGLL_ERR_INVALID;
+    }
+    return DGLL_OK;
+}
+
 DGLL_API void dgll_hip_csr_plan_destroy(dgll_csr_plan* p) {
     if (!p) return;
     if (p->d_long_row) (void)hipFree(p->d_long_row);
@@ -357,6 +385,7 @@ DGLL_API int dgll_hip_spmm_csr(void* stream, const dgll_csr_plan* plan, const in
     a.ldx = ldx; a.ldy = ldy; a.n_rows = n_rows; a.feat = feat; a.reduce = reduce; a.epilogue = epilogue; a.bias = bias;
     a.ws_ld = ws_ld_for(feat);
     a.rows_per_wave = 1;
+    a.flags = g_tune_flags;
     if (plan) {
         DGLL_REQUIRE(plan->n_rows == n_rows, "plan was built for a different CSR");
         a.threshold = plan->threshold;
@@ -376,6 +405,7 @@ DGLL_API int dgll_hip_spmm_csr(void* stream, const dgll_csr_plan* plan, const in
                                  (x_dtype == DGLL_BF16 ? 2.0 : 4.0);
         int rpw = row_bytes > 0 ? (int)(8192.0 / row_bytes) : 8;
         a.rows_per_wave = std::min(std::max(rpw, 1), 8);
+        if (g_tune_rows_per_wave > 0) a.rows_per_wave = g_tune_rows_per_wave;
     }
     const int64_t waves = (n_rows + a.rows_per_wave - 1) / a.rows_per_wave;
     const int64_t row_blocks = (waves + kWavesPerBlock - 1) / kWavesPerBlock;

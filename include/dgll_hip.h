@@ -46,10 +46,14 @@ const char* dgll_hip_last_error(void);
 /* Fills name (<= name_len bytes), compute-unit count and total global memory of `device`. */
 int dgll_hip_device_info(int device, char* name, int name_len, int* compute_units, int64_t* global_mem_bytes);
 
+/* Diagnostics only: kernel tuning knobs used by tools/spmm_tune.py (0 unroll depth, 1 rows per wavefront, 2 flags,
+ * 3 default long-row threshold).  Not part of the data path; not thread-safe. */
+int dgll_hip_debug_tune(int key, int value);
+
 /* ---- CSR schedule ----------------------------------------------------------------------------------
  * Built once per adjacency structure (the reference builds its adjacency once per graph,
  * nn/utils/utils.py:171,179).  Rows longer than `long_row_threshold` nonzeros (<= 0 selects the default,
- * 512) are split into chunks that are reduced in a fixed order, so results are bit-reproducible and
+ * 256) are split into chunks that are reduced in a fixed order, so results are bit-reproducible and
  * power-law rows do not serialise the launch.  Synchronises `stream` (it reads a count back).          */
 int dgll_hip_csr_plan_create(void* stream, const int64_t* rowptr, int64_t n_rows, int64_t nnz,
                              int long_row_threshold, dgll_csr_plan** out_plan);
@@ -116,6 +120,26 @@ int dgll_hip_gat_bwd(void* stream, const int64_t* rowptr, const int32_t* col,
  * aligned with padded leading dimensions.                                                                   */
 int dgll_hip_segment_max(void* stream, const int64_t* rowptr, const int32_t* col, const void* X, int64_t ldx,
                          void* Y, int32_t* arg, int64_t ldy, int dtype, int64_t n_rows, int feat);
+
+/* ---- dense transform, exact fp32: C[M,N] = act(A[M,K].B[K,N] + bias) --------------------------------------
+ * F.mm / F.matmul of gcnconv.py:30, sageconv.py:41,72, gatconv.py:31,117 for callers that only have the C ABI
+ * (fmaf accumulation in k order: bit-stable).  relu != 0 fuses max(.,0); bias may be NULL.                   */
+int dgll_hip_gemm_f32(void* stream, const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
+                      int64_t M, int N, int K, const float* bias, int relu);
+
+/* ---- a10: H = relu(A_csr . (X[:, :actual_F] . W[:actual_F, :])) --------------------------------------------
+ * launch_gcn_fused_kernel is the reference's own symbol with its exact signature
+ * (/root/reference/dgll/FusedKernel/gcn_fused_kernel.cu:190-195, bound at gcn_extension.cpp:5-10,46-55): int32 CSR,
+ * fp32, default stream, synchronous, `num_neighbors` = diff(row_ptr); a libgcn replacement can be relinked against
+ * this library unchanged.  dgll_hip_gcn_fused_forward is the same computation with this library's conventions
+ * (explicit stream, caller-owned workspace of dgll_hip_gcn_fused_workspace_bytes(), error code).               */
+void launch_gcn_fused_kernel(const int* row_ptr, const int* col_idx, const float* values, const float* X, const float* W,
+                             float* H, const int* num_neighbors, int N, int F_padded, int actual_F, int H_dim,
+                             int total_nnz);
+int dgll_hip_gcn_fused_forward(void* stream, const int32_t* row_ptr, const int32_t* col_idx, const float* values,
+                               const float* X, const float* W, float* H, int N, int F_padded, int actual_F, int H_dim,
+                               int total_nnz, void* workspace, size_t workspace_bytes);
+size_t dgll_hip_gcn_fused_workspace_bytes(int N, int actual_F, int H_dim);
 
 #ifdef __cplusplus
 }
