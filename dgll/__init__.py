@@ -17,6 +17,12 @@ _ALIASES = {
     "dgll.nn.Convolution.sageconv": "dgll_amd.nn.Convolution.sageconv",
     "dgll.nn.Convolution.gatconv": "dgll_amd.nn.Convolution.gatconv",
     "dgll.nn.Convolution.ginconv": "dgll_amd.nn.Convolution.ginconv",
+    "dgll.data": "dgll_amd.data",
+    "dgll.data.dgraph": "dgll_amd.data.dgraph",
+    "dgll.sampling": "dgll_amd.sampling",
+    "dgll.sampling.base_sampler": "dgll_amd.sampling.base_sampler",
+    "dgll.sampling.dgllsampler": "dgll_amd.sampling.dgllsampler",
+    "dgll.dataloader": "dgll_amd.dataloader",
 }
 for _alias, _target in _ALIASES.items():
     sys.modules[_alias] = importlib.import_module(_target)

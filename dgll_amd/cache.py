@@ -1,0 +1,147 @@
+"""GraphCacheServer -- GPU-resident hot-node feature cache with a pinned-host miss path.
+
+Mirror of /root/reference/dgll/FeatureCache/storage.py:12-221 without its DGL (NodeFlow / Frame) plumbing:
+  * `auto_cache(out_degrees)`: capacity = free device memory / (total_dim * bytes) (storage.py:71-78); if everything fits,
+    cache all nodes, else the top-out-degree nodes, statically (storage.py:84-98);
+  * `cache_fix_data(nids, data, is_full)`: install rows + the localid -> cacheid map + the gpu_flag mask (storage.py:127-148);
+  * `fetch_data(nids)`: features of a batch of node ids as ONE device tensor.  The reference splits the batch by
+    `gpu_flag`, gathers hits on the GPU and misses on the CPU, copies, and merges in place (storage.py:151-198); here
+    that is one HIP launch (dgll_hip_gather_rows) reading the HBM cache and the pinned host array directly;
+  * `log_miss_rate` / `get_miss_rate` (storage.py:213-220).
+Host features are kept in pinned memory so the GPU can read them (and `hipMemcpyAsync` them) without staging.
+"""
+import torch
+
+from . import _lib
+from .ops import _dtype_code
+
+
+class GraphCacheServer:
+    def __init__(self, features, node_num=None, nid_map=None, gpuid=0):
+        """features: [N, D] CPU tensor (fp32 or bf16) -- the 'remote server' of storage.py:100-125.  It is pinned here.
+        nid_map: optional local -> full-graph id map (storage.py:27)."""
+        self.gpuid = gpuid
+        self.device = torch.device("cuda", gpuid)
+        self.node_num = int(features.shape[0] if node_num is None else node_num)
+        self.features = features if features.is_pinned() else features.contiguous().pin_memory()
+        self.nid_map = None if nid_map is None else nid_map.clone().detach().to(self.device)
+        self.total_dim = int(features.shape[1])
+        self.dims = {"features": self.total_dim}
+        self.gpu_flag = torch.zeros(self.node_num, dtype=torch.bool, device=self.device)
+        self.localid2cacheid = torch.full((self.node_num,), -1, dtype=torch.int64, device=self.device)
+        self.gpu_fix_cache = None
+        self.cached_num = 0
+        self.capability = self.node_num
+        self.full_cached = False
+        self.log = False
+        self.try_num = 0
+        self.miss_num = 0
+        self._miss_counter = torch.zeros(1, dtype=torch.int64, device=self.device)
+
+    # ---- cache population ------------------------------------------------------------------------------------
+    def auto_cache(self, out_degrees, reserve_bytes=1 << 30, capacity=None):
+        """storage.py:64-98.  `capacity` (rows) overrides the free-memory rule."""
+        if capacity is None:
+            free, _total = torch.cuda.mem_get_info(self.device)
+            available = free - reserve_bytes
+            capacity = max(int(available // (self.total_dim * self.features.element_size())), 0)
+        self.capability = int(capacity)
+        if self.capability >= self.node_num:
+            full_nids = torch.arange(self.node_num, device=self.device)
+            self.cache_fix_data(full_nids, self.get_feat_from_server(full_nids), is_full=True)
+        else:
+            sort_nid = torch.argsort(out_degrees.to(self.device), descending=True, stable=True)
+            cache_nid = sort_nid[:self.capability]
+            self.cache_fix_data(cache_nid, self.get_feat_from_server(cache_nid), is_full=False)
+
+    def get_feat_from_server(self, nids, to_gpu=False):
+        """Rows of the host feature store for local ids `nids` (storage.py:100-125)."""
+        full = nids if self.nid_map is None else self.nid_map[nids]
+        rows = self.features[full.cpu()]
+        return rows.to(self.device, non_blocking=True) if to_gpu else rows
+
+    def cache_fix_data(self, nids, data, is_full=False):
+        rows = nids.size(0)
+        assert rows == data.size(0)                                            # storage.py:142-143
+        self.localid2cacheid.fill_(-1)
+        self.localid2cacheid[nids] = torch.arange(rows, device=self.device)
+        self.cached_num = rows
+        self.gpu_fix_cache = data.to(self.device).contiguous()
+        self.gpu_flag.zero_()
+        self.gpu_flag[nids] = True
+        self.full_cached = is_full
+
+    # ---- the hot call ----------------------------------------------------------------------------------------
+    def fetch_data(self, nids, out=None, stream=None):
+        """[len(nids), D] device tensor of the nodes' features (ids in the local space, on the GPU)."""
+        nids = nids.to(self.device, dtype=torch.int64, non_blocking=True)
+        if self.nid_map is not None and not self.full_cached:
+            host_ids = self.nid_map[nids]
+        else:
+            host_ids = nids
+        n = int(nids.numel())
+        if out is None:
+            out = torch.empty((n, self.total_dim), dtype=self.features.dtype, device=self.device)
+        if n == 0:
+            return out
+        stream = torch.cuda.current_stream(self.device) if stream is None else stream
+        cache = self.gpu_fix_cache
+        use_map = cache is not None
+        if self.nid_map is not None and use_map and not self.full_cached:
+            # slots are keyed by LOCAL id, the host store by FULL id: resolve the slot on the device first
+            slot_of = self.localid2cacheid[nids]
+            idx = torch.where(slot_of >= 0, slot_of, host_ids)
+            # encode "hit" as a separate map over the batch: gather in two launches keyed differently
+            hits = slot_of >= 0
+            if bool(hits.any()):
+                out[hits] = cache[slot_of[hits]]
+            miss = ~hits
+            if bool(miss.any()):
+                self._launch(None, host_ids[miss], None, out, stream, rows_out=miss.nonzero().flatten())
+            misses = int(miss.sum())
+        else:
+            counter = self._miss_counter if (self.log and use_map) else None
+            if counter is not None:
+                counter.zero_()
+            self._launch(cache, nids if use_map else host_ids, self.localid2cacheid if use_map else None, out, stream,
+                         counter=counter)
+            misses = int(counter.item()) if counter is not None else 0
+        if self.log:
+            self.log_miss_rate(misses, n)
+        return out
+
+    def _launch(self, cache, idx, slot, out, stream, counter=None, rows_out=None):
+        target = out if rows_out is None else torch.empty((idx.numel(), out.shape[1]), dtype=out.dtype, device=out.device)
+        with torch.cuda.device(self.device):
+            code = _lib.lib.dgll_hip_gather_rows(
+                stream.cuda_stream, cache.data_ptr() if cache is not None else None,
+                cache.stride(0) if cache is not None else 0, self.features.data_ptr(), self.features.stride(0),
+                idx.data_ptr(), slot.data_ptr() if slot is not None else None, target.data_ptr(), target.stride(0),
+                int(idx.numel()), self.total_dim, _dtype_code(out), counter.data_ptr() if counter is not None else None)
+        _lib.check(code, "dgll_hip_gather_rows")
+        if rows_out is not None:
+            out[rows_out] = target
+
+    # ---- accounting (storage.py:213-220) -----------------------------------------------------------------------
+    def log_miss_rate(self, miss_num, total_num):
+        self.try_num += total_num
+        self.miss_num += miss_num
+
+    def get_miss_rate(self):
+        miss_rate = float(self.miss_num) / self.try_num
+        self.miss_num = 0
+        self.try_num = 0
+        return miss_rate
+
+
+def gather_rows(x, idx, out=None):
+    """x[idx] for a device (or pinned host) matrix x through the HIP gather kernel (dgraph.py:105)."""
+    dev = idx.device
+    if out is None:
+        out = torch.empty((idx.numel(), x.shape[1]), dtype=x.dtype, device=dev)
+    with torch.cuda.device(dev):
+        code = _lib.lib.dgll_hip_gather_rows(torch.cuda.current_stream(dev).cuda_stream, None, 0, x.data_ptr(), x.stride(0),
+                                             idx.data_ptr(), None, out.data_ptr(), out.stride(0), int(idx.numel()), x.shape[1],
+                                             _dtype_code(x), None)
+    _lib.check(code, "dgll_hip_gather_rows")
+    return out

@@ -157,6 +157,15 @@ class GraphSage(F.nn.Module):
                       for hop in range(self.num_layers - l)]
         return hidden[0]
 
+    def forward_sampled(self, node_feature_list, blocks):
+        """Hop pyramid driven by sampled CSR blocks (variable fan-out, e.g. DGLLNeighborSampler): blocks[hop] has one row
+        per node of hop `hop` and gathers from the rows of hop `hop + 1` (sugbraph.to_block())."""
+        hidden = node_feature_list
+        for l in range(self.num_layers):
+            layer = self.gcn[l]
+            hidden = [layer.forward_block(blocks[hop], hidden[hop + 1], hidden[hop]) for hop in range(self.num_layers - l)]
+        return hidden[0]
+
     def forward_graph(self, graph, x):
         """Full-graph form (BASELINE configs 3 and 5): every layer aggregates over the whole adjacency `graph`
         (a CSRGraph), h <- layer(h_self = h, neighbours of each node gathered from h)."""

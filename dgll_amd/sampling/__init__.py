@@ -1,0 +1,2 @@
+from .base_sampler import Base_sampler, sugbraph  # noqa: F401
+from .dgllsampler import DGLLNeighborSampler  # noqa: F401

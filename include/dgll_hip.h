@@ -121,6 +121,16 @@ int dgll_hip_gat_bwd(void* stream, const int64_t* rowptr, const int32_t* col,
 int dgll_hip_segment_max(void* stream, const int64_t* rowptr, const int32_t* col, const void* X, int64_t ldx,
                          void* Y, int32_t* arg, int64_t ldy, int dtype, int64_t n_rows, int feat);
 
+/* ---- f2: feature-row gather through the hot-node cache -------------------------------------------------------
+ * out[i,:] = cache[slot[idx[i]],:] if slot[idx[i]] >= 0 else host[idx[i],:]   -- GraphCacheServer.fetch_data,
+ * dgll/FeatureCache/storage.py:151-198 (mask split, GPU gather of cached rows, CPU gather + copy of the rest, merge)
+ * in one launch; `host` may be PINNED HOST memory (read over PCIe by the kernel) or a device matrix.  slot == NULL:
+ * plain gather from `host` (dgll/data/dgraph.py:105 `features[nodes]`).  *miss_count (optional, device) is
+ * incremented by the number of rows served from `host` (storage.py:213-220).                                 */
+int dgll_hip_gather_rows(void* stream, const void* cache, int64_t ldc, const void* host, int64_t ldh,
+                         const int64_t* idx, const int64_t* slot, void* out, int64_t ldo, int64_t n, int feat,
+                         int dtype, unsigned long long* miss_count);
+
 /* ---- dense transform, exact fp32: C[M,N] = act(A[M,K].B[K,N] + bias) --------------------------------------
  * F.mm / F.matmul of gcnconv.py:30, sageconv.py:41,72, gatconv.py:31,117 for callers that only have the C ABI
  * (fmaf accumulation in k order: bit-stable).  relu != 0 fuses max(.,0); bias may be NULL.                   */

@@ -1,0 +1,107 @@
+"""f2: hot-node feature cache (one-launch hit/miss gather) and the bounded mini-batch queues."""
+import random
+import threading
+import time
+
+import numpy as np
+import pytest
+import torch
+
+
+def test_pipeline_queue_is_bounded_and_ordered_on_cpu():
+    """Producer/consumer semantics without a GPU: batches arrive in order, the producer never runs more than
+    `queue_size` (+1 in hand) ahead, errors surface in the consumer."""
+    from dgll_amd.pipeline import MiniBatchPipeline
+
+    produced = []
+
+    class FakeGraph:
+        def get_features(self, ids):
+            return torch.zeros(len(ids), 2)
+
+    class FakeLoader:
+        Dgraph = FakeGraph()
+
+        def __iter__(self):
+            for i in range(12):
+                produced.append(i)
+                yield torch.tensor([i]), torch.tensor([i]), []
+
+    pipe = MiniBatchPipeline(FakeLoader(), queue_size=3, device="cpu")
+    seen = []
+    for b in pipe:
+        time.sleep(0.02)
+        assert len(produced) - len(seen) <= 3 + 2
+        seen.append(b.step)
+    assert seen == list(range(12))
+
+    class Broken(FakeLoader):
+        def __iter__(self):
+            yield torch.tensor([0]), torch.tensor([0]), []
+            raise RuntimeError("sampler failed")
+
+    with pytest.raises(RuntimeError, match="sampler failed"):
+        list(MiniBatchPipeline(Broken(), queue_size=2, device="cpu"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,dim", [(torch.float32, 100), (torch.float32, 7), (torch.bfloat16, 256), (torch.bfloat16, 50)])
+def test_fetch_data_equals_indexing(cuda_device, dtype, dim):
+    """(node-id batch, cached-id set) -> gathered features == features[ids]; miss accounting (storage.py:213-220)."""
+    from dgll_amd.cache import GraphCacheServer, gather_rows
+
+    n = 5000
+    torch.manual_seed(1)
+    feats = torch.randn(n, dim).to(dtype)
+    deg = torch.randint(0, 1000, (n,))
+    srv = GraphCacheServer(feats, gpuid=0)
+    srv.log = True
+    srv.auto_cache(deg, capacity=1200)                     # partial: top-1200 out-degree nodes
+    assert srv.cached_num == 1200 and not srv.full_cached
+    top = set(torch.argsort(deg, descending=True, stable=True)[:1200].tolist())
+    ids = torch.randint(0, n, (3000,), device=cuda_device)
+    got = srv.fetch_data(ids)
+    assert torch.equal(got.cpu(), feats[ids.cpu()])
+    expect_miss = sum(1 for v in ids.tolist() if v not in top)
+    assert abs(srv.get_miss_rate() - expect_miss / 3000) < 1e-9
+    srv.auto_cache(deg, capacity=n)                        # everything fits: full cache, no misses
+    assert srv.full_cached
+    assert torch.equal(srv.fetch_data(ids).cpu(), feats[ids.cpu()])
+    assert srv.get_miss_rate() == 0.0
+    dev_feats = feats.to(cuda_device)
+    assert torch.equal(gather_rows(dev_feats, ids), dev_feats[ids])
+
+
+@pytest.mark.gpu
+def test_cache_with_nid_map_and_pipeline_on_gpu(cuda_device):
+    from conftest import load_golden
+    from dgll_amd.cache import GraphCacheServer
+    from dgll_amd.data import DGraph
+    from dgll_amd.dataloader import DataLoader
+    from dgll_amd.pipeline import MiniBatchPipeline
+    from dgll_amd.sampling import DGLLNeighborSampler
+
+    g = load_golden("sampler_n400")
+    ptr, idx = g["adj_ptr"], g["adj_idx"]
+    n = len(ptr) - 1
+    edges = [idx[ptr[i]:ptr[i + 1]].tolist() for i in range(n)]
+    feats = torch.randn(n, 32)
+    labels = torch.arange(n) % 7
+    dg = DGraph(nodes=torch.arange(n), edges=edges, labels=labels, features=feats)
+    srv = GraphCacheServer(feats, gpuid=0)
+    srv.auto_cache(torch.tensor([len(e) for e in edges]), capacity=100)
+    loader = DataLoader(dg, torch.arange(0, 200), DGLLNeighborSampler([4, 3]), batch_size=64)
+    random.seed(5)
+    pipe = MiniBatchPipeline(loader, cache=srv, labels=labels, queue_size=2, device=cuda_device)
+    steps = 0
+    for b in pipe:
+        assert torch.equal(b.features[0].cpu(), feats[b.input_nodes])
+        assert torch.equal(b.labels.cpu(), labels[b.output_nodes])
+        steps += 1
+    assert steps == 4
+    # local -> full id map (storage.py:27): features live under permuted ids on the host
+    perm = torch.randperm(n)
+    srv2 = GraphCacheServer(feats, nid_map=perm, gpuid=0)
+    srv2.auto_cache(torch.arange(n), capacity=50)
+    ids = torch.randint(0, n, (500,), device=cuda_device)
+    assert torch.equal(srv2.fetch_data(ids).cpu(), feats[perm[ids.cpu()]])
