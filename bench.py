@@ -40,6 +40,9 @@ def parse_args():
     ap.add_argument("--classes", type=int, default=47)
     ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--locality", type=float, default=0.9,
+                    help="fraction of edges inside one of 64 planted communities (METIS-relabelled products shape); "
+                         "0 = structure-free RMAT")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=200_000)
     ap.add_argument("--spmm-only", action="store_true", help="also print the per-shape SpMM table to stderr")
@@ -103,8 +106,12 @@ def main():
     if world > 1:
         import torch.distributed as dist
 
+        # "nccl" is RCCL on ROCm.  DGLL_BENCH_BACKEND=gloo lets several ranks share one GPU (functional check of
+        # the multi-rank path on a 1-GPU box; never used for reported numbers).
+        backend = os.environ.get("DGLL_BENCH_BACKEND", "nccl")
+        local_rank = local_rank % torch.cuda.device_count()
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl")   # RCCL on ROCm
+        dist.init_process_group(backend=backend)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -117,7 +124,8 @@ def main():
     torch.manual_seed(args.seed)
 
     # ---- workload: the same seeded graph on every rank -------------------------------------------------
-    full = synth.products_like_graph(dev, seed=args.seed, n=args.nodes, n_undirected=args.undirected_edges)
+    full = synth.products_like_graph(dev, seed=args.seed, n=args.nodes, n_undirected=args.undirected_edges,
+                                     locality=args.locality)
     n, nnz = full.n_rows, full.nnz
     gen = torch.Generator(device=dev)
     gen.manual_seed(args.seed + 1)
@@ -183,6 +191,10 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
+    global_loss = loss.detach().double() / world      # this rank's share of the mean loss
+    if world > 1:
+        torch.distributed.all_reduce(global_loss)
+    global_loss = float(global_loss)
     ms_per_step = elapsed / args.steps * 1e3
     value = spmm_launches_per_step * nnz * args.steps / elapsed
 
@@ -212,9 +224,9 @@ def main():
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "full-graph 3-layer GraphSAGE (mean aggr, %d-%d-%d-%d) training step on an "
                                "ogbn-products-shaped RMAT graph" % (args.in_feats, args.hidden, args.hidden, args.classes),
-                   "nodes": n, "nnz": nnz, "hidden": args.hidden, "parallelism": "1-D row partition x%d" % world,
+                   "nodes": n, "nnz": nnz, "hidden": args.hidden, "locality": args.locality, "parallelism": "1-D row partition x%d" % world,
                    "spmm_launches_per_step": spmm_launches_per_step},
-        "epoch_time_s": ms_per_step / 1e3, "loss": float(loss.detach()) / world,
+        "epoch_time_s": ms_per_step / 1e3, "loss": global_loss,
         "roofline": roofline,
         "spmm_launch_table": {"%s F=%d %s %s" % (t[0], t[1], t[2].replace("torch.", ""), "weighted" if t[3] else "unweighted"):
                               {"count": c, "avg_ms": a, "G_edges_per_s": t[4] / (a * 1e-3) / 1e9}

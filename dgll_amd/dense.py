@@ -44,7 +44,7 @@ class _SageTransform(torch.autograd.Function):
     def backward(ctx, g):
         h, agg, wsd, wnd, out = ctx.saved_tensors
         if ctx.relu:
-            g = g * (out > 0)
+            g = torch.ops.aten.threshold_backward(g.contiguous(), out, 0)   # one vectorised pass: g where out > 0
         g = g.contiguous()
         gh = torch.mm(g, wsd.t()) if ctx.needs_input_grad[0] else None
         gagg = torch.mm(g, wnd.t()) if ctx.needs_input_grad[1] else None

@@ -127,7 +127,7 @@ class _Spmm(torch.autograd.Function):
         x, val, y = ctx.saved_tensors
         graph = ctx.graph
         if ctx.relu:
-            g = g * (y > 0)
+            g = torch.ops.aten.threshold_backward(g.contiguous(), y, 0)
         g = _row_major(g)
         grad_x = grad_val = grad_bias = None
         if ctx.has_bias and ctx.needs_input_grad[2]:

@@ -82,13 +82,39 @@ PRODUCTS_UNDIRECTED_EDGES = 61_859_140
 
 
 def products_like_graph(device, seed=0, n=PRODUCTS_NODES, n_undirected=PRODUCTS_UNDIRECTED_EDGES, weighted=False,
-                        self_loops=False):
-    """ogbn-products-shaped synthetic graph: N = 2 449 029 nodes, ~61.86 M undirected RMAT edges symmetrised to
-    ~123.7 M directed ones (duplicates coalesce, so nnz lands slightly below 123 718 280).  RMAT ids are drawn at
-    scale ceil(log2 N) and folded into [0, N) with a modulo."""
+                        self_loops=False, locality=0.0, n_blocks=64):
+    """ogbn-products-shaped synthetic graph: N = 2 449 029 nodes, ~61.86 M undirected power-law (RMAT) edges symmetrised
+    to ~123.7 M directed ones (duplicates coalesce, so nnz lands a few per cent below 123 718 280).
+
+    locality = 0: one global RMAT, ids folded into [0, N) -- no community structure at all (worst case for caches and for
+    any partitioner).  locality = p > 0: the node range is cut into `n_blocks` equal communities; every edge picks a
+    community, draws its source there (RMAT inside the block), and with probability p its destination in the SAME block,
+    else anywhere (global RMAT).  This models the graph after a METIS / community relabelling (BASELINE config 3 names METIS
+    partitions; ogbn-products is a co-purchase network with strong communities): a contiguous k-way split then cuts
+    about (1 - p)(1 - 1/k) of the edges."""
+    dev = torch.device(device)
     scale = int(np.ceil(np.log2(n)))
-    src, dst = rmat_edges_torch(scale, n_undirected, seed, device) if torch.device(device).type != "cpu" else \
-        tuple(torch.from_numpy(x) for x in rmat_edges_np(scale, n_undirected, seed))
-    src, dst = src % n, dst % n
+    on_cpu = dev.type == "cpu"
+
+    def rmat(sc, m, sd):
+        if on_cpu:
+            return tuple(torch.from_numpy(x) for x in rmat_edges_np(sc, m, sd))
+        return rmat_edges_torch(sc, m, sd, dev)
+
+    if locality <= 0.0:
+        src, dst = rmat(scale, n_undirected, seed)
+        src, dst = src % n, dst % n
+    else:
+        block = -(-n // n_blocks)
+        bscale = int(np.ceil(np.log2(block)))
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(seed + 7919)
+        blk = torch.randint(0, n_blocks, (n_undirected,), generator=gen, device=dev)
+        local = torch.rand(n_undirected, generator=gen, device=dev) < locality
+        ls, ld = rmat(bscale, n_undirected, seed)               # positions inside the community
+        _, gd = rmat(scale, n_undirected, seed + 1)             # global destination for the cross-community edges
+        base = blk * block
+        src = (base + ls % block).clamp(max=n - 1)
+        dst = torch.where(local, (base + ld % block).clamp(max=n - 1), gd % n)
     keep = src != dst
     return build_graph(src[keep], dst[keep], n, symmetric=True, self_loops=self_loops, weighted=weighted)

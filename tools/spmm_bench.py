@@ -32,10 +32,11 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--feats", default="256,128,100,64")
     ap.add_argument("--dtypes", default="bf16,f32")
+    ap.add_argument("--locality", type=float, default=0.0)
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     if args.graph == "products":
-        g = synth.products_like_graph(dev, seed=0)
+        g = synth.products_like_graph(dev, seed=0, locality=args.locality)
     else:
         g = synth.rmat_graph(int(args.graph.replace("rmat", "")), 16, seed=0, device=dev, symmetric=False, weighted=False)
     gw = g.with_values(torch.rand(g.nnz, device=dev))
