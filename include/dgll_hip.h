@@ -137,6 +137,18 @@ int dgll_hip_gather_rows(void* stream, const void* cache, int64_t ldc, const voi
 int dgll_hip_gemm_f32(void* stream, const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
                       int64_t M, int N, int K, const float* bias, int relu);
 
+/* ---- bf16 MFMA transform: out[M,N] = act( A1[M,K1].Wt1[N,K1]^T (+ A2[M,K2].Wt2[N,K2]^T) + bias ) -------------
+ * The dense W-transform next to the aggregation on matrix cores (v_mfma_f32_32x32x16_bf16, fp32 accumulation):
+ * sageConv's act(src.W_s + agg.W_n) in ONE pass (sageconv.py:71-82), gcnConv / GAT x.W (gcnconv.py:30,
+ * gatconv.py:31,117), and their input gradients g.W^T (pass Wt := W; `relu_mask`, same shape as A1, fuses the
+ * ReLU backward: A1 is zeroed where the mask is <= 0).  A*: bf16 row-major, 16-byte aligned, lda a multiple of 8.
+ * Wt*: the weight TRANSPOSED, bf16 [>= 32*ceil(N/32) rows, ld >= 64*ceil(K/64)], zero padded.  N <= 256.
+ * out: bf16 or fp32 [M, ldo].  A2/Wt2/relu_mask/bias may be NULL.                                              */
+int dgll_hip_transform_bf16(void* stream, const void* A1, int64_t lda1, int K1, const void* Wt1, int64_t ldw1,
+                            const void* A2, int64_t lda2, int K2, const void* Wt2, int64_t ldw2,
+                            const void* relu_mask, int64_t ldm, void* out, int64_t ldo, int out_dtype,
+                            int64_t M, int N, int relu, const float* bias);
+
 /* ---- a10: H = relu(A_csr . (X[:, :actual_F] . W[:actual_F, :])) --------------------------------------------
  * launch_gcn_fused_kernel is the reference's own symbol with its exact signature
  * (/root/reference/dgll/FusedKernel/gcn_fused_kernel.cu:190-195, bound at gcn_extension.cpp:5-10,46-55): int32 CSR,

@@ -99,3 +99,48 @@ def test_split_k_weight_gradient(cuda_device):
     x = torch.randn(70_001, 24, device=cuda_device)
     g = torch.randn(70_001, 40, device=cuda_device)
     np.testing.assert_allclose(dense.grad_weight(x, g).cpu().numpy(), (x.double().t() @ g.double()).cpu().numpy(), rtol=1e-4, atol=1e-2)
+
+
+@pytest.mark.parametrize("M,K1,K2,N,relu", [(1000, 256, 256, 256, True), (777, 100, 100, 256, True), (513, 256, 256, 47, False),
+                                            (130, 64, 0, 128, False), (4097, 40, 24, 33, True), (128, 256, 0, 256, False)])
+def test_mfma_transform_kernel(cuda_device, M, K1, K2, N, relu):
+    """dgll_hip_transform_bf16 (v_mfma_f32_32x32x16_bf16) vs an fp32 matmul of the same bf16-rounded operands; the
+    weights are asymmetric so a transposed fragment layout cannot pass."""
+    from dgll_amd import dense, ops
+
+    torch.manual_seed(M + N)
+    a1 = ops.alloc_features(M, K1, torch.bfloat16, cuda_device)
+    a1.copy_(torch.randn(M, K1, device=cuda_device))
+    w1 = (torch.randn(K1, N, device=cuda_device) * 0.1 + torch.arange(N, device=cuda_device) * 1e-3).to(torch.bfloat16)
+    ref = a1.float() @ w1.float()
+    a2 = w2 = None
+    if K2:
+        a2 = ops.alloc_features(M, K2, torch.bfloat16, cuda_device)
+        a2.copy_(torch.randn(M, K2, device=cuda_device))
+        w2 = (torch.randn(K2, N, device=cuda_device) * 0.1).to(torch.bfloat16)
+        ref = ref + a2.float() @ w2.float()
+    if relu:
+        ref = ref.relu()
+    out32 = dense.transform_bf16(a1, w1.t(), a2, None if w2 is None else w2.t(), relu=relu, out_dtype=torch.float32)
+    np.testing.assert_allclose(out32.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-3)
+    out = dense.transform_bf16(a1, w1.t(), a2, None if w2 is None else w2.t(), relu=relu)
+    assert out.dtype == torch.bfloat16 and out.shape == (M, N)
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref.cpu().numpy(), rtol=1e-2, atol=2e-2)
+
+
+def test_mfma_transform_relu_mask_and_nan_pads(cuda_device):
+    """Fused ReLU-backward mask; uninitialised pad columns (NaN bit patterns) must not leak into the result."""
+    from dgll_amd import dense
+
+    M, K, N = 300, 100, 64
+    store = torch.full((M, 104), float("nan"), device=cuda_device, dtype=torch.bfloat16)
+    a = store[:, :K]
+    a.copy_(torch.randn(M, K, device=cuda_device))
+    mstore = torch.full((M, 104), float("nan"), device=cuda_device, dtype=torch.bfloat16)
+    mask = mstore[:, :K]
+    mask.copy_(torch.randn(M, K, device=cuda_device))
+    w = torch.randn(K, N, device=cuda_device).to(torch.bfloat16)
+    out = dense.transform_bf16(a, w.t(), out_dtype=torch.float32, mask=mask)
+    ref = (a.float() * (mask.float() > 0)) @ w.float()
+    assert torch.isfinite(out).all()
+    np.testing.assert_allclose(out.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-3)
