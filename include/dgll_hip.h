@@ -53,7 +53,7 @@ int dgll_hip_debug_tune(int key, int value);
 /* ---- CSR schedule ----------------------------------------------------------------------------------
  * Built once per adjacency structure (the reference builds its adjacency once per graph,
  * nn/utils/utils.py:171,179).  Rows longer than `long_row_threshold` nonzeros (<= 0 selects the default,
- * 256) are split into chunks that are reduced in a fixed order, so results are bit-reproducible and
+ * 128) are split into chunks that are reduced in a fixed order, so results are bit-reproducible and
  * power-law rows do not serialise the launch.  Synchronises `stream` (it reads a count back).          */
 int dgll_hip_csr_plan_create(void* stream, const int64_t* rowptr, int64_t n_rows, int64_t nnz,
                              int long_row_threshold, dgll_csr_plan** out_plan);

@@ -10,7 +10,7 @@ cd /tmp
 for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum"; do
   tag=$(echo $grp | tr ' ' '_')
   rm -rf /tmp/pmc_$tag
-  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d /tmp/pmc_$tag -o p -- python3 $R/tools/pmc_spmm.py --reps 3 > $OUT/pmc_$tag.log 2>&1
+  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d /tmp/pmc_$tag -o p -- python3 $R/tools/pmc_spmm.py --reps 3 $PMC_ARGS > $OUT/pmc_$tag.log 2>&1
   f=$(find /tmp/pmc_$tag -name '*counter_collection.csv' | head -1)
   [ -n "$f" ] && grep -E "Counter_Name|spmm_csr_kernel" $f > $OUT/pmc_$tag.csv
 done

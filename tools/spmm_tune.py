@@ -11,7 +11,8 @@ from dgll_amd import _lib, ops, synth  # noqa: E402
 
 dev = torch.device("cuda:0")
 feat = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-base = synth.products_like_graph(dev, seed=0)
+loc = float(sys.argv[2]) if len(sys.argv) > 2 else 0.0
+base = synth.products_like_graph(dev, seed=0, locality=loc)
 x = torch.randn(base.n_cols, feat, device=dev).to(torch.bfloat16)
 
 
@@ -45,19 +46,10 @@ def degree_sorted(g):
     return dgll_amd.CSRGraph(rp, c, None, g.n_rows, g.n_cols, check=False)
 
 
-configs = [
-    ("remap thr512", dict(unroll=4, rpw=0, flags=1, threshold=512), False),
-    ("noremap thr512", dict(unroll=4, rpw=0, flags=0, threshold=512), False),
-    ("noremap thr256", dict(unroll=4, rpw=0, flags=0, threshold=256), False),
-    ("noremap thr128", dict(unroll=4, rpw=0, flags=0, threshold=128), False),
-    ("noremap thr1024", dict(unroll=4, rpw=0, flags=0, threshold=1024), False),
-    ("noremap thr512 degsorted", dict(unroll=4, rpw=0, flags=0, threshold=512), True),
-    ("noremap thr256 degsorted", dict(unroll=4, rpw=0, flags=0, threshold=256), True),
-    ("noremap thr2048 degsorted", dict(unroll=4, rpw=0, flags=0, threshold=2048), True),
-    ("remap thr512 degsorted", dict(unroll=4, rpw=0, flags=1, threshold=512), True),
-]
+configs = [("thr%d rpw%d remap%d" % (t, r, f), dict(unroll=4, rpw=r, flags=f, threshold=t), False)
+           for t in (64, 128, 256) for r in (1, 2, 4) for f in (0, 1)]
 sorted_base = degree_sorted(base)
-for rnd in range(2):
+for rnd in range(1):
     for name, kw, srt in configs:
         tune(**kw)
         src = sorted_base if srt else base
