@@ -55,11 +55,12 @@ SIGNATURES = {
     "dgll_hip_spmm_csr": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _i64, _i32, _i64, _i64, _i32, _i32,
                                  _i32, _vp, _vp, _sz]),
     "dgll_hip_sddmm_csr": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i32, _vp, _i64, _i32]),
-    "dgll_hip_gat_fwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i64, _i32, _i32,
-                                C.c_float, _i32, _i32]),
-    "dgll_hip_gat_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i32,
+    "dgll_hip_gat_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i64, _i32, _i32,
+                                C.c_float, _i32, _i32, _vp, _sz]),
+    "dgll_hip_gat_workspace_bytes": (_sz, [_vp, _i32, _i32]),
+    "dgll_hip_gat_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i32,
                                 _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32, C.c_float, _i32,
-                                _i32]),
+                                _i32, _vp, _sz]),
     "dgll_hip_gather_rows": (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp]),
     "dgll_hip_gemm_f32": (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _i32]),
     "dgll_hip_transform_bf16": (_i32, [_vp, _vp, _i64, _i32, _vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _i64,

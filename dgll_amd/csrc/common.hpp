@@ -8,6 +8,20 @@
 
 #define DGLL_API extern "C" __attribute__((visibility("default")))
 
+// Load-balancing schedule of one CSR structure (opaque to callers; include/dgll_hip.h).  Rows longer than `threshold`
+// nonzeros are cut into chunks that run as independent work items and are reduced in a fixed order afterwards.
+struct dgll_csr_plan {
+    int device = 0;
+    int64_t n_rows = 0, nnz = 0;
+    int threshold = 128;
+    int64_t n_long = 0, n_chunks = 0;
+    int64_t* d_long_row = nullptr;    // [n_long]      row id of each long row (ascending)
+    int32_t* d_long_chunk0 = nullptr; // [n_long + 1]  first chunk of each long row
+    int64_t* d_chunk_begin = nullptr; // [n_chunks]    first edge of the chunk
+    int64_t* d_chunk_end = nullptr;   // [n_chunks]    one past its last edge
+    int64_t* d_chunk_row = nullptr;   // [n_chunks]    row the chunk belongs to
+};
+
 namespace dgll {
 
 constexpr int kWave = 64;           // CDNA4 wavefront width

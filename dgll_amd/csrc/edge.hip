@@ -43,7 +43,47 @@ struct EdgeArgs {
     float alpha, sign;          // leaky-relu slope; -1: exp(-lrelu) (sparseGatConv), +1: softmax(+lrelu) (gatConv)
     int apply_elu, use_max;
     int32_t* arg_out;           // segment_max: int32 [n_rows, ld] source row of the maximum
+    // long-row schedule (threshold == 0: none): chunk work items come first in the grid, partials go to `ws`
+    int threshold;
+    int64_t n_chunks;
+    const int64_t* chunk_begin;
+    const int64_t* chunk_end;
+    const int64_t* chunk_row;
+    float* ws;                  // [n_chunks, ws_ld]: [0, feat) vector partial | [ws_vec, +heads) scalar | [+heads, +2 heads) max
+    int ws_ld, ws_vec;
+    uint32_t chunk_blocks;
 };
+
+// Work item of this wavefront: a whole (short) row, or one chunk of a long row.
+struct WorkItem {
+    int64_t row, b, e, chunk;   // chunk < 0: whole row
+    bool valid, first;          // first: this item starts at the row's first edge (writes the per-row outputs)
+};
+
+__device__ __forceinline__ WorkItem resolve_item(const EdgeArgs& a, int wave) {
+    WorkItem w;
+    w.chunk = -1;
+    w.first = true;
+    const uint32_t bid = blockIdx.x;
+    if (bid < a.chunk_blocks) {
+        const int64_t c = __builtin_amdgcn_readfirstlane((int)(bid * kWavesPerBlock + wave));
+        w.valid = c < a.n_chunks;
+        if (!w.valid) { w.row = w.b = w.e = 0; return w; }
+        w.chunk = c;
+        w.row = uniform64(a.chunk_row[c]);
+        w.b = uniform64(a.chunk_begin[c]);
+        w.e = uniform64(a.chunk_end[c]);
+        w.first = w.b == uniform64(a.rowptr[w.row]);
+        return w;
+    }
+    w.row = (int64_t)(bid - a.chunk_blocks) * kWavesPerBlock + wave;
+    w.valid = w.row < a.n_rows;
+    if (!w.valid) { w.b = w.e = 0; return w; }
+    w.b = uniform64(a.rowptr[w.row]);
+    w.e = uniform64(a.rowptr[w.row + 1]);
+    if (a.threshold > 0 && w.e - w.b > a.threshold) w.valid = false;   // handled as chunks
+    return w;
+}
 
 __device__ __forceinline__ float lrelu(float z, float alpha) { return z > 0.0f ? z : alpha * z; }
 
@@ -138,10 +178,9 @@ __global__ __launch_bounds__(kBlock) void gat_fwd_kernel(const EdgeArgs a, int l
     const int c0 = ((int)blockIdx.y * LPR + sub) * EPV;
     const bool col_ok = c0 < a.feat;
     const int head = col_ok ? c0 / a.fo : 0;
-    const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int64_t row = (int64_t)bid * kWavesPerBlock + wave;
-    if (row >= a.n_rows) return;
-    const int64_t b = uniform64(a.rowptr[row]), e = uniform64(a.rowptr[row + 1]);
+    const WorkItem it = resolve_item(a, wave);
+    if (!it.valid) return;
+    const int64_t row = it.row, b = it.b, e = it.e;
     const float s_i = a.S[row * a.heads + head];
     const XT* hcol = static_cast<const XT*>(a.H) + (col_ok ? c0 : 0);
 
@@ -194,6 +233,18 @@ __global__ __launch_bounds__(kBlock) void gat_fwd_kernel(const EdgeArgs a, int l
 #pragma unroll
     for (int i = 0; i < EPV; ++i) acc[i] = slot_sum<LPR>(acc[i]);
     den = slot_sum<LPR>(den);
+    if (it.chunk >= 0) {  // partial of a long row: (acc, den, local max) -> workspace, combined by gat_long_finalize_kernel
+        if (slot == 0 && col_ok) {
+            float* w = a.ws + it.chunk * a.ws_ld;
+#pragma unroll
+            for (int i = 0; i < EPV; ++i) w[c0 + i] = acc[i];
+            if ((sub % lph) == 0) {
+                w[a.ws_vec + head] = den;
+                w[a.ws_vec + a.heads + head] = m_i;
+            }
+        }
+        return;
+    }
     if (slot == 0 && col_ok) {
         const float inv = 1.0f / den;  // 0/0 -> NaN for edgeless rows, as gatconv.py:139
 #pragma unroll
@@ -223,10 +274,9 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_rows_kernel(const EdgeArgs a, 
     const int c0 = ((int)blockIdx.y * LPR + sub) * EPV;
     const bool col_ok = c0 < a.feat;
     const int head = col_ok ? c0 / a.fo : 0;
-    const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int64_t row = (int64_t)bid * kWavesPerBlock + wave;
-    if (row >= a.n_rows) return;
-    const int64_t b = uniform64(a.rowptr[row]), e = uniform64(a.rowptr[row + 1]);
+    const WorkItem it = resolve_item(a, wave);
+    if (!it.valid) return;
+    const int64_t row = it.row, b = it.b, e = it.e;
     const float s_i = a.S[row * a.heads + head];
     const float m_i = a.M ? a.M[row * a.heads + head] : 0.0f;
     const float inv_den = 1.0f / a.DEN[row * a.heads + head];
@@ -249,7 +299,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_rows_kernel(const EdgeArgs a, 
             dn[i] = dhp * inv_den;
         }
         dd = -head_sum(part, lph) * inv_den;
-        if (slot == 0 && col_ok) {
+        if (slot == 0 && col_ok && it.first) {   // per-row outputs: written by the row itself or by its first chunk
             VecIO<XT, EPV>::store(static_cast<XT*>(a.Y) + row * a.ldy + c0, dn);
             if ((sub % lph) == 0) a.out_b[row * a.heads + head] = dd;
         }
@@ -293,7 +343,10 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_rows_kernel(const EdgeArgs a, 
         }
     });
     ds = slot_sum<LPR>(ds);
-    if (slot == 0 && col_ok && (sub % lph) == 0) a.out_a[row * a.heads + head] = ds;
+    if (slot == 0 && col_ok && (sub % lph) == 0) {
+        if (it.chunk >= 0) a.ws[it.chunk * a.ws_ld + a.ws_vec + head] = ds;
+        else a.out_a[row * a.heads + head] = ds;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ GAT backward, pass 2 (rows of A^T)
@@ -310,10 +363,9 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_cols_kernel(const EdgeArgs a, 
     const int c0 = ((int)blockIdx.y * LPR + sub) * EPV;
     const bool col_ok = c0 < a.feat;
     const int head = col_ok ? c0 / a.fo : 0;
-    const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int64_t row = (int64_t)bid * kWavesPerBlock + wave;
-    if (row >= a.n_rows) return;
-    const int64_t b = uniform64(a.rowptr[row]), e = uniform64(a.rowptr[row + 1]);
+    const WorkItem it = resolve_item(a, wave);
+    if (!it.valid) return;
+    const int64_t row = it.row, b = it.b, e = it.e;
     const float t_j = a.S[row * a.heads + head];
     float hj[EPV];
     IO::unpack(col_ok ? IO::load(static_cast<const XT*>(a.G) + row * a.ldg + c0) : IO::zero(), hj);
@@ -363,8 +415,60 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_cols_kernel(const EdgeArgs a, 
     for (int i = 0; i < EPV; ++i) acc[i] = slot_sum<LPR>(acc[i]);
     dt = slot_sum<LPR>(dt);
     if (slot == 0 && col_ok) {
-        VecIO<YT, EPV>::store(static_cast<YT*>(a.Y) + row * a.ldy + c0, acc);
-        if ((sub % lph) == 0) a.out_a[row * a.heads + head] = dt;
+        if (it.chunk >= 0) {
+            float* w = a.ws + it.chunk * a.ws_ld;
+#pragma unroll
+            for (int i = 0; i < EPV; ++i) w[c0 + i] = acc[i];
+            if ((sub % lph) == 0) w[a.ws_vec + head] = dt;
+        } else {
+            VecIO<YT, EPV>::store(static_cast<YT*>(a.Y) + row * a.ldy + c0, acc);
+            if ((sub % lph) == 0) a.out_a[row * a.heads + head] = dt;
+        }
+    }
+}
+
+// Second pass for long rows of the three GAT kernels: combine the chunk partials in chunk order.
+//   kind 0 (forward): softmax-merge (local max m_c, denominator d_c, vector v_c): M = max m_c, den = sum d_c e^{m_c-M},
+//                     out = act(sum v_c e^{m_c-M} / den); writes out, rowsum, rowmax
+//   kind 1 (backward rows): out_a[row, head] = sum of scalar partials
+//   kind 2 (backward cols): Y[row, :] = sum of vector partials, out_a[row, head] = sum of scalar partials
+template <typename YT>
+__global__ __launch_bounds__(kBlock) void gat_long_finalize_kernel(const EdgeArgs a, const int64_t* __restrict__ long_row,
+                                                                   const int32_t* __restrict__ long_chunk0, int kind) {
+    const int64_t li = blockIdx.x;
+    const int64_t row = long_row[li];
+    const int cb = long_chunk0[li], ce = long_chunk0[li + 1];
+    for (int f = (int)threadIdx.x; f < a.feat + a.heads; f += kBlock) {
+        const bool vec = f < a.feat;
+        const int head = vec ? f / a.fo : f - a.feat;
+        const int off = vec ? f : a.ws_vec + head;
+        if (kind == 0) {
+            float M = -INFINITY;
+            for (int c = cb; c < ce; ++c) M = fmaxf(M, a.ws[(int64_t)c * a.ws_ld + a.ws_vec + a.heads + head]);
+            float den = 0.0f, v = 0.0f;
+            for (int c = cb; c < ce; ++c) {
+                const float* w = a.ws + (int64_t)c * a.ws_ld;
+                const float sc = __expf(w[a.ws_vec + a.heads + head] - M);
+                den += w[a.ws_vec + head] * sc;
+                if (vec) v += w[f] * sc;
+            }
+            if (vec) {
+                float o = v / den;
+                if (a.apply_elu) o = o > 0.0f ? o : expm1f(o);
+                store_one<YT>(static_cast<YT*>(a.Y) + row * a.ldy + f, o);
+            } else {
+                a.out_a[row * a.heads + head] = den;
+                if (a.out_b) a.out_b[row * a.heads + head] = M;
+            }
+        } else {
+            float sacc = 0.0f;
+            for (int c = cb; c < ce; ++c) sacc += a.ws[(int64_t)c * a.ws_ld + off];
+            if (vec) {
+                if (kind == 2) store_one<YT>(static_cast<YT*>(a.Y) + row * a.ldy + f, sacc);
+            } else {
+                a.out_a[row * a.heads + head] = sacc;
+            }
+        }
     }
 }
 
@@ -483,6 +587,47 @@ DGLL_API int dgll_hip_sddmm_csr(void* stream, const int64_t* rowptr, const int32
     return DGLL_OK;
 }
 
+static int gat_ws_vec(int heads, int fo) { return (heads * fo + 7) & ~7; }
+static int gat_ws_ld(int heads, int fo) { return (gat_ws_vec(heads, fo) + 2 * heads + 7) & ~7; }
+
+DGLL_API size_t dgll_hip_gat_workspace_bytes(const dgll_csr_plan* plan, int heads, int fo) {
+    if (!plan || plan->n_chunks == 0 || heads <= 0 || fo <= 0) return 0;
+    return (size_t)plan->n_chunks * (size_t)gat_ws_ld(heads, fo) * sizeof(float);
+}
+
+// Attach the long-row schedule of `plan` (may be NULL) to the launch arguments and size the grid.
+static int gat_schedule(EdgeArgs& a, const dgll_csr_plan* plan, int64_t n_rows, void* workspace, size_t workspace_bytes,
+                        dim3* grid) {
+    a.threshold = 0; a.n_chunks = 0; a.chunk_blocks = 0; a.ws = nullptr;
+    a.ws_vec = gat_ws_vec(a.heads, a.fo); a.ws_ld = gat_ws_ld(a.heads, a.fo);
+    if (plan) {
+        DGLL_REQUIRE(plan->n_rows == n_rows, "plan was built for a different CSR");
+        a.threshold = plan->threshold;
+        a.n_chunks = plan->n_chunks;
+        a.chunk_begin = plan->d_chunk_begin; a.chunk_end = plan->d_chunk_end; a.chunk_row = plan->d_chunk_row;
+        if (plan->n_chunks > 0) {
+            const size_t need = dgll_hip_gat_workspace_bytes(plan, a.heads, a.fo);
+            if (!workspace || workspace_bytes < need) {
+                set_error("workspace too small for the plan's long-row partials");
+                return DGLL_ERR_WORKSPACE;
+            }
+            a.ws = static_cast<float*>(workspace);
+        }
+        a.chunk_blocks = (uint32_t)((plan->n_chunks + kWavesPerBlock - 1) / kWavesPerBlock);
+    }
+    grid->x = a.chunk_blocks + (uint32_t)((n_rows + kWavesPerBlock - 1) / kWavesPerBlock);
+    return DGLL_OK;
+}
+
+template <typename YT>
+static int gat_finalize(const EdgeArgs& a, const dgll_csr_plan* plan, int kind, hipStream_t s) {
+    if (!plan || plan->n_long == 0) return DGLL_OK;
+    hipLaunchKernelGGL(gat_long_finalize_kernel<YT>, dim3((uint32_t)plan->n_long), dim3(kBlock), 0, s, a, plan->d_long_row,
+                       plan->d_long_chunk0, kind);
+    DGLL_HIP_TRY(hipGetLastError());
+    return DGLL_OK;
+}
+
 static int gat_common(EdgeArgs& a, const int64_t* rowptr, const int32_t* col, int64_t n_rows, int heads, int fo, int dtype,
                       float alpha, int mode, int apply_elu, int* lph, int* lpr, dim3* grid) {
     DGLL_REQUIRE(rowptr && col, "NULL CSR");
@@ -500,10 +645,10 @@ static int gat_common(EdgeArgs& a, const int64_t* rowptr, const int32_t* col, in
     return DGLL_OK;
 }
 
-DGLL_API int dgll_hip_gat_fwd(void* stream, const int64_t* rowptr, const int32_t* col, const void* H, int64_t ldh,
-                              const float* S, const float* T, const float* edge_scale, void* out, int64_t ldo, int dtype,
-                              float* rowsum, float* rowmax, int64_t n_rows, int heads, int fo, float alpha, int apply_elu,
-                              int mode) {
+DGLL_API int dgll_hip_gat_fwd(void* stream, const dgll_csr_plan* plan, const int64_t* rowptr, const int32_t* col,
+                              const void* H, int64_t ldh, const float* S, const float* T, const float* edge_scale, void* out,
+                              int64_t ldo, int dtype, float* rowsum, float* rowmax, int64_t n_rows, int heads, int fo,
+                              float alpha, int apply_elu, int mode, void* workspace, size_t workspace_bytes) {
     if (n_rows <= 0) return DGLL_OK;
     EdgeArgs a{};
     int lph, lpr;
@@ -516,6 +661,8 @@ DGLL_API int dgll_hip_gat_fwd(void* stream, const int64_t* rowptr, const int32_t
     DGLL_REQUIRE(vec_ok(H, ldh, esz) && vec_ok(out, ldo, esz) && ldh >= a.feat && ldo >= a.feat, "H/out must be 16-byte aligned");
     a.H = H; a.ldh = ldh; a.S = S; a.T = T; a.edge_scale = edge_scale; a.Y = out; a.ldy = ldo;
     a.out_a = rowsum; a.out_b = mode == 1 ? rowmax : nullptr;
+    rc = gat_schedule(a, plan, n_rows, workspace, workspace_bytes, &grid);
+    if (rc != DGLL_OK) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
 #define CALL(L)                                                                                                                \
     if (dtype == DGLL_F32) hipLaunchKernelGGL((gat_fwd_kernel<float, float, 4, L, 4>), grid, dim3(kBlock), 0, s, a, lph);      \
@@ -523,10 +670,10 @@ DGLL_API int dgll_hip_gat_fwd(void* stream, const int64_t* rowptr, const int32_t
     DGLL_LPR_SWITCH(lpr, CALL)
 #undef CALL
     DGLL_HIP_TRY(hipGetLastError());
-    return DGLL_OK;
+    return dtype == DGLL_F32 ? gat_finalize<float>(a, plan, 0, s) : gat_finalize<bf16_t>(a, plan, 0, s);
 }
 
-DGLL_API int dgll_hip_gat_bwd(void* stream,
+DGLL_API int dgll_hip_gat_bwd(void* stream, const dgll_csr_plan* plan, const dgll_csr_plan* t_plan,
                               const int64_t* rowptr, const int32_t* col,          /* A   */
                               const int64_t* t_rowptr, const int32_t* t_col, const int64_t* t_perm, /* A^T */
                               const void* H, int64_t ldh, const float* S, const float* T, const float* edge_scale,
@@ -534,7 +681,8 @@ DGLL_API int dgll_hip_gat_bwd(void* stream,
                               const float* rowsum, const float* rowmax,
                               void* dn_scratch, int64_t ldn, float* dd_scratch,
                               void* grad_H, int64_t ldgh, float* grad_S, float* grad_T,
-                              int64_t n_rows, int64_t n_cols, int heads, int fo, float alpha, int apply_elu, int mode) {
+                              int64_t n_rows, int64_t n_cols, int heads, int fo, float alpha, int apply_elu, int mode,
+                              void* workspace, size_t workspace_bytes) {
     if (n_rows <= 0 && n_cols <= 0) return DGLL_OK;
     EdgeArgs a{};
     int lph, lpr;
@@ -553,12 +701,16 @@ DGLL_API int dgll_hip_gat_bwd(void* stream,
     a.H = H; a.ldh = ldh; a.S = S; a.T = T; a.M = mode == 1 ? rowmax : nullptr; a.DEN = rowsum; a.edge_scale = edge_scale;
     a.G = grad_out; a.ldg = ldg; a.O = out; a.ldo = ldo; a.Y = dn_scratch; a.ldy = ldn; a.out_a = grad_S; a.out_b = dd_scratch;
     if (n_rows > 0) {
+        rc = gat_schedule(a, plan, n_rows, workspace, workspace_bytes, &grid);
+        if (rc != DGLL_OK) return rc;
 #define CALL(L)                                                                                                              \
     if (dtype == DGLL_F32) hipLaunchKernelGGL((gat_bwd_rows_kernel<float, 4, L, 4>), grid, dim3(kBlock), 0, s, a, lph);      \
     else hipLaunchKernelGGL((gat_bwd_rows_kernel<bf16_t, 8, L, 4>), grid, dim3(kBlock), 0, s, a, lph);
         DGLL_LPR_SWITCH(lpr, CALL)
 #undef CALL
         DGLL_HIP_TRY(hipGetLastError());
+        rc = gat_finalize<float>(a, plan, 1, s);
+        if (rc != DGLL_OK) return rc;
     }
     // pass 2: rows of A^T
     EdgeArgs t = a;
@@ -566,13 +718,17 @@ DGLL_API int dgll_hip_gat_bwd(void* stream,
     t.H = dn_scratch; t.ldh = ldn; t.G = H; t.ldg = ldh; t.S = T; t.T = S; t.DD = dd_scratch;
     t.Y = grad_H; t.ldy = ldgh; t.out_a = grad_T; t.out_b = nullptr;
     if (n_cols > 0) {
-        dim3 tgrid((uint32_t)((n_cols + kWavesPerBlock - 1) / kWavesPerBlock), grid.y);
+        dim3 tgrid(1, grid.y);
+        rc = gat_schedule(t, t_plan, n_cols, workspace, workspace_bytes, &tgrid);   // the same scratch, used after pass 1
+        if (rc != DGLL_OK) return rc;
 #define CALL(L)                                                                                                                   \
     if (dtype == DGLL_F32) hipLaunchKernelGGL((gat_bwd_cols_kernel<float, float, 4, L, 4>), tgrid, dim3(kBlock), 0, s, t, lph);   \
     else hipLaunchKernelGGL((gat_bwd_cols_kernel<bf16_t, bf16_t, 8, L, 4>), tgrid, dim3(kBlock), 0, s, t, lph);
         DGLL_LPR_SWITCH(lpr, CALL)
 #undef CALL
         DGLL_HIP_TRY(hipGetLastError());
+        rc = dtype == DGLL_F32 ? gat_finalize<float>(t, t_plan, 2, s) : gat_finalize<bf16_t>(t, t_plan, 2, s);
+        if (rc != DGLL_OK) return rc;
     }
     return DGLL_OK;
 }

@@ -26,17 +26,6 @@
 
 #include "common.hpp"
 
-struct dgll_csr_plan {
-    int device = 0;
-    int64_t n_rows = 0, nnz = 0;
-    int threshold = 128;
-    int64_t n_long = 0, n_chunks = 0;
-    int64_t* d_long_row = nullptr;    // [n_long]      row id of each long row (ascending)
-    int32_t* d_long_chunk0 = nullptr; // [n_long + 1]  first chunk of each long row
-    int64_t* d_chunk_begin = nullptr; // [n_chunks]    first edge of the chunk
-    int64_t* d_chunk_end = nullptr;   // [n_chunks]    one past its last edge
-};
-
 namespace dgll {
 
 struct LongRow { int64_t row, begin, end; };
@@ -303,7 +292,7 @@ DGLL_API int dgll_hip_csr_plan_create(void* stream, const int64_t* rowptr, int64
     }
     std::sort(h_list.begin(), h_list.end(), [](const LongRow& x, const LongRow& y) { return x.row < y.row; });
 
-    std::vector<int64_t> long_row(h_count), chunk_begin, chunk_end;
+    std::vector<int64_t> long_row(h_count), chunk_begin, chunk_end, chunk_row;
     std::vector<int32_t> chunk0(h_count + 1, 0);
     for (size_t i = 0; i < h_count; ++i) {
         long_row[i] = h_list[i].row;
@@ -311,6 +300,7 @@ DGLL_API int dgll_hip_csr_plan_create(void* stream, const int64_t* rowptr, int64
         for (int64_t b = h_list[i].begin; b < h_list[i].end; b += p->threshold) {
             chunk_begin.push_back(b);
             chunk_end.push_back(std::min<int64_t>(b + p->threshold, h_list[i].end));
+            chunk_row.push_back(h_list[i].row);
         }
     }
     chunk0[h_count] = (int32_t)chunk_begin.size();
@@ -321,6 +311,8 @@ DGLL_API int dgll_hip_csr_plan_create(void* stream, const int64_t* rowptr, int64
         PLAN_TRY(hipMalloc(&p->d_long_chunk0, sizeof(int32_t) * (h_count + 1)));
         PLAN_TRY(hipMalloc(&p->d_chunk_begin, sizeof(int64_t) * chunk_begin.size()));
         PLAN_TRY(hipMalloc(&p->d_chunk_end, sizeof(int64_t) * chunk_end.size()));
+        PLAN_TRY(hipMalloc(&p->d_chunk_row, sizeof(int64_t) * chunk_row.size()));
+        PLAN_TRY(hipMemcpyAsync(p->d_chunk_row, chunk_row.data(), sizeof(int64_t) * chunk_row.size(), hipMemcpyHostToDevice, s));
         PLAN_TRY(hipMemcpyAsync(p->d_long_row, long_row.data(), sizeof(int64_t) * h_count, hipMemcpyHostToDevice, s));
         PLAN_TRY(hipMemcpyAsync(p->d_long_chunk0, chunk0.data(), sizeof(int32_t) * (h_count + 1), hipMemcpyHostToDevice, s));
         PLAN_TRY(hipMemcpyAsync(p->d_chunk_begin, chunk_begin.data(), sizeof(int64_t) * chunk_begin.size(), hipMemcpyHostToDevice, s));
@@ -350,6 +342,7 @@ DGLL_API void dgll_hip_csr_plan_destroy(dgll_csr_plan* p) {
     if (p->d_long_chunk0) (void)hipFree(p->d_long_chunk0);
     if (p->d_chunk_begin) (void)hipFree(p->d_chunk_begin);
     if (p->d_chunk_end) (void)hipFree(p->d_chunk_end);
+    if (p->d_chunk_row) (void)hipFree(p->d_chunk_row);
     delete p;
 }
 

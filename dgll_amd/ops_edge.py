@@ -123,12 +123,15 @@ class _GatAggregate(torch.autograd.Function):
         rowmax = torch.empty((graph.n_rows, heads), dtype=torch.float32, device=dev) if mode == 1 else None
         if edge_scale is not None:
             edge_scale = edge_scale.to(torch.float32).contiguous()
+        plan = graph.plan()
+        ws_bytes = int(_lib.lib.dgll_hip_gat_workspace_bytes(plan, heads, fo))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
         with torch.cuda.device(dev):
             code = _lib.lib.dgll_hip_gat_fwd(
-                _stream(dev), graph.rowptr.data_ptr(), graph.col.data_ptr(), h.data_ptr(), h.stride(0), s.data_ptr(),
+                _stream(dev), plan, graph.rowptr.data_ptr(), graph.col.data_ptr(), h.data_ptr(), h.stride(0), s.data_ptr(),
                 t.data_ptr(), edge_scale.data_ptr() if edge_scale is not None else None, out.data_ptr(), out.stride(0),
                 _dtype_code(h), rowsum.data_ptr(), rowmax.data_ptr() if rowmax is not None else None, graph.n_rows, heads,
-                fo, float(alpha), int(apply_elu), int(mode))
+                fo, float(alpha), int(apply_elu), int(mode), ws.data_ptr() if ws is not None else None, ws_bytes)
         _lib.check(code, "dgll_hip_gat_fwd")
         ctx.graph, ctx.cfg = graph, (heads, fo, float(alpha), int(apply_elu), int(mode))
         ctx.save_for_backward(h, s, t, edge_scale, out, rowsum, rowmax)
@@ -147,14 +150,19 @@ class _GatAggregate(torch.autograd.Function):
         grad_h = _empty_padded(graph.n_cols, heads * fo, h.dtype, dev)
         grad_s = torch.empty((graph.n_rows, heads), dtype=torch.float32, device=dev)
         grad_t = torch.empty((graph.n_cols, heads), dtype=torch.float32, device=dev)
+        plan, t_plan = graph.plan(), gt.plan()
+        ws_bytes = max(int(_lib.lib.dgll_hip_gat_workspace_bytes(plan, heads, fo)),
+                       int(_lib.lib.dgll_hip_gat_workspace_bytes(t_plan, heads, fo)))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
         with torch.cuda.device(dev):
             code = _lib.lib.dgll_hip_gat_bwd(
-                _stream(dev), graph.rowptr.data_ptr(), graph.col.data_ptr(), gt.rowptr.data_ptr(), gt.col.data_ptr(),
+                _stream(dev), plan, t_plan, graph.rowptr.data_ptr(), graph.col.data_ptr(), gt.rowptr.data_ptr(), gt.col.data_ptr(),
                 perm.data_ptr(), h.data_ptr(), h.stride(0), s.data_ptr(), t.data_ptr(),
                 edge_scale.data_ptr() if edge_scale is not None else None, out.data_ptr(), out.stride(0), g.data_ptr(),
                 g.stride(0), _dtype_code(h), rowsum.data_ptr(), rowmax.data_ptr() if rowmax is not None else None,
                 dn.data_ptr(), dn.stride(0), dd.data_ptr(), grad_h.data_ptr(), grad_h.stride(0), grad_s.data_ptr(),
-                grad_t.data_ptr(), graph.n_rows, graph.n_cols, heads, fo, alpha, apply_elu, mode)
+                grad_t.data_ptr(), graph.n_rows, graph.n_cols, heads, fo, alpha, apply_elu, mode,
+                ws.data_ptr() if ws is not None else None, ws_bytes)
         _lib.check(code, "dgll_hip_gat_bwd")
         return grad_h, grad_s, grad_t, None, None, None, None, None, None, None
 

@@ -97,23 +97,29 @@ int dgll_hip_sddmm_csr(void* stream, const int64_t* rowptr, const int32_t* col,
  * multipliers, applied after the row sum exactly as gatconv.py:129-135 orders them.  rowsum (and rowmax in
  * mode 1) are fp32 [n_rows, heads] outputs kept for the backward pass.  `fo` must make fo*sizeof(dtype)/16 a
  * power of two (the host pads each head with zero columns).                                                */
-int dgll_hip_gat_fwd(void* stream, const int64_t* rowptr, const int32_t* col,
+int dgll_hip_gat_fwd(void* stream, const dgll_csr_plan* plan, const int64_t* rowptr, const int32_t* col,
                      const void* H, int64_t ldh, const float* S, const float* T, const float* edge_scale,
                      void* out, int64_t ldo, int dtype, float* rowsum, float* rowmax,
-                     int64_t n_rows, int heads, int fo, float alpha, int apply_elu, int mode);
+                     int64_t n_rows, int heads, int fo, float alpha, int apply_elu, int mode,
+                     void* workspace, size_t workspace_bytes);
+/* Scratch for the long-row partials of dgll_hip_gat_fwd / _bwd with this plan (0 without long rows). `plan` (and
+ * `t_plan`, the plan of A^T, in the backward) may be NULL: every row is then handled by one wavefront.          */
+size_t dgll_hip_gat_workspace_bytes(const dgll_csr_plan* plan, int heads, int fo);
 
 /* Backward of dgll_hip_gat_fwd: two gather passes (rows of A, then rows of A^T given by t_rowptr/t_col with
  * t_perm[k] = A's edge slot of A^T's k-th edge), nothing stored per edge.  Scratch: dn_scratch
  * [n_rows, ldn] in `dtype`, dd_scratch fp32 [n_rows, heads].  Outputs: grad_H [n_cols, ldgh] in `dtype`,
  * grad_S fp32 [n_rows, heads], grad_T fp32 [n_cols, heads].                                                 */
-int dgll_hip_gat_bwd(void* stream, const int64_t* rowptr, const int32_t* col,
+int dgll_hip_gat_bwd(void* stream, const dgll_csr_plan* plan, const dgll_csr_plan* t_plan,
+                     const int64_t* rowptr, const int32_t* col,
                      const int64_t* t_rowptr, const int32_t* t_col, const int64_t* t_perm,
                      const void* H, int64_t ldh, const float* S, const float* T, const float* edge_scale,
                      const void* out, int64_t ldo, const void* grad_out, int64_t ldg, int dtype,
                      const float* rowsum, const float* rowmax,
                      void* dn_scratch, int64_t ldn, float* dd_scratch,
                      void* grad_H, int64_t ldgh, float* grad_S, float* grad_T,
-                     int64_t n_rows, int64_t n_cols, int heads, int fo, float alpha, int apply_elu, int mode);
+                     int64_t n_rows, int64_t n_cols, int heads, int fo, float alpha, int apply_elu, int mode,
+                     void* workspace, size_t workspace_bytes);   /* >= max of the two plans' workspace bytes */
 
 /* ---- a3 (max): Y[i,f] = max_k X[col[k], f], arg[i,f] = the source row holding it (-1 / 0.0 for empty rows) --
  * NeighborAggregator's "max" (sageconv.py:37-38).  Y and arg share the leading dimension ldy; X/Y 16-byte
