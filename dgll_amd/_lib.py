@@ -54,6 +54,8 @@ SIGNATURES = {
     "dgll_hip_csr_plan_num_chunks": (_i64, [_vp]),
     "dgll_hip_spmm_csr": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _i64, _i32, _i64, _i64, _i32, _i32,
                                  _i32, _vp, _vp, _sz]),
+    "dgll_hip_spmm_csr_ex": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _i64, _i32, _i64, _i64, _i32, _i32,
+                                    _i32, _vp, _vp, _sz, _vp, _i32]),
     "dgll_hip_sddmm_csr": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i32, _vp, _i64, _i32]),
     "dgll_hip_gat_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i64, _i32, _i32,
                                 C.c_float, _i32, _i32, _vp, _sz]),

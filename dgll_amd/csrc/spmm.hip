@@ -61,6 +61,8 @@ struct SpmmArgs {
     uint32_t chunk_blocks, row_blocks;
     int rows_per_wave;
     int flags;  // bit 0: XCD-contiguous row mapping
+    const float* row_scale;   // optional fp32[n_rows]: replaces the reduce's own scale (split adjacencies share one degree)
+    int accumulate;           // add the existing Y row before scaling (Y = scale * (A.X + Y))
 };
 
 // Accumulate edges [b, e) of one row into acc (this lane's EPV columns starting at xcol).
@@ -123,9 +125,18 @@ __device__ __forceinline__ void gather_edges(const int32_t* __restrict__ col, co
     }
 }
 
+template <typename T> __device__ __forceinline__ float load_one(const T* p);
+template <> __device__ __forceinline__ float load_one<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float load_one<bf16_t>(const bf16_t* p) { return bf16_to_f32(*p); }
+
 template <typename YT, int EPV>
 __device__ __forceinline__ void finish_row(YT* __restrict__ y, int c0, int feat, float scale, int epilogue,
-                                           const float* __restrict__ bias, float (&acc)[EPV]) {
+                                           const float* __restrict__ bias, float (&acc)[EPV], int accumulate) {
+    if (accumulate) {
+#pragma unroll
+        for (int i = 0; i < EPV; ++i)
+            if (c0 + i < feat) acc[i] += load_one<YT>(y + c0 + i);
+    }
 #pragma unroll
     for (int i = 0; i < EPV; ++i) {
         float v = acc[i] * scale;
@@ -181,8 +192,9 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_kernel(const SpmmArgs a) {
         for (int i = 0; i < EPV; ++i) acc[i] = 0.0f;
         gather_edges<XT, EPV, LPR, HAS_VAL, U>(a.col, a.val, xcol, a.ldx, b, e, lane, acc);
         if (lane < LPR && col_ok) {
-            const float scale = (a.reduce == DGLL_REDUCE_MEAN && e > b) ? 1.0f / (float)(e - b) : 1.0f;
-            finish_row<YT, EPV>(static_cast<YT*>(a.Y) + row * a.ldy, c0, a.feat, scale, a.epilogue, a.bias, acc);
+            const float scale = a.row_scale ? a.row_scale[row]
+                                            : ((a.reduce == DGLL_REDUCE_MEAN && e > b) ? 1.0f / (float)(e - b) : 1.0f);
+            finish_row<YT, EPV>(static_cast<YT*>(a.Y) + row * a.ldy, c0, a.feat, scale, a.epilogue, a.bias, acc, a.accumulate);
         }
     }
 }
@@ -198,7 +210,9 @@ __global__ __launch_bounds__(kBlock) void spmm_long_finalize_kernel(const SpmmAr
     if (f >= a.feat) return;
     float s = 0.0f;
     for (int c = cb; c < ce; ++c) s += a.ws[(int64_t)c * a.ws_ld + f];
-    if (a.reduce == DGLL_REDUCE_MEAN) s *= 1.0f / (float)(a.rowptr[row + 1] - a.rowptr[row]);
+    if (a.accumulate) s += load_one<YT>(static_cast<const YT*>(a.Y) + row * a.ldy + f);
+    if (a.row_scale) s *= a.row_scale[row];
+    else if (a.reduce == DGLL_REDUCE_MEAN) s *= 1.0f / (float)(a.rowptr[row + 1] - a.rowptr[row]);
     if (a.epilogue & DGLL_EPI_BIAS) s += a.bias[f];
     if (a.epilogue & DGLL_EPI_RELU) s = fmaxf(s, 0.0f);
     store_one<YT>(static_cast<YT*>(a.Y) + row * a.ldy + f, s);
@@ -354,10 +368,32 @@ DGLL_API size_t dgll_hip_csr_plan_workspace_bytes(const dgll_csr_plan* p, int fe
 DGLL_API int64_t dgll_hip_csr_plan_num_long_rows(const dgll_csr_plan* p) { return p ? p->n_long : 0; }
 DGLL_API int64_t dgll_hip_csr_plan_num_chunks(const dgll_csr_plan* p) { return p ? p->n_chunks : 0; }
 
+static int spmm_csr_impl(void* stream, const dgll_csr_plan* plan, const int64_t* rowptr, const int32_t* col,
+                         const float* val, const void* X, int64_t ldx, int x_dtype, void* Y, int64_t ldy,
+                         int y_dtype, int64_t n_rows, int64_t n_cols, int feat, int reduce, int epilogue,
+                         const float* bias, void* workspace, size_t workspace_bytes, const float* row_scale, int accumulate);
+
 DGLL_API int dgll_hip_spmm_csr(void* stream, const dgll_csr_plan* plan, const int64_t* rowptr, const int32_t* col,
                                const float* val, const void* X, int64_t ldx, int x_dtype, void* Y, int64_t ldy,
                                int y_dtype, int64_t n_rows, int64_t n_cols, int feat, int reduce, int epilogue,
                                const float* bias, void* workspace, size_t workspace_bytes) {
+    return spmm_csr_impl(stream, plan, rowptr, col, val, X, ldx, x_dtype, Y, ldy, y_dtype, n_rows, n_cols, feat, reduce,
+                         epilogue, bias, workspace, workspace_bytes, nullptr, 0);
+}
+
+DGLL_API int dgll_hip_spmm_csr_ex(void* stream, const dgll_csr_plan* plan, const int64_t* rowptr, const int32_t* col,
+                                  const float* val, const void* X, int64_t ldx, int x_dtype, void* Y, int64_t ldy,
+                                  int y_dtype, int64_t n_rows, int64_t n_cols, int feat, int reduce, int epilogue,
+                                  const float* bias, void* workspace, size_t workspace_bytes, const float* row_scale,
+                                  int accumulate) {
+    return spmm_csr_impl(stream, plan, rowptr, col, val, X, ldx, x_dtype, Y, ldy, y_dtype, n_rows, n_cols, feat, reduce,
+                         epilogue, bias, workspace, workspace_bytes, row_scale, accumulate);
+}
+
+static int spmm_csr_impl(void* stream, const dgll_csr_plan* plan, const int64_t* rowptr, const int32_t* col,
+                         const float* val, const void* X, int64_t ldx, int x_dtype, void* Y, int64_t ldy,
+                         int y_dtype, int64_t n_rows, int64_t n_cols, int feat, int reduce, int epilogue,
+                         const float* bias, void* workspace, size_t workspace_bytes, const float* row_scale, int accumulate) {
     DGLL_REQUIRE(n_rows >= 0 && n_cols >= 0 && feat >= 0, "negative size");
     if (n_rows == 0 || feat == 0) return DGLL_OK;
     DGLL_REQUIRE(rowptr && X && Y, "NULL rowptr/X/Y");
@@ -379,6 +415,8 @@ DGLL_API int dgll_hip_spmm_csr(void* stream, const dgll_csr_plan* plan, const in
     a.ws_ld = ws_ld_for(feat);
     a.rows_per_wave = 1;
     a.flags = g_tune_flags;
+    a.row_scale = row_scale;
+    a.accumulate = accumulate;
     if (plan) {
         DGLL_REQUIRE(plan->n_rows == n_rows, "plan was built for a different CSR");
         a.threshold = plan->threshold;

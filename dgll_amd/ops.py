@@ -72,9 +72,11 @@ class LaunchTimer:
         return {k: (n, tot / n) for k, (n, tot) in out.items()}
 
 
-def spmm_raw(graph, x, val=None, reduce="sum", bias=None, relu=False, out_dtype=None, out=None):
+def spmm_raw(graph, x, val=None, reduce="sum", bias=None, relu=False, out_dtype=None, out=None, row_scale=None,
+             accumulate=False):
     """Y = epilogue(reduce_j A[i,j] X[j,:]) with no autograd.  `val` overrides graph.val (None = unweighted
-    unless graph.val is set)."""
+    unless graph.val is set).  accumulate: add the rows already in `out` first; row_scale: fp32[n_rows] replacing the
+    reduce's own scale (both used by the partitioned path, dgll_hip_spmm_csr_ex)."""
     _require_cuda(x, graph.rowptr)
     x = _row_major(x)
     if x.shape[0] != graph.n_cols:
@@ -98,11 +100,12 @@ def spmm_raw(graph, x, val=None, reduce="sum", bias=None, relu=False, out_dtype=
     end = timer.start(("spmm", feat, str(x.dtype), val is not None, graph.nnz), x.device) if timer is not None else None
     with torch.cuda.device(x.device):
         stream = torch.cuda.current_stream(x.device).cuda_stream
-        code = _lib.lib.dgll_hip_spmm_csr(
+        code = _lib.lib.dgll_hip_spmm_csr_ex(
             stream, plan, graph.rowptr.data_ptr(), graph.col.data_ptr(), val.data_ptr() if val is not None else None,
             x.data_ptr(), x.stride(0), _dtype_code(x), out.data_ptr(), out.stride(0), _dtype_code(out),
             graph.n_rows, graph.n_cols, feat, _REDUCE[reduce], epi, bias.data_ptr() if bias is not None else None,
-            ws.data_ptr() if ws is not None else None, ws_bytes)
+            ws.data_ptr() if ws is not None else None, ws_bytes,
+            row_scale.data_ptr() if row_scale is not None else None, int(bool(accumulate)))
     if end is not None:
         end.record(torch.cuda.current_stream(x.device))
     _lib.check(code, "dgll_hip_spmm_csr")

@@ -78,6 +78,16 @@ int dgll_hip_spmm_csr(void* stream, const dgll_csr_plan* plan,
                       int reduce, int epilogue, const float* bias,
                       void* workspace, size_t workspace_bytes);
 
+/* Same launch with two extras used by the partitioned (multi-GPU) path, where one destination row's neighbours are
+ * split over an owned-columns CSR and a halo-columns CSR: `accumulate` != 0 adds the row already in Y before the
+ * epilogue (Y = act(scale * (A.X + Y) + bias)); `row_scale` (fp32[n_rows], may be NULL) replaces the reduce's own
+ * 1/nnz(row) so both halves share the full degree.                                                            */
+int dgll_hip_spmm_csr_ex(void* stream, const dgll_csr_plan* plan,
+                         const int64_t* rowptr, const int32_t* col, const float* val,
+                         const void* X, int64_t ldx, int x_dtype, void* Y, int64_t ldy, int y_dtype,
+                         int64_t n_rows, int64_t n_cols, int feat, int reduce, int epilogue, const float* bias,
+                         void* workspace, size_t workspace_bytes, const float* row_scale, int accumulate);
+
 /* ---- a7 backward: edge_out[k] = <G[row(k), :], B[col[k], :]> ------------------------------------------
  * The sampled dense-dense product SpecialSpmmFunction.backward computes through a dense N x N matmul
  * (gatconv.py:76-78).  G and B share `dtype`; both must be 16-byte aligned with leading dimensions padded to

@@ -326,3 +326,32 @@ def test_gemm_f32_kernel(cuda_device):
                                       N, M, N, K, bd.data_ptr(), 1)
     assert code == 0
     np.testing.assert_allclose(C.cpu().numpy(), np.maximum(cref.gemm(A, B, bias), 0), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_spmm_accumulate_and_row_scale(cuda_device, dtype):
+    """dgll_hip_spmm_csr_ex: Y = scale * (A.X + Y_old) -- the two-CSR (owned / halo columns) form of the partitioned
+    path must equal one launch over the union, incl. rows longer than the chunk threshold."""
+    from dgll_amd import ops
+
+    n, feat = 400, 72
+    rowptr, col, _ = np_graph(n, 10, seed=91, heavy_rows=[(7, 380)], empty_rows=[3], weighted=False)
+    x = np.random.default_rng(3).standard_normal((n, feat)).astype(np.float32)
+    if dtype == torch.bfloat16:
+        x = bf16_round(x)
+    full = to_dev(rowptr, col, None, n, cuda_device)
+    xd = torch.from_numpy(x).to(cuda_device).to(dtype)
+    ref = ops.spmm_raw(full, xd, reduce="mean", out_dtype=torch.float32)
+    # split the edges by column parity into two CSRs over the same rows
+    row = np.repeat(np.arange(n), np.diff(rowptr))
+    halves = []
+    for parity in (0, 1):
+        m = (col % 2) == parity
+        ptr = np.zeros(n + 1, np.int64)
+        np.cumsum(np.bincount(row[m], minlength=n), out=ptr[1:])
+        halves.append(to_dev(ptr, col[m], None, n, cuda_device))
+    inv_deg = torch.from_numpy((1.0 / np.maximum(np.diff(rowptr), 1)).astype(np.float32)).to(cuda_device)
+    out = torch.empty(n, feat, device=cuda_device, dtype=torch.float32)
+    ops.spmm_raw(halves[0], xd, out=out)
+    ops.spmm_raw(halves[1], xd, out=out, row_scale=inv_deg, accumulate=True)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol=1e-5)
