@@ -157,7 +157,9 @@ def main():
         full.transpose()[0].plan()
         full.mean_scale_transposed()
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
-    spmm_launches_per_step = 3 + 2   # forward: 3 layers; backward: layers 2 and 3 (the input features need no gradient)
+    # forward: 3 layers; backward: layers 2 and 3 (the input features need no gradient).  The last layer narrows
+    # (256 -> 47), so it aggregates the 47-wide product X.W_n instead of the 256-wide input (mean is linear).
+    spmm_launches_per_step = 3 + 2
 
     def step():
         opt.zero_grad(set_to_none=True)

@@ -99,3 +99,58 @@ class _SageTransform(torch.autograd.Function):
 
 def sage_transform(h, agg, ws, wn, relu):
     return _SageTransform.apply(h, agg, ws, wn, relu)
+
+
+class _Linear(torch.autograd.Function):
+    """x . w with the MFMA kernel in the forward (bf16, N <= 256), library GEMM for dX and split-K for dW."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        wd = w.to(x.dtype)
+        if _mfma_ok(x) and wd.shape[1] <= 256:
+            out = transform_bf16(x, wd.t())
+        else:
+            out = torch.mm(x, wd)
+        ctx.save_for_backward(x, wd)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, wd = ctx.saved_tensors
+        g = g.contiguous()
+        gx = torch.mm(g, wd.t()) if ctx.needs_input_grad[0] else None
+        gw = grad_weight(x, g) if ctx.needs_input_grad[1] else None
+        return gx, gw
+
+
+def linear(x, w):
+    return _Linear.apply(x, w)
+
+
+class _AddLinearAct(torch.autograd.Function):
+    """act(addend + x . w): the self term of a transform-first SAGE layer (the neighbour term arrives already
+    aggregated).  Library addmm, in-place ReLU, split-K weight gradient."""
+
+    @staticmethod
+    def forward(ctx, addend, x, w, relu):
+        wd = w.to(x.dtype)
+        out = torch.addmm(addend, x, wd)
+        if relu:
+            out.relu_()
+        ctx.relu = relu
+        ctx.save_for_backward(x, wd, out if relu else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, wd, out = ctx.saved_tensors
+        if ctx.relu:
+            g = torch.ops.aten.threshold_backward(g.contiguous(), out, 0)
+        g = g.contiguous()
+        gx = torch.mm(g, wd.t()) if ctx.needs_input_grad[1] else None
+        gw = grad_weight(x, g) if ctx.needs_input_grad[2] else None
+        return (g if ctx.needs_input_grad[0] else None), gx, gw, None
+
+
+def add_linear_act(addend, x, w, relu):
+    return _AddLinearAct.apply(addend, x, w, relu)

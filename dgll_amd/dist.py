@@ -297,7 +297,13 @@ class DistGraph:
         """Full-graph GraphSage forward on this rank's rows (x_local in local row order)."""
         h = x_local
         for layer in model.gcn:
-            h = layer.transform_block(h, self.aggregate(h, reduce=layer.aggr_neighbor_method))
+            if layer.transform_first(h):
+                from . import dense
+
+                z = dense.linear(h, layer.neighborAgg.weight)
+                h = layer.finish_transform_first(h, self.aggregate(z, reduce=layer.aggr_neighbor_method))
+            else:
+                h = layer.transform_block(h, self.aggregate(h, reduce=layer.aggr_neighbor_method))
         return h
 
 

@@ -98,6 +98,8 @@ class sageConv(F.nn.Module):
         self.neighborAgg = NeighborAggregator(input_dim, hidden_dim, aggr_method=aggr_neighbor_method)
         self.reset_parameters()
 
+    reorder = True   # allow transform-before-aggregate in forward_block when the layer narrows
+
     def reset_parameters(self):
         F.init.kaiming_uniform_(self.weight)        # sageconv.py:68
 
@@ -120,7 +122,22 @@ class sageConv(F.nn.Module):
         of x_src, the usual block convention)."""
         if x_dst is None:
             x_dst = x_src[:block.n_rows]
+        if self.transform_first(x_src):
+            # mean/sum are linear: reduce(X).W_n == reduce(X.W_n).  When the layer narrows (hidden < input) aggregate
+            # the NARROW product -- fewer bytes per gathered edge in the forward and in the backward gather.
+            z = dense.linear(x_src, self.neighborAgg.weight)
+            return self.finish_transform_first(x_dst, self.neighborAgg.reduce_block(block, z))
         return self.transform_block(x_dst, self.neighborAgg.reduce_block(block, x_src))
+
+    def transform_first(self, x):
+        """Whether forward_block applies W_n before the neighbour reduction (set sageConv.reorder = False to keep the
+        reference's aggregate-then-transform order, sageconv.py:33-41, everywhere)."""
+        return (self.reorder and x.is_cuda and self.hidden_dim < self.input_dim
+                and self.aggr_neighbor_method in ("mean", "sum") and self.aggr_hid_method == "sum"
+                and not self.neighborAgg.use_bias and self.activation in (None, F.relu))
+
+    def finish_transform_first(self, x_dst, reduced_z):
+        return dense.add_linear_act(reduced_z, x_dst, self.weight, self.activation is not None)
 
     def transform_block(self, x_dst, reduced):
         """act(x_dst . weight (+|++) reduced . neighborAgg.weight) given the already aggregated neighbours."""

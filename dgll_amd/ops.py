@@ -138,10 +138,19 @@ class _Spmm(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gt, perm = graph.transpose()
             tval = gt.val if val is None else val.detach()[perm]  # gt.val is the cached permuted graph.val
-            if ctx.reduce == "mean":
+            gin = g
+            if (g.stride(0) * g.element_size()) % 16 or g.data_ptr() % 16:
+                # rows not 16-byte aligned (e.g. a 47-wide gradient): one copy into padded rows keeps the gather on
+                # the vectorised kernel, and the mean's 1/deg(i) is folded into that copy instead of per-edge weights
+                gin = alloc_features(g.shape[0], g.shape[1], g.dtype, g.device, pad_to=8 if g.dtype == torch.bfloat16 else 4)
+                if ctx.reduce == "mean":
+                    torch.mul(g, (1.0 / graph.degrees().clamp(min=1).to(torch.float32)).unsqueeze(1).to(g.dtype), out=gin)
+                else:
+                    gin.copy_(g)
+            elif ctx.reduce == "mean":
                 scale = graph.mean_scale_transposed()  # A^T edge (j <- i) carries 1/deg(i)
                 tval = scale if tval is None else tval * scale
-            grad_x = spmm_raw(gt, g, val=tval, reduce="sum")
+            grad_x = spmm_raw(gt, gin, val=tval, reduce="sum")
         if val is not None and ctx.needs_input_grad[1]:
             from .ops_edge import sddmm_raw
 
