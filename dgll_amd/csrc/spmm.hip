@@ -199,23 +199,38 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_kernel(const SpmmArgs a) {
     }
 }
 
-// Second pass for long rows: sum the chunk partials in chunk order, then the same epilogue.
+// Second pass for long rows: sum the chunk partials in chunk order, then the same epilogue.  One wavefront per long row,
+// four columns per lane (float4 reads of the partials); most long rows have only two or three chunks.
 template <typename YT>
 __global__ __launch_bounds__(kBlock) void spmm_long_finalize_kernel(const SpmmArgs a, const int64_t* __restrict__ long_row,
-                                                                    const int32_t* __restrict__ long_chunk0) {
-    const int64_t li = blockIdx.x;
+                                                                    const int32_t* __restrict__ long_chunk0, int64_t n_long) {
+    const int lane = lane_id();
+    const int64_t li = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (li >= n_long) return;
     const int64_t row = long_row[li];
     const int cb = long_chunk0[li], ce = long_chunk0[li + 1];
-    const int f = (int)(blockIdx.y * kBlock + threadIdx.x);
-    if (f >= a.feat) return;
-    float s = 0.0f;
-    for (int c = cb; c < ce; ++c) s += a.ws[(int64_t)c * a.ws_ld + f];
-    if (a.accumulate) s += load_one<YT>(static_cast<const YT*>(a.Y) + row * a.ldy + f);
-    if (a.row_scale) s *= a.row_scale[row];
-    else if (a.reduce == DGLL_REDUCE_MEAN) s *= 1.0f / (float)(a.rowptr[row + 1] - a.rowptr[row]);
-    if (a.epilogue & DGLL_EPI_BIAS) s += a.bias[f];
-    if (a.epilogue & DGLL_EPI_RELU) s = fmaxf(s, 0.0f);
-    store_one<YT>(static_cast<YT*>(a.Y) + row * a.ldy + f, s);
+    float scale = 1.0f;
+    if (a.row_scale) scale = a.row_scale[row];
+    else if (a.reduce == DGLL_REDUCE_MEAN) scale = 1.0f / (float)(a.rowptr[row + 1] - a.rowptr[row]);
+    YT* y = static_cast<YT*>(a.Y) + row * a.ldy;
+    for (int f = lane * 4; f < a.feat; f += kWave * 4) {   // ws_ld is a multiple of 8 floats: the float4 stays in the row
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int c = cb; c < ce; ++c) {
+            const float4 p = *reinterpret_cast<const float4*>(a.ws + (int64_t)c * a.ws_ld + f);
+            s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+        }
+        float v[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (f + i >= a.feat) continue;
+            float t = v[i];
+            if (a.accumulate) t += load_one<YT>(y + f + i);
+            t *= scale;
+            if (a.epilogue & DGLL_EPI_BIAS) t += a.bias[f + i];
+            if (a.epilogue & DGLL_EPI_RELU) t = fmaxf(t, 0.0f);
+            store_one<YT>(y + f + i, t);
+        }
+    }
 }
 
 static int ws_ld_for(int feat) { return (feat + 7) & ~7; }
@@ -470,11 +485,13 @@ static int spmm_csr_impl(void* stream, const dgll_csr_plan* plan, const int64_t*
     if (err != hipSuccess) return hip_fail(err, "spmm_csr_kernel launch");
 
     if (plan && plan->n_long > 0) {
-        dim3 grid((uint32_t)plan->n_long, (uint32_t)((feat + kBlock - 1) / kBlock));
+        dim3 grid((uint32_t)((plan->n_long + kWavesPerBlock - 1) / kWavesPerBlock));
         if (y_dtype == DGLL_F32)
-            hipLaunchKernelGGL(spmm_long_finalize_kernel<float>, grid, dim3(kBlock), 0, s, a, plan->d_long_row, plan->d_long_chunk0);
+            hipLaunchKernelGGL(spmm_long_finalize_kernel<float>, grid, dim3(kBlock), 0, s, a, plan->d_long_row,
+                               plan->d_long_chunk0, plan->n_long);
         else
-            hipLaunchKernelGGL(spmm_long_finalize_kernel<bf16_t>, grid, dim3(kBlock), 0, s, a, plan->d_long_row, plan->d_long_chunk0);
+            hipLaunchKernelGGL(spmm_long_finalize_kernel<bf16_t>, grid, dim3(kBlock), 0, s, a, plan->d_long_row,
+                               plan->d_long_chunk0, plan->n_long);
         err = hipGetLastError();
         if (err != hipSuccess) return hip_fail(err, "spmm_long_finalize_kernel launch");
     }
