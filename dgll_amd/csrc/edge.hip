@@ -292,8 +292,9 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_rows_kernel(const EdgeArgs a, 
         for (int i = 0; i < EPV; ++i) {
             float dhp = g[i], hp = o[i];
             if (a.apply_elu && o[i] <= 0.0f) {  // out = expm1(hp): elu'(hp) = out + 1, hp = log1p(out)
-                dhp = g[i] * (o[i] + 1.0f);
-                hp = log1pf(o[i]);
+                const float op1 = o[i] + 1.0f;    // saturated ELU (out == -1): gradient 0, and 0 * log(0) must stay 0
+                dhp = g[i] * op1;
+                hp = op1 > 0.0f ? log1pf(o[i]) : 0.0f;
             }
             part = fmaf(dhp, hp, part);
             dn[i] = dhp * inv_den;

@@ -38,7 +38,10 @@ def main():
     if args.graph == "products":
         g = synth.products_like_graph(dev, seed=0, locality=args.locality)
     else:
-        g = synth.rmat_graph(int(args.graph.replace("rmat", "")), 16, seed=0, device=dev, symmetric=False, weighted=False)
+        g = synth.rmat_graph(int(args.graph.replace("rmat", "")), 16, seed=0, device=dev, symmetric=False, weighted=False,
+                             self_loops=True)
+        torch.cuda.empty_cache()
+        print("peak memory while building: %.1f GB" % (torch.cuda.max_memory_allocated() / 1e9), flush=True)
     gw = g.with_values(torch.rand(g.nnz, device=dev))
     deg = g.degrees()
     print("graph %s: n=%d nnz=%d avg_deg=%.1f max_deg=%d long_rows=%d" % (args.graph, g.n_rows, g.nnz, g.nnz / g.n_rows,
