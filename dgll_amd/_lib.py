@@ -68,6 +68,8 @@ SIGNATURES = {
     "dgll_hip_transform_bf16": (_i32, [_vp, _vp, _i64, _i32, _vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _i64,
                                        _i32, _i64, _i32, _i32, _vp]),
     "launch_gcn_fused_kernel": (None, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32]),
+    "launch_gcn_fused_kernel_backward_optimized": (None, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32,
+                                                          _i32, _i32]),
     "dgll_hip_gcn_fused_forward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _sz]),
     "dgll_hip_gcn_fused_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "dgll_hip_segment_max": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i32, _i64, _i32]),

@@ -10,10 +10,11 @@ namespace dgll {
 constexpr int TM = 64, TN = 64, TK = 16;   // 64x64 output tile per 256-thread block, 4x4 outputs per thread
 
 // fp32 LDS-tiled GEMM, fmaf accumulation in k order (bit-stable), optional bias and ReLU epilogue.
+// trans bit 0: A is stored [K, M] (use A^T); bit 1: B is stored [N, K] (use B^T).
 __global__ __launch_bounds__(kBlock) void gemm_f32_kernel(const float* __restrict__ A, int64_t lda,
                                                           const float* __restrict__ B, int64_t ldb,
                                                           float* __restrict__ C, int64_t ldc, int64_t M, int N, int K,
-                                                          const float* __restrict__ bias, int relu) {
+                                                          const float* __restrict__ bias, int relu, int trans) {
     __shared__ float sA[TK][TM + 4];   // stored k-major so the inner product reads are conflict-free
     __shared__ float sB[TK][TN + 4];
     const int tx = threadIdx.x % 16, ty = threadIdx.x / 16;
@@ -24,11 +25,11 @@ __global__ __launch_bounds__(kBlock) void gemm_f32_kernel(const float* __restric
         for (int i = threadIdx.x; i < TM * TK; i += kBlock) {   // A tile: TM rows x TK cols
             const int r = i / TK, c = i % TK;
             const int64_t gm = m0 + r;
-            sA[c][r] = (gm < M && k0 + c < K) ? A[gm * lda + k0 + c] : 0.0f;
+            sA[c][r] = (gm < M && k0 + c < K) ? ((trans & 1) ? A[(int64_t)(k0 + c) * lda + gm] : A[gm * lda + k0 + c]) : 0.0f;
         }
         for (int i = threadIdx.x; i < TK * TN; i += kBlock) {   // B tile: TK rows x TN cols
             const int r = i / TN, c = i % TN;
-            sB[r][c] = (k0 + r < K && n0 + c < N) ? B[(int64_t)(k0 + r) * ldb + n0 + c] : 0.0f;
+            sB[r][c] = (k0 + r < K && n0 + c < N) ? ((trans & 2) ? B[(int64_t)(n0 + c) * ldb + k0 + r] : B[(int64_t)(k0 + r) * ldb + n0 + c]) : 0.0f;
         }
         __syncthreads();
 #pragma unroll
@@ -60,10 +61,10 @@ __global__ __launch_bounds__(kBlock) void gemm_f32_kernel(const float* __restric
 }
 
 int launch_gemm_f32(hipStream_t s, const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
-                    int64_t M, int N, int K, const float* bias, int relu) {
+                    int64_t M, int N, int K, const float* bias, int relu, int trans) {
     if (M <= 0 || N <= 0) return DGLL_OK;
     dim3 grid((uint32_t)((M + TM - 1) / TM), (uint32_t)((N + TN - 1) / TN));
-    hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(kBlock), 0, s, A, lda, B, ldb, C, ldc, M, N, K, bias, relu);
+    hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(kBlock), 0, s, A, lda, B, ldb, C, ldc, M, N, K, bias, relu, trans);
     DGLL_HIP_TRY(hipGetLastError());
     return DGLL_OK;
 }
@@ -78,7 +79,7 @@ DGLL_API int dgll_hip_gemm_f32(void* stream, const float* A, int64_t lda, const 
     if (M == 0 || N == 0) return DGLL_OK;
     DGLL_REQUIRE(A && B && C, "NULL matrix");
     DGLL_REQUIRE(lda >= K && ldb >= N && ldc >= N, "leading dimension too small");
-    return launch_gemm_f32(static_cast<hipStream_t>(stream), A, lda, B, ldb, C, ldc, M, N, K, bias, relu);
+    return launch_gemm_f32(static_cast<hipStream_t>(stream), A, lda, B, ldb, C, ldc, M, N, K, bias, relu, 0);
 }
 
 // =====================================================================================================================

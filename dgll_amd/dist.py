@@ -357,3 +357,46 @@ class RaCoM:
     def all_reduce_and_wait(self):
         self.launch()
         self.wait()
+
+
+class RaCoMOptimizer:
+    """RaCoM's "asynchronous gradient sharing with adaptive periodic synchronisation" (README.md:27,34-37) around any
+    torch optimizer.  step() launches the bucket all-reduce of THIS step's gradients on the RaCoM stream and applies the
+    gradients reduced `staleness` steps ago (a queue, as the reference's gradient_buffer Queue(maxsize=4),
+    buffer_queues.py:76), so communication overlaps the next forward/backward; every `sync_every`-th step (and at
+    flush()) the queue is drained so replicas re-converge.  staleness = 0 is the reference's actual (synchronous)
+    behaviour, MQGCN.py:55-79, and equals DDP."""
+
+    def __init__(self, optimizer, params, device, staleness=1, sync_every=8, group=None):
+        self.opt = optimizer
+        self.params = [p for p in params if p.requires_grad]
+        self.device, self.group = torch.device(device), group
+        self.staleness, self.sync_every = int(staleness), int(sync_every)
+        self.pending = []      # RaCoM objects whose reduction is in flight, oldest first
+        self.free = []
+        self.steps = 0
+
+    def _bucket(self):
+        return self.free.pop() if self.free else RaCoM(self.params, self.device, self.group)
+
+    def _apply_oldest(self):
+        r = self.pending.pop(0)
+        r.wait()               # copies the averaged bucket into .grad
+        self.opt.step()
+        self.free.append(r)
+
+    def step(self):
+        self.steps += 1
+        r = self._bucket()
+        r.launch()
+        self.pending.append(r)
+        drain = self.staleness == 0 or (self.sync_every > 0 and self.steps % self.sync_every == 0)
+        while self.pending and (drain or len(self.pending) > self.staleness):
+            self._apply_oldest()
+
+    def flush(self):
+        while self.pending:
+            self._apply_oldest()
+
+    def zero_grad(self, set_to_none=False):
+        self.opt.zero_grad(set_to_none=set_to_none)

@@ -174,6 +174,13 @@ int dgll_hip_transform_bf16(void* stream, const void* A1, int64_t lda1, int K1, 
 void launch_gcn_fused_kernel(const int* row_ptr, const int* col_idx, const float* values, const float* X, const float* W,
                              float* H, const int* num_neighbors, int N, int F_padded, int actual_F, int H_dim,
                              int total_nnz);
+/* The backward twin with the reference's exact signature (gcn_fused_kernel.cu:238-244).  Computes the gradient of the
+ * forward above -- G = grad_output * (A.X.W > 0), grad_W[:actual_F] = (A.X)^T.G, grad_X[:, :actual_F] = A^T.(G.W^T) --
+ * not the reference kernel's known-wrong arithmetic.  Default stream, synchronous.        */
+void launch_gcn_fused_kernel_backward_optimized(const int* row_ptr, const int* col_idx, const float* values,
+                                                const float* X, const float* W, const float* grad_output,
+                                                float* grad_W, float* grad_X, const int* num_neighbors,
+                                                int N, int F_padded, int actual_F, int H_dim, int total_nnz);
 int dgll_hip_gcn_fused_forward(void* stream, const int32_t* row_ptr, const int32_t* col_idx, const float* values,
                                const float* X, const float* W, float* H, int N, int F_padded, int actual_F, int H_dim,
                                int total_nnz, void* workspace, size_t workspace_bytes);

@@ -75,6 +75,45 @@ def _worker(rank, world, port, weighted, feat):
         dist.destroy_process_group()
 
 
+def _racom_worker(rank, world, port):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dgll_amd import dist as ddist
+
+        def run(staleness, sync_every, steps=6):
+            torch.manual_seed(0)
+            w = torch.nn.Parameter(torch.zeros(4))
+            opt = ddist.RaCoMOptimizer(torch.optim.SGD([w], lr=1.0), [w], "cpu", staleness=staleness, sync_every=sync_every)
+            trace = []
+            for t in range(steps):
+                w.grad = torch.full((4,), float((rank + 1) * (t + 1)))      # rank- and step-dependent gradient
+                opt.step()
+                trace.append(w.detach().clone())
+            opt.flush()
+            return trace, w.detach().clone()
+
+        mean_rank = sum(range(1, world + 1)) / world
+        # staleness 0 == DDP: after step t the weights moved by the mean gradient of every step so far
+        trace, final = run(0, 0)
+        for t, wt in enumerate(trace):
+            assert torch.allclose(wt, torch.full((4,), -mean_rank * sum(range(1, t + 2))))
+        # staleness 1: the update lags one step, flush() applies the rest; the final weights are identical
+        trace1, final1 = run(1, 0)
+        assert torch.allclose(trace1[0], torch.zeros(4))                       # nothing applied yet after step 1
+        assert torch.allclose(trace1[2], torch.full((4,), -mean_rank * 3))      # steps 1 and 2 applied after step 3
+        assert torch.allclose(final1, final)
+        # periodic synchronisation drains the queue
+        trace2, _ = run(1, 3)
+        assert torch.allclose(trace2[2], torch.full((4,), -mean_rank * 6))      # step 3 is a sync step: all three applied
+    finally:
+        dist.destroy_process_group()
+
+
+def test_racom_async_queue_and_periodic_sync():
+    mp.spawn(_racom_worker, args=(2, _free_port()), nprocs=2, join=True)
+
+
 @pytest.mark.parametrize("world,weighted,feat", [(2, False, 12), (2, True, 7), (3, False, 5)])
 def test_partitioned_aggregation_matches_single_process(world, weighted, feat):
     mp.spawn(_worker, args=(world, _free_port(), weighted, feat), nprocs=world, join=True)

@@ -310,6 +310,14 @@ def test_fused_gcn_launcher_vs_oracle(cuda_device, F_padded, actual_F, H):
     (Yd * gout.to(d)).sum().backward()
     np.testing.assert_allclose(Xg.grad.cpu().numpy(), Xt.grad.numpy(), rtol=2e-3, atol=2e-4)
     np.testing.assert_allclose(Wg.grad.cpu().numpy(), Wt.grad.numpy(), rtol=2e-3, atol=2e-3)
+    # the reference's backward symbol (gcn_fused_kernel.cu:238-244), verbatim signature, correct math
+    gW, gX, go = torch.full_like(Wd, 7.0), torch.full_like(Xd, 7.0), gout.to(d).contiguous()
+    torch.cuda.synchronize()
+    _lib.lib.launch_gcn_fused_kernel_backward_optimized(rp.data_ptr(), ci.data_ptr(), va.data_ptr(), Xd.data_ptr(), Wd.data_ptr(),
+                                                        go.data_ptr(), gW.data_ptr(), gX.data_ptr(), nn_.data_ptr(), n, F_padded,
+                                                        actual_F, H, int(ci.numel()))
+    np.testing.assert_allclose(gX.cpu().numpy(), Xt.grad.numpy(), rtol=2e-3, atol=2e-4)
+    np.testing.assert_allclose(gW.cpu().numpy(), Wt.grad.numpy(), rtol=2e-3, atol=2e-3)
 
 
 def test_gemm_f32_kernel(cuda_device):
