@@ -224,6 +224,22 @@ class DistGraph:
             if part.send_reduce is not None:
                 part.send_reduce.plan()
 
+    def verify(self):
+        """Cross-check the locally derived exchange lists across ranks (a mismatch would otherwise hang the first
+        send/recv): every rank must see the same graph, and what r sends to q must be what q expects from r."""
+        if not dist.is_initialized() or self.part.world == 1:
+            return
+        p = self.part
+        comm_dev = self.device if dist.get_backend(self.exchange.group) == "nccl" else torch.device("cpu")
+        mine = torch.tensor(p.send_counts + p.recv_counts + [p.nnz, p.n_own], dtype=torch.int64, device=comm_dev)
+        everyone = [torch.empty_like(mine) for _ in range(p.world)]
+        dist.all_gather(everyone, mine, group=self.exchange.group)
+        for q, row in enumerate(everyone):
+            row = row.tolist()
+            if row[p.world + p.rank] != p.send_counts[q]:
+                raise RuntimeError("halo exchange lists disagree: rank %d sends %d rows to rank %d, which expects %d "
+                                   "(the ranks did not build the same graph)" % (p.rank, p.send_counts[q], q, row[p.world + p.rank]))
+
     # ---- helpers used by DistAggregate
     def _ld(self, feat, dtype):
         epv = 8 if dtype == torch.bfloat16 else 4

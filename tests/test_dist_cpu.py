@@ -55,6 +55,7 @@ def _worker(rank, world, port, weighted, feat):
         assert part.local.n_rows == part.halo.n_rows == part.n_own and part.local.nnz + part.halo.nnz == part.nnz
         assert sum(part.recv_counts) == part.n_halo and part.recv_counts[rank] == 0
         engine = ddist.DistGraph(part, "cpu", spmm_fn=_cpu_spmm)
+        engine.verify()
         blk = slice(part.own_begin, part.own_end)
         h = engine.permute_to_local(x[blk]).clone().requires_grad_()
         out = engine.aggregate(h, reduce="mean")
