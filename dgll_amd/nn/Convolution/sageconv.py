@@ -186,7 +186,10 @@ class GraphSage(F.nn.Module):
     def forward_graph(self, graph, x):
         """Full-graph form (BASELINE configs 3 and 5): every layer aggregates over the whole adjacency `graph`
         (a CSRGraph), h <- layer(h_self = h, neighbours of each node gathered from h)."""
+        from ... import fused_layers
+
         h = x
         for layer in self.gcn:
-            h = layer.forward_block(graph, h, h)
+            out = fused_layers.sage_graph_layer(layer, graph, h)
+            h = layer.forward_block(graph, h, h) if out is None else out
         return h
