@@ -64,6 +64,8 @@ SIGNATURES = {
                                 _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32, C.c_float, _i32,
                                 _i32, _vp, _sz]),
     "dgll_hip_gather_rows": (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp]),
+    "dgll_host_sample_neighbors": (_i32, [_vp, C.POINTER(_i32), _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _i64,
+                                          C.POINTER(_i64)]),
     "dgll_hip_gemm_f32": (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _i32]),
     "dgll_hip_transform_bf16": (_i32, [_vp, _vp, _i64, _i32, _vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _i64,
                                        _i32, _i64, _i32, _i32, _vp]),

@@ -1,0 +1,111 @@
+// sampler.hip -- native (host) neighbour sampler that is BIT-EXACT with the reference's Python sampler.
+//
+// The reference samples with the interpreter's global Mersenne Twister: for every seed node, in order,
+// `random.sample(neighbors, fanout)` when the node has more than `fanout` neighbours, else all of them
+// (/root/reference/dgll/sampling/base_sampler.py:45-58).  BASELINE's north star asks for sampled node/edge IDs that are
+// bit-identical to the reference under `random.seed(s)`.  This file restates, in C++, exactly what CPython 3.10's
+// random.sample does with the generator so that the SAME ids come out ~100x faster:
+//   * MT19937 genrand_uint32 (the generator behind random.getrandbits);
+//   * getrandbits(k) = genrand_uint32() >> (32 - k) for k <= 32;
+//   * _randbelow_with_getrandbits(n): k = n.bit_length(); draw until r < n;
+//   * sample(): n <= setsize -> "pool" algorithm (swap the drawn slot with the last live slot), else rejection
+//     sampling against the set of already selected POSITIONS; setsize = 21 (+ 4**ceil(log(3k, 4)) for k > 5) is
+//     computed by the Python caller with the interpreter's own math so no floating-point corner can differ.
+// The generator state is imported from `random.getstate()` and exported back, so Python code before and after a call
+// sees the stream exactly as if the reference's pure-Python loop had run.  (The algorithm is CPython-version
+// specific; tests/test_sampler.py checks it against the running interpreter and against the goldens.)
+#include <vector>
+
+#include "common.hpp"
+
+namespace {
+
+struct MT19937 {
+    uint32_t* mt;   // 624 words, caller-owned
+    int idx;
+    uint32_t next() {
+        constexpr int N = 624, M = 397;
+        constexpr uint32_t MATRIX_A = 0x9908b0dfU, UPPER = 0x80000000U, LOWER = 0x7fffffffU;
+        if (idx >= N) {
+            int kk;
+            for (kk = 0; kk < N - M; kk++) {
+                uint32_t y = (mt[kk] & UPPER) | (mt[kk + 1] & LOWER);
+                mt[kk] = mt[kk + M] ^ (y >> 1) ^ ((y & 1U) ? MATRIX_A : 0U);
+            }
+            for (; kk < N - 1; kk++) {
+                uint32_t y = (mt[kk] & UPPER) | (mt[kk + 1] & LOWER);
+                mt[kk] = mt[kk + (M - N)] ^ (y >> 1) ^ ((y & 1U) ? MATRIX_A : 0U);
+            }
+            uint32_t y = (mt[N - 1] & UPPER) | (mt[0] & LOWER);
+            mt[N - 1] = mt[M - 1] ^ (y >> 1) ^ ((y & 1U) ? MATRIX_A : 0U);
+            idx = 0;
+        }
+        uint32_t y = mt[idx++];
+        y ^= (y >> 11);
+        y ^= (y << 7) & 0x9d2c5680U;
+        y ^= (y << 15) & 0xefc60000U;
+        y ^= (y >> 18);
+        return y;
+    }
+    // random._randbelow_with_getrandbits for 0 < n < 2**32
+    uint32_t randbelow(uint32_t n) {
+        const int k = 32 - __builtin_clz(n);          // n.bit_length()
+        uint32_t r = next() >> (32 - k);
+        while (r >= n) r = next() >> (32 - k);
+        return r;
+    }
+};
+
+}  // namespace
+
+// One hop of base_sampler.py:45-58 for `n_seeds` seeds over a CSR copy of DGraph.edges (indptr/indices).
+// fanout < 0 means None (take every neighbour).  out_src/out_dst need sum(min(deg, fanout)) slots (`capacity`);
+// out_counts[n_seeds] receives the number of neighbours kept per seed occurrence.
+DGLL_API int dgll_host_sample_neighbors(uint32_t* mt_state, int* mt_index, const int64_t* indptr, const int64_t* indices,
+                                        const int64_t* seeds, int64_t n_seeds, int64_t fanout, int64_t setsize,
+                                        int64_t* out_src, int64_t* out_dst, int64_t* out_counts, int64_t capacity,
+                                        int64_t* n_out) {
+    DGLL_REQUIRE(mt_state && mt_index && indptr && indices && (seeds || n_seeds == 0) && out_counts && n_out, "NULL argument");
+    DGLL_REQUIRE(*mt_index >= 0 && *mt_index <= 624, "bad generator index");
+    MT19937 rng{mt_state, *mt_index};
+    std::vector<int64_t> pool;
+    std::vector<uint8_t> selected;   // position bitmap for the rejection branch
+    int64_t at = 0;
+    for (int64_t s = 0; s < n_seeds; ++s) {
+        const int64_t v = seeds[s];
+        const int64_t* nb = indices + indptr[v];
+        const int64_t n = indptr[v + 1] - indptr[v];
+        int64_t take = (fanout < 0 || n <= fanout) ? n : fanout;
+        if (at + take > capacity) {
+            dgll::set_error("sampler output capacity exceeded");
+            return DGLL_ERR_WORKSPACE;
+        }
+        if (take == n) {                                  // all neighbours, no draw (base_sampler.py:49-54)
+            for (int64_t i = 0; i < n; ++i) { out_src[at + i] = nb[i]; out_dst[at + i] = v; }
+        } else if (n <= setsize) {                        // pool algorithm
+            DGLL_REQUIRE(n < (int64_t)0xffffffff, "degree too large");
+            pool.assign(nb, nb + n);
+            for (int64_t i = 0; i < take; ++i) {
+                const uint32_t j = rng.randbelow((uint32_t)(n - i));
+                out_src[at + i] = pool[j];
+                out_dst[at + i] = v;
+                pool[j] = pool[n - i - 1];
+            }
+        } else {                                          // rejection against the selected positions
+            DGLL_REQUIRE(n < (int64_t)0xffffffff, "degree too large");
+            selected.assign((size_t)n, 0);
+            for (int64_t i = 0; i < take; ++i) {
+                uint32_t j = rng.randbelow((uint32_t)n);
+                while (selected[j]) j = rng.randbelow((uint32_t)n);
+                selected[j] = 1;
+                out_src[at + i] = nb[j];
+                out_dst[at + i] = v;
+            }
+        }
+        out_counts[s] = take;
+        at += take;
+    }
+    *mt_index = rng.idx;
+    *n_out = at;
+    return DGLL_OK;
+}

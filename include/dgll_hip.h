@@ -147,6 +147,16 @@ int dgll_hip_gather_rows(void* stream, const void* cache, int64_t ldc, const voi
                          const int64_t* idx, const int64_t* slot, void* out, int64_t ldo, int64_t n, int feat,
                          int dtype, unsigned long long* miss_count);
 
+/* ---- f1 (host code): one hop of the reference's neighbour sampler, bit-exact with CPython 3.10's random.sample -------
+ * For every seed in order: all neighbours if deg <= fanout (or fanout < 0), else random.sample(neighbors, fanout)
+ * (/root/reference/dgll/sampling/base_sampler.py:45-58), drawn from the MT19937 state passed in (`random.getstate()`:
+ * 624 words + index) and updated in place, so the ids and the generator stream are identical to the Python loop.
+ * indptr/indices: CSR copy of DGraph.edges (HOST pointers, like every argument of this call).  `setsize` is
+ * CPython's pool/set switch-over (21, or 21 + 4**ceil(log(3*fanout, 4)) when fanout > 5), computed by the caller.  */
+int dgll_host_sample_neighbors(uint32_t* mt_state, int* mt_index, const int64_t* indptr, const int64_t* indices,
+                               const int64_t* seeds, int64_t n_seeds, int64_t fanout, int64_t setsize,
+                               int64_t* out_src, int64_t* out_dst, int64_t* out_counts, int64_t capacity, int64_t* n_out);
+
 /* ---- dense transform, exact fp32: C[M,N] = act(A[M,K].B[K,N] + bias) --------------------------------------
  * F.mm / F.matmul of gcnconv.py:30, sageconv.py:41,72, gatconv.py:31,117 for callers that only have the C ABI
  * (fmaf accumulation in k order: bit-stable).  relu != 0 fuses max(.,0); bias may be NULL.                   */

@@ -9,7 +9,7 @@ from conftest import ROOT
 def _declared_functions():
     text = open(os.path.join(ROOT, "include", "dgll_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    names = re.findall(r"\b(dgll_hip_\w+|launch_gcn_fused_kernel\w*)\s*\(", text)
+    names = re.findall(r"\b(dgll_hip_\w+|dgll_host_\w+|launch_gcn_fused_kernel\w*)\s*\(", text)
     assert names, "no declarations parsed"
     return sorted(set(names))
 

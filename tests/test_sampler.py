@@ -44,6 +44,44 @@ def test_sampled_ids_are_bit_exact():
             assert blk.nnz == sg.num_src_nodes() and int(blk.rowptr[-1]) == blk.nnz
 
 
+def test_native_sampler_is_bit_exact_with_the_python_one():
+    """dgll_host_sample_neighbors (C++ MT19937 + CPython's random.sample algorithm) vs the stdlib-driven sampler: same
+    ids AND the same generator state afterwards, through both branches of random.sample (pool and set) and across
+    several fan-outs; then against the reference goldens."""
+    from dgll_amd.sampling import FastNeighborSampler
+
+    rng = np.random.default_rng(0)
+    n = 3000
+    edges = []
+    for v in range(n):
+        deg = int(min(n - 1, rng.zipf(1.3))) if v % 11 else 0        # heavy tail: degrees up to n-1
+        edges.append(rng.choice(n, size=deg, replace=False).tolist())
+    dg = DGraph(nodes=torch.arange(n), edges=edges, labels=torch.zeros(n), features=torch.zeros(n, 1))
+    assert max(len(e) for e in edges) > 1000
+    for seed, fanouts in [(0, [3]), (1, [5, 4]), (2, [6, 25]), (3, [25, 10, 10]), (4, [100, 1])]:
+        seeds = torch.from_numpy(rng.integers(0, n, 200))
+        random.seed(seed)
+        a = DGLLNeighborSampler(fanouts).sample(dg, seeds)
+        state_a = random.getstate()
+        random.seed(seed)
+        b = FastNeighborSampler(fanouts).sample(dg, seeds)
+        assert random.getstate() == state_a                          # the stream was consumed identically
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        for sa, sb in zip(a[2], b[2]):
+            assert torch.equal(sa.src_nodes(), sb.src_nodes()) and torch.equal(sa.dst_nodes(), sb.dst_nodes())
+            assert torch.equal(sa.indptr, sb.indptr)
+    g, gdg = golden_graph()
+    for ci, case in enumerate(g.meta["cases"]):
+        if not case["fanouts"]:
+            continue
+        random.seed(case["seed"])
+        inp, outp, subgs = FastNeighborSampler(case["fanouts"]).sample(gdg, torch.tensor(case["seeds"]))
+        assert torch.equal(inp, g.t("c%d_input_nodes" % ci))
+        for li, sg in enumerate(subgs):
+            assert torch.equal(sg.src_nodes(), g.t("c%d_l%d_src" % (ci, li)))
+            assert torch.equal(sg.dst_nodes(), g.t("c%d_l%d_dst" % (ci, li)))
+
+
 def test_dgraph_queries_match_reference():
     g, dg = golden_graph()
     q = g.t("q_nodes")
