@@ -14,6 +14,7 @@
 // The generator state is imported from `random.getstate()` and exported back, so Python code before and after a call
 // sees the stream exactly as if the reference's pure-Python loop had run.  (The algorithm is CPython-version
 // specific; tests/test_sampler.py checks it against the running interpreter and against the goldens.)
+#include <algorithm>
 #include <vector>
 
 #include "common.hpp"
@@ -69,7 +70,8 @@ DGLL_API int dgll_host_sample_neighbors(uint32_t* mt_state, int* mt_index, const
     DGLL_REQUIRE(*mt_index >= 0 && *mt_index <= 624, "bad generator index");
     MT19937 rng{mt_state, *mt_index};
     std::vector<int64_t> pool;
-    std::vector<uint8_t> selected;   // position bitmap for the rejection branch
+    std::vector<uint32_t> stamp;     // rejection branch: position j is selected iff stamp[j] == epoch (no per-seed clear)
+    uint32_t epoch = 0;
     int64_t at = 0;
     for (int64_t s = 0; s < n_seeds; ++s) {
         const int64_t v = seeds[s];
@@ -93,11 +95,12 @@ DGLL_API int dgll_host_sample_neighbors(uint32_t* mt_state, int* mt_index, const
             }
         } else {                                          // rejection against the selected positions
             DGLL_REQUIRE(n < (int64_t)0xffffffff, "degree too large");
-            selected.assign((size_t)n, 0);
+            if ((size_t)n > stamp.size()) stamp.resize((size_t)n, 0);
+            if (++epoch == 0) { std::fill(stamp.begin(), stamp.end(), 0u); epoch = 1; }
             for (int64_t i = 0; i < take; ++i) {
                 uint32_t j = rng.randbelow((uint32_t)n);
-                while (selected[j]) j = rng.randbelow((uint32_t)n);
-                selected[j] = 1;
+                while (stamp[j] == epoch) j = rng.randbelow((uint32_t)n);
+                stamp[j] = epoch;
                 out_src[at + i] = nb[j];
                 out_dst[at + i] = v;
             }

@@ -1,1 +1,1 @@
-from .dgraph import DGraph  # noqa: F401
+from .dgraph import CSRAdjacency, DGraph  # noqa: F401

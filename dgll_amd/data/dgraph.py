@@ -10,6 +10,24 @@ import torch
 from ..graph import CSRGraph
 
 
+class CSRAdjacency:
+    """List-of-lists view over CSR arrays (numpy int64 indptr / indices): `edges[v]` is node v's neighbour list, as
+    DGraph.edges is in the reference (dgraph.py:33), without materialising a hundred million Python ints."""
+
+    def __init__(self, indptr, indices):
+        self.indptr, self.indices = indptr, indices
+
+    def __len__(self):
+        return len(self.indptr) - 1
+
+    def __getitem__(self, v):
+        return self.indices[self.indptr[v]:self.indptr[v + 1]].tolist()
+
+    def __iter__(self):
+        for v in range(len(self)):
+            yield self[v]
+
+
 class DGraph(object):
     def __init__(self, nodes=None, edges=None, labels=None, features=None, train_mask=None, test_mask=None,
                  validation_mask=None):
@@ -54,6 +72,13 @@ class DGraph(object):
         return self.nodes[self.test_mask]
 
     # ---- additions -----------------------------------------------------------------------------------
+    @classmethod
+    def from_csr(cls, indptr, indices, **kw):
+        """DGraph whose adjacency lists are backed by CSR arrays (numpy int64)."""
+        n = len(indptr) - 1
+        kw.setdefault("nodes", torch.arange(n))
+        return cls(edges=CSRAdjacency(indptr, indices), **kw)
+
     def feature_size(self):
         return int(self.features.shape[1])
 
@@ -62,9 +87,14 @@ class DGraph(object):
 
     def to_csr(self, device="cpu", weighted=False):
         """Whole adjacency as a CSRGraph (row v gathers from edges[v]), optionally with D^-1 weights."""
-        deg = torch.tensor([len(e) for e in self.edges], dtype=torch.int64)
-        rowptr = torch.zeros(len(self.edges) + 1, dtype=torch.int64)
-        torch.cumsum(deg, 0, out=rowptr[1:])
-        col = torch.tensor([u for e in self.edges for u in e], dtype=torch.int32)
+        if isinstance(self.edges, CSRAdjacency):
+            rowptr = torch.from_numpy(self.edges.indptr.astype("int64"))
+            col = torch.from_numpy(self.edges.indices.astype("int32"))
+            deg = rowptr[1:] - rowptr[:-1]
+        else:
+            deg = torch.tensor([len(e) for e in self.edges], dtype=torch.int64)
+            rowptr = torch.zeros(len(self.edges) + 1, dtype=torch.int64)
+            torch.cumsum(deg, 0, out=rowptr[1:])
+            col = torch.tensor([u for e in self.edges for u in e], dtype=torch.int32)
         val = (1.0 / deg.clamp(min=1).float())[torch.repeat_interleave(torch.arange(len(self.edges)), deg)] if weighted else None
         return CSRGraph(rowptr, col, val, len(self.edges), len(self.edges)).to(device)

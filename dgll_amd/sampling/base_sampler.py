@@ -21,7 +21,14 @@ class sugbraph():
         self.src_data = src_data
         self.dst_data = dst_data
         self.indptr = indptr
-        self.graph_nodes = torch.unique(torch.cat((self.src_data, dst_data)))
+        self._graph_nodes = None     # unique(src ++ dst), base_sampler.py:82 -- computed on first use (it costs more than
+                                     # drawing the sample itself on multi-million-edge hops)
+
+    @property
+    def graph_nodes(self):
+        if self._graph_nodes is None:
+            self._graph_nodes = torch.unique(torch.cat((self.src_data, self.dst_data)))
+        return self._graph_nodes
 
     def src_nodes(self):
         return self.src_data

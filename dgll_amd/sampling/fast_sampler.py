@@ -31,6 +31,8 @@ class FastNeighborSampler(Base_sampler):
         self._indptr = self._indices = None
 
     def _csr(self, g):
+        if hasattr(g.edges, "indptr"):           # CSRAdjacency: use the arrays directly
+            return (np.ascontiguousarray(g.edges.indptr, dtype=np.int64), np.ascontiguousarray(g.edges.indices, dtype=np.int64))
         if self._csr_of is not g.edges:
             deg = np.fromiter((len(e) for e in g.edges), dtype=np.int64, count=len(g.edges))
             self._indptr = np.zeros(len(g.edges) + 1, dtype=np.int64)
