@@ -21,7 +21,7 @@ softmax then attends uniformly to ALL nodes; here, as in sparseGatConv, such row
 import os
 
 from ... import backend as F
-from ... import ops
+from ... import dense, ops
 from ...graph import CSRGraph, as_csr_graph
 
 _CHECK_NAN = os.environ.get("DGLL_CHECK_NAN", "0") == "1"
@@ -51,10 +51,16 @@ def _fused_heads(x, adj, Ws, a1s, a2s, alpha, concat, mode, dropout, training):
     """Shared GPU path: Ws [heads][Fin, fo], a1s/a2s [heads][fo] -> [N, heads*fo]."""
     heads, fo = len(Ws), Ws[0].shape[1]
     graph = as_csr_graph(adj)
-    h = F.mm(x, Ws[0] if heads == 1 else F.cat(Ws, dim=1))                     # gatconv.py:31,117 for every head at once
-    hv = h.view(h.shape[0], heads, fo)
-    s = (hv * F.stack(a1s).to(h.dtype)).sum(-1)                                # a[:fo] . h_i
-    t = (hv * F.stack(a2s).to(h.dtype)).sum(-1)                                # a[fo:] . h_j
+    W = (Ws[0] if heads == 1 else F.cat(Ws, dim=1))
+    h = dense.linear(x, W)                                                     # gatconv.py:31,117 for every head at once
+    # per-node scores for every head as ONE skinny GEMM: [N, heads*fo] . blockdiag(a1_k | a2_k) -> [N, 2*heads]
+    # (the reference forms a[:fo].h_i + a[fo:].h_j per edge from a materialised [2*fo, E] matrix, gatconv.py:122-125)
+    A = h.new_zeros(heads * fo, 2 * heads)
+    for k in range(heads):
+        A[k * fo:(k + 1) * fo, k] = a1s[k].to(h.dtype)
+        A[k * fo:(k + 1) * fo, heads + k] = a2s[k].to(h.dtype)
+    st = F.mm(h, A).float()
+    s, t = st[:, :heads], st[:, heads:]
     fo_pad = ops.head_width_padded(fo, h.dtype)
     out = ops.gat_aggregate(graph, _pad_heads(h, heads, fo, fo_pad), s, t, heads, alpha, apply_elu=concat, mode=mode,
                             edge_scale=_attention_dropout(graph, heads, dropout, training, h.device))
