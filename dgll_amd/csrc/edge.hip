@@ -13,6 +13,8 @@
 // neighbour slots, U gathers in flight per lane, a coalesced 64-edge index batch handed out with ds_bpermute,
 // fp32 accumulation, no atomics (fixed reduction order, bit-reproducible).  Nothing per-edge is ever stored:
 // the backward passes recompute e_ij from S and T.
+#include <algorithm>
+
 #include "common.hpp"
 
 namespace dgll {
@@ -52,23 +54,26 @@ struct EdgeArgs {
     float* ws;                  // [n_chunks, ws_ld]: [0, feat) vector partial | [ws_vec, +heads) scalar | [+heads, +2 heads) max
     int ws_ld, ws_vec;
     uint32_t chunk_blocks;
+    int rows_per_wave;          // consecutive rows one wavefront handles before retiring (row items only)
 };
 
 // Work item of this wavefront: a whole (short) row, or one chunk of a long row.
 struct WorkItem {
     int64_t row, b, e, chunk;   // chunk < 0: whole row
-    bool valid, first;          // first: this item starts at the row's first edge (writes the per-row outputs)
-};
+    bool valid, first, done;    // first: the item starts at the row's first edge (writes the per-row outputs);
+};                              // done: nothing more for this wavefront; !valid && !done: skip to the next row
 
-__device__ __forceinline__ WorkItem resolve_item(const EdgeArgs& a, int wave) {
+// r-th item of this wavefront (r < rows_per_wave for row items; chunk items are a single item).
+__device__ __forceinline__ WorkItem resolve_item(const EdgeArgs& a, int wave, int r) {
     WorkItem w;
     w.chunk = -1;
     w.first = true;
+    w.done = false;
     const uint32_t bid = blockIdx.x;
     if (bid < a.chunk_blocks) {
         const int64_t c = __builtin_amdgcn_readfirstlane((int)(bid * kWavesPerBlock + wave));
-        w.valid = c < a.n_chunks;
-        if (!w.valid) { w.row = w.b = w.e = 0; return w; }
+        w.valid = r == 0 && c < a.n_chunks;
+        if (!w.valid) { w.row = w.b = w.e = 0; w.done = true; return w; }
         w.chunk = c;
         w.row = uniform64(a.chunk_row[c]);
         w.b = uniform64(a.chunk_begin[c]);
@@ -76,9 +81,9 @@ __device__ __forceinline__ WorkItem resolve_item(const EdgeArgs& a, int wave) {
         w.first = w.b == uniform64(a.rowptr[w.row]);
         return w;
     }
-    w.row = (int64_t)(bid - a.chunk_blocks) * kWavesPerBlock + wave;
+    w.row = ((int64_t)(bid - a.chunk_blocks) * kWavesPerBlock + wave) * a.rows_per_wave + r;
     w.valid = w.row < a.n_rows;
-    if (!w.valid) { w.b = w.e = 0; return w; }
+    if (!w.valid) { w.b = w.e = 0; w.done = true; return w; }
     w.b = uniform64(a.rowptr[w.row]);
     w.e = uniform64(a.rowptr[w.row + 1]);
     if (a.threshold > 0 && w.e - w.b > a.threshold) w.valid = false;   // handled as chunks
@@ -178,8 +183,10 @@ __global__ __launch_bounds__(kBlock) void gat_fwd_kernel(const EdgeArgs a, int l
     const int c0 = ((int)blockIdx.y * LPR + sub) * EPV;
     const bool col_ok = c0 < a.feat;
     const int head = col_ok ? c0 / a.fo : 0;
-    const WorkItem it = resolve_item(a, wave);
-    if (!it.valid) return;
+  for (int r = 0; r < a.rows_per_wave; ++r) {   // several consecutive rows per wavefront (amortises wave start-up)
+    const WorkItem it = resolve_item(a, wave, r);
+    if (it.done) return;
+    if (!it.valid) continue;
     const int64_t row = it.row, b = it.b, e = it.e;
     const float s_i = a.S[row * a.heads + head];
     const XT* hcol = static_cast<const XT*>(a.H) + (col_ok ? c0 : 0);
@@ -259,6 +266,7 @@ __global__ __launch_bounds__(kBlock) void gat_fwd_kernel(const EdgeArgs a, int l
             if (a.out_b) a.out_b[row * a.heads + head] = m_i;
         }
     }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ GAT backward, pass 1 (rows of A)
@@ -274,8 +282,10 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_rows_kernel(const EdgeArgs a, 
     const int c0 = ((int)blockIdx.y * LPR + sub) * EPV;
     const bool col_ok = c0 < a.feat;
     const int head = col_ok ? c0 / a.fo : 0;
-    const WorkItem it = resolve_item(a, wave);
-    if (!it.valid) return;
+  for (int r = 0; r < a.rows_per_wave; ++r) {   // several consecutive rows per wavefront (amortises wave start-up)
+    const WorkItem it = resolve_item(a, wave, r);
+    if (it.done) return;
+    if (!it.valid) continue;
     const int64_t row = it.row, b = it.b, e = it.e;
     const float s_i = a.S[row * a.heads + head];
     const float m_i = a.M ? a.M[row * a.heads + head] : 0.0f;
@@ -348,6 +358,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_rows_kernel(const EdgeArgs a, 
         if (it.chunk >= 0) a.ws[it.chunk * a.ws_ld + a.ws_vec + head] = ds;
         else a.out_a[row * a.heads + head] = ds;
     }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ GAT backward, pass 2 (rows of A^T)
@@ -364,8 +375,10 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_cols_kernel(const EdgeArgs a, 
     const int c0 = ((int)blockIdx.y * LPR + sub) * EPV;
     const bool col_ok = c0 < a.feat;
     const int head = col_ok ? c0 / a.fo : 0;
-    const WorkItem it = resolve_item(a, wave);
-    if (!it.valid) return;
+  for (int r = 0; r < a.rows_per_wave; ++r) {   // several consecutive rows per wavefront (amortises wave start-up)
+    const WorkItem it = resolve_item(a, wave, r);
+    if (it.done) return;
+    if (!it.valid) continue;
     const int64_t row = it.row, b = it.b, e = it.e;
     const float t_j = a.S[row * a.heads + head];
     float hj[EPV];
@@ -426,6 +439,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_cols_kernel(const EdgeArgs a, 
             if ((sub % lph) == 0) a.out_a[row * a.heads + head] = dt;
         }
     }
+  }
 }
 
 // Second pass for long rows of the three GAT kernels: combine the chunk partials in chunk order.
@@ -598,8 +612,8 @@ DGLL_API size_t dgll_hip_gat_workspace_bytes(const dgll_csr_plan* plan, int head
 
 // Attach the long-row schedule of `plan` (may be NULL) to the launch arguments and size the grid.
 static int gat_schedule(EdgeArgs& a, const dgll_csr_plan* plan, int64_t n_rows, void* workspace, size_t workspace_bytes,
-                        dim3* grid) {
-    a.threshold = 0; a.n_chunks = 0; a.chunk_blocks = 0; a.ws = nullptr;
+                        dim3* grid, int esz) {
+    a.threshold = 0; a.n_chunks = 0; a.chunk_blocks = 0; a.ws = nullptr; a.rows_per_wave = 1;
     a.ws_vec = gat_ws_vec(a.heads, a.fo); a.ws_ld = gat_ws_ld(a.heads, a.fo);
     if (plan) {
         DGLL_REQUIRE(plan->n_rows == n_rows, "plan was built for a different CSR");
@@ -615,8 +629,12 @@ static int gat_schedule(EdgeArgs& a, const dgll_csr_plan* plan, int64_t n_rows, 
             a.ws = static_cast<float*>(workspace);
         }
         a.chunk_blocks = (uint32_t)((plan->n_chunks + kWavesPerBlock - 1) / kWavesPerBlock);
+        // as in spmm.hip: ~96 KiB of gathered bytes per wavefront
+        const double row_bytes = (double)plan->nnz / (double)std::max<int64_t>(n_rows, 1) * a.feat * (double)esz;
+        a.rows_per_wave = std::min(std::max(row_bytes > 0 ? (int)(98304.0 / row_bytes) : 8, 1), 8);
     }
-    grid->x = a.chunk_blocks + (uint32_t)((n_rows + kWavesPerBlock - 1) / kWavesPerBlock);
+    const int64_t waves = (n_rows + a.rows_per_wave - 1) / a.rows_per_wave;
+    grid->x = a.chunk_blocks + (uint32_t)((waves + kWavesPerBlock - 1) / kWavesPerBlock);
     return DGLL_OK;
 }
 
@@ -662,7 +680,7 @@ DGLL_API int dgll_hip_gat_fwd(void* stream, const dgll_csr_plan* plan, const int
     DGLL_REQUIRE(vec_ok(H, ldh, esz) && vec_ok(out, ldo, esz) && ldh >= a.feat && ldo >= a.feat, "H/out must be 16-byte aligned");
     a.H = H; a.ldh = ldh; a.S = S; a.T = T; a.edge_scale = edge_scale; a.Y = out; a.ldy = ldo;
     a.out_a = rowsum; a.out_b = mode == 1 ? rowmax : nullptr;
-    rc = gat_schedule(a, plan, n_rows, workspace, workspace_bytes, &grid);
+    rc = gat_schedule(a, plan, n_rows, workspace, workspace_bytes, &grid, esz);
     if (rc != DGLL_OK) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
 #define CALL(L)                                                                                                                \
@@ -702,11 +720,11 @@ DGLL_API int dgll_hip_gat_bwd(void* stream, const dgll_csr_plan* plan, const dgl
     a.H = H; a.ldh = ldh; a.S = S; a.T = T; a.M = mode == 1 ? rowmax : nullptr; a.DEN = rowsum; a.edge_scale = edge_scale;
     a.G = grad_out; a.ldg = ldg; a.O = out; a.ldo = ldo; a.Y = dn_scratch; a.ldy = ldn; a.out_a = grad_S; a.out_b = dd_scratch;
     if (n_rows > 0) {
-        rc = gat_schedule(a, plan, n_rows, workspace, workspace_bytes, &grid);
+        rc = gat_schedule(a, plan, n_rows, workspace, workspace_bytes, &grid, esz);
         if (rc != DGLL_OK) return rc;
 #define CALL(L)                                                                                                              \
-    if (dtype == DGLL_F32) hipLaunchKernelGGL((gat_bwd_rows_kernel<float, 4, L, 4>), grid, dim3(kBlock), 0, s, a, lph);      \
-    else hipLaunchKernelGGL((gat_bwd_rows_kernel<bf16_t, 8, L, 4>), grid, dim3(kBlock), 0, s, a, lph);
+    if (dtype == DGLL_F32) hipLaunchKernelGGL((gat_bwd_rows_kernel<float, 4, L, 2>), grid, dim3(kBlock), 0, s, a, lph);      \
+    else hipLaunchKernelGGL((gat_bwd_rows_kernel<bf16_t, 8, L, 2>), grid, dim3(kBlock), 0, s, a, lph);
         DGLL_LPR_SWITCH(lpr, CALL)
 #undef CALL
         DGLL_HIP_TRY(hipGetLastError());
@@ -720,11 +738,11 @@ DGLL_API int dgll_hip_gat_bwd(void* stream, const dgll_csr_plan* plan, const dgl
     t.Y = grad_H; t.ldy = ldgh; t.out_a = grad_T; t.out_b = nullptr;
     if (n_cols > 0) {
         dim3 tgrid(1, grid.y);
-        rc = gat_schedule(t, t_plan, n_cols, workspace, workspace_bytes, &tgrid);   // the same scratch, used after pass 1
+        rc = gat_schedule(t, t_plan, n_cols, workspace, workspace_bytes, &tgrid, esz);   // the same scratch, used after pass 1
         if (rc != DGLL_OK) return rc;
 #define CALL(L)                                                                                                                   \
-    if (dtype == DGLL_F32) hipLaunchKernelGGL((gat_bwd_cols_kernel<float, float, 4, L, 4>), tgrid, dim3(kBlock), 0, s, t, lph);   \
-    else hipLaunchKernelGGL((gat_bwd_cols_kernel<bf16_t, bf16_t, 8, L, 4>), tgrid, dim3(kBlock), 0, s, t, lph);
+    if (dtype == DGLL_F32) hipLaunchKernelGGL((gat_bwd_cols_kernel<float, float, 4, L, 2>), tgrid, dim3(kBlock), 0, s, t, lph);   \
+    else hipLaunchKernelGGL((gat_bwd_cols_kernel<bf16_t, bf16_t, 8, L, 2>), tgrid, dim3(kBlock), 0, s, t, lph);
         DGLL_LPR_SWITCH(lpr, CALL)
 #undef CALL
         DGLL_HIP_TRY(hipGetLastError());
