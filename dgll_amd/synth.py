@@ -46,24 +46,51 @@ def build_graph(src, dst, n, symmetric=False, self_loops=True, normalise="row", 
 
     symmetric: add the reverse of every edge; self_loops: add (i, i); normalise: 'row' gives D^-1 A fp32 weights
     (nn/utils/utils.py:240-247), None gives all-ones; weighted=False drops the value array (SAGE mean/sum)."""
+    dev = src.device
     if symmetric:
         src, dst = torch.cat([src, dst]), torch.cat([dst, src])
     if self_loops:
-        loops = torch.arange(n, dtype=torch.int64, device=src.device)
+        loops = torch.arange(n, dtype=torch.int64, device=dev)
         src, dst = torch.cat([src, loops]), torch.cat([dst, loops])
-    key = torch.unique(src * n + dst)            # sorted + coalesced (duplicates dropped, weight 1)
-    row = torch.div(key, n, rounding_mode="floor")
-    col = (key - row * n).to(torch.int32)
-    del key
-    counts = torch.bincount(row, minlength=n)
-    rowptr = torch.zeros(n + 1, dtype=torch.int64, device=src.device)
+    if src.numel() < (1 << 30):
+        key = torch.unique(src * n + dst)        # sorted + coalesced (duplicates dropped, weight 1)
+        row = torch.div(key, n, rounding_mode="floor")
+        col = (key - row * n).to(torch.int32)
+        del key
+        counts = torch.bincount(row, minlength=n)
+    else:
+        # torch.unique is limited to < 2^31 elements: coalesce in source-row blocks (RMAT-27 has 2.3e9 edges) and
+        # concatenate -- the blocks are disjoint and ascending, so the result is the same sorted edge list
+        parts = 4 * (src.numel() >> 30) + 4
+        rows, cols, cnts = [], [], []
+        step = 1 << 28                 # boolean-mask selection is done on slices (torch's mask indexing overflows past 2^31)
+        for p in range(parts):
+            lo, hi = (n * p) // parts, (n * (p + 1)) // parts
+            keys = []
+            for s0 in range(0, src.numel(), step):
+                ss, dd = src[s0:s0 + step], dst[s0:s0 + step]
+                m = (ss >= lo) & (ss < hi)
+                keys.append(ss[m] * n + dd[m])
+            key = torch.unique(torch.cat(keys))
+            del keys
+            r = torch.div(key, n, rounding_mode="floor")
+            cnts.append(torch.bincount(r - lo, minlength=hi - lo))
+            if weighted:
+                rows.append(r)
+            cols.append((key - r * n).to(torch.int32))
+            del key, r
+        del src, dst
+        col, counts = torch.cat(cols), torch.cat(cnts)
+        row = torch.cat(rows) if weighted else None
+        del rows, cols, cnts
+    rowptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
     torch.cumsum(counts, 0, out=rowptr[1:])
     val = None
     if weighted:
         if normalise == "row":
             val = (1.0 / counts.clamp(min=1).to(torch.float32))[row]
         else:
-            val = torch.ones(col.numel(), dtype=torch.float32, device=src.device)
+            val = torch.ones(col.numel(), dtype=torch.float32, device=dev)
     return CSRGraph(rowptr, col, val, n, n, check=False)
 
 

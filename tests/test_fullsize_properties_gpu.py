@@ -79,3 +79,22 @@ def test_gat_attention_is_a_convex_combination(products, cuda_device):
         out = ops.gat_aggregate(g, h, s, t, heads, 0.2, apply_elu=False, mode=mode)
         err = (out.float() - const.unsqueeze(0)).abs().max()
         assert float(err) <= 0.04 * heads, (mode, float(err))      # bf16 output rounding of values up to 8
+
+
+def test_rmat27_int64_rowptr_path_is_exact(cuda_device):
+    """BASELINE config 5 shape on one GPU: RMAT-27, 134 M nodes, 2.26e9 nonzeros (> 2^31: the int64 row-pointer path for
+    real), F = 128 bf16.  mean-aggregating ones is exactly 1 on every row; sum-aggregating ones is the degree."""
+    from dgll_amd import ops, synth
+
+    g = synth.rmat_graph(27, 16, seed=0, device=cuda_device, symmetric=False, weighted=False, self_loops=True)
+    assert g.nnz > 2 ** 31 and g.n_rows == 1 << 27
+    torch.cuda.empty_cache()
+    ones = torch.ones(g.n_cols, 128, device=cuda_device, dtype=torch.bfloat16)
+    y = ops.spmm_raw(g, ones, reduce="mean")
+    assert bool((y == 1).all())
+    del y, ones
+    deg = ops.spmm_raw(g, torch.ones(g.n_cols, 4, device=cuda_device), reduce="sum")[:, 0]
+    small = g.degrees() < (1 << 24)                       # fp32 counts are exact below 2^24
+    assert torch.equal(deg[small].long(), g.degrees()[small])
+    del g, deg
+    torch.cuda.empty_cache()
