@@ -146,6 +146,7 @@ def main():
         x_local.copy_(engine.permute_to_local(feats[part.own_begin:part.own_end]).to(dtype))
         del feats
         labels = engine.permute_to_local(labels_all[part.own_begin:part.own_end])
+        placed_input = engine.place_input_halo(x_local)     # input features of halo nodes live with the partition
         del full
         graph_for_cpu = None
         racom = ddist.RaCoM(model.parameters(), dev)
@@ -169,7 +170,7 @@ def main():
         if engine is None:
             out = model.forward_graph(full, x_local)
         else:
-            out = engine.sage_forward(model, x_local)
+            out = engine.sage_forward(model, x_local, placed_input)
         # cross-entropy summed over this rank's nodes / global node count (x world: RaCoM averages over ranks)
         logp = torch.log_softmax(out.float(), dim=1)
         loss = -logp.gather(1, labels.unsqueeze(1)).sum() * (world / n)

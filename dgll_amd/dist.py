@@ -304,15 +304,44 @@ class DistGraph:
     def aggregate(self, h_own, reduce="mean"):
         return DistAggregate.apply(h_own, self, reduce)
 
+    def place_input_halo(self, x_own):
+        """One-time placement of the halo rows of the INPUT features (they never change: like DistDGL, each partition
+        keeps the features of its halo nodes).  Returns a handle for aggregate_static; no communication afterwards."""
+        p = self.part
+        h_store, h_view = self.rows_of(x_own)
+        send_store = h_store.index_select(0, p.send_idx) if p.send_idx.numel() else h_store[:0]
+        halo_store, halo_view = self.alloc_rows(p.n_halo, x_own.shape[1], x_own.dtype)
+        with self.comm_scope():
+            self.exchange.wait(self.exchange.start(send_store, halo_store))
+        self.join_comm()
+        if self.device.type == "cuda":
+            torch.cuda.current_stream(self.device).synchronize()
+        return (h_view, halo_view)
+
+    def aggregate_static(self, placed, reduce="mean"):
+        """Aggregation of input features whose halo rows were placed once (no gradient flows to raw features)."""
+        p = self.part
+        h_view, halo_view = placed
+        scale = p.inv_deg if reduce == "mean" else None
+        _, out = self.alloc_rows(p.n_own, h_view.shape[1], h_view.dtype)
+        self.spmm(p.local, h_view, out, row_scale=None if p.n_halo else scale)
+        if p.n_halo:
+            self.spmm(p.halo, halo_view, out, row_scale=scale, accumulate=True)
+        return out
+
     def permute_to_local(self, x_block):
         """Rows of this rank's block in global order -> local order (the identity for contiguous partitions; kept as
         the one place a relabelling partitioner would hook in)."""
         return x_block
 
-    def sage_forward(self, model, x_local):
-        """Full-graph GraphSage forward on this rank's rows (x_local in local row order)."""
+    def sage_forward(self, model, x_local, placed_input=None):
+        """Full-graph GraphSage forward on this rank's rows (x_local in local row order).  `placed_input`: handle from
+        place_input_halo(x_local) -- the first layer then needs no exchange."""
         h = x_local
-        for layer in model.gcn:
+        for li, layer in enumerate(model.gcn):
+            if li == 0 and placed_input is not None and not x_local.requires_grad and not layer.transform_first(h):
+                h = layer.transform_block(h, self.aggregate_static(placed_input, reduce=layer.aggr_neighbor_method))
+                continue
             if layer.transform_first(h):
                 from . import dense
 

@@ -62,6 +62,9 @@ def _worker(rank, world, port, weighted, feat):
         np.testing.assert_allclose(out.detach().numpy(), ref.detach()[blk].numpy(), rtol=1e-5, atol=1e-6)  # 1/deg is fp32
         (out * gout[blk]).sum().backward()
         np.testing.assert_allclose(h.grad.numpy(), xr.grad[blk].numpy(), rtol=1e-5, atol=1e-6)
+        # input features: halo rows placed once, then aggregated without communication
+        placed = engine.place_input_halo(x[blk].clone())
+        np.testing.assert_allclose(engine.aggregate_static(placed, "mean").numpy(), ref.detach()[blk].numpy(), rtol=1e-5, atol=1e-6)
 
         # RaCoM: one flattened bucket, averaged (MQGCN.py:63-64)
         w = torch.nn.Parameter(torch.ones(3, 2))
