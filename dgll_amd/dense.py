@@ -26,14 +26,16 @@ def _mfma_ok(*mats):
                              and m.stride(0) % 8 == 0 and m.data_ptr() % 16 == 0) for m in mats)
 
 
-def transform_bf16(a1, wt1, a2=None, wt2=None, relu=False, out_dtype=torch.bfloat16, n_out=None, mask=None, bias=None):
+def transform_bf16(a1, wt1, a2=None, wt2=None, relu=False, out_dtype=torch.bfloat16, n_out=None, mask=None, bias=None,
+                   ld_align=None):
     """out[M, N] = act(a1 . wt1^T (+ a2 . wt2^T)) on the MFMA kernel.  wt*: [N, K] weights (transposed), any float
     dtype; padded here.  a*: bf16 [M, K], 16-byte aligned rows."""
     n = wt1.shape[0] if n_out is None else n_out
     m = a1.shape[0]
     p1 = _pad_wt(wt1)
     p2 = _pad_wt(wt2) if a2 is not None else None
-    ld = -(-n // 8) * 8 if out_dtype == torch.bfloat16 else -(-n // 4) * 4
+    ld_align = ld_align or (8 if out_dtype == torch.bfloat16 else 4)
+    ld = -(-n // ld_align) * ld_align
     store = torch.empty((m, ld), dtype=out_dtype, device=a1.device)
     out = store[:, :n] if ld != n else store
     if bias is not None:
@@ -108,7 +110,8 @@ class _Linear(torch.autograd.Function):
     def forward(ctx, x, w):
         wd = w.to(x.dtype)
         if _mfma_ok(x) and wd.shape[1] <= 256:
-            out = transform_bf16(x, wd.t())
+            # narrow outputs feed a gather: give every row its own 128-byte line (a 94-byte row would straddle two)
+            out = transform_bf16(x, wd.t(), ld_align=64 if wd.shape[1] < 64 else None)
         else:
             out = torch.mm(x, wd)
         ctx.save_for_backward(x, wd)

@@ -59,7 +59,9 @@ class _SageGraphLayerTransformFirst(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h, ws, wn, graph, reduce, relu):
         wsd, wnd = ws.to(h.dtype), wn.to(h.dtype)
-        z = dense.transform_bf16(h, wnd.t()) if (dense._mfma_ok(h) and wn.shape[1] <= 256) else torch.mm(h, wnd)
+        # the narrow product is gathered next: one 128-byte line per row (ld_align) instead of rows straddling two lines
+        z = (dense.transform_bf16(h, wnd.t(), ld_align=64 if wn.shape[1] < 64 else None)
+             if (dense._mfma_ok(h) and wn.shape[1] <= 256) else torch.mm(h, wnd))
         out = torch.addmm(ops.spmm_raw(graph, z, reduce=reduce), h, wsd)
         if relu:
             out.relu_()
@@ -75,7 +77,8 @@ class _SageGraphLayerTransformFirst(torch.autograd.Function):
         if ctx.relu:
             g = torch.ops.aten.threshold_backward(g, out, 0)
         # d/dz of reduce_A(z): A^T . g (1/deg folded into the padded copy of the narrow gradient)
-        gp = ops.alloc_features(g.shape[0], g.shape[1], g.dtype, g.device, pad_to=8 if g.dtype == torch.bfloat16 else 4)
+        line = 128 // g.element_size()
+        gp = ops.alloc_features(g.shape[0], g.shape[1], g.dtype, g.device, pad_to=line if g.shape[1] < line else (16 // g.element_size()))
         if ctx.reduce == "mean":
             torch.mul(g, (1.0 / graph.degrees().clamp(min=1).to(torch.float32)).unsqueeze(1).to(g.dtype), out=gp)
         else:

@@ -142,7 +142,9 @@ class _Spmm(torch.autograd.Function):
             if (g.stride(0) * g.element_size()) % 16 or g.data_ptr() % 16:
                 # rows not 16-byte aligned (e.g. a 47-wide gradient): one copy into padded rows keeps the gather on
                 # the vectorised kernel, and the mean's 1/deg(i) is folded into that copy instead of per-edge weights
-                gin = alloc_features(g.shape[0], g.shape[1], g.dtype, g.device, pad_to=8 if g.dtype == torch.bfloat16 else 4)
+                line = 128 // g.element_size()      # narrow rows: one 128-byte line each
+                gin = alloc_features(g.shape[0], g.shape[1], g.dtype, g.device,
+                                     pad_to=line if g.shape[1] < line else 16 // g.element_size())
                 if ctx.reduce == "mean":
                     torch.mul(g, (1.0 / graph.degrees().clamp(min=1).to(torch.float32)).unsqueeze(1).to(g.dtype), out=gin)
                 else:
