@@ -19,7 +19,7 @@ OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libdgll_hip.so")
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
-         "-ffp-contract=fast"]
+         "-ffp-contract=fast", "-pthread"]
 
 
 def _hipcc():
@@ -92,7 +92,7 @@ def build(force=False, verbose=False):
         results = list(ex.map(compile_one, srcs))
     objs = [o for o, _ in results]
     if force or any(ch for _, ch in results) or not os.path.exists(LIB) or os.path.getmtime(LIB) < _newest(objs):
-        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-pthread", "-o", LIB] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         res = subprocess.run(cmd, capture_output=True, text=True)

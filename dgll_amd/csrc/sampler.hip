@@ -15,6 +15,7 @@
 // sees the stream exactly as if the reference's pure-Python loop had run.  (The algorithm is CPython-version
 // specific; tests/test_sampler.py checks it against the running interpreter and against the goldens.)
 #include <algorithm>
+#include <thread>
 #include <vector>
 
 #include "common.hpp"
@@ -62,6 +63,12 @@ struct MT19937 {
 // One hop of base_sampler.py:45-58 for `n_seeds` seeds over a CSR copy of DGraph.edges (indptr/indices).
 // fanout < 0 means None (take every neighbour).  out_src/out_dst need sum(min(deg, fanout)) slots (`capacity`);
 // out_counts[n_seeds] receives the number of neighbours kept per seed occurrence.
+//
+// Two phases.  (1) SEQUENTIAL, in seed order: consume the generator exactly as random.sample does and record, for every
+// kept neighbour, its POSITION in the seed's adjacency list -- the pool algorithm is run on positions (pool[j] starts
+// as j), which selects the same elements as running it on the values.  This phase touches only the generator, the
+// degree of each seed and a small scratch array, so it is cache-resident.  (2) PARALLEL (std::thread): translate positions to
+// neighbour ids, the memory-bound part (random reads into a multi-hundred-megabyte index array).
 DGLL_API int dgll_host_sample_neighbors(uint32_t* mt_state, int* mt_index, const int64_t* indptr, const int64_t* indices,
                                         const int64_t* seeds, int64_t n_seeds, int64_t fanout, int64_t setsize,
                                         int64_t* out_src, int64_t* out_dst, int64_t* out_counts, int64_t capacity,
@@ -69,28 +76,29 @@ DGLL_API int dgll_host_sample_neighbors(uint32_t* mt_state, int* mt_index, const
     DGLL_REQUIRE(mt_state && mt_index && indptr && indices && (seeds || n_seeds == 0) && out_counts && n_out, "NULL argument");
     DGLL_REQUIRE(*mt_index >= 0 && *mt_index <= 624, "bad generator index");
     MT19937 rng{mt_state, *mt_index};
-    std::vector<int64_t> pool;
+    std::vector<uint32_t> pool;      // pool algorithm, on positions
     std::vector<uint32_t> stamp;     // rejection branch: position j is selected iff stamp[j] == epoch (no per-seed clear)
     uint32_t epoch = 0;
+    std::vector<int64_t> offset((size_t)n_seeds + 1, 0);
+    // ---- phase 1: positions (stored in out_src for now)
     int64_t at = 0;
     for (int64_t s = 0; s < n_seeds; ++s) {
         const int64_t v = seeds[s];
-        const int64_t* nb = indices + indptr[v];
         const int64_t n = indptr[v + 1] - indptr[v];
-        int64_t take = (fanout < 0 || n <= fanout) ? n : fanout;
+        const int64_t take = (fanout < 0 || n <= fanout) ? n : fanout;
         if (at + take > capacity) {
             dgll::set_error("sampler output capacity exceeded");
             return DGLL_ERR_WORKSPACE;
         }
         if (take == n) {                                  // all neighbours, no draw (base_sampler.py:49-54)
-            for (int64_t i = 0; i < n; ++i) { out_src[at + i] = nb[i]; out_dst[at + i] = v; }
+            for (int64_t i = 0; i < n; ++i) out_src[at + i] = i;
         } else if (n <= setsize) {                        // pool algorithm
             DGLL_REQUIRE(n < (int64_t)0xffffffff, "degree too large");
-            pool.assign(nb, nb + n);
+            pool.resize((size_t)n);
+            for (int64_t i = 0; i < n; ++i) pool[i] = (uint32_t)i;
             for (int64_t i = 0; i < take; ++i) {
                 const uint32_t j = rng.randbelow((uint32_t)(n - i));
                 out_src[at + i] = pool[j];
-                out_dst[at + i] = v;
                 pool[j] = pool[n - i - 1];
             }
         } else {                                          // rejection against the selected positions
@@ -101,14 +109,36 @@ DGLL_API int dgll_host_sample_neighbors(uint32_t* mt_state, int* mt_index, const
                 uint32_t j = rng.randbelow((uint32_t)n);
                 while (stamp[j] == epoch) j = rng.randbelow((uint32_t)n);
                 stamp[j] = epoch;
-                out_src[at + i] = nb[j];
-                out_dst[at + i] = v;
+                out_src[at + i] = j;
             }
         }
         out_counts[s] = take;
+        offset[s] = at;
         at += take;
     }
+    offset[n_seeds] = at;
     *mt_index = rng.idx;
     *n_out = at;
+    // ---- phase 2: positions -> neighbour ids, destination ids
+    auto translate = [&](int64_t s0, int64_t s1) {
+        for (int64_t s = s0; s < s1; ++s) {
+            const int64_t v = seeds[s];
+            const int64_t* nb = indices + indptr[v];
+            for (int64_t k = offset[s]; k < offset[s + 1]; ++k) {
+                out_src[k] = nb[out_src[k]];
+                out_dst[k] = v;
+            }
+        }
+    };
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int64_t n_threads = at < (1 << 16) ? 1 : std::min<int64_t>(hw ? hw : 1, 16);
+    if (n_threads <= 1) {
+        translate(0, n_seeds);
+    } else {   // plain std::thread (no OpenMP runtime next to torch's): contiguous seed ranges, disjoint output ranges
+        std::vector<std::thread> workers;
+        for (int64_t t = 0; t < n_threads; ++t)
+            workers.emplace_back(translate, n_seeds * t / n_threads, n_seeds * (t + 1) / n_threads);
+        for (auto& w : workers) w.join();
+    }
     return DGLL_OK;
 }
