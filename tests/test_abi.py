@@ -61,3 +61,41 @@ def test_ops_refuse_cpu_tensors():
     g = dgll_amd.CSRGraph.from_coo(torch.tensor([0, 1]), torch.tensor([1, 0]), None, (2, 2))
     with pytest.raises(RuntimeError):
         ops.spmm(g, torch.ones(2, 4))
+
+
+def _compile_c_client(tmp_path):
+    import shutil
+    import subprocess
+
+    from dgll_amd import _lib
+
+    exe = str(tmp_path / "spmm_smoke")
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cmd = [shutil.which("gcc") or "gcc", "-std=c99", "-Wall", os.path.join(ROOT, "tests", "c_abi", "spmm_smoke.c"),
+           "-I", os.path.join(ROOT, "include"), "-I", os.path.join(rocm, "include"), "-D__HIP_PLATFORM_AMD__",
+           "-L", libdir, "-ldgll_hip", "-L", os.path.join(rocm, "lib"), "-lamdhip64",
+           "-Wl,-rpath," + libdir, "-Wl,-rpath," + os.path.join(rocm, "lib"), "-lm", "-o", exe]
+    subprocess.run(cmd, check=True, capture_output=True, text=True)
+    return exe
+
+
+def test_header_is_plain_c_and_a_c_client_links(tmp_path):
+    """include/dgll_hip.h compiles as C99 and a C program links against libdgll_hip.so (no Python, no torch types)."""
+    import subprocess
+
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", os.path.join(ROOT, "include", "dgll_hip.h")],
+                   check=True, capture_output=True)
+    assert os.path.exists(_compile_c_client(tmp_path))
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_c_client_runs_on_the_gpu(tmp_path):
+    import subprocess
+
+    res = subprocess.run([_compile_c_client(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "c abi smoke ok" in res.stdout
