@@ -155,7 +155,7 @@ __global__ __launch_bounds__(kBlock) void sddmm_kernel(const EdgeArgs a) {
             for (int u = 0; u < U; ++u) {
                 idx[u] = j + u * SLOTS + slot;
                 const int c = __shfl(cur_col, idx[u] < nb ? idx[u] : nb - 1);
-                v[u] = IO::load(hcol + (int64_t)c * a.ldh);
+                v[u] = IO::load(hcol + (uint64_t)(uint32_t)c * (uint32_t)a.ldh);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(kBlock) void gat_fwd_kernel(const EdgeArgs a, int l
                 const int c = __shfl(cur_col, idx[u]);
                 t[u] = a.T[(int64_t)c * a.heads + head];
                 sc[u] = a.edge_scale ? a.edge_scale[(k0 + idx[u]) * a.heads + head] : 1.0f;
-                v[u] = IO::load(hcol + (int64_t)c * a.ldh);
+                v[u] = IO::load(hcol + (uint64_t)(uint32_t)c * (uint32_t)a.ldh);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_rows_kernel(const EdgeArgs a, 
                 const int c = __shfl(cur_col, idx[u]);
                 t[u] = a.T[(int64_t)c * a.heads + head];
                 sc[u] = a.edge_scale ? a.edge_scale[(k0 + idx[u]) * a.heads + head] : 1.0f;
-                v[u] = IO::load(hcol + (int64_t)c * a.ldh);
+                v[u] = IO::load(hcol + (uint64_t)(uint32_t)c * (uint32_t)a.ldh);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_cols_kernel(const EdgeArgs a, 
                 m[u] = a.M ? a.M[c * a.heads + head] : 0.0f;
                 dd[u] = a.DD[c * a.heads + head];
                 sc[u] = a.edge_scale ? a.edge_scale[a.perm[k0 + idx[u]] * a.heads + head] : 1.0f;
-                v[u] = IO::load(dncol + c * a.ldh);
+                v[u] = IO::load(dncol + (uint64_t)(uint32_t)c * (uint32_t)a.ldh);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(kBlock) void segment_max_kernel(const EdgeArgs a) {
                 const int idx = j + u * SLOTS + slot;
                 ok[u] = idx < nb;
                 c[u] = __shfl(cur_col, ok[u] ? idx : nb - 1);
-                v[u] = IO::load(hcol + (int64_t)c[u] * a.ldh);
+                v[u] = IO::load(hcol + (uint64_t)(uint32_t)c[u] * (uint32_t)a.ldh);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {

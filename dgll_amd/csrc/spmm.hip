@@ -91,9 +91,33 @@ __device__ __forceinline__ void gather_edges(const int32_t* __restrict__ col, co
             my_col = __builtin_nontemporal_load(col + kn);
             if (HAS_VAL) my_val = __builtin_nontemporal_load(val + kn);
         }
-        for (int j = 0; j < nb; j += SLOTS * U) {
-            // All U gathers are issued back to back with no branch in between: an out-of-range slot re-reads the
-            // batch's last valid edge (same cache lines as a live request) and is zeroed after the load.
+        // Row offsets are formed with ONE 32x32->64 multiply (v_mad_u64_u32): column ids and the leading dimension both
+        // fit 32 bits.  Full rounds need no masking; only the last, partial round clamps and zeroes its idle slots.
+        const uint32_t ld32 = (uint32_t)ldx;
+        int j = 0;
+        for (; j + SLOTS * U <= nb; j += SLOTS * U) {
+            int c[U];
+            float w[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int src = j + u * SLOTS + slot;
+                c[u] = __shfl(cur_col, src);
+                w[u] = HAS_VAL ? __shfl(cur_val, src) : 1.0f;
+            }
+            typename IO::raw_t v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = IO::load(xcol + (uint64_t)(uint32_t)c[u] * ld32);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float f[EPV];
+                IO::unpack(v[u], f);
+#pragma unroll
+                for (int i = 0; i < EPV; ++i) acc[i] = HAS_VAL ? fmaf(w[u], f[i], acc[i]) : acc[i] + f[i];
+            }
+        }
+        if (j < nb) {
+            // the U gathers are still issued back to back with no branch in between: an out-of-range slot re-reads the
+            // batch's last valid edge (same cache lines as a live request) and is zeroed after the load
             int c[U];
             float w[U];
             bool ok[U];
@@ -107,7 +131,7 @@ __device__ __forceinline__ void gather_edges(const int32_t* __restrict__ col, co
             }
             typename IO::raw_t v[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) v[u] = IO::load(xcol + (int64_t)c[u] * ldx);
+            for (int u = 0; u < U; ++u) v[u] = IO::load(xcol + (uint64_t)(uint32_t)c[u] * ld32);
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 float f[EPV];
@@ -413,6 +437,7 @@ static int spmm_csr_impl(void* stream, const dgll_csr_plan* plan, const int64_t*
     if (n_rows == 0 || feat == 0) return DGLL_OK;
     DGLL_REQUIRE(rowptr && X && Y, "NULL rowptr/X/Y");
     DGLL_REQUIRE(ldx >= feat && ldy >= feat, "leading dimension smaller than feat");
+    DGLL_REQUIRE(ldx < ((int64_t)1 << 31) && n_cols < ((int64_t)1 << 31), "leading dimension / column count must fit 31 bits");
     DGLL_REQUIRE(x_dtype == DGLL_F32 || x_dtype == DGLL_BF16, "x_dtype");
     DGLL_REQUIRE(y_dtype == DGLL_F32 || y_dtype == DGLL_BF16, "y_dtype");
     DGLL_REQUIRE(reduce == DGLL_REDUCE_SUM || reduce == DGLL_REDUCE_MEAN, "reduce");
