@@ -102,7 +102,7 @@ DGLL_API int dgll_hip_gemm_f32(void* stream, const float* A, int64_t lda, const 
 //     (conflict-free ds_read_b128); it is re-read from L2 per 128-row block (the weights are tiny and stay resident);
 //   * the reduction index inside a 64-k chunk is permuted (lane half h takes k = 32h + 8kk + j) so each lane's four
 //     16-byte activation loads per chunk are one contiguous 64-byte run; A and B use the same permutation.
-// Wt must be zero-padded by the host to [32*NT rows, ceil(K/64)*64 columns]; activations need no padding (tail
+// Wt must be zero-padded by the host to [32*NT rows (NT = 2, 4 or 8: 64 / 128 / 256), ceil(K/64)*64 columns]; activations need no padding (tail
 // vectors are masked element-wise, so uninitialised pad columns can never inject NaNs).
 namespace dgll {
 

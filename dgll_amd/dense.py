@@ -14,9 +14,11 @@ _SLABS = 256
 
 
 def _pad_wt(wt):
-    """[N, K] -> zero-padded bf16 [32*ceil(N/32), 64*ceil(K/64)] as dgll_hip_transform_bf16 wants its weights."""
+    """[N, K] -> zero-padded bf16 [64 | 128 | 256 rows, 64*ceil(K/64) columns] as dgll_hip_transform_bf16 wants its
+    weights (the kernel is instantiated for 2, 4 or 8 column tiles of 32 and stages that many rows)."""
     n, k = wt.shape
-    out = torch.zeros((-(-n // 32) * 32, -(-k // 64) * 64), dtype=torch.bfloat16, device=wt.device)
+    rows = 64 if n <= 64 else 128 if n <= 128 else 256
+    out = torch.zeros((rows, -(-k // 64) * 64), dtype=torch.bfloat16, device=wt.device)
     out[:n, :k] = wt
     return out
 

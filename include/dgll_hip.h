@@ -168,7 +168,8 @@ int dgll_hip_gemm_f32(void* stream, const float* A, int64_t lda, const float* B,
  * sageConv's act(src.W_s + agg.W_n) in ONE pass (sageconv.py:71-82), gcnConv / GAT x.W (gcnconv.py:30,
  * gatconv.py:31,117), and their input gradients g.W^T (pass Wt := W; `relu_mask`, same shape as A1, fuses the
  * ReLU backward: A1 is zeroed where the mask is <= 0).  A*: bf16 row-major, 16-byte aligned, lda a multiple of 8.
- * Wt*: the weight TRANSPOSED, bf16 [>= 32*ceil(N/32) rows, ld >= 64*ceil(K/64)], zero padded.  N <= 256.
+ * Wt*: the weight TRANSPOSED, bf16, zero padded to [64 rows if N <= 64, 128 if N <= 128, else 256] x
+ * [ld >= 64*ceil(K/64) columns] (the kernel stages 2, 4 or 8 column tiles of 32 rows of Wt).  N <= 256.
  * out: bf16 or fp32 [M, ldo].  A2/Wt2/relu_mask/bias may be NULL.                                              */
 int dgll_hip_transform_bf16(void* stream, const void* A1, int64_t lda1, int K1, const void* Wt1, int64_t ldw1,
                             const void* A2, int64_t lda2, int K2, const void* Wt2, int64_t ldw2,

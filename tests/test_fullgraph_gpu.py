@@ -102,7 +102,8 @@ def test_split_k_weight_gradient(cuda_device):
 
 
 @pytest.mark.parametrize("M,K1,K2,N,relu", [(1000, 256, 256, 256, True), (777, 100, 100, 256, True), (513, 256, 256, 47, False),
-                                            (130, 64, 0, 128, False), (4097, 40, 24, 33, True), (128, 256, 0, 256, False)])
+                                            (130, 64, 0, 128, False), (4097, 40, 24, 33, True), (128, 256, 0, 256, False),
+                                            (3000, 64, 0, 10, False), (500, 40, 40, 64, True), (77, 8, 0, 1, False)])
 def test_mfma_transform_kernel(cuda_device, M, K1, K2, N, relu):
     """dgll_hip_transform_bf16 (v_mfma_f32_32x32x16_bf16) vs an fp32 matmul of the same bf16-rounded operands; the
     weights are asymmetric so a transposed fragment layout cannot pass."""
