@@ -67,8 +67,8 @@ SIGNATURES = {
     "dgll_host_sample_neighbors": (_i32, [_vp, C.POINTER(_i32), _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _i64,
                                           C.POINTER(_i64)]),
     "dgll_hip_gemm_f32": (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _i32]),
-    "dgll_hip_transform_bf16": (_i32, [_vp, _vp, _i64, _i32, _vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _i64,
-                                       _i32, _i64, _i32, _i32, _vp]),
+    "dgll_hip_transform_bf16": (_i32, [_vp, _vp, _i64, _i32, _vp, _i64, _vp, _i64, _i32, _vp, _i64, _i32, _vp, _i64, _vp,
+                                       _i64, _i32, _i64, _i32, _i32, _vp]),
     "launch_gcn_fused_kernel": (None, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32]),
     "launch_gcn_fused_kernel_backward_optimized": (None, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32,
                                                           _i32, _i32]),

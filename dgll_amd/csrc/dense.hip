@@ -283,13 +283,15 @@ static hipError_t launch_mfma(const MfmaGemmArgs& a, hipStream_t s) {
 }  // namespace dgll
 
 DGLL_API int dgll_hip_transform_bf16(void* stream, const void* A1, int64_t lda1, int K1, const void* Wt1, int64_t ldw1,
-                                     const void* A2, int64_t lda2, int K2, const void* Wt2, int64_t ldw2,
+                                     const void* A2, int64_t lda2, int K2, const void* Wt2, int64_t ldw2, int wt_rows,
                                      const void* relu_mask, int64_t ldm, void* out, int64_t ldo, int out_dtype, int64_t M,
                                      int N, int relu, const float* bias) {
     DGLL_REQUIRE(M >= 0 && N >= 0 && K1 >= 0 && K2 >= 0, "negative size");
     if (M == 0 || N == 0) return DGLL_OK;
     DGLL_REQUIRE(A1 && Wt1 && out && K1 > 0, "NULL operand");
     DGLL_REQUIRE(N <= 256, "dgll_hip_transform_bf16 keeps all N <= 256 output columns of a row block in accumulators");
+    DGLL_REQUIRE(wt_rows >= (N <= 64 ? 64 : N <= 128 ? 128 : 256),
+                 "Wt must be zero-padded to 64 / 128 / 256 rows (the kernel stages whole 32-row tiles of it)");
     DGLL_REQUIRE(out_dtype == DGLL_F32 || out_dtype == DGLL_BF16, "out_dtype");
     MfmaGemmArgs a{};
     a.A[0] = static_cast<const bf16_t*>(A1); a.lda[0] = lda1; a.K[0] = K1; a.Wt[0] = static_cast<const bf16_t*>(Wt1); a.ldw[0] = ldw1;

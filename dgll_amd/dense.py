@@ -47,7 +47,7 @@ def transform_bf16(a1, wt1, a2=None, wt2=None, relu=False, out_dtype=torch.bfloa
             torch.cuda.current_stream(a1.device).cuda_stream, a1.data_ptr(), a1.stride(0), a1.shape[1], p1.data_ptr(),
             p1.stride(0), a2.data_ptr() if a2 is not None else None, a2.stride(0) if a2 is not None else 0,
             a2.shape[1] if a2 is not None else 0, p2.data_ptr() if p2 is not None else None,
-            p2.stride(0) if p2 is not None else 0, mask.data_ptr() if mask is not None else None,
+            p2.stride(0) if p2 is not None else 0, p1.shape[0], mask.data_ptr() if mask is not None else None,
             mask.stride(0) if mask is not None else 0, out.data_ptr(), out.stride(0),
             _lib.BF16 if out_dtype == torch.bfloat16 else _lib.F32, m, n, int(relu), bias.data_ptr() if bias is not None else None)
     _lib.check(code, "dgll_hip_transform_bf16")

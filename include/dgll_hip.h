@@ -172,9 +172,9 @@ int dgll_hip_gemm_f32(void* stream, const float* A, int64_t lda, const float* B,
  * [ld >= 64*ceil(K/64) columns] (the kernel stages 2, 4 or 8 column tiles of 32 rows of Wt).  N <= 256.
  * out: bf16 or fp32 [M, ldo].  A2/Wt2/relu_mask/bias may be NULL.                                              */
 int dgll_hip_transform_bf16(void* stream, const void* A1, int64_t lda1, int K1, const void* Wt1, int64_t ldw1,
-                            const void* A2, int64_t lda2, int K2, const void* Wt2, int64_t ldw2,
+                            const void* A2, int64_t lda2, int K2, const void* Wt2, int64_t ldw2, int wt_rows,
                             const void* relu_mask, int64_t ldm, void* out, int64_t ldo, int out_dtype,
-                            int64_t M, int N, int relu, const float* bias);
+                            int64_t M, int N, int relu, const float* bias);   /* wt_rows: rows allocated in Wt1/Wt2 */
 
 /* ---- a10: H = relu(A_csr . (X[:, :actual_F] . W[:actual_F, :])) --------------------------------------------
  * launch_gcn_fused_kernel is the reference's own symbol with its exact signature
