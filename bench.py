@@ -48,7 +48,6 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-worst-case", action="store_true", help="skip the extra locality-0 SpMM measurement")
     ap.add_argument("--cpu-sample-rows", type=int, default=200_000)
-    ap.add_argument("--spmm-only", action="store_true", help="also print the per-shape SpMM table to stderr")
     return ap.parse_args()
 
 
