@@ -12,7 +12,7 @@ dgll_amd.CSRGraph.
 import math
 
 from ... import backend as F
-from ... import ops
+from ... import dense, ops
 from ...graph import as_csr_graph
 
 
@@ -35,9 +35,10 @@ class gcnConv(F.nn.Module):
                 self.bias.uniform_(-bound, bound)
 
     def forward(self, x, adj):
-        support = F.mm(x, self.weight.to(x.dtype))           # transform first (gcnconv.py:30)
-        if support.is_cuda:
+        if x.is_cuda:
+            support = dense.linear(x, self.weight)           # transform first (gcnconv.py:30): MFMA kernel for bf16 inputs
             return ops.spmm(as_csr_graph(adj), support, bias=self.bias)   # aggregate + fused bias (gcnconv.py:31-33)
+        support = F.mm(x, self.weight.to(x.dtype))
         out = F.spmm(adj, support)
         return out if self.bias is None else out + self.bias
 
