@@ -44,6 +44,7 @@ struct EdgeArgs {
     int heads, fo, feat;        // feat = heads * fo
     float alpha, sign;          // leaky-relu slope; -1: exp(-lrelu) (sparseGatConv), +1: softmax(+lrelu) (gatConv)
     int apply_elu, use_max;
+    int raw, accumulate;        // partitioned use: raw = leave the row un-normalised (num, den); accumulate = add what is already there
     int32_t* arg_out;           // segment_max: int32 [n_rows, ld] source row of the maximum
     // long-row schedule (threshold == 0: none): chunk work items come first in the grid, partials go to `ws`
     int threshold;
@@ -91,6 +92,10 @@ __device__ __forceinline__ WorkItem resolve_item(const EdgeArgs& a, int wave, in
 }
 
 __device__ __forceinline__ float lrelu(float z, float alpha) { return z > 0.0f ? z : alpha * z; }
+
+template <typename T> __device__ __forceinline__ float load_scalar(const T* p);
+template <> __device__ __forceinline__ float load_scalar<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float load_scalar<bf16_t>(const bf16_t* p) { return bf16_to_f32(*p); }
 
 // sum over the `lph` adjacent lanes that hold one head's columns (lph is a power of two <= 64)
 __device__ __forceinline__ float head_sum(float v, int lph) {
@@ -253,18 +258,28 @@ __global__ __launch_bounds__(kBlock) void gat_fwd_kernel(const EdgeArgs a, int l
         return;
     }
     if (slot == 0 && col_ok) {
-        const float inv = 1.0f / den;  // 0/0 -> NaN for edgeless rows, as gatconv.py:139
+        YT* yrow = static_cast<YT*>(a.Y) + row * a.ldy + c0;
+        if (a.accumulate) {   // second half of a split adjacency: the first launch left (num, den) of the other columns here
+            den += a.out_a[row * a.heads + head];
 #pragma unroll
-        for (int i = 0; i < EPV; ++i) {
-            float v = acc[i] * inv;
-            if (a.apply_elu) v = v > 0.0f ? v : expm1f(v);
-            acc[i] = v;
+            for (int i = 0; i < EPV; ++i) acc[i] += load_scalar<YT>(yrow + i);
         }
-        VecIO<YT, EPV>::store(static_cast<YT*>(a.Y) + row * a.ldy + c0, acc);
-        if ((sub % lph) == 0) {
-            a.out_a[row * a.heads + head] = den;
-            if (a.out_b) a.out_b[row * a.heads + head] = m_i;
+        if (!a.raw) {
+            const float inv = 1.0f / den;  // 0/0 -> NaN for edgeless rows, as gatconv.py:139
+#pragma unroll
+            for (int i = 0; i < EPV; ++i) {
+                float v = acc[i] * inv;
+                if (a.apply_elu) v = v > 0.0f ? v : expm1f(v);
+                acc[i] = v;
+            }
         }
+        VecIO<YT, EPV>::store(yrow, acc);
+    }
+    // the per-(row, head) scalars are written after every lane has read the previous launch's denominator
+    __builtin_amdgcn_wave_barrier();
+    if (slot == 0 && col_ok && (sub % lph) == 0) {
+        a.out_a[row * a.heads + head] = den;
+        if (a.out_b) a.out_b[row * a.heads + head] = m_i;
     }
   }
 }
@@ -310,7 +325,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_rows_kernel(const EdgeArgs a, 
             dn[i] = dhp * inv_den;
         }
         dd = -head_sum(part, lph) * inv_den;
-        if (slot == 0 && col_ok && it.first) {   // per-row outputs: written by the row itself or by its first chunk
+        if (slot == 0 && col_ok && it.first && !a.accumulate) {   // per-row outputs: written once (row itself / first chunk, first launch)
             VecIO<XT, EPV>::store(static_cast<XT*>(a.Y) + row * a.ldy + c0, dn);
             if ((sub % lph) == 0) a.out_b[row * a.heads + head] = dd;
         }
@@ -356,7 +371,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_rows_kernel(const EdgeArgs a, 
     ds = slot_sum<LPR>(ds);
     if (slot == 0 && col_ok && (sub % lph) == 0) {
         if (it.chunk >= 0) a.ws[it.chunk * a.ws_ld + a.ws_vec + head] = ds;
-        else a.out_a[row * a.heads + head] = ds;
+        else a.out_a[row * a.heads + head] = (a.accumulate ? a.out_a[row * a.heads + head] : 0.0f) + ds;
     }
   }
 }
@@ -453,6 +468,9 @@ __global__ __launch_bounds__(kBlock) void gat_long_finalize_kernel(const EdgeArg
     const int64_t li = blockIdx.x;
     const int64_t row = long_row[li];
     const int cb = long_chunk0[li], ce = long_chunk0[li + 1];
+    // per-(row, head) scalars are written after the whole block has read the previous launch's denominators
+    int my_head = -1;
+    float my_den = 0.0f, my_max = 0.0f;
     for (int f = (int)threadIdx.x; f < a.feat + a.heads; f += kBlock) {
         const bool vec = f < a.feat;
         const int head = vec ? f / a.fo : f - a.feat;
@@ -467,13 +485,15 @@ __global__ __launch_bounds__(kBlock) void gat_long_finalize_kernel(const EdgeArg
                 den += w[a.ws_vec + head] * sc;
                 if (vec) v += w[f] * sc;
             }
+            if (a.accumulate) den += a.out_a[row * a.heads + head];
             if (vec) {
-                float o = v / den;
-                if (a.apply_elu) o = o > 0.0f ? o : expm1f(o);
-                store_one<YT>(static_cast<YT*>(a.Y) + row * a.ldy + f, o);
+                YT* y = static_cast<YT*>(a.Y) + row * a.ldy + f;
+                if (a.accumulate) v += load_scalar<YT>(y);
+                float o = a.raw ? v : v / den;
+                if (!a.raw && a.apply_elu) o = o > 0.0f ? o : expm1f(o);
+                store_one<YT>(y, o);
             } else {
-                a.out_a[row * a.heads + head] = den;
-                if (a.out_b) a.out_b[row * a.heads + head] = M;
+                my_head = head; my_den = den; my_max = M;
             }
         } else {
             float sacc = 0.0f;
@@ -481,9 +501,15 @@ __global__ __launch_bounds__(kBlock) void gat_long_finalize_kernel(const EdgeArg
             if (vec) {
                 if (kind == 2) store_one<YT>(static_cast<YT*>(a.Y) + row * a.ldy + f, sacc);
             } else {
-                a.out_a[row * a.heads + head] = sacc;
+                my_head = head;
+                my_den = ((kind == 1 && a.accumulate) ? a.out_a[row * a.heads + head] : 0.0f) + sacc;
             }
         }
+    }
+    __syncthreads();
+    if (my_head >= 0) {
+        a.out_a[row * a.heads + my_head] = my_den;
+        if (kind == 0 && a.out_b) a.out_b[row * a.heads + my_head] = my_max;
     }
 }
 
@@ -664,10 +690,31 @@ static int gat_common(EdgeArgs& a, const int64_t* rowptr, const int32_t* col, in
     return DGLL_OK;
 }
 
+static int gat_fwd_impl(void* stream, const dgll_csr_plan* plan, const int64_t* rowptr, const int32_t* col,
+                        const void* H, int64_t ldh, const float* S, const float* T, const float* edge_scale, void* out,
+                        int64_t ldo, int dtype, float* rowsum, float* rowmax, int64_t n_rows, int heads, int fo,
+                        float alpha, int apply_elu, int mode, void* workspace, size_t workspace_bytes, int raw, int accumulate);
+
 DGLL_API int dgll_hip_gat_fwd(void* stream, const dgll_csr_plan* plan, const int64_t* rowptr, const int32_t* col,
                               const void* H, int64_t ldh, const float* S, const float* T, const float* edge_scale, void* out,
                               int64_t ldo, int dtype, float* rowsum, float* rowmax, int64_t n_rows, int heads, int fo,
                               float alpha, int apply_elu, int mode, void* workspace, size_t workspace_bytes) {
+    return gat_fwd_impl(stream, plan, rowptr, col, H, ldh, S, T, edge_scale, out, ldo, dtype, rowsum, rowmax, n_rows, heads, fo,
+                        alpha, apply_elu, mode, workspace, workspace_bytes, 0, 0);
+}
+
+DGLL_API int dgll_hip_gat_fwd_ex(void* stream, const dgll_csr_plan* plan, const int64_t* rowptr, const int32_t* col,
+                                 const void* H, int64_t ldh, const float* S, const float* T, const float* edge_scale, void* out,
+                                 int64_t ldo, int dtype, float* rowsum, int64_t n_rows, int heads, int fo, float alpha,
+                                 int apply_elu, void* workspace, size_t workspace_bytes, int raw, int accumulate) {
+    return gat_fwd_impl(stream, plan, rowptr, col, H, ldh, S, T, edge_scale, out, ldo, dtype, rowsum, nullptr, n_rows, heads, fo,
+                        alpha, apply_elu, 0, workspace, workspace_bytes, raw, accumulate);
+}
+
+static int gat_fwd_impl(void* stream, const dgll_csr_plan* plan, const int64_t* rowptr, const int32_t* col,
+                        const void* H, int64_t ldh, const float* S, const float* T, const float* edge_scale, void* out,
+                        int64_t ldo, int dtype, float* rowsum, float* rowmax, int64_t n_rows, int heads, int fo,
+                        float alpha, int apply_elu, int mode, void* workspace, size_t workspace_bytes, int raw, int accumulate) {
     if (n_rows <= 0) return DGLL_OK;
     EdgeArgs a{};
     int lph, lpr;
@@ -680,6 +727,8 @@ DGLL_API int dgll_hip_gat_fwd(void* stream, const dgll_csr_plan* plan, const int
     DGLL_REQUIRE(vec_ok(H, ldh, esz) && vec_ok(out, ldo, esz) && ldh >= a.feat && ldo >= a.feat, "H/out must be 16-byte aligned");
     a.H = H; a.ldh = ldh; a.S = S; a.T = T; a.edge_scale = edge_scale; a.Y = out; a.ldy = ldo;
     a.out_a = rowsum; a.out_b = mode == 1 ? rowmax : nullptr;
+    DGLL_REQUIRE(mode == 0 || (!raw && !accumulate), "split (raw / accumulate) launches support mode 0 only");
+    a.raw = raw; a.accumulate = accumulate;
     rc = gat_schedule(a, plan, n_rows, workspace, workspace_bytes, &grid, esz);
     if (rc != DGLL_OK) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -692,6 +741,75 @@ DGLL_API int dgll_hip_gat_fwd(void* stream, const dgll_csr_plan* plan, const int
     return dtype == DGLL_F32 ? gat_finalize<float>(a, plan, 0, s) : gat_finalize<bf16_t>(a, plan, 0, s);
 }
 
+// Pass 1 of the backward (rows of A or of one column-half of A): DN, DD (written unless `accumulate`) and grad_S (+=).
+DGLL_API int dgll_hip_gat_bwd_rows(void* stream, const dgll_csr_plan* plan, const int64_t* rowptr, const int32_t* col,
+                                   const void* H, int64_t ldh, const float* S, const float* T, const float* edge_scale,
+                                   const void* out, int64_t ldo, const void* grad_out, int64_t ldg, int dtype,
+                                   const float* rowsum, const float* rowmax, void* dn, int64_t ldn, float* dd, float* grad_S,
+                                   int64_t n_rows, int heads, int fo, float alpha, int apply_elu, int mode, int accumulate,
+                                   void* workspace, size_t workspace_bytes) {
+    if (n_rows <= 0) return DGLL_OK;
+    EdgeArgs a{};
+    int lph, lpr;
+    dim3 grid;
+    int rc = gat_common(a, rowptr, col, n_rows, heads, fo, dtype, alpha, mode, apply_elu, &lph, &lpr, &grid);
+    if (rc != DGLL_OK) return rc;
+    DGLL_REQUIRE(H && S && T && out && grad_out && rowsum && dn && dd && grad_S, "NULL argument");
+    DGLL_REQUIRE(mode == 0 || rowmax, "mode 1 needs the forward's rowmax");
+    const int esz = dtype == DGLL_BF16 ? 2 : 4;
+    DGLL_REQUIRE(vec_ok(H, ldh, esz) && vec_ok(out, ldo, esz) && vec_ok(grad_out, ldg, esz) && vec_ok(dn, ldn, esz),
+                 "matrices must be 16-byte aligned with padded leading dimensions");
+    a.H = H; a.ldh = ldh; a.S = S; a.T = T; a.M = mode == 1 ? rowmax : nullptr; a.DEN = rowsum; a.edge_scale = edge_scale;
+    a.G = grad_out; a.ldg = ldg; a.O = out; a.ldo = ldo; a.Y = dn; a.ldy = ldn; a.out_a = grad_S; a.out_b = dd;
+    a.accumulate = accumulate;
+    rc = gat_schedule(a, plan, n_rows, workspace, workspace_bytes, &grid, esz);
+    if (rc != DGLL_OK) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+#define CALL(L)                                                                                                              \
+    if (dtype == DGLL_F32) hipLaunchKernelGGL((gat_bwd_rows_kernel<float, 4, L, 2>), grid, dim3(kBlock), 0, s, a, lph);      \
+    else hipLaunchKernelGGL((gat_bwd_rows_kernel<bf16_t, 8, L, 2>), grid, dim3(kBlock), 0, s, a, lph);
+    DGLL_LPR_SWITCH(lpr, CALL)
+#undef CALL
+    DGLL_HIP_TRY(hipGetLastError());
+    return gat_finalize<float>(a, plan, 1, s);
+}
+
+// Pass 2 of the backward over a transposed structure (rows = source nodes j, columns = destination rows i):
+// grad_H[j] = sum_i w_ij scale_ij DN[i], grad_T[j] = sum_i dz_ij.  Hrow / T_row belong to the rows of this pass, DN / S_col /
+// DD / M_col to its columns.
+DGLL_API int dgll_hip_gat_bwd_cols(void* stream, const dgll_csr_plan* t_plan, const int64_t* t_rowptr, const int32_t* t_col,
+                                   const int64_t* t_perm, const void* dn, int64_t ldn, const void* Hrow, int64_t ldh,
+                                   const float* T_row, const float* S_col, const float* dd_col, const float* rowmax_col,
+                                   const float* edge_scale, void* grad_H, int64_t ldgh, float* grad_T, int dtype,
+                                   int64_t n_rows_t, int heads, int fo, float alpha, int mode, void* workspace,
+                                   size_t workspace_bytes) {
+    if (n_rows_t <= 0) return DGLL_OK;
+    EdgeArgs t{};
+    int lph, lpr;
+    dim3 grid;
+    int rc = gat_common(t, t_rowptr, t_col, n_rows_t, heads, fo, dtype, alpha, mode, 0, &lph, &lpr, &grid);
+    if (rc != DGLL_OK) return rc;
+    DGLL_REQUIRE(dn && Hrow && T_row && S_col && dd_col && grad_H && grad_T, "NULL argument");
+    DGLL_REQUIRE(mode == 0 || rowmax_col, "mode 1 needs the forward's rowmax");
+    DGLL_REQUIRE(!edge_scale || t_perm, "edge_scale needs the transpose permutation");
+    const int esz = dtype == DGLL_BF16 ? 2 : 4;
+    DGLL_REQUIRE(vec_ok(dn, ldn, esz) && vec_ok(Hrow, ldh, esz) && vec_ok(grad_H, ldgh, esz),
+                 "matrices must be 16-byte aligned with padded leading dimensions");
+    t.perm = t_perm; t.H = dn; t.ldh = ldn; t.G = Hrow; t.ldg = ldh; t.S = T_row; t.T = S_col; t.DD = dd_col;
+    t.M = mode == 1 ? rowmax_col : nullptr; t.edge_scale = edge_scale; t.Y = grad_H; t.ldy = ldgh; t.out_a = grad_T;
+    t.out_b = nullptr;
+    rc = gat_schedule(t, t_plan, n_rows_t, workspace, workspace_bytes, &grid, esz);
+    if (rc != DGLL_OK) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+#define CALL(L)                                                                                                                  \
+    if (dtype == DGLL_F32) hipLaunchKernelGGL((gat_bwd_cols_kernel<float, float, 4, L, 2>), grid, dim3(kBlock), 0, s, t, lph);   \
+    else hipLaunchKernelGGL((gat_bwd_cols_kernel<bf16_t, bf16_t, 8, L, 2>), grid, dim3(kBlock), 0, s, t, lph);
+    DGLL_LPR_SWITCH(lpr, CALL)
+#undef CALL
+    DGLL_HIP_TRY(hipGetLastError());
+    return dtype == DGLL_F32 ? gat_finalize<float>(t, t_plan, 2, s) : gat_finalize<bf16_t>(t, t_plan, 2, s);
+}
+
 DGLL_API int dgll_hip_gat_bwd(void* stream, const dgll_csr_plan* plan, const dgll_csr_plan* t_plan,
                               const int64_t* rowptr, const int32_t* col,          /* A   */
                               const int64_t* t_rowptr, const int32_t* t_col, const int64_t* t_perm, /* A^T */
@@ -702,54 +820,15 @@ DGLL_API int dgll_hip_gat_bwd(void* stream, const dgll_csr_plan* plan, const dgl
                               void* grad_H, int64_t ldgh, float* grad_S, float* grad_T,
                               int64_t n_rows, int64_t n_cols, int heads, int fo, float alpha, int apply_elu, int mode,
                               void* workspace, size_t workspace_bytes) {
-    if (n_rows <= 0 && n_cols <= 0) return DGLL_OK;
-    EdgeArgs a{};
-    int lph, lpr;
-    dim3 grid;
-    int rc = gat_common(a, rowptr, col, n_rows, heads, fo, dtype, alpha, mode, apply_elu, &lph, &lpr, &grid);
+    DGLL_REQUIRE(t_rowptr && t_col, "NULL transposed CSR");
+    int rc = dgll_hip_gat_bwd_rows(stream, plan, rowptr, col, H, ldh, S, T, edge_scale, out, ldo, grad_out, ldg, dtype, rowsum,
+                                   rowmax, dn_scratch, ldn, dd_scratch, grad_S, n_rows, heads, fo, alpha, apply_elu, mode, 0,
+                                   workspace, workspace_bytes);
     if (rc != DGLL_OK) return rc;
-    DGLL_REQUIRE(t_rowptr && t_col && H && S && T && out && grad_out && rowsum && dn_scratch && dd_scratch && grad_H && grad_S && grad_T,
-                 "NULL argument");
-    DGLL_REQUIRE(mode == 0 || rowmax, "mode 1 needs the forward's rowmax");
-    DGLL_REQUIRE(!edge_scale || t_perm, "edge_scale needs the transpose permutation");
-    const int esz = dtype == DGLL_BF16 ? 2 : 4;
-    DGLL_REQUIRE(vec_ok(H, ldh, esz) && vec_ok(out, ldo, esz) && vec_ok(grad_out, ldg, esz) && vec_ok(dn_scratch, ldn, esz) &&
-                 vec_ok(grad_H, ldgh, esz), "matrices must be 16-byte aligned with padded leading dimensions");
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    // pass 1: rows of A
-    a.H = H; a.ldh = ldh; a.S = S; a.T = T; a.M = mode == 1 ? rowmax : nullptr; a.DEN = rowsum; a.edge_scale = edge_scale;
-    a.G = grad_out; a.ldg = ldg; a.O = out; a.ldo = ldo; a.Y = dn_scratch; a.ldy = ldn; a.out_a = grad_S; a.out_b = dd_scratch;
-    if (n_rows > 0) {
-        rc = gat_schedule(a, plan, n_rows, workspace, workspace_bytes, &grid, esz);
-        if (rc != DGLL_OK) return rc;
-#define CALL(L)                                                                                                              \
-    if (dtype == DGLL_F32) hipLaunchKernelGGL((gat_bwd_rows_kernel<float, 4, L, 2>), grid, dim3(kBlock), 0, s, a, lph);      \
-    else hipLaunchKernelGGL((gat_bwd_rows_kernel<bf16_t, 8, L, 2>), grid, dim3(kBlock), 0, s, a, lph);
-        DGLL_LPR_SWITCH(lpr, CALL)
-#undef CALL
-        DGLL_HIP_TRY(hipGetLastError());
-        rc = gat_finalize<float>(a, plan, 1, s);
-        if (rc != DGLL_OK) return rc;
-    }
-    // pass 2: rows of A^T
-    EdgeArgs t = a;
-    t.rowptr = t_rowptr; t.col = t_col; t.perm = t_perm; t.n_rows = n_cols;
-    t.H = dn_scratch; t.ldh = ldn; t.G = H; t.ldg = ldh; t.S = T; t.T = S; t.DD = dd_scratch;
-    t.Y = grad_H; t.ldy = ldgh; t.out_a = grad_T; t.out_b = nullptr;
-    if (n_cols > 0) {
-        dim3 tgrid(1, grid.y);
-        rc = gat_schedule(t, t_plan, n_cols, workspace, workspace_bytes, &tgrid, esz);   // the same scratch, used after pass 1
-        if (rc != DGLL_OK) return rc;
-#define CALL(L)                                                                                                                   \
-    if (dtype == DGLL_F32) hipLaunchKernelGGL((gat_bwd_cols_kernel<float, float, 4, L, 2>), tgrid, dim3(kBlock), 0, s, t, lph);   \
-    else hipLaunchKernelGGL((gat_bwd_cols_kernel<bf16_t, bf16_t, 8, L, 2>), tgrid, dim3(kBlock), 0, s, t, lph);
-        DGLL_LPR_SWITCH(lpr, CALL)
-#undef CALL
-        DGLL_HIP_TRY(hipGetLastError());
-        rc = dtype == DGLL_F32 ? gat_finalize<float>(t, t_plan, 2, s) : gat_finalize<bf16_t>(t, t_plan, 2, s);
-        if (rc != DGLL_OK) return rc;
-    }
-    return DGLL_OK;
+    // the same scratch is reused: pass 2 is stream-ordered after pass 1
+    return dgll_hip_gat_bwd_cols(stream, t_plan, t_rowptr, t_col, t_perm, dn_scratch, ldn, H, ldh, T, S, dd_scratch, rowmax,
+                                 edge_scale, grad_H, ldgh, grad_T, dtype, n_cols, heads, fo, alpha, mode, workspace,
+                                 workspace_bytes);
 }
 
 DGLL_API int dgll_hip_segment_max(void* stream, const int64_t* rowptr, const int32_t* col, const void* X, int64_t ldx,

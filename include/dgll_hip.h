@@ -131,6 +131,29 @@ int dgll_hip_gat_bwd(void* stream, const dgll_csr_plan* plan, const dgll_csr_pla
                      int64_t n_rows, int64_t n_cols, int heads, int fo, float alpha, int apply_elu, int mode,
                      void* workspace, size_t workspace_bytes);   /* >= max of the two plans' workspace bytes */
 
+/* The same three launches as separate entry points for the partitioned (multi-GPU) path, where a destination row's
+ * neighbours are split over an owned-columns CSR and a halo-columns CSR (mode 0 only):
+ *   dgll_hip_gat_fwd_ex   raw != 0: leave the row un-normalised (numerator in `out`, denominator in rowsum);
+ *                         accumulate != 0: add the numerator / denominator already there, then (unless raw) normalise + ELU;
+ *   dgll_hip_gat_bwd_rows pass 1 over one half; accumulate != 0: add to grad_S and do not rewrite DN / DD;
+ *   dgll_hip_gat_bwd_cols pass 2 over one transposed structure: rows = source nodes (Hrow, T_row), columns = destination
+ *                         rows (dn, S_col, dd_col, rowmax_col).                                                     */
+int dgll_hip_gat_fwd_ex(void* stream, const dgll_csr_plan* plan, const int64_t* rowptr, const int32_t* col,
+                        const void* H, int64_t ldh, const float* S, const float* T, const float* edge_scale,
+                        void* out, int64_t ldo, int dtype, float* rowsum, int64_t n_rows, int heads, int fo, float alpha,
+                        int apply_elu, void* workspace, size_t workspace_bytes, int raw, int accumulate);
+int dgll_hip_gat_bwd_rows(void* stream, const dgll_csr_plan* plan, const int64_t* rowptr, const int32_t* col,
+                          const void* H, int64_t ldh, const float* S, const float* T, const float* edge_scale,
+                          const void* out, int64_t ldo, const void* grad_out, int64_t ldg, int dtype,
+                          const float* rowsum, const float* rowmax, void* dn, int64_t ldn, float* dd, float* grad_S,
+                          int64_t n_rows, int heads, int fo, float alpha, int apply_elu, int mode, int accumulate,
+                          void* workspace, size_t workspace_bytes);
+int dgll_hip_gat_bwd_cols(void* stream, const dgll_csr_plan* t_plan, const int64_t* t_rowptr, const int32_t* t_col,
+                          const int64_t* t_perm, const void* dn, int64_t ldn, const void* Hrow, int64_t ldh,
+                          const float* T_row, const float* S_col, const float* dd_col, const float* rowmax_col,
+                          const float* edge_scale, void* grad_H, int64_t ldgh, float* grad_T, int dtype,
+                          int64_t n_rows_t, int heads, int fo, float alpha, int mode, void* workspace, size_t workspace_bytes);
+
 /* ---- a3 (max): Y[i,f] = max_k X[col[k], f], arg[i,f] = the source row holding it (-1 / 0.0 for empty rows) --
  * NeighborAggregator's "max" (sageconv.py:37-38).  Y and arg share the leading dimension ldy; X/Y 16-byte
  * aligned with padded leading dimensions.                                                                   */
