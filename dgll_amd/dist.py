@@ -138,17 +138,21 @@ class _Exchange:
     def __init__(self, part, group=None):
         self.part, self.group = part, group
 
-    def start(self, send_buf, recv_buf, reverse=False):
+    def start(self, send_buf, recv_buf, reverse=False, more=()):
+        """One grouped call moving `send_buf` rows to their peers and filling `recv_buf`; `more` = further
+        (send, recv) pairs with the same row layout (e.g. the fp32 score rows next to the feature rows)."""
         p = self.part
         s_counts, r_counts = (p.recv_counts, p.send_counts) if reverse else (p.send_counts, p.recv_counts)
-        opsl, so, ro = [], 0, 0
-        for q in range(p.world):
-            if s_counts[q]:
-                opsl.append(dist.P2POp(dist.isend, send_buf[so:so + s_counts[q]], q, self.group))
-            if r_counts[q]:
-                opsl.append(dist.P2POp(dist.irecv, recv_buf[ro:ro + r_counts[q]], q, self.group))
-            so += s_counts[q]
-            ro += r_counts[q]
+        opsl = []
+        for sb, rb in ((send_buf, recv_buf),) + tuple(more):
+            so = ro = 0
+            for q in range(p.world):
+                if s_counts[q]:
+                    opsl.append(dist.P2POp(dist.isend, sb[so:so + s_counts[q]], q, self.group))
+                if r_counts[q]:
+                    opsl.append(dist.P2POp(dist.irecv, rb[ro:ro + r_counts[q]], q, self.group))
+                so += s_counts[q]
+                ro += r_counts[q]
         return dist.batch_isend_irecv(opsl) if opsl else []
 
     @staticmethod
@@ -206,6 +210,80 @@ class DistAggregate(torch.autograd.Function):
         if n_send:     # returned halo gradients: fixed-order reduction at the owner, no atomics
             engine.spmm(p.send_reduce, recv_view, g_own, accumulate=True)
         return g_own, None, None
+
+
+class DistGatAggregate(torch.autograd.Function):
+    """Multi-head edge-softmax aggregation (sparseGatConv semantics, gatconv.py:111-148) over the partitioned adjacency.
+    One exchange moves the halo rows of h together with their per-head scores t; the `local` half runs un-normalised
+    (numerator, denominator) while the exchange flies, the `halo` half accumulates and normalises.  Backward: the
+    row pass over both halves (grad_s accumulates), then the column pass over halo^T -- whose results travel back to the
+    owners -- overlapped with the column pass over local^T; returned pieces are reduced in fixed order."""
+
+    @staticmethod
+    def forward(ctx, h_own, s_own, t_own, engine, heads, fo, alpha, apply_elu):
+        from . import ops_edge as oe
+
+        p = engine.part
+        feat = heads * fo
+        dev, dtype = h_own.device, h_own.dtype
+        h_store, h_view = engine.rows_of(h_own)
+        s_own = s_own.detach().float().contiguous()
+        t_own = t_own.detach().float().contiguous()
+        has_halo = p.n_halo > 0
+        send_h = h_store.index_select(0, p.send_idx) if p.send_idx.numel() else h_store[:0]
+        send_t = t_own.index_select(0, p.send_idx) if p.send_idx.numel() else t_own[:0]
+        halo_store, halo_h = engine.alloc_rows(p.n_halo, feat, dtype)
+        halo_t = torch.empty((p.n_halo, heads), dtype=torch.float32, device=dev)
+        _, out = engine.alloc_rows(p.n_own, feat, dtype)
+        rowsum = torch.empty((p.n_own, heads), dtype=torch.float32, device=dev)
+        with engine.comm_scope():
+            reqs = engine.exchange.start(send_h, halo_store, more=((send_t, halo_t),))
+        oe.gat_fwd_part(p.local, h_view, s_own, t_own, out, rowsum, heads, fo, alpha, apply_elu, raw=has_halo, accumulate=False)
+        with engine.comm_scope():
+            engine.exchange.wait(reqs)
+        engine.join_comm()
+        if has_halo:
+            oe.gat_fwd_part(p.halo, halo_h, s_own, halo_t, out, rowsum, heads, fo, alpha, apply_elu, raw=False, accumulate=True)
+        ctx.engine, ctx.cfg = engine, (heads, fo, alpha, apply_elu)
+        ctx.save_for_backward(h_view, halo_h, s_own, t_own, halo_t, out, rowsum)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import ops_edge as oe
+
+        h_view, halo_h, s_own, t_own, halo_t, out, rowsum = ctx.saved_tensors
+        engine = ctx.engine
+        heads, fo, alpha, apply_elu = ctx.cfg
+        p = engine.part
+        feat = heads * fo
+        dev, dtype = h_view.device, h_view.dtype
+        _, gv = engine.rows_of(g.to(dtype))
+        _, dn = engine.alloc_rows(p.n_own, feat, dtype)
+        dd = torch.empty((p.n_own, heads), dtype=torch.float32, device=dev)
+        grad_s = torch.empty((p.n_own, heads), dtype=torch.float32, device=dev)
+        oe.gat_bwd_rows_part(p.local, h_view, s_own, t_own, out, gv, rowsum, dn, dd, grad_s, heads, fo, alpha, apply_elu, False)
+        if p.n_halo:
+            oe.gat_bwd_rows_part(p.halo, halo_h, s_own, halo_t, out, gv, rowsum, dn, dd, grad_s, heads, fo, alpha, apply_elu, True)
+        n_send = int(p.send_idx.numel())
+        gh_halo_store, gh_halo = engine.alloc_rows(p.n_halo, feat, dtype)
+        gt_halo = torch.empty((p.n_halo, heads), dtype=torch.float32, device=dev)
+        recv_store, recv_gh = engine.alloc_rows(n_send, feat, dtype)
+        recv_gt = torch.empty((n_send, heads), dtype=torch.float32, device=dev)
+        if p.n_halo:   # contributions to REMOTE source nodes first: they have to travel back to their owners
+            oe.gat_bwd_cols_part(engine.transposed(p.halo), dn, halo_h, halo_t, s_own, dd, gh_halo, gt_halo, heads, fo, alpha)
+        with engine.comm_scope():
+            reqs = engine.exchange.start(gh_halo_store, recv_store, reverse=True, more=((gt_halo, recv_gt),))
+        _, grad_h = engine.alloc_rows(p.n_own, feat, dtype)
+        grad_t = torch.empty((p.n_own, heads), dtype=torch.float32, device=dev)
+        oe.gat_bwd_cols_part(engine.transposed(p.local), dn, h_view, t_own, s_own, dd, grad_h, grad_t, heads, fo, alpha)
+        with engine.comm_scope():
+            engine.exchange.wait(reqs)
+        engine.join_comm()
+        if n_send:     # fixed-order reduction of the returned pieces at the owner
+            engine.spmm(p.send_reduce, recv_gh, grad_h, accumulate=True)
+            engine.spmm(p.send_reduce, recv_gt, grad_t, accumulate=True)
+        return grad_h, grad_s, grad_t, None, None, None, None, None
 
 
 class DistGraph:
@@ -333,6 +411,34 @@ class DistGraph:
         """Rows of this rank's block in global order -> local order (the identity for contiguous partitions; kept as
         the one place a relabelling partitioner would hook in)."""
         return x_block
+
+    def gat_layer(self, x, Ws, a1s, a2s, alpha, concat):
+        """One (multi-head) sparseGatConv layer on this rank's rows: the partitioned twin of
+        nn.Convolution.gatconv._fused_heads (mode 0, attention dropout inactive)."""
+        from . import dense, ops
+
+        heads, fo = len(Ws), Ws[0].shape[1]
+        h = dense.linear(x, Ws[0] if heads == 1 else torch.cat(Ws, dim=1))
+        A = h.new_zeros(heads * fo, 2 * heads)
+        for k in range(heads):
+            A[k * fo:(k + 1) * fo, k] = a1s[k].to(h.dtype)
+            A[k * fo:(k + 1) * fo, heads + k] = a2s[k].to(h.dtype)
+        st = torch.mm(h, A).float()
+        fo_pad = ops.head_width_padded(fo, h.dtype)
+        hp = h if fo_pad == fo else torch.nn.functional.pad(h.view(-1, heads, fo), (0, fo_pad - fo)).reshape(-1, heads * fo_pad)
+        out = DistGatAggregate.apply(hp, st[:, :heads], st[:, heads:], self, heads, fo_pad, alpha, concat)
+        return out if fo_pad == fo else out.view(-1, heads, fo_pad)[:, :, :fo].reshape(-1, heads * fo)
+
+    def spgat_forward(self, model, x_local):
+        """SpGAT.forward (gatconv.py:194-199) on this rank's rows; input/attention dropout must be inactive."""
+        if model.training and model.dropout > 0:
+            raise NotImplementedError("the partitioned GAT path runs with dropout inactive (eval mode or p = 0)")
+        halves = [att._split_a() for att in model.attentions]
+        x = self.gat_layer(x_local, [att.W for att in model.attentions], [h[0] for h in halves], [h[1] for h in halves],
+                           model.attentions[0].alpha, True)
+        a1, a2 = model.out_att._split_a()
+        x = torch.nn.functional.elu(self.gat_layer(x, [model.out_att.W], [a1], [a2], model.out_att.alpha, False))
+        return torch.log_softmax(x, dim=1)
 
     def sage_forward(self, model, x_local, placed_input=None):
         """Full-graph GraphSage forward on this rank's rows (x_local in local row order).  `placed_input`: handle from

@@ -176,3 +176,53 @@ def gat_aggregate(graph, h, s, t, heads, alpha, apply_elu=True, mode=0, edge_sca
     if fo * heads != h.shape[1] or head_width_padded(fo, h.dtype) != fo:
         raise ValueError("per-head width %d is not padded for the kernels (need %d)" % (fo, head_width_padded(fo, h.dtype)))
     return _GatAggregate.apply(h, s, t, edge_scale, graph, heads, fo, alpha, apply_elu, mode)
+
+
+# ------------------------------------------------------------------------------------------------ split launches
+# Building blocks of the partitioned GAT (dgll_amd/dist.py): the same kernels on the two column-halves of an adjacency.
+def _ws(plan, heads, fo, dev, other_plan=None):
+    n = int(_lib.lib.dgll_hip_gat_workspace_bytes(plan, heads, fo))
+    if other_plan is not None:
+        n = max(n, int(_lib.lib.dgll_hip_gat_workspace_bytes(other_plan, heads, fo)))
+    return (torch.empty(n, dtype=torch.uint8, device=dev) if n else None), n
+
+
+def gat_fwd_part(graph, h, s_rows, t_cols, out, rowsum, heads, fo, alpha, apply_elu, raw, accumulate):
+    """One half of a split forward: rows of `graph` gather from `h` / `t_cols`; numerator into `out`, denominator into
+    `rowsum` (raw), optionally on top of what a previous launch left there (accumulate)."""
+    dev = h.device
+    ws, nbytes = _ws(graph.plan(), heads, fo, dev)
+    with torch.cuda.device(dev):
+        code = _lib.lib.dgll_hip_gat_fwd_ex(
+            _stream(dev), graph.plan(), graph.rowptr.data_ptr(), graph.col.data_ptr(), h.data_ptr(), h.stride(0),
+            s_rows.data_ptr(), t_cols.data_ptr(), None, out.data_ptr(), out.stride(0), _dtype_code(h), rowsum.data_ptr(),
+            graph.n_rows, heads, fo, float(alpha), int(apply_elu), ws.data_ptr() if ws is not None else None, nbytes,
+            int(raw), int(accumulate))
+    _lib.check(code, "dgll_hip_gat_fwd_ex")
+
+
+def gat_bwd_rows_part(graph, h_cols, s_rows, t_cols, out, g, rowsum, dn, dd, grad_s, heads, fo, alpha, apply_elu, accumulate):
+    dev = out.device
+    ws, nbytes = _ws(graph.plan(), heads, fo, dev)
+    with torch.cuda.device(dev):
+        code = _lib.lib.dgll_hip_gat_bwd_rows(
+            _stream(dev), graph.plan(), graph.rowptr.data_ptr(), graph.col.data_ptr(), h_cols.data_ptr(), h_cols.stride(0),
+            s_rows.data_ptr(), t_cols.data_ptr(), None, out.data_ptr(), out.stride(0), g.data_ptr(), g.stride(0),
+            _dtype_code(out), rowsum.data_ptr(), None, dn.data_ptr(), dn.stride(0), dd.data_ptr(), grad_s.data_ptr(),
+            graph.n_rows, heads, fo, float(alpha), int(apply_elu), 0, int(accumulate), ws.data_ptr() if ws is not None else None,
+            nbytes)
+    _lib.check(code, "dgll_hip_gat_bwd_rows")
+
+
+def gat_bwd_cols_part(graph_t, dn, h_rows, t_rows, s_cols, dd_cols, grad_h, grad_t, heads, fo, alpha):
+    """Pass 2 over a transposed structure `graph_t` (rows = source nodes with features h_rows / scores t_rows, columns =
+    destination rows with dn / s_cols / dd_cols)."""
+    dev = dn.device
+    ws, nbytes = _ws(graph_t.plan(), heads, fo, dev)
+    with torch.cuda.device(dev):
+        code = _lib.lib.dgll_hip_gat_bwd_cols(
+            _stream(dev), graph_t.plan(), graph_t.rowptr.data_ptr(), graph_t.col.data_ptr(), None, dn.data_ptr(), dn.stride(0),
+            h_rows.data_ptr(), h_rows.stride(0), t_rows.data_ptr(), s_cols.data_ptr(), dd_cols.data_ptr(), None, None,
+            grad_h.data_ptr(), grad_h.stride(0), grad_t.data_ptr(), _dtype_code(dn), graph_t.n_rows, heads, fo, float(alpha), 0,
+            ws.data_ptr() if ws is not None else None, nbytes)
+    _lib.check(code, "dgll_hip_gat_bwd_cols")

@@ -421,3 +421,63 @@ def test_training_mode_gat_runs_with_dropout(cuda_device):
     out = model(torch.randn(n, 16, device=cuda_device), adj.to(cuda_device))
     out.sum().backward()
     assert torch.isfinite(out).all() and all(torch.isfinite(p.grad).all() for p in model.parameters())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gat_split_launches_equal_the_fused_one(cuda_device, dtype):
+    """The partitioned GAT's building blocks on one GPU: the adjacency split by column parity into two CSRs; raw +
+    accumulate forward launches, two-part backward (rows pass accumulated over the halves, cols pass per transposed
+    half) vs the single fused forward/backward."""
+    from dgll_amd import ops
+    from dgll_amd.ops_edge import _empty_padded, gat_bwd_cols_part, gat_bwd_rows_part, gat_fwd_part
+
+    n, heads, fo = 500, 4, 8
+    rowptr, col, _ = np_graph(n, 9, seed=123, heavy_rows=[(5, 460)], weighted=False)
+    dense = np.zeros((n, n), bool)
+    dense[np.repeat(np.arange(n), np.diff(rowptr)), col] = True
+    np.fill_diagonal(dense, True)
+    r, c = np.nonzero(dense)
+    rowptr, col, _ = cref.coo_to_csr(r, c, None, n)
+    d = cuda_device
+    full = to_dev(rowptr, col, None, n, d)
+    row = np.repeat(np.arange(n), np.diff(rowptr))
+    halves = []
+    for parity in (0, 1):
+        m = (col % 2) == parity
+        ptr = np.zeros(n + 1, np.int64)
+        np.cumsum(np.bincount(row[m], minlength=n), out=ptr[1:])
+        halves.append(to_dev(ptr, col[m], None, n, d))
+    torch.manual_seed(3)
+    h = (0.5 * torch.randn(n, heads * fo, device=d)).to(dtype).requires_grad_()
+    s = torch.randn(n, heads, device=d, requires_grad=True)
+    t = torch.randn(n, heads, device=d, requires_grad=True)
+    go = torch.randn(n, heads * fo, device=d).to(dtype)
+    ref = ops.gat_aggregate(full, h, s, t, heads, 0.2, apply_elu=True, mode=0)
+    gh_ref, gs_ref, gt_ref = torch.autograd.grad(ref, (h, s, t), go)
+    # forward: raw on the first half, accumulate + normalise on the second
+    out = _empty_padded(n, heads * fo, dtype, d)
+    rowsum = torch.empty(n, heads, device=d)
+    hd, sd, td = h.detach(), s.detach().contiguous(), t.detach().contiguous()
+    gat_fwd_part(halves[0], hd, sd, td, out, rowsum, heads, fo, 0.2, True, raw=True, accumulate=False)
+    gat_fwd_part(halves[1], hd, sd, td, out, rowsum, heads, fo, 0.2, True, raw=False, accumulate=True)
+    tol = dict(rtol=1e-4, atol=1e-5) if dtype == torch.float32 else dict(rtol=3e-2, atol=3e-2)
+    torch.testing.assert_close(out.float(), ref.detach().float(), **tol)
+    # backward
+    dn = _empty_padded(n, heads * fo, dtype, d)
+    dd = torch.empty(n, heads, device=d)
+    gs = torch.empty(n, heads, device=d)
+    gat_bwd_rows_part(halves[0], hd, sd, td, out, go, rowsum, dn, dd, gs, heads, fo, 0.2, True, accumulate=False)
+    gat_bwd_rows_part(halves[1], hd, sd, td, out, go, rowsum, dn, dd, gs, heads, fo, 0.2, True, accumulate=True)
+    gh = torch.zeros(n, heads * fo, device=d, dtype=torch.float32)
+    gt = torch.zeros(n, heads, device=d)
+    for half in halves:
+        ht, _ = half.transpose()
+        gh_part = _empty_padded(n, heads * fo, dtype, d)
+        gt_part = torch.empty(n, heads, device=d)
+        gat_bwd_cols_part(ht, dn, hd, td, sd, dd, gh_part, gt_part, heads, fo, 0.2)
+        gh += gh_part.float()
+        gt += gt_part
+    gtol = dict(rtol=2e-3, atol=2e-4) if dtype == torch.float32 else dict(rtol=5e-2, atol=8e-2)
+    torch.testing.assert_close(gs, gs_ref, **gtol)
+    torch.testing.assert_close(gt, gt_ref, **gtol)
+    torch.testing.assert_close(gh, gh_ref.float(), **gtol)
