@@ -17,6 +17,8 @@ _ALIASES = {
     "dgll.nn.Convolution.sageconv": "dgll_amd.nn.Convolution.sageconv",
     "dgll.nn.Convolution.gatconv": "dgll_amd.nn.Convolution.gatconv",
     "dgll.nn.Convolution.ginconv": "dgll_amd.nn.Convolution.ginconv",
+    "dgll.nn.GlobalPooling": "dgll_amd.nn.GlobalPooling",
+    "dgll.nn.GlobalPooling.Pooling": "dgll_amd.nn.GlobalPooling.Pooling",
     "dgll.data": "dgll_amd.data",
     "dgll.data.dgraph": "dgll_amd.data.dgraph",
     "dgll.sampling": "dgll_amd.sampling",

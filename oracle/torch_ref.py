@@ -91,3 +91,30 @@ def multihead_model(kind, rowptr, col, x, W, a, W_out, a_out, alpha):
 def special_spmm(rowptr, col, values, b):
     """SpecialSpmmFunction.forward, gatconv.py:66-69 (autograd gives the :72-81 gradients)."""
     return spmm_coo(_rows(rowptr), col.long(), values, b, rowptr.numel() - 1)
+
+
+def scatter_pool(x, batch, size=None, reduce="sum"):
+    """Graph read-out the reference gets from torch_scatter.scatter(x, batch, dim=0, dim_size=size, reduce=...)
+    (dgll/nn/GlobalPooling/Pooling.py:37,59,81).  torch_scatter is an un-vendored, unpinned dependency
+    (requirements.txt:2) that is not installed here, so this restates its published semantics -- 'add'/'sum': segment
+    sum; 'mean': sum / max(count, 1); 'max': segment maximum, 0 for segments without entries -- and is PARITY UNPINNED:
+    no golden vector of the reference exists for it."""
+    size = int(batch.max()) + 1 if size is None else size
+    idx = batch.long().view(-1, 1).expand(-1, x.shape[1])
+    if reduce in ("sum", "add", "mean"):
+        out = torch.zeros(size, x.shape[1], dtype=x.dtype).scatter_add_(0, idx, x)
+        if reduce == "mean":
+            cnt = torch.bincount(batch.long(), minlength=size).clamp(min=1).to(x.dtype)
+            out = out / cnt.unsqueeze(1)
+        return out
+    if reduce == "max":
+        # torch_scatter's max returns ONE arg-max per (segment, feature) and routes the gradient there; ties go to
+        # the first entry in node order (its CPU loop updates on strict '>').
+        n = x.shape[0]
+        m = torch.full((size, x.shape[1]), float("-inf"), dtype=x.dtype).scatter_reduce_(0, idx, x.detach(), "amax", include_self=True)
+        pos = torch.arange(n).view(-1, 1).expand(-1, x.shape[1])
+        cand = torch.where(x.detach() == m[batch.long()], pos, torch.full_like(pos, n))
+        arg = torch.full((size, x.shape[1]), n, dtype=torch.int64).scatter_reduce_(0, idx, cand, "amin", include_self=True)
+        has = arg < n
+        return torch.where(has, x.gather(0, arg.clamp(max=max(n - 1, 0))), torch.zeros((), dtype=x.dtype))
+    raise ValueError(reduce)

@@ -76,6 +76,7 @@ def load_reference():
     ref.gatconv = by_path("ref_gatconv", "dgll/nn/Convolution/gatconv.py")
     ref.utils = by_path("ref_nn_utils", "dgll/nn/utils/utils.py")
     ref.ppi_model = by_path("ref_ppi_gcn_model", "Evaluation/PPI/gcn_model.py")
+    ref.ppi_loader = by_path("ref_ppi_dataloader", "Evaluation/PPI/ppi_dataloader.py")
     # dgll.data / dgll.sampling use relative imports of the backend: give them a package home.
     pkg_data = types.ModuleType("dgll.data")
     pkg_data.__path__ = [os.path.join(REF, "dgll/data")]
@@ -412,14 +413,127 @@ def gen_adj_prep(ref):
          src=src, dst=dst, adj_row=ind[0], adj_col=ind[1], adj_val=adj._values())
 
 
+def _edge_set(edge_index, n):
+    e = edge_index.numpy() if isinstance(edge_index, torch.Tensor) else edge_index
+    return np.unique(e[0].astype(np.int64) * n + e[1])
+
+
+def gen_formats(ref):
+    """f4: the two on-disk formats in front of the layers, run through the reference's own loaders.
+    (1) Cora-format text -> utils.py:146-185 load_data; (2) GraphSAGE-format PPI directory ->
+    Evaluation/PPI/ppi_dataloader.py:10-61; (3) one graph of the REAL bundled PPI data (Evaluation/PPI.tar.xz) with the
+    reference's Evaluation/PPI/gcn_model.py run on it -- BASELINE config 1 on its own data."""
+    import tarfile
+    import tempfile
+    import warnings
+
+    warnings.simplefilter("ignore")
+    rng = np.random.default_rng(21)
+    with tempfile.TemporaryDirectory() as tmp:
+        # ---- (1) citation text: non-contiguous ids, a repeated citation, a mutual pair, a self citation, an empty row
+        n, nf = 70, 23
+        ids = rng.permutation(np.arange(1000, 1000 + 5 * n, 5))[:n]
+        feats = (rng.random((n, nf)) < 0.2).astype(np.int64)
+        feats[7] = 0
+        names = np.array(["Theory", "Neural_Nets", "Case_Based", "Rule_Learning", "Genetic"])[rng.integers(0, 5, n)]
+        pairs = ids[rng.integers(0, n, (260, 2))]
+        pairs = np.concatenate([pairs, pairs[:3], pairs[5:8, ::-1], np.array([[ids[4], ids[4]]])])
+        content = "\n".join("%d\t%s\t%s" % (ids[i], "\t".join(map(str, feats[i])), names[i]) for i in range(n)) + "\n"
+        cites = "\n".join("%d\t%d" % (a, b) for a, b in pairs) + "\n"
+        open(os.path.join(tmp, "syn.content"), "w").write(content)
+        open(os.path.join(tmp, "syn.cites"), "w").write(cites)
+        with contextlib.redirect_stdout(io.StringIO()):
+            adj, features, labels, i_tr, i_va, i_te = ref.utils.load_data(path=tmp + "/", dataset="syn")
+        adj = adj.coalesce()
+        save("citation_format_n70", dict(row="f4", ref="dgll/nn/utils/utils.py:146-185,240-257", n=n, nfeat=nf,
+                                         note="labels: the reference numbers classes in set() order (hash-seed "
+                                              "dependent); compare as a partition, not by id"),
+             content=np.array(content), cites=np.array(cites), adj_row=adj.indices()[0], adj_col=adj.indices()[1],
+             adj_val=adj.values(), features=features, labels=labels, class_names=names, idx_train=i_tr, idx_val=i_va,
+             idx_test=i_te)
+
+        # ---- (2) GraphSAGE-format directory: 3 graphs, undirected node-link file with a self-loop and a repeated link
+        sizes = [17, 9, 30]
+        gid = np.repeat(np.array([4, 5, 6]), sizes)
+        tot = int(sum(sizes))
+        links, base = [], 0
+        for sz in sizes:
+            e = rng.integers(0, sz, (3 * sz, 2)) + base
+            e[:, 0] = np.maximum(e[:, 0], base + 0)
+            links += [dict(source=int(a), target=int(b)) for a, b in e]
+            links.append(dict(source=base, target=base + 1))            # the first node always has an edge
+            base += sz
+        links.append(dict(source=3, target=3))
+        links.append(dict(links[0]))
+        node_link = dict(directed=False, multigraph=False, graph={}, nodes=[dict(id=i) for i in range(tot)], links=links)
+        d = os.path.join(tmp, "sage")
+        os.makedirs(d)
+        gjson = json.dumps(node_link)
+        open(os.path.join(d, "valid_graph.json"), "w").write(gjson)
+        fx = rng.standard_normal((tot, 6))
+        fy = (rng.random((tot, 4)) < 0.3).astype(np.int64)
+        np.save(os.path.join(d, "valid_feats.npy"), fx)
+        np.save(os.path.join(d, "valid_labels.npy"), fy)
+        np.save(os.path.join(d, "valid_graph_id.npy"), gid)
+        graphs = ref.ppi_loader.load_ppi_dataset(d, "valid")
+        arrays = dict(graph_json=np.array(gjson), feats=fx, labels=fy, graph_id=gid)
+        for k, (ei, x, y) in enumerate(graphs):
+            arrays["g%d_edges" % k] = _edge_set(ei, x.shape[0])       # order-free: key = src * n + dst, sorted
+            arrays["g%d_x" % k] = x
+            arrays["g%d_y" % k] = y
+        save("sage_format_3graphs", dict(row="f4", ref="Evaluation/PPI/ppi_dataloader.py:10-61", n_graphs=len(graphs),
+                                         sizes=sizes, edges="sorted unique keys src*n+dst per graph"), **arrays)
+
+        # ---- (3) the real PPI data: cross-check the build's loader on all three splits, keep one graph as a fixture
+        with tarfile.open(os.path.join(REF, "Evaluation/PPI.tar.xz")) as tf:
+            tf.extractall(tmp)
+        real = os.path.join(tmp, "PPI")
+        spec = importlib.util.spec_from_file_location("build_formats", os.path.join(os.path.dirname(OUT), "..", "dgll_amd", "data", "formats.py"))
+        mine = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mine)
+        stats = {}
+        for split in ("train", "valid", "test"):
+            a = ref.ppi_loader.load_ppi_dataset(real, split)
+            b = mine.load_ppi_dataset(real, split)
+            assert len(a) == len(b)
+            for (e1, x1, y1), (e2, x2, y2) in zip(a, b):
+                assert torch.equal(x1, x2) and torch.equal(y1, y2)
+                assert np.array_equal(_edge_set(e1, x1.shape[0]), _edge_set(e2, x1.shape[0]))
+                assert e1.shape == e2.shape
+            stats[split] = dict(graphs=len(a), nodes=int(sum(x.shape[0] for _, x, _ in a)), edges=int(sum(e.shape[1] for e, _, _ in a)))
+            if split == "test":
+                ei, x, y = a[1]
+        print("real PPI: build loader == reference loader on", stats)
+        torch.manual_seed(13)
+        model = ref.ppi_model.GCN(x.shape[1], 64, y.shape[1], num_layers=2)      # config 1: 2-layer GCN
+        with torch.no_grad():
+            for layer in model.layers:
+                layer.weight.mul_(0.05)
+        xg = x.clone().requires_grad_(True)
+        out = model(ei, xg)
+        loss = torch.nn.CrossEntropyLoss()(out, y)                                 # train_gcn.py:27,45
+        ps = [xg] + [l.weight for l in model.layers] + [model.out_layer.weight, model.out_layer.bias]
+        gs = torch.autograd.grad(loss, ps)
+        rows = torch.arange(0, x.shape[0], 4)
+        save("ppi_real_test1_gcn2", dict(row="a1 (config 1, bundled data)", ref="Evaluation/PPI/{ppi_dataloader.py:10-61,"
+                                         "gcn_model.py:63-94,train_gcn.py:27,45}", n=int(x.shape[0]), hidden=64,
+                                         split="test", graph=1, loader_crosscheck=stats, y_rows="every 4th row"),
+             edge_index=ei.to(torch.int32), x=x, labels=y.to(torch.uint8), out_rows=out[rows], out_colsum=out.double().sum(0),
+             loss=loss, w0=ps[1], w1=ps[2], w_out=ps[3], b_out=ps[4], grad_x_rows=gs[0][rows], grad_w0=gs[1], grad_w1=gs[2],
+             grad_w_out=gs[3], grad_b_out=gs[4])
+
+
 def main():
     ref = load_reference()
+    if sys.argv[1:] == ["formats"]:
+        return gen_formats(ref)
     gen_gcn(ref)
     gen_sage(ref)
     gen_gat(ref)
     gen_ppi(ref)
     gen_sampler(ref)
     gen_adj_prep(ref)
+    gen_formats(ref)
 
 
 if __name__ == "__main__":
