@@ -171,8 +171,7 @@ def main():
         else:
             out = engine.sage_forward(model, x_local, placed_input)
         # cross-entropy summed over this rank's nodes / global node count (x world: RaCoM averages over ranks)
-        logp = torch.log_softmax(out.float(), dim=1)
-        loss = -logp.gather(1, labels.unsqueeze(1)).sum() * (world / n)
+        loss = ops.cross_entropy(out, labels, reduction="sum") * (world / n)     # one kernel per direction
         loss.backward()
         if racom is not None:
             racom.all_reduce_and_wait()

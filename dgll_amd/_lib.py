@@ -56,6 +56,8 @@ SIGNATURES = {
                                  _i32, _vp, _vp, _sz]),
     "dgll_hip_spmm_csr_ex": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _i64, _i32, _i64, _i64, _i32, _i32,
                                     _i32, _vp, _vp, _sz, _vp, _i32]),
+    "dgll_hip_spmm_csr_gated": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _i64, _i32, _i64, _i64, _i32, _i32,
+                                       _i32, _vp, _vp, _sz, _vp, _i32, _vp, _i64]),
     "dgll_hip_sddmm_csr": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i32, _vp, _i64, _i32]),
     "dgll_hip_gat_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i64, _i32, _i32,
                                 C.c_float, _i32, _i32, _vp, _sz]),
@@ -75,6 +77,9 @@ SIGNATURES = {
     "dgll_hip_gemm_f32": (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _i32]),
     "dgll_hip_transform_bf16": (_i32, [_vp, _vp, _i64, _i32, _vp, _i64, _vp, _i64, _i32, _vp, _i64, _i32, _vp, _i64, _vp,
                                        _i64, _i32, _i64, _i32, _i32, _vp]),
+    "dgll_hip_transform_bf16_gated": (_i32, [_vp, _vp, _i64, _i32, _vp, _i64, _vp, _i64, _i32, _vp, _i64, _i32, _vp, _i64,
+                                             _vp, _i64, _i32, _i64, _i32, _i32, _vp, _vp, _i64, _vp]),
+    "dgll_hip_softmax_xent": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _i64, _vp, _i64, _i32]),
     "launch_gcn_fused_kernel": (None, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32]),
     "launch_gcn_fused_kernel_backward_optimized": (None, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32,
                                                           _i32, _i32]),

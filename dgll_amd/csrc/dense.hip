@@ -123,6 +123,9 @@ struct MfmaGemmArgs {
     int64_t M;
     int N, relu, out_f32, pairs;
     const float* bias;
+    const bf16_t* out_gate; // optional [M, N]: outputs are zeroed where out_gate <= 0 (the consumer's ReLU backward)
+    int64_t ldgate;
+    const float* row_scale; // optional fp32 [M]: out = act(row_scale[m] * (A.W) + bias)
 };
 
 constexpr int kChunkK = 64;                 // k per LDS stage
@@ -236,8 +239,59 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_bf16_nt_kernel(const MfmaGemmA
         }
     }
 
-    if (row >= a.M) return;
     // D[i][j]: j = lane%32 = activation row, i = (r&3) + 8*(r>>2) + 4*half = output column inside the tile
+    const float rs = a.row_scale ? a.row_scale[row_ld] : 1.0f;
+    if (!a.out_f32) {
+        // bf16 output: each lane holds 4-column pieces of ONE row, so direct stores would scatter 8-byte pieces over 32
+        // rows per instruction.  Transpose through LDS (the weight buffers are idle now): every wavefront parks its
+        // 32 x (NT*32) tile, then writes -- and reads the optional gate -- as whole 16-byte vectors along the rows.
+        constexpr int kOPitch = NT * 64 + 16;               // bytes per staged row (16-byte multiple, bank-skewed)
+        __syncthreads();                                    // every wave is done with the weight buffers
+        char* mine = smem + wave * 32 * kOPitch;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = t * 32 + g * 8 + half * 4;
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float x = acc[t][g * 4 + i] * rs;
+                    if (a.bias && n + i < a.N) x += a.bias[n + i];
+                    if (a.relu) x = fmaxf(x, 0.0f);
+                    v[i] = x;
+                }
+                *reinterpret_cast<uint2*>(mine + l32 * kOPitch + n * 2) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+            }
+        }
+        __syncthreads();
+        constexpr int kVecs = NT * 4;                       // 16-byte vectors per staged row
+        const bool vec_rows = (a.ldo & 7) == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15u) == 0;
+#pragma unroll 4
+        for (int it = 0; it < 32 * kVecs / kWave; ++it) {
+            const int idx = it * kWave + lane;
+            const int r = idx / kVecs, n = (idx % kVecs) * 8;
+            const int64_t grow = m0 + r;
+            if (grow >= a.M || n >= a.N) continue;
+            uint4 d = *reinterpret_cast<const uint4*>(mine + r * kOPitch + n * 2);
+            bf16_t* o = static_cast<bf16_t*>(a.out) + grow * a.ldo + n;
+            if (n + 8 <= a.N && vec_rows) {
+                if (a.out_gate) d = relu_mask(d, *reinterpret_cast<const uint4*>(a.out_gate + grow * a.ldgate + n));
+                *reinterpret_cast<uint4*>(o) = d;
+            } else {
+                const uint32_t w[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    if (n + e >= a.N) continue;
+                    bf16_t b = (bf16_t)((w[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+                    if (a.out_gate && !(bf16_to_f32(a.out_gate[grow * a.ldgate + n + e]) > 0.0f)) b = 0;
+                    o[e] = b;
+                }
+            }
+        }
+        return;
+    }
+    if (row >= a.M) return;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
 #pragma unroll
@@ -247,22 +301,21 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_bf16_nt_kernel(const MfmaGemmA
             float v[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                float x = acc[t][g * 4 + i];
+                float x = acc[t][g * 4 + i] * rs;
                 if (a.bias && n + i < a.N) x += a.bias[n + i];
                 if (a.relu) x = fmaxf(x, 0.0f);
                 v[i] = x;
             }
-            if (a.out_f32) {
-                float* o = static_cast<float*>(a.out) + row * a.ldo + n;
-                if (n + 4 <= a.N && (a.ldo & 3) == 0) *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-                else
-                    for (int i = 0; i < 4; ++i) if (n + i < a.N) o[i] = v[i];
-            } else {
-                bf16_t* o = static_cast<bf16_t*>(a.out) + row * a.ldo + n;
-                if (n + 4 <= a.N && (a.ldo & 3) == 0) *reinterpret_cast<uint2*>(o) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-                else
-                    for (int i = 0; i < 4; ++i) if (n + i < a.N) o[i] = f32_to_bf16(v[i]);
+            if (a.out_gate) {
+                const bf16_t* gp = a.out_gate + row * a.ldgate + n;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (n + i < a.N && !(bf16_to_f32(gp[i]) > 0.0f)) v[i] = 0.0f;
             }
+            float* o = static_cast<float*>(a.out) + row * a.ldo + n;
+            if (n + 4 <= a.N && (a.ldo & 3) == 0) *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+            else
+                for (int i = 0; i < 4; ++i) if (n + i < a.N) o[i] = v[i];
         }
     }
 }
@@ -282,10 +335,34 @@ static hipError_t launch_mfma(const MfmaGemmArgs& a, hipStream_t s) {
 
 }  // namespace dgll
 
+static int transform_bf16_impl(void* stream, const void* A1, int64_t lda1, int K1, const void* Wt1, int64_t ldw1,
+                               const void* A2, int64_t lda2, int K2, const void* Wt2, int64_t ldw2, int wt_rows,
+                               const void* relu_mask, int64_t ldm, void* out, int64_t ldo, int out_dtype, int64_t M,
+                               int N, int relu, const float* bias, const void* out_gate, int64_t ldgate,
+                               const float* row_scale);
+
 DGLL_API int dgll_hip_transform_bf16(void* stream, const void* A1, int64_t lda1, int K1, const void* Wt1, int64_t ldw1,
                                      const void* A2, int64_t lda2, int K2, const void* Wt2, int64_t ldw2, int wt_rows,
                                      const void* relu_mask, int64_t ldm, void* out, int64_t ldo, int out_dtype, int64_t M,
                                      int N, int relu, const float* bias) {
+    return transform_bf16_impl(stream, A1, lda1, K1, Wt1, ldw1, A2, lda2, K2, Wt2, ldw2, wt_rows, relu_mask, ldm, out, ldo,
+                               out_dtype, M, N, relu, bias, nullptr, 0, nullptr);
+}
+
+DGLL_API int dgll_hip_transform_bf16_gated(void* stream, const void* A1, int64_t lda1, int K1, const void* Wt1, int64_t ldw1,
+                                           const void* A2, int64_t lda2, int K2, const void* Wt2, int64_t ldw2, int wt_rows,
+                                           const void* relu_mask, int64_t ldm, void* out, int64_t ldo, int out_dtype,
+                                           int64_t M, int N, int relu, const float* bias, const void* out_gate,
+                                           int64_t ldgate, const float* row_scale) {
+    return transform_bf16_impl(stream, A1, lda1, K1, Wt1, ldw1, A2, lda2, K2, Wt2, ldw2, wt_rows, relu_mask, ldm, out, ldo,
+                               out_dtype, M, N, relu, bias, out_gate, ldgate, row_scale);
+}
+
+static int transform_bf16_impl(void* stream, const void* A1, int64_t lda1, int K1, const void* Wt1, int64_t ldw1,
+                               const void* A2, int64_t lda2, int K2, const void* Wt2, int64_t ldw2, int wt_rows,
+                               const void* relu_mask, int64_t ldm, void* out, int64_t ldo, int out_dtype, int64_t M,
+                               int N, int relu, const float* bias, const void* out_gate, int64_t ldgate,
+                               const float* row_scale) {
     DGLL_REQUIRE(M >= 0 && N >= 0 && K1 >= 0 && K2 >= 0, "negative size");
     if (M == 0 || N == 0) return DGLL_OK;
     DGLL_REQUIRE(A1 && Wt1 && out && K1 > 0, "NULL operand");
@@ -310,6 +387,10 @@ DGLL_API int dgll_hip_transform_bf16(void* stream, const void* A1, int64_t lda1,
     if (relu_mask) DGLL_REQUIRE(aligned16(relu_mask) && (ldm * 2) % 16 == 0, "mask alignment");
     a.mask = static_cast<const bf16_t*>(relu_mask); a.ldm = ldm;
     a.out = out; a.ldo = ldo; a.M = M; a.N = N; a.relu = relu; a.out_f32 = out_dtype == DGLL_F32; a.bias = bias;
+    DGLL_REQUIRE(!out_gate || (ldgate >= N && aligned16(out_gate) && (ldgate * 2) % 16 == 0),
+                 "out_gate: bf16 [M, ldgate >= N], 16-byte aligned rows");
+    a.out_gate = static_cast<const bf16_t*>(out_gate); a.ldgate = ldgate;
+    a.row_scale = row_scale;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int nt = (N + 31) / 32;
     hipError_t e;

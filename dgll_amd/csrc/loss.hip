@@ -1,0 +1,119 @@
+// loss.hip -- softmax cross-entropy over the last layer's rows, loss and gradient each in one pass.
+//
+// The reference's training loops end in nn.CrossEntropyLoss on the model output (Evaluation/PPI/train_gcn.py:27,45; the
+// GraphSAGE loop in examples).  Done with library ops that is six passes over [N, C] (cast, log_softmax, gather, and their
+// backward twins, ~1.6 ms per step on the products-shaped graph); here each direction reads the logits once:
+//   row_loss[i] = logsumexp(z_i) - z_i[label_i]                       (0 where label_i < 0: ignored, as ignore_index)
+//   grad[i, c]  = scale * (softmax(z_i)[c] - [c == label_i])          (scale read from device memory: no host sync)
+// A group of G lanes owns one row (64/G rows per wavefront) and each lane up to PER = 8 classes (G = pow2 >= C/8: 8 lanes
+// for 47 classes, so a wavefront covers 8 rows = one contiguous 752-byte stretch of bf16 logits); group reductions with
+// wave shuffles, fp32 math.  HBM-bound: C * (s_z [+ s_g]) bytes per row.
+#include "common.hpp"
+
+namespace dgll {
+
+struct XentArgs {
+    const void* z;
+    int64_t ldz;
+    const int64_t* labels;
+    float* row_loss;        // optional
+    void* grad;             // optional
+    int64_t ldg;
+    const float* scale;     // device scalar (may be NULL: 1)
+    int64_t n_rows;
+    int n_classes;
+};
+
+template <typename T> __device__ __forceinline__ float ld(const T* p);
+template <> __device__ __forceinline__ float ld<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ld<bf16_t>(const bf16_t* p) { return bf16_to_f32(*p); }
+
+template <typename T, int G, int PER>
+__global__ __launch_bounds__(kBlock) void softmax_xent_kernel(const XentArgs a) {
+    constexpr int ROWS = kWave / G;
+    const int lane = lane_id();
+    const int sub = lane % G;
+    const int64_t row = ((int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * ROWS + lane / G;
+    const bool live = row < a.n_rows;
+    const int64_t r = live ? row : a.n_rows - 1;          // every lane takes part in the shuffles
+    const T* z = static_cast<const T*>(a.z) + r * a.ldz;
+    float v[PER];
+    float m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int c = sub + j * G;
+        v[j] = c < a.n_classes ? ld<T>(z + c) : -INFINITY;
+        m = fmaxf(m, v[j]);
+    }
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    float sum = 0.0f;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        v[j] = __expf(v[j] - m);                           // exp(-inf) = 0 for the padding classes
+        sum += v[j];
+    }
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+    if (!live) return;
+    const int64_t label = a.labels[r];
+    const bool counted = label >= 0 && label < a.n_classes;
+    if (a.row_loss && sub == 0) a.row_loss[r] = counted ? (m + __logf(sum)) - ld<T>(z + label) : 0.0f;
+    if (a.grad) {
+        const float scale = counted ? (a.scale ? *a.scale : 1.0f) : 0.0f;
+        const float inv = 1.0f / sum;
+        T* g = static_cast<T*>(a.grad) + r * a.ldg;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int c = sub + j * G;
+            if (c < a.n_classes) store_one<T>(g + c, scale * (v[j] * inv - (c == label ? 1.0f : 0.0f)));
+        }
+    }
+}
+
+template <typename T, int G, int PER>
+static hipError_t launch_xent(const XentArgs& a, hipStream_t s) {
+    const int64_t rows_per_block = (int64_t)kWavesPerBlock * (kWave / G);
+    dim3 grid((uint32_t)((a.n_rows + rows_per_block - 1) / rows_per_block));
+    hipLaunchKernelGGL((softmax_xent_kernel<T, G, PER>), grid, dim3(kBlock), 0, s, a);
+    return hipGetLastError();
+}
+
+template <typename T>
+static hipError_t dispatch_xent(const XentArgs& a, hipStream_t s) {
+    const int c = a.n_classes;
+    if (c <= 8) return launch_xent<T, 1, 8>(a, s);
+    if (c <= 16) return launch_xent<T, 2, 8>(a, s);
+    if (c <= 32) return launch_xent<T, 4, 8>(a, s);
+    if (c <= 64) return launch_xent<T, 8, 8>(a, s);
+    if (c <= 128) return launch_xent<T, 16, 8>(a, s);
+    if (c <= 256) return launch_xent<T, 32, 8>(a, s);
+    if (c <= 512) return launch_xent<T, 64, 8>(a, s);
+    return launch_xent<T, 64, 16>(a, s);
+}
+
+}  // namespace dgll
+
+using namespace dgll;
+
+DGLL_API int dgll_hip_softmax_xent(void* stream, const void* logits, int64_t ldz, int dtype, const int64_t* labels,
+                                   float* row_loss, void* grad, int64_t ldg, const float* grad_scale, int64_t n_rows,
+                                   int n_classes) {
+    DGLL_REQUIRE(n_rows >= 0 && n_classes >= 0, "negative size");
+    if (n_rows == 0 || n_classes == 0) return DGLL_OK;
+    DGLL_REQUIRE(logits && labels, "NULL logits/labels");
+    DGLL_REQUIRE(row_loss || grad, "nothing to compute: pass row_loss and/or grad");
+    DGLL_REQUIRE(ldz >= n_classes && (!grad || ldg >= n_classes), "leading dimension smaller than n_classes");
+    DGLL_REQUIRE(dtype == DGLL_F32 || dtype == DGLL_BF16, "dtype");
+    if (n_classes > 1024) {
+        set_error("dgll_hip_softmax_xent keeps a row's classes in registers: n_classes <= 1024");
+        return DGLL_ERR_UNSUPPORTED;
+    }
+    XentArgs a{};
+    a.z = logits; a.ldz = ldz; a.labels = labels; a.row_loss = row_loss; a.grad = grad; a.ldg = ldg; a.scale = grad_scale;
+    a.n_rows = n_rows; a.n_classes = n_classes;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const hipError_t e = dtype == DGLL_F32 ? dispatch_xent<float>(a, s) : dispatch_xent<bf16_t>(a, s);
+    if (e != hipSuccess) return hip_fail(e, "softmax_xent_kernel launch");
+    return DGLL_OK;
+}

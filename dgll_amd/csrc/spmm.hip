@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include <type_traits>
 
 namespace dgll {
 
@@ -63,6 +64,8 @@ struct SpmmArgs {
     int flags;  // bit 0: XCD-contiguous row mapping
     const float* row_scale;   // optional fp32[n_rows]: replaces the reduce's own scale (split adjacencies share one degree)
     int accumulate;           // add the existing Y row before scaling (Y = scale * (A.X + Y))
+    const void* gate;         // optional [n_rows, ldg] of Y's type: outputs are zeroed where gate <= 0 (fused ReLU backward)
+    int64_t ldg;
 };
 
 // Accumulate edges [b, e) of one row into acc (this lane's EPV columns starting at xcol).
@@ -153,13 +156,59 @@ template <typename T> __device__ __forceinline__ float load_one(const T* p);
 template <> __device__ __forceinline__ float load_one<float>(const float* p) { return *p; }
 template <> __device__ __forceinline__ float load_one<bf16_t>(const bf16_t* p) { return bf16_to_f32(*p); }
 
-template <typename YT, int EPV>
-__device__ __forceinline__ void finish_row(YT* __restrict__ y, int c0, int feat, float scale, int epilogue,
-                                           const float* __restrict__ bias, float (&acc)[EPV], int accumulate) {
-    if (accumulate) {
+// EPV consecutive elements of the OUTPUT type, kept PACKED (one or two 16-byte registers quads, or one scalar) while the
+// gather runs and unpacked to floats only in the epilogue.
+template <typename YT, int EPV> struct RowVec {
+    static constexpr bool kVec = sizeof(YT) * EPV >= 16;
+    static constexpr int kN = kVec ? (int)(sizeof(YT) * EPV / 16) : 1;
+    uint4 q[kN];
+    __device__ __forceinline__ void load(const YT* __restrict__ p) {
+        if constexpr (kVec) {
 #pragma unroll
-        for (int i = 0; i < EPV; ++i)
-            if (c0 + i < feat) acc[i] += load_one<YT>(y + c0 + i);
+            for (int i = 0; i < kN; ++i) q[i] = reinterpret_cast<const uint4*>(p)[i];
+        } else {
+            q[0].x = (uint32_t)*reinterpret_cast<const typename std::conditional<sizeof(YT) == 2, uint16_t, uint32_t>::type*>(p);
+        }
+    }
+    __device__ __forceinline__ void unpack(float (&f)[EPV]) const {
+        if constexpr (!kVec) {
+            if constexpr (sizeof(YT) == 2) f[0] = bf16_to_f32((bf16_t)q[0].x);
+            else f[0] = __uint_as_float(q[0].x);
+        } else if constexpr (sizeof(YT) == 2) {
+#pragma unroll
+            for (int i = 0; i < kN; ++i) {
+                f[8 * i + 0] = bf16_lo(q[i].x); f[8 * i + 1] = bf16_hi(q[i].x); f[8 * i + 2] = bf16_lo(q[i].y); f[8 * i + 3] = bf16_hi(q[i].y);
+                f[8 * i + 4] = bf16_lo(q[i].z); f[8 * i + 5] = bf16_hi(q[i].z); f[8 * i + 6] = bf16_lo(q[i].w); f[8 * i + 7] = bf16_hi(q[i].w);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < kN; ++i) {
+                f[4 * i + 0] = __uint_as_float(q[i].x); f[4 * i + 1] = __uint_as_float(q[i].y);
+                f[4 * i + 2] = __uint_as_float(q[i].z); f[4 * i + 3] = __uint_as_float(q[i].w);
+            }
+        }
+    }
+};
+
+// Epilogue of one row.  EXTRA = the launch accumulates into Y and/or gates the output (a separate instantiation, so the
+// plain aggregation keeps its register budget: 64 VGPRs = 8 waves per SIMD).  `prev` / `gatev` arrive as packed 16-byte
+// loads when the lane's EPV columns are all inside the row (`full`); the ragged last vector of a row reads them here,
+// element by element.  (Issuing those loads ahead of the gather costs 8 more live registers -- 82 VGPRs, 5 waves -- and
+// measured no faster than loading after it at 78 / 6 waves; forcing 72 with waves_per_eu spills and is 11 % slower.)
+template <typename YT, int EPV, bool EXTRA>
+__device__ __forceinline__ void finish_row(YT* __restrict__ y, int c0, int feat, float scale, int epilogue,
+                                           const float* __restrict__ bias, float (&acc)[EPV], int accumulate,
+                                           const YT* __restrict__ gate, bool full, const RowVec<YT, EPV>& prev,
+                                           const RowVec<YT, EPV>& gatev) {
+    if constexpr (EXTRA) {
+        if (accumulate) {
+            float p[EPV];
+            if (full) prev.unpack(p);
+#pragma unroll
+            for (int i = 0; i < EPV; ++i)
+                if (full) acc[i] += p[i];
+                else if (c0 + i < feat) acc[i] += load_one<YT>(y + c0 + i);
+        }
     }
 #pragma unroll
     for (int i = 0; i < EPV; ++i) {
@@ -168,7 +217,18 @@ __device__ __forceinline__ void finish_row(YT* __restrict__ y, int c0, int feat,
         if (epilogue & DGLL_EPI_RELU) v = fmaxf(v, 0.0f);
         acc[i] = v;
     }
-    if (c0 + EPV <= feat) {
+    if constexpr (EXTRA) {
+        if (gate) {
+            float gv[EPV];
+            if (full) gatev.unpack(gv);
+#pragma unroll
+            for (int i = 0; i < EPV; ++i) {
+                if (full) { if (!(gv[i] > 0.0f)) acc[i] = 0.0f; }
+                else if (c0 + i < feat && !(load_one<YT>(gate + c0 + i) > 0.0f)) acc[i] = 0.0f;
+            }
+        }
+    }
+    if (full) {
         VecIO<YT, EPV>::store(y + c0, acc);
     } else {
 #pragma unroll
@@ -177,7 +237,7 @@ __device__ __forceinline__ void finish_row(YT* __restrict__ y, int c0, int feat,
     }
 }
 
-template <typename XT, typename YT, int EPV, int LPR, bool HAS_VAL, int U>
+template <typename XT, typename YT, int EPV, int LPR, bool HAS_VAL, int U, bool EXTRA>
 __global__ __launch_bounds__(kBlock) void spmm_csr_kernel(const SpmmArgs a) {
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -214,11 +274,25 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_kernel(const SpmmArgs a) {
         float acc[EPV];
 #pragma unroll
         for (int i = 0; i < EPV; ++i) acc[i] = 0.0f;
+        YT* yrow = static_cast<YT*>(a.Y) + row * a.ldy;
+        const bool writer = lane < LPR && col_ok;
+        const bool full = c0 + EPV <= a.feat;
+        RowVec<YT, EPV> prev, gatev;
+        const YT* grow = nullptr;
+        if constexpr (EXTRA) {
+            grow = a.gate ? static_cast<const YT*>(a.gate) + row * a.ldg : nullptr;
+        }
         gather_edges<XT, EPV, LPR, HAS_VAL, U>(a.col, a.val, xcol, a.ldx, b, e, lane, acc);
-        if (lane < LPR && col_ok) {
+        if constexpr (EXTRA) {
+            if (writer && full) {
+                if (a.accumulate) prev.load(yrow + c0);
+                if (grow) gatev.load(grow + c0);
+            }
+        }
+        if (writer) {
             const float scale = a.row_scale ? a.row_scale[row]
                                             : ((a.reduce == DGLL_REDUCE_MEAN && e > b) ? 1.0f / (float)(e - b) : 1.0f);
-            finish_row<YT, EPV>(static_cast<YT*>(a.Y) + row * a.ldy, c0, a.feat, scale, a.epilogue, a.bias, acc, a.accumulate);
+            finish_row<YT, EPV, EXTRA>(yrow, c0, a.feat, scale, a.epilogue, a.bias, acc, a.accumulate, grow, full, prev, gatev);
         }
     }
 }
@@ -237,6 +311,7 @@ __global__ __launch_bounds__(kBlock) void spmm_long_finalize_kernel(const SpmmAr
     if (a.row_scale) scale = a.row_scale[row];
     else if (a.reduce == DGLL_REDUCE_MEAN) scale = 1.0f / (float)(a.rowptr[row + 1] - a.rowptr[row]);
     YT* y = static_cast<YT*>(a.Y) + row * a.ldy;
+    const YT* gate = a.gate ? static_cast<const YT*>(a.gate) + row * a.ldg : nullptr;
     for (int f = lane * 4; f < a.feat; f += kWave * 4) {   // ws_ld is a multiple of 8 floats: the float4 stays in the row
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int c = cb; c < ce; ++c) {
@@ -252,8 +327,12 @@ __global__ __launch_bounds__(kBlock) void spmm_long_finalize_kernel(const SpmmAr
             t *= scale;
             if (a.epilogue & DGLL_EPI_BIAS) t += a.bias[f + i];
             if (a.epilogue & DGLL_EPI_RELU) t = fmaxf(t, 0.0f);
-            store_one<YT>(y + f + i, t);
+            if (gate && !(load_one<YT>(gate + f + i) > 0.0f)) t = 0.0f;
+            v[i] = t;
         }
+        if (f + 4 <= a.feat && (a.flags & 2)) VecIO<YT, 4>::store(y + f, v);     // flags bit 1: rows are 16-byte aligned
+        else
+            for (int i = 0; i < 4; ++i) if (f + i < a.feat) store_one<YT>(y + f + i, v[i]);
     }
 }
 
@@ -267,10 +346,14 @@ static int g_tune_threshold = 0;     // 0 = plan default (512)
 
 template <typename XT, typename YT, int EPV, int LPR, int U>
 static hipError_t launch_u(const SpmmArgs& a, dim3 grid, hipStream_t s) {
-    if (a.val)
-        hipLaunchKernelGGL((spmm_csr_kernel<XT, YT, EPV, LPR, true, U>), grid, dim3(kBlock), 0, s, a);
-    else
-        hipLaunchKernelGGL((spmm_csr_kernel<XT, YT, EPV, LPR, false, U>), grid, dim3(kBlock), 0, s, a);
+    const bool extra = a.accumulate || a.gate;
+    if (a.val) {
+        if (extra) hipLaunchKernelGGL((spmm_csr_kernel<XT, YT, EPV, LPR, true, U, true>), grid, dim3(kBlock), 0, s, a);
+        else hipLaunchKernelGGL((spmm_csr_kernel<XT, YT, EPV, LPR, true, U, false>), grid, dim3(kBlock), 0, s, a);
+    } else {
+        if (extra) hipLaunchKernelGGL((spmm_csr_kernel<XT, YT, EPV, LPR, false, U, true>), grid, dim3(kBlock), 0, s, a);
+        else hipLaunchKernelGGL((spmm_csr_kernel<XT, YT, EPV, LPR, false, U, false>), grid, dim3(kBlock), 0, s, a);
+    }
     return hipGetLastError();
 }
 
@@ -410,14 +493,15 @@ DGLL_API int64_t dgll_hip_csr_plan_num_chunks(const dgll_csr_plan* p) { return p
 static int spmm_csr_impl(void* stream, const dgll_csr_plan* plan, const int64_t* rowptr, const int32_t* col,
                          const float* val, const void* X, int64_t ldx, int x_dtype, void* Y, int64_t ldy,
                          int y_dtype, int64_t n_rows, int64_t n_cols, int feat, int reduce, int epilogue,
-                         const float* bias, void* workspace, size_t workspace_bytes, const float* row_scale, int accumulate);
+                         const float* bias, void* workspace, size_t workspace_bytes, const float* row_scale, int accumulate,
+                         const void* gate, int64_t ldg);
 
 DGLL_API int dgll_hip_spmm_csr(void* stream, const dgll_csr_plan* plan, const int64_t* rowptr, const int32_t* col,
                                const float* val, const void* X, int64_t ldx, int x_dtype, void* Y, int64_t ldy,
                                int y_dtype, int64_t n_rows, int64_t n_cols, int feat, int reduce, int epilogue,
                                const float* bias, void* workspace, size_t workspace_bytes) {
     return spmm_csr_impl(stream, plan, rowptr, col, val, X, ldx, x_dtype, Y, ldy, y_dtype, n_rows, n_cols, feat, reduce,
-                         epilogue, bias, workspace, workspace_bytes, nullptr, 0);
+                         epilogue, bias, workspace, workspace_bytes, nullptr, 0, nullptr, 0);
 }
 
 DGLL_API int dgll_hip_spmm_csr_ex(void* stream, const dgll_csr_plan* plan, const int64_t* rowptr, const int32_t* col,
@@ -426,14 +510,25 @@ DGLL_API int dgll_hip_spmm_csr_ex(void* stream, const dgll_csr_plan* plan, const
                                   const float* bias, void* workspace, size_t workspace_bytes, const float* row_scale,
                                   int accumulate) {
     return spmm_csr_impl(stream, plan, rowptr, col, val, X, ldx, x_dtype, Y, ldy, y_dtype, n_rows, n_cols, feat, reduce,
-                         epilogue, bias, workspace, workspace_bytes, row_scale, accumulate);
+                         epilogue, bias, workspace, workspace_bytes, row_scale, accumulate, nullptr, 0);
+}
+
+DGLL_API int dgll_hip_spmm_csr_gated(void* stream, const dgll_csr_plan* plan, const int64_t* rowptr, const int32_t* col,
+                                     const float* val, const void* X, int64_t ldx, int x_dtype, void* Y, int64_t ldy,
+                                     int y_dtype, int64_t n_rows, int64_t n_cols, int feat, int reduce, int epilogue,
+                                     const float* bias, void* workspace, size_t workspace_bytes, const float* row_scale,
+                                     int accumulate, const void* gate, int64_t ldg) {
+    return spmm_csr_impl(stream, plan, rowptr, col, val, X, ldx, x_dtype, Y, ldy, y_dtype, n_rows, n_cols, feat, reduce,
+                         epilogue, bias, workspace, workspace_bytes, row_scale, accumulate, gate, ldg);
 }
 
 static int spmm_csr_impl(void* stream, const dgll_csr_plan* plan, const int64_t* rowptr, const int32_t* col,
                          const float* val, const void* X, int64_t ldx, int x_dtype, void* Y, int64_t ldy,
                          int y_dtype, int64_t n_rows, int64_t n_cols, int feat, int reduce, int epilogue,
-                         const float* bias, void* workspace, size_t workspace_bytes, const float* row_scale, int accumulate) {
+                         const float* bias, void* workspace, size_t workspace_bytes, const float* row_scale, int accumulate,
+                         const void* gate, int64_t ldg) {
     DGLL_REQUIRE(n_rows >= 0 && n_cols >= 0 && feat >= 0, "negative size");
+    DGLL_REQUIRE(!gate || ldg >= feat, "gate leading dimension smaller than feat");
     if (n_rows == 0 || feat == 0) return DGLL_OK;
     DGLL_REQUIRE(rowptr && X && Y, "NULL rowptr/X/Y");
     DGLL_REQUIRE(ldx >= feat && ldy >= feat, "leading dimension smaller than feat");
@@ -457,6 +552,7 @@ static int spmm_csr_impl(void* stream, const dgll_csr_plan* plan, const int64_t*
     a.flags = g_tune_flags;
     a.row_scale = row_scale;
     a.accumulate = accumulate;
+    a.gate = gate; a.ldg = ldg;
     if (plan) {
         DGLL_REQUIRE(plan->n_rows == n_rows, "plan was built for a different CSR");
         a.threshold = plan->threshold;
@@ -491,7 +587,8 @@ static int spmm_csr_impl(void* stream, const dgll_csr_plan* plan, const int64_t*
     const int ysz = y_dtype == DGLL_BF16 ? 2 : 4;
     const int epv = 16 / esz;
     const bool fast = aligned16(X) && aligned16(Y) && (ldx * esz) % 16 == 0 && (ldy * ysz) % 16 == 0 &&
-                      ((int64_t)epv * ysz) % 16 == 0;
+                      ((int64_t)epv * ysz) % 16 == 0 && (!gate || (aligned16(gate) && (ldg * ysz) % 16 == 0));
+    if (fast) a.flags |= 2;
     hipError_t err;
     if (fast) {
         const int vecs = (feat + epv - 1) / epv;

@@ -1,7 +1,13 @@
 """Whole-layer autograd nodes for full-graph GraphSAGE (forward_graph): the layer's input feeds both the self term
 and the neighbour aggregation, so its gradient has two contributions.  Written as separate autograd nodes (as the
 reference's op-by-op layers are, sageconv.py:70-83) they are summed by an extra elementwise pass over [N, F]; here the
-second contribution is accumulated by the epilogue of the kernel that produces it (SpMM `accumulate`, or addmm)."""
+second contribution is accumulated by the epilogue of the kernel that produces it (SpMM `accumulate`, or addmm).
+
+ReLU backward between two such nodes is fused the same way.  Inside GraphSage.forward_graph the activations between
+layers are seen by nobody else, so the pair (producer, consumer) may agree that the consumer hands back the gradient
+ALREADY masked by (h > 0) -- written by the epilogue of the kernel that produces it (`gate_input`: SpMM gate /
+MFMA output gate) -- and the producer skips its own masking pass (`grad_is_gated`).  Masking is linear and idempotent, so
+the parameter gradients and the model-input gradient are exactly those of the unfused graph."""
 import torch
 
 from . import dense, ops
@@ -15,9 +21,10 @@ class _SageGraphLayer(torch.autograd.Function):
     """out = act(h.Ws + reduce_A(h).Wn)  -- aggregate-then-transform (sageconv.py:33-41,72-75)."""
 
     @staticmethod
-    def forward(ctx, h, ws, wn, graph, reduce, relu):
+    def forward(ctx, h, ws, wn, graph, reduce, relu, grad_is_gated=False, gate_input=False):
         agg = ops.spmm_raw(graph, h, reduce=reduce)
         wsd, wnd = ws.to(h.dtype), wn.to(h.dtype)
+        ctx.grad_is_gated, ctx.gate_input = grad_is_gated, gate_input
         if dense._mfma_ok(h, agg) and ws.shape[1] <= 256:
             out = dense.transform_bf16(h, wsd.t(), agg, wnd.t(), relu=relu)
         else:
@@ -33,32 +40,40 @@ class _SageGraphLayer(torch.autograd.Function):
         h, agg, wsd, wnd, out = ctx.saved_tensors
         graph = ctx.graph
         g = g.contiguous()
-        if ctx.relu:
+        if ctx.relu and not ctx.grad_is_gated:
             g = torch.ops.aten.threshold_backward(g, out, 0)
         gws = dense.grad_weight(h, g) if ctx.needs_input_grad[1] else None
         gwn = dense.grad_weight(agg, g) if ctx.needs_input_grad[2] else None
         gh = None
         if ctx.needs_input_grad[0]:
             gh = torch.mm(g, wsd.t())                      # self path
-            gagg = torch.mm(g, wnd.t())
             gt, _ = graph.transpose()
             tval = gt.val
+            # (folding 1/deg into this product's rows -- transform_bf16(row_scale=) -- so that the SpMM runs unweighted was
+            # measured: SpMM 5.21 -> 5.12 ms, but the MFMA kernel takes 0.70 ms against the library's 0.53: no net gain)
+            gagg = torch.mm(g, wnd.t())
             if ctx.reduce == "mean":
                 scale = graph.mean_scale_transposed()
                 tval = scale if tval is None else tval * scale
             if _aligned(gh) and _aligned(gagg):            # neighbour path lands on top of the self path in the epilogue
-                ops.spmm_raw(gt, gagg, val=tval, reduce="sum", out=gh, accumulate=True)
+                gate = h if (ctx.gate_input and h.stride(1) == 1) else None
+                ops.spmm_raw(gt, gagg, val=tval, reduce="sum", out=gh, accumulate=True, gate=gate)
+                if ctx.gate_input and gate is None:
+                    gh = torch.ops.aten.threshold_backward(gh, h, 0)
             else:
                 gh = gh + ops.spmm_raw(gt, gagg, val=tval, reduce="sum")
-        return gh, gws, gwn, None, None, None
+                if ctx.gate_input:
+                    gh = torch.ops.aten.threshold_backward(gh, h, 0)
+        return gh, gws, gwn, None, None, None, None, None
 
 
 class _SageGraphLayerTransformFirst(torch.autograd.Function):
     """out = act(h.Ws + reduce_A(h.Wn))  -- the narrowing layer: the NARROW product is aggregated (mean/sum are linear)."""
 
     @staticmethod
-    def forward(ctx, h, ws, wn, graph, reduce, relu):
+    def forward(ctx, h, ws, wn, graph, reduce, relu, grad_is_gated=False, gate_input=False):
         wsd, wnd = ws.to(h.dtype), wn.to(h.dtype)
+        ctx.grad_is_gated, ctx.gate_input = grad_is_gated, gate_input
         # the narrow product is gathered next: one 128-byte line per row (ld_align) instead of rows straddling two lines
         z = (dense.transform_bf16(h, wnd.t(), ld_align=64 if wn.shape[1] < 64 else None)
              if (dense._mfma_ok(h) and wn.shape[1] <= 256) else torch.mm(h, wnd))
@@ -73,36 +88,52 @@ class _SageGraphLayerTransformFirst(torch.autograd.Function):
     def backward(ctx, g):
         h, wsd, wnd, out = ctx.saved_tensors
         graph = ctx.graph
-        g = g.contiguous()
-        if ctx.relu:
-            g = torch.ops.aten.threshold_backward(g, out, 0)
-        # d/dz of reduce_A(z): A^T . g (1/deg folded into the padded copy of the narrow gradient)
+        # the (masked) gradient in a buffer whose rows start on a 128-byte line: it is gathered and fed to the MFMA kernel
         line = 128 // g.element_size()
-        gp = ops.alloc_features(g.shape[0], g.shape[1], g.dtype, g.device, pad_to=line if g.shape[1] < line else (16 // g.element_size()))
-        if ctx.reduce == "mean":
-            torch.mul(g, (1.0 / graph.degrees().clamp(min=1).to(torch.float32)).unsqueeze(1).to(g.dtype), out=gp)
+        pad = line if g.shape[1] < line else (16 // g.element_size())
+        gm = ops.alloc_features(g.shape[0], g.shape[1], g.dtype, g.device, pad_to=pad)
+        if ctx.relu and not ctx.grad_is_gated:
+            torch.ops.aten.threshold_backward.grad_input(g, out, 0, grad_input=gm)
         else:
-            gp.copy_(g)
+            gm.copy_(g)
+        # d/dz of reduce_A(z): A^T . g (1/deg folded into a scaled copy of the narrow gradient)
+        if ctx.reduce == "mean":
+            gp = ops.alloc_features(g.shape[0], g.shape[1], g.dtype, g.device, pad_to=pad)
+            torch.mul(gm, (1.0 / graph.degrees().clamp(min=1).to(torch.float32)).unsqueeze(1).to(g.dtype), out=gp)
+        else:
+            gp = gm
         gt, _ = graph.transpose()
         gz = ops.spmm_raw(gt, gp, val=gt.val, reduce="sum")
-        gws = dense.grad_weight(h, g) if ctx.needs_input_grad[1] else None
+        gws = dense.grad_weight(h, gm) if ctx.needs_input_grad[1] else None
         gwn = dense.grad_weight(h, gz) if ctx.needs_input_grad[2] else None
         gh = None
         if ctx.needs_input_grad[0]:
-            gh = torch.addmm(torch.mm(g, wsd.t()), gz, wnd.t())     # both paths in one GEMM epilogue
-        return gh, gws, gwn, None, None, None
+            if dense._mfma_ok(gm, gz) and wsd.shape[0] <= 256 and (not ctx.gate_input or h.stride(1) == 1):
+                # g.Ws^T + gz.Wn^T and the ReLU mask of the layer below: one MFMA launch, every operand read once
+                gh = dense.transform_bf16(gm, wsd, gz, wnd, out_gate=h if ctx.gate_input else None)
+            else:
+                gh = torch.mm(gm, wsd.t())
+                gh.addmm_(gz, wnd.t())                                # both paths in one GEMM epilogue, in place
+                if ctx.gate_input:
+                    gh = torch.ops.aten.threshold_backward(gh, h, 0)
+        return gh, gws, gwn, None, None, None, None, None
 
 
-def sage_graph_layer(layer, graph, h):
-    """Full-graph sageConv (x_dst is x_src) through the fused nodes when the layer has the standard configuration;
-    None otherwise (the caller falls back to forward_block)."""
+def can_fuse(layer, on_gpu):
+    """The standard sageConv configuration the fused nodes implement."""
     from . import backend as F
 
-    if not (h.is_cuda and layer.aggr_hid_method == "sum" and not layer.neighborAgg.use_bias
-            and layer.aggr_neighbor_method in ("mean", "sum") and layer.activation in (None, F.relu)):
+    return bool(on_gpu and layer.aggr_hid_method == "sum" and not layer.neighborAgg.use_bias
+                and layer.aggr_neighbor_method in ("mean", "sum") and layer.activation in (None, F.relu))
+
+
+def sage_graph_layer(layer, graph, h, grad_is_gated=False, gate_input=False):
+    """Full-graph sageConv (x_dst is x_src) through the fused nodes when the layer has the standard configuration;
+    None otherwise (the caller falls back to forward_block).  grad_is_gated / gate_input: see the module docstring --
+    only GraphSage.forward_graph, which owns the activations between its layers, sets them."""
+    if not can_fuse(layer, h.is_cuda):
         return None
     relu = layer.activation is not None
-    if layer.transform_first(h):
-        return _SageGraphLayerTransformFirst.apply(h, layer.weight, layer.neighborAgg.weight, graph,
-                                                   layer.aggr_neighbor_method, relu)
-    return _SageGraphLayer.apply(h, layer.weight, layer.neighborAgg.weight, graph, layer.aggr_neighbor_method, relu)
+    node = _SageGraphLayerTransformFirst if layer.transform_first(h) else _SageGraphLayer
+    return node.apply(h, layer.weight, layer.neighborAgg.weight, graph, layer.aggr_neighbor_method, relu,
+                      bool(grad_is_gated and relu), bool(gate_input))

@@ -166,6 +166,12 @@ class CSRGraph:
             self._transpose = (gt, perm)
         return self._transpose
 
+    def inv_degrees(self):
+        """fp32[n_rows]: 1 / max(deg, 1) -- the mean reduce's row factor; cached."""
+        if getattr(self, "_inv_deg", None) is None:
+            self._inv_deg = (1.0 / self.degrees().clamp(min=1).to(torch.float32)).contiguous()
+        return self._inv_deg
+
     def mean_scale_transposed(self):
         """fp32[nnz] in A^T edge order: 1/deg(i) of the destination row i each edge came from (backward of the
         mean reduce); cached."""

@@ -188,8 +188,14 @@ class GraphSage(F.nn.Module):
         (a CSRGraph), h <- layer(h_self = h, neighbours of each node gathered from h)."""
         from ... import fused_layers
 
+        fusable = [fused_layers.can_fuse(layer, x.is_cuda) for layer in self.gcn]
+        # layer i hands the gradient of its input back already masked by layer i-1's ReLU (written by the epilogue of the
+        # kernel that produces it); layer i-1 then skips its own masking pass.  Only between two fused layers.
+        gates = [i > 0 and fusable[i] and fusable[i - 1] and self.gcn[i - 1].activation is not None
+                 for i in range(len(self.gcn))]
         h = x
-        for layer in self.gcn:
-            out = fused_layers.sage_graph_layer(layer, graph, h)
+        for i, layer in enumerate(self.gcn):
+            out = fused_layers.sage_graph_layer(layer, graph, h, gate_input=gates[i],
+                                                grad_is_gated=i + 1 < len(gates) and gates[i + 1])
             h = layer.forward_block(graph, h, h) if out is None else out
         return h

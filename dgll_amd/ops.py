@@ -73,10 +73,11 @@ class LaunchTimer:
 
 
 def spmm_raw(graph, x, val=None, reduce="sum", bias=None, relu=False, out_dtype=None, out=None, row_scale=None,
-             accumulate=False):
+             accumulate=False, gate=None):
     """Y = epilogue(reduce_j A[i,j] X[j,:]) with no autograd.  `val` overrides graph.val (None = unweighted
     unless graph.val is set).  accumulate: add the rows already in `out` first; row_scale: fp32[n_rows] replacing the
-    reduce's own scale (both used by the partitioned path, dgll_hip_spmm_csr_ex)."""
+    reduce's own scale (both used by the partitioned path, dgll_hip_spmm_csr_ex).  gate: [n_rows, feat] of the output
+    dtype -- outputs are zeroed where gate <= 0 (dgll_hip_spmm_csr_gated: the ReLU backward of the layer below)."""
     _require_cuda(x, graph.rowptr)
     x = _row_major(x)
     if x.shape[0] != graph.n_cols:
@@ -100,12 +101,15 @@ def spmm_raw(graph, x, val=None, reduce="sum", bias=None, relu=False, out_dtype=
     end = timer.start(("spmm", feat, str(x.dtype), val is not None, graph.nnz), x.device) if timer is not None else None
     with torch.cuda.device(x.device):
         stream = torch.cuda.current_stream(x.device).cuda_stream
-        code = _lib.lib.dgll_hip_spmm_csr_ex(
+        if gate is not None and (gate.dtype != out.dtype or gate.shape != out.shape or gate.stride(1) != 1):
+            raise ValueError("gate must match the output's shape and dtype, rows contiguous")
+        code = _lib.lib.dgll_hip_spmm_csr_gated(
             stream, plan, graph.rowptr.data_ptr(), graph.col.data_ptr(), val.data_ptr() if val is not None else None,
             x.data_ptr(), x.stride(0), _dtype_code(x), out.data_ptr(), out.stride(0), _dtype_code(out),
             graph.n_rows, graph.n_cols, feat, _REDUCE[reduce], epi, bias.data_ptr() if bias is not None else None,
             ws.data_ptr() if ws is not None else None, ws_bytes,
-            row_scale.data_ptr() if row_scale is not None else None, int(bool(accumulate)))
+            row_scale.data_ptr() if row_scale is not None else None, int(bool(accumulate)),
+            gate.data_ptr() if gate is not None else None, gate.stride(0) if gate is not None else 0)
     if end is not None:
         end.record(torch.cuda.current_stream(x.device))
     _lib.check(code, "dgll_hip_spmm_csr")
@@ -170,6 +174,59 @@ def spmm(graph, x, val=None, reduce="sum", bias=None, relu=False):
     if val is None and graph.val is not None and graph.val.requires_grad:
         val = graph.val
     return _Spmm.apply(x, val, bias, graph, reduce, relu)
+
+
+# ------------------------------------------------------------------------------------------------ loss
+class _CrossEntropy(torch.autograd.Function):
+    """Softmax cross-entropy with class-index targets, one kernel per direction (dgll_hip_softmax_xent)."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, reduction):
+        _require_cuda(logits, labels)
+        if logits.dim() != 2 or labels.shape != (logits.shape[0],):
+            raise ValueError("cross_entropy expects logits [N, C] and labels [N]")
+        if logits.dtype not in (torch.float32, torch.bfloat16):
+            raise TypeError("cross_entropy: fp32 or bf16 logits")
+        z = logits if logits.stride(1) == 1 else logits.contiguous()
+        labels = labels.to(torch.int64).contiguous()
+        n, c = z.shape
+        row_loss = torch.empty(n, dtype=torch.float32, device=z.device)
+        with torch.cuda.device(z.device):
+            code = _lib.lib.dgll_hip_softmax_xent(torch.cuda.current_stream(z.device).cuda_stream, z.data_ptr(), z.stride(0),
+                                                  _dtype_code(z), labels.data_ptr(), row_loss.data_ptr(), None, 0, None, n, c)
+        _lib.check(code, "dgll_hip_softmax_xent")
+        ctx.reduction = reduction
+        if reduction == "mean":          # torch semantics: mean over the targets that are not ignored
+            count = ((labels >= 0) & (labels < c)).sum().to(torch.float32)
+            ctx.save_for_backward(z, labels, count)
+            return row_loss.sum() / count
+        ctx.save_for_backward(z, labels, None)
+        return row_loss.sum() if reduction == "sum" else row_loss
+
+    @staticmethod
+    def backward(ctx, g):
+        z, labels, count = ctx.saved_tensors
+        n, c = z.shape
+        per_row = ctx.reduction == "none"
+        scale = (g.float() / count if count is not None else g.float()).reshape(-1) if not per_row else None
+        grad = torch.empty_like(z)
+        with torch.cuda.device(z.device):
+            code = _lib.lib.dgll_hip_softmax_xent(torch.cuda.current_stream(z.device).cuda_stream, z.data_ptr(), z.stride(0),
+                                                  _dtype_code(z), labels.data_ptr(), None, grad.data_ptr(), grad.stride(0),
+                                                  scale.data_ptr() if scale is not None else None, n, c)
+        _lib.check(code, "dgll_hip_softmax_xent")
+        if per_row:
+            grad = grad * g.to(grad.dtype).unsqueeze(1)
+        return grad, None, None
+
+
+def cross_entropy(logits, labels, reduction="mean"):
+    """F.cross_entropy(logits, labels) for GPU logits [N, C] (fp32 or bf16; math in fp32) and int64 class indices;
+    labels outside [0, C) (e.g. -100) are ignored.  The loss the reference's training loops put on the last layer
+    (Evaluation/PPI/train_gcn.py:27)."""
+    if reduction not in ("mean", "sum", "none"):
+        raise ValueError("reduction must be 'mean', 'sum' or 'none'")
+    return _CrossEntropy.apply(logits, labels, reduction)
 
 
 from .ops_edge import gat_aggregate, head_width_padded, sddmm_raw, segment_max  # noqa: E402,F401

@@ -88,6 +88,17 @@ int dgll_hip_spmm_csr_ex(void* stream, const dgll_csr_plan* plan,
                          int64_t n_rows, int64_t n_cols, int feat, int reduce, int epilogue, const float* bias,
                          void* workspace, size_t workspace_bytes, const float* row_scale, int accumulate);
 
+/* dgll_hip_spmm_csr_ex plus a fused ReLU backward for the layer BELOW: where gate[i, c] <= 0 (gate: [n_rows, ldg] of Y's
+ * dtype, the forward activations relu produced; may be NULL) the output element is written as 0.  Used when Y is the
+ * gradient w.r.t. those activations (sageconv.py:81-82 applies the activation last): the separate masking pass over
+ * [N, F] disappears.                                                                                              */
+int dgll_hip_spmm_csr_gated(void* stream, const dgll_csr_plan* plan,
+                            const int64_t* rowptr, const int32_t* col, const float* val,
+                            const void* X, int64_t ldx, int x_dtype, void* Y, int64_t ldy, int y_dtype,
+                            int64_t n_rows, int64_t n_cols, int feat, int reduce, int epilogue, const float* bias,
+                            void* workspace, size_t workspace_bytes, const float* row_scale, int accumulate,
+                            const void* gate, int64_t ldg);
+
 /* ---- a7 backward: edge_out[k] = <G[row(k), :], B[col[k], :]> ------------------------------------------
  * The sampled dense-dense product SpecialSpmmFunction.backward computes through a dense N x N matmul
  * (gatconv.py:76-78).  G and B share `dtype`; both must be 16-byte aligned with leading dimensions padded to
@@ -198,6 +209,25 @@ int dgll_hip_transform_bf16(void* stream, const void* A1, int64_t lda1, int K1, 
                             const void* A2, int64_t lda2, int K2, const void* Wt2, int64_t ldw2, int wt_rows,
                             const void* relu_mask, int64_t ldm, void* out, int64_t ldo, int out_dtype,
                             int64_t M, int N, int relu, const float* bias);   /* wt_rows: rows allocated in Wt1/Wt2 */
+/* The same with an OUTPUT gate: out[i, n] is written as 0 where out_gate[i, n] <= 0 (bf16 [M, ldgate], may be NULL) --
+ * the input gradient g.Ws^T + gz.Wn^T of a layer whose input came out of a ReLU, masked in the epilogue -- and an
+ * optional per-row factor (fp32 [M], may be NULL): out = act(row_scale[i] * (A.W) + bias), e.g. the 1/deg of a mean
+ * aggregation folded into the product that is aggregated next, so that SpMM runs unweighted.                       */
+int dgll_hip_transform_bf16_gated(void* stream, const void* A1, int64_t lda1, int K1, const void* Wt1, int64_t ldw1,
+                                  const void* A2, int64_t lda2, int K2, const void* Wt2, int64_t ldw2, int wt_rows,
+                                  const void* relu_mask, int64_t ldm, void* out, int64_t ldo, int out_dtype,
+                                  int64_t M, int N, int relu, const float* bias, const void* out_gate, int64_t ldgate,
+                                  const float* row_scale);
+
+/* ---- the loss at the end of the path: softmax cross-entropy with class-index targets ---------------------------
+ * nn.CrossEntropyLoss on the last layer's output (Evaluation/PPI/train_gcn.py:27,45), one pass per direction:
+ * row_loss[i] = logsumexp(z_i) - z_i[label_i]  and/or  grad[i, c] = *grad_scale * (softmax(z_i)[c] - [c == label_i]).
+ * logits/grad: fp32 or bf16 [n_rows, ld]; labels int64, a label outside [0, n_classes) (e.g. -100) is ignored (loss 0,
+ * zero gradient); grad_scale: DEVICE pointer to one float (NULL = 1), so upstream gradients need no host sync.
+ * row_loss or grad may be NULL.  n_classes <= 1024.                                                              */
+int dgll_hip_softmax_xent(void* stream, const void* logits, int64_t ldz, int dtype, const int64_t* labels,
+                          float* row_loss, void* grad, int64_t ldg, const float* grad_scale, int64_t n_rows,
+                          int n_classes);
 
 /* ---- a10: H = relu(A_csr . (X[:, :actual_F] . W[:actual_F, :])) --------------------------------------------
  * launch_gcn_fused_kernel is the reference's own symbol with its exact signature

@@ -93,6 +93,69 @@ def test_bf16_forward_graph_tracks_fp32(cuda_device):
     assert all(torch.isfinite(p.grad).all() for p in m.parameters())
 
 
+def test_bf16_fused_relu_gates_equal_the_unfused_layers(cuda_device):
+    """The bench configuration (100-256-256-47, bf16): forward_graph hands gradients between its layers already masked
+    (SpMM gate epilogue, MFMA output gate) and skips the separate ReLU-backward passes.  Parameter and input gradients
+    must equal those of the same layers run one by one without that agreement."""
+    from dgll_amd import fused_layers, ops
+
+    g_cpu, model, x = _setup(cuda_device, fin=100, hidden=(256, 256, 47))
+    g = g_cpu.to(cuda_device)
+    m = model.to(cuda_device)
+    xb = ops.alloc_features(g.n_rows, 100, torch.bfloat16, cuda_device)
+    xb.copy_(x.to(cuda_device))
+    gout = torch.randn(g.n_rows, 47, device=cuda_device).to(torch.bfloat16)
+
+    def run(fused):
+        m.zero_grad()
+        store = ops.alloc_features(g.n_rows, 100, torch.bfloat16, cuda_device)
+        store.copy_(xb)
+        xin = store.requires_grad_()
+        if fused:
+            out = m.forward_graph(g, xin)
+        else:
+            h = xin
+            for layer in m.gcn:
+                h = fused_layers.sage_graph_layer(layer, g, h)          # no gate agreement: every node masks for itself
+            out = h
+        (out.float() * gout.float()).sum().backward()
+        return out.detach(), xin.grad.detach().clone(), [p.grad.detach().clone() for p in m.parameters()]
+
+    out_a, gx_a, gp_a = run(True)
+    out_b, gx_b, gp_b = run(False)
+    assert torch.equal(out_a, out_b)
+    # same kernels and operand values; the only difference is where the mask is applied -> agreement to bf16 rounding
+    torch.testing.assert_close(gx_a.float(), gx_b.float(), rtol=2e-2, atol=2e-2 * float(gx_b.float().abs().max()))
+    for a, b in zip(gp_a, gp_b):
+        torch.testing.assert_close(a, b, rtol=2e-2, atol=2e-2 * float(b.abs().max()))
+
+
+def test_mfma_transform_output_gate(cuda_device):
+    from dgll_amd import dense, ops
+
+    M, K1, K2, N = 1111, 47, 47, 256
+    a1 = ops.alloc_features(M, K1, torch.bfloat16, cuda_device, pad_to=64)
+    a1.copy_(torch.randn(M, K1, device=cuda_device))
+    a2 = ops.alloc_features(M, K2, torch.bfloat16, cuda_device)
+    a2.copy_(torch.randn(M, K2, device=cuda_device))
+    w1 = torch.randn(N, K1, device=cuda_device).to(torch.bfloat16)
+    w2 = torch.randn(N, K2, device=cuda_device).to(torch.bfloat16)
+    gate = torch.randn(M, N, device=cuda_device).to(torch.bfloat16)
+    gate[5] = 0
+    ref = (a1.float() @ w1.float().t() + a2.float() @ w2.float().t()) * (gate.float() > 0)
+    out = dense.transform_bf16(a1, w1, a2, w2, out_dtype=torch.float32, out_gate=gate)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-3)
+    rs = torch.rand(M, device=cuda_device) + 0.5
+    out_rs = dense.transform_bf16(a1, w1, a2, w2, out_dtype=torch.float32, out_gate=gate, row_scale=rs)
+    np.testing.assert_allclose(out_rs.cpu().numpy(), (ref * rs[:, None]).cpu().numpy(), rtol=1e-4, atol=1e-3)
+    out_rs16 = dense.transform_bf16(a1, w1, row_scale=rs, relu=True)
+    np.testing.assert_allclose(out_rs16.float().cpu().numpy(), ((a1.float() @ w1.float().t()) * rs[:, None]).relu().cpu().numpy(),
+                               rtol=1e-2, atol=5e-2)
+    out16 = dense.transform_bf16(a1, w1, a2, w2, out_gate=gate)
+    assert bool(((out16 == 0) | (gate > 0)).all())
+    np.testing.assert_allclose(out16.float().cpu().numpy(), ref.cpu().numpy(), rtol=1e-2, atol=5e-2)
+
+
 def test_split_k_weight_gradient(cuda_device):
     from dgll_amd import dense
 

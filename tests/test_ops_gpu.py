@@ -365,6 +365,30 @@ def test_spmm_accumulate_and_row_scale(cuda_device, dtype):
     np.testing.assert_allclose(out.cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("feat", [72, 256, 5])
+def test_spmm_gate_epilogue(cuda_device, dtype, feat):
+    """dgll_hip_spmm_csr_gated: Y = (A.X + Y_old) with elements zeroed where gate <= 0 -- the ReLU backward of the layer
+    below fused into the kernel that produces the gradient; incl. chunked long rows, empty rows, -0.0 and negative gates."""
+    from dgll_amd import ops
+
+    n = 500
+    rowptr, col, val = np_graph(n, 9, seed=17, heavy_rows=[(11, 450), (12, 140)], empty_rows=[0, 5], weighted=True)
+    g = to_dev(rowptr, col, val, n, cuda_device)
+    rng = np.random.default_rng(8)
+    x = torch.from_numpy(rng.standard_normal((n, feat)).astype(np.float32)).to(cuda_device).to(dtype)
+    gate = torch.from_numpy(rng.standard_normal((n, feat)).astype(np.float32)).to(cuda_device).to(dtype)
+    gate[3] = 0.0
+    gate[4] = -0.0
+    base = torch.from_numpy(rng.standard_normal((n, feat)).astype(np.float32)).to(cuda_device).to(dtype)
+    plain = ops.spmm_raw(g, x, out=base.clone(), accumulate=True)
+    ref = torch.where(gate > 0, plain, torch.zeros_like(plain))
+    out = ops.spmm_raw(g, x, out=base.clone(), accumulate=True, gate=gate)
+    assert torch.equal(out, ref)
+    with pytest.raises(ValueError):
+        ops.spmm_raw(g, x, gate=gate[:, :-1])
+
+
 @pytest.mark.parametrize("mode", [0, 1])
 def test_gat_attention_dropout_scale_forward_and_backward(cuda_device, mode):
     """edge_scale path (attention dropout, gatconv.py:37,132): multipliers applied AFTER the row sum; forward and the
