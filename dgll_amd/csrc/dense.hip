@@ -126,6 +126,7 @@ struct MfmaGemmArgs {
     const bf16_t* out_gate; // optional [M, N]: outputs are zeroed where out_gate <= 0 (the consumer's ReLU backward)
     int64_t ldgate;
     const float* row_scale; // optional fp32 [M]: out = act(row_scale[m] * (A.W) + bias)
+    int kperm;              // diagnostics: 0 = natural k order (shipped), 1 = the two halves of a row 64 bytes apart
 };
 
 constexpr int kChunkK = 64;                 // k per LDS stage
@@ -170,10 +171,12 @@ __device__ __forceinline__ void mfma_load_chunk(const MfmaGemmArgs& a, int c, in
         wreg[i] = *reinterpret_cast<const u32x4_t*>(w + (int64_t)(v >> 3) * ldw + k0 + (v & 7) * 8);
     }
     const bf16_t* x = (second ? a.A[1] : a.A[0]) + row_ld * lda;
-    const int kb = k0 + half * 32;
+    // natural MFMA k order: step kk takes k = kk*16 + half*8 .. +8, so the two lanes of a row read ADJACENT 16-byte pieces
+    // (32 contiguous bytes per row per load instruction instead of two pieces 64 bytes apart)
+    const int kb = k0 + half * (a.kperm ? 32 : 8);
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-        const int k = kb + kk * 8;
+        const int k = kb + kk * (a.kperm ? 8 : 16);
         uint4 v = make_uint4(0, 0, 0, 0);
         if (k < K) {
             v = *reinterpret_cast<const uint4*>(x + k);
@@ -223,13 +226,13 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_bf16_nt_kernel(const MfmaGemmA
     for (int c = 0; c < n_chunks; ++c) {
         uint4 cur[4] = {areg[0], areg[1], areg[2], areg[3]};
         if (c + 1 < n_chunks) mfma_load_chunk<NT>(a, c + 1, chunks0, tid, half, row_ld, wreg, areg);   // in flight during the MFMAs
-        const char* base = smem + (c & 1) * kBufBytes + l32 * kWPitch + half * 64;
+        const char* base = smem + (c & 1) * kBufBytes + l32 * kWPitch + half * (a.kperm ? 64 : 16);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             const bf16x8_t xf = __builtin_bit_cast(bf16x8_t, cur[kk]);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const uint4 wv = *reinterpret_cast<const uint4*>(base + t * 32 * kWPitch + kk * 16);
+                const uint4 wv = *reinterpret_cast<const uint4*>(base + t * 32 * kWPitch + kk * (a.kperm ? 16 : 32));
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wv), xf, acc[t], 0, 0, 0);
             }
         }
@@ -335,6 +338,8 @@ static hipError_t launch_mfma(const MfmaGemmArgs& a, hipStream_t s) {
 
 }  // namespace dgll
 
+int g_tune_mfma_kperm = 0;   // set through dgll_hip_debug_tune(4, .)
+
 static int transform_bf16_impl(void* stream, const void* A1, int64_t lda1, int K1, const void* Wt1, int64_t ldw1,
                                const void* A2, int64_t lda2, int K2, const void* Wt2, int64_t ldw2, int wt_rows,
                                const void* relu_mask, int64_t ldm, void* out, int64_t ldo, int out_dtype, int64_t M,
@@ -391,6 +396,7 @@ static int transform_bf16_impl(void* stream, const void* A1, int64_t lda1, int K
                  "out_gate: bf16 [M, ldgate >= N], 16-byte aligned rows");
     a.out_gate = static_cast<const bf16_t*>(out_gate); a.ldgate = ldgate;
     a.row_scale = row_scale;
+    a.kperm = g_tune_mfma_kperm;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int nt = (N + 31) / 32;
     hipError_t e;

@@ -461,12 +461,15 @@ DGLL_API int dgll_hip_csr_plan_create(void* stream, const int64_t* rowptr, int64
     return DGLL_OK;
 }
 
+extern int g_tune_mfma_kperm;   // dense.hip
+
 DGLL_API int dgll_hip_debug_tune(int key, int value) {
     switch (key) {
         case 0: g_tune_unroll = value; break;
         case 1: g_tune_rows_per_wave = value; break;
         case 2: g_tune_flags = value; break;
         case 3: g_tune_threshold = value; break;
+        case 4: g_tune_mfma_kperm = value; break;
         default: set_error("unknown tuning key"); return DGLL_ERR_INVALID;
     }
     return DGLL_OK;

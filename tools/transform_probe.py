@@ -32,6 +32,11 @@ for K, N in [(256, 256), (100, 256), (256, 47)]:
         return out.relu_()
 
     ideal = (2 * M * K + M * N) * 2 / 5e12 * 1e3
+    from dgll_amd import _lib
+    for perm in (1, 0, 1, 0):
+        _lib.lib.dgll_hip_debug_tune(4, perm)
+        print("   kperm=%d  fused %.3f ms  single %.3f ms" % (perm, t(lambda: dense.transform_bf16(h, wst, agg, wnt, relu=True)),
+                                                          t(lambda: dense.transform_bf16(h, wst))), flush=True)
     print("K=%d N=%d  library mm+addmm+relu %.3f ms | MFMA fused %.3f ms | single-pair MFMA %.3f ms vs mm %.3f ms | ideal@5TB/s %.3f" % (
         K, N, t(lib), t(lambda: dense.transform_bf16(h, wst, agg, wnt, relu=True)),
         t(lambda: dense.transform_bf16(h, wst)), t(lambda: torch.mm(h, ws)), ideal), flush=True)
