@@ -327,9 +327,9 @@ template <int NT>
 static hipError_t launch_mfma(const MfmaGemmArgs& a, hipStream_t s) {
     const size_t lds = 2 * (size_t)NT * 32 * kWPitch;
     if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_nt_kernel<NT>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
+        static hipError_t raised = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_nt_kernel<NT>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   // once: keeps
+        if (raised != hipSuccess) return raised;                            // launches free of non-stream calls (graph capture)
     }
     dim3 grid((uint32_t)((a.M + 127) / 128));
     hipLaunchKernelGGL((gemm_bf16_nt_kernel<NT>), grid, dim3(kBlock), lds, s, a);

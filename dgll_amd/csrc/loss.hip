@@ -15,7 +15,9 @@ namespace dgll {
 struct XentArgs {
     const void* z;
     int64_t ldz;
-    const int64_t* labels;
+    const int64_t* labels;  // class-index targets, or NULL when `soft` is given
+    const float* soft;      // probability / multi-hot targets fp32 [n_rows, lds] (nn.CrossEntropyLoss with float targets)
+    int64_t lds;
     float* row_loss;        // optional
     void* grad;             // optional
     int64_t ldg;
@@ -28,7 +30,7 @@ template <typename T> __device__ __forceinline__ float ld(const T* p);
 template <> __device__ __forceinline__ float ld<float>(const float* p) { return *p; }
 template <> __device__ __forceinline__ float ld<bf16_t>(const bf16_t* p) { return bf16_to_f32(*p); }
 
-template <typename T, int G, int PER>
+template <typename T, int G, int PER, bool SOFT>
 __global__ __launch_bounds__(kBlock) void softmax_xent_kernel(const XentArgs a) {
     constexpr int ROWS = kWave / G;
     const int lane = lane_id();
@@ -37,16 +39,24 @@ __global__ __launch_bounds__(kBlock) void softmax_xent_kernel(const XentArgs a) 
     const bool live = row < a.n_rows;
     const int64_t r = live ? row : a.n_rows - 1;          // every lane takes part in the shuffles
     const T* z = static_cast<const T*>(a.z) + r * a.ldz;
-    float v[PER];
-    float m = -INFINITY;
+    float v[PER], t[SOFT ? PER : 1];
+    float m = -INFINITY, tsum = 0.0f, tz = 0.0f;
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
         const int c = sub + j * G;
         v[j] = c < a.n_classes ? ld<T>(z + c) : -INFINITY;
         m = fmaxf(m, v[j]);
+        if constexpr (SOFT) {
+            t[j] = c < a.n_classes ? a.soft[r * a.lds + c] : 0.0f;
+            tsum += t[j];
+            if (c < a.n_classes) tz += t[j] * v[j];
+        }
     }
 #pragma unroll
-    for (int off = G / 2; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    for (int off = G / 2; off > 0; off >>= 1) {
+        m = fmaxf(m, __shfl_xor(m, off));
+        if constexpr (SOFT) { tsum += __shfl_xor(tsum, off); tz += __shfl_xor(tz, off); }
+    }
     float sum = 0.0f;
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
@@ -56,17 +66,30 @@ __global__ __launch_bounds__(kBlock) void softmax_xent_kernel(const XentArgs a) 
 #pragma unroll
     for (int off = G / 2; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
     if (!live) return;
-    const int64_t label = a.labels[r];
-    const bool counted = label >= 0 && label < a.n_classes;
-    if (a.row_loss && sub == 0) a.row_loss[r] = counted ? (m + __logf(sum)) - ld<T>(z + label) : 0.0f;
-    if (a.grad) {
-        const float scale = counted ? (a.scale ? *a.scale : 1.0f) : 0.0f;
-        const float inv = 1.0f / sum;
-        T* g = static_cast<T*>(a.grad) + r * a.ldg;
+    const float inv = 1.0f / sum;
+    if constexpr (SOFT) {      // loss_i = -sum_c t_c log p_c = (logsumexp) * sum_c t_c - sum_c t_c z_c ;  d/dz_c = p_c sum_c t_c - t_c
+        if (a.row_loss && sub == 0) a.row_loss[r] = (m + __logf(sum)) * tsum - tz;
+        if (a.grad) {
+            const float scale = a.scale ? *a.scale : 1.0f;
+            T* g = static_cast<T*>(a.grad) + r * a.ldg;
 #pragma unroll
-        for (int j = 0; j < PER; ++j) {
-            const int c = sub + j * G;
-            if (c < a.n_classes) store_one<T>(g + c, scale * (v[j] * inv - (c == label ? 1.0f : 0.0f)));
+            for (int j = 0; j < PER; ++j) {
+                const int c = sub + j * G;
+                if (c < a.n_classes) store_one<T>(g + c, scale * (v[j] * inv * tsum - t[j]));
+            }
+        }
+    } else {
+        const int64_t label = a.labels[r];
+        const bool counted = label >= 0 && label < a.n_classes;
+        if (a.row_loss && sub == 0) a.row_loss[r] = counted ? (m + __logf(sum)) - ld<T>(z + label) : 0.0f;
+        if (a.grad) {
+            const float scale = counted ? (a.scale ? *a.scale : 1.0f) : 0.0f;
+            T* g = static_cast<T*>(a.grad) + r * a.ldg;
+#pragma unroll
+            for (int j = 0; j < PER; ++j) {
+                const int c = sub + j * G;
+                if (c < a.n_classes) store_one<T>(g + c, scale * (v[j] * inv - (c == label ? 1.0f : 0.0f)));
+            }
         }
     }
 }
@@ -75,7 +98,8 @@ template <typename T, int G, int PER>
 static hipError_t launch_xent(const XentArgs& a, hipStream_t s) {
     const int64_t rows_per_block = (int64_t)kWavesPerBlock * (kWave / G);
     dim3 grid((uint32_t)((a.n_rows + rows_per_block - 1) / rows_per_block));
-    hipLaunchKernelGGL((softmax_xent_kernel<T, G, PER>), grid, dim3(kBlock), 0, s, a);
+    if (a.soft) hipLaunchKernelGGL((softmax_xent_kernel<T, G, PER, true>), grid, dim3(kBlock), 0, s, a);
+    else hipLaunchKernelGGL((softmax_xent_kernel<T, G, PER, false>), grid, dim3(kBlock), 0, s, a);
     return hipGetLastError();
 }
 
@@ -96,24 +120,39 @@ static hipError_t dispatch_xent(const XentArgs& a, hipStream_t s) {
 
 using namespace dgll;
 
-DGLL_API int dgll_hip_softmax_xent(void* stream, const void* logits, int64_t ldz, int dtype, const int64_t* labels,
-                                   float* row_loss, void* grad, int64_t ldg, const float* grad_scale, int64_t n_rows,
-                                   int n_classes) {
+static int xent_impl(void* stream, const void* logits, int64_t ldz, int dtype, const int64_t* labels, const float* soft,
+                     int64_t lds, float* row_loss, void* grad, int64_t ldg, const float* grad_scale, int64_t n_rows,
+                     int n_classes) {
     DGLL_REQUIRE(n_rows >= 0 && n_classes >= 0, "negative size");
     if (n_rows == 0 || n_classes == 0) return DGLL_OK;
-    DGLL_REQUIRE(logits && labels, "NULL logits/labels");
+    DGLL_REQUIRE(logits && (labels || soft), "NULL logits/targets");
     DGLL_REQUIRE(row_loss || grad, "nothing to compute: pass row_loss and/or grad");
-    DGLL_REQUIRE(ldz >= n_classes && (!grad || ldg >= n_classes), "leading dimension smaller than n_classes");
+    DGLL_REQUIRE(ldz >= n_classes && (!grad || ldg >= n_classes) && (!soft || lds >= n_classes),
+                 "leading dimension smaller than n_classes");
     DGLL_REQUIRE(dtype == DGLL_F32 || dtype == DGLL_BF16, "dtype");
     if (n_classes > 1024) {
         set_error("dgll_hip_softmax_xent keeps a row's classes in registers: n_classes <= 1024");
         return DGLL_ERR_UNSUPPORTED;
     }
     XentArgs a{};
-    a.z = logits; a.ldz = ldz; a.labels = labels; a.row_loss = row_loss; a.grad = grad; a.ldg = ldg; a.scale = grad_scale;
-    a.n_rows = n_rows; a.n_classes = n_classes;
+    a.z = logits; a.ldz = ldz; a.labels = labels; a.soft = soft; a.lds = lds; a.row_loss = row_loss; a.grad = grad; a.ldg = ldg;
+    a.scale = grad_scale; a.n_rows = n_rows; a.n_classes = n_classes;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const hipError_t e = dtype == DGLL_F32 ? dispatch_xent<float>(a, s) : dispatch_xent<bf16_t>(a, s);
     if (e != hipSuccess) return hip_fail(e, "softmax_xent_kernel launch");
     return DGLL_OK;
+}
+
+DGLL_API int dgll_hip_softmax_xent(void* stream, const void* logits, int64_t ldz, int dtype, const int64_t* labels,
+                                   float* row_loss, void* grad, int64_t ldg, const float* grad_scale, int64_t n_rows,
+                                   int n_classes) {
+    DGLL_REQUIRE(labels || n_rows == 0, "NULL labels");
+    return xent_impl(stream, logits, ldz, dtype, labels, nullptr, 0, row_loss, grad, ldg, grad_scale, n_rows, n_classes);
+}
+
+DGLL_API int dgll_hip_softmax_xent_soft(void* stream, const void* logits, int64_t ldz, int dtype, const float* targets,
+                                        int64_t ldt, float* row_loss, void* grad, int64_t ldg, const float* grad_scale,
+                                        int64_t n_rows, int n_classes) {
+    DGLL_REQUIRE(targets || n_rows == 0, "NULL targets");
+    return xent_impl(stream, logits, ldz, dtype, nullptr, targets, ldt, row_loss, grad, ldg, grad_scale, n_rows, n_classes);
 }

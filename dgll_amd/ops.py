@@ -177,53 +177,78 @@ def spmm(graph, x, val=None, reduce="sum", bias=None, relu=False):
 
 
 # ------------------------------------------------------------------------------------------------ loss
+def _xent_launch(z, target, soft, row_loss, grad, scale):
+    n, c = z.shape
+    with torch.cuda.device(z.device):
+        stream = torch.cuda.current_stream(z.device).cuda_stream
+        rl = row_loss.data_ptr() if row_loss is not None else None
+        gp, gld = (grad.data_ptr(), grad.stride(0)) if grad is not None else (None, 0)
+        sp = scale.data_ptr() if scale is not None else None
+        if soft:
+            code = _lib.lib.dgll_hip_softmax_xent_soft(stream, z.data_ptr(), z.stride(0), _dtype_code(z), target.data_ptr(),
+                                                       target.stride(0), rl, gp, gld, sp, n, c)
+        else:
+            code = _lib.lib.dgll_hip_softmax_xent(stream, z.data_ptr(), z.stride(0), _dtype_code(z), target.data_ptr(),
+                                                  rl, gp, gld, sp, n, c)
+    _lib.check(code, "dgll_hip_softmax_xent")
+
+
 class _CrossEntropy(torch.autograd.Function):
-    """Softmax cross-entropy with class-index targets, one kernel per direction (dgll_hip_softmax_xent)."""
+    """Softmax cross-entropy, one kernel per direction (dgll_hip_softmax_xent / _soft).  The per-row losses are summed in
+    two stages (a [n] -> [~sqrt n] -> scalar tree of small reductions) rather than by one large single-output reduction:
+    the latter relies on a memset node when captured in a HIP graph, which replays unreliably on this stack
+    (dgll_amd/graphs.py)."""
 
     @staticmethod
-    def forward(ctx, logits, labels, reduction):
-        _require_cuda(logits, labels)
-        if logits.dim() != 2 or labels.shape != (logits.shape[0],):
-            raise ValueError("cross_entropy expects logits [N, C] and labels [N]")
+    def forward(ctx, logits, target, reduction):
+        _require_cuda(logits, target)
+        if logits.dim() != 2:
+            raise ValueError("cross_entropy expects logits [N, C]")
         if logits.dtype not in (torch.float32, torch.bfloat16):
             raise TypeError("cross_entropy: fp32 or bf16 logits")
+        soft = target.is_floating_point()
+        if soft:
+            if target.shape != logits.shape:
+                raise ValueError("probability targets must have the logits' shape [N, C]")
+            target = target.to(torch.float32)
+            target = target if target.stride(1) == 1 else target.contiguous()
+        else:
+            if target.shape != (logits.shape[0],):
+                raise ValueError("cross_entropy expects logits [N, C] and labels [N]")
+            target = target.to(torch.int64).contiguous()
         z = logits if logits.stride(1) == 1 else logits.contiguous()
-        labels = labels.to(torch.int64).contiguous()
         n, c = z.shape
-        row_loss = torch.empty(n, dtype=torch.float32, device=z.device)
-        with torch.cuda.device(z.device):
-            code = _lib.lib.dgll_hip_softmax_xent(torch.cuda.current_stream(z.device).cuda_stream, z.data_ptr(), z.stride(0),
-                                                  _dtype_code(z), labels.data_ptr(), row_loss.data_ptr(), None, 0, None, n, c)
-        _lib.check(code, "dgll_hip_softmax_xent")
-        ctx.reduction = reduction
-        if reduction == "mean":          # torch semantics: mean over the targets that are not ignored
-            count = ((labels >= 0) & (labels < c)).sum().to(torch.float32)
-            ctx.save_for_backward(z, labels, count)
-            return row_loss.sum() / count
-        ctx.save_for_backward(z, labels, None)
-        return row_loss.sum() if reduction == "sum" else row_loss
+        store = torch.empty(-(-n // 256) * 256, dtype=torch.float32, device=z.device)   # padded for the two-stage sum
+        store[n:].zero_()
+        row_loss = store[:n]
+        _xent_launch(z, target, soft, row_loss, None, None)
+        ctx.reduction, ctx.soft = reduction, soft
+        count = None
+        if reduction == "mean":          # torch semantics: mean over the targets that are not ignored (soft targets: over N)
+            count = (torch.full((), float(n), device=z.device) if soft
+                     else ((target >= 0) & (target < c)).sum().to(torch.float32))
+        ctx.save_for_backward(z, target, count)
+        if reduction == "none":
+            return row_loss
+        total = store.view(-1, 256).sum(1).sum() if n > 4096 else row_loss.sum()
+        return total / count if reduction == "mean" else total
 
     @staticmethod
     def backward(ctx, g):
-        z, labels, count = ctx.saved_tensors
-        n, c = z.shape
+        z, target, count = ctx.saved_tensors
         per_row = ctx.reduction == "none"
         scale = (g.float() / count if count is not None else g.float()).reshape(-1) if not per_row else None
         grad = torch.empty_like(z)
-        with torch.cuda.device(z.device):
-            code = _lib.lib.dgll_hip_softmax_xent(torch.cuda.current_stream(z.device).cuda_stream, z.data_ptr(), z.stride(0),
-                                                  _dtype_code(z), labels.data_ptr(), None, grad.data_ptr(), grad.stride(0),
-                                                  scale.data_ptr() if scale is not None else None, n, c)
-        _lib.check(code, "dgll_hip_softmax_xent")
+        _xent_launch(z, target, ctx.soft, None, grad, scale)
         if per_row:
             grad = grad * g.to(grad.dtype).unsqueeze(1)
         return grad, None, None
 
 
 def cross_entropy(logits, labels, reduction="mean"):
-    """F.cross_entropy(logits, labels) for GPU logits [N, C] (fp32 or bf16; math in fp32) and int64 class indices;
-    labels outside [0, C) (e.g. -100) are ignored.  The loss the reference's training loops put on the last layer
-    (Evaluation/PPI/train_gcn.py:27)."""
+    """F.cross_entropy(logits, target) for GPU logits [N, C] (fp32 or bf16; math in fp32).  `target`: int64 class indices
+    [N] (entries outside [0, C), e.g. -100, are ignored) or a float [N, C] matrix of probabilities / multi-hot labels --
+    the PPI loop's case (Evaluation/PPI/train_gcn.py:27,45 hands nn.CrossEntropyLoss the float label matrix)."""
     if reduction not in ("mean", "sum", "none"):
         raise ValueError("reduction must be 'mean', 'sum' or 'none'")
     return _CrossEntropy.apply(logits, labels, reduction)

@@ -14,6 +14,7 @@ import time
 import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+from dgll_amd import ops  # noqa: E402
 from dgll_amd.evaluation.ppi import GCN, load_ppi_dataset  # noqa: E402
 
 
@@ -38,6 +39,8 @@ def main():
     ap.add_argument("--hidden", type=int, default=64)
     ap.add_argument("--layers", type=int, default=2)
     ap.add_argument("--lr", type=float, default=0.01)
+    ap.add_argument("--capturable", action="store_true", help="eager loop with the capture-safe Adam (A/B against --hip-graphs)")
+    ap.add_argument("--hip-graphs", action="store_true", help="capture each graph's training step into a HIP graph")
     args = ap.parse_args()
     if not torch.cuda.is_available():
         raise SystemExit("this example runs the HIP kernels: a GPU is required")
@@ -52,19 +55,31 @@ def main():
     with torch.no_grad():
         for layer in model.layers:          # the reference's unscaled randn init overflows the loss on real PPI
             layer.weight.mul_(1.0 / layer.weight.shape[0] ** 0.5)
-    opt = torch.optim.Adam(model.parameters(), lr=args.lr)
-    crit = torch.nn.CrossEntropyLoss()
+    opt = torch.optim.Adam(model.parameters(), lr=args.lr, capturable=args.hip_graphs or args.capturable)
+    crit = ops.cross_entropy             # nn.CrossEntropyLoss()(out, float multi-hot labels) in one kernel per direction
+    steps = None
+    if args.hip_graphs:        # static shapes per graph: the whole epoch (one step per graph) becomes ONE HIP graph
+        from dgll_amd.graphs import GraphedTrainStep
+
+        t0 = time.time()
+        steps = GraphedTrainStep([lambda e=e, x=x, y=y: crit(model(e, x), y) for e, x, y in train], opt, warmup=1)
+        print("captured the %d steps of an epoch into one HIP graph in %.2f s (the warm-up epoch counts as training)"
+              % (len(train), time.time() - t0))
     edges_per_epoch = sum(int(e.shape[1]) for e, _, _ in train) * args.layers * 2      # forward + transposed backward
     for epoch in range(args.epochs):
         torch.cuda.synchronize()
         t0 = time.time()
         total = torch.zeros((), device=dev)
-        for e, x, y in train:
-            opt.zero_grad()
-            loss = crit(model(e, x), y)
-            loss.backward()
-            opt.step()
-            total += loss.detach()
+        if steps is not None:
+            steps()                                                      # one host call replays the epoch
+            total = steps.total                                          # static scalar computed inside the graph
+        else:
+            for e, x, y in train:
+                opt.zero_grad()
+                loss = crit(model(e, x), y)
+                loss.backward()
+                opt.step()
+                total += loss.detach()
         torch.cuda.synchronize()
         dt = time.time() - t0
         print("Epoch %d/%d, Loss: %.4f, Time per Epoch: %.4fs, %.1f M aggregated edges/s"

@@ -228,6 +228,12 @@ int dgll_hip_transform_bf16_gated(void* stream, const void* A1, int64_t lda1, in
 int dgll_hip_softmax_xent(void* stream, const void* logits, int64_t ldz, int dtype, const int64_t* labels,
                           float* row_loss, void* grad, int64_t ldg, const float* grad_scale, int64_t n_rows,
                           int n_classes);
+/* The same loss with probability / multi-hot targets (fp32 [n_rows, ldt]) -- what nn.CrossEntropyLoss computes for the
+ * float label matrix of the PPI loop (train_gcn.py:27,45): row_loss[i] = -sum_c t_ic log softmax(z_i)[c],
+ * grad[i, c] = *grad_scale * (softmax(z_i)[c] * sum_c t_ic - t_ic).                                             */
+int dgll_hip_softmax_xent_soft(void* stream, const void* logits, int64_t ldz, int dtype, const float* targets,
+                               int64_t ldt, float* row_loss, void* grad, int64_t ldg, const float* grad_scale,
+                               int64_t n_rows, int n_classes);
 
 /* ---- a10: H = relu(A_csr . (X[:, :actual_F] . W[:actual_F, :])) --------------------------------------------
  * launch_gcn_fused_kernel is the reference's own symbol with its exact signature

@@ -42,3 +42,26 @@ def test_cross_entropy_padded_rows_and_errors(cuda_device):
         ops.cross_entropy(z, labels[:5])
     with pytest.raises(RuntimeError):
         ops.cross_entropy(torch.randn(4, 2000, device=cuda_device), torch.zeros(4, dtype=torch.long, device=cuda_device))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("classes,n", [(121, 3230), (5, 70000), (300, 513)])
+@pytest.mark.parametrize("reduction", ["mean", "sum", "none"])
+def test_soft_target_cross_entropy_matches_torch(cuda_device, dtype, classes, n, reduction):
+    """nn.CrossEntropyLoss with a float [N, C] target (multi-hot PPI labels, train_gcn.py:27,45)."""
+    from dgll_amd import ops
+
+    torch.manual_seed(classes + n)
+    z = (torch.randn(n, classes, device=cuda_device) * 3).to(dtype)
+    t = (torch.rand(n, classes, device=cuda_device) < 0.3).float()
+    t[7] = 0                                                          # a row without any label
+    za = z.clone().requires_grad_()
+    zr = z.float().clone().requires_grad_()
+    loss = ops.cross_entropy(za, t, reduction=reduction)
+    ref = F.cross_entropy(zr, t, reduction=reduction)
+    torch.testing.assert_close(loss, ref, rtol=2e-5, atol=1e-4)
+    w = torch.randn_like(ref)
+    (loss * w).sum().backward()
+    (ref * w).sum().backward()
+    tol = 2e-5 if dtype == torch.float32 else 1e-2
+    torch.testing.assert_close(za.grad.float(), zr.grad, rtol=tol, atol=tol * float(zr.grad.abs().max()))
