@@ -107,3 +107,70 @@ def _gat_worker(rank, world, port):
 def test_partitioned_gat_two_ranks_match_single_process():
     """Config 4's multi-GPU leg: the fused edge-softmax kernels over the split adjacency, forward and backward."""
     mp.spawn(_gat_worker, args=(2, _free_port()), nprocs=2, join=True)
+
+
+def _rccl_worker(rank, world, port):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    try:
+        from dgll_amd import dist as ddist
+        from dgll_amd import nn as dnn
+        from dgll_amd import synth
+
+        torch.manual_seed(0)
+        full = synth.products_like_graph(dev, seed=3, n=3000, n_undirected=20000, locality=0.8, n_blocks=8)
+        model = dnn.GraphSage(16, [32, 8], None).to(dev)
+        x = torch.randn(full.n_rows, 16, device=dev)
+        part = ddist.partition_contiguous(full, world, rank)
+        engine = ddist.DistGraph(part, dev)
+        engine.verify()
+        out = engine.sage_forward(model, engine.permute_to_local(x))
+        out.sum().backward()
+        before = [p.grad.clone() for p in model.parameters()]
+        racom = ddist.RaCoM(model.parameters(), dev)
+        racom.launch()                                   # bucketed all-reduce on RCCL, own stream
+        racom.wait()
+        for p, q in zip(model.parameters(), before):
+            torch.testing.assert_close(p.grad, q)
+        t = torch.tensor([3.5], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)         # the bench's max-over-ranks timing reduction
+        dist.barrier()
+        assert float(t) == 3.5 and torch.equal(out, model.forward_graph(full, x))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_backend_initialises_and_reduces_at_world_size_one():
+    """Backend "nccl" (= RCCL) end to end on the one GPU of the test box: process-group init, the engine at world size 1,
+    RaCoM's bucket all-reduce on its own stream, the bench's MAX reduction and barrier."""
+    mp.spawn(_rccl_worker, args=(1, _free_port()), nprocs=1, join=True)
+
+
+def _rccl_p2p_worker(rank, world, port):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    try:
+        # the exchange's transport exactly as dist._Exchange issues it: one grouped batch of isend/irecv on a side
+        # stream, here with the only peer there is on a 1-GPU box (the rank itself), bf16 rows and fp32 score rows
+        comm = torch.cuda.Stream()
+        send_h = torch.randn(5000, 256, device=dev).to(torch.bfloat16)
+        send_t = torch.randn(5000, 8, device=dev)
+        recv_h, recv_t = torch.empty_like(send_h), torch.empty_like(send_t)
+        comm.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(comm):
+            ops_ = [dist.P2POp(dist.isend, send_h, 0), dist.P2POp(dist.irecv, recv_h, 0),
+                    dist.P2POp(dist.isend, send_t, 0), dist.P2POp(dist.irecv, recv_t, 0)]
+            for req in dist.batch_isend_irecv(ops_):
+                req.wait()
+        torch.cuda.current_stream().wait_stream(comm)
+        assert torch.equal(recv_h, send_h) and torch.equal(recv_t, send_t)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_grouped_send_recv_on_a_side_stream():
+    mp.spawn(_rccl_p2p_worker, args=(1, _free_port()), nprocs=1, join=True)
