@@ -184,7 +184,13 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        step()
+        wl = step()
+        if os.environ.get("DGLL_BENCH_TRACE_LOSS"):      # debugging aid: per-step global loss (costs a sync + all-reduce)
+            g = wl.detach().double() / world
+            if world > 1:
+                torch.distributed.all_reduce(g)
+            if rank == 0:
+                print("warm-up loss %.6f" % float(g), file=sys.stderr)
     barrier()
     with ops.LaunchTimer() as timer:
         t0 = time.perf_counter()

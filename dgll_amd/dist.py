@@ -133,18 +133,30 @@ def nnz_balanced_bounds(graph, world):
 
 # ----------------------------------------------------------------------------------------------------------------
 class _Exchange:
-    """Grouped point-to-point halo exchange (works on RCCL and gloo)."""
+    """Grouped point-to-point halo exchange.
+
+    RCCL ("nccl"): device buffers, stream-ordered -- the product path.  gloo has no device send/recv (it would read the
+    device pointer from the host with no ordering against the GPU kernels that fill the buffer: silent races), so for
+    device tensors on gloo -- the functional multi-rank tests that share one GPU -- the rows are staged through host
+    memory explicitly: copy out (synchronising), send/recv on CPU tensors, copy back on the communication stream."""
 
     def __init__(self, part, group=None):
         self.part, self.group = part, group
+
+    def _staged(self, t):
+        return t.is_cuda and self.part.world > 1 and dist.is_initialized() and dist.get_backend(self.group) != "nccl"
 
     def start(self, send_buf, recv_buf, reverse=False, more=()):
         """One grouped call moving `send_buf` rows to their peers and filling `recv_buf`; `more` = further
         (send, recv) pairs with the same row layout (e.g. the fp32 score rows next to the feature rows)."""
         p = self.part
         s_counts, r_counts = (p.recv_counts, p.send_counts) if reverse else (p.send_counts, p.recv_counts)
-        opsl = []
+        opsl, copy_back = [], []
         for sb, rb in ((send_buf, recv_buf),) + tuple(more):
+            if self._staged(sb) or self._staged(rb):
+                host_recv = torch.empty(rb.shape, dtype=rb.dtype, device="cpu")
+                copy_back.append((rb, host_recv))
+                sb, rb = sb.cpu(), host_recv                 # .cpu() waits for the kernels that produced the rows
             so = ro = 0
             for q in range(p.world):
                 if s_counts[q]:
@@ -153,12 +165,16 @@ class _Exchange:
                     opsl.append(dist.P2POp(dist.irecv, rb[ro:ro + r_counts[q]], q, self.group))
                 so += s_counts[q]
                 ro += r_counts[q]
-        return dist.batch_isend_irecv(opsl) if opsl else []
+        reqs = dist.batch_isend_irecv(opsl) if opsl else []
+        return (reqs, copy_back)
 
     @staticmethod
-    def wait(reqs):
+    def wait(handle):
+        reqs, copy_back = handle
         for r in reqs:
             r.wait()
+        for dev_buf, host_buf in copy_back:
+            dev_buf.copy_(host_buf)
 
 
 class DistAggregate(torch.autograd.Function):

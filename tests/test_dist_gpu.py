@@ -1,6 +1,7 @@
-"""The partitioned engine with the REAL kernels: two ranks sharing the one GPU of the test box (gloo transport, which
-accepts device tensors), full-graph GraphSage forward + backward vs the single-process result.  (RCCL itself needs one
-GPU per rank and is exercised by the driver's multi-GPU bench.)"""
+"""The partitioned engine with the REAL kernels: two ranks sharing the one GPU of the test box over gloo (whose device
+send/recv is staged through host memory by dist._Exchange -- gloo itself would read device pointers unordered), full-graph
+GraphSage / SpGAT forward + backward and multi-step training vs the single-process result.  RCCL needs one GPU per rank:
+here only its world-size-1 paths and a grouped self send/recv run; the multi-GPU bench is the driver's."""
 import os
 import socket
 
@@ -174,3 +175,62 @@ def _rccl_p2p_worker(rank, world, port):
 
 def test_rccl_grouped_send_recv_on_a_side_stream():
     mp.spawn(_rccl_p2p_worker, args=(1, _free_port()), nprocs=1, join=True)
+
+
+def _train_worker(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dgll_amd import dist as ddist
+        from dgll_amd import nn as dnn
+        from dgll_amd import ops, synth
+
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        torch.manual_seed(0)
+        full = synth.products_like_graph(dev, seed=0, n=120000, n_undirected=2400000, locality=0.9)
+        n = full.n_rows
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(1)
+        model = dnn.GraphSage(100, [256, 256, 47], None).to(dev)
+        labels_all = torch.randint(0, 47, (n,), generator=gen, device=dev)
+        feats = torch.randn(n, 100, generator=gen, device=dev)
+        part = ddist.partition_contiguous(full, world, rank)
+        engine = ddist.DistGraph(part, dev)
+        engine.verify()
+        x_local = ops.alloc_features(part.n_own, 100, torch.bfloat16, dev, pad_to=64)
+        x_local.copy_(engine.permute_to_local(feats[part.own_begin:part.own_end]).to(torch.bfloat16))
+        labels = engine.permute_to_local(labels_all[part.own_begin:part.own_end])
+        placed = engine.place_input_halo(x_local)
+        racom = ddist.RaCoM(model.parameters(), dev)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+        losses = []
+        for _ in range(5):
+            opt.zero_grad(set_to_none=True)
+            out = engine.sage_forward(model, x_local, placed)
+            loss = ops.cross_entropy(out, labels, reduction="sum") * (world / n)
+            loss.backward()
+            racom.all_reduce_and_wait()
+            opt.step()
+            g = loss.detach().double() / world
+            if world > 1:
+                dist.all_reduce(g)
+            losses.append(float(g))
+        if rank == 0:
+            torch.save(losses, out_path)
+    finally:
+        if world > 1:
+            dist.destroy_process_group()
+
+
+def test_partitioned_training_steps_track_the_single_process_run(tmp_path):
+    """Five optimizer steps of the bench's model (bf16, 100-256-256-47) on a 120 k-node graph: the 2-rank loss trace must
+    follow the 1-rank trace step by step.  Large enough that every exchange is megabytes -- an unordered transport (gloo
+    reading device pointers from the host; see dist._Exchange) shows up as garbage from the second step on."""
+    a, b = str(tmp_path / "w1.pt"), str(tmp_path / "w2.pt")
+    mp.spawn(_train_worker, args=(1, _free_port(), a), nprocs=1, join=True)
+    mp.spawn(_train_worker, args=(2, _free_port(), b), nprocs=2, join=True)
+    one, two = torch.load(a), torch.load(b)
+    assert one[-1] < one[0] - 1.0                                   # it trains
+    torch.testing.assert_close(torch.tensor(two), torch.tensor(one), rtol=2e-4, atol=2e-4)
