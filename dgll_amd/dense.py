@@ -139,6 +139,35 @@ def linear(x, w):
     return _Linear.apply(x, w)
 
 
+class _SkinnyLinear(torch.autograd.Function):
+    """x[M, K] . w[K, n] -> fp32 [M, n] for a handful of output columns (the per-node attention scores of all GAT heads:
+    n = 2 * heads).  Forward on the MFMA kernel with fp32 output (no bf16 rounding of the scores); the weight gradient
+    x^T . g -- an M = millions reduction into a K x n sliver, for which the library picks a 5 ms kernel at the products
+    shape -- goes through the split-K batched GEMM (0.3 ms)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        wd = w.to(x.dtype)
+        if _mfma_ok(x) and wd.shape[1] <= 256:
+            out = transform_bf16(x, wd.t(), out_dtype=torch.float32)
+        else:
+            out = torch.mm(x, wd).float()
+        ctx.save_for_backward(x, wd)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, wd = ctx.saved_tensors
+        gd = g.to(x.dtype).contiguous()
+        gx = torch.mm(gd, wd.t()) if ctx.needs_input_grad[0] else None
+        gw = grad_weight(x, gd) if ctx.needs_input_grad[1] else None
+        return gx, gw
+
+
+def skinny_linear(x, w):
+    return _SkinnyLinear.apply(x, w)
+
+
 class _AddLinearAct(torch.autograd.Function):
     """act(addend + x . w): the self term of a transform-first SAGE layer (the neighbour term arrives already
     aggregated).  Library addmm, in-place ReLU, split-K weight gradient."""

@@ -439,7 +439,7 @@ class DistGraph:
         for k in range(heads):
             A[k * fo:(k + 1) * fo, k] = a1s[k].to(h.dtype)
             A[k * fo:(k + 1) * fo, heads + k] = a2s[k].to(h.dtype)
-        st = torch.mm(h, A).float()
+        st = dense.skinny_linear(h, A)
         fo_pad = ops.head_width_padded(fo, h.dtype)
         hp = h if fo_pad == fo else torch.nn.functional.pad(h.view(-1, heads, fo), (0, fo_pad - fo)).reshape(-1, heads * fo_pad)
         out = DistGatAggregate.apply(hp, st[:, :heads], st[:, heads:], self, heads, fo_pad, alpha, concat)

@@ -59,7 +59,7 @@ def _fused_heads(x, adj, Ws, a1s, a2s, alpha, concat, mode, dropout, training):
     for k in range(heads):
         A[k * fo:(k + 1) * fo, k] = a1s[k].to(h.dtype)
         A[k * fo:(k + 1) * fo, heads + k] = a2s[k].to(h.dtype)
-    st = F.mm(h, A).float()
+    st = dense.skinny_linear(h, A)                                             # fp32 [N, 2*heads]
     s, t = st[:, :heads], st[:, heads:]
     fo_pad = ops.head_width_padded(fo, h.dtype)
     out = ops.gat_aggregate(graph, _pad_heads(h, heads, fo, fo_pad), s, t, heads, alpha, apply_elu=concat, mode=mode,
