@@ -76,6 +76,22 @@ def grad_weight(x, g):
     return out
 
 
+def column_sum(g, slabs=2048):
+    """g.sum(0) in fp32 for a tall matrix (bias gradients).  torch's single-pass column reduction of a [2.4 M, 47] bf16
+    matrix takes 12-18 ms; reduced in two stages -- [slabs, rows, F] over rows, then over slabs -- it reads g once at HBM
+    speed (0.10 ms), with fp32 accumulation throughout.  (A ones-vector GEMM costs 1-2 ms; the batched split-K form spends
+    11 ms per call on the host in the library's heuristics for that shape.)"""
+    m = g.shape[0]
+    if m < 64 * slabs:
+        return g.sum(0, dtype=torch.float32)
+    rows = m // slabs
+    main = rows * slabs
+    out = g[:main].view(slabs, rows, g.shape[1]).sum(1, dtype=torch.float32).sum(0)
+    if main < m:
+        out = out + g[main:].sum(0, dtype=torch.float32)
+    return out
+
+
 class _SageTransform(torch.autograd.Function):
     """relu?( h.Ws + agg.Wn ) with one fused add (addmm) and in-place activation; backward shares the masked gradient
     between the four products (sageconv.py:71-82 computes the same terms as separate autograd nodes)."""

@@ -34,13 +34,16 @@ class gcnConv(F.nn.Module):
             if self.bias is not None:
                 self.bias.uniform_(-bound, bound)
 
-    def forward(self, x, adj):
+    def forward(self, x, adj, relu=False):
+        """adj . (x . weight) + bias (gcnconv.py:29-35).  relu=True (an extension GCN.forward uses) applies the activation
+        that always follows inside the aggregation kernel's epilogue instead of as a pass of its own."""
         if x.is_cuda:
             support = dense.linear(x, self.weight)           # transform first (gcnconv.py:30): MFMA kernel for bf16 inputs
-            return ops.spmm(as_csr_graph(adj), support, bias=self.bias)   # aggregate + fused bias (gcnconv.py:31-33)
+            return ops.spmm(as_csr_graph(adj), support, bias=self.bias, relu=relu)   # aggregate + fused bias (:31-33)
         support = F.mm(x, self.weight.to(x.dtype))
         out = F.spmm(adj, support)
-        return out if self.bias is None else out + self.bias
+        out = out if self.bias is None else out + self.bias
+        return F.relu(out) if relu else out
 
     def extra_repr(self):
         return "%d -> %d" % (self.in_features, self.out_features)
@@ -56,6 +59,6 @@ class GCN(F.nn.Module):
         self.gcn2 = gcnConv(nhid, nclass)
 
     def forward(self, x, adj):
-        hidden = F.relu(self.gcn1(x, adj))
+        hidden = self.gcn1(x, adj, relu=True)                 # F.relu(self.gcn1(x, adj)), gcnconv.py:54
         hidden = F.dropout(hidden, self.dropout, training=self.training)
         return F.log_softmax(self.gcn2(hidden, adj), dim=1)

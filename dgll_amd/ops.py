@@ -138,7 +138,9 @@ class _Spmm(torch.autograd.Function):
         g = _row_major(g)
         grad_x = grad_val = grad_bias = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            grad_bias = g.sum(0, dtype=torch.float32)
+            from .dense import column_sum
+
+            grad_bias = column_sum(g)
         if ctx.needs_input_grad[0]:
             gt, perm = graph.transpose()
             tval = gt.val if val is None else val.detach()[perm]  # gt.val is the cached permuted graph.val
