@@ -15,6 +15,9 @@
 // sees the stream exactly as if the reference's pure-Python loop had run.  (The algorithm is CPython-version
 // specific; tests/test_sampler.py checks it against the running interpreter and against the goldens.)
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <thread>
 #include <vector>
 
@@ -23,37 +26,47 @@
 namespace {
 
 struct MT19937 {
-    uint32_t* mt;   // 624 words, caller-owned
+    uint32_t* mt;   // 624 words, caller-owned (CPython's untempered state vector)
     int idx;
-    uint32_t next() {
+    uint32_t out[624];   // the tempered outputs of the current block: next() is a load; twist + tempering run once per
+                         // 624 draws in loops the compiler vectorises
+    bool fresh = false;  // `out` matches `mt`
+    void temper() {
+        for (int i = 0; i < 624; ++i) {
+            uint32_t y = mt[i];
+            y ^= (y >> 11);
+            y ^= (y << 7) & 0x9d2c5680U;
+            y ^= (y << 15) & 0xefc60000U;
+            y ^= (y >> 18);
+            out[i] = y;
+        }
+        fresh = true;
+    }
+    void twist() {
         constexpr int N = 624, M = 397;
         constexpr uint32_t MATRIX_A = 0x9908b0dfU, UPPER = 0x80000000U, LOWER = 0x7fffffffU;
-        if (idx >= N) {
-            int kk;
-            for (kk = 0; kk < N - M; kk++) {
-                uint32_t y = (mt[kk] & UPPER) | (mt[kk + 1] & LOWER);
-                mt[kk] = mt[kk + M] ^ (y >> 1) ^ ((y & 1U) ? MATRIX_A : 0U);
-            }
-            for (; kk < N - 1; kk++) {
-                uint32_t y = (mt[kk] & UPPER) | (mt[kk + 1] & LOWER);
-                mt[kk] = mt[kk + (M - N)] ^ (y >> 1) ^ ((y & 1U) ? MATRIX_A : 0U);
-            }
-            uint32_t y = (mt[N - 1] & UPPER) | (mt[0] & LOWER);
-            mt[N - 1] = mt[M - 1] ^ (y >> 1) ^ ((y & 1U) ? MATRIX_A : 0U);
-            idx = 0;
+        int kk;
+        for (kk = 0; kk < N - M; kk++) {
+            uint32_t y = (mt[kk] & UPPER) | (mt[kk + 1] & LOWER);
+            mt[kk] = mt[kk + M] ^ (y >> 1) ^ ((0U - (y & 1U)) & MATRIX_A);
         }
-        uint32_t y = mt[idx++];
-        y ^= (y >> 11);
-        y ^= (y << 7) & 0x9d2c5680U;
-        y ^= (y << 15) & 0xefc60000U;
-        y ^= (y >> 18);
-        return y;
+        for (; kk < N - 1; kk++) {
+            uint32_t y = (mt[kk] & UPPER) | (mt[kk + 1] & LOWER);
+            mt[kk] = mt[kk + (M - N)] ^ (y >> 1) ^ ((0U - (y & 1U)) & MATRIX_A);
+        }
+        uint32_t y = (mt[N - 1] & UPPER) | (mt[0] & LOWER);
+        mt[N - 1] = mt[M - 1] ^ (y >> 1) ^ ((0U - (y & 1U)) & MATRIX_A);
+    }
+    inline uint32_t next() {
+        if (__builtin_expect(idx >= 624, 0)) { twist(); temper(); idx = 0; }
+        else if (__builtin_expect(!fresh, 0)) temper();
+        return out[idx++];
     }
     // random._randbelow_with_getrandbits for 0 < n < 2**32
-    uint32_t randbelow(uint32_t n) {
-        const int k = 32 - __builtin_clz(n);          // n.bit_length()
-        uint32_t r = next() >> (32 - k);
-        while (r >= n) r = next() >> (32 - k);
+    inline uint32_t randbelow(uint32_t n) {
+        const int sh = __builtin_clz(n);              // 32 - n.bit_length()
+        uint32_t r = next() >> sh;
+        while (r >= n) r = next() >> sh;
         return r;
     }
 };
@@ -75,8 +88,11 @@ DGLL_API int dgll_host_sample_neighbors(uint32_t* mt_state, int* mt_index, const
                                         int64_t* n_out) {
     DGLL_REQUIRE(mt_state && mt_index && indptr && indices && (seeds || n_seeds == 0) && out_counts && n_out, "NULL argument");
     DGLL_REQUIRE(*mt_index >= 0 && *mt_index <= 624, "bad generator index");
+    static const bool profile = std::getenv("DGLL_SAMPLER_PROFILE") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
     MT19937 rng{mt_state, *mt_index};
-    std::vector<uint32_t> pool;      // pool algorithm, on positions
+    std::vector<uint32_t> pool;      // pool algorithm, on positions: kept equal to the identity between seeds (only the
+                                     // entries a sample overwrote are restored, not all n re-initialised)
     std::vector<uint32_t> stamp;     // rejection branch: position j is selected iff stamp[j] == epoch (no per-seed clear)
     uint32_t epoch = 0;
     std::vector<int64_t> offset((size_t)n_seeds + 1, 0);
@@ -94,13 +110,21 @@ DGLL_API int dgll_host_sample_neighbors(uint32_t* mt_state, int* mt_index, const
             for (int64_t i = 0; i < n; ++i) out_src[at + i] = i;
         } else if (n <= setsize) {                        // pool algorithm
             DGLL_REQUIRE(n < (int64_t)0xffffffff, "degree too large");
-            pool.resize((size_t)n);
-            for (int64_t i = 0; i < n; ++i) pool[i] = (uint32_t)i;
+            if ((size_t)n > pool.size()) {
+                const size_t old = pool.size();
+                pool.resize((size_t)n);
+                for (size_t i = old; i < (size_t)n; ++i) pool[i] = (uint32_t)i;
+            }
+            uint32_t touched[64];
+            const bool log = take <= 64;
             for (int64_t i = 0; i < take; ++i) {
                 const uint32_t j = rng.randbelow((uint32_t)(n - i));
                 out_src[at + i] = pool[j];
                 pool[j] = pool[n - i - 1];
+                if (log) touched[i] = j;
             }
+            if (log) for (int64_t i = 0; i < take; ++i) pool[touched[i]] = touched[i];
+            else for (int64_t i = 0; i < n; ++i) pool[i] = (uint32_t)i;
         } else {                                          // rejection against the selected positions
             DGLL_REQUIRE(n < (int64_t)0xffffffff, "degree too large");
             if ((size_t)n > stamp.size()) stamp.resize((size_t)n, 0);
@@ -119,6 +143,7 @@ DGLL_API int dgll_host_sample_neighbors(uint32_t* mt_state, int* mt_index, const
     offset[n_seeds] = at;
     *mt_index = rng.idx;
     *n_out = at;
+    const auto t_phase1 = std::chrono::steady_clock::now();
     // ---- phase 2: positions -> neighbour ids, destination ids
     auto translate = [&](int64_t s0, int64_t s1) {
         for (int64_t s = s0; s < s1; ++s) {
@@ -139,6 +164,12 @@ DGLL_API int dgll_host_sample_neighbors(uint32_t* mt_state, int* mt_index, const
         for (int64_t t = 0; t < n_threads; ++t)
             workers.emplace_back(translate, n_seeds * t / n_threads, n_seeds * (t + 1) / n_threads);
         for (auto& w : workers) w.join();
+    }
+    if (profile) {
+        const auto t_end = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[dgll sampler] %lld seeds -> %lld edges: sequential draw phase %.2f ms, translation (%lld threads) %.2f ms\n",
+                     (long long)n_seeds, (long long)at, std::chrono::duration<double, std::milli>(t_phase1 - t_begin).count(),
+                     (long long)n_threads, std::chrono::duration<double, std::milli>(t_end - t_phase1).count());
     }
     return DGLL_OK;
 }

@@ -87,6 +87,28 @@ def timed_fetch(ids):
 
 
 pipe._fetch = timed_fetch
+_hops, hops_s = pipe.hops, [0.0]
+
+
+def timed_hops(b):
+    t = time.perf_counter()
+    out = _hops(b)
+    hops_s[0] += time.perf_counter() - t
+    return out
+
+
+pipe.hops = timed_hops
+_put, put_s = pipe.queue.put, [0.0]
+
+
+def timed_put(item):
+    t = time.perf_counter()
+    _put(item)
+    put_s[0] += time.perf_counter() - t
+
+
+pipe.queue.put = timed_put
+blocks_s = [0.0]
 model = dnn.GraphSage(args.feats, [args.hidden] * (L - 1) + [args.classes], fanouts).to(dev)
 opt = torch.optim.Adam(model.parameters(), lr=1e-3)
 random.seed(0)
@@ -97,7 +119,9 @@ gpu_ms = 0.0
 for b in pipe:
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ev0.record()
+    tb = time.perf_counter()
     blocks = [b.subgraphs[L - 1 - h].to_block(dev) for h in range(L)]
+    blocks_s[0] += time.perf_counter() - tb
     out = model.forward_sampled(b.features, blocks)
     loss = torch.nn.functional.cross_entropy(out.float(), b.labels)
     opt.zero_grad(set_to_none=True)
@@ -118,5 +142,7 @@ print("%d batches of %d seeds in %.2f s: %.1f ms/batch, %.2f M aggregated sample
 print("producer-side feature fetch calls (host time): %.1f ms/batch" % (fetch_s[0] / n_batches * 1e3))
 print("host sampler: %.1f ms/batch; GPU side (blocks + forward/backward/Adam, batches 3..): %.1f ms/batch" % (
     TimedSampler.seconds / n_batches * 1e3, gpu_ms / max(n_batches - 2, 1)), flush=True)
+print("producer: hop-id lists %.1f ms/batch, blocked on a full queue %.1f ms/batch; consumer: block build host time %.1f ms/batch" % (
+    hops_s[0] / n_batches * 1e3, put_s[0] / n_batches * 1e3, blocks_s[0] / n_batches * 1e3))
 if not args.batches:
     print("epoch time (%d train nodes): %.2f s" % (args.train_nodes, dt), flush=True)
