@@ -387,6 +387,11 @@ def test_spmm_gate_epilogue(cuda_device, dtype, feat):
     assert torch.equal(out, ref)
     with pytest.raises(ValueError):
         ops.spmm_raw(g, x, gate=gate[:, :-1])
+    if dtype == torch.bfloat16:      # bf16 gather into an fp32 output (two 16-byte loads of the previous row / the gate per lane)
+        base32, gate32 = base.float(), gate.float()
+        plain32 = ops.spmm_raw(g, x, out=base32.clone(), accumulate=True)
+        out32 = ops.spmm_raw(g, x, out=base32.clone(), accumulate=True, gate=gate32)
+        assert torch.equal(out32, torch.where(gate32 > 0, plain32, torch.zeros_like(plain32)))
 
 
 @pytest.mark.parametrize("mode", [0, 1])
