@@ -177,55 +177,172 @@ class _Exchange:
             dev_buf.copy_(host_buf)
 
 
+def _aggregate_forward(engine, h_own, reduce):
+    """out[row] = reduce_j A[row, j] h[j] over the partitioned adjacency (h_own: this rank's rows)."""
+    p = engine.part
+    feat = h_own.shape[1]
+    scale = p.inv_deg if reduce == "mean" else None
+    # exchange buffers hold whole (16-byte padded) rows so that every message is one contiguous block
+    h_store, h_view = engine.rows_of(h_own)
+    send_store = h_store.index_select(0, p.send_idx) if p.send_idx.numel() else h_store[:0]
+    halo_store, halo_view = engine.alloc_rows(p.n_halo, feat, h_own.dtype)
+    _, out = engine.alloc_rows(p.n_own, feat, h_own.dtype)
+    with engine.comm_scope():
+        reqs = engine.exchange.start(send_store, halo_store)
+    # owned-column edges (the bulk of the work) overlap the exchange
+    engine.spmm(p.local, h_view, out, row_scale=None if p.n_halo else scale)
+    with engine.comm_scope():
+        engine.exchange.wait(reqs)
+    engine.join_comm()
+    if p.n_halo:   # halo-column edges accumulate into the same rows; the mean scale is applied once, here
+        engine.spmm(p.halo, halo_view, out, row_scale=scale, accumulate=True)
+    return out
+
+
+def _aggregate_backward(engine, g, into=None, gate=None):
+    """A^T . g across the ranks (g already carries the mean's 1/deg): halo gradients are produced first and travel while
+    the local transposed SpMM runs; the pieces that come back are reduced in fixed order.  `into`: a row buffer the result
+    is ACCUMULATED into (the self-path gradient of a fused layer); `gate`: rows of the forward activations -- the final
+    accumulation zeroes the result where gate <= 0 (ReLU backward of the layer below)."""
+    p = engine.part
+    feat = g.shape[1]
+    _, g = engine.rows_of(g)                 # 16-byte aligned rows: a 47-wide gradient would fall on the scalar kernel
+    n_send = int(p.send_idx.numel())
+    recv_store, recv_view = engine.alloc_rows(n_send, feat, g.dtype)
+    ghalo_store, ghalo_view = engine.alloc_rows(p.n_halo, feat, g.dtype)
+    if p.n_halo:   # halo gradients first: they have to travel
+        engine.spmm(engine.transposed(p.halo), g, ghalo_view)
+    with engine.comm_scope():
+        reqs = engine.exchange.start(ghalo_store, recv_store, reverse=True)
+    if into is None:
+        _, g_own = engine.alloc_rows(p.n_own, feat, g.dtype)
+        engine.spmm(engine.transposed(p.local), g, g_own, gate=None if n_send else gate)      # overlaps the exchange
+    else:
+        g_own = into
+        engine.spmm(engine.transposed(p.local), g, g_own, accumulate=True, gate=None if n_send else gate)
+    with engine.comm_scope():
+        engine.exchange.wait(reqs)
+    engine.join_comm()
+    if n_send:     # returned halo gradients: fixed-order reduction at the owner, no atomics
+        engine.spmm(p.send_reduce, recv_view, g_own, accumulate=True, gate=gate)
+    return g_own
+
+
 class DistAggregate(torch.autograd.Function):
     """Neighbour aggregation over the distributed adjacency: out[row] = reduce_j A[row, j] h[j], with h partitioned by
     owner.  forward(h_own [n_own, F]) -> [n_own, F]; reduce 'sum' or 'mean'."""
 
     @staticmethod
     def forward(ctx, h_own, engine, reduce):
-        p = engine.part
-        feat = h_own.shape[1]
-        scale = p.inv_deg if reduce == "mean" else None
-        # exchange buffers hold whole (16-byte padded) rows so that every message is one contiguous block
-        h_store, h_view = engine.rows_of(h_own)
-        send_store = h_store.index_select(0, p.send_idx) if p.send_idx.numel() else h_store[:0]
-        halo_store, halo_view = engine.alloc_rows(p.n_halo, feat, h_own.dtype)
-        _, out = engine.alloc_rows(p.n_own, feat, h_own.dtype)
-        with engine.comm_scope():
-            reqs = engine.exchange.start(send_store, halo_store)
-        # owned-column edges (the bulk of the work) overlap the exchange
-        engine.spmm(p.local, h_view, out, row_scale=None if p.n_halo else scale)
-        with engine.comm_scope():
-            engine.exchange.wait(reqs)
-        engine.join_comm()
-        if p.n_halo:   # halo-column edges accumulate into the same rows; the mean scale is applied once, here
-            engine.spmm(p.halo, halo_view, out, row_scale=scale, accumulate=True)
         ctx.engine, ctx.reduce = engine, reduce
+        return _aggregate_forward(engine, h_own, reduce)
+
+    @staticmethod
+    def backward(ctx, g):
+        engine = ctx.engine
+        if ctx.reduce == "mean":
+            g = g * engine.part.inv_deg.unsqueeze(1).to(g.dtype)
+        return _aggregate_backward(engine, g.contiguous()), None, None
+
+
+class _DistSageLayer(torch.autograd.Function):
+    """act(h.Ws + reduce_A(h).Wn) on this rank's rows -- the partitioned twin of fused_layers._SageGraphLayer: the
+    neighbour-path gradient is accumulated onto the self-path gradient by the SpMM epilogues, the ReLU mask of the layer
+    below rides on the last of them (`gate_input`), and this layer's own mask is skipped when the layer above already
+    applied it (`grad_is_gated`).  `placed`: the static input halo (first layer; no gradient to the raw features)."""
+
+    @staticmethod
+    def forward(ctx, h, ws, wn, engine, reduce, relu, grad_is_gated, gate_input, placed):
+        from . import dense
+
+        agg = engine.aggregate_static(placed, reduce) if placed is not None else _aggregate_forward(engine, h, reduce)
+        wsd, wnd = ws.to(h.dtype), wn.to(h.dtype)
+        if h.is_cuda and dense._mfma_ok(h, agg) and ws.shape[1] <= 256:
+            out = dense.transform_bf16(h, wsd.t(), agg, wnd.t(), relu=relu)
+        else:
+            out = torch.addmm(torch.mm(h, wsd), agg, wnd)
+            if relu:
+                out.relu_()
+        ctx.engine, ctx.reduce, ctx.relu = engine, reduce, relu
+        ctx.grad_is_gated, ctx.gate_input = grad_is_gated, gate_input
+        ctx.save_for_backward(h, agg, wsd, wnd, out if relu else None)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        engine, reduce = ctx.engine, ctx.reduce
-        p = engine.part
-        feat = g.shape[1]
-        if reduce == "mean":
-            g = g * p.inv_deg.unsqueeze(1).to(g.dtype)
+        from . import dense
+
+        h, agg, wsd, wnd, out = ctx.saved_tensors
+        engine = ctx.engine
         g = g.contiguous()
-        n_send = int(p.send_idx.numel())
-        recv_store, recv_view = engine.alloc_rows(n_send, feat, g.dtype)
-        ghalo_store, ghalo_view = engine.alloc_rows(p.n_halo, feat, g.dtype)
-        if p.n_halo:   # halo gradients first: they have to travel
-            engine.spmm(engine.transposed(p.halo), g, ghalo_view)
-        with engine.comm_scope():
-            reqs = engine.exchange.start(ghalo_store, recv_store, reverse=True)
-        _, g_own = engine.alloc_rows(p.n_own, feat, g.dtype)
-        engine.spmm(engine.transposed(p.local), g, g_own)                        # overlaps the exchange
-        with engine.comm_scope():
-            engine.exchange.wait(reqs)
-        engine.join_comm()
-        if n_send:     # returned halo gradients: fixed-order reduction at the owner, no atomics
-            engine.spmm(p.send_reduce, recv_view, g_own, accumulate=True)
-        return g_own, None, None
+        if ctx.relu and not ctx.grad_is_gated:
+            g = torch.ops.aten.threshold_backward(g, out, 0)
+        gws = dense.grad_weight(h, g) if ctx.needs_input_grad[1] else None
+        gwn = dense.grad_weight(agg, g) if ctx.needs_input_grad[2] else None
+        gh = None
+        if ctx.needs_input_grad[0]:
+            _, gh = engine.rows_of(torch.mm(g, wsd.t()))                          # self path
+            inv = engine.part.inv_deg if ctx.reduce == "mean" else None
+            if inv is not None and g.is_cuda and dense._mfma_ok(g) and wnd.shape[0] <= 256:
+                gagg = dense.transform_bf16(g, wnd, row_scale=inv)                 # (g.Wn^T) / deg in one kernel
+            else:
+                gagg = torch.mm(g, wnd.t())
+                if inv is not None:
+                    gagg = gagg * inv.unsqueeze(1).to(gagg.dtype)
+            gate = h if (ctx.gate_input and h.stride(1) == 1) else None
+            gh = _aggregate_backward(engine, gagg, into=gh, gate=gate)
+            if ctx.gate_input and gate is None:
+                gh = torch.ops.aten.threshold_backward(gh, h, 0)
+        return gh, gws, gwn, None, None, None, None, None, None
+
+
+class _DistSageLayerTransformFirst(torch.autograd.Function):
+    """act(h.Ws + reduce_A(h.Wn)) -- the narrowing layer: the NARROW product crosses the links and is aggregated."""
+
+    @staticmethod
+    def forward(ctx, h, ws, wn, engine, reduce, relu, grad_is_gated, gate_input):
+        from . import dense
+
+        wsd, wnd = ws.to(h.dtype), wn.to(h.dtype)
+        z = (dense.transform_bf16(h, wnd.t(), ld_align=64 if wn.shape[1] < 64 else None)
+             if (h.is_cuda and dense._mfma_ok(h) and wn.shape[1] <= 256) else torch.mm(h, wnd))
+        out = torch.addmm(_aggregate_forward(engine, z, reduce), h, wsd)
+        if relu:
+            out.relu_()
+        ctx.engine, ctx.reduce, ctx.relu = engine, reduce, relu
+        ctx.grad_is_gated, ctx.gate_input = grad_is_gated, gate_input
+        ctx.save_for_backward(h, wsd, wnd, out if relu else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import dense
+
+        h, wsd, wnd, out = ctx.saved_tensors
+        engine = ctx.engine
+        _, gm = engine.alloc_rows(g.shape[0], g.shape[1], g.dtype)               # (masked) gradient in aligned rows
+        if ctx.relu and not ctx.grad_is_gated:
+            torch.ops.aten.threshold_backward.grad_input(g, out, 0, grad_input=gm)
+        else:
+            gm.copy_(g)
+        if ctx.reduce == "mean":
+            _, gp = engine.alloc_rows(g.shape[0], g.shape[1], g.dtype)
+            torch.mul(gm, engine.part.inv_deg.unsqueeze(1).to(g.dtype), out=gp)
+        else:
+            gp = gm
+        gz = _aggregate_backward(engine, gp)
+        gws = dense.grad_weight(h, gm) if ctx.needs_input_grad[1] else None
+        gwn = dense.grad_weight(h, gz) if ctx.needs_input_grad[2] else None
+        gh = None
+        if ctx.needs_input_grad[0]:
+            if g.is_cuda and dense._mfma_ok(gm, gz) and wsd.shape[0] <= 256 and (not ctx.gate_input or h.stride(1) == 1):
+                gh = dense.transform_bf16(gm, wsd, gz, wnd, out_gate=h if ctx.gate_input else None)
+            else:
+                gh = torch.mm(gm, wsd.t())
+                gh.addmm_(gz, wnd.t())
+                if ctx.gate_input:
+                    gh = torch.ops.aten.threshold_backward(gh, h, 0)
+        return gh, gws, gwn, None, None, None, None, None
 
 
 class DistGatAggregate(torch.autograd.Function):
@@ -356,16 +473,18 @@ class DistGraph:
         view.copy_(h)
         return store, view
 
-    def spmm(self, graph, x, out, row_scale=None, accumulate=False, val=None):
+    def spmm(self, graph, x, out, row_scale=None, accumulate=False, val=None, gate=None):
         if self._spmm_fn is not None:
             y = self._spmm_fn(graph, x, val)
             if accumulate:
                 y = y + out
             if row_scale is not None:
                 y = y * row_scale.unsqueeze(1).to(y.dtype)
+            if gate is not None:
+                y = torch.where(gate > 0, y, torch.zeros_like(y))
             out.copy_(y)
             return out
-        return ops.spmm_raw(graph, x, val=val, reduce="sum", out=out, row_scale=row_scale, accumulate=accumulate)
+        return ops.spmm_raw(graph, x, val=val, reduce="sum", out=out, row_scale=row_scale, accumulate=accumulate, gate=gate)
 
     def transposed(self, graph):
         return graph.transpose()[0]
@@ -459,18 +578,35 @@ class DistGraph:
     def sage_forward(self, model, x_local, placed_input=None):
         """Full-graph GraphSage forward on this rank's rows (x_local in local row order).  `placed_input`: handle from
         place_input_halo(x_local) -- the first layer then needs no exchange."""
+        from . import fused_layers
+
+        layers = model.gcn
+        fusable = [fused_layers.can_fuse(layer, x_local.is_cuda) for layer in layers]
+        # as in GraphSage.forward_graph: layer i returns the gradient of its input already masked by layer i-1's ReLU
+        gates = [i > 0 and fusable[i] and fusable[i - 1] and layers[i - 1].activation is not None for i in range(len(layers))]
         h = x_local
-        for li, layer in enumerate(model.gcn):
-            if li == 0 and placed_input is not None and not x_local.requires_grad and not layer.transform_first(h):
-                h = layer.transform_block(h, self.aggregate_static(placed_input, reduce=layer.aggr_neighbor_method))
+        for li, layer in enumerate(layers):
+            reduce = layer.aggr_neighbor_method
+            static = li == 0 and placed_input is not None and not x_local.requires_grad and not layer.transform_first(h)
+            if fusable[li]:
+                relu = layer.activation is not None
+                gated = bool(li + 1 < len(layers) and gates[li + 1] and relu)
+                if layer.transform_first(h):
+                    h = _DistSageLayerTransformFirst.apply(h, layer.weight, layer.neighborAgg.weight, self, reduce, relu,
+                                                           gated, gates[li])
+                else:
+                    h = _DistSageLayer.apply(h, layer.weight, layer.neighborAgg.weight, self, reduce, relu, gated, gates[li],
+                                             placed_input if static else None)
                 continue
-            if layer.transform_first(h):
+            if static:
+                h = layer.transform_block(h, self.aggregate_static(placed_input, reduce=reduce))
+            elif layer.transform_first(h):
                 from . import dense
 
                 z = dense.linear(h, layer.neighborAgg.weight)
-                h = layer.finish_transform_first(h, self.aggregate(z, reduce=layer.aggr_neighbor_method))
+                h = layer.finish_transform_first(h, self.aggregate(z, reduce=reduce))
             else:
-                h = layer.transform_block(h, self.aggregate(h, reduce=layer.aggr_neighbor_method))
+                h = layer.transform_block(h, self.aggregate(h, reduce=reduce))
         return h
 
 
