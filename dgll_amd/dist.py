@@ -199,11 +199,9 @@ def _aggregate_forward(engine, h_own, reduce):
     return out
 
 
-def _aggregate_backward(engine, g, into=None, gate=None):
-    """A^T . g across the ranks (g already carries the mean's 1/deg): halo gradients are produced first and travel while
-    the local transposed SpMM runs; the pieces that come back are reduced in fixed order.  `into`: a row buffer the result
-    is ACCUMULATED into (the self-path gradient of a fused layer); `gate`: rows of the forward activations -- the final
-    accumulation zeroes the result where gate <= 0 (ReLU backward of the layer below)."""
+def _aggregate_backward_start(engine, g):
+    """First half of A^T . g across the ranks (g already carries the mean's 1/deg): the gradients of the halo rows are
+    produced and sent on their way.  Whatever the caller issues before _aggregate_backward_finish overlaps the exchange."""
     p = engine.part
     feat = g.shape[1]
     _, g = engine.rows_of(g)                 # 16-byte aligned rows: a 47-wide gradient would fall on the scalar kernel
@@ -214,9 +212,18 @@ def _aggregate_backward(engine, g, into=None, gate=None):
         engine.spmm(engine.transposed(p.halo), g, ghalo_view)
     with engine.comm_scope():
         reqs = engine.exchange.start(ghalo_store, recv_store, reverse=True)
+    return g, reqs, recv_view, n_send, (ghalo_store, recv_store)      # the stores stay referenced until the finish
+
+
+def _aggregate_backward_finish(engine, state, into=None, gate=None):
+    """Second half: the local transposed SpMM (still overlapping the exchange), then the pieces that came back are reduced
+    in fixed order.  `into`: a row buffer the result is ACCUMULATED into (the self-path gradient of a fused layer);
+    `gate`: rows of the forward activations -- the final accumulation zeroes the result where gate <= 0."""
+    p = engine.part
+    g, reqs, recv_view, n_send, _keep = state
     if into is None:
-        _, g_own = engine.alloc_rows(p.n_own, feat, g.dtype)
-        engine.spmm(engine.transposed(p.local), g, g_own, gate=None if n_send else gate)      # overlaps the exchange
+        _, g_own = engine.alloc_rows(p.n_own, g.shape[1], g.dtype)
+        engine.spmm(engine.transposed(p.local), g, g_own, gate=None if n_send else gate)
     else:
         g_own = into
         engine.spmm(engine.transposed(p.local), g, g_own, accumulate=True, gate=None if n_send else gate)
@@ -226,6 +233,10 @@ def _aggregate_backward(engine, g, into=None, gate=None):
     if n_send:     # returned halo gradients: fixed-order reduction at the owner, no atomics
         engine.spmm(p.send_reduce, recv_view, g_own, accumulate=True, gate=gate)
     return g_own
+
+
+def _aggregate_backward(engine, g, into=None, gate=None):
+    return _aggregate_backward_finish(engine, _aggregate_backward_start(engine, g), into=into, gate=gate)
 
 
 class DistAggregate(torch.autograd.Function):
@@ -277,11 +288,8 @@ class _DistSageLayer(torch.autograd.Function):
         g = g.contiguous()
         if ctx.relu and not ctx.grad_is_gated:
             g = torch.ops.aten.threshold_backward(g, out, 0)
-        gws = dense.grad_weight(h, g) if ctx.needs_input_grad[1] else None
-        gwn = dense.grad_weight(agg, g) if ctx.needs_input_grad[2] else None
-        gh = None
-        if ctx.needs_input_grad[0]:
-            _, gh = engine.rows_of(torch.mm(g, wsd.t()))                          # self path
+        state = None
+        if ctx.needs_input_grad[0]:   # the neighbour-path gradient first: its halo part has to travel
             inv = engine.part.inv_deg if ctx.reduce == "mean" else None
             if inv is not None and g.is_cuda and dense._mfma_ok(g) and wnd.shape[0] <= 256:
                 gagg = dense.transform_bf16(g, wnd, row_scale=inv)                 # (g.Wn^T) / deg in one kernel
@@ -289,8 +297,15 @@ class _DistSageLayer(torch.autograd.Function):
                 gagg = torch.mm(g, wnd.t())
                 if inv is not None:
                     gagg = gagg * inv.unsqueeze(1).to(gagg.dtype)
+            state = _aggregate_backward_start(engine, gagg)
+        # everything below up to the finish overlaps the exchange
+        gws = dense.grad_weight(h, g) if ctx.needs_input_grad[1] else None
+        gwn = dense.grad_weight(agg, g) if ctx.needs_input_grad[2] else None
+        gh = None
+        if state is not None:
+            _, gh = engine.rows_of(torch.mm(g, wsd.t()))                          # self path
             gate = h if (ctx.gate_input and h.stride(1) == 1) else None
-            gh = _aggregate_backward(engine, gagg, into=gh, gate=gate)
+            gh = _aggregate_backward_finish(engine, state, into=gh, gate=gate)
             if ctx.gate_input and gate is None:
                 gh = torch.ops.aten.threshold_backward(gh, h, 0)
         return gh, gws, gwn, None, None, None, None, None, None
@@ -330,8 +345,9 @@ class _DistSageLayerTransformFirst(torch.autograd.Function):
             torch.mul(gm, engine.part.inv_deg.unsqueeze(1).to(g.dtype), out=gp)
         else:
             gp = gm
-        gz = _aggregate_backward(engine, gp)
-        gws = dense.grad_weight(h, gm) if ctx.needs_input_grad[1] else None
+        state = _aggregate_backward_start(engine, gp)
+        gws = dense.grad_weight(h, gm) if ctx.needs_input_grad[1] else None      # overlaps the exchange
+        gz = _aggregate_backward_finish(engine, state)
         gwn = dense.grad_weight(h, gz) if ctx.needs_input_grad[2] else None
         gh = None
         if ctx.needs_input_grad[0]:
