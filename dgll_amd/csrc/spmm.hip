@@ -402,6 +402,10 @@ DGLL_API int dgll_hip_csr_plan_create(void* stream, const int64_t* rowptr, int64
     p->threshold = long_row_threshold > 0 ? long_row_threshold : (g_tune_threshold > 0 ? g_tune_threshold : 128);
     hipError_t e = hipGetDevice(&p->device);
     if (e != hipSuccess) { delete p; return hip_fail(e, "hipGetDevice"); }
+    if (long_row_threshold < 0) {   // caller's guarantee: no row is longer than the default threshold (e.g. a sampled block with
+        *out_plan = p;              // fan-out <= 128) -- no device scan, no allocation, no synchronisation
+        return DGLL_OK;
+    }
 
     const unsigned long long capacity = (unsigned long long)(nnz / p->threshold) + 1;
     LongRow* d_list = nullptr;

@@ -60,8 +60,16 @@ class CSRGraph:
             self._deg = self.rowptr[1:] - self.rowptr[:-1]
         return self._deg
 
+    max_degree = None        # upper bound on the row length when the constructor knows one (sampled blocks: the fan-out)
+    identity_cols = False    # True for sampled blocks: col == arange(nnz), every source row belongs to exactly one edge
+
     def row_index(self):
         """Expanded int64 row id of every nonzero (COO row vector)."""
+        if self.identity_cols:           # blocks are rebuilt per mini-batch and need it in the backward pass: keep it
+            if getattr(self, "_row_index", None) is None:
+                self._row_index = torch.repeat_interleave(torch.arange(self.n_rows, device=self.device), self.degrees(),
+                                                          output_size=self.nnz)
+            return self._row_index
         return torch.repeat_interleave(torch.arange(self.n_rows, device=self.device), self.degrees())
 
     def with_values(self, val):
@@ -136,7 +144,10 @@ class CSRGraph:
             raise ValueError("N*K must fit int32")
         rowptr = torch.arange(0, n * k + 1, k, dtype=torch.int64, device=device) if k > 0 else torch.zeros(n + 1, dtype=torch.int64, device=device)
         col = torch.arange(n * k, dtype=torch.int32, device=device)
-        return cls(rowptr, col, None, n, n * k, check=False)
+        g = cls(rowptr, col, None, n, n * k, check=False)
+        g.identity_cols = True
+        g.max_degree = k
+        return g
 
     def to(self, device):
         device = torch.device(device)
@@ -194,7 +205,9 @@ class CSRGraph:
             handle = C.c_void_p()
             with torch.cuda.device(self.device):
                 stream = torch.cuda.current_stream(self.device).cuda_stream
-                _lib.check(_lib.lib.dgll_hip_csr_plan_create(stream, self.rowptr.data_ptr(), self.n_rows, self.nnz, 0,
+                # max_degree (set by the block constructors) <= 128: no row can be "long" -> host-only plan, no sync
+                threshold = -1 if (self.max_degree is not None and self.max_degree <= 128) else 0
+                _lib.check(_lib.lib.dgll_hip_csr_plan_create(stream, self.rowptr.data_ptr(), self.n_rows, self.nnz, threshold,
                                                              C.byref(handle)), "dgll_hip_csr_plan_create")
             self._plan = handle.value
             self._plan_finalizer = weakref.finalize(self, _lib.lib.dgll_hip_csr_plan_destroy, C.c_void_p(handle.value))

@@ -141,7 +141,17 @@ class _Spmm(torch.autograd.Function):
             from .dense import column_sum
 
             grad_bias = column_sum(g)
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and graph.identity_cols and graph.n_cols == graph.nnz:
+            # sampled block (col == arange): source row e receives exactly g[row(e)] (times its weight) -- one gather,
+            # no transposed CSR to sort together and no launch plan for it, both of which would be rebuilt every batch
+            gs = g
+            if ctx.reduce == "mean":
+                gs = g * (1.0 / graph.degrees().clamp(min=1).to(torch.float32)).unsqueeze(1).to(g.dtype)
+            grad_x = gs.index_select(0, graph.row_index())
+            w = graph.val if val is None else val.detach()
+            if w is not None:
+                grad_x = grad_x * w.unsqueeze(1).to(grad_x.dtype)
+        elif ctx.needs_input_grad[0]:
             gt, perm = graph.transpose()
             tval = gt.val if val is None else val.detach()[perm]  # gt.val is the cached permuted graph.val
             gin = g

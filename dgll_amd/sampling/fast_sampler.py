@@ -61,7 +61,9 @@ class FastNeighborSampler(Base_sampler):
         random.setstate((version, tuple(int(x) for x in state) + (index.value,), gauss))
         ptr = np.zeros(len(seeds) + 1, dtype=np.int64)
         np.cumsum(counts, out=ptr[1:])
-        return sugbraph(torch.from_numpy(src), torch.from_numpy(dst), torch.from_numpy(ptr))
+        sg = sugbraph(torch.from_numpy(src), torch.from_numpy(dst), torch.from_numpy(ptr))
+        sg.max_degree = None if fanout is None else int(fanout)      # lets to_block() skip the long-row scan (host-only plan)
+        return sg
 
     def sample(self, g, seed_nodes):
         output_nodes = seed_nodes

@@ -54,7 +54,10 @@ int dgll_hip_debug_tune(int key, int value);
  * Built once per adjacency structure (the reference builds its adjacency once per graph,
  * nn/utils/utils.py:171,179).  Rows longer than `long_row_threshold` nonzeros (<= 0 selects the default,
  * 128) are split into chunks that are reduced in a fixed order, so results are bit-reproducible and
- * power-law rows do not serialise the launch.  Synchronises `stream` (it reads a count back).          */
+ * power-law rows do not serialise the launch.  Synchronises `stream` (it reads a count back).
+ * long_row_threshold < 0 is the caller's guarantee that NO row exceeds the default threshold (a sampled block whose
+ * fan-out is at most 128): the plan is then created on the host alone -- no scan, no allocation, no synchronisation --
+ * which matters for blocks that are rebuilt every mini-batch.                                            */
 int dgll_hip_csr_plan_create(void* stream, const int64_t* rowptr, int64_t n_rows, int64_t nnz,
                              int long_row_threshold, dgll_csr_plan** out_plan);
 void dgll_hip_csr_plan_destroy(dgll_csr_plan* plan);

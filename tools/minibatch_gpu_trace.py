@@ -55,3 +55,12 @@ for e in evs:
     if d >= 60:
         print("%9.1f us  +%8.1f us  %s" % (e.time_range.start - t0, d, e.name[:100]))
 print("kernel time %.3f ms, span %.3f ms, %d kernels" % (tot / 1e3, (evs[-1].time_range.end - t0) / 1e3, len(evs)))
+from collections import Counter
+cnt = Counter(e.name[:70] for e in evs)
+for name, c in cnt.most_common(14):
+    print("%4d x %s" % (c, name))
+cpu = sorted((e for e in prof.events() if e.device_type == torch.autograd.DeviceType.CPU and e.name.startswith("aten::")), key=lambda e: -(e.time_range.end - e.time_range.start))
+agg = Counter()
+for e in cpu:
+    agg[e.name] += e.time_range.end - e.time_range.start
+print("top host ops (us, inclusive):", [(k, round(v)) for k, v in agg.most_common(12)])
