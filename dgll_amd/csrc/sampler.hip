@@ -93,6 +93,7 @@ DGLL_API int dgll_host_sample_neighbors(uint32_t* mt_state, int* mt_index, const
     MT19937 rng{mt_state, *mt_index};
     std::vector<uint32_t> pool;      // pool algorithm, on positions: kept equal to the identity between seeds (only the
                                      // entries a sample overwrote are restored, not all n re-initialised)
+    std::vector<uint32_t> touched;   // pool positions a sample overwrote
     std::vector<uint32_t> stamp;     // rejection branch: position j is selected iff stamp[j] == epoch (no per-seed clear)
     uint32_t epoch = 0;
     std::vector<int64_t> offset((size_t)n_seeds + 1, 0);
@@ -109,31 +110,45 @@ DGLL_API int dgll_host_sample_neighbors(uint32_t* mt_state, int* mt_index, const
         if (take == n) {                                  // all neighbours, no draw (base_sampler.py:49-54)
             for (int64_t i = 0; i < n; ++i) out_src[at + i] = i;
         } else if (n <= setsize) {                        // pool algorithm
-            DGLL_REQUIRE(n < (int64_t)0xffffffff, "degree too large");
-            if ((size_t)n > pool.size()) {
+            DGLL_REQUIRE(n < (int64_t)0x7fffffff, "degree too large");
+            // Branch-free form of `j = randbelow(n - i)` + swap: every generator output is examined once; a rejected
+            // one (r >= n - i) performs the same loads and stores with no effect and does not advance i.  The retry loop
+            // of randbelow mispredicts up to every second output, which cost more than the arithmetic.  The pool is kept
+            // equal to the identity between seeds and is long enough for any k-bit output.
+            const size_t need = (size_t)1 << (32 - __builtin_clz((uint32_t)n));
+            if (need > pool.size()) {
                 const size_t old = pool.size();
-                pool.resize((size_t)n);
-                for (size_t i = old; i < (size_t)n; ++i) pool[i] = (uint32_t)i;
+                pool.resize(need);
+                for (size_t i = old; i < need; ++i) pool[i] = (uint32_t)i;
             }
-            uint32_t touched[64];
-            const bool log = take <= 64;
-            for (int64_t i = 0; i < take; ++i) {
-                const uint32_t j = rng.randbelow((uint32_t)(n - i));
-                out_src[at + i] = pool[j];
-                pool[j] = pool[n - i - 1];
-                if (log) touched[i] = j;
+            if ((size_t)take > touched.size()) touched.resize((size_t)take);
+            uint32_t* pl = pool.data();
+            int64_t i = 0;
+            while (i < take) {
+                const uint32_t m = (uint32_t)(n - i);
+                const uint32_t r = rng.next() >> __builtin_clz(m);
+                const bool ok = r < m;
+                const uint32_t pr = pl[r], last = pl[m - 1];
+                out_src[at + i] = pr;
+                pl[r] = ok ? last : pr;
+                touched[(size_t)i] = r;
+                i += ok;
             }
-            if (log) for (int64_t i = 0; i < take; ++i) pool[touched[i]] = touched[i];
-            else for (int64_t i = 0; i < n; ++i) pool[i] = (uint32_t)i;
+            for (int64_t t = 0; t < take; ++t) pl[touched[(size_t)t]] = touched[(size_t)t];
         } else {                                          // rejection against the selected positions
-            DGLL_REQUIRE(n < (int64_t)0xffffffff, "degree too large");
-            if ((size_t)n > stamp.size()) stamp.resize((size_t)n, 0);
+            DGLL_REQUIRE(n < (int64_t)0x7fffffff, "degree too large");
+            const size_t need = (size_t)1 << (32 - __builtin_clz((uint32_t)n));     // any k-bit output indexes the stamps
+            if (need > stamp.size()) stamp.resize(need, 0);
             if (++epoch == 0) { std::fill(stamp.begin(), stamp.end(), 0u); epoch = 1; }
-            for (int64_t i = 0; i < take; ++i) {
-                uint32_t j = rng.randbelow((uint32_t)n);
-                while (stamp[j] == epoch) j = rng.randbelow((uint32_t)n);
-                stamp[j] = epoch;
-                out_src[at + i] = j;
+            const int sh = __builtin_clz((uint32_t)n);
+            uint32_t* st = stamp.data();
+            int64_t i = 0;
+            while (i < take) {                            // same idea: one pass over the outputs, no data-dependent branch
+                const uint32_t r = rng.next() >> sh;
+                const bool ok = (r < (uint32_t)n) & (st[r] != epoch);
+                out_src[at + i] = r;
+                st[r] = epoch;                            // r >= n: never consulted; r < n: selected now or before
+                i += ok;
             }
         }
         out_counts[s] = take;
