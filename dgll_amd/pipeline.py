@@ -6,10 +6,11 @@ stage the batch on `d_stream`, `gpu_queue.put`), :74-113 (`sample_consumer`: `gp
 `c_stream`, gradient sharing on `g_stream`), MQGCN.py:98,150-155 (BUFFER_SIZE = 4, one producer + one consumer thread,
 `Queue(maxsize=4)` + `Condition`), README.md:27-29 (three queues: sampling -> feature loading -> training).
 
-Here: the producer thread samples on the host (stdlib RNG, bit-exact with the reference), fetches the input features
-through the GraphCacheServer on a side stream (hot rows from HBM, misses over PCIe from pinned memory), records an
-event, and blocks when `queue_size` batches are waiting; the consumer waits on the event from its compute stream, so the
-copy of batch i+1 overlaps the compute of batch i.  The end of the epoch is signalled with a sentinel
+Here, the three queues of README.md:27-29 as two producer stages and the consumer: a SAMPLING thread draws the batches on
+the host (stdlib RNG stream, bit-exact with the reference -- one thread, so the stream stays sequential) into a bounded
+queue; a LOADING thread takes them, fetches the input features through the GraphCacheServer on a side stream (hot rows
+from HBM, misses over PCIe from pinned memory), records an event and fills the second bounded queue; the consumer waits
+on the event from its compute stream.  Sampling of batch i+2, loading of batch i+1 and training on batch i overlap.  The end of the epoch is signalled with a sentinel
 (buffer_queues.py:43-46 sets a flag under the Condition).
 """
 import queue
@@ -35,18 +36,33 @@ class MiniBatchPipeline:
         whose features are needed (default: the input nodes only, graphage.py:52)."""
         self.dataloader, self.cache, self.labels = dataloader, cache, labels
         self.device = torch.device(device)
-        self.queue = queue.Queue(maxsize=queue_size)              # MQGCN.py:98 BUFFER_SIZE
+        self.queue = queue.Queue(maxsize=queue_size)              # MQGCN.py:98 BUFFER_SIZE  (loaded batches)
+        self.sampled = queue.Queue(maxsize=2)                     # sampled, not yet loaded: a short hand-over queue
         self.hops = hops
         self.load_stream = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None   # d_stream
         self._thread = None
         self._error = None
 
-    # ---- producer (buffer_queues.py:22-46) ---------------------------------------------------------------------
-    def _produce(self):
+    # ---- producer stage 1: sampling (buffer_queues.py:22-46) ---------------------------------------------------
+    def _sample(self):
         try:
             for step, (inp, outp, subgs) in enumerate(self.dataloader):
+                self.sampled.put((step, inp, outp, subgs))            # blocks while the queue is full
+        except BaseException as exc:  # noqa: BLE001  (surface producer failures in the consumer)
+            self._error = exc
+        finally:
+            self.sampled.put(_DONE)
+
+    # ---- producer stage 2: feature loading --------------------------------------------------------------------
+    def _load(self):
+        try:
+            while True:
+                item = self.sampled.get()
+                if item is _DONE:
+                    break
                 b = Batch()
-                b.step, b.input_nodes, b.output_nodes, b.subgraphs = step, inp, outp, subgs
+                b.step, b.input_nodes, b.output_nodes, b.subgraphs = item
+                inp, outp = b.input_nodes, b.output_nodes
                 id_lists = self.hops(b) if self.hops is not None else [inp]
                 if self.load_stream is not None:
                     with torch.cuda.stream(self.load_stream):
@@ -60,8 +76,10 @@ class MiniBatchPipeline:
                     if self.labels is not None:
                         b.labels = self.labels[outp]
                 self.queue.put(b)                                   # blocks while the queue is full
-        except BaseException as exc:  # noqa: BLE001  (surface producer failures in the consumer)
+        except BaseException as exc:  # noqa: BLE001
             self._error = exc
+            while self.sampled.get() is not _DONE:                  # let the sampling thread run to its end
+                pass
         finally:
             self.queue.put(_DONE)
 
@@ -74,8 +92,10 @@ class MiniBatchPipeline:
     # ---- consumer side -----------------------------------------------------------------------------------------
     def __iter__(self):
         self._error = None
-        self._thread = threading.Thread(target=self._produce, name="dgll-sample-producer", daemon=True)
+        self._thread = threading.Thread(target=self._sample, name="dgll-sample-producer", daemon=True)
+        self._loader = threading.Thread(target=self._load, name="dgll-feature-loader", daemon=True)
         self._thread.start()
+        self._loader.start()
         while True:
             b = self.queue.get()
             if b is _DONE:
@@ -84,5 +104,6 @@ class MiniBatchPipeline:
                 torch.cuda.current_stream(self.device).wait_event(b.ready)   # compute stream waits for the load stream
             yield b
         self._thread.join()
+        self._loader.join()
         if self._error is not None:
             raise self._error
