@@ -74,6 +74,7 @@ SIGNATURES = {
     "dgll_hip_gather_rows": (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp]),
     "dgll_host_sample_neighbors": (_i32, [_vp, C.POINTER(_i32), _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _i64,
                                           C.POINTER(_i64)]),
+    "dgll_host_translate_neighbors": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "dgll_hip_gemm_f32": (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _i32]),
     "dgll_hip_transform_bf16": (_i32, [_vp, _vp, _i64, _i32, _vp, _i64, _vp, _i64, _i32, _vp, _i64, _i32, _vp, _i64, _vp,
                                        _i64, _i32, _i64, _i32, _i32, _vp]),

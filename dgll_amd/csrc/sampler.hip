@@ -86,7 +86,7 @@ DGLL_API int dgll_host_sample_neighbors(uint32_t* mt_state, int* mt_index, const
                                         const int64_t* seeds, int64_t n_seeds, int64_t fanout, int64_t setsize,
                                         int64_t* out_src, int64_t* out_dst, int64_t* out_counts, int64_t capacity,
                                         int64_t* n_out) {
-    DGLL_REQUIRE(mt_state && mt_index && indptr && indices && (seeds || n_seeds == 0) && out_counts && n_out, "NULL argument");
+    DGLL_REQUIRE(mt_state && mt_index && indptr && indices && (seeds || n_seeds == 0) && out_src && out_counts && n_out, "NULL argument");
     DGLL_REQUIRE(*mt_index >= 0 && *mt_index <= 624, "bad generator index");
     static const bool profile = std::getenv("DGLL_SAMPLER_PROFILE") != nullptr;
     const auto t_begin = std::chrono::steady_clock::now();
@@ -159,6 +159,12 @@ DGLL_API int dgll_host_sample_neighbors(uint32_t* mt_state, int* mt_index, const
     *mt_index = rng.idx;
     *n_out = at;
     const auto t_phase1 = std::chrono::steady_clock::now();
+    if (!out_dst) {   // positions only: the caller translates later (dgll_host_translate_neighbors), e.g. on another thread
+        if (profile)
+            std::fprintf(stderr, "[dgll sampler] %lld seeds -> %lld edges: sequential draw phase %.2f ms, translation deferred\n",
+                         (long long)n_seeds, (long long)at, std::chrono::duration<double, std::milli>(t_phase1 - t_begin).count());
+        return DGLL_OK;
+    }
     // ---- phase 2: positions -> neighbour ids, destination ids
     auto translate = [&](int64_t s0, int64_t s1) {
         for (int64_t s = s0; s < s1; ++s) {
@@ -185,6 +191,40 @@ DGLL_API int dgll_host_sample_neighbors(uint32_t* mt_state, int* mt_index, const
         std::fprintf(stderr, "[dgll sampler] %lld seeds -> %lld edges: sequential draw phase %.2f ms, translation (%lld threads) %.2f ms\n",
                      (long long)n_seeds, (long long)at, std::chrono::duration<double, std::milli>(t_phase1 - t_begin).count(),
                      (long long)n_threads, std::chrono::duration<double, std::milli>(t_end - t_phase1).count());
+    }
+    return DGLL_OK;
+}
+
+
+// Phase 2 of dgll_host_sample_neighbors on its own: src_inout holds, per seed occurrence, the POSITIONS of the kept neighbours
+// in that seed's adjacency list (what the call above leaves when out_dst is NULL); they are replaced by the neighbour ids and
+// out_dst receives the seed of every edge.  Touches no generator state, so it may run on another thread while the next batch
+// is being drawn.
+DGLL_API int dgll_host_translate_neighbors(const int64_t* indptr, const int64_t* indices, const int64_t* seeds, int64_t n_seeds,
+                                           const int64_t* counts, int64_t* src_inout, int64_t* out_dst) {
+    DGLL_REQUIRE(indptr && indices && (seeds || n_seeds == 0) && counts && src_inout && out_dst, "NULL argument");
+    std::vector<int64_t> offset((size_t)n_seeds + 1, 0);
+    for (int64_t s = 0; s < n_seeds; ++s) offset[s + 1] = offset[s] + counts[s];
+    const int64_t total = offset[n_seeds];
+    auto translate = [&](int64_t s0, int64_t s1) {
+        for (int64_t s = s0; s < s1; ++s) {
+            const int64_t v = seeds[s];
+            const int64_t* nb = indices + indptr[v];
+            for (int64_t k = offset[s]; k < offset[s + 1]; ++k) {
+                src_inout[k] = nb[src_inout[k]];
+                out_dst[k] = v;
+            }
+        }
+    };
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int64_t n_threads = total < (1 << 16) ? 1 : std::min<int64_t>(hw ? hw : 1, 16);
+    if (n_threads <= 1) {
+        translate(0, n_seeds);
+    } else {
+        std::vector<std::thread> workers;
+        for (int64_t t = 0; t < n_threads; ++t)
+            workers.emplace_back(translate, n_seeds * t / n_threads, n_seeds * (t + 1) / n_threads);
+        for (auto& w : workers) w.join();
     }
     return DGLL_OK;
 }

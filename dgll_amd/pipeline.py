@@ -62,6 +62,8 @@ class MiniBatchPipeline:
                     break
                 b = Batch()
                 b.step, b.input_nodes, b.output_nodes, b.subgraphs = item
+                if hasattr(b.input_nodes, "resolve"):      # FastNeighborSampler(defer_last_hop=True): the outermost hop's
+                    b.input_nodes = b.input_nodes.resolve()    # positions become ids here, off the sampling thread
                 inp, outp = b.input_nodes, b.output_nodes
                 id_lists = self.hops(b) if self.hops is not None else [inp]
                 if self.load_stream is not None:

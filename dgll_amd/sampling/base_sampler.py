@@ -17,12 +17,28 @@ from ..graph import CSRGraph
 class sugbraph():
     """Sampled one-hop subgraph: edge k goes src_data[k] -> dst_data[k] (base_sampler.py:65-109)."""
 
-    def __init__(self, src_data, dst_data, indptr=None):
-        self.src_data = src_data
-        self.dst_data = dst_data
+    def __init__(self, src_data, dst_data, indptr=None, finish=None):
+        """finish: optional callable completing src_data / dst_data in place on first access (the native sampler can hand
+        the outermost hop over with neighbour POSITIONS only and translate them to ids later, on the loading thread)."""
+        self._src, self._dst, self._finish = src_data, dst_data, finish
         self.indptr = indptr
         self._graph_nodes = None     # unique(src ++ dst), base_sampler.py:82 -- computed on first use (it costs more than
                                      # drawing the sample itself on multi-million-edge hops)
+
+    def _complete(self):
+        if self._finish is not None:
+            finish, self._finish = self._finish, None
+            finish()
+
+    @property
+    def src_data(self):
+        self._complete()
+        return self._src
+
+    @property
+    def dst_data(self):
+        self._complete()
+        return self._dst
 
     @property
     def graph_nodes(self):
@@ -40,10 +56,10 @@ class sugbraph():
         return self.graph_nodes
 
     def num_src_nodes(self):
-        return self.src_data.shape[0]
+        return self._src.shape[0]
 
     def num_dst_nodes(self):
-        return self.dst_data.shape[0]
+        return self._dst.shape[0]
 
     def get_features(self, g, subgs):
         unique_nodes = torch.unique(torch.cat([subg.nodes() for subg in subgs]))
@@ -54,7 +70,7 @@ class sugbraph():
         `src_data` positions (the next hop's feature rows are stored in that order, so col = arange)."""
         if self.indptr is None:
             raise ValueError("this sugbraph was not produced by a sampler (no per-seed counts)")
-        n_src = int(self.src_data.shape[0])
+        n_src = int(self._src.shape[0])
         g = CSRGraph(self.indptr.to(device), torch.arange(n_src, dtype=torch.int32, device=device), None,
                      int(self.indptr.numel() - 1), n_src, check=False)
         g.identity_cols = True           # the transposed product of the backward pass is then a plain row gather

@@ -23,10 +23,21 @@ def _setsize(k):
     return setsize
 
 
+class _LazyInput:
+    """Stands for `subgs[0].src_nodes()` (the input nodes of the batch) without forcing the deferred translation."""
+
+    def __init__(self, subg):
+        self._subg = subg
+
+    def resolve(self):
+        return self._subg.src_nodes()
+
+
 class FastNeighborSampler(Base_sampler):
-    def __init__(self, fanouts):
+    def __init__(self, fanouts, defer_last_hop=False):
         super().__init__()
         self.fanouts = fanouts
+        self.defer_last_hop = defer_last_hop
         self._csr_of = None
         self._indptr = self._indices = None
 
@@ -41,7 +52,7 @@ class FastNeighborSampler(Base_sampler):
             self._csr_of = g.edges
         return self._indptr, self._indices
 
-    def sample_neighbours(self, g, nodes, fanout=None):
+    def sample_neighbours(self, g, nodes, fanout=None, defer_translation=False):
         indptr, indices = self._csr(g)
         seeds = np.ascontiguousarray(nodes.numpy() if isinstance(nodes, torch.Tensor) else np.asarray(nodes), dtype=np.int64)
         deg = indptr[seeds + 1] - indptr[seeds]
@@ -56,21 +67,33 @@ class FastNeighborSampler(Base_sampler):
         code = _lib.lib.dgll_host_sample_neighbors(
             state.ctypes.data, C.byref(index), indptr.ctypes.data, indices.ctypes.data, seeds.ctypes.data, len(seeds),
             -1 if fanout is None else int(fanout), _setsize(fanout) if fanout is not None else 21, src.ctypes.data,
-            dst.ctypes.data, counts.ctypes.data, cap, C.byref(n_out))
+            None if defer_translation else dst.ctypes.data, counts.ctypes.data, cap, C.byref(n_out))
         _lib.check(code, "dgll_host_sample_neighbors")
         random.setstate((version, tuple(int(x) for x in state) + (index.value,), gauss))
         ptr = np.zeros(len(seeds) + 1, dtype=np.int64)
         np.cumsum(counts, out=ptr[1:])
-        sg = sugbraph(torch.from_numpy(src), torch.from_numpy(dst), torch.from_numpy(ptr))
+        finish = None
+        if defer_translation:     # positions -> ids later (no generator state involved): whoever first reads the ids pays
+
+            def finish():
+                _lib.check(_lib.lib.dgll_host_translate_neighbors(indptr.ctypes.data, indices.ctypes.data, seeds.ctypes.data,
+                                                                  len(seeds), counts.ctypes.data, src.ctypes.data,
+                                                                  dst.ctypes.data), "dgll_host_translate_neighbors")
+
+        sg = sugbraph(torch.from_numpy(src), torch.from_numpy(dst), torch.from_numpy(ptr), finish=finish)
         sg.max_degree = None if fanout is None else int(fanout)      # lets to_block() skip the long-row scan (host-only plan)
         return sg
 
     def sample(self, g, seed_nodes):
         output_nodes = seed_nodes
         subgs = []
-        for fanout in reversed(self.fanouts):
-            subg = self.sample_neighbours(g, seed_nodes, fanout)
-            seed_nodes = subg.src_nodes()
+        order = list(reversed(self.fanouts))
+        for k, fanout in enumerate(order):
+            last = k == len(order) - 1
+            # the outermost hop's ids feed nothing inside this call: leave their translation to the first reader (the
+            # pipeline's loading thread), so this thread -- the only one allowed to touch the generator -- moves on
+            subg = self.sample_neighbours(g, seed_nodes, fanout, defer_translation=last and self.defer_last_hop)
             subgs.insert(0, subg)
-            input_nodes = seed_nodes
-        return input_nodes, output_nodes, subgs
+            if not last:
+                seed_nodes = subg.src_nodes()
+        return _LazyInput(subgs[0]) if self.defer_last_hop else subgs[0].src_nodes(), output_nodes, subgs

@@ -193,6 +193,11 @@ int dgll_hip_gather_rows(void* stream, const void* cache, int64_t ldc, const voi
 int dgll_host_sample_neighbors(uint32_t* mt_state, int* mt_index, const int64_t* indptr, const int64_t* indices,
                                const int64_t* seeds, int64_t n_seeds, int64_t fanout, int64_t setsize,
                                int64_t* out_src, int64_t* out_dst, int64_t* out_counts, int64_t capacity, int64_t* n_out);
+/* out_dst == NULL above stops after the (sequential) draw phase: out_src then holds POSITIONS inside each seed's adjacency
+ * list.  This call finishes the job -- positions -> neighbour ids, out_dst = the seed of every edge -- and touches no
+ * generator state, so a pipeline can run it on another thread while the next batch is being drawn.              */
+int dgll_host_translate_neighbors(const int64_t* indptr, const int64_t* indices, const int64_t* seeds, int64_t n_seeds,
+                                  const int64_t* counts, int64_t* src_inout, int64_t* out_dst);
 
 /* ---- dense transform, exact fp32: C[M,N] = act(A[M,K].B[K,N] + bias) --------------------------------------
  * F.mm / F.matmul of gcnconv.py:30, sageconv.py:41,72, gatconv.py:31,117 for callers that only have the C ABI

@@ -137,3 +137,34 @@ def test_minibatch_graphsage_on_sampled_blocks(cuda_device):
     loss = torch.nn.functional.cross_entropy(out, dg.get_labels(outp).to(cuda_device))
     loss.backward()
     assert all(torch.isfinite(p.grad).all() for p in model.parameters())
+
+
+def test_deferred_translation_gives_the_same_ids():
+    """FastNeighborSampler(defer_last_hop=True) leaves the outermost hop as positions until first read: same ids, same
+    generator state afterwards."""
+    import random
+
+    import numpy as np
+    import torch
+
+    from dgll_amd.data import DGraph
+    from dgll_amd.sampling import FastNeighborSampler
+
+    rng = np.random.default_rng(4)
+    n = 500
+    deg = rng.integers(0, 120, n)
+    indptr = np.zeros(n + 1, np.int64)
+    np.cumsum(deg, out=indptr[1:])
+    indices = rng.integers(0, n, int(indptr[-1])).astype(np.int64)
+    g = DGraph.from_csr(indptr, indices, labels=torch.zeros(n, dtype=torch.long), features=torch.zeros(n, 1))
+    seeds = torch.from_numpy(rng.integers(0, n, 64))
+    random.seed(11)
+    a_in, a_out, a_sub = FastNeighborSampler([25, 10, 5]).sample(g, seeds)
+    state_a = random.getstate()
+    random.seed(11)
+    b_in, b_out, b_sub = FastNeighborSampler([25, 10, 5], defer_last_hop=True).sample(g, seeds)
+    assert random.getstate() == state_a                      # the generator never waits for the translation
+    assert torch.equal(b_in.resolve(), a_in)
+    for x, y in zip(a_sub, b_sub):
+        assert torch.equal(x.src_nodes(), y.src_nodes()) and torch.equal(x.dst_nodes(), y.dst_nodes())
+        assert torch.equal(x.indptr, y.indptr)

@@ -67,7 +67,7 @@ class TimedSampler(FastNeighborSampler):
         return out
 
 
-loader = DataLoader(dg, train, TimedSampler(fanouts), batch_size=args.batch)
+loader = DataLoader(dg, train, TimedSampler(fanouts, defer_last_hop=True), batch_size=args.batch)
 L = len(fanouts)
 
 
