@@ -146,3 +146,15 @@ print("producer: hop-id lists %.1f ms/batch, blocked on a full queue %.1f ms/bat
     hops_s[0] / n_batches * 1e3, put_s[0] / n_batches * 1e3, blocks_s[0] / n_batches * 1e3))
 if not args.batches:
     print("epoch time (%d train nodes): %.2f s" % (args.train_nodes, dt), flush=True)
+    # a second epoch: nothing left to warm up (library handles, GEMM heuristics, allocator pools)
+    torch.cuda.synchronize()
+    t1 = time.time()
+    for b in pipe:
+        blocks = [b.subgraphs[L - 1 - h].to_block(dev) for h in range(L)]
+        out = model.forward_sampled(b.features, blocks)
+        loss = torch.nn.functional.cross_entropy(out.float(), b.labels)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+    torch.cuda.synchronize()
+    print("second epoch: %.2f s" % (time.time() - t1), flush=True)
