@@ -98,3 +98,43 @@ def test_graphed_step_requires_capturable_optimizer(cuda_device):
     w = torch.nn.Parameter(torch.ones(4, device=cuda_device))
     with pytest.raises(ValueError):
         GraphedTrainStep(lambda: (w * w).sum(), torch.optim.Adam([w], capturable=False))
+
+
+def test_graphed_bf16_sage_step_uses_the_mfma_and_gate_kernels(cuda_device):
+    """Full-graph GraphSAGE (bf16: MFMA transforms, gated SpMM epilogues, the loss kernel) captured in a HIP graph."""
+    from dgll_amd import nn as dnn
+    from dgll_amd import ops, synth
+    from dgll_amd.graphs import GraphedTrainStep
+
+    torch.manual_seed(0)
+    g = synth.products_like_graph(cuda_device, seed=1, n=20000, n_undirected=300000, locality=0.9)
+    n = g.n_rows
+    x = ops.alloc_features(n, 100, torch.bfloat16, cuda_device, pad_to=64)
+    x.copy_(torch.randn(n, 100, device=cuda_device))
+    labels = torch.randint(0, 47, (n,), device=cuda_device)
+    base = dnn.GraphSage(100, [256, 256, 47], None).to(cuda_device)
+
+    def run(graphed):
+        model = copy.deepcopy(base)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=True)
+        fn = lambda: ops.cross_entropy(model.forward_graph(g, x), labels)      # noqa: E731
+        losses = []
+        if graphed:
+            step = GraphedTrainStep(fn, opt, warmup=2)
+            for _ in range(4):
+                losses.append(float(step()))
+        else:
+            for i in range(6):
+                opt.zero_grad(set_to_none=True)
+                loss = fn()
+                loss.backward()
+                opt.step()
+                if i >= 2:
+                    losses.append(float(loss.detach()))
+        return losses, [p.detach().clone() for p in model.parameters()]
+
+    la, pa = run(False)
+    lb, pb = run(True)
+    torch.testing.assert_close(torch.tensor(lb), torch.tensor(la), rtol=1e-4, atol=1e-4)
+    for a, b in zip(pa, pb):
+        torch.testing.assert_close(b, a, rtol=1e-3, atol=1e-5)
