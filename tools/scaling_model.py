@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""What ONE rank of the N-GPU bench computes and exchanges per step, measured on one GPU.
+
+For N in 2, 4, 8 the bench graph is partitioned exactly as bench.py does; rank 0's engine runs real training steps with a
+stand-in transport that moves nothing (received buffers keep whatever they hold): the kernels, launch counts and buffer
+sizes are those of the real run, only the wire time is missing.  Printed: the rank's compute per step, the bytes it
+receives and sends per step, and the step time / speed-up that follows for a given per-GPU exchange bandwidth under two
+bounds -- exchange fully hidden behind compute, and not hidden at all.  (xGMI: 7 links x ~64 GB/s per direction per
+GPU at the guide's 153 GB/s bidirectional per link; RCCL's point-to-point efficiency decides where in between it lands.)
+"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from dgll_amd import dist as ddist, nn as dnn, ops, synth  # noqa: E402
+
+
+class NullExchange:
+    """Counts the bytes a grouped send/recv would move; moves nothing."""
+
+    def __init__(self, part):
+        self.part, self.group = part, None
+        self.sent = self.received = 0
+
+    def start(self, send_buf, recv_buf, reverse=False, more=()):
+        for sb, rb in ((send_buf, recv_buf),) + tuple(more):
+            self.sent += sb.numel() * sb.element_size()
+            self.received += rb.numel() * rb.element_size()
+        return ([], [])
+
+    @staticmethod
+    def wait(handle):
+        return None
+
+
+def main():
+    dev = torch.device("cuda:0")
+    full = synth.products_like_graph(dev, seed=0, locality=0.9)
+    n, nnz = full.n_rows, full.nnz
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1)
+    feats = torch.randn(n, 100, generator=gen, device=dev)
+    labels_all = torch.randint(0, 47, (n,), generator=gen, device=dev)
+    single_ms = float(os.environ.get("SINGLE_MS", "24.1"))
+    print("single-process step (bench.py): %.1f ms" % single_ms)
+    for world in (2, 4, 8):
+        torch.manual_seed(0)
+        model = dnn.GraphSage(100, [256, 256, 47], None).to(dev)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+        part = ddist.partition_contiguous(full, world, 0)
+        engine = ddist.DistGraph(part, dev)
+        engine.exchange = NullExchange(part)
+        x = ops.alloc_features(part.n_own, 100, torch.bfloat16, dev, pad_to=64)
+        x.copy_(feats[part.own_begin:part.own_end])
+        labels = labels_all[part.own_begin:part.own_end]
+        placed = engine.place_input_halo(x)
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            out = engine.sage_forward(model, x, placed)
+            loss = ops.cross_entropy(out, labels, reduction="sum") * (world / n)
+            loss.backward()
+            opt.step()
+
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        engine.exchange.sent = engine.exchange.received = 0
+        t0 = time.perf_counter()
+        reps = 10
+        for _ in range(reps):
+            step()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / reps * 1e3
+        rx, tx = engine.exchange.received / reps, engine.exchange.sent / reps
+        line = "N=%d rank 0: %d rows, %d + %d (halo) edges, %d halo rows | compute %.2f ms/step | receives %.0f MB, sends %.0f MB per step" % (
+            world, part.n_own, part.local.nnz, part.halo.nnz, part.n_halo, ms, rx / 1e6, tx / 1e6)
+        print(line)
+        for bw in (150e9, 300e9, 450e9):
+            wire = max(rx, tx) / bw * 1e3
+            print("      at %3.0f GB/s per direction: wire %.2f ms -> step %.2f (hidden) .. %.2f ms (exposed): speed-up %.1fx .. %.1fx" % (
+                bw / 1e9, wire, max(ms, wire), ms + wire, single_ms / max(ms, wire), single_ms / (ms + wire)))
+        del engine, part, model, opt
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Kernel timeline of rank 0's step at world size N (stand-in transport, see tools/scaling_model.py).  usage: scaling_trace.py [N]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+from torch.profiler import ProfilerActivity, profile  # noqa: E402
+
+from dgll_amd import dist as ddist, nn as dnn, ops, synth  # noqa: E402
+from scaling_model import NullExchange  # noqa: E402
+
+world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+dev = torch.device("cuda:0")
+full = synth.products_like_graph(dev, seed=0, locality=0.9)
+n = full.n_rows
+model = dnn.GraphSage(100, [256, 256, 47], None).to(dev)
+opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+part = ddist.partition_contiguous(full, world, 0)
+engine = ddist.DistGraph(part, dev)
+engine.exchange = NullExchange(part)
+x = ops.alloc_features(part.n_own, 100, torch.bfloat16, dev, pad_to=64)
+x.copy_(torch.randn(part.n_own, 100, device=dev))
+labels = torch.randint(0, 47, (part.n_own,), device=dev)
+placed = engine.place_input_halo(x)
+
+
+def step():
+    opt.zero_grad(set_to_none=True)
+    out = engine.sage_forward(model, x, placed)
+    loss = ops.cross_entropy(out, labels, reduction="sum") * (world / n)
+    loss.backward()
+    opt.step()
+
+
+for _ in range(3):
+    step()
+torch.cuda.synchronize()
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+    step()
+    torch.cuda.synchronize()
+evs = sorted((e for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA), key=lambda e: e.time_range.start)
+t0 = evs[0].time_range.start
+tot = 0.0
+for e in evs:
+    d = e.time_range.end - e.time_range.start
+    tot += d
+    if d >= 40:
+        print("%9.1f us  +%8.1f us  %s" % (e.time_range.start - t0, d, e.name[:100]))
+print("N=%d kernel time %.3f ms, span %.3f ms, %d kernels" % (world, tot / 1e3, (evs[-1].time_range.end - t0) / 1e3, len(evs)))
