@@ -63,7 +63,7 @@ struct SpmmArgs {
     int rows_per_wave;
     int flags;  // bit 0: XCD-contiguous row mapping
     const float* row_scale;   // optional fp32[n_rows]: replaces the reduce's own scale (split adjacencies share one degree)
-    int accumulate;           // add the existing Y row before scaling (Y = scale * (A.X + Y))
+    int accumulate;           // 1: Y = epi(scale * (A.X + Y));  2: Y += gate(scale * A.X), rows without edges untouched
     const void* gate;         // optional [n_rows, ldg] of Y's type: outputs are zeroed where gate <= 0 (fused ReLU backward)
     int64_t ldg;
 };
@@ -201,7 +201,7 @@ __device__ __forceinline__ void finish_row(YT* __restrict__ y, int c0, int feat,
                                            const YT* __restrict__ gate, bool full, const RowVec<YT, EPV>& prev,
                                            const RowVec<YT, EPV>& gatev) {
     if constexpr (EXTRA) {
-        if (accumulate) {
+        if (accumulate == 1) {
             float p[EPV];
             if (full) prev.unpack(p);
 #pragma unroll
@@ -236,6 +236,14 @@ __device__ __forceinline__ void finish_row(YT* __restrict__ y, int c0, int feat,
                 if (full) { if (!(gv[i] > 0.0f)) acc[i] = 0.0f; }
                 else if (c0 + i < feat && !(load_one<YT>(gate + c0 + i) > 0.0f)) acc[i] = 0.0f;
             }
+        }
+        if (accumulate == 2) {       // increment form: the (scaled, gated) sum of this launch is added to what Y holds
+            float p[EPV];
+            if (full) prev.unpack(p);
+#pragma unroll
+            for (int i = 0; i < EPV; ++i)
+                if (full) acc[i] += p[i];
+                else if (c0 + i < feat) acc[i] += load_one<YT>(y + c0 + i);
         }
     }
     if (full) {
@@ -281,6 +289,9 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_kernel(const SpmmArgs a) {
         if (row >= a.n_rows) return;
         const int64_t b = uniform64(a.rowptr[row]), e = uniform64(a.rowptr[row + 1]);
         if (a.threshold > 0 && e - b > a.threshold) continue;  // handled as chunks
+        if constexpr (EXTRA) {
+            if (a.accumulate == 2 && e == b) continue;         // increment form: nothing to add to this row
+        }
         float acc[EPV];
 #pragma unroll
         for (int i = 0; i < EPV; ++i) acc[i] = 0.0f;
@@ -333,11 +344,12 @@ __global__ __launch_bounds__(kBlock) void spmm_long_finalize_kernel(const SpmmAr
         for (int i = 0; i < 4; ++i) {
             if (f + i >= a.feat) continue;
             float t = v[i];
-            if (a.accumulate) t += load_one<YT>(y + f + i);
+            if (a.accumulate == 1) t += load_one<YT>(y + f + i);
             t *= scale;
             if (a.epilogue & DGLL_EPI_BIAS) t += a.bias[f + i];
             if (a.epilogue & DGLL_EPI_RELU) t = fmaxf(t, 0.0f);
             if (gate && !(load_one<YT>(gate + f + i) > 0.0f)) t = 0.0f;
+            if (a.accumulate == 2) t += load_one<YT>(y + f + i);
             v[i] = t;
         }
         if (f + 4 <= a.feat && (a.flags & 2)) VecIO<YT, 4>::store(y + f, v);     // flags bit 1: rows are 16-byte aligned
@@ -546,6 +558,8 @@ static int spmm_csr_impl(void* stream, const dgll_csr_plan* plan, const int64_t*
                          const void* gate, int64_t ldg) {
     DGLL_REQUIRE(n_rows >= 0 && n_cols >= 0 && feat >= 0, "negative size");
     DGLL_REQUIRE(!gate || ldg >= feat, "gate leading dimension smaller than feat");
+    DGLL_REQUIRE(accumulate >= 0 && accumulate <= 2, "accumulate: 0, 1 (add Y before the epilogue) or 2 (add the epilogue's result to Y)");
+    DGLL_REQUIRE(accumulate != 2 || epilogue == 0, "the increment form (accumulate = 2) takes no bias / ReLU epilogue");
     if (n_rows == 0 || feat == 0) return DGLL_OK;
     DGLL_REQUIRE(rowptr && X && Y, "NULL rowptr/X/Y");
     DGLL_REQUIRE(ldx >= feat && ldy >= feat, "leading dimension smaller than feat");

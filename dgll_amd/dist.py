@@ -190,12 +190,12 @@ def _aggregate_forward(engine, h_own, reduce):
     with engine.comm_scope():
         reqs = engine.exchange.start(send_store, halo_store)
     # owned-column edges (the bulk of the work) overlap the exchange
-    engine.spmm(p.local, h_view, out, row_scale=None if p.n_halo else scale)
+    engine.spmm(p.local, h_view, out, row_scale=scale)
     with engine.comm_scope():
         engine.exchange.wait(reqs)
     engine.join_comm()
-    if p.n_halo:   # halo-column edges accumulate into the same rows; the mean scale is applied once, here
-        engine.spmm(p.halo, halo_view, out, row_scale=scale, accumulate=True)
+    if p.n_halo:   # halo-column edges: their (scaled) sums are ADDED to the rows that have any -- the others stay untouched
+        engine.spmm(p.halo, halo_view, out, row_scale=scale, accumulate=2)
     return out
 
 
@@ -223,16 +223,16 @@ def _aggregate_backward_finish(engine, state, into=None, gate=None):
     g, reqs, recv_view, n_send, _keep = state
     if into is None:
         _, g_own = engine.alloc_rows(p.n_own, g.shape[1], g.dtype)
-        engine.spmm(engine.transposed(p.local), g, g_own, gate=None if n_send else gate)
+        engine.spmm(engine.transposed(p.local), g, g_own, gate=gate)
     else:
         g_own = into
-        engine.spmm(engine.transposed(p.local), g, g_own, accumulate=True, gate=None if n_send else gate)
+        engine.spmm(engine.transposed(p.local), g, g_own, accumulate=True, gate=gate)
     with engine.comm_scope():
         engine.exchange.wait(reqs)
     engine.join_comm()
-    if n_send:     # returned halo gradients: fixed-order reduction at the owner, no atomics
-        engine.spmm(p.send_reduce, recv_view, g_own, accumulate=True, gate=gate)
-    return g_own
+    if n_send:     # returned halo gradients: fixed-order reduction at the owner, no atomics; only the rows that were sent
+        engine.spmm(p.send_reduce, recv_view, g_own, accumulate=2, gate=gate)   # are touched (the gate is linear: applied
+    return g_own                                                                # to the local part above and to this one)
 
 
 def _aggregate_backward(engine, g, into=None, gate=None):
@@ -430,8 +430,8 @@ class DistGatAggregate(torch.autograd.Function):
             engine.exchange.wait(reqs)
         engine.join_comm()
         if n_send:     # fixed-order reduction of the returned pieces at the owner
-            engine.spmm(p.send_reduce, recv_gh, grad_h, accumulate=True)
-            engine.spmm(p.send_reduce, recv_gt, grad_t, accumulate=True)
+            engine.spmm(p.send_reduce, recv_gh, grad_h, accumulate=2)
+            engine.spmm(p.send_reduce, recv_gt, grad_t, accumulate=2)
         return grad_h, grad_s, grad_t, None, None, None, None, None
 
 
@@ -492,12 +492,14 @@ class DistGraph:
     def spmm(self, graph, x, out, row_scale=None, accumulate=False, val=None, gate=None):
         if self._spmm_fn is not None:
             y = self._spmm_fn(graph, x, val)
-            if accumulate:
+            if accumulate == 1 or accumulate is True:
                 y = y + out
             if row_scale is not None:
                 y = y * row_scale.unsqueeze(1).to(y.dtype)
             if gate is not None:
                 y = torch.where(gate > 0, y, torch.zeros_like(y))
+            if accumulate == 2 and accumulate is not True:
+                y = y + out
             out.copy_(y)
             return out
         return ops.spmm_raw(graph, x, val=val, reduce="sum", out=out, row_scale=row_scale, accumulate=accumulate, gate=gate)
@@ -553,9 +555,9 @@ class DistGraph:
         h_view, halo_view = placed
         scale = p.inv_deg if reduce == "mean" else None
         _, out = self.alloc_rows(p.n_own, h_view.shape[1], h_view.dtype)
-        self.spmm(p.local, h_view, out, row_scale=None if p.n_halo else scale)
+        self.spmm(p.local, h_view, out, row_scale=scale)
         if p.n_halo:
-            self.spmm(p.halo, halo_view, out, row_scale=scale, accumulate=True)
+            self.spmm(p.halo, halo_view, out, row_scale=scale, accumulate=2)
         return out
 
     def permute_to_local(self, x_block):

@@ -76,7 +76,8 @@ def spmm_raw(graph, x, val=None, reduce="sum", bias=None, relu=False, out_dtype=
              accumulate=False, gate=None):
     """Y = epilogue(reduce_j A[i,j] X[j,:]) with no autograd.  `val` overrides graph.val (None = unweighted
     unless graph.val is set).  accumulate: add the rows already in `out` first; row_scale: fp32[n_rows] replacing the
-    reduce's own scale (both used by the partitioned path, dgll_hip_spmm_csr_ex).  gate: [n_rows, feat] of the output
+    reduce's own scale (both used by the partitioned path, dgll_hip_spmm_csr_ex); accumulate=2 ("add"): the increment
+    form out += gate(scale . A.X), rows without edges untouched.  gate: [n_rows, feat] of the output
     dtype -- outputs are zeroed where gate <= 0 (dgll_hip_spmm_csr_gated: the ReLU backward of the layer below)."""
     _require_cuda(x, graph.rowptr)
     x = _row_major(x)
@@ -108,7 +109,7 @@ def spmm_raw(graph, x, val=None, reduce="sum", bias=None, relu=False, out_dtype=
             x.data_ptr(), x.stride(0), _dtype_code(x), out.data_ptr(), out.stride(0), _dtype_code(out),
             graph.n_rows, graph.n_cols, feat, _REDUCE[reduce], epi, bias.data_ptr() if bias is not None else None,
             ws.data_ptr() if ws is not None else None, ws_bytes,
-            row_scale.data_ptr() if row_scale is not None else None, int(bool(accumulate)),
+            row_scale.data_ptr() if row_scale is not None else None, 2 if accumulate in (2, "add") else int(bool(accumulate)),
             gate.data_ptr() if gate is not None else None, gate.stride(0) if gate is not None else 0)
     if end is not None:
         end.record(torch.cuda.current_stream(x.device))

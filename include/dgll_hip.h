@@ -84,7 +84,9 @@ int dgll_hip_spmm_csr(void* stream, const dgll_csr_plan* plan,
 /* Same launch with two extras used by the partitioned (multi-GPU) path, where one destination row's neighbours are
  * split over an owned-columns CSR and a halo-columns CSR: `accumulate` != 0 adds the row already in Y before the
  * epilogue (Y = act(scale * (A.X + Y) + bias)); `row_scale` (fp32[n_rows], may be NULL) replaces the reduce's own
- * 1/nnz(row) so both halves share the full degree.                                                            */
+ * 1/nnz(row) so both halves share the full degree.  `accumulate` == 2 is the increment form, Y += gate(scale * A.X)
+ * with rows that have no edge left untouched (no bias / ReLU): the halo half and the reduction of returned gradient
+ * pieces touch a fraction of the rows, and re-writing all of them cost more than the gathers.                  */
 int dgll_hip_spmm_csr_ex(void* stream, const dgll_csr_plan* plan,
                          const int64_t* rowptr, const int32_t* col, const float* val,
                          const void* X, int64_t ldx, int x_dtype, void* Y, int64_t ldy, int y_dtype,

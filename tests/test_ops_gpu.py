@@ -366,6 +366,32 @@ def test_spmm_accumulate_and_row_scale(cuda_device, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_spmm_increment_form_leaves_edgeless_rows_alone(cuda_device, dtype):
+    """accumulate = 2: Y += gate(scale * A.X); rows without an edge are not read or written (they may hold anything, here
+    NaN-free sentinels), chunked long rows included."""
+    from dgll_amd import ops
+
+    n, feat = 600, 136
+    rowptr, col, val = np_graph(n, 3, seed=23, heavy_rows=[(9, 500), (10, 140)], empty_rows=list(range(100, 400)), weighted=True)
+    g = to_dev(rowptr, col, val, n, cuda_device)
+    rng = np.random.default_rng(2)
+    x = torch.from_numpy(rng.standard_normal((n, feat)).astype(np.float32)).to(cuda_device).to(dtype)
+    base = torch.from_numpy(rng.standard_normal((n, feat)).astype(np.float32)).to(cuda_device).to(dtype)
+    gate = torch.from_numpy(rng.standard_normal((n, feat)).astype(np.float32)).to(cuda_device).to(dtype)
+    scale = torch.from_numpy(rng.random(n).astype(np.float32) + 0.5).to(cuda_device)
+    inc = ops.spmm_raw(g, x, row_scale=scale, out_dtype=torch.float32)                  # scale * A.X in fp32
+    inc = torch.where(gate.float() > 0, inc, torch.zeros_like(inc))
+    ref = (base.float() + inc).to(dtype)
+    out = ops.spmm_raw(g, x, out=base.clone(), row_scale=scale, accumulate=2, gate=gate)
+    tol = dict(rtol=1e-5, atol=1e-5) if dtype == torch.float32 else dict(rtol=1e-2, atol=2e-2)
+    torch.testing.assert_close(out.float(), ref.float(), **tol)
+    empty = torch.from_numpy(np.diff(rowptr) == 0).to(cuda_device)
+    assert torch.equal(out[empty], base[empty])                                          # bit-untouched
+    with pytest.raises(RuntimeError):
+        ops.spmm_raw(g, x, out=base.clone(), accumulate=2, relu=True)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("feat", [72, 256, 5])
 def test_spmm_gate_epilogue(cuda_device, dtype, feat):
     """dgll_hip_spmm_csr_gated: Y = (A.X + Y_old) with elements zeroed where gate <= 0 -- the ReLU backward of the layer
