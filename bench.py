@@ -227,6 +227,9 @@ def main():
                     "frac": achieved / HBM_PEAK_GBPS, "traffic": load_traffic(args) if world == 1 else None,
                     "kernel": "spmm_csr_kernel<bf16,bf16,8,32,unweighted> (forward mean aggregation, F=%d)" % args.hidden,
                     "launches_timed": cnt, "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": b_alg,
+                    # SURVEY 8(d)'s compulsory lower bound: every index once, every feature / output row once
+                    "compulsory_bytes_per_launch": dom_tag[4] * 4 + (n if engine is None else engine.part.n_own + engine.part.n_halo) * args.hidden * esz
+                                                   + local_rows * (args.hidden * esz + 8),
                     "edges_per_s_this_kernel": dom_tag[4] / (avg_ms * 1e-3)}
     result = {
         "metric": "aggregated edges/sec + epoch time, 3-layer GraphSAGE ogbn-products, 1/2/4/8 GPU",
