@@ -31,7 +31,7 @@ def _load():
     from . import build as _build
 
     if not _build.is_current():
-        _build.build()
+        _build.build()      # serialised across processes by a file lock; the library is linked to a temporary name and renamed
     if not os.path.exists(LIB_PATH):
         raise ImportError("libdgll_hip.so is missing (expected at %s); run `python -m dgll_amd.build`" % LIB_PATH)
     return C.CDLL(LIB_PATH)
@@ -72,6 +72,7 @@ SIGNATURES = {
                                 _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32, C.c_float, _i32,
                                 _i32, _vp, _sz]),
     "dgll_hip_gather_rows": (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp]),
+    "dgll_hip_gather_rows_mapped": (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp]),
     "dgll_host_sample_neighbors": (_i32, [_vp, C.POINTER(_i32), _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _i64,
                                           C.POINTER(_i64)]),
     "dgll_host_translate_neighbors": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _vp]),

@@ -65,6 +65,23 @@ def is_current():
 
 
 def build(force=False, verbose=False):
+    """Compile + link under an exclusive file lock (torchrun imports the package on every rank at once: without it the
+    ranks would run hipcc over the same objects and one could dlopen a half-linked library).  A rank that waited on the
+    lock re-checks the stamp and returns without building."""
+    import fcntl
+
+    if not force and is_current():
+        return LIB
+    os.makedirs(LIBDIR, exist_ok=True)
+    with open(os.path.join(LIBDIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build_locked(force, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force, verbose):
     srcs, hdrs = sources(), headers()
     if not force and is_current():
         return LIB
@@ -92,14 +109,19 @@ def build(force=False, verbose=False):
         results = list(ex.map(compile_one, srcs))
     objs = [o for o, _ in results]
     if force or any(ch for _, ch in results) or not os.path.exists(LIB) or os.path.getmtime(LIB) < _newest(objs):
-        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-pthread", "-o", LIB] + objs
+        tmp = LIB + ".tmp.%d" % os.getpid()
+        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-pthread", "-o", tmp] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         res = subprocess.run(cmd, capture_output=True, text=True)
         if res.returncode != 0:
+            if os.path.exists(tmp):
+                os.remove(tmp)
             raise RuntimeError("link failed:\n%s\n%s" % (res.stdout, res.stderr))
-    with open(STAMP, "w") as f:
+        os.replace(tmp, LIB)              # atomic: a concurrent dlopen sees the old or the new library, never a partial one
+    with open(STAMP + ".tmp", "w") as f:
         f.write(source_digest())
+    os.replace(STAMP + ".tmp", STAMP)     # the stamp goes last
     return LIB
 
 

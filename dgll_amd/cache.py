@@ -10,6 +10,8 @@ Mirror of /root/reference/dgll/FeatureCache/storage.py:12-221 without its DGL (N
   * `log_miss_rate` / `get_miss_rate` (storage.py:213-220).
 Host features are kept in pinned memory so the GPU can read them (and `hipMemcpyAsync` them) without staging.
 """
+import threading
+
 import torch
 
 from . import _lib
@@ -36,7 +38,8 @@ class GraphCacheServer:
         self.log = False
         self.try_num = 0
         self.miss_num = 0
-        self._miss_counter = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self._pending = []          # (device miss counter, batch size) of logged fetches not yet read back
+        self._pending_lock = threading.Lock()   # fetches come from the pipeline's loading thread
 
     # ---- cache population ------------------------------------------------------------------------------------
     def auto_cache(self, out_degrees, reserve_bytes=1 << 30, capacity=None):
@@ -73,61 +76,53 @@ class GraphCacheServer:
 
     # ---- the hot call ----------------------------------------------------------------------------------------
     def fetch_data(self, nids, out=None, stream=None):
-        """[len(nids), D] device tensor of the nodes' features (ids in the local space, on the GPU)."""
-        nids = nids.to(self.device, dtype=torch.int64, non_blocking=True)
-        if self.nid_map is not None and not self.full_cached:
-            host_ids = self.nid_map[nids]
-        else:
-            host_ids = nids
-        n = int(nids.numel())
-        if out is None:
-            out = torch.empty((n, self.total_dim), dtype=self.features.dtype, device=self.device)
-        if n == 0:
-            return out
+        """[len(nids), D] device tensor of the nodes' features (ids in the local space).  ONE launch and no host
+        synchronisation whatever the cache state: with a partition (`nid_map`) the kernel resolves hit -> cache slot of
+        the LOCAL id, miss -> host row nid_map[local id] itself (dgll_hip_gather_rows_mapped).  Everything -- the id
+        upload, the allocation of `out`, the launch -- is issued on `stream` (default: the current stream), so `out`
+        belongs to that stream; a consumer on another stream must wait for it and `record_stream` the tensor.  The miss
+        count of a logged fetch is read back lazily (get_miss_rate), not here."""
         stream = torch.cuda.current_stream(self.device) if stream is None else stream
-        cache = self.gpu_fix_cache
-        use_map = cache is not None
-        if self.nid_map is not None and use_map and not self.full_cached:
-            # slots are keyed by LOCAL id, the host store by FULL id: resolve the slot on the device first
-            slot_of = self.localid2cacheid[nids]
-            idx = torch.where(slot_of >= 0, slot_of, host_ids)
-            # encode "hit" as a separate map over the batch: gather in two launches keyed differently
-            hits = slot_of >= 0
-            if bool(hits.any()):
-                out[hits] = cache[slot_of[hits]]
-            miss = ~hits
-            if bool(miss.any()):
-                self._launch(None, host_ids[miss], None, out, stream, rows_out=miss.nonzero().flatten())
-            misses = int(miss.sum())
-        else:
-            counter = self._miss_counter if (self.log and use_map) else None
-            if counter is not None:
-                counter.zero_()
-            self._launch(cache, nids if use_map else host_ids, self.localid2cacheid if use_map else None, out, stream,
-                         counter=counter)
-            misses = int(counter.item()) if counter is not None else 0
-        if self.log:
-            self.log_miss_rate(misses, n)
+        with torch.cuda.stream(stream):
+            nids = nids.to(self.device, dtype=torch.int64, non_blocking=True)
+            n = int(nids.numel())
+            if out is None:
+                out = torch.empty((n, self.total_dim), dtype=self.features.dtype, device=self.device)
+            if n == 0:
+                return out
+            cache = self.gpu_fix_cache
+            use_map = cache is not None
+            host_map = self.nid_map          # full_cached: every id hits, the map is never consulted
+            counter = None
+            if self.log and use_map:
+                counter = torch.zeros(1, dtype=torch.int64, device=self.device)
+            with torch.cuda.device(self.device):
+                code = _lib.lib.dgll_hip_gather_rows_mapped(
+                    stream.cuda_stream, cache.data_ptr() if use_map else None, cache.stride(0) if use_map else 0,
+                    self.features.data_ptr(), self.features.stride(0), nids.data_ptr(),
+                    self.localid2cacheid.data_ptr() if use_map else None,
+                    host_map.data_ptr() if host_map is not None else None, out.data_ptr(), out.stride(0), n,
+                    self.total_dim, _dtype_code(out), counter.data_ptr() if counter is not None else None)
+            _lib.check(code, "dgll_hip_gather_rows_mapped")
+            if self.log:
+                with self._pending_lock:
+                    self._pending.append((counter, n))
         return out
-
-    def _launch(self, cache, idx, slot, out, stream, counter=None, rows_out=None):
-        target = out if rows_out is None else torch.empty((idx.numel(), out.shape[1]), dtype=out.dtype, device=out.device)
-        with torch.cuda.device(self.device):
-            code = _lib.lib.dgll_hip_gather_rows(
-                stream.cuda_stream, cache.data_ptr() if cache is not None else None,
-                cache.stride(0) if cache is not None else 0, self.features.data_ptr(), self.features.stride(0),
-                idx.data_ptr(), slot.data_ptr() if slot is not None else None, target.data_ptr(), target.stride(0),
-                int(idx.numel()), self.total_dim, _dtype_code(out), counter.data_ptr() if counter is not None else None)
-        _lib.check(code, "dgll_hip_gather_rows")
-        if rows_out is not None:
-            out[rows_out] = target
 
     # ---- accounting (storage.py:213-220) -----------------------------------------------------------------------
     def log_miss_rate(self, miss_num, total_num):
         self.try_num += total_num
         self.miss_num += miss_num
 
+    def _drain(self):
+        """Fold the device-side miss counters of the logged fetches into the totals (the only host read-back)."""
+        with self._pending_lock:
+            pending, self._pending = self._pending, []
+        for counter, n in pending:
+            self.log_miss_rate(int(counter.item()) if counter is not None else 0, n)
+
     def get_miss_rate(self):
+        self._drain()
         miss_rate = float(self.miss_num) / self.try_num
         self.miss_num = 0
         self.try_num = 0

@@ -24,6 +24,7 @@ struct GatherArgs {
     int64_t ldc, ldh, ldo, n;
     int row_bytes;          // bytes actually copied per row
     unsigned long long* miss_count;   // optional
+    const int64_t* host_map; // optional [n_nodes]: row of `host` that holds node i (local -> full-graph id, storage.py:27)
 };
 
 template <int VEC>  // bytes per lane per step: 16, 4 or 2
@@ -36,7 +37,7 @@ __global__ __launch_bounds__(kBlock) void gather_rows_kernel(const GatherArgs a,
         const int64_t node = a.idx[i];
         const int64_t s = a.slot ? a.slot[node] : -1;
         const char* src = (s >= 0) ? static_cast<const char*>(a.cache) + s * a.ldc * esz
-                                   : static_cast<const char*>(a.host) + node * a.ldh * esz;
+                                   : static_cast<const char*>(a.host) + (a.host_map ? a.host_map[node] : node) * a.ldh * esz;
         char* dst = static_cast<char*>(a.out) + i * a.ldo * esz;
         misses += (a.slot && s < 0) ? 1 : 0;
         for (int st = 0; st < steps; ++st) {
@@ -55,9 +56,25 @@ __global__ __launch_bounds__(kBlock) void gather_rows_kernel(const GatherArgs a,
 
 using namespace dgll;
 
+static int gather_rows_impl(void* stream, const void* cache, int64_t ldc, const void* host, int64_t ldh,
+                            const int64_t* idx, const int64_t* slot, void* out, int64_t ldo, int64_t n, int feat,
+                            int dtype, unsigned long long* miss_count, const int64_t* host_map);
+
 DGLL_API int dgll_hip_gather_rows(void* stream, const void* cache, int64_t ldc, const void* host, int64_t ldh,
                                   const int64_t* idx, const int64_t* slot, void* out, int64_t ldo, int64_t n, int feat,
                                   int dtype, unsigned long long* miss_count) {
+    return gather_rows_impl(stream, cache, ldc, host, ldh, idx, slot, out, ldo, n, feat, dtype, miss_count, nullptr);
+}
+
+DGLL_API int dgll_hip_gather_rows_mapped(void* stream, const void* cache, int64_t ldc, const void* host, int64_t ldh,
+                                         const int64_t* idx, const int64_t* slot, const int64_t* host_map, void* out,
+                                         int64_t ldo, int64_t n, int feat, int dtype, unsigned long long* miss_count) {
+    return gather_rows_impl(stream, cache, ldc, host, ldh, idx, slot, out, ldo, n, feat, dtype, miss_count, host_map);
+}
+
+static int gather_rows_impl(void* stream, const void* cache, int64_t ldc, const void* host, int64_t ldh,
+                            const int64_t* idx, const int64_t* slot, void* out, int64_t ldo, int64_t n, int feat,
+                            int dtype, unsigned long long* miss_count, const int64_t* host_map) {
     if (n <= 0 || feat <= 0) return DGLL_OK;
     DGLL_REQUIRE(host && idx && out, "NULL argument");
     DGLL_REQUIRE(!slot || cache, "a slot map needs a cache matrix");
@@ -66,7 +83,7 @@ DGLL_API int dgll_hip_gather_rows(void* stream, const void* cache, int64_t ldc, 
     DGLL_REQUIRE(ldh >= feat && ldo >= feat && (!slot || ldc >= feat), "leading dimension smaller than feat");
     GatherArgs a{};
     a.cache = cache; a.host = host; a.idx = idx; a.slot = slot; a.out = out;
-    a.ldc = ldc; a.ldh = ldh; a.ldo = ldo; a.n = n; a.row_bytes = feat * esz; a.miss_count = miss_count;
+    a.ldc = ldc; a.ldh = ldh; a.ldo = ldo; a.n = n; a.row_bytes = feat * esz; a.miss_count = miss_count; a.host_map = host_map;
     auto ok16 = [&](const void* p, int64_t ld) { return !p || (aligned16(p) && (ld * esz) % 16 == 0); };
     const bool v16 = a.row_bytes % 16 == 0 && ok16(cache, ldc) && ok16(host, ldh) && ok16(out, ldo);
     const bool v4 = a.row_bytes % 4 == 0 && (ldh * esz) % 4 == 0 && (ldo * esz) % 4 == 0 && (!slot || (ldc * esz) % 4 == 0);

@@ -364,7 +364,7 @@ static int ws_ld_for(int feat) { return (feat + 7) & ~7; }
 static int g_tune_unroll = 4;        // gathers in flight per lane (2, 4 or 8; 8 only for the widest variants)
 static int g_tune_rows_per_wave = 0; // 0 = automatic
 static int g_tune_flags = 0;         // bit 0: XCD-contiguous row mapping (off: measured slower when degree correlates with row id)
-static int g_tune_threshold = 0;     // 0 = plan default (512)
+static int g_tune_threshold = 0;     // 0 = plan default (128)
 
 template <typename XT, typename YT, int EPV, int LPR, int U>
 static hipError_t launch_u(const SpmmArgs& a, dim3 grid, hipStream_t s) {
@@ -415,8 +415,9 @@ DGLL_API int dgll_hip_csr_plan_create(void* stream, const int64_t* rowptr, int64
     hipError_t e = hipGetDevice(&p->device);
     if (e != hipSuccess) { delete p; return hip_fail(e, "hipGetDevice"); }
     if (long_row_threshold < 0) {   // caller's guarantee: no row is longer than the default threshold (e.g. a sampled block with
-        *out_plan = p;              // fan-out <= 128) -- no device scan, no allocation, no synchronisation
-        return DGLL_OK;
+        p->threshold = 0;           // fan-out <= 128) -- no device scan, no allocation, no synchronisation.  threshold 0 =
+        *out_plan = p;              // "no chunk schedule": every row is gathered inline whatever its length, so a wrong
+        return DGLL_OK;             // bound (or the debug knob) can cost speed but never leaves a row unwritten
     }
 
     const unsigned long long capacity = (unsigned long long)(nnz / p->threshold) + 1;

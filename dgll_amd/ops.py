@@ -238,8 +238,14 @@ class _CrossEntropy(torch.autograd.Function):
         ctx.reduction, ctx.soft = reduction, soft
         count = None
         if reduction == "mean":          # torch semantics: mean over the targets that are not ignored (soft targets: over N)
-            count = (torch.full((), float(n), device=z.device) if soft
-                     else ((target >= 0) & (target < c)).sum().to(torch.float32))
+            if soft:
+                count = torch.full((), float(n), device=z.device)
+            else:
+                # the same two-stage tree as the loss total (a single-output reduction over [n] replays as 0 inside a
+                # captured HIP graph on this stack, which would turn the loss and every gradient into inf / NaN)
+                valid = torch.zeros(store.numel(), dtype=torch.float32, device=z.device)
+                valid[:n] = ((target >= 0) & (target < c))
+                count = valid.view(-1, 256).sum(1).sum() if n > 4096 else valid[:n].sum()
         ctx.save_for_backward(z, target, count)
         if reduction == "none":
             return row_loss

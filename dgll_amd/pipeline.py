@@ -103,7 +103,15 @@ class MiniBatchPipeline:
             if b is _DONE:
                 break
             if b.ready is not None:
-                torch.cuda.current_stream(self.device).wait_event(b.ready)   # compute stream waits for the load stream
+                cur = torch.cuda.current_stream(self.device)
+                cur.wait_event(b.ready)                      # compute stream waits for the load stream
+                # The tensors were allocated on the load stream and are consumed on `cur`: tell the caching allocator, or
+                # the block returns to the load stream's pool when the consumer drops the batch -- while forward/backward
+                # kernels reading it may still be queued -- and the loader's next gather could be written into it.
+                for t in b.features or ():
+                    t.record_stream(cur)
+                if b.labels is not None and b.labels.is_cuda:
+                    b.labels.record_stream(cur)
             yield b
         self._thread.join()
         self._loader.join()

@@ -186,6 +186,13 @@ int dgll_hip_gather_rows(void* stream, const void* cache, int64_t ldc, const voi
                          const int64_t* idx, const int64_t* slot, void* out, int64_t ldo, int64_t n, int feat,
                          int dtype, unsigned long long* miss_count);
 
+/* Same gather when the cache server holds a PARTITION of the graph: idx / slot are keyed by the partition-local id and
+ * host_map[local id] is the row of `host` (the full-graph feature store) -- storage.py:27 `nid_map`, :104-107.  The
+ * hit / miss split, both gathers and the miss count stay one launch; host_map == NULL is dgll_hip_gather_rows.      */
+int dgll_hip_gather_rows_mapped(void* stream, const void* cache, int64_t ldc, const void* host, int64_t ldh,
+                                const int64_t* idx, const int64_t* slot, const int64_t* host_map, void* out,
+                                int64_t ldo, int64_t n, int feat, int dtype, unsigned long long* miss_count);
+
 /* ---- f1 (host code): one hop of the reference's neighbour sampler, bit-exact with CPython 3.10's random.sample -------
  * For every seed in order: all neighbours if deg <= fanout (or fanout < 0), else random.sample(neighbors, fanout)
  * (/root/reference/dgll/sampling/base_sampler.py:45-58), drawn from the MT19937 state passed in (`random.getstate()`:
