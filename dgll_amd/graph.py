@@ -192,6 +192,29 @@ class CSRGraph:
             self._mean_scale_t = inv[gt.col.long()]
         return self._mean_scale_t
 
+    # ------------------------------------------------------------------ locality pass
+    perm = None        # set on a graph returned by reorder(): row i of this graph is row perm[i] of the caller's graph
+    inv_perm = None    # and caller node v is row inv_perm[v] here
+
+    def reorder(self, method="lpa", seed=0, sweeps=8):
+        """(relabelled CSRGraph, perm): the engine's one-off locality pass (dgll_amd/reorder.py) -- community relabelling
+        computed on the device the graph lives on.  Permute node data once with `x[perm]` (`to_engine_order`); results come
+        back in the caller's node order through `to_caller_order`."""
+        from . import reorder as _reorder
+
+        if self.n_rows != self.n_cols:
+            raise ValueError("reorder needs a square adjacency (one id space for rows and columns)")
+        perm = _reorder.locality_order(self.rowptr, self.col, self.n_rows, method=method, seed=seed, sweeps=sweeps)
+        return _reorder.relabel(self, perm), perm
+
+    def to_engine_order(self, x):
+        """Node-major tensor in the caller's order -> this (reordered) graph's row order."""
+        return x if self.perm is None else x[self.perm.to(x.device)]
+
+    def to_caller_order(self, y):
+        """Rows of a result computed on this (reordered) graph -> the caller's node order."""
+        return y if self.inv_perm is None else y[self.inv_perm.to(y.device)]
+
     # ------------------------------------------------------------------ HIP schedule
     def plan(self):
         """Opaque dgll_csr_plan* (long-row chunking for load balance); created on first use."""

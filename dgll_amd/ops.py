@@ -99,7 +99,12 @@ def spmm_raw(graph, x, val=None, reduce="sum", bias=None, relu=False, out_dtype=
     ws_bytes = graph.workspace_bytes(feat)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes else None
     timer = LaunchTimer.active
-    end = timer.start(("spmm", feat, str(x.dtype), val is not None, graph.nnz), x.device) if timer is not None else None
+    if timer is not None:      # what distinguishes the launch kinds of a step: width, dtype, weights, nnz, epilogue extras
+        extra = "+".join(t for t, on in (("accumulate", bool(accumulate)), ("gate", gate is not None),
+                                         ("row_scale", row_scale is not None)) if on)
+        end = timer.start(("spmm", feat, str(x.dtype), val is not None, graph.nnz, extra), x.device)
+    else:
+        end = None
     with torch.cuda.device(x.device):
         stream = torch.cuda.current_stream(x.device).cuda_stream
         if gate is not None and (gate.dtype != out.dtype or gate.shape != out.shape or gate.stride(1) != 1):

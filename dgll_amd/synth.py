@@ -109,16 +109,22 @@ PRODUCTS_UNDIRECTED_EDGES = 61_859_140
 
 
 def products_like_graph(device, seed=0, n=PRODUCTS_NODES, n_undirected=PRODUCTS_UNDIRECTED_EDGES, weighted=False,
-                        self_loops=False, locality=0.0, n_blocks=64):
+                        self_loops=False, locality=0.0, n_blocks=64, exact=False, permute_ids=False):
     """ogbn-products-shaped synthetic graph: N = 2 449 029 nodes, ~61.86 M undirected power-law (RMAT) edges symmetrised
-    to ~123.7 M directed ones (duplicates coalesce, so nnz lands a few per cent below 123 718 280).
+    to ~123.7 M directed ones.
 
     locality = 0: one global RMAT, ids folded into [0, N) -- no community structure at all (worst case for caches and for
     any partitioner).  locality = p > 0: the node range is cut into `n_blocks` equal communities; every edge picks a
     community, draws its source there (RMAT inside the block), and with probability p its destination in the SAME block,
     else anywhere (global RMAT).  This models the graph after a METIS / community relabelling (BASELINE config 3 names METIS
     partitions; ogbn-products is a co-purchase network with strong communities): a contiguous k-way split then cuts
-    about (1 - p)(1 - 1/k) of the edges."""
+    about (1 - p)(1 - 1/k) of the edges.
+
+    exact: duplicates coalesce, so one draw of `n_undirected` edges lands several per cent short (dense RMAT blocks: 11 %);
+    with exact=True further seeded draws top the edge set up until it holds EXACTLY `n_undirected` distinct undirected
+    edges without self-loops, i.e. nnz = 2 * n_undirected (products: 123 718 280).
+    permute_ids: relabel the nodes by a seeded random permutation afterwards -- the communities still exist but ids are no
+    longer sorted by community, which is what a raw dataset looks like before any reordering."""
     dev = torch.device(device)
     scale = int(np.ceil(np.log2(n)))
     on_cpu = dev.type == "cpu"
@@ -128,20 +134,58 @@ def products_like_graph(device, seed=0, n=PRODUCTS_NODES, n_undirected=PRODUCTS_
             return tuple(torch.from_numpy(x) for x in rmat_edges_np(sc, m, sd))
         return rmat_edges_torch(sc, m, sd, dev)
 
-    if locality <= 0.0:
-        src, dst = rmat(scale, n_undirected, seed)
-        src, dst = src % n, dst % n
-    else:
+    def draw(m, sd):
+        if locality <= 0.0:
+            src, dst = rmat(scale, m, sd)
+            return src % n, dst % n
         block = -(-n // n_blocks)
         bscale = int(np.ceil(np.log2(block)))
         gen = torch.Generator(device=dev)
-        gen.manual_seed(seed + 7919)
-        blk = torch.randint(0, n_blocks, (n_undirected,), generator=gen, device=dev)
-        local = torch.rand(n_undirected, generator=gen, device=dev) < locality
-        ls, ld = rmat(bscale, n_undirected, seed)               # positions inside the community
-        _, gd = rmat(scale, n_undirected, seed + 1)             # global destination for the cross-community edges
+        gen.manual_seed(sd + 7919)
+        blk = torch.randint(0, n_blocks, (m,), generator=gen, device=dev)
+        local = torch.rand(m, generator=gen, device=dev) < locality
+        ls, ld = rmat(bscale, m, sd)               # positions inside the community
+        _, gd = rmat(scale, m, sd + 1)             # global destination for the cross-community edges
         base = blk * block
         src = (base + ls % block).clamp(max=n - 1)
         dst = torch.where(local, (base + ld % block).clamp(max=n - 1), gd % n)
-    keep = src != dst
-    return build_graph(src[keep], dst[keep], n, symmetric=True, self_loops=self_loops, weighted=weighted)
+        return src, dst
+
+    src, dst = draw(n_undirected, seed)
+    if exact:
+        def canon(s, d):
+            keep = s != d
+            s, d = s[keep], d[keep]
+            return torch.unique(torch.minimum(s, d) * n + torch.maximum(s, d))
+
+        keys = canon(src, dst)
+        del src, dst
+        rounds = 0
+        while keys.numel() < n_undirected:
+            rounds += 1
+            if rounds > 64:
+                raise RuntimeError("could not reach %d distinct edges (graph too dense for this generator)" % n_undirected)
+            need = n_undirected - keys.numel()
+            s2, d2 = draw(max(int(need * 1.5) + 1024, 4096), seed + 104729 * rounds)
+            fresh = canon(s2, d2)
+            del s2, d2
+            fresh = fresh[~torch.isin(fresh, keys, assume_unique=True)]
+            if fresh.numel() > need:      # keep a seeded random subset of the new edges: exactly `need` of them
+                gen = torch.Generator(device=dev)
+                gen.manual_seed(seed + 15485863 * rounds)
+                fresh = fresh[torch.randperm(fresh.numel(), generator=gen, device=dev)[:need]]
+            keys = torch.cat([keys, fresh])
+            del fresh
+        lo = torch.div(keys, n, rounding_mode="floor")
+        hi = keys - lo * n
+        del keys
+        src, dst = lo, hi
+    else:
+        keep = src != dst
+        src, dst = src[keep], dst[keep]
+    if permute_ids:
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(seed + 2654435761 % (1 << 31))
+        perm = torch.randperm(n, generator=gen, device=dev)
+        src, dst = perm[src], perm[dst]
+    return build_graph(src, dst, n, symmetric=True, self_loops=self_loops, weighted=weighted)

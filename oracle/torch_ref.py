@@ -40,6 +40,29 @@ def sage_conv(src, nbr, weight, nbr_weight, aggr="mean", hid="sum", act=True):
     return torch.relu(out) if act else out
 
 
+def sage_block(rowptr, col, x_dst, x_src, weight, nbr_weight, aggr="mean", act=True, transform_first=False, store=None):
+    """sageConv on a sampled CSR block (rows = destination nodes, columns index x_src): the K-axis reduce of
+    sageconv.py:33-36 over a ragged neighbour list (a seed with fewer than `fanout` neighbours keeps them all,
+    base_sampler.py:53-54), then sageconv.py:41,72-75.  transform_first: reduce(x_src.W_n) instead of reduce(x_src).W_n
+    (equal in exact arithmetic; the build aggregates the narrow product when a layer narrows).  `store`: optional
+    rounding applied where the GPU path stores a tensor (bf16 emulation with a straight-through gradient)."""
+    store = store or (lambda t: t)
+    n = rowptr.numel() - 1
+    row, colv = _rows(rowptr), col.long()
+    deg = (rowptr[1:] - rowptr[:-1]).clamp(min=1).to(x_src.dtype)
+    val = (1.0 / deg)[row] if aggr == "mean" else torch.ones(row.numel(), dtype=x_src.dtype)
+
+    def reduce(m):
+        return torch.zeros(n, m.shape[1], dtype=m.dtype).index_add_(0, row, val[:, None] * m[colv])
+
+    if transform_first:
+        nh = store(reduce(store(x_src @ nbr_weight)))
+    else:
+        nh = store(reduce(x_src)) @ nbr_weight
+    out = x_dst @ weight + nh
+    return store(torch.relu(out) if act else out)
+
+
 def spgat_conv(rowptr, col, x, W, a, alpha, concat=True, heads=1):
     """sparseGatConv.forward, gatconv.py:111-148 (dropout inactive); multi-head when W is [heads, Fin, Fo] and a is
     [heads, 1, 2*Fo] (the torch.cat over heads of SpGAT.forward, gatconv.py:196)."""

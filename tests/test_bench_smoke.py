@@ -40,19 +40,57 @@ def test_bench_single_rank_contract():
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["unit"] == "edges/s" and d["vs_baseline"] is None
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
     assert d["roofline"]["bound"] == "hbm" and d["roofline"]["traffic"] is None       # counters exist for the default shape only
+    assert d["roofline"]["frac"] is None or d["roofline"]["frac"] <= 1.0 or d["roofline"]["frac_algorithmic"] == d["roofline"]["frac"]
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(d["cpu_baseline"]) and d["cpu_baseline"]["kind"] == "port"
+    # the reference's COO op AND the CSR variant, warm-up + median of 3, torch version and cores stated
+    assert set(("torch_sparse_mm_csr_edges_per_s", "oracle_c_openmp_csr_edges_per_s", "torch_version", "threads")) <= set(d["cpu_baseline"])
     assert "workload" in d["config"] and "model" not in d["config"]
+    assert d["config"]["nnz"] == 2 * 200000                      # exactly the requested number of distinct undirected edges
+    assert d["config"]["reorder"] == "lpa" and d["config"]["permuted_ids"] is True
+    # every SpMM-type launch of the step is listed; the headline is the longest hidden-width one
+    wide = [v for v in d["spmm_launch_table"].values() if v["feat"] == 64]
+    assert len(wide) >= 2 and abs(max(v["avg_ms"] for v in wide) - d["roofline"]["avg_launch_ms"]) < 1e-9
+    assert "roofline_no_locality" in d and "roofline_raw_order" in d
     test_bench_single_rank_contract.loss = d["loss"]
+
+
+def _check_two_ranks(res):
+    assert res.returncode == 0, res.stderr[-3000:]
+    d = _last_json(res.stdout)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and "cpu_baseline" not in d
+    assert d["config"]["ranks"] == 2 and d["config"]["backend"] == "gloo"
+    one = getattr(test_bench_single_rank_contract, "loss", None)
+    if one is not None:
+        assert abs(d["loss"] - one) < 2e-2 * abs(one)
+    return d
 
 
 def test_bench_two_ranks_on_one_gpu_agree_with_one_rank():
     env = dict(os.environ, DGLL_BENCH_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SHAPE
-    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    _check_two_ranks(subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env))
+
+
+def test_bench_gpus_flag_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` with no torchrun around it (the shape of the driver's N = 1 command): the parent spawns the
+    two ranks, relays rank 0's line and exits with their status (MQGCN.py:161-163 `mp.spawn(run, nprocs=num_gpus)`)."""
+    env = dict(os.environ, DGLL_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SHAPE, capture_output=True, text=True,
+                         timeout=900, env=env)
+    _check_two_ranks(res)
+    # asynchronous RaCoM (gradients applied one step late, drained every sync period): same contract, finite loss
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--racom-async"] + SHAPE,
+                         capture_output=True, text=True, timeout=900, env=env)
     assert res.returncode == 0, res.stderr[-3000:]
     d = _last_json(res.stdout)
-    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and "cpu_baseline" not in d
-    one = getattr(test_bench_single_rank_contract, "loss", None)
-    if one is not None:
-        assert abs(d["loss"] - one) < 2e-2 * abs(one)
+    assert d["n_gpus"] == 2 and "async" in d["config"]["gradient_sharing"] and d["loss"] == d["loss"]
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SHAPE, capture_output=True, text=True,
+                         timeout=300, env=env)
+    assert res.returncode == 2 and "WORLD_SIZE" in res.stderr

@@ -1,0 +1,223 @@
+"""BASELINE config 2 at its shape: 3-layer GraphSAGE on a Reddit-sized graph, one mini-batch of 1024 seeds with
+fan-out 25-10-10, hidden 256, bf16 -- through FastNeighborSampler + GraphCacheServer (partial cache) +
+MiniBatchPipeline + GraphSage.forward_sampled, checked against the oracle:
+
+  (a) sampled node / edge ids bit-equal to oracle/sampler.py under the same random.seed (and the same generator state
+      afterwards);                                         reference loop: dgll/sampling/dgllsampler.py:10-21
+  (b) fetched features == features[ids] with a partial cache, miss accounting exact;     FeatureCache/storage.py:151-220
+  (c) the bf16 forward against oracle/cref (fp32 arithmetic on the bf16-rounded inputs / weights) and against the torch
+      restatement with bf16 storage rounding emulated;                                   sageconv.py:32-45,70-83,103-114
+  (d) input and parameter gradients against CPU autograd of oracle/torch_ref.
+Reddit itself is not available offline: the graph is the seeded Reddit-shaped RMAT of SURVEY.md section 8(d)
+(N = 232 965, 114.6 M directed edges, F = 602, 41 classes).
+"""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+N, UNDIRECTED, FEATS, CLASSES, HIDDEN, BATCH = 232_965, 57_300_000, 602, 41, 256, 1024
+FANOUTS = [25, 10, 10]
+
+
+def _bf16_round(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def _store(t):                  # bf16 storage rounding with a straight-through gradient
+    return t + (_bf16_round(t.detach()) - t.detach())
+
+
+@pytest.fixture(scope="module")
+def reddit_batch(cuda_device):
+    from dgll_amd import synth
+    from dgll_amd.cache import GraphCacheServer
+    from dgll_amd.data import DGraph
+    from dgll_amd.dataloader import DataLoader
+    from dgll_amd.pipeline import MiniBatchPipeline
+    from dgll_amd.sampling import FastNeighborSampler
+
+    dev = cuda_device
+    g = synth.products_like_graph(dev, seed=1, n=N, n_undirected=UNDIRECTED, locality=0.0, exact=True)
+    assert g.nnz == 2 * UNDIRECTED                                   # 114.6 M directed edges, average degree 492
+    indptr, indices = g.rowptr.cpu().numpy(), g.col.cpu().numpy().astype(np.int64)
+    deg = g.degrees().cpu()
+    del g
+    torch.manual_seed(0)
+    feats = torch.randn(N, FEATS).to(torch.bfloat16)
+    labels = torch.randint(0, CLASSES, (N,))
+    dg = DGraph.from_csr(indptr, indices, labels=labels, features=feats)
+    cache = GraphCacheServer(feats, gpuid=dev.index or 0)
+    cache.log = True
+    cache.auto_cache(deg, capacity=N // 4)                           # PARTIAL cache: top quarter by out-degree
+    assert not cache.full_cached and cache.cached_num == N // 4
+    seeds = torch.randperm(N, generator=torch.Generator().manual_seed(5))[:BATCH]
+    L = len(FANOUTS)
+
+    def hop_ids(b):          # hop 0 = seeds, hop h+1 = sources sampled around hop h (subgs are outermost first)
+        return [b.output_nodes] + [b.subgraphs[L - 1 - h].src_nodes() for h in range(L)]
+
+    loader = DataLoader(dg, seeds, FastNeighborSampler(FANOUTS, defer_last_hop=True), batch_size=BATCH)
+    pipe = MiniBatchPipeline(loader, cache=cache, labels=labels, queue_size=4, device=dev, hops=hop_ids)
+    random.seed(7)
+    batches = list(pipe)
+    state_after = random.getstate()
+    assert len(batches) == 1
+    return dict(dg=dg, feats=feats, labels=labels, cache=cache, seeds=seeds, batch=batches[0], state_after=state_after,
+                hop_ids=hop_ids(batches[0]), dev=dev)
+
+
+@pytest.mark.gpu
+def test_sampled_ids_are_bit_equal_to_the_oracle(reddit_batch):
+    from oracle import sampler as osampler
+
+    r = reddit_batch
+    random.seed(7)
+    inp, outp, layers = osampler.sample(r["dg"].edges, r["seeds"].tolist(), FANOUTS)
+    assert random.getstate() == r["state_after"]                     # the generator was consumed identically
+    b = r["batch"]
+    assert b.output_nodes.tolist() == outp
+    assert len(b.subgraphs) == len(layers) == 3
+    for sg, (src, dst) in zip(b.subgraphs, layers):
+        assert torch.equal(sg.src_nodes(), torch.tensor(src, dtype=torch.int64))
+        assert torch.equal(sg.dst_nodes(), torch.tensor(dst, dtype=torch.int64))
+    assert torch.equal(b.input_nodes, torch.tensor(inp, dtype=torch.int64))
+    # the shape BASELINE names: 1024 -> 10 240 -> 102 400 -> 2.56 M (every degree here exceeds the fan-out or is kept whole)
+    sizes = [len(x) for x in r["hop_ids"]]
+    assert sizes[0] == BATCH and sizes[1] <= 10 * sizes[0] and sizes[2] <= 10 * sizes[1] and sizes[3] <= 25 * sizes[2]
+    assert sizes[3] > 2_000_000
+
+
+@pytest.mark.gpu
+def test_fetched_features_equal_indexing_with_a_partial_cache(reddit_batch):
+    r = reddit_batch
+    b, cache = r["batch"], r["cache"]
+    torch.cuda.synchronize()
+    total = misses = 0
+    flag = cache.gpu_flag.cpu()
+    for ids, got in zip(r["hop_ids"], b.features):
+        assert got.dtype == torch.bfloat16 and got.shape == (len(ids), FEATS)
+        assert torch.equal(got.cpu(), r["feats"][ids])               # bit-exact rows, hits from HBM and misses over PCIe
+        total += len(ids)
+        misses += int((~flag[ids]).sum())
+    assert 0 < misses < total
+    assert abs(cache.get_miss_rate() - misses / total) < 1e-12        # storage.py:213-220 accounting
+    assert torch.equal(b.labels.cpu(), r["labels"][b.output_nodes])
+
+
+def _model(dev):
+    from dgll_amd import nn as dnn
+
+    torch.manual_seed(3)
+    return dnn.GraphSage(FEATS, [HIDDEN, HIDDEN, CLASSES], FANOUTS).to(dev)
+
+
+@pytest.mark.gpu
+def test_bf16_forward_matches_the_oracle(reddit_batch):
+    """hidden-256 bf16 output of GraphSage.forward_sampled vs oracle/cref (spmm_csr mean + gemm) on the bf16-rounded inputs
+    and weights in fp32: bf16 tolerance (8 mantissa bits; three layers of bf16 storage) = 3e-2 of the output's RMS."""
+    from oracle import cref
+
+    r = reddit_batch
+    b, dev = r["batch"], r["dev"]
+    model = _model(dev)
+    L = 3
+    blocks = [b.subgraphs[L - 1 - h].to_block(dev) for h in range(L)]
+    with torch.no_grad():
+        out = model.forward_sampled(b.features, blocks)
+    assert out.dtype == torch.bfloat16 and out.shape == (BATCH, CLASSES)
+    hid = [f.float().cpu().numpy() for f in b.features]
+    ptrs = [b.subgraphs[L - 1 - h].indptr.numpy() for h in range(L)]
+    for l, layer in enumerate(model.gcn):
+        ws = _bf16_round(layer.weight.detach().cpu()).numpy()
+        wn = _bf16_round(layer.neighborAgg.weight.detach().cpu()).numpy()
+        nxt = []
+        for hop in range(L - l):
+            col = np.arange(hid[hop + 1].shape[0], dtype=np.int32)
+            agg = cref.spmm_csr(ptrs[hop], col, None, hid[hop + 1], reduce="mean")
+            z = cref.gemm(hid[hop], ws) + cref.gemm(agg, wn)
+            nxt.append(np.maximum(z, 0) if layer.activation is not None else z)
+        hid = nxt
+    ref = hid[0]
+    got = out.float().cpu().numpy()
+    rms = float(np.sqrt((ref ** 2).mean()))
+    assert np.isfinite(got).all() and rms > 0
+    np.testing.assert_allclose(got, ref, rtol=3e-2, atol=3e-2 * rms)
+    assert float(np.abs(got - ref).mean()) < 6e-3 * rms
+
+
+@pytest.mark.gpu
+def test_bf16_gradients_match_cpu_autograd_of_the_oracle(reddit_batch):
+    """Forward (tight: bf16 storage rounding emulated at the points where the GPU path stores a tensor) and backward
+    (input-feature and parameter gradients) vs CPU autograd of oracle/torch_ref.sage_block."""
+    from oracle import torch_ref
+
+    r = reddit_batch
+    b, dev = r["batch"], r["dev"]
+    model = _model(dev)
+    L = 3
+    blocks = [b.subgraphs[L - 1 - h].to_block(dev) for h in range(L)]
+    xs = [f.detach().clone().requires_grad_() for f in b.features]
+    out = model.forward_sampled(xs, blocks)
+    loss = torch.nn.functional.cross_entropy(out.float(), b.labels)
+    loss.backward()
+    torch.cuda.synchronize()
+
+    # ---- CPU oracle: fp32 arithmetic, bf16 storage emulated, same parameters ----
+    ptrs = [b.subgraphs[L - 1 - h].indptr for h in range(L)]
+    cx = [f.float().cpu().requires_grad_(h < L) for h, f in enumerate(b.features)]     # hop-3 rows: closed form below
+    params = []
+    hid = cx
+    kept = {}
+    for l, layer in enumerate(model.gcn):
+        ws = _bf16_round(layer.weight.detach().cpu()).requires_grad_()
+        wn = _bf16_round(layer.neighborAgg.weight.detach().cpu()).requires_grad_()
+        params.append((ws, wn))
+        nxt = []
+        for hop in range(L - l):
+            col = torch.arange(hid[hop + 1].shape[0], dtype=torch.int32)
+            src = hid[hop + 1]
+            if l == 0 and hop == L - 1:
+                # the outermost hop (2.56 M x 602) enters through its mean only: make the mean a leaf-like retained tensor
+                with torch.no_grad():
+                    from oracle import cref
+
+                    agg0 = torch.from_numpy(cref.spmm_csr(ptrs[hop].numpy(), col.numpy(), None, src.detach().numpy(), reduce="mean"))
+                agg0 = _bf16_round(agg0).requires_grad_()
+                kept["agg"] = agg0
+                z = hid[hop] @ ws + agg0 @ wn
+                nxt.append(_store(torch.relu(z) if layer.activation is not None else z))
+                continue
+            nxt.append(torch_ref.sage_block(ptrs[hop], col, hid[hop], src, ws, wn, act=layer.activation is not None,
+                                            transform_first=layer.transform_first(b.features[hop + 1]), store=_store))
+        hid = nxt
+    ref_out = hid[0]
+    ref_loss = torch.nn.functional.cross_entropy(ref_out, b.labels.cpu())
+    ref_loss.backward()
+
+    got = out.detach().float().cpu()
+    rms = float(ref_out.detach().pow(2).mean().sqrt())
+    # tight forward check: only accumulation order and 1-ulp rounding flips separate the two
+    assert float((got - ref_out.detach()).abs().max()) <= 2.0 ** -6 * max(float(ref_out.detach().abs().max()), rms)
+    assert abs(float(loss) - float(ref_loss)) < 2e-3 * abs(float(ref_loss))
+
+    def close(name, a, ref, tol=4e-2):
+        a, ref = a.detach().float().cpu(), ref.detach()
+        scale = float(ref.abs().max())
+        assert scale > 0, name
+        err = float((a - ref).abs().max())
+        assert err <= tol * scale, "%s: max err %.3e vs scale %.3e" % (name, err, scale)
+        assert float((a - ref).abs().mean()) <= 0.25 * tol * float(ref.abs().mean()) + 1e-12, name
+
+    for l, layer in enumerate(model.gcn):
+        close("layer %d weight" % l, layer.weight.grad, params[l][0].grad)
+        close("layer %d neighborAgg.weight" % l, layer.neighborAgg.weight.grad, params[l][1].grad)
+    for h in range(L):
+        close("features of hop %d" % h, xs[h].grad, cx[h].grad)
+    # hop 3: every row belongs to exactly one edge; its gradient is grad(mean)[seed occurrence] / deg
+    deg = (ptrs[L - 1][1:] - ptrs[L - 1][:-1])
+    rows = torch.repeat_interleave(torch.arange(deg.numel()), deg)
+    expect = kept["agg"].grad[rows] / deg.clamp(min=1).float()[rows, None]
+    sel = torch.randperm(expect.shape[0], generator=torch.Generator().manual_seed(1))[:200_000]
+    close("features of hop 3 (sampled rows)", xs[L].grad[sel.to(dev)], expect[sel])

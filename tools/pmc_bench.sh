@@ -1,0 +1,28 @@
+#!/bin/bash
+# rocprofv3 evidence for bench.py's roofline, collected on THE SAME command bench.py's default run uses (same build,
+# same graph, same kernels): one --kernel-trace --stats pass (per-kernel durations) and one --pmc pass per counter
+# group (kernel-trace only, as gpurun requires; FETCH_SIZE and WRITE_SIZE cannot share a pass -- TCC has 4 slots).
+#   usage (on the GPU box, from the repo root):  bash tools/pmc_bench.sh <tag> [bench.py args...]
+# writes gpurun_out/<tag>/{kernel_stats.csv, bench_under_rocprof.json, pmc_<group>.csv}; tools/pmc_parse.py turns the
+# counter files into profiles/traffic.json entries.
+set -u
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+TAG=${1:-pmc}
+shift || true
+OUT=$R/gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+cd /tmp
+BENCH_ARGS="--steps 3 --warmup 2 --no-cpu-baseline --calibrate $*"
+rm -rf /tmp/kt_$TAG
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$TAG -o p -- python3 $R/bench.py $BENCH_ARGS > $OUT/bench_under_rocprof.json 2> $OUT/kernel_trace.log
+f=$(find /tmp/kt_$TAG -name '*kernel_stats.csv' | head -1)
+[ -n "$f" ] && cp $f $OUT/kernel_stats.csv
+for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
+  tag=$(echo $grp | tr ' ' '_')
+  rm -rf /tmp/pmc_${TAG}_$tag
+  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d /tmp/pmc_${TAG}_$tag -o p -- python3 $R/bench.py $BENCH_ARGS --no-extra-graphs > $OUT/pmc_$tag.json 2> $OUT/pmc_$tag.log
+  f=$(find /tmp/pmc_${TAG}_$tag -name '*counter_collection.csv' | head -1)
+  [ -n "$f" ] && grep -E "Counter_Name|spmm_csr_kernel|spmm_long_finalize|gemm_bf16" $f > $OUT/pmc_$tag.csv
+done
+ls -la $OUT
