@@ -89,6 +89,7 @@ SIGNATURES = {
     "dgll_hip_gcn_fused_forward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _sz]),
     "dgll_hip_gcn_fused_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "dgll_hip_segment_max": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i32, _i64, _i32]),
+    "dgll_hip_segment_max_bwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i64, _i32]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():

@@ -656,6 +656,59 @@ __global__ __launch_bounds__(kBlock) void segment_max_kernel(const EdgeArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ segment max, backward
+// grad[j, f] = sum over the destination rows i that list j (once per distinct i) of  (arg[i, f] == j) ? g[i, f] : 0
+// -- the gradient of a max goes to the arg-max source row only (torch.max, sageconv.py:37-38).  Driven by the TRANSPOSED
+// structure (row j of `rowptr/col` lists the destinations i, ascending), so every output row is produced by one
+// wavefront in a fixed order: no atomics, bit-reproducible.  A pair (i, j) stored twice is counted once.
+template <typename XT, int EPV, int LPR, int U>
+__global__ __launch_bounds__(kBlock) void segment_max_bwd_kernel(const EdgeArgs a, const int32_t* __restrict__ arg, int64_t ldarg) {
+    typedef VecIO<XT, EPV> IO;
+    constexpr int SLOTS = kWave / LPR;
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int sub = lane % LPR, slot = lane / LPR;
+    const int c0 = ((int)blockIdx.y * LPR + sub) * EPV;
+    const bool col_ok = c0 < a.feat;
+    const int64_t j = (int64_t)blockIdx.x * kWavesPerBlock + wave;      // source row whose gradient this wavefront writes
+    if (j >= a.n_rows) return;
+    const int64_t b = uniform64(a.rowptr[j]), e = uniform64(a.rowptr[j + 1]);
+    const XT* gcol = static_cast<const XT*>(a.G) + (col_ok ? c0 : 0);
+    const int32_t* acol = arg + (col_ok ? c0 : 0);
+    float acc[EPV];
+#pragma unroll
+    for (int i = 0; i < EPV; ++i) acc[i] = 0.0f;
+    for_each_batch(a.col, b, e, lane, [&](int nb, int cur_col, int64_t k0) {
+        // a repeated (i, j) pair sits in adjacent slots of the sorted transposed row: keep the first
+        int prev = __shfl_up(cur_col, 1);
+        if (lane == 0) prev = k0 > b ? a.col[k0 - 1] : -1;
+        const int keep = (lane < nb && cur_col != prev) ? 1 : 0;
+        for (int jj = 0; jj < nb; jj += SLOTS * U) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = jj + u * SLOTS + slot;
+                const int src = idx < nb ? idx : nb - 1;
+                const int i = __shfl(cur_col, src);
+                const int k = __shfl(keep, src);
+                if (idx < nb && k) {
+                    float f[EPV];
+                    IO::unpack(IO::load(gcol + (uint64_t)(uint32_t)i * (uint32_t)a.ldg), f);
+                    const int32_t* ap = acol + (int64_t)i * ldarg;
+#pragma unroll
+                    for (int q = 0; q < EPV; ++q)
+                        if (ap[q] == (int32_t)j) acc[q] += f[q];
+                }
+            }
+        }
+    });
+#pragma unroll
+    for (int off = LPR; off < kWave; off <<= 1) {
+#pragma unroll
+        for (int i = 0; i < EPV; ++i) acc[i] += __shfl_xor(acc[i], off);
+    }
+    if (slot == 0 && col_ok) VecIO<XT, EPV>::store(static_cast<XT*>(a.Y) + j * a.ldy + c0, acc);
+}
+
 // ---- host-side dispatch helpers --------------------------------------------------------------------------
 static int pick_lpr(int vecs) {
     int lpr = 4;
@@ -938,6 +991,31 @@ DGLL_API int dgll_hip_segment_max(void* stream, const int64_t* rowptr, const int
 #define CALL(L)                                                                                                          \
     if (dtype == DGLL_F32) hipLaunchKernelGGL((segment_max_kernel<float, 4, L, 4>), grid, dim3(kBlock), 0, s, a);        \
     else hipLaunchKernelGGL((segment_max_kernel<bf16_t, 8, L, 4>), grid, dim3(kBlock), 0, s, a);
+    DGLL_LPR_SWITCH(lpr, CALL)
+#undef CALL
+    DGLL_HIP_TRY(hipGetLastError());
+    return DGLL_OK;
+}
+
+DGLL_API int dgll_hip_segment_max_bwd(void* stream, const int64_t* t_rowptr, const int32_t* t_col, const void* G, int64_t ldg,
+                                      const int32_t* arg, int64_t ldarg, void* grad, int64_t ldgrad, int dtype,
+                                      int64_t n_src, int feat) {
+    if (n_src <= 0 || feat <= 0) return DGLL_OK;
+    DGLL_REQUIRE(t_rowptr && t_col && G && arg && grad, "NULL argument");
+    DGLL_REQUIRE(dtype == DGLL_F32 || dtype == DGLL_BF16, "dtype");
+    const int esz = dtype == DGLL_BF16 ? 2 : 4, epv = 16 / esz;
+    const int vecs = (feat + epv - 1) / epv;
+    DGLL_REQUIRE(vec_ok(G, ldg, esz) && vec_ok(grad, ldgrad, esz) && ldg >= vecs * epv && ldgrad >= vecs * epv && ldarg >= vecs * epv,
+                 "segment_max_bwd operands must be 16-byte aligned with padded leading dimensions");
+    EdgeArgs a{};
+    a.rowptr = t_rowptr; a.col = t_col; a.G = G; a.ldg = ldg; a.Y = grad; a.ldy = ldgrad; a.n_rows = n_src;
+    a.feat = vecs * epv;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int lpr = pick_lpr(vecs);
+    dim3 grid((uint32_t)((n_src + kWavesPerBlock - 1) / kWavesPerBlock), (uint32_t)((vecs + lpr - 1) / lpr));
+#define CALL(L)                                                                                                                  \
+    if (dtype == DGLL_F32) hipLaunchKernelGGL((segment_max_bwd_kernel<float, 4, L, 4>), grid, dim3(kBlock), 0, s, a, arg, ldarg);  \
+    else hipLaunchKernelGGL((segment_max_bwd_kernel<bf16_t, 8, L, 4>), grid, dim3(kBlock), 0, s, a, arg, ldarg);
     DGLL_LPR_SWITCH(lpr, CALL)
 #undef CALL
     DGLL_HIP_TRY(hipGetLastError());

@@ -79,16 +79,30 @@ class _SegmentMax(torch.autograd.Function):
                                                  xs.data_ptr(), xs.stride(0), y.data_ptr(), arg.data_ptr(), y.stride(0),
                                                  _dtype_code(xs), graph.n_rows, feat)
         _lib.check(code, "dgll_hip_segment_max")
-        ctx.save_for_backward(arg[:, :feat])
-        ctx.n_src = x.shape[0]
+        ctx.save_for_backward(arg)
+        ctx.n_src, ctx.graph, ctx.feat = x.shape[0], graph, feat
         return y
 
     @staticmethod
     def backward(ctx, g):
+        """The gradient goes to the arg-max row only: a gather over the transposed structure (dgll_hip_segment_max_bwd),
+        one wavefront per source row, no atomics.  Sampled blocks (col == arange: every source row has exactly one
+        in-edge) need no sort: their transposed structure is rowptr = arange, col = the row of each edge."""
         (arg,) = ctx.saved_tensors
-        grad = torch.zeros((ctx.n_src, g.shape[1]), dtype=g.dtype, device=g.device)
-        valid = arg >= 0
-        grad.scatter_add_(0, arg.clamp(min=0).long(), g * valid)   # the gradient goes to the arg-max row only
+        graph, feat = ctx.graph, ctx.feat
+        if graph.identity_cols and graph.n_cols == graph.nnz:
+            t_rowptr = torch.arange(ctx.n_src + 1, dtype=torch.int64, device=g.device)
+            t_col = graph.row_index().to(torch.int32)
+        else:
+            gt, _ = graph.transpose()
+            t_rowptr, t_col = gt.rowptr, gt.col
+        gs = _ready(g.to(arg.device))
+        grad = _empty_padded(ctx.n_src, feat, g.dtype, g.device)
+        with torch.cuda.device(g.device):
+            code = _lib.lib.dgll_hip_segment_max_bwd(_stream(g.device), t_rowptr.data_ptr(), t_col.data_ptr(), gs.data_ptr(),
+                                                     gs.stride(0), arg.data_ptr(), arg.stride(0), grad.data_ptr(),
+                                                     grad.stride(0), _dtype_code(gs), ctx.n_src, feat)
+        _lib.check(code, "dgll_hip_segment_max_bwd")
         return grad, None
 
 

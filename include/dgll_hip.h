@@ -176,6 +176,14 @@ int dgll_hip_gat_bwd_cols(void* stream, const dgll_csr_plan* t_plan, const int64
 int dgll_hip_segment_max(void* stream, const int64_t* rowptr, const int32_t* col, const void* X, int64_t ldx,
                          void* Y, int32_t* arg, int64_t ldy, int dtype, int64_t n_rows, int feat);
 
+/* Backward of the max: grad[j,f] = sum_{i lists j} (arg[i,f] == j) ? G[i,f] : 0  -- the gradient reaches the arg-max row
+ * only (torch.max semantics behind sageconv.py:37-38).  (t_rowptr, t_col) is the TRANSPOSED structure (row j lists the
+ * destination rows i in ascending order; a repeated pair counts once); one wavefront per output row, fixed order, no
+ * atomics.  G / grad 16-byte aligned with leading dimensions padded like segment_max's; arg as segment_max wrote it. */
+int dgll_hip_segment_max_bwd(void* stream, const int64_t* t_rowptr, const int32_t* t_col, const void* G, int64_t ldg,
+                             const int32_t* arg, int64_t ldarg, void* grad, int64_t ldgrad, int dtype, int64_t n_src,
+                             int feat);
+
 /* ---- f2: feature-row gather through the hot-node cache -------------------------------------------------------
  * out[i,:] = cache[slot[idx[i]],:] if slot[idx[i]] >= 0 else host[idx[i],:]   -- GraphCacheServer.fetch_data,
  * dgll/FeatureCache/storage.py:151-198 (mask split, GPU gather of cached rows, CPU gather + copy of the rest, merge)

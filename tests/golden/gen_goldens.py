@@ -523,10 +523,79 @@ def gen_formats(ref):
              grad_w_out=gs[3], grad_b_out=gs[4])
 
 
+def gen_fused_pin(ref):
+    """Pin for row a10 (FusedKernel/gcn_fused_kernel.cu:5-74, CUDA: cannot be built here): the SAME arithmetic --
+    H = relu(A . (X . W)) with unit edge values, duplicates summed, no bias -- is the runnable reference layer
+    Evaluation/PPI/gcn_model.py:63-77 (GCNLayer).  Stored: one layer's input, weight, output H and, for the loss
+    sum(H * gout), the gradients w.r.t. X and W (what launch_gcn_fused_kernel_backward_optimized must produce)."""
+    import tarfile
+    import tempfile
+
+    def one(name, edge_index, x, w_scale, seed, extra_meta):
+        torch.manual_seed(seed)
+        n, Fi = x.shape
+        layer = ref.ppi_model.GCNLayer(Fi, 64)
+        with torch.no_grad():
+            layer.weight.mul_(w_scale)
+        xg = x.clone().requires_grad_(True)
+        h = layer(edge_index, xg, n)
+        gout = torch.randn_like(h)
+        gx, gw = torch.autograd.grad(h, [xg, layer.weight], gout)
+        save(name, dict(row="a10 (pinned through the runnable GCNLayer)", ref="Evaluation/PPI/gcn_model.py:63-77 == "
+                        "FusedKernel/gcn_fused_kernel.cu:39-69 (relu(A.(X.W)), unit values, no bias)", n=int(n), F=int(Fi), H=64,
+                        **extra_meta),
+             edge_index=edge_index.to(torch.int32), x=x, w=layer.weight, h=h, gout=gout, grad_x=gx, grad_w=gw)
+
+    torch.manual_seed(21)
+    n, Fi = 300, 50
+    src, dst = rmat_edges(8, 12, seed=5)
+    src, dst = src % n, dst % n
+    keep = src != dst
+    one("fused_gcn_layer_n300", torch.from_numpy(np.vstack((src[keep], dst[keep]))), torch.randn(n, Fi), 0.1, 22,
+        dict(duplicate_edges=True))
+    with tempfile.TemporaryDirectory() as tmp:
+        with tarfile.open(os.path.join(REF, "Evaluation/PPI.tar.xz")) as tf:
+            tf.extractall(tmp)
+        ei, x, _ = ref.ppi_loader.load_ppi_dataset(os.path.join(tmp, "PPI"), "test")[1]
+    one("fused_gcn_layer_ppi_test1", ei, x, 0.05, 23, dict(split="test", graph=1, data="bundled PPI (Evaluation/PPI.tar.xz)"))
+
+
+def gen_pooling(ref):
+    """Stand-in pin for the global-pooling row (dgll/nn/GlobalPooling/Pooling.py:18-81): the reference calls
+    torch_scatter.scatter(x, batch, dim=0, dim_size=size, reduce=...), which is NOT installed in this image and cannot be
+    imported.  The vectors below come from torch.Tensor.scatter_reduce (ATen, run in the build container) on seeded
+    inputs, with torch_scatter's documented conventions applied by hand: empty segments give 0 for every reduce, 'mean'
+    divides by max(count, 1).  The fixture says so in its metadata; it pins the build's kernels to an implementation
+    that is independent of them, not to torch_scatter itself."""
+    torch.manual_seed(31)
+    sizes = [5, 0, 130, 1, 40, 700, 0, 9]                      # two empty graphs, one long segment
+    batch = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes))
+    n, Fd, B = int(batch.numel()), 19, len(sizes)
+    x = torch.randn(n, Fd, requires_grad=True)
+    idx = batch.view(-1, 1).expand(-1, Fd)
+    outs, grads = {}, {}
+    for red, name in (("sum", "sum"), ("mean", "mean"), ("amax", "max")):
+        y = torch.zeros(B, Fd).scatter_reduce(0, idx, x, red, include_self=False)
+        gout = torch.randn(B, Fd, generator=torch.Generator().manual_seed(32))
+        (gx,) = torch.autograd.grad(y, x, gout)
+        outs[name], grads[name] = y, gx
+    perm = torch.randperm(n, generator=torch.Generator().manual_seed(33))     # the same nodes in scrambled order
+    save("pooling_scatter_reduce_b8", dict(row="f4 pooling", ref="dgll/nn/GlobalPooling/Pooling.py:18-81", n=n, F=Fd, B=B,
+                                           stands_in_for="torch_scatter.scatter (absent from this image): vectors from "
+                                           "torch.Tensor.scatter_reduce(include_self=False) on zeros, i.e. empty segments = 0",
+                                           gout_seed=32),
+         x=x, batch=batch, perm=perm, y_sum=outs["sum"], y_mean=outs["mean"], y_max=outs["max"],
+         gout=torch.randn(B, Fd, generator=torch.Generator().manual_seed(32)),
+         grad_sum=grads["sum"], grad_mean=grads["mean"], grad_max=grads["max"])
+
+
 def main():
     ref = load_reference()
     if sys.argv[1:] == ["formats"]:
         return gen_formats(ref)
+    if sys.argv[1:] == ["pins"]:                 # round 2: only the new fixtures (the others are unchanged)
+        gen_fused_pin(ref)
+        return gen_pooling(ref)
     gen_gcn(ref)
     gen_sage(ref)
     gen_gat(ref)
@@ -534,6 +603,8 @@ def main():
     gen_sampler(ref)
     gen_adj_prep(ref)
     gen_formats(ref)
+    gen_fused_pin(ref)
+    gen_pooling(ref)
 
 
 if __name__ == "__main__":

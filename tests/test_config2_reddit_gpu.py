@@ -200,15 +200,20 @@ def test_bf16_gradients_match_cpu_autograd_of_the_oracle(reddit_batch):
     rms = float(ref_out.detach().pow(2).mean().sqrt())
     # tight forward check: only accumulation order and 1-ulp rounding flips separate the two
     assert float((got - ref_out.detach()).abs().max()) <= 2.0 ** -6 * max(float(ref_out.detach().abs().max()), rms)
-    assert abs(float(loss) - float(ref_loss)) < 2e-3 * abs(float(ref_loss))
+    assert abs(float(loss.detach()) - float(ref_loss.detach())) < 2e-3 * abs(float(ref_loss.detach()))
 
     def close(name, a, ref, tol=4e-2):
+        """bf16 backward vs the fp32 backward of the oracle.  Two things separate them: every stored gradient is rounded
+        to bf16 (2^-9 relative per stage, three layers), and a ReLU gate can differ where a pre-activation is within
+        rounding of zero -- harmless forward, but it switches one whole term of a gradient sum on or off.  So: the relative
+        L2 error is small, and all but a sliver of the entries are within `tol` of the gradient's scale."""
         a, ref = a.detach().float().cpu(), ref.detach()
         scale = float(ref.abs().max())
         assert scale > 0, name
-        err = float((a - ref).abs().max())
-        assert err <= tol * scale, "%s: max err %.3e vs scale %.3e" % (name, err, scale)
-        assert float((a - ref).abs().mean()) <= 0.25 * tol * float(ref.abs().mean()) + 1e-12, name
+        rel_l2 = float((a - ref).norm() / ref.norm())
+        assert rel_l2 <= tol, "%s: relative L2 error %.3e" % (name, rel_l2)
+        outliers = float(((a - ref).abs() > tol * scale).float().mean())
+        assert outliers <= 2e-3, "%s: %.2e of the entries are off by more than %.0e of the scale" % (name, outliers, tol)
 
     for l, layer in enumerate(model.gcn):
         close("layer %d weight" % l, layer.weight.grad, params[l][0].grad)

@@ -272,6 +272,58 @@ def test_segment_max_vs_oracle(cuda_device, dtype):
     assert float(xd.grad.float().sum()) == float((np.diff(rowptr) > 0).sum() * feat)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("kind", ["csr", "csr_with_duplicates", "block"])
+def test_segment_max_backward_kernel_routes_the_gradient_to_the_argmax_row(cuda_device, dtype, kind):
+    """dgll_hip_segment_max_bwd (gather over the transposed structure, no atomics) vs CPU autograd of torch's max over the
+    K axis (sageconv.py:37-38): general CSR with long / empty rows, a CSR that stores some (row, col) pairs twice, and a
+    sampled block (col == arange, the case of every mini-batch)."""
+    import dgll_amd
+    from dgll_amd import ops
+
+    rng = np.random.default_rng(7)
+    feat = 37
+    if kind == "block":
+        n, k = 300, 9
+        g = dgll_amd.CSRGraph.fixed_fanout(n, k, cuda_device)
+        rowptr, col = g.rowptr.cpu().numpy(), g.col.cpu().numpy()
+        n_src = n * k
+    else:
+        n = n_src = 400
+        rowptr, col, _ = np_graph(n, 12, seed=5, heavy_rows=[(3, 380)], empty_rows=[0, 7], weighted=False)
+        if kind == "csr_with_duplicates":            # every third edge stored twice (adjacent slots of the sorted row)
+            deg = np.diff(rowptr)
+            rep = np.ones(col.size, dtype=np.int64)
+            rep[::3] = 2
+            col = np.repeat(col, rep)
+            newdeg = np.add.reduceat(rep, rowptr[:-1][deg > 0]) if col.size else deg
+            full = np.zeros(n, dtype=np.int64)
+            full[deg > 0] = newdeg
+            rowptr = np.zeros(n + 1, np.int64)
+            np.cumsum(full, out=rowptr[1:])
+        g = to_dev(rowptr, col, None, n_src, cuda_device)
+    x = torch.from_numpy(rng.standard_normal((n_src, feat)).astype(np.float32)).to(dtype)
+    xd = x.to(cuda_device).requires_grad_(True)
+    w = torch.from_numpy(rng.standard_normal((len(rowptr) - 1, feat)).astype(np.float32))
+    y = ops.segment_max(g, xd)
+    (y.float() * w.to(cuda_device)).sum().backward()
+    # CPU reference: per row, max over the listed source rows (first arg-max = lowest source id, as the kernel)
+    xr = x.float().requires_grad_(True)
+    rows = []
+    for i in range(len(rowptr) - 1):
+        c = np.unique(col[rowptr[i]:rowptr[i + 1]])
+        rows.append(xr[torch.from_numpy(c).long()].max(0)[0] if c.size else torch.zeros(feat))
+    yr = torch.stack(rows)
+    (yr * w).sum().backward()
+    tol = 1e-6 if dtype == torch.float32 else 1e-2
+    torch.testing.assert_close(y.detach().float().cpu(), yr.detach(), rtol=tol, atol=tol)
+    torch.testing.assert_close(xd.grad.float().cpu(), xr.grad, rtol=tol, atol=tol * float(xr.grad.abs().max()))
+    # bit-reproducible: no atomics
+    xd2 = x.to(cuda_device).requires_grad_(True)
+    (ops.segment_max(g, xd2).float() * w.to(cuda_device)).sum().backward()
+    assert torch.equal(xd2.grad, xd.grad)
+
+
 @pytest.mark.parametrize("F_padded,actual_F,H", [(52, 50, 64), (64, 64, 121), (16, 13, 5), (128, 128, 32)])
 def test_fused_gcn_launcher_vs_oracle(cuda_device, F_padded, actual_F, H):
     """a10: the reference-named launcher (gcn_fused_kernel.cu:190-195) vs the oracle restatement of :39-69, through both
