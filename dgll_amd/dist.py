@@ -58,26 +58,13 @@ def _csr_rows(rowptr, col, val, rows):
     return new_ptr, col[pos], (None if val is None else val[pos])
 
 
-def partition_contiguous(graph, world, rank, bounds=None):
-    """Row-partition `graph` (the SAME full CSRGraph on every rank) into `world` contiguous blocks and build this
-    rank's Partition.  `bounds` (len world+1) overrides the equal-rows split (e.g. METIS part boundaries after a
-    community relabelling, or an nnz-balanced split)."""
-    n = graph.n_rows
-    dev = graph.device
-    if bounds is None:
-        bounds = [(n * r) // world for r in range(world + 1)]
+def _split_block(p, rowptr, col, val, bounds, dev):
+    """Fill the Partition's two column halves from this rank's row block (local rowptr, GLOBAL column ids).  Returns the
+    sorted global ids of the halo nodes and their owner ranks."""
+    world = len(bounds) - 1
     bounds_t = torch.tensor(bounds, dtype=torch.int64, device=dev)
-    p = Partition()
-    p.rank, p.world = rank, world
-    p.own_begin, p.own_end = bounds[rank], bounds[rank + 1]
-    p.n_own = p.own_end - p.own_begin
-    rp = graph.rowptr
-    e0, e1 = int(rp[p.own_begin]), int(rp[p.own_end])
-    col = graph.col[e0:e1].to(torch.int64)
-    val = None if graph.val is None else graph.val[e0:e1]
-    rowptr = rp[p.own_begin:p.own_end + 1] - e0
-    p.nnz = e1 - e0
-
+    col = col.to(torch.int64)
+    p.nnz = int(col.numel())
     owned = (col >= p.own_begin) & (col < p.own_end)
     halo_ids = torch.unique(col[~owned])                       # sorted by global id == grouped by owner rank
     p.n_halo = int(halo_ids.numel())
@@ -97,21 +84,13 @@ def partition_contiguous(graph, world, rank, bounds=None):
     # boolean masking keeps the row-major edge order, so each half is a valid CSR over the same rows
     p.local = sub_csr(owned, col[owned] - p.own_begin, p.n_own)
     p.halo = sub_csr(~owned, torch.searchsorted(halo_ids, col[~owned]), p.n_halo)
+    return halo_ids, owner
 
-    # what each peer needs from me: the unique columns of ITS rows that fall in my range (every rank derives this
-    # from the same full graph, so it equals the peer's halo list restricted to my block -- no setup communication)
-    send, counts = [], []
-    for q in range(world):
-        if q == rank:
-            counts.append(0)
-            continue
-        q0, q1 = int(rp[bounds[q]]), int(rp[bounds[q + 1]])
-        qc = graph.col[q0:q1].to(torch.int64)
-        mine = torch.unique(qc[(qc >= p.own_begin) & (qc < p.own_end)])
-        send.append(mine - p.own_begin)
-        counts.append(int(mine.numel()))
-    p.send_counts = counts
-    p.send_idx = torch.cat(send) if send else torch.zeros(0, dtype=torch.int64, device=dev)
+
+def _finish_send(p, send_lists, dev):
+    """send_lists[q]: sorted LOCAL row ids rank q needs from this rank (empty for q == rank)."""
+    p.send_counts = [int(t.numel()) for t in send_lists]
+    p.send_idx = torch.cat(send_lists) if send_lists else torch.zeros(0, dtype=torch.int64, device=dev)
     # deterministic owner-side reduction of returned halo gradients: row r sums the slots of send_idx equal to r
     n_send = int(p.send_idx.numel())
     if n_send:
@@ -121,6 +100,81 @@ def partition_contiguous(graph, world, rank, bounds=None):
         torch.cumsum(cnt, 0, out=sptr[1:])
         p.send_reduce = CSRGraph(sptr, order.to(torch.int32), None, p.n_own, n_send, check=False)
     return p
+
+
+def partition_contiguous(graph, world, rank, bounds=None):
+    """Row-partition `graph` (the SAME full CSRGraph on every rank) into `world` contiguous blocks and build this
+    rank's Partition with NO setup communication: every rank derives what its peers need from the full graph.  `bounds`
+    (len world+1) overrides the equal-rows split (METIS part boundaries after a relabelling -- partition.bounds_from_book /
+    relabel_by_parts -- or an nnz-balanced split).  For graphs too large to hold everywhere use `partition_rows`."""
+    n = graph.n_rows
+    dev = graph.device
+    if bounds is None:
+        bounds = [(n * r) // world for r in range(world + 1)]
+    p = Partition()
+    p.rank, p.world = rank, world
+    p.own_begin, p.own_end = bounds[rank], bounds[rank + 1]
+    p.n_own = p.own_end - p.own_begin
+    rp = graph.rowptr
+    e0, e1 = int(rp[p.own_begin]), int(rp[p.own_end])
+    val = None if graph.val is None else graph.val[e0:e1]
+    _split_block(p, rp[p.own_begin:p.own_end + 1] - e0, graph.col[e0:e1], val, bounds, dev)
+    # what each peer needs from me: the unique columns of ITS rows that fall in my range (every rank derives this
+    # from the same full graph, so it equals the peer's halo list restricted to my block)
+    send = []
+    for q in range(world):
+        if q == rank:
+            send.append(torch.zeros(0, dtype=torch.int64, device=dev))
+            continue
+        q0, q1 = int(rp[bounds[q]]), int(rp[bounds[q + 1]])
+        qc = graph.col[q0:q1].to(torch.int64)
+        send.append(torch.unique(qc[(qc >= p.own_begin) & (qc < p.own_end)]) - p.own_begin)
+    return _finish_send(p, send, dev)
+
+
+def partition_rows(rowptr, col, val, bounds, rank, group=None):
+    """Build this rank's Partition from ITS OWN ROW BLOCK only: `rowptr` (local, starting at 0) / `col` (GLOBAL ids) / `val`
+    are the CSR rows bounds[rank] .. bounds[rank+1] -- what a rank loads from its own part file.  No rank ever holds the
+    whole adjacency (RMAT-27 would be ~27 GB of indices per rank otherwise).  The send lists come from ONE exchange: every
+    rank tells each owner which of its rows it needs (the halo ids, already unique and sorted), so they are consistent by
+    construction -- there is nothing to `verify()`."""
+    world = len(bounds) - 1
+    dev = rowptr.device
+    p = Partition()
+    p.rank, p.world = rank, world
+    p.own_begin, p.own_end = int(bounds[rank]), int(bounds[rank + 1])
+    p.n_own = p.own_end - p.own_begin
+    if rowptr.numel() != p.n_own + 1:
+        raise ValueError("the row block has %d rows, bounds give %d" % (rowptr.numel() - 1, p.n_own))
+    halo_ids, owner = _split_block(p, rowptr - rowptr[0], col, val, list(bounds), dev)
+    empty = torch.zeros(0, dtype=torch.int64, device=dev)
+    if world == 1:
+        return _finish_send(p, [empty], dev)
+    staged = dist.get_backend(group) != "nccl"                # gloo moves host tensors
+    cdev = torch.device("cpu") if staged else dev
+    mine = torch.tensor(p.recv_counts, dtype=torch.int64, device=cdev)
+    table = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(table, mine, group=group)                 # table[r][q] = rows r needs from q
+    want = [int(table[q][rank]) for q in range(world)]        # rows q needs from me
+    need = [halo_ids[owner == q].to(cdev) for q in range(world)]
+    got = [torch.empty(want[q], dtype=torch.int64, device=cdev) for q in range(world)]
+    opsl = []
+    for q in range(world):
+        if q == rank:
+            continue
+        if need[q].numel():
+            opsl.append(dist.P2POp(dist.isend, need[q], q, group))
+        if want[q]:
+            opsl.append(dist.P2POp(dist.irecv, got[q], q, group))
+    for r in (dist.batch_isend_irecv(opsl) if opsl else []):
+        r.wait()
+    send = []
+    for q in range(world):
+        ids = got[q].to(dev)
+        if ids.numel() and (int(ids.min()) < p.own_begin or int(ids.max()) >= p.own_end):
+            raise RuntimeError("rank %d asked rank %d for rows it does not own (bounds differ between ranks)" % (q, rank))
+        send.append(ids - p.own_begin if q != rank else empty)
+    return _finish_send(p, send, dev)
 
 
 def nnz_balanced_bounds(graph, world):

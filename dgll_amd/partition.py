@@ -1,0 +1,130 @@
+"""Graph-partition ingestion for the multi-GPU path: external partitions -> a relabelled id space + row bounds.
+
+BASELINE config 3 names "METIS partitions".  The reference does not partition in-process; its scripts read what DGL's
+`partition_graph` (METIS) wrote: a partition-book JSON with `num_parts` and, per part, a CONTIGUOUS id range in the
+relabelled id space -- `node_map["_N"][part] = [start, end]` -- and enumerate a part's nodes as
+`torch.arange(start, end)`           (/root/reference/dgll/GPU Accelerator/utils.py:224-255: `load_partition_book`,
+`load_partition`, `part2nids`; `metis` is listed in requirements.txt:5 but is not installable here).
+
+This module supplies the same entry points and the two conversions the engine needs:
+
+  * `load_partition_book(path, graph_name)` / `part2nids(gpb, part_id)`   -- the reference's names and behaviour;
+  * `bounds_from_book(gpb)`                     -> [0, b1, ..., N] row bounds for `dist.partition_rows / _contiguous`;
+  * `relabel_by_parts(part_of_node, n_parts)`   -> (perm, bounds): a raw membership vector (what METIS returns: node -> part)
+    becomes the permutation that makes every part contiguous (stable inside a part) plus the bounds;
+  * `write_partition_book(...)`                 -- writes the JSON subset read above (round trips, tests, hand-over to the
+    reference's scripts);
+  * `community_parts(graph, n_parts)`           -- a partitioner of the engine's own for when no external one is given:
+    label-propagation communities (dgll_amd/reorder.py) packed into `n_parts` bins of equal edge count, largest first.
+    It stands where METIS stands in the reference's pipeline: few cut edges, balanced work.
+"""
+import json
+import os
+
+import torch
+
+
+def load_partition_book(path, graph_name):
+    """utils.py:224-227."""
+    with open("{}/{}.json".format(path, graph_name), "r") as f:
+        return json.load(f)
+
+
+def part2nids(gpb, part_id):
+    """utils.py:251-253: the node ids of a part are its contiguous range."""
+    rng = gpb["node_map"]["_N"][part_id]
+    return torch.arange(rng[0], rng[-1], 1)
+
+
+def bounds_from_book(gpb):
+    """Row bounds [0, ..., N] of the book's parts; raises if the ranges are not a contiguous cover in part order."""
+    ranges = gpb["node_map"]["_N"]
+    if len(ranges) != int(gpb["num_parts"]):
+        raise ValueError("partition book lists %d node ranges for num_parts = %d" % (len(ranges), gpb["num_parts"]))
+    bounds = [int(ranges[0][0])]
+    for p, r in enumerate(ranges):
+        if int(r[0]) != bounds[-1] or int(r[-1]) < int(r[0]):
+            raise ValueError("part %d covers [%d, %d) but the previous part ended at %d" % (p, r[0], r[-1], bounds[-1]))
+        bounds.append(int(r[-1]))
+    if bounds[0] != 0:
+        raise ValueError("the first part must start at node 0")
+    if "num_nodes" in gpb and int(gpb["num_nodes"]) != bounds[-1]:
+        raise ValueError("node ranges end at %d but num_nodes = %d" % (bounds[-1], gpb["num_nodes"]))
+    return bounds
+
+
+def write_partition_book(path, graph_name, bounds, num_edges=None, extra=None):
+    """The JSON DGL's partition_graph writes, restricted to the keys the reference reads (+ num_nodes / num_edges)."""
+    os.makedirs(path, exist_ok=True)
+    book = {"graph_name": graph_name, "num_parts": len(bounds) - 1, "num_nodes": int(bounds[-1]),
+            "node_map": {"_N": [[int(bounds[p]), int(bounds[p + 1])] for p in range(len(bounds) - 1)]},
+            "part_method": "metis", "halo_hops": 1}
+    if num_edges is not None:
+        book["num_edges"] = int(num_edges)
+    if extra:
+        book.update(extra)
+    for p in range(len(bounds) - 1):
+        book["part-%d" % p] = {"part_graph": "part%d/graph.bin" % p}
+    with open(os.path.join(path, graph_name + ".json"), "w") as f:
+        json.dump(book, f)
+    return book
+
+
+def relabel_by_parts(part_of_node, n_parts=None):
+    """Membership vector (node -> part, any integer dtype) -> (perm, bounds): new node i is old node perm[i]; part p owns the
+    new ids [bounds[p], bounds[p+1]).  Stable: nodes of a part keep their relative order (DGL's relabelling does the same)."""
+    part = part_of_node.to(torch.int64)
+    if part.dim() != 1:
+        raise ValueError("the membership vector must be 1-D")
+    n_parts = (int(part.max()) + 1 if part.numel() else 0) if n_parts is None else int(n_parts)
+    if part.numel() and (int(part.min()) < 0 or int(part.max()) >= n_parts):
+        raise ValueError("part ids must lie in [0, %d)" % n_parts)
+    perm = torch.sort(part, stable=True)[1]
+    counts = torch.bincount(part, minlength=n_parts)
+    bounds = [0] + torch.cumsum(counts, 0).tolist()
+    return perm, bounds
+
+
+def community_parts(graph, n_parts, seed=0, sweeps=8):
+    """node -> part for a square CSRGraph: communities found by label propagation, packed largest-first into the part
+    with the fewest edges so far (longest-processing-time bin packing on the communities' edge counts).  Communities larger
+    than a fair share are split by node order so that no part exceeds it by more than one community's worth."""
+    from . import reorder
+
+    if graph.n_rows != graph.n_cols:
+        raise ValueError("partitioning needs a square adjacency")
+    n = graph.n_rows
+    labels = reorder.label_propagation(graph.rowptr, graph.col, n, sweeps=sweeps, seed=seed)
+    _, dense = torch.unique(labels, return_inverse=True)
+    deg = graph.degrees()
+    n_comm = int(dense.max()) + 1 if n else 0
+    work = torch.zeros(n_comm, dtype=torch.int64, device=deg.device).index_add_(0, dense, deg + 1)   # +1: isolated nodes count
+    order = torch.argsort(work, descending=True, stable=True).tolist()
+    work_l = work.tolist()
+    fair = (sum(work_l) + n_parts - 1) // max(n_parts, 1)
+    load = [0] * n_parts
+    part_of_comm = [0] * n_comm
+    split = []                                       # communities bigger than a fair share: dealt out node by node below
+    for c in order:
+        if work_l[c] > fair:
+            split.append(c)
+            continue
+        p = min(range(n_parts), key=lambda q: (load[q], q))
+        part_of_comm[c] = p
+        load[p] += work_l[c]
+    part = torch.tensor(part_of_comm, dtype=torch.int64, device=deg.device)[dense]
+    for c in split:                                  # cut an oversized community into runs that top the lightest parts up
+        nodes = torch.nonzero(dense == c).flatten()
+        w = (deg[nodes] + 1).cumsum(0)
+        start, done = 0, 0
+        while start < nodes.numel():
+            p = min(range(n_parts), key=lambda q: (load[q], q))
+            room = max(fair - load[p], (work_l[c] + n_parts - 1) // n_parts)
+            end = int(torch.searchsorted(w, torch.tensor(done + room, device=w.device), right=True))
+            end = min(max(end, start + 1), nodes.numel())
+            part[nodes[start:end]] = p
+            took = int(w[end - 1]) - done
+            load[p] += took
+            done += took
+            start = end
+    return part

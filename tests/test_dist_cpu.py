@@ -138,3 +138,49 @@ def test_partition_covers_every_edge_once():
         assert (int(p.local.col.max()) if p.local.nnz else -1) < p.n_own              # owned-column half
         assert (int(p.halo.col.max()) if p.halo.nnz else -1) < p.n_halo              # halo-column half
         assert p.inv_deg.shape == (p.n_own,)
+
+
+def _rows_worker(rank, world, port):
+    """partition_rows: every rank holds ONLY its own row block; the send lists come from one exchange of halo ids."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dgll_amd import dist as ddist
+        from dgll_amd import synth
+
+        full = synth.products_like_graph("cpu", seed=2, n=900, n_undirected=7000, locality=0.7, n_blocks=6, exact=True)
+        bounds = ddist.nnz_balanced_bounds(full, world)
+        want = ddist.partition_contiguous(full, world, rank, bounds)          # the all-ranks-hold-everything construction
+        e0, e1 = int(full.rowptr[bounds[rank]]), int(full.rowptr[bounds[rank + 1]])
+        rowptr = full.rowptr[bounds[rank]:bounds[rank + 1] + 1].clone()       # NOT rebased: partition_rows does it
+        col = full.col[e0:e1].clone()
+        del full
+        got = ddist.partition_rows(rowptr, col, None, bounds, rank)
+        for name in ("n_own", "n_halo", "nnz", "recv_counts", "send_counts"):
+            assert getattr(got, name) == getattr(want, name), name
+        assert torch.equal(got.send_idx, want.send_idx)
+        for a, b in ((got.local, want.local), (got.halo, want.halo), (got.send_reduce, want.send_reduce)):
+            assert torch.equal(a.rowptr, b.rowptr) and torch.equal(a.col, b.col)
+        assert torch.equal(got.inv_deg, want.inv_deg)
+        engine = ddist.DistGraph(got, "cpu", spmm_fn=_cpu_spmm)
+        engine.verify()                                                        # still passes (lists are consistent by construction)
+        x = torch.randn(got.n_own, 6, dtype=torch.float64, generator=torch.Generator().manual_seed(rank))
+        y_rows = engine.aggregate(x, reduce="mean")
+        y_full = ddist.DistGraph(want, "cpu", spmm_fn=_cpu_spmm).aggregate(x, reduce="mean")
+        assert torch.equal(y_rows, y_full)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_partition_from_own_row_block_equals_the_full_graph_construction(world):
+    mp.spawn(_rows_worker, args=(world, _free_port()), nprocs=world, join=True)
+
+
+def test_partition_rows_single_rank_needs_no_process_group():
+    from dgll_amd import dist as ddist
+    from dgll_amd import synth
+
+    g = synth.rmat_graph(7, 5, seed=1, device="cpu", symmetric=True, weighted=False)
+    p = ddist.partition_rows(g.rowptr, g.col, None, [0, g.n_rows], 0)
+    assert p.n_halo == 0 and p.local.nnz == g.nnz and p.send_counts == [0]

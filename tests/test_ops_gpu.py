@@ -308,7 +308,7 @@ def test_segment_max_backward_kernel_routes_the_gradient_to_the_argmax_row(cuda_
     y = ops.segment_max(g, xd)
     (y.float() * w.to(cuda_device)).sum().backward()
     # CPU reference: per row, max over the listed source rows (first arg-max = lowest source id, as the kernel)
-    xr = x.float().requires_grad_(True)
+    xr = x.float().clone().requires_grad_(True)
     rows = []
     for i in range(len(rowptr) - 1):
         c = np.unique(col[rowptr[i]:rowptr[i + 1]])
