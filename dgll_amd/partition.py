@@ -85,7 +85,24 @@ def relabel_by_parts(part_of_node, n_parts=None):
     return perm, bounds
 
 
-def community_parts(graph, n_parts, seed=0, sweeps=8):
+def partition_and_order(graph, n_parts, seed=0, sweeps=8):
+    """(perm, bounds) for the multi-GPU engine in one pass: parts from `community_parts`, and inside every part the
+    locality order of dgll_amd/reorder.py (communities contiguous, largest first; hubs first inside a community).  New node
+    i is old node perm[i]; part p owns [bounds[p], bounds[p+1])."""
+    part, dense = community_parts(graph, n_parts, seed=seed, sweeps=sweeps, return_communities=True)
+    n = graph.n_rows
+    deg = graph.degrees()
+    dmax = int(deg.max()) + 1 if n else 1
+    ids = torch.arange(n, device=deg.device)
+    # three stable sorts, least significant key first: (degree descending, id) -> community -> part
+    order = torch.argsort((dmax - 1 - deg) * n + ids)
+    order = order[torch.argsort(dense[order], stable=True)]
+    order = order[torch.argsort(part[order], stable=True)]
+    counts = torch.bincount(part, minlength=n_parts)
+    return order, [0] + torch.cumsum(counts, 0).tolist()
+
+
+def community_parts(graph, n_parts, seed=0, sweeps=8, return_communities=False):
     """node -> part for a square CSRGraph: communities found by label propagation, packed largest-first into the part
     with the fewest edges so far (longest-processing-time bin packing on the communities' edge counts).  Communities larger
     than a fair share are split by node order so that no part exceeds it by more than one community's worth."""
@@ -95,7 +112,10 @@ def community_parts(graph, n_parts, seed=0, sweeps=8):
         raise ValueError("partitioning needs a square adjacency")
     n = graph.n_rows
     labels = reorder.label_propagation(graph.rowptr, graph.col, n, sweeps=sweeps, seed=seed)
-    _, dense = torch.unique(labels, return_inverse=True)
+    _, dense, size = torch.unique(labels, return_inverse=True, return_counts=True)
+    rank = torch.empty_like(size)                    # communities numbered largest first (as reorder.locality_order)
+    rank[torch.argsort(size, descending=True, stable=True)] = torch.arange(size.numel(), device=size.device)
+    dense = rank[dense]
     deg = graph.degrees()
     n_comm = int(dense.max()) + 1 if n else 0
     work = torch.zeros(n_comm, dtype=torch.int64, device=deg.device).index_add_(0, dense, deg + 1)   # +1: isolated nodes count
@@ -127,4 +147,4 @@ def community_parts(graph, n_parts, seed=0, sweeps=8):
             load[p] += took
             done += took
             start = end
-    return part
+    return (part, dense) if return_communities else part

@@ -15,7 +15,7 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
-from dgll_amd import dist as ddist, nn as dnn, ops, synth  # noqa: E402
+from dgll_amd import dist as ddist, nn as dnn, ops, partition as dpart, reorder as dreorder, synth  # noqa: E402
 
 
 class NullExchange:
@@ -38,19 +38,22 @@ class NullExchange:
 
 def main():
     dev = torch.device("cuda:0")
-    full = synth.products_like_graph(dev, seed=0, locality=0.9)
-    n, nnz = full.n_rows, full.nnz
+    raw = synth.products_like_graph(dev, seed=0, locality=0.9, exact=True, permute_ids=True)     # bench.py's default graph
+    n, nnz = raw.n_rows, raw.nnz
     gen = torch.Generator(device=dev)
     gen.manual_seed(1)
     feats = torch.randn(n, 100, generator=gen, device=dev)
     labels_all = torch.randint(0, 47, (n,), generator=gen, device=dev)
-    single_ms = float(os.environ.get("SINGLE_MS", "24.1"))
+    single_ms = float(os.environ.get("SINGLE_MS", "24.1"))      # bench.py --gpus 1 on the same box
     print("single-process step (bench.py): %.1f ms" % single_ms)
     for world in (2, 4, 8):
         torch.manual_seed(0)
         model = dnn.GraphSage(100, [256, 256, 47], None).to(dev)
         opt = torch.optim.Adam(model.parameters(), lr=1e-3)
-        part = ddist.partition_contiguous(full, world, 0)
+        perm, bounds = dpart.partition_and_order(raw, world, seed=0)        # as bench.py: communities packed into parts
+        full = dreorder.relabel(raw, perm)
+        part = ddist.partition_contiguous(full, world, 0, bounds)
+        del full
         engine = ddist.DistGraph(part, dev)
         engine.exchange = NullExchange(part)
         x = ops.alloc_features(part.n_own, 100, torch.bfloat16, dev, pad_to=64)

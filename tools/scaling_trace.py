@@ -7,16 +7,19 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 from torch.profiler import ProfilerActivity, profile  # noqa: E402
 
-from dgll_amd import dist as ddist, nn as dnn, ops, synth  # noqa: E402
+from dgll_amd import dist as ddist, nn as dnn, ops, partition as dpart, reorder as dreorder, synth  # noqa: E402
 from scaling_model import NullExchange  # noqa: E402
 
 world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 dev = torch.device("cuda:0")
-full = synth.products_like_graph(dev, seed=0, locality=0.9)
-n = full.n_rows
+raw = synth.products_like_graph(dev, seed=0, locality=0.9, exact=True, permute_ids=True)
+n = raw.n_rows
+perm, bounds = dpart.partition_and_order(raw, world, seed=0)
+full = dreorder.relabel(raw, perm)
+del raw
 model = dnn.GraphSage(100, [256, 256, 47], None).to(dev)
 opt = torch.optim.Adam(model.parameters(), lr=1e-3)
-part = ddist.partition_contiguous(full, world, 0)
+part = ddist.partition_contiguous(full, world, 0, bounds)
 engine = ddist.DistGraph(part, dev)
 engine.exchange = NullExchange(part)
 x = ops.alloc_features(part.n_own, 100, torch.bfloat16, dev, pad_to=64)
