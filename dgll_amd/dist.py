@@ -689,7 +689,13 @@ class RaCoM:
     stream, averaged and copied back into .grad; `all_reduce_and_wait` is the synchronous form (identical to DDP),
     `launch` / `wait` let the caller overlap the reduction with other work."""
 
-    def __init__(self, params, device, group=None):
+    def __init__(self, params, device, group=None, average="reference"):
+        """average: "reference" = all-reduce SUM, then divide by world_size (MQGCN.py:61-64); "ddp" = divide, then
+        all-reduce SUM (torch DDP's order).  The two are bit-identical whenever world_size is a power of two -- every
+        configuration BASELINE names (1/2/4/8 GPUs) -- and differ in the last bit otherwise."""
+        if average not in ("reference", "ddp"):
+            raise ValueError("average must be 'reference' or 'ddp'")
+        self.average = average
         self.params = [p for p in params if p.requires_grad]
         self.device = torch.device(device)
         self.group = group
@@ -708,6 +714,8 @@ class RaCoM:
             self.bucket[off:off + n].copy_(g.reshape(-1))
             off += n
         self._views = views
+        if self.world > 1 and self.average == "ddp":
+            self.bucket.div_(self.world)
         if self.world > 1:
             if self.stream is not None:
                 self.stream.wait_stream(torch.cuda.current_stream(self.device))
@@ -722,7 +730,7 @@ class RaCoM:
             self._work = None
         if self.stream is not None:
             torch.cuda.current_stream(self.device).wait_stream(self.stream)
-        if self.world > 1:
+        if self.world > 1 and self.average == "reference":
             self.bucket.div_(self.world)                      # MQGCN.py:64
         for p, off, n in self._views:
             if p.grad is None:
@@ -756,8 +764,9 @@ class RaCoMOptimizer:
     flush()) the queue is drained so replicas re-converge.  staleness = 0 is the reference's actual (synchronous)
     behaviour, MQGCN.py:55-79, and equals DDP."""
 
-    def __init__(self, optimizer, params, device, staleness=1, sync_every=8, group=None):
+    def __init__(self, optimizer, params, device, staleness=1, sync_every=8, group=None, average="reference"):
         self.opt = optimizer
+        self.average = average
         self.params = [p for p in params if p.requires_grad]
         self.device, self.group = torch.device(device), group
         self.staleness, self.sync_every = int(staleness), int(sync_every)
@@ -766,7 +775,7 @@ class RaCoMOptimizer:
         self.steps = 0
 
     def _bucket(self):
-        return self.free.pop() if self.free else RaCoM(self.params, self.device, self.group)
+        return self.free.pop() if self.free else RaCoM(self.params, self.device, self.group, average=self.average)
 
     def _apply_oldest(self):
         r = self.pending.pop(0)

@@ -184,3 +184,57 @@ def test_partition_rows_single_rank_needs_no_process_group():
     g = synth.rmat_graph(7, 5, seed=1, device="cpu", symmetric=True, weighted=False)
     p = ddist.partition_rows(g.rowptr, g.col, None, [0, g.n_rows], 0)
     assert p.n_halo == 0 and p.local.nnz == g.nnz and p.send_counts == [0]
+
+
+def _ddp_worker(rank, world, port):
+    """RaCoM with staleness 0 (sync period 1) must equal DistributedDataParallel bit for bit (SURVEY 8 f3;
+    reference semantics avg = sum of grads / world_size, MQGCN.py:55-79)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from torch.nn.parallel import DistributedDataParallel as DDP
+
+        from dgll_amd import dist as ddist
+
+        def make():
+            torch.manual_seed(11)                                    # identical initial replicas
+            return torch.nn.Sequential(torch.nn.Linear(8, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3))
+
+        gen = torch.Generator().manual_seed(100 + rank)              # every rank sees different data
+        data = [(torch.randn(16, 8, generator=gen), torch.randint(0, 3, (16,), generator=gen)) for _ in range(5)]
+        ref_model = make()
+        ddp = DDP(ref_model)
+        ref_opt = torch.optim.SGD(ddp.parameters(), lr=0.1, momentum=0.9)
+        model = make()
+        base = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9)
+        # Two ranks: one addition per element, so the reduction order is the same whatever the transport does, and the
+        # reference's "sum, then / world_size" equals DDP's "divide, then sum" exactly (division by 2 is exact): bit-equal.
+        # More ranks: the all-reduce itself adds the ranks in an order that depends on where an element sits in the buffer
+        # (ring chunks), and DDP lays its bucket out differently from RaCoM's flat parameter order -- the same reduction in a
+        # different association: equal to rounding.
+        pow2 = world == 2
+        opt = ddist.RaCoMOptimizer(base, model.parameters(), "cpu", staleness=0, sync_every=1,
+                                   average="reference" if world & (world - 1) == 0 else "ddp")
+        for x, y in data:
+            ref_opt.zero_grad()
+            torch.nn.functional.cross_entropy(ddp(x), y).backward()
+            ref_opt.step()
+            opt.zero_grad()
+            torch.nn.functional.cross_entropy(model(x), y).backward()
+            opt.step()
+            for a, b in zip(ref_model.parameters(), model.parameters()):
+                if pow2:
+                    assert torch.equal(a, b), "RaCoM(staleness=0) diverged from DDP"
+                else:
+                    torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-7)
+        # and the documented rule for the sync period (README.md:35: "based on graph size and GPU count")
+        assert ddist.racom_sync_period(2_449_029, 8) == 2 and ddist.racom_sync_period(2_449_029, 2) == 8
+        assert ddist.racom_sync_period(134_217_728, 8) == 14 and ddist.racom_sync_period(1000, 8) == 2
+        assert ddist.racom_sync_period(10 ** 12, 1) == 64
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4, 3])
+def test_racom_sync_form_equals_ddp_bit_for_bit(world):
+    mp.spawn(_ddp_worker, args=(world, _free_port()), nprocs=world, join=True)

@@ -19,7 +19,8 @@ def main():
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
-    g = synth.products_like_graph(dev, seed=0, n=args.nodes, n_undirected=args.edges, locality=args.locality)
+    g = synth.products_like_graph(dev, seed=0, n=args.nodes, n_undirected=args.edges, locality=args.locality, exact=True,
+                                  permute_ids=True).reorder(seed=0)[0]          # bench.py's default workload
     n = g.n_rows
     model = dnn.GraphSage(100, [256, 256, 47], None).to(dev)
     x = ops.alloc_features(n, 100, torch.bfloat16, dev, pad_to=64)
