@@ -57,6 +57,50 @@ class GraphCacheServer:
             cache_nid = sort_nid[:self.capability]
             self.cache_fix_data(cache_nid, self.get_feat_from_server(cache_nid), is_full=False)
 
+    # ---- global neighbour-sampling cache (README.md:27-29: "global neighbor sampling with caching") ---------------------
+    def global_sampling_cache(self, weights, capacity=None, seed=0, reserve_bytes=1 << 30):
+        """Populate the cache with a GLOBAL SAMPLE of the nodes instead of the static top-degree set: `capacity` nodes
+        drawn without replacement with probability proportional to `weights` (out-degrees: the chance that a neighbour
+        sampler reaches a node grows with its degree; any importance vector works).  Re-drawing periodically (`refresh`)
+        rotates the tail of the distribution through the cache while the hubs stay in with near certainty.  The sampled ids
+        of the mini-batches are NOT biased by the cache (they stay bit-identical to the reference sampler's)."""
+        if capacity is None:
+            free, _total = torch.cuda.mem_get_info(self.device)
+            capacity = max(int((free - reserve_bytes) // (self.total_dim * self.features.element_size())), 0)
+        self.capability = int(min(capacity, self.node_num))
+        self._gs_weights = weights.to(self.device, dtype=torch.float32).clamp(min=0) + 1e-12
+        self._gs_gen = torch.Generator(device=self.device)
+        self._gs_gen.manual_seed(seed)
+        self.refresh()
+
+    def refresh(self):
+        """Draw a new global sample (weighted, without replacement: Gumbel top-k on the device) and install it."""
+        if self.capability >= self.node_num:
+            full = torch.arange(self.node_num, device=self.device)
+            return self.cache_fix_data(full, self.get_feat_from_server(full), is_full=True)
+        u = torch.rand(self.node_num, generator=self._gs_gen, device=self.device).clamp_(min=1e-20)
+        keys = torch.log(self._gs_weights) - torch.log(-torch.log(u))        # Gumbel-max: top-k == weighted sample w/o replacement
+        nids = torch.topk(keys, self.capability).indices
+        self.cache_fix_data(nids, self.get_feat_from_server(nids), is_full=False)
+
+    def record_access(self, nids, stream=None):
+        """Accumulate how often every node is fetched (device-side, no host sync) for `refresh_from_access`."""
+        stream = torch.cuda.current_stream(self.device) if stream is None else stream
+        with torch.cuda.stream(stream):
+            if getattr(self, "_access", None) is None:
+                self._access = torch.zeros(self.node_num, dtype=torch.int64, device=self.device)
+            nids = nids.to(self.device, dtype=torch.int64, non_blocking=True)
+            self._access.index_add_(0, nids, torch.ones_like(nids))
+
+    def refresh_from_access(self, decay=0.5):
+        """Re-populate the cache with the nodes fetched most often since the last refresh (the empirical version of the global
+        sample: it follows the training set's actual neighbourhood distribution); counts are decayed, not cleared."""
+        if getattr(self, "_access", None) is None or self.capability >= self.node_num:
+            return
+        nids = torch.topk(self._access, self.capability).indices
+        self.cache_fix_data(nids, self.get_feat_from_server(nids), is_full=False)
+        self._access = (self._access.to(torch.float64) * decay).to(torch.int64)
+
     def get_feat_from_server(self, nids, to_gpu=False):
         """Rows of the host feature store for local ids `nids` (storage.py:100-125)."""
         full = nids if self.nid_map is None else self.nid_map[nids]

@@ -13,12 +13,81 @@ from HBM, misses over PCIe from pinned memory), records an event and fills the s
 on the event from its compute stream.  Sampling of batch i+2, loading of batch i+1 and training on batch i overlap.  The end of the epoch is signalled with a sentinel
 (buffer_queues.py:43-46 sets a flag under the Condition).
 """
-import queue
 import threading
+import time
 
 import torch
 
 _DONE = object()
+
+
+class AdaptiveQueue:
+    """Bounded FIFO whose bound moves with the balance between its producer and its consumer -- README.md:29's "adaptive
+    queue-sizing strategy to balance computation and memory efficiency" (the reference's code keeps BUFFER_SIZE = 4,
+    MQGCN.py:98).  Every `window` items the queue looks at how long the consumer sat starved (get() found it empty) and how
+    long the producer sat blocked (put() found it full):
+      * the consumer starved for more than 5 % of the window  -> double the bound (up to `max_size`): more run-ahead hides
+        the producer's jitter (a hub-heavy batch takes several times the median to sample and load);
+      * the consumer never starved and the producer was blocked for more than half of the window -> shrink by one (down to
+        `min_size`): the depth beyond what keeps the consumer busy is memory held for nothing.
+    `max_size` is a MEMORY bound: MiniBatchPipeline sets it from the bytes of a loaded batch against a budget of device
+    memory (set_memory_bound)."""
+
+    def __init__(self, size=4, min_size=2, max_size=64, window=8, adaptive=True):
+        self.size, self.min_size, self.max_size, self.window, self.adaptive = int(size), int(min_size), int(max_size), int(window), adaptive
+        self._items = []
+        self._cv = threading.Condition()
+        self._starved = self._blocked = 0.0
+        self._t_window = time.perf_counter()
+        self._count = 0
+        self.history = [int(size)]          # the bound after every adjustment (diagnostics / tests)
+
+    def set_memory_bound(self, batch_bytes, budget_bytes):
+        with self._cv:
+            if batch_bytes > 0:
+                self.max_size = max(self.min_size, min(self.max_size, int(budget_bytes // batch_bytes)))
+                if self.size > self.max_size:
+                    self.size = self.max_size
+                    self.history.append(self.size)
+
+    def put(self, item):
+        with self._cv:
+            t0 = time.perf_counter()
+            while len(self._items) >= self.size:
+                self._cv.wait()
+            self._blocked += time.perf_counter() - t0
+            self._items.append(item)
+            self._cv.notify_all()
+
+    def get(self):
+        with self._cv:
+            t0 = time.perf_counter()
+            while not self._items:
+                self._cv.wait()
+            self._starved += time.perf_counter() - t0
+            item = self._items.pop(0)
+            self._count += 1
+            if self.adaptive and self._count % self.window == 0:
+                self._adapt()
+            self._cv.notify_all()
+            return item
+
+    def _adapt(self):
+        now = time.perf_counter()
+        span = max(now - self._t_window, 1e-9)
+        starved, blocked = self._starved / span, self._blocked / span
+        if starved > 0.05 and self.size < self.max_size:
+            self.size = min(self.size * 2, self.max_size)
+            self.history.append(self.size)
+        elif starved == 0.0 and blocked > 0.5 and self.size > self.min_size:
+            self.size -= 1
+            self.history.append(self.size)
+        self._starved = self._blocked = 0.0
+        self._t_window = now
+
+    def qsize(self):
+        with self._cv:
+            return len(self._items)
 
 
 class Batch:
@@ -30,14 +99,21 @@ class Batch:
 
 
 class MiniBatchPipeline:
-    def __init__(self, dataloader, cache=None, labels=None, queue_size=4, device="cuda", hops=None):
+    def __init__(self, dataloader, cache=None, labels=None, queue_size=4, device="cuda", hops=None, memory_fraction=0.1,
+                 record_access=False):
         """dataloader: dgll_amd.dataloader.DataLoader; cache: GraphCacheServer (None: features come from
         dataloader.Dgraph.get_features on the host and are copied); hops: optional callable batch -> list of id tensors
-        whose features are needed (default: the input nodes only, graphage.py:52)."""
+        whose features are needed (default: the input nodes only, graphage.py:52).
+        queue_size: an int fixes the bound of the loaded-batch queue (MQGCN.py:98 uses 4); "auto" starts at 4 and lets it
+        adapt (AdaptiveQueue), never holding more loaded batches than fit in `memory_fraction` of the free device memory.
+        record_access: feed the cache's access counters (GraphCacheServer.refresh_from_access)."""
         self.dataloader, self.cache, self.labels = dataloader, cache, labels
         self.device = torch.device(device)
-        self.queue = queue.Queue(maxsize=queue_size)              # MQGCN.py:98 BUFFER_SIZE  (loaded batches)
-        self.sampled = queue.Queue(maxsize=2)                     # sampled, not yet loaded: a short hand-over queue
+        adaptive = queue_size == "auto"
+        self.queue = AdaptiveQueue(4 if adaptive else int(queue_size), adaptive=adaptive)      # loaded batches
+        self.sampled = AdaptiveQueue(2, adaptive=False)           # sampled, not yet loaded: a short hand-over queue
+        self.memory_fraction, self.record_access = memory_fraction, record_access
+        self._memory_bound_set = False
         self.hops = hops
         self.load_stream = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None   # d_stream
         self._thread = None
@@ -73,6 +149,11 @@ class MiniBatchPipeline:
                             b.labels = self.labels[outp].to(self.device, non_blocking=True)
                         b.ready = torch.cuda.Event()
                         b.ready.record(self.load_stream)
+                    if not self._memory_bound_set:          # first loaded batch: how many of these fit in the memory budget
+                        self._memory_bound_set = True
+                        nbytes = sum(t.numel() * t.element_size() for t in b.features)
+                        free, _total = torch.cuda.mem_get_info(self.device)
+                        self.queue.set_memory_bound(nbytes, self.memory_fraction * free)
                 else:
                     b.features = [self._fetch(ids) for ids in id_lists]
                     if self.labels is not None:
@@ -87,6 +168,8 @@ class MiniBatchPipeline:
 
     def _fetch(self, ids):
         if self.cache is not None:
+            if self.record_access:
+                self.cache.record_access(ids, stream=self.load_stream)
             return self.cache.fetch_data(ids, stream=self.load_stream)
         feats = self.dataloader.Dgraph.get_features(ids)
         return feats.to(self.device, non_blocking=True)

@@ -105,3 +105,93 @@ def test_cache_with_nid_map_and_pipeline_on_gpu(cuda_device):
     srv2.auto_cache(torch.arange(n), capacity=50)
     ids = torch.randint(0, n, (500,), device=cuda_device)
     assert torch.equal(srv2.fetch_data(ids).cpu(), feats[perm[ids.cpu()]])
+
+
+def test_adaptive_queue_grows_when_the_consumer_starves_and_shrinks_when_the_producer_idles():
+    """README.md:29 "adaptive queue-sizing strategy to balance computation and memory efficiency"."""
+    from dgll_amd.pipeline import AdaptiveQueue
+
+    # (a) bursty producer (a slow item every few), fast consumer -> the consumer starves -> the bound doubles, up to the cap
+    q = AdaptiveQueue(size=2, min_size=2, max_size=16, window=4)
+
+    def produce(n, slow_every, slow, fast):
+        for i in range(n):
+            time.sleep(slow if i % slow_every == 0 else fast)
+            q.put(i)
+        q.put(None)
+
+    t = threading.Thread(target=produce, args=(40, 5, 0.03, 0.0))
+    t.start()
+    got = []
+    while True:
+        item = q.get()
+        if item is None:
+            break
+        got.append(item)
+        time.sleep(0.004)
+    t.join()
+    assert got == list(range(40))                       # FIFO, nothing lost
+    assert max(q.history) > 2 and max(q.history) <= 16
+
+    # (b) fast producer, slow consumer -> never starved, producer blocked most of the time -> shrinks towards min_size
+    q = AdaptiveQueue(size=8, min_size=2, max_size=16, window=4)
+    t = threading.Thread(target=produce, args=(48, 10 ** 9, 0.0, 0.0))
+    t.start()
+    n = 0
+    while q.get() is not None:
+        n += 1
+        time.sleep(0.003)
+    t.join()
+    assert n == 48 and q.history[-1] < 8 and min(q.history) >= 2
+
+    # (c) the memory bound caps the growth: 10 batches of this size fit the budget
+    q = AdaptiveQueue(size=4, max_size=64)
+    q.set_memory_bound(batch_bytes=100, budget_bytes=1000)
+    assert q.max_size == 10
+    q.set_memory_bound(batch_bytes=1000, budget_bytes=1500)      # not even two fit: the floor is min_size
+    assert q.max_size == 2 and q.size == 2
+
+    # (d) a fixed bound never moves
+    q = AdaptiveQueue(size=3, adaptive=False, window=2)
+    for i in range(3):
+        q.put(i)
+    assert [q.get() for _ in range(3)] == [0, 1, 2] and q.history == [3]
+
+
+@pytest.mark.gpu
+def test_global_sampling_cache_and_access_driven_refresh(cuda_device):
+    """README.md:27-29 "global neighbor sampling with caching": the cache holds a weighted global sample of the nodes
+    (re-drawn by refresh()), or the nodes fetched most often; whatever it holds, fetch_data == features[ids]."""
+    from dgll_amd.cache import GraphCacheServer
+
+    n, dim, cap = 20000, 64, 2000
+    torch.manual_seed(2)
+    feats = torch.randn(n, dim).to(torch.bfloat16)
+    deg = torch.cat([torch.full((200,), 5000), torch.randint(1, 30, (n - 200,))])      # 200 hubs, then a light tail
+    srv = GraphCacheServer(feats, gpuid=0)
+    srv.log = True
+    srv.global_sampling_cache(deg, capacity=cap, seed=1)
+    assert srv.cached_num == cap and not srv.full_cached
+    flag = srv.gpu_flag.cpu()
+    assert int(flag[:200].sum()) >= 195                      # a hub is ~400x likelier than a tail node: (almost) all are in
+    assert int(flag[200:].sum()) >= cap - 200                # the rest of the capacity is a sample of the tail
+    ids = torch.randint(0, n, (5000,))
+    assert torch.equal(srv.fetch_data(ids.cuda()).cpu(), feats[ids])
+    first = flag.clone()
+    srv.refresh()                                            # a new draw: the tail rotates, hubs stay
+    second = srv.gpu_flag.cpu()
+    assert int((first & second)[:200].sum()) >= 190 and int((first ^ second).sum()) > 1000
+    assert torch.equal(srv.fetch_data(ids.cuda()).cpu(), feats[ids])
+    # access-driven refresh: nodes 10000..10999 are fetched over and over -> they all move into the cache
+    hot = torch.arange(10000, 11000)
+    for _ in range(3):
+        srv.record_access(hot.cuda())
+    srv.record_access(ids.cuda())
+    srv.refresh_from_access()
+    assert bool(srv.gpu_flag[hot.cuda()].all())
+    srv.get_miss_rate()
+    got = srv.fetch_data(hot.cuda())
+    assert torch.equal(got.cpu(), feats[hot]) and srv.get_miss_rate() == 0.0
+    # capacity >= node count: everything cached
+    srv.global_sampling_cache(deg, capacity=n)
+    assert srv.full_cached
