@@ -52,19 +52,21 @@ class AdaptiveQueue:
 
     def put(self, item):
         with self._cv:
-            t0 = time.perf_counter()
-            while len(self._items) >= self.size:
-                self._cv.wait()
-            self._blocked += time.perf_counter() - t0
+            if len(self._items) >= self.size:
+                t0 = time.perf_counter()
+                while len(self._items) >= self.size:
+                    self._cv.wait()
+                self._blocked += time.perf_counter() - t0
             self._items.append(item)
             self._cv.notify_all()
 
     def get(self):
         with self._cv:
-            t0 = time.perf_counter()
-            while not self._items:
-                self._cv.wait()
-            self._starved += time.perf_counter() - t0
+            if not self._items:
+                t0 = time.perf_counter()
+                while not self._items:
+                    self._cv.wait()
+                self._starved += time.perf_counter() - t0
             item = self._items.pop(0)
             self._count += 1
             if self.adaptive and self._count % self.window == 0:
