@@ -69,6 +69,9 @@ def parse_args(argv=None):
     ap.add_argument("--calibrate", action="store_true",
                     help="launch the known-byte identity gather 3 times before the timed steps (PMC calibration rows)")
     ap.add_argument("--cpu-sample-rows", type=int, default=400_000)
+    ap.add_argument("--dataset", default=None,
+                    help="run a REAL dataset instead of the synthetic graph when its files are present: a .npz edge-list dump, a "
+                         "directory with reddit_data.npz / reddit_graph.npz, or an OGB raw directory (dgll_amd/data/formats.py)")
     return ap.parse_args(argv)
 
 
@@ -211,14 +214,25 @@ def main():
     torch.manual_seed(args.seed)
 
     # ---- workload: the same seeded graph on every rank -------------------------------------------------
-    full = synth.products_like_graph(dev, seed=args.seed, n=args.nodes, n_undirected=args.undirected_edges,
-                                     locality=args.locality, exact=not args.inexact_edges, permute_ids=not args.no_permute)
-    n, nnz = full.n_rows, full.nnz
     gen = torch.Generator(device=dev)
     gen.manual_seed(args.seed + 1)
+    if args.dataset:
+        from dgll_amd.data import formats
+
+        dg = formats.load_node_dataset(args.dataset, symmetrise=True) if not os.path.exists(os.path.join(args.dataset, "reddit_data.npz")) \
+            else formats.load_node_dataset(args.dataset)
+        full = dg.to_csr(dev)
+        feats_all = dg.features.to(dev)
+        labels_all = dg.labels.to(dev).long()
+        args.nodes, args.in_feats, args.classes = full.n_rows, int(feats_all.shape[1]), int(labels_all.max()) + 1
+        del dg
+    else:
+        full = synth.products_like_graph(dev, seed=args.seed, n=args.nodes, n_undirected=args.undirected_edges,
+                                         locality=args.locality, exact=not args.inexact_edges, permute_ids=not args.no_permute)
+        labels_all = torch.randint(0, args.classes, (full.n_rows,), generator=gen, device=dev)
+        feats_all = torch.randn(full.n_rows, args.in_feats, generator=gen, device=dev)
+    n, nnz = full.n_rows, full.nnz
     model = dnn.GraphSage(args.in_feats, [args.hidden, args.hidden, args.classes], None).to(dev)
-    labels_all = torch.randint(0, args.classes, (n,), generator=gen, device=dev)
-    feats_all = torch.randn(n, args.in_feats, generator=gen, device=dev)
 
     # ---- the engine's one-off locality pass (outside the timed steps, like a METIS relabelling) -----------
     reorder_s = 0.0
@@ -399,7 +413,7 @@ def main():
         "metric": "aggregated edges/sec + epoch time, 3-layer GraphSAGE ogbn-products, 1/2/4/8 GPU",
         "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": args.dtype, "data": "synthetic",
+        "dtype": args.dtype, "data": ("real: " + args.dataset) if args.dataset else "synthetic",
         "config": {"workload": "full-graph 3-layer GraphSAGE (mean aggr, %d-%d-%d-%d) training step on an ogbn-products-sized "
                                "synthetic graph: %d nodes, nnz %d, 64 planted communities (locality %.2f), node ids %s, "
                                "engine reorder: %s" % (args.in_feats, args.hidden, args.hidden, args.classes, n, nnz,
@@ -416,7 +430,7 @@ def main():
     }
     if trace:
         result["warmup_loss_trace"] = trace
-    if world == 1 and not args.no_extra:
+    if world == 1 and not args.no_extra and not args.dataset:
         del model, opt
         result["roofline_no_locality"] = extra_roofline(args, dev, dtype, esz, locality=0.0, permute=False, reorder="none",
                                                         note="structure-free RMAT (locality 0): nothing for caches or a reordering to exploit")

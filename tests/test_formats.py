@@ -126,3 +126,87 @@ def test_ppi_evaluation_model_on_gpu(name, cuda_device):
         np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=2e-4, atol=2e-5 * float(np.abs(ref).max()))
     out2 = model(ei, x)                            # second call: the cached CSR, same result bit for bit
     assert torch.equal(out2, out)
+
+
+def _toy_dataset(n=60, e=400, f=7, c=5, seed=0):
+    rng = np.random.default_rng(seed)
+    src, dst = rng.integers(0, n, e), rng.integers(0, n, e)
+    feat = rng.standard_normal((n, f)).astype(np.float32)
+    label = rng.integers(0, c, n)
+    return src, dst, feat, label
+
+
+def _expect_adj(src, dst, n, symmetrise):
+    s = set(zip(src.tolist(), dst.tolist()))
+    if symmetrise:
+        s |= set(zip(dst.tolist(), src.tolist()))
+    return [sorted(u for (v2, u) in s if v2 == v) for v in range(n)]
+
+
+@pytest.mark.parametrize("layout", ["edge_index", "src_dst", "csr"])
+@pytest.mark.parametrize("symmetrise", [False, True])
+def test_edge_list_npz_loader(tmp_path, layout, symmetrise):
+    """Raw edge-list datasets (ogbn-products' processed dict, PyG-style dumps) -> DGraph, for every key spelling."""
+    from dgll_amd.data import formats
+
+    src, dst, feat, label = _toy_dataset()
+    n = feat.shape[0]
+    arrays = dict(node_feat=feat, node_label=label.reshape(-1, 1), train_idx=np.arange(0, 30), valid_idx=np.arange(30, 45),
+                  test_idx=np.arange(45, 60))
+    if layout == "edge_index":
+        arrays["edge_index"] = np.stack([src, dst])
+    elif layout == "src_dst":
+        arrays.update(src=src, dst=dst)
+        arrays["x"] = arrays.pop("node_feat")
+        arrays["y"] = arrays.pop("node_label")[:, 0]
+    else:
+        import scipy.sparse as sp
+
+        a = sp.csr_matrix((np.ones(src.size), (src, dst)), shape=(n, n))
+        a.sum_duplicates()
+        a.sort_indices()
+        arrays.update(indptr=a.indptr, indices=a.indices)
+    path = tmp_path / "toy.npz"
+    np.savez(path, **arrays)
+    g = formats.load_node_dataset(str(path), symmetrise=symmetrise)
+    want = _expect_adj(src, dst, n, symmetrise)
+    assert [g.edges[v] for v in range(n)] == want
+    assert g.get_neighbors(torch.tensor([3, 7])) == [want[3], want[7]]
+    np.testing.assert_array_equal(g.features.numpy(), feat)
+    np.testing.assert_array_equal(g.labels.numpy(), label)
+    assert g.get_train_nodes().tolist() == list(range(30)) and g.get_test_nodes().tolist() == list(range(45, 60))
+    csr = g.to_csr("cpu")
+    assert csr.nnz == sum(len(w) for w in want) and csr.n_rows == n
+
+
+def test_reddit_and_ogb_raw_loaders(tmp_path):
+    import gzip
+
+    from dgll_amd.data import formats
+
+    src, dst, feat, label = _toy_dataset(n=40, e=300, seed=3)
+    n = feat.shape[0]
+    # DGL's RedditDataset files
+    rd = tmp_path / "reddit"
+    rd.mkdir()
+    types = np.array([1] * 25 + [2] * 5 + [3] * 10)
+    np.savez(rd / "reddit_data.npz", feature=feat, label=label, node_types=types)
+    np.savez(rd / "reddit_graph.npz", row=src, col=dst, data=np.ones(src.size), shape=np.array([n, n]))
+    g = formats.load_node_dataset(str(rd))
+    assert [g.edges[v] for v in range(n)] == _expect_adj(src, dst, n, False)
+    assert g.get_train_nodes().tolist() == list(range(25)) and g.get_validation_nodes().tolist() == list(range(25, 30))
+    # OGB raw csv files (gzipped), undirected-once edge list
+    od = tmp_path / "ogbn_toy"
+    (od / "raw").mkdir(parents=True)
+    (od / "split" / "sales_ranking").mkdir(parents=True)
+    for stem, arr, fmt in (("edge", np.stack([src, dst], 1), "%d"), ("node-feat", feat, "%.8g"), ("node-label", label.reshape(-1, 1), "%d")):
+        with gzip.open(od / "raw" / (stem + ".csv.gz"), "wt") as f:
+            np.savetxt(f, arr, delimiter=",", fmt=fmt)
+    for stem, idx in (("train", np.arange(0, 20)), ("valid", np.arange(20, 30)), ("test", np.arange(30, 40))):
+        with gzip.open(od / "split" / "sales_ranking" / (stem + ".csv.gz"), "wt") as f:
+            np.savetxt(f, idx, fmt="%d")
+    g2 = formats.load_node_dataset(str(od))
+    assert [g2.edges[v] for v in range(n)] == _expect_adj(src, dst, n, True)
+    np.testing.assert_allclose(g2.features.numpy(), feat, rtol=1e-6)
+    np.testing.assert_array_equal(g2.labels.numpy(), label)
+    assert g2.get_test_nodes().tolist() == list(range(30, 40))
