@@ -70,6 +70,36 @@ def _fused_heads(x, adj, Ws, a1s, a2s, alpha, concat, mode, dropout, training):
     return out
 
 
+def _host_heads(x, adj, Ws, a1s, a2s, alpha, concat, mode, dropout, training):
+    """The same computation for HOST tensors, on the CSR structure with torch's own segment ops (index_add /
+    scatter_reduce) -- per-node scores s, t; per-edge weight from s[row] + t[col]; row-wise normalisation; weighted gather.
+    No dense N x N, no [2*fo, E] edge matrix.  It exists so that the layers' host-side logic (constructors, parameter names,
+    adjacency conversion) can be exercised where there is no GPU; a GPU tensor never reaches it."""
+    graph = as_csr_graph(adj)
+    row, col = graph.row_index(), graph.col.long()
+    n = graph.n_rows
+    outs = []
+    for W, a1, a2 in zip(Ws, a1s, a2s):
+        h = x @ W
+        z = F.nn.functional.leaky_relu((h @ a1)[row] + (h @ a2)[col], alpha)
+        if mode == 0:                                   # sparseGatConv: exp(-leakyrelu), gatconv.py:125
+            w = F.exp(-z)
+        else:                                           # gatConv: softmax of +leakyrelu over the row's edges, gatconv.py:36
+            top = F.full((n,), -float("inf"), dtype=z.dtype).scatter_reduce(0, row, z, "amax")
+            w = F.exp(z - top[row])
+        den = F.zeros(n, dtype=h.dtype).index_add_(0, row, w)
+        if training and dropout > 0.0:
+            w = F.dropout(w, dropout, training=True)    # on the attention weights (gatconv.py:37,132)
+        hp = F.zeros(n, h.shape[1], dtype=h.dtype).index_add_(0, row, w.unsqueeze(1) * h[col]) / den.unsqueeze(1)
+        outs.append(F.elu(hp) if concat else hp)
+    return outs[0] if len(outs) == 1 else F.cat(outs, dim=1)
+
+
+def _heads(x, adj, Ws, a1s, a2s, alpha, concat, mode, dropout, training):
+    fn = _fused_heads if x.is_cuda else _host_heads
+    return fn(x, adj, Ws, a1s, a2s, alpha, concat, mode, dropout, training)
+
+
 class gatConv(F.nn.Module):
     """Dense-adjacency GAT layer: softmax_j(leakyrelu(a1.Wh_i + a2.Wh_j)) over adj > 0 (gatconv.py:30-54)."""
 
@@ -87,16 +117,8 @@ class gatConv(F.nn.Module):
         return self.a[:self.out_features, 0], self.a[self.out_features:, 0]
 
     def forward(self, h, adj):
-        if h.is_cuda:
-            a1, a2 = self._split_a()
-            return _fused_heads(h, adj, [self.W], [a1], [a2], self.alpha, self.concat, 1, self.dropout, self.training)
-        # CPU tensors: the reference's dense formulation with torch's own ops
-        Wh = F.mm(h, self.W)
-        e = self.leakyrelu(F.matmul(Wh, self.a[:self.out_features, :]) + F.matmul(Wh, self.a[self.out_features:, :]).T)
-        attention = F.softmax(F.where(adj > 0, e, -9e15 * F.ones_like(e)), dim=1)
-        attention = F.dropout(attention, self.dropout, training=self.training)
-        h_prime = F.matmul(attention, Wh)
-        return F.elu(h_prime) if self.concat else h_prime
+        a1, a2 = self._split_a()
+        return _heads(h, adj, [self.W], [a1], [a2], self.alpha, self.concat, 1, self.dropout, self.training)
 
     def extra_repr(self):
         return "%d -> %d" % (self.in_features, self.out_features)
@@ -120,11 +142,10 @@ class SpecialSpmmFunction(F.autograd.Function):
     @staticmethod
     def forward(ctx, indices, values, shape, b):
         assert indices.requires_grad == False  # noqa: E712  (gatconv.py:65)
-        if not b.is_cuda:
-            a = F.sparse_coo_tensor(indices, values, shape)
-            ctx.save_for_backward(a, b)
-            ctx.N, ctx.gpu = shape[0], False
-            return F.matmul(a, b)
+        if not b.is_cuda:           # host tensors: the same three products as segment ops on the index lists
+            ctx.save_for_backward(indices, values.detach(), b)
+            ctx.N, ctx.gpu = int(shape[0]), False
+            return F.zeros(ctx.N, b.shape[1], dtype=b.dtype).index_add_(0, indices[0], values.detach().unsqueeze(1) * b[indices[1]])
         graph, order = _graph_of_indices(indices, shape)
         vals = values.detach().to(F.float32)
         vals = vals if order is None else vals[order]
@@ -136,13 +157,11 @@ class SpecialSpmmFunction(F.autograd.Function):
     def backward(ctx, grad_output):
         grad_values = grad_b = None
         if not ctx.gpu:
-            a, b = ctx.saved_tensors
-            if ctx.needs_input_grad[1]:
-                grad_a_dense = grad_output.matmul(b.t())
-                edge_idx = a._indices()[0, :] * ctx.N + a._indices()[1, :]
-                grad_values = grad_a_dense.view(-1)[edge_idx]
-            if ctx.needs_input_grad[3]:
-                grad_b = a.t().matmul(grad_output)
+            indices, values, b = ctx.saved_tensors
+            if ctx.needs_input_grad[1]:                                     # SDDMM: <g[row_e], b[col_e]>
+                grad_values = (grad_output[indices[0]] * b[indices[1]]).sum(1)
+            if ctx.needs_input_grad[3]:                                     # A^T . g
+                grad_b = F.zeros_like(b).index_add_(0, indices[1], values.unsqueeze(1) * grad_output[indices[0]])
             return None, grad_values, None, grad_b
         vals, b = ctx.saved_tensors
         graph = ctx.graph
@@ -182,19 +201,8 @@ class sparseGatConv(F.nn.Module):
         return self.a[0, :self.out_features], self.a[0, self.out_features:]
 
     def forward(self, input, adj):
-        if input.is_cuda:
-            a1, a2 = self._split_a()
-            return _fused_heads(input, adj, [self.W], [a1], [a2], self.alpha, self.concat, 0, self.dropout.p, self.training)
-        # CPU tensors: the reference's op sequence with torch's own ops
-        N = input.size(0)
-        edge = adj.nonzero().t()
-        h = F.mm(input, self.W)
-        edge_h = F.cat((h[edge[0, :], :], h[edge[1, :], :]), dim=1).t()
-        edge_e = F.exp(-self.leakyrelu(self.a.mm(edge_h).squeeze()))
-        e_rowsum = self.special_spmm(edge, edge_e, F.Size([N, N]), F.ones(N, 1))
-        h_prime = self.special_spmm(edge, self.dropout(edge_e), F.Size([N, N]), h).div(e_rowsum)
-        assert not F.isnan(h_prime).any()
-        return F.elu(h_prime) if self.concat else h_prime
+        a1, a2 = self._split_a()
+        return _heads(input, adj, [self.W], [a1], [a2], self.alpha, self.concat, 0, self.dropout.p, self.training)
 
     def extra_repr(self):
         return "%d -> %d" % (self.in_features, self.out_features)
@@ -215,13 +223,10 @@ class _MultiHead(F.nn.Module):
 
     def forward(self, x, adj):
         x = F.dropout(x, self.dropout, training=self.training)
-        if x.is_cuda:   # every head in one launch
-            first = self.attentions[0]
-            halves = [att._split_a() for att in self.attentions]
-            x = _fused_heads(x, adj, [att.W for att in self.attentions], [h[0] for h in halves], [h[1] for h in halves],
-                             first.alpha, True, self.mode, self.dropout, self.training)
-        else:
-            x = F.cat([att(x, adj) for att in self.attentions], dim=1)
+        first = self.attentions[0]      # every head in one launch
+        halves = [att._split_a() for att in self.attentions]
+        x = _heads(x, adj, [att.W for att in self.attentions], [h[0] for h in halves], [h[1] for h in halves],
+                   first.alpha, True, self.mode, self.dropout, self.training)
         x = F.dropout(x, self.dropout, training=self.training)
         x = F.elu(self.out_att(x, adj))
         return F.log_softmax(x, dim=1)
