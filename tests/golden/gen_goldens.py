@@ -560,6 +560,27 @@ def gen_fused_pin(ref):
     one("fused_gcn_layer_ppi_test1", ei, x, 0.05, 23, dict(split="test", graph=1, data="bundled PPI (Evaluation/PPI.tar.xz)"))
 
 
+def gen_sage_model_grads(ref):
+    """a5 with gradients: the same 2-layer GraphSage hop pyramid as sage_model_k3 (same seed, same tensors), plus the
+    gradients of every input hop and every parameter for the loss sum(y * gout)."""
+    torch.manual_seed(4)
+    D, hidden, K, n0 = 12, [16, 8], [3, 3], 10
+    model = ref.sageconv.GraphSage(D, hidden, K)
+    model.gcn1.reset_parameters()
+    model.gcn2.reset_parameters()
+    feats = [torch.randn(n0, D), torch.randn(n0 * 3, D), torch.randn(n0 * 9, D)]
+    feats = [f.requires_grad_(True) for f in feats]
+    y = model(feats)
+    gout = torch.randn(y.shape, generator=torch.Generator().manual_seed(41))
+    ps = feats + [model.gcn1.weight, model.gcn1.neighborAgg.weight, model.gcn2.weight, model.gcn2.neighborAgg.weight]
+    gs = grads_of(y, gout, ps)
+    save("sage_model_k3_grads", dict(row="a5", ref="dgll/nn/Convolution/sageconv.py:86-114", D=D, hidden=hidden,
+                                     num_neighbors=K, fix=SAGE_FIX, same_tensors_as="sage_model_k3"),
+         h0=feats[0], h1=feats[1], h2=feats[2], y=y, gout=gout,
+         w1=ps[3], wn1=ps[4], w2=ps[5], wn2=ps[6],
+         grad_h0=gs[0], grad_h1=gs[1], grad_h2=gs[2], grad_w1=gs[3], grad_wn1=gs[4], grad_w2=gs[5], grad_wn2=gs[6])
+
+
 def gen_pooling(ref):
     """Stand-in pin for the global-pooling row (dgll/nn/GlobalPooling/Pooling.py:18-81): the reference calls
     torch_scatter.scatter(x, batch, dim=0, dim_size=size, reduce=...), which is NOT installed in this image and cannot be
@@ -595,6 +616,7 @@ def main():
         return gen_formats(ref)
     if sys.argv[1:] == ["pins"]:                 # round 2: only the new fixtures (the others are unchanged)
         gen_fused_pin(ref)
+        gen_sage_model_grads(ref)
         return gen_pooling(ref)
     gen_gcn(ref)
     gen_sage(ref)
@@ -604,6 +626,7 @@ def main():
     gen_adj_prep(ref)
     gen_formats(ref)
     gen_fused_pin(ref)
+    gen_sage_model_grads(ref)
     gen_pooling(ref)
 
 

@@ -93,6 +93,27 @@ def test_sage_model(device):
     close(y, g["y"], **ACT)
 
 
+@pytest.mark.parametrize("device", DEVICES)
+def test_sage_model_gradients(device):
+    """a5, model level, backward: gradients of all three input hops and all four weights vs the imported reference."""
+    g = load_golden("sage_model_k3_grads")
+    m = g.meta
+    model = dnn.GraphSage(m["D"], m["hidden"], m["num_neighbors"])
+    model.load_state_dict({"gcn1.weight": g.t("w1"), "gcn1.neighborAgg.weight": g.t("wn1"),
+                           "gcn2.weight": g.t("w2"), "gcn2.neighborAgg.weight": g.t("wn2")})
+    model = model.to(device)
+    hs = [g.t(k, device).requires_grad_() for k in ("h0", "h1", "h2")]
+    y = model(hs)
+    close(y, g["y"], **ACT)
+    close(y, load_golden("sage_model_k3")["y"], **ACT)                 # the same tensors as the forward-only fixture
+    (y * g.t("gout", device)).sum().backward()
+    for h, k in zip(hs, ("grad_h0", "grad_h1", "grad_h2")):
+        close(h.grad, g[k], **GRAD)
+    for p, k in ((model.gcn1.weight, "grad_w1"), (model.gcn1.neighborAgg.weight, "grad_wn1"),
+                 (model.gcn2.weight, "grad_w2"), (model.gcn2.neighborAgg.weight, "grad_wn2")):
+        close(p.grad, g[k], **GRAD)
+
+
 def test_sage_rejects_unknown_methods():
     with pytest.raises(ValueError):
         dnn.sageConv(4, 4, aggr_neighbor_method="median")(torch.zeros(2, 4), torch.zeros(2, 3, 4))
