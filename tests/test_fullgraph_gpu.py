@@ -168,21 +168,22 @@ def test_split_k_weight_gradient(cuda_device):
                                             (130, 64, 0, 128, False), (4097, 40, 24, 33, True), (128, 256, 0, 256, False),
                                             (3000, 64, 0, 10, False), (500, 40, 40, 64, True), (77, 8, 0, 1, False)])
 def test_mfma_transform_kernel(cuda_device, M, K1, K2, N, relu):
-    """dgll_hip_transform_bf16 (v_mfma_f32_32x32x16_bf16) vs an fp32 matmul of the same bf16-rounded operands; the
-    weights are asymmetric so a transposed fragment layout cannot pass."""
+    """dgll_hip_transform_bf16 (v_mfma_f32_32x32x16_bf16) vs an fp32 matmul of the same bf16-rounded operands computed ON
+    THE HOST (torch CPU: shares neither the device nor a BLAS with the kernel under test); the weights are asymmetric so a
+    transposed fragment layout cannot pass."""
     from dgll_amd import dense, ops
 
     torch.manual_seed(M + N)
     a1 = ops.alloc_features(M, K1, torch.bfloat16, cuda_device)
     a1.copy_(torch.randn(M, K1, device=cuda_device))
     w1 = (torch.randn(K1, N, device=cuda_device) * 0.1 + torch.arange(N, device=cuda_device) * 1e-3).to(torch.bfloat16)
-    ref = a1.float() @ w1.float()
+    ref = a1.float().cpu() @ w1.float().cpu()
     a2 = w2 = None
     if K2:
         a2 = ops.alloc_features(M, K2, torch.bfloat16, cuda_device)
         a2.copy_(torch.randn(M, K2, device=cuda_device))
         w2 = (torch.randn(K2, N, device=cuda_device) * 0.1).to(torch.bfloat16)
-        ref = ref + a2.float() @ w2.float()
+        ref = ref + a2.float().cpu() @ w2.float().cpu()
     if relu:
         ref = ref.relu()
     out32 = dense.transform_bf16(a1, w1.t(), a2, None if w2 is None else w2.t(), relu=relu, out_dtype=torch.float32)

@@ -10,7 +10,9 @@ pytestmark = pytest.mark.gpu
 def products(cuda_device):
     from dgll_amd import synth
 
-    g = synth.products_like_graph(cuda_device, seed=0, locality=0.9)
+    # bench.py's default workload: exact products size, permuted ids, the engine's reordering
+    g = synth.products_like_graph(cuda_device, seed=0, locality=0.9, exact=True, permute_ids=True).reorder(seed=0)[0]
+    assert g.nnz == 123_718_280 and g.n_rows == 2_449_029
     g.plan()
     return g
 
@@ -79,6 +81,47 @@ def test_gat_attention_is_a_convex_combination(products, cuda_device):
         out = ops.gat_aggregate(g, h, s, t, heads, 0.2, apply_elu=False, mode=mode)
         err = (out.float() - const.unsqueeze(0)).abs().max()
         assert float(err) <= 0.04 * heads, (mode, float(err))      # bf16 output rounding of values up to 8
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_gat_backward_passes_at_full_size(cuda_device, mode):
+    """BASELINE config 4 shape (8 heads x 32, products size): both backward gather passes of the fused edge-softmax.
+    (1) For fixed scores the layer is linear in h, so <P h, g> == <h, P^T g> checks the column pass (grad_h);
+    (2) the row pass (grad_s) and the score part of the column pass (grad_t) against a central difference of the forward
+        along a random direction.  fp32 features so the difference quotient is not drowned in bf16 rounding."""
+    from dgll_amd import ops, synth
+
+    g = synth.products_like_graph(cuda_device, seed=0, locality=0.9, self_loops=True, exact=True)   # every row needs an edge
+    heads, fo = 8, 32
+    torch.manual_seed(3)
+    h = torch.randn(g.n_cols, heads * fo, device=cuda_device).requires_grad_()
+    s = (0.5 * torch.randn(g.n_rows, heads, device=cuda_device)).requires_grad_()
+    t = (0.5 * torch.randn(g.n_cols, heads, device=cuda_device)).requires_grad_()
+    go = torch.randn(g.n_rows, heads * fo, device=cuda_device)
+
+    def f(hh, ss, tt):
+        return ops.gat_aggregate(g, hh, ss, tt, heads, 0.2, apply_elu=False, mode=mode)
+
+    out = f(h, s, t)
+    assert torch.isfinite(out).all()
+    out.backward(go)
+    lhs = (out.detach().double() * go.double()).sum()
+    rhs = (h.detach().double() * h.grad.double()).sum()
+    assert abs(float(lhs - rhs)) <= 1e-4 * abs(float(lhs)) + 1e-2, (float(lhs), float(rhs))
+    ds, dt = torch.randn_like(s), torch.randn_like(t)
+    eps = 1e-2
+    with torch.no_grad():
+        fp = (f(h.detach(), s + eps * ds, t + eps * dt).double() * go.double()).sum()
+        fm = (f(h.detach(), s - eps * ds, t - eps * dt).double() * go.double()).sum()
+    numeric = float(fp - fm) / (2 * eps)
+    analytic = float((s.grad.double() * ds.double()).sum() + (t.grad.double() * dt.double()).sum())
+    scale = float(s.grad.double().norm() * ds.double().norm() + t.grad.double().norm() * dt.double().norm())
+    assert abs(numeric - analytic) <= 2e-2 * abs(analytic) + 1e-4 * scale, (numeric, analytic)
+    # bit-reproducible (no atomics in either pass)
+    h2 = h.detach().clone().requires_grad_()
+    s2, t2 = s.detach().clone().requires_grad_(), t.detach().clone().requires_grad_()
+    f(h2, s2, t2).backward(go)
+    assert torch.equal(h2.grad, h.grad) and torch.equal(s2.grad, s.grad) and torch.equal(t2.grad, t.grad)
 
 
 def test_rmat27_int64_rowptr_path_is_exact(cuda_device):
