@@ -29,10 +29,11 @@ def _mfma_ok(*mats):
 
 
 def transform_bf16(a1, wt1, a2=None, wt2=None, relu=False, out_dtype=torch.bfloat16, n_out=None, mask=None, bias=None,
-                   ld_align=None, out_gate=None, row_scale=None):
+                   ld_align=None, out_gate=None, row_scale=None, addend=None):
     """out[M, N] = act(a1 . wt1^T (+ a2 . wt2^T)) on the MFMA kernel.  wt*: [N, K] weights (transposed), any float
     dtype; padded here.  a*: bf16 [M, K], 16-byte aligned rows.  out_gate: bf16 [M, N]; out is zeroed where it is <= 0.
-    row_scale: fp32 [M] factor on the product (before bias / activation)."""
+    row_scale: fp32 [M] factor on the product (before bias / activation).  addend: bf16 [M, N] added before the
+    activation."""
     n = wt1.shape[0] if n_out is None else n_out
     m = a1.shape[0]
     p1 = _pad_wt(wt1)
@@ -48,7 +49,9 @@ def transform_bf16(a1, wt1, a2=None, wt2=None, relu=False, out_dtype=torch.bfloa
             raise ValueError("row_scale must be a contiguous fp32 vector with one entry per row")
         if out_gate is not None and (out_gate.dtype != torch.bfloat16 or out_gate.shape != (m, n) or out_gate.stride(1) != 1):
             raise ValueError("out_gate must be bf16 [M, N] with contiguous rows")
-        code = _lib.lib.dgll_hip_transform_bf16_gated(
+        if addend is not None and (addend.dtype != torch.bfloat16 or addend.shape != (m, n) or addend.stride(1) != 1):
+            raise ValueError("addend must be bf16 [M, N] with contiguous rows")
+        code = _lib.lib.dgll_hip_transform_bf16_add(
             torch.cuda.current_stream(a1.device).cuda_stream, a1.data_ptr(), a1.stride(0), a1.shape[1], p1.data_ptr(),
             p1.stride(0), a2.data_ptr() if a2 is not None else None, a2.stride(0) if a2 is not None else 0,
             a2.shape[1] if a2 is not None else 0, p2.data_ptr() if p2 is not None else None,
@@ -56,7 +59,8 @@ def transform_bf16(a1, wt1, a2=None, wt2=None, relu=False, out_dtype=torch.bfloa
             mask.stride(0) if mask is not None else 0, out.data_ptr(), out.stride(0),
             _lib.BF16 if out_dtype == torch.bfloat16 else _lib.F32, m, n, int(relu), bias.data_ptr() if bias is not None else None,
             out_gate.data_ptr() if out_gate is not None else None, out_gate.stride(0) if out_gate is not None else 0,
-            row_scale.data_ptr() if row_scale is not None else None)
+            row_scale.data_ptr() if row_scale is not None else None,
+            addend.data_ptr() if addend is not None else None, addend.stride(0) if addend is not None else 0)
     _lib.check(code, "dgll_hip_transform_bf16")
     return out
 
@@ -191,9 +195,12 @@ class _AddLinearAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, addend, x, w, relu):
         wd = w.to(x.dtype)
-        out = torch.addmm(addend, x, wd)
-        if relu:
-            out.relu_()
+        if _mfma_ok(x) and addend.dtype == torch.bfloat16 and addend.stride(1) == 1 and wd.shape[1] <= 256:
+            out = transform_bf16(x, wd.t(), relu=relu, addend=addend)      # one MFMA launch instead of addmm + ReLU pass
+        else:
+            out = torch.addmm(addend, x, wd)
+            if relu:
+                out.relu_()
         ctx.relu = relu
         ctx.save_for_backward(x, wd, out if relu else None)
         return out

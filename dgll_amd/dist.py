@@ -375,9 +375,13 @@ class _DistSageLayerTransformFirst(torch.autograd.Function):
         wsd, wnd = ws.to(h.dtype), wn.to(h.dtype)
         z = (dense.transform_bf16(h, wnd.t(), ld_align=64 if wn.shape[1] < 64 else None)
              if (h.is_cuda and dense._mfma_ok(h) and wn.shape[1] <= 256) else torch.mm(h, wnd))
-        out = torch.addmm(_aggregate_forward(engine, z, reduce), h, wsd)
-        if relu:
-            out.relu_()
+        aggz = _aggregate_forward(engine, z, reduce)
+        if h.is_cuda and dense._mfma_ok(h) and aggz.dtype == torch.bfloat16 and aggz.stride(1) == 1 and ws.shape[1] <= 256:
+            out = dense.transform_bf16(h, wsd.t(), relu=relu, addend=aggz)
+        else:
+            out = torch.addmm(aggz, h, wsd)
+            if relu:
+                out.relu_()
         ctx.engine, ctx.reduce, ctx.relu = engine, reduce, relu
         ctx.grad_is_gated, ctx.gate_input = grad_is_gated, gate_input
         ctx.save_for_backward(h, wsd, wnd, out if relu else None)

@@ -77,9 +77,14 @@ class _SageGraphLayerTransformFirst(torch.autograd.Function):
         # the narrow product is gathered next: one 128-byte line per row (ld_align) instead of rows straddling two lines
         z = (dense.transform_bf16(h, wnd.t(), ld_align=64 if wn.shape[1] < 64 else None)
              if (dense._mfma_ok(h) and wn.shape[1] <= 256) else torch.mm(h, wnd))
-        out = torch.addmm(ops.spmm_raw(graph, z, reduce=reduce), h, wsd)
-        if relu:
-            out.relu_()
+        aggz = ops.spmm_raw(graph, z, reduce=reduce)
+        if dense._mfma_ok(h) and aggz.dtype == torch.bfloat16 and aggz.stride(1) == 1 and ws.shape[1] <= 256:
+            # act(agg + h.Ws) in ONE MFMA launch: the aggregated term rides in the epilogue (library: addmm + ReLU pass)
+            out = dense.transform_bf16(h, wsd.t(), relu=relu, addend=aggz)
+        else:
+            out = torch.addmm(aggz, h, wsd)
+            if relu:
+                out.relu_()
         ctx.graph, ctx.reduce, ctx.relu = graph, reduce, relu
         ctx.save_for_backward(h, wsd, wnd, out if relu else None)
         return out

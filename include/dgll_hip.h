@@ -244,6 +244,15 @@ int dgll_hip_transform_bf16_gated(void* stream, const void* A1, int64_t lda1, in
                                   int64_t M, int N, int relu, const float* bias, const void* out_gate, int64_t ldgate,
                                   const float* row_scale);
 
+/* The same transform with a bf16 [M, ldadd] matrix added before the activation:
+ * out = act(row_scale * (A1.Wt1^T + A2.Wt2^T) + bias + addend) -- the self term of a transform-first SAGE layer, whose
+ * neighbour term arrives already aggregated (sageconv.py:72-75 computes src.W + aggregated as two ops and an add). */
+int dgll_hip_transform_bf16_add(void* stream, const void* A1, int64_t lda1, int K1, const void* Wt1, int64_t ldw1,
+                                const void* A2, int64_t lda2, int K2, const void* Wt2, int64_t ldw2, int wt_rows,
+                                const void* relu_mask, int64_t ldm, void* out, int64_t ldo, int out_dtype, int64_t M,
+                                int N, int relu, const float* bias, const void* out_gate, int64_t ldgate,
+                                const float* row_scale, const void* addend, int64_t ldadd);
+
 /* ---- the loss at the end of the path: softmax cross-entropy with class-index targets ---------------------------
  * nn.CrossEntropyLoss on the last layer's output (Evaluation/PPI/train_gcn.py:27,45), one pass per direction:
  * row_loss[i] = logsumexp(z_i) - z_i[label_i]  and/or  grad[i, c] = *grad_scale * (softmax(z_i)[c] - [c == label_i]).

@@ -33,10 +33,12 @@ for K, N in [(256, 256), (100, 256), (256, 47)]:
 
     ideal = (2 * M * K + M * N) * 2 / 5e12 * 1e3
     from dgll_amd import _lib
-    for perm in (1, 0, 1, 0):
-        _lib.lib.dgll_hip_debug_tune(4, perm)
-        print("   kperm=%d  fused %.3f ms  single %.3f ms" % (perm, t(lambda: dense.transform_bf16(h, wst, agg, wnt, relu=True)),
-                                                          t(lambda: dense.transform_bf16(h, wst))), flush=True)
+    for variant in (1, 3, 2, 1, 3):   # 1 = the 4-wave kernel, 3 = the persistent 8-wave kernel, 2 = same without chunk rotation
+        _lib.lib.dgll_hip_debug_tune(4, variant)
+        tf, ts = t(lambda: dense.transform_bf16(h, wst, agg, wnt, relu=True)), t(lambda: dense.transform_bf16(h, wst))
+        print("   variant=%d  fused %.3f ms (%.2f TB/s)  single %.3f ms (%.2f TB/s)" % (
+            variant, tf, (2 * M * K + M * N) * 2 / tf / 1e9, ts, (M * K + M * N) * 2 / ts / 1e9), flush=True)
+    _lib.lib.dgll_hip_debug_tune(4, 0)
     print("K=%d N=%d  library mm+addmm+relu %.3f ms | MFMA fused %.3f ms | single-pair MFMA %.3f ms vs mm %.3f ms | ideal@5TB/s %.3f" % (
         K, N, t(lib), t(lambda: dense.transform_bf16(h, wst, agg, wnt, relu=True)),
         t(lambda: dense.transform_bf16(h, wst)), t(lambda: torch.mm(h, ws)), ideal), flush=True)
