@@ -432,9 +432,13 @@ def main():
         result["warmup_loss_trace"] = trace
     if world == 1 and not args.no_extra and not args.dataset:
         del model, opt
-        result["roofline_no_locality"] = extra_roofline(args, dev, dtype, esz, locality=0.0, permute=False, reorder="none",
-                                                        note="structure-free RMAT (locality 0): nothing for caches or a reordering to exploit")
+        result["roofline_no_locality"] = extra_roofline(args, dev, dtype, esz, locality=0.0, permute=False, reorder=args.reorder,
+                                                        note="structure-free RMAT (locality 0: no communities), engine reorder '%s' as in "
+                                                             "the headline run" % args.reorder)
         if args.reorder != "none":
+            result["roofline_no_locality_raw_order"] = extra_roofline(
+                args, dev, dtype, esz, locality=0.0, permute=False, reorder="none",
+                note="structure-free RMAT in the generator's own id order (hubs at low ids), no reordering: round 1's figure")
             result["roofline_raw_order"] = extra_roofline(args, dev, dtype, esz, locality=args.locality, permute=not args.no_permute,
                                                           reorder="none", note="the headline graph WITHOUT the engine's reordering pass")
     if world == 1 and not args.no_cpu_baseline:

@@ -13,7 +13,7 @@
 struct dgll_csr_plan {
     int device = 0;
     int64_t n_rows = 0, nnz = 0;
-    int threshold = 128;
+    int threshold = 256;
     int64_t n_long = 0, n_chunks = 0;
     int64_t* d_long_row = nullptr;    // [n_long]      row id of each long row (ascending)
     int32_t* d_long_chunk0 = nullptr; // [n_long + 1]  first chunk of each long row

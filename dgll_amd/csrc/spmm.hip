@@ -364,7 +364,7 @@ static int ws_ld_for(int feat) { return (feat + 7) & ~7; }
 static int g_tune_unroll = 4;        // gathers in flight per lane (2, 4 or 8; 8 only for the widest variants)
 static int g_tune_rows_per_wave = 0; // 0 = automatic
 static int g_tune_flags = 0;         // bit 0: XCD-contiguous row mapping (off: measured slower when degree correlates with row id)
-static int g_tune_threshold = 0;     // 0 = plan default (128)
+static int g_tune_threshold = 0;     // 0 = plan default (256)
 
 template <typename XT, typename YT, int EPV, int LPR, int U>
 static hipError_t launch_u(const SpmmArgs& a, dim3 grid, hipStream_t s) {
@@ -411,7 +411,7 @@ DGLL_API int dgll_hip_csr_plan_create(void* stream, const int64_t* rowptr, int64
     dgll_csr_plan* p = new dgll_csr_plan();
     p->n_rows = n_rows;
     p->nnz = nnz;
-    p->threshold = long_row_threshold > 0 ? long_row_threshold : (g_tune_threshold > 0 ? g_tune_threshold : 128);
+    p->threshold = long_row_threshold > 0 ? long_row_threshold : (g_tune_threshold > 0 ? g_tune_threshold : 256);
     hipError_t e = hipGetDevice(&p->device);
     if (e != hipSuccess) { delete p; return hip_fail(e, "hipGetDevice"); }
     if (long_row_threshold < 0) {   // caller's guarantee: no row is longer than the default threshold (e.g. a sampled block with

@@ -40,6 +40,8 @@ class Partition:
         self.send_counts = None    # python list, rows sent to each rank
         self.recv_counts = None    # python list, halo rows received from each rank
         self.send_reduce = None    # CSRGraph [n_own, sum(send_counts)]: owner-side deterministic reduction of returned grads
+        self.merged = None         # CSRGraph [n_own, n_own + n_halo]: both halves over ONE column space (own rows first, then
+                                   # the halo rows) -- for operands whose halo is already in place (the static input features)
         self.nnz = 0
 
 
@@ -83,7 +85,13 @@ def _split_block(p, rowptr, col, val, bounds, dev):
 
     # boolean masking keeps the row-major edge order, so each half is a valid CSR over the same rows
     p.local = sub_csr(owned, col[owned] - p.own_begin, p.n_own)
-    p.halo = sub_csr(~owned, torch.searchsorted(halo_ids, col[~owned]), p.n_halo)
+    halo_col = torch.searchsorted(halo_ids, col[~owned])
+    p.halo = sub_csr(~owned, halo_col, p.n_halo)
+    merged_col = col - p.own_begin
+    merged_col[~owned] = p.n_own + halo_col
+    ptr = torch.zeros(p.n_own + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(deg, 0, out=ptr[1:])
+    p.merged = CSRGraph(ptr, merged_col.to(torch.int32), val, p.n_own, p.n_own + p.n_halo, check=False)
     return halo_ids, owner
 
 
@@ -599,20 +607,28 @@ class DistGraph:
         p = self.part
         h_store, h_view = self.rows_of(x_own)
         send_store = h_store.index_select(0, p.send_idx) if p.send_idx.numel() else h_store[:0]
-        halo_store, halo_view = self.alloc_rows(p.n_halo, x_own.shape[1], x_own.dtype)
+        # own rows and halo rows in ONE buffer, [n_own + n_halo, F]: the first layer then aggregates both column halves in
+        # a single pass over the merged adjacency (no second sweep over the rows, no read-modify-write of the output)
+        all_store, all_view = self.alloc_rows(p.n_own + p.n_halo, x_own.shape[1], x_own.dtype)
+        all_store[:p.n_own].copy_(h_store)
+        halo_store = all_store[p.n_own:]
         with self.comm_scope():
             self.exchange.wait(self.exchange.start(send_store, halo_store))
         self.join_comm()
         if self.device.type == "cuda":
             torch.cuda.current_stream(self.device).synchronize()
-        return (h_view, halo_view)
+            p.merged.plan()
+        return (h_view, all_view[p.n_own:], all_view)
 
     def aggregate_static(self, placed, reduce="mean"):
         """Aggregation of input features whose halo rows were placed once (no gradient flows to raw features)."""
         p = self.part
-        h_view, halo_view = placed
+        h_view, halo_view = placed[0], placed[1]
         scale = p.inv_deg if reduce == "mean" else None
         _, out = self.alloc_rows(p.n_own, h_view.shape[1], h_view.dtype)
+        if len(placed) > 2 and p.merged is not None:
+            self.spmm(p.merged, placed[2], out, row_scale=scale)
+            return out
         self.spmm(p.local, h_view, out, row_scale=scale)
         if p.n_halo:
             self.spmm(p.halo, halo_view, out, row_scale=scale, accumulate=2)

@@ -204,6 +204,8 @@ class CSRGraph:
 
         if self.n_rows != self.n_cols:
             raise ValueError("reorder needs a square adjacency (one id space for rows and columns)")
+        if method == "lpa" and self.nnz >= _reorder._LARGE_NNZ:
+            method = "degree"         # label propagation sorts the edge list in one call; beyond 2^30 edges fall back to hubs-first
         perm = _reorder.locality_order(self.rowptr, self.col, self.n_rows, method=method, seed=seed, sweeps=sweeps)
         return _reorder.relabel(self, perm), perm
 

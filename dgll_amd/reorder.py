@@ -19,6 +19,8 @@ once with x[perm] and results come back in caller order with y_new[inv_perm] (`C
 """
 import torch
 
+_LARGE_NNZ = 1 << 30     # above this many edges nothing here sorts the whole edge list in one call
+
 
 def label_propagation(rowptr, col, n, sweeps=8, seed=0):
     """int64 [n] community label per node (labels are node ids of the community's 'founder')."""
@@ -56,12 +58,16 @@ def label_propagation(rowptr, col, n, sweeps=8, seed=0):
 
 def locality_order(rowptr, col, n, method="lpa", seed=0, sweeps=8):
     """perm (int64 [n]): the node that becomes row i of the reordered graph."""
-    if method not in ("lpa", "degree"):
-        raise ValueError("reorder method must be 'lpa' or 'degree'")
+    if method not in ("lpa", "degree", "random"):
+        raise ValueError("reorder method must be 'lpa', 'degree' or 'random'")
     deg = rowptr[1:] - rowptr[:-1]
     dmax = int(deg.max()) + 1 if n else 1
     ids = torch.arange(n, device=rowptr.device)
-    if method == "degree":
+    if method == "random":          # no structure sought: only break whatever correlation the given ids have with degree
+        gen = torch.Generator(device=rowptr.device)
+        gen.manual_seed(seed + 977)
+        return torch.randperm(n, generator=gen, device=rowptr.device)
+    if method == "degree":          # hubs first (what "lpa" degenerates to when the graph is one community)
         key = (dmax - 1 - deg) * n + ids
     else:
         labels = label_propagation(rowptr, col, n, sweeps=sweeps, seed=seed)
@@ -91,6 +97,30 @@ def relabel(graph, perm):
     new_deg = deg[perm]
     rowptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
     torch.cumsum(new_deg, 0, out=rowptr[1:])
+    if graph.nnz >= _LARGE_NNZ:
+        # too many edges for one sort (RMAT-27: 2.3e9): move the rows block by block; columns keep their old relative order
+        # inside a row (no kernel needs them ascending)
+        inv32 = inv.to(torch.int32)
+        col = torch.empty(graph.nnz, dtype=torch.int32, device=dev)
+        val = None if graph.val is None else torch.empty(graph.nnz, dtype=torch.float32, device=dev)
+        block = max(1, int(n * (float(1 << 28) / max(graph.nnz, 1))))           # ~2.7e8 edges per block
+        for r0 in range(0, n, block):
+            r1 = min(r0 + block, n)
+            rows = perm[r0:r1]
+            d = deg[rows]
+            total = int(d.sum())
+            if total == 0:
+                continue
+            starts = torch.repeat_interleave(graph.rowptr[rows] - (rowptr[r0:r1] - rowptr[r0]), d)
+            pos = starts + torch.arange(total, device=dev)
+            e0 = int(rowptr[r0])
+            col[e0:e0 + total] = inv32[graph.col[pos].long()]
+            if val is not None:
+                val[e0:e0 + total] = graph.val[pos]
+            del starts, pos
+        g = CSRGraph(rowptr, col, val, n, n, check=False)
+        g.perm, g.inv_perm = perm, inv
+        return g
     new_row = inv[graph.row_index()]
     key = new_row * n + inv[graph.col.long()]
     del new_row

@@ -50,7 +50,7 @@ def test_bench_single_rank_contract():
     # every SpMM-type launch of the step is listed; the headline is the longest hidden-width one
     wide = [v for v in d["spmm_launch_table"].values() if v["feat"] == 64]
     assert len(wide) >= 2 and abs(max(v["avg_ms"] for v in wide) - d["roofline"]["avg_launch_ms"]) < 1e-9
-    assert "roofline_no_locality" in d and "roofline_raw_order" in d
+    assert "roofline_no_locality" in d and "roofline_raw_order" in d and "roofline_no_locality_raw_order" in d
     test_bench_single_rank_contract.loss = d["loss"]
 
 

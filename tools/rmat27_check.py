@@ -29,16 +29,35 @@ assert torch.equal(deg.long(), g.degrees()) or int((deg.long() - g.degrees()).ab
 print("exactness checks passed (mean(1) == 1 on all %d rows; sum(1) == degree)" % g.n_rows, flush=True)
 del ones, y, deg
 x = torch.randn(g.n_cols, F, device=dev).to(torch.bfloat16)
-ops.spmm_raw(g, x, reduce="mean")
-torch.cuda.synchronize()
-reps = 5
-a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-a.record()
-for _ in range(reps):
-    ops.spmm_raw(g, x, reduce="mean")
-b.record()
-torch.cuda.synchronize()
-ms = a.elapsed_time(b) / reps
-b_alg = g.nnz * (F * 2 + 4) + g.n_rows * (F * 2 + 8)
-print("SpMM F=%d bf16 mean: %.1f ms, %.2f G edges/s, %.0f GB/s algorithmic (%.0f%% of 8 TB/s), memory in use %.1f GB" % (
-    F, ms, g.nnz / ms / 1e6, b_alg / ms / 1e6, b_alg / ms / 1e6 / 80, torch.cuda.memory_allocated() / 1e9), flush=True)
+
+
+def timed(graph, label):
+    graph.plan()
+    ops.spmm_raw(graph, x, reduce="mean")
+    torch.cuda.synchronize()
+    reps = 5
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        ops.spmm_raw(graph, x, reduce="mean")
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / reps
+    b_alg = graph.nnz * (F * 2 + 4) + graph.n_rows * (F * 2 + 8)
+    print("%-28s SpMM F=%d bf16 mean: %.1f ms, %.2f G edges/s, %.0f GB/s algorithmic (%.0f%% of 8 TB/s), memory in use %.1f GB" % (
+        label, F, ms, graph.nnz / ms / 1e6, b_alg / ms / 1e6, b_alg / ms / 1e6 / 80, torch.cuda.memory_allocated() / 1e9), flush=True)
+
+
+timed(g, "generator's (RMAT) ids:")
+# the engine's locality pass: above 2^30 edges label propagation's edge sort does not fit one call, so the pass is the hub-first
+# order ("degree") -- what "lpa" degenerates to on a structure-free graph anyway -- or a plain random relabelling
+for method in (["degree", "random"] if g.nnz >= (1 << 30) else ["lpa", "degree", "random"]):
+    t0 = time.time()
+    g2, perm = g.reorder(method=method)
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    y2 = ops.spmm_raw(g2, torch.ones(g.n_cols, 8, device=dev), reduce="sum")[:, 0]
+    assert torch.equal(y2.long()[:1000], g.degrees()[perm][:1000])
+    timed(g2, "reorder(%s), %.1f s:" % (method, dt))
+    del g2, perm, y2
+    torch.cuda.empty_cache()
