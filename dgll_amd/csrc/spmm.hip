@@ -318,6 +318,107 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_kernel(const SpmmArgs a) {
     }
 }
 
+// ---- short-row / narrow-row variant: one output row per SLOT, 64 / LPR rows per wavefront at a time ---------------------
+// The wave-per-row kernel above pays a fixed price per row -- row pointers, one index batch, a cross-slot shuffle tree
+// (log2(SLOTS) x EPV shuffles), the epilogue -- and runs those prices one row after the other.  That is noise for a 256-wide
+// row with 50 neighbours; it is most of the time for narrow rows (F <= 64: 8 slots, 24 shuffles per row) and for short rows
+// (the halo halves of a partitioned graph average 3 - 9 edges per row).  Here every lane group of LPR lanes owns a row of its
+// own: the SLOTS rows of a wavefront advance together, each slot walks ITS row U edges at a time (one 16-byte read of U
+// column ids, U feature-row gathers), nothing is reduced across lanes, and the epilogues of SLOTS rows are one pass.  Rows
+// above the plan's threshold are skipped here and run as chunks exactly as above (same launch, same workspace).
+template <typename XT, typename YT, int EPV, int LPR, bool HAS_VAL, bool EXTRA>
+__global__ __launch_bounds__(kBlock) void spmm_rowslot_kernel(const SpmmArgs a) {
+    typedef VecIO<XT, EPV> IO;
+    constexpr int SLOTS = kWave / LPR;
+    constexpr int U = 4;
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int sub = lane % LPR, slot = lane / LPR;
+    const int c0 = ((int)blockIdx.y * LPR + sub) * EPV;
+    const bool col_ok = c0 < a.feat;
+    const XT* xcol = static_cast<const XT*>(a.X) + (col_ok ? c0 : 0);
+    uint32_t bid = blockIdx.x;
+
+    if (bid < a.chunk_blocks) {  // ---- a chunk of a long row: identical to spmm_csr_kernel's chunk items
+        const int64_t chunk = __builtin_amdgcn_readfirstlane((int)(bid * kWavesPerBlock + wave));
+        if (chunk >= a.n_chunks) return;
+        float acc[EPV];
+#pragma unroll
+        for (int i = 0; i < EPV; ++i) acc[i] = 0.0f;
+        gather_edges<XT, EPV, LPR, HAS_VAL, U>(a.col, a.val, xcol, a.ldx, uniform64(a.chunk_begin[chunk]),
+                                               uniform64(a.chunk_end[chunk]), lane, acc);
+        if (lane < LPR && col_ok) {
+            float* w = a.ws + chunk * a.ws_ld + c0;
+#pragma unroll
+            for (int i = 0; i < EPV; ++i) w[i] = acc[i];
+        }
+        return;
+    }
+    bid -= a.chunk_blocks;
+    const uint32_t ld32 = (uint32_t)a.ldx;
+    const int64_t row0 = ((int64_t)bid * kWavesPerBlock + wave) * a.rows_per_wave;     // rows_per_wave is a multiple of SLOTS
+    for (int r = 0; r < a.rows_per_wave; r += SLOTS) {
+        if (row0 + r >= a.n_rows) return;
+        const int64_t row = row0 + r + slot;
+        int64_t b = 0, e = 0;
+        if (row < a.n_rows) { b = a.rowptr[row]; e = a.rowptr[row + 1]; }
+        const int64_t full_len = e - b;
+        bool mine = row < a.n_rows && !(a.threshold > 0 && full_len > a.threshold);    // long rows: handled as chunks
+        if constexpr (EXTRA) {
+            if (a.accumulate == 2 && full_len == 0) mine = false;                        // increment form: nothing to add
+        }
+        const int n = mine ? (int)full_len : 0;
+        float acc[EPV];
+#pragma unroll
+        for (int i = 0; i < EPV; ++i) acc[i] = 0.0f;
+        // this slot's column ids, U at a time; the next group is fetched while the current one is gathered
+        int cnext[U];
+        float wnext[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            cnext[u] = u < n ? __builtin_nontemporal_load(a.col + b + u) : 0;
+            wnext[u] = (HAS_VAL && u < n) ? __builtin_nontemporal_load(a.val + b + u) : 0.0f;
+        }
+        for (int k = 0; __any(k < n); k += U) {
+            int c[U];
+            float w[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) { c[u] = cnext[u]; w[u] = wnext[u]; }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int kn = k + U + u;
+                cnext[u] = kn < n ? __builtin_nontemporal_load(a.col + b + kn) : 0;
+                wnext[u] = (HAS_VAL && kn < n) ? __builtin_nontemporal_load(a.val + b + kn) : 0.0f;
+            }
+            typename IO::raw_t v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = IO::load(xcol + (uint64_t)(uint32_t)c[u] * ld32);   // idle slots re-read row 0
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float f[EPV];
+                IO::unpack(k + u < n ? v[u] : IO::zero(), f);
+#pragma unroll
+                for (int i = 0; i < EPV; ++i) acc[i] = HAS_VAL ? fmaf(w[u], f[i], acc[i]) : acc[i] + f[i];
+            }
+        }
+        if (!mine || !col_ok) continue;
+        YT* yrow = static_cast<YT*>(a.Y) + row * a.ldy;
+        const bool full = c0 + EPV <= a.feat;
+        RowVec<YT, EPV> prev, gatev;
+        const YT* grow = nullptr;
+        if constexpr (EXTRA) {
+            grow = a.gate ? static_cast<const YT*>(a.gate) + row * a.ldg : nullptr;
+            if (full) {
+                if (a.accumulate) prev.load(yrow + c0);
+                if (grow) gatev.load(grow + c0);
+            }
+        }
+        const float scale = a.row_scale ? a.row_scale[row]
+                                        : ((a.reduce == DGLL_REDUCE_MEAN && n > 0) ? 1.0f / (float)n : 1.0f);
+        finish_row<YT, EPV, EXTRA>(yrow, c0, a.feat, scale, a.epilogue, a.bias, acc, a.accumulate, grow, full, prev, gatev);
+    }
+}
+
 // Second pass for long rows: sum the chunk partials in chunk order, then the same epilogue.  One wavefront per long row,
 // four columns per lane (float4 reads of the partials); most long rows have only two or three chunks.
 template <typename YT>
@@ -365,6 +466,7 @@ static int g_tune_unroll = 4;        // gathers in flight per lane (2, 4 or 8; 8
 static int g_tune_rows_per_wave = 0; // 0 = automatic
 static int g_tune_flags = 0;         // bit 0: XCD-contiguous row mapping (off: measured slower when degree correlates with row id)
 static int g_tune_threshold = 0;     // 0 = plan default (256)
+static int g_tune_rowslot = 0;       // 0 = automatic choice of the row-per-slot kernel, 1 = never, 2 = whenever it applies
 
 template <typename XT, typename YT, int EPV, int LPR, int U>
 static hipError_t launch_u(const SpmmArgs& a, dim3 grid, hipStream_t s) {
@@ -386,6 +488,29 @@ static hipError_t launch_variant(const SpmmArgs& a, dim3 grid, hipStream_t s) {
         if (g_tune_unroll == 2) return launch_u<XT, YT, EPV, LPR, 2>(a, grid, s);
     }
     return launch_u<XT, YT, EPV, LPR, 4>(a, grid, s);
+}
+
+template <typename XT, typename YT, int EPV, int LPR>
+static hipError_t launch_rowslot(const SpmmArgs& a, dim3 grid, hipStream_t s) {
+    const bool extra = a.accumulate || a.gate;
+    if (a.val) {
+        if (extra) hipLaunchKernelGGL((spmm_rowslot_kernel<XT, YT, EPV, LPR, true, true>), grid, dim3(kBlock), 0, s, a);
+        else hipLaunchKernelGGL((spmm_rowslot_kernel<XT, YT, EPV, LPR, true, false>), grid, dim3(kBlock), 0, s, a);
+    } else {
+        if (extra) hipLaunchKernelGGL((spmm_rowslot_kernel<XT, YT, EPV, LPR, false, true>), grid, dim3(kBlock), 0, s, a);
+        else hipLaunchKernelGGL((spmm_rowslot_kernel<XT, YT, EPV, LPR, false, false>), grid, dim3(kBlock), 0, s, a);
+    }
+    return hipGetLastError();
+}
+
+template <typename XT, typename YT, int EPV>
+static hipError_t launch_rowslot_lpr(const SpmmArgs& a, int lpr, dim3 grid, hipStream_t s) {
+    switch (lpr) {
+        case 4: return launch_rowslot<XT, YT, EPV, 4>(a, grid, s);
+        case 8: return launch_rowslot<XT, YT, EPV, 8>(a, grid, s);
+        case 16: return launch_rowslot<XT, YT, EPV, 16>(a, grid, s);
+        default: return launch_rowslot<XT, YT, EPV, 32>(a, grid, s);
+    }
 }
 
 template <typename XT, typename YT, int EPV>
@@ -497,6 +622,7 @@ DGLL_API int dgll_hip_debug_tune(int key, int value) {
         case 2: g_tune_flags = value; break;
         case 3: g_tune_threshold = value; break;
         case 4: g_tune_mfma_kperm = value; break;
+        case 5: g_tune_rowslot = value; break;
         default: set_error("unknown tuning key"); return DGLL_ERR_INVALID;
     }
     return DGLL_OK;
@@ -622,7 +748,37 @@ static int spmm_csr_impl(void* stream, const dgll_csr_plan* plan, const int64_t*
                       ((int64_t)epv * ysz) % 16 == 0 && (!gate || (aligned16(gate) && (ldg * ysz) % 16 == 0));
     if (fast) a.flags |= 2;
     hipError_t err;
+    bool rowslot = false;
     if (fast) {
+        const int vecs = (feat + epv - 1) / epv;
+        int lpr = 4;
+        while (lpr < 64 && lpr < vecs) lpr <<= 1;
+        // row-per-slot kernel: SHORT rows (<= 24 edges on average) of at most 16 vectors (F <= 128 bf16).  Measured on MI355X
+        // (tools/rowslot_ab.py): 6.6 edges per row -- the halo halves of an 8-way partition -- F = 47: 1.00 -> 0.47 ms, F = 100 /
+        // 128: -24 %; F = 256 (two slots): +6 %, and at 51 edges per row the wave-per-row kernel wins everywhere (+11 .. +32 %:
+        // a slot walks its row U edges at a time, a whole wavefront 64).
+        const double avg_len = plan ? (double)plan->nnz / (double)std::max<int64_t>(n_rows, 1) : 1e9;
+        rowslot = lpr <= 32 && g_tune_rowslot != 1 && (g_tune_rowslot == 2 || (lpr <= 16 && avg_len <= 24.0));
+        if (rowslot) {
+            const int slots = kWave / lpr;
+            a.rows_per_wave = std::max(a.rows_per_wave, 1);
+            a.rows_per_wave = (a.rows_per_wave + slots - 1) / slots * slots;
+            if (g_tune_rows_per_wave > 0) a.rows_per_wave = (g_tune_rows_per_wave + slots - 1) / slots * slots;
+        }
+    }
+    if (rowslot) {   // the grid depends on rows_per_wave: recompute
+        const int64_t waves2 = (n_rows + a.rows_per_wave - 1) / a.rows_per_wave;
+        const int64_t row_blocks2 = (waves2 + kWavesPerBlock - 1) / kWavesPerBlock;
+        DGLL_REQUIRE(row_blocks2 + chunk_blocks < (int64_t)0x7fffffff, "grid too large");
+        a.row_blocks = (uint32_t)row_blocks2;
+        const int vecs = (feat + epv - 1) / epv;
+        int lpr = 4;
+        while (lpr < 64 && lpr < vecs) lpr <<= 1;
+        dim3 grid((uint32_t)(row_blocks2 + chunk_blocks), (uint32_t)((vecs + lpr - 1) / lpr));
+        if (x_dtype == DGLL_F32) err = launch_rowslot_lpr<float, float, 4>(a, lpr, grid, s);
+        else if (y_dtype == DGLL_BF16) err = launch_rowslot_lpr<bf16_t, bf16_t, 8>(a, lpr, grid, s);
+        else err = launch_rowslot_lpr<bf16_t, float, 8>(a, lpr, grid, s);
+    } else if (fast) {
         const int vecs = (feat + epv - 1) / epv;
         int lpr = 4;
         while (lpr < 64 && lpr < vecs) lpr <<= 1;
