@@ -114,6 +114,13 @@ template <> struct VecIO<bf16_t, 8> {
         *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]),
                                                   pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7]));
     }
+    // streaming form: an output row is written once and not read again by this launch -- keep it from displacing the
+    // gathered feature rows in L2
+    static __device__ __forceinline__ void store_nt(bf16_t* p, const float (&f)[8]) {
+        typedef __attribute__((ext_vector_type(4))) unsigned int u4;
+        const u4 v = {pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7])};
+        __builtin_nontemporal_store(v, reinterpret_cast<u4*>(p));
+    }
 };
 template <> struct VecIO<bf16_t, 1> {
     typedef bf16_t raw_t;

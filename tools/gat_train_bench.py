@@ -13,7 +13,10 @@ from dgll_amd import ops, synth  # noqa: E402
 
 dev = torch.device("cuda:0")
 loc = float(sys.argv[1]) if len(sys.argv) > 1 else 0.9
-g = synth.products_like_graph(dev, seed=0, locality=loc, self_loops=True)
+reorder = (sys.argv[2] if len(sys.argv) > 2 else "lpa")
+g = synth.products_like_graph(dev, seed=0, locality=loc, self_loops=True, exact=True, permute_ids=True)   # bench.py's graph + I
+if reorder != "none":
+    g = g.reorder(method=reorder, seed=0)[0]
 n = g.n_rows
 torch.manual_seed(0)
 model = dnn.SpGAT(100, 32, 47, dropout=0.0, alpha=0.2, nheads=8).to(dev)
