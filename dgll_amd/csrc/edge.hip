@@ -729,6 +729,8 @@ static bool vec_ok(const void* p, int64_t ld, int esz) { return aligned16(p) && 
 
 }  // namespace dgll
 
+int g_tune_gat_unroll = 2;   // dgll_hip_debug_tune(7, v): gathers in flight per lane in the two GAT backward passes (bf16)
+
 using namespace dgll;
 
 static int check_heads(int heads, int fo, int epv, int* lph_out) {
@@ -909,6 +911,7 @@ DGLL_API int dgll_hip_gat_bwd_rows(void* stream, const dgll_csr_plan* plan, cons
     hipStream_t s = static_cast<hipStream_t>(stream);
 #define CALL(L)                                                                                                              \
     if (dtype == DGLL_F32) hipLaunchKernelGGL((gat_bwd_rows_kernel<float, 4, L, 2>), grid, dim3(kBlock), 0, s, a, lph);      \
+    else if (g_tune_gat_unroll == 4) hipLaunchKernelGGL((gat_bwd_rows_kernel<bf16_t, 8, L, 4>), grid, dim3(kBlock), 0, s, a, lph); \
     else hipLaunchKernelGGL((gat_bwd_rows_kernel<bf16_t, 8, L, 2>), grid, dim3(kBlock), 0, s, a, lph);
     DGLL_LPR_SWITCH(lpr, CALL)
 #undef CALL
@@ -945,6 +948,7 @@ DGLL_API int dgll_hip_gat_bwd_cols(void* stream, const dgll_csr_plan* t_plan, co
     hipStream_t s = static_cast<hipStream_t>(stream);
 #define CALL(L)                                                                                                                  \
     if (dtype == DGLL_F32) hipLaunchKernelGGL((gat_bwd_cols_kernel<float, float, 4, L, 2>), grid, dim3(kBlock), 0, s, t, lph);   \
+    else if (g_tune_gat_unroll == 4) hipLaunchKernelGGL((gat_bwd_cols_kernel<bf16_t, bf16_t, 8, L, 4>), grid, dim3(kBlock), 0, s, t, lph); \
     else hipLaunchKernelGGL((gat_bwd_cols_kernel<bf16_t, bf16_t, 8, L, 2>), grid, dim3(kBlock), 0, s, t, lph);
     DGLL_LPR_SWITCH(lpr, CALL)
 #undef CALL

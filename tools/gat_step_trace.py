@@ -10,7 +10,7 @@ from torch.profiler import ProfilerActivity, profile  # noqa: E402
 from dgll_amd import nn as dnn, ops, synth  # noqa: E402
 
 dev = torch.device("cuda:0")
-g = synth.products_like_graph(dev, seed=0, locality=0.9, self_loops=True)
+g = synth.products_like_graph(dev, seed=0, locality=0.9, self_loops=True, exact=True, permute_ids=True).reorder(seed=0)[0]
 n = g.n_rows
 torch.manual_seed(0)
 model = dnn.SpGAT(100, 32, 47, dropout=0.0, alpha=0.2, nheads=8).to(dev)
