@@ -131,6 +131,9 @@ struct MfmaGemmArgs {
     int no_rotate;          // diagnostics: 1 = every block walks the reduction from chunk 0
     const bf16_t* addend;   // optional bf16 [M, N] added before the activation (the aggregated term of a transform-first layer)
     int64_t ldadd;
+#ifdef DGLL_RES_TRACE
+    unsigned long long* trace;   // probe builds only (tools/probes/res_trace.hip): [wg < 16][wave 8][block < 4][16 events]
+#endif
 };
 
 constexpr int kChunkK = 64;                 // k per LDS stage
@@ -667,6 +670,413 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_w8_kernel(const MfmaGemmArgs
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the unused loads of the last round
 }
 
+// =====================================================================================================================
+// Resident-weights variant ("res"): the weights of the WHOLE reduction live in LDS for the lifetime of a persistent
+// workgroup (128 KiB, 128-byte rows XOR-swizzled: no padding), staged once.  What that removes from the main loop:
+//   * the per-chunk weight fetch + stage + s_barrier -- waves never synchronise with each other again, so a wave is never
+//     parked behind the slowest load of seven others (the 8-wave kernel above: 50 % of wave cycles in s_waitcnt / barrier);
+//   * the weight loads from every wave's in-order vmcnt queue -- with only activation loads in the queue a D-deep in-place
+//     register ring really runs D chunks ahead (`s_waitcnt vmcnt(4 (D - 1))`); with a weight load issued every phase, waiting
+//     for it drains every older activation load and the ring collapses to one chunk of run-ahead.
+// A wave owns 32 rows x 128 columns (64 accumulator registers), which leaves room for a 6-deep ring (24 KiB of activation
+// loads in flight per wave, 192 KiB per CU).  128 KiB of LDS holds NC x NWG x 128 bytes: all 256 columns for NC <= 4 chunks
+// (two waves per row group, CS = 2), 128 columns for NC = 8 (COLSPLIT = 2: two workgroups, on the same XCD and walking the
+// same row blocks, each produce half of the columns; the partner's activation reads hit that XCD's L2).
+// The epilogue transposes one 32 x 32 tile at a time through a wave-private 2.5 KiB LDS scratch: no barrier either.
+template <int OUTSTANDING>
+__device__ __forceinline__ void res_wait(u32x4_t (&areg)[4]) {
+    static_assert(OUTSTANDING % 4 == 0 && OUTSTANDING <= 28, "whole activation sets, at most seven in flight");
+#define RES_WAIT_ASM(TXT) asm volatile(TXT : "+v"(areg[0]), "+v"(areg[1]), "+v"(areg[2]), "+v"(areg[3]) :: "memory");
+    if constexpr (OUTSTANDING == 0) { RES_WAIT_ASM("s_waitcnt vmcnt(0)") }
+    else if constexpr (OUTSTANDING == 4) { RES_WAIT_ASM("s_waitcnt vmcnt(4)") }
+    else if constexpr (OUTSTANDING == 8) { RES_WAIT_ASM("s_waitcnt vmcnt(8)") }
+    else if constexpr (OUTSTANDING == 12) { RES_WAIT_ASM("s_waitcnt vmcnt(12)") }
+    else if constexpr (OUTSTANDING == 16) { RES_WAIT_ASM("s_waitcnt vmcnt(16)") }
+    else if constexpr (OUTSTANDING == 20) { RES_WAIT_ASM("s_waitcnt vmcnt(20)") }
+    else if constexpr (OUTSTANDING == 24) { RES_WAIT_ASM("s_waitcnt vmcnt(24)") }
+    else { RES_WAIT_ASM("s_waitcnt vmcnt(28)") }
+#undef RES_WAIT_ASM
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// ---- the steady-state ring --------------------------------------------------------------------------------------------
+// Every phase consumes one 64-k chunk from ring slot P % D and refills that slot with the chunk D phases ahead -- ACROSS row
+// blocks: the tail phases of a block already fetch the head of the next one, so the number of loads in flight never drops to
+// zero at a block boundary and never jumps by a whole block's worth after it (the first version issued the next block's
+// D x 4 loads in one burst after the last phase: 6.6 k cycles of issue back-pressure per block, tools/probes/res_trace.hip).
+// Slot arithmetic stays compile-time because the loop body is a "super-iteration" of Q x NC phases with D | Q x NC.
+struct ResCtx {                 // wave-uniform (SGPRs) except a_voff
+    const bf16_t* A[2];
+    int64_t lda[2];
+    uint32_t ldab[2], tail[2];  // bytes per row; bytes of a row that are read (K rounded up to 8 elements)
+    uint32_t a_voff[2];         // per lane: its row inside the block (+ its 16-byte half)
+    int64_t M, n_blocks, stride;
+    int chunks0, K0, K1, rotate;
+};
+
+template <int ROWS>
+__device__ __forceinline__ i32x4_t res_rsrc(const ResCtx& x, bool second, int64_t blk) {
+    const bf16_t* A = second ? x.A[1] : x.A[0];
+    const int64_t lda = second ? x.lda[1] : x.lda[0];
+    const uint32_t ldab = second ? x.ldab[1] : x.ldab[0], tail = second ? x.tail[1] : x.tail[0];
+    const bool live = blk < x.n_blocks;                 // past the end: a zero-byte descriptor -- the loads return zeros, no traffic
+    const int64_t r0 = live ? blk * ROWS : 0;
+    const int64_t left = x.M - r0;
+    const uint32_t rows = (uint32_t)(left < ROWS ? left : ROWS);
+    return make_rsrc(A + r0 * lda, live ? (rows - 1) * ldab + tail : 0u);
+}
+
+template <int NC>
+__device__ __forceinline__ int res_rot(const ResCtx& x, int64_t blk, int c) {   // block blk walks the reduction from chunk blk % NC
+    c += x.rotate ? (int)((uint32_t)blk % (uint32_t)NC) : 0;
+    return c >= NC ? c - NC : c;
+}
+
+__device__ __forceinline__ void res_trim(const ResCtx& x, int cc, int half, u32x4_t (&areg)[4]) {   // see w8_trim_acts
+    const bool second = cc >= x.chunks0;
+    const int k0 = (second ? cc - x.chunks0 : cc) * kChunkK;
+    const int K = second ? x.K1 : x.K0;
+    if (k0 + kChunkK <= K) return;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const uint4 v = mask_tail(make_uint4(areg[kk][0], areg[kk][1], areg[kk][2], areg[kk][3]), K - (k0 + half * 8 + kk * 16));
+        areg[kk] = u32x4_t{v.x, v.y, v.z, v.w};
+    }
+}
+
+struct ResIssue { i32x4_t r; uint32_t voff, k0b; };
+
+template <int NC, int ROWS>
+__device__ __forceinline__ ResIssue res_target(const ResCtx& x, int64_t blk, int c) {
+    const int cc = res_rot<NC>(x, blk, c);
+    const bool second = cc >= x.chunks0;
+    ResIssue t;
+    t.r = res_rsrc<ROWS>(x, second, blk);
+    t.voff = second ? x.a_voff[1] : x.a_voff[0];
+    t.k0b = (uint32_t)((second ? cc - x.chunks0 : cc) * kChunkK * 2);
+    return t;
+}
+
+__device__ __forceinline__ void res_issue1(const ResIssue& t, int kk, u32x4_t& dst) {
+    switch (kk) {
+        case 0: asm_bufload16<0>(dst, t.voff, t.r, t.k0b); break;
+        case 1: asm_bufload16<32>(dst, t.voff, t.r, t.k0b); break;
+        case 2: asm_bufload16<64>(dst, t.voff, t.r, t.k0b); break;
+        default: asm_bufload16<96>(dst, t.voff, t.r, t.k0b); break;
+    }
+}
+
+#ifdef DGLL_RES_TRACE
+#define RES_TRACE(EV) do { if (a.trace && blockIdx.x < 16 && t_blk < 4 && lane == 0)                                     \
+        a.trace[(((int64_t)blockIdx.x * 8 + wave) * 4 + t_blk) * 16 + (EV)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define RES_TRACE(EV) do { } while (0)
+#endif
+
+// phase P of the super-iteration that starts at row block blk0: chunk P % NC of block blk0 + (P / NC) stride
+template <int NTW, int NC, int D, int ROWS, int P>
+__device__ __forceinline__ void res_phase(const MfmaGemmArgs& a, const ResCtx& x, int64_t blk0, int half, const char* wlane,
+                                          int chunk_bytes, f32x16_t (&acc)[NTW], u32x4_t (&A)[D][4], const int (&slot_off)[4],
+                                          int t_blk, int lane, int wave) {
+    constexpr int S = P % D;
+    const int cc = res_rot<NC>(x, blk0 + (P / NC) * x.stride, P % NC);
+    res_trim(x, cc, half, A[S]);
+    const ResIssue nxt = res_target<NC, ROWS>(x, blk0 + ((P + D) / NC) * x.stride, (P + D) % NC);
+    const char* base = wlane + cc * chunk_bytes;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const bf16x8_t xf = __builtin_bit_cast(bf16x8_t, A[S][kk]);
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            const uint4 wv = *reinterpret_cast<const uint4*>(base + t * 32 * 128 + slot_off[kk]);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wv), xf, acc[t], 0, 0, 0);
+        }
+        res_issue1(nxt, kk, A[S][kk]);              // into the register its last MFMA just vacated
+    }
+    res_wait<4 * (D - 1)>(A[(P + 1) % D]);          // the next phase's chunk has landed; D - 1 younger sets may still fly
+    RES_TRACE(2 + P % NC);
+    (void)t_blk; (void)lane; (void)wave; (void)a;
+}
+
+template <int NTW, int NC, int D, int ROWS, int P, int PEND>
+__device__ __forceinline__ void res_phases(const MfmaGemmArgs& a, const ResCtx& x, int64_t blk0, int half, const char* wlane,
+                                           int chunk_bytes, f32x16_t (&acc)[NTW], u32x4_t (&A)[D][4], const int (&slot_off)[4],
+                                           int t_blk, int lane, int wave) {
+    if constexpr (P < PEND) {
+        res_phase<NTW, NC, D, ROWS, P>(a, x, blk0, half, wlane, chunk_bytes, acc, A, slot_off, t_blk, lane, wave);
+        res_phases<NTW, NC, D, ROWS, P + 1, PEND>(a, x, blk0, half, wlane, chunk_bytes, acc, A, slot_off, t_blk, lane, wave);
+    }
+}
+
+// epilogue of one wave: 32 rows x NTW*32 columns from global column n0, one 32 x 32 tile at a time through `scratch`
+// (wave-private: 32 rows x 80 bytes)
+// PLAIN (bf16 output, no row scale / addend / gate): the epilogue issues NO vector-memory load.  That matters more than the
+// arithmetic it saves: a load the compiler can see is waited for with the `s_waitcnt vmcnt` IT computes, and it knows nothing
+// of the inline-asm prefetch of the next block queued ahead of that load -- so it emits vmcnt(0) and the whole prefetch is
+// drained before the epilogue starts (measured with cycle stamps, tools/probes/res_trace.hip: 19 k of a block's 34 k cycles
+// sat in that wait).  The bias therefore comes from LDS (staged once), never from global memory.
+template <int NTW, bool PLAIN>
+__device__ __forceinline__ void res_epilogue(const MfmaGemmArgs& a, char* scratch, const float* bias_w, f32x16_t (&acc)[NTW],
+                                             int64_t m0, int64_t row, int64_t row_ld, int n0, int lane, int half, int l32) {
+    float rs = 1.0f;
+    if constexpr (!PLAIN) rs = a.row_scale ? a.row_scale[row_ld] : 1.0f;
+    constexpr int kPitch = 80;                                  // 64 bytes of bf16 + 16: conflict-free 8-byte writes
+    const bool vec_rows = (a.ldo & 7) == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15u) == 0;
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+        const int nt0 = n0 + t * 32;
+        if (nt0 >= a.N) break;                                  // wave-uniform
+        if (!PLAIN && a.out_f32) {
+            if (row < a.M) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n = nt0 + g * 8 + half * 4;
+                    if (n >= a.N) continue;
+                    const float4 bv = *reinterpret_cast<const float4*>(bias_w + t * 32 + g * 8 + half * 4);
+                    const float b4[4] = {bv.x, bv.y, bv.z, bv.w};
+                    float v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float xv = acc[t][g * 4 + i] * rs + b4[i];
+                        if (a.addend && n + i < a.N) xv += bf16_to_f32(a.addend[row * a.ldadd + n + i]);
+                        if (a.relu) xv = fmaxf(xv, 0.0f);
+                        if (a.out_gate && n + i < a.N && !(bf16_to_f32(a.out_gate[row * a.ldgate + n + i]) > 0.0f)) xv = 0.0f;
+                        v[i] = xv;
+                    }
+                    float* o = static_cast<float*>(a.out) + row * a.ldo + n;
+                    if (n + 4 <= a.N && (a.ldo & 3) == 0) *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+                    else
+                        for (int i = 0; i < 4; ++i) if (n + i < a.N) o[i] = v[i];
+                }
+            }
+            continue;
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int nl = g * 8 + half * 4;
+            const int n = nt0 + nl;
+            const float4 bv = *reinterpret_cast<const float4*>(bias_w + t * 32 + nl);
+            const float b4[4] = {bv.x, bv.y, bv.z, bv.w};
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float xv = acc[t][g * 4 + i] * rs + b4[i];
+                if constexpr (!PLAIN) { if (a.addend && n + i < a.N) xv += bf16_to_f32(a.addend[row_ld * a.ldadd + n + i]); }
+                if (a.relu) xv = fmaxf(xv, 0.0f);
+                v[i] = xv;
+            }
+            *reinterpret_cast<uint2*>(scratch + l32 * kPitch + nl * 2) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the whole wave's tile is in the scratch (one wave: no barrier)
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {                       // 32 rows x 4 vectors of 16 bytes = 128 vectors, two per lane
+            const int idx = it * kWave + lane;
+            const int r = idx >> 2, nl = (idx & 3) * 8;
+            const int n = nt0 + nl;
+            const int64_t grow = m0 + r;
+            if (grow >= a.M || n >= a.N) continue;
+            uint4 d = *reinterpret_cast<const uint4*>(scratch + r * kPitch + nl * 2);
+            bf16_t* o = static_cast<bf16_t*>(a.out) + grow * a.ldo + n;
+            if (n + 8 <= a.N && vec_rows) {
+                if constexpr (!PLAIN) { if (a.out_gate) d = relu_mask(d, *reinterpret_cast<const uint4*>(a.out_gate + grow * a.ldgate + n)); }
+                *reinterpret_cast<uint4*>(o) = d;
+            } else {
+                const uint32_t w[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    if (n + e >= a.N) continue;
+                    bf16_t b = (bf16_t)((w[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+                    if constexpr (!PLAIN) { if (a.out_gate && !(bf16_to_f32(a.out_gate[grow * a.ldgate + n + e]) > 0.0f)) b = 0; }
+                    o[e] = b;
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // reads done before the next tile overwrites the scratch
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+struct ResLane { int lane, half, l32, rgroup, n_col0; char* scratch; const float* bias_w; };
+
+// blocks QI .. Q-1 of a super-iteration; true = the last row block of this workgroup has been written
+template <int NTW, int NC, int D, int ROWS, int Q, bool PLAIN, int QI>
+__device__ __forceinline__ bool res_blocks(const MfmaGemmArgs& a, const ResCtx& x, int64_t blk0, const ResLane& L, const char* wlane,
+                                           int chunk_bytes, u32x4_t (&A)[D][4], const int (&slot_off)[4], int& t_blk, int wave) {
+    if constexpr (QI < Q) {
+        const int lane = L.lane;
+        RES_TRACE(0);
+        f32x16_t acc[NTW];
+#pragma unroll
+        for (int t = 0; t < NTW; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+        res_phases<NTW, NC, D, ROWS, QI * NC, QI * NC + NC>(a, x, blk0, L.half, wlane, chunk_bytes, acc, A, slot_off, t_blk, lane, wave);
+        const int64_t blk = blk0 + QI * x.stride;
+        const int64_t m0 = blk * ROWS + L.rgroup * 32;
+        const int64_t row = m0 + L.l32;
+        const int64_t row_ld = row < a.M ? row : a.M - 1;
+        {   // opaque copies of the lane coordinates: what the epilogue derives from them (staging addresses, the store loop's
+            // row / column pairs) would otherwise be hoisted out of the persistent loop and stay live through the main loop
+            int e_lane = L.lane, e_half = L.half, e_l32 = L.l32, e_n0 = L.n_col0;
+            asm volatile("" : "+v"(e_lane), "+v"(e_half), "+v"(e_l32), "+s"(e_n0));
+            RES_TRACE(11);
+            res_epilogue<NTW, PLAIN>(a, L.scratch, L.bias_w, acc, m0, row, row_ld, e_n0, e_lane, e_half, e_l32);
+            RES_TRACE(12);
+        }
+        ++t_blk;
+        if (blk + x.stride >= x.n_blocks) return true;
+        return res_blocks<NTW, NC, D, ROWS, Q, PLAIN, QI + 1>(a, x, blk0, L, wlane, chunk_bytes, A, slot_off, t_blk, wave);
+    } else {
+        return false;
+    }
+}
+
+template <int NC, int D, int ROWS, int P>
+__device__ __forceinline__ void res_prologue(const ResCtx& x, int64_t blk0, u32x4_t (&A)[D][4]) {
+    if constexpr (P < D) {
+        const ResIssue t = res_target<NC, ROWS>(x, blk0 + (P / NC) * x.stride, P % NC);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) res_issue1(t, kk, A[P][kk]);
+        res_prologue<NC, D, ROWS, P + 1>(x, blk0, A);
+    }
+}
+
+template <int NTW, int NC, int CS, int COLSPLIT, int D, bool PLAIN>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_res_kernel(const MfmaGemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    static_assert(D % NC == 0 || NC % D == 0, "ring slots must line up from one super-iteration to the next");
+    constexpr int Q = D > NC ? D / NC : 1;              // row blocks per super-iteration
+    constexpr int NWG_T = NTW * CS;                     // 32-column tiles this workgroup produces
+    constexpr int kRows = 256 / CS;                     // rows per block
+    constexpr int kChunkBytes = NWG_T * 32 * 128;       // one 64-k chunk of this workgroup's weight rows
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l32 = lane & 31;
+    const int rgroup = wave / CS, t0 = (wave % CS) * NTW;
+    // partners (the COLSPLIT column shares of the same rows) sit on the same XCD: block b runs on XCD b % 8, so the partner
+    // of b is b + 8.  pair = which sequence of row blocks, share = which columns.
+    const int bid = blockIdx.x;
+    const int share = COLSPLIT == 1 ? 0 : (bid >> 3) % COLSPLIT;
+    const int pair = COLSPLIT == 1 ? bid : (bid >> 3) / COLSPLIT * 8 + (bid & 7);
+    const int n_pairs = COLSPLIT == 1 ? (int)gridDim.x : (int)gridDim.x / COLSPLIT;
+    const int n_wg0 = share * NWG_T * 32;               // first global column of this workgroup
+    const int chunks0 = (a.K[0] + kChunkK - 1) / kChunkK;
+
+    // ---- stage ALL weights of this workgroup's columns once: [chunk][row n][8 slots of 16 bytes, slot ^ ((n >> 1) & 7)]
+    for (int c = 0; c < NC; ++c) {
+        const bool second = c >= chunks0;
+        const bf16_t* w = second ? a.Wt[1] : a.Wt[0];
+        const int64_t ldw = second ? a.ldw[1] : a.ldw[0];
+        const int k0 = (second ? c - chunks0 : c) * kChunkK;
+        for (int v = tid; v < NWG_T * 32 * 8; v += 512) {
+            const int nl = v >> 3, slot = v & 7;
+            const u32x4_t val = *reinterpret_cast<const u32x4_t*>(w + (int64_t)(n_wg0 + nl) * ldw + k0 + slot * 8);
+            *reinterpret_cast<u32x4_t*>(smem + c * kChunkBytes + nl * 128 + ((slot ^ ((nl >> 1) & 7)) * 16)) = val;
+        }
+    }
+    float* bias_l = reinterpret_cast<float*>(smem + NC * kChunkBytes + 8 * 32 * 80);   // this workgroup's columns (zeros: no bias)
+    for (int n = tid; n < NWG_T * 32; n += 512) bias_l[n] = (a.bias && n_wg0 + n < a.N) ? a.bias[n_wg0 + n] : 0.0f;
+    __syncthreads();                                    // the only barrier of the kernel; every staging load has landed
+    const char* wlane = smem + (t0 * 32 + l32) * 128;
+    const int swz = (l32 >> 1) & 7;                      // (tile * 32 + l32) >> 1 & 7 == (l32 >> 1) & 7
+    int slot_off[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) slot_off[kk] = ((2 * kk + half) ^ swz) * 16;
+
+    ResCtx x;
+    x.A[0] = a.A[0]; x.A[1] = a.pairs > 1 ? a.A[1] : a.A[0];
+    x.lda[0] = a.lda[0]; x.lda[1] = a.pairs > 1 ? a.lda[1] : a.lda[0];
+    x.ldab[0] = (uint32_t)(x.lda[0] * 2); x.ldab[1] = (uint32_t)(x.lda[1] * 2);
+    x.tail[0] = (uint32_t)((a.K[0] + 7) / 8) * 16; x.tail[1] = (uint32_t)(((a.pairs > 1 ? a.K[1] : a.K[0]) + 7) / 8) * 16;
+    const uint32_t rin = (uint32_t)(rgroup * 32 + l32);
+    x.a_voff[0] = rin * x.ldab[0] + (uint32_t)half * 16;
+    x.a_voff[1] = rin * x.ldab[1] + (uint32_t)half * 16;
+    x.M = a.M; x.n_blocks = (a.M + kRows - 1) / kRows; x.stride = n_pairs;
+    x.chunks0 = chunks0; x.K0 = a.K[0]; x.K1 = a.K[1]; x.rotate = g_rot_enabled(a) ? 1 : 0;
+
+    ResLane L;
+    L.lane = lane; L.half = half; L.l32 = l32; L.rgroup = rgroup; L.n_col0 = n_wg0 + t0 * 32;
+    L.scratch = smem + NC * kChunkBytes + wave * (32 * 80);
+    L.bias_w = bias_l + t0 * 32;
+
+    int64_t blk = pair;
+    if (blk >= x.n_blocks) return;                      // more workgroups than row blocks (tiny M): nothing to do
+    u32x4_t A[D][4];
+    res_prologue<NC, D, kRows, 0>(x, blk, A);
+    res_wait<4 * (D - 1)>(A[0]);
+    int t_blk = 0;
+    for (;;) {
+        if (res_blocks<NTW, NC, D, kRows, Q, PLAIN, 0>(a, x, blk, L, wlane, kChunkBytes, A, slot_off, t_blk, wave)) break;
+        blk += Q * x.stride;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the loads issued past the last block (zero-byte descriptors)
+}
+
+template <int NTW, int NC, int CS, int COLSPLIT, bool PLAIN>
+static hipError_t launch_mfma_res_p(const MfmaGemmArgs& a, hipStream_t s);
+
+template <int NTW, int NC, int CS, int COLSPLIT>
+static hipError_t launch_mfma_res(const MfmaGemmArgs& a, hipStream_t s) {
+    const bool plain = !a.out_f32 && !a.row_scale && !a.addend && !a.out_gate;
+    return plain ? launch_mfma_res_p<NTW, NC, CS, COLSPLIT, true>(a, s) : launch_mfma_res_p<NTW, NC, CS, COLSPLIT, false>(a, s);
+}
+
+template <int NTW, int NC, int CS, int COLSPLIT, bool PLAIN>
+static hipError_t launch_mfma_res_p(const MfmaGemmArgs& a, hipStream_t s) {
+    // ring depth: D | NC or NC | D (slot arithmetic)
+#ifdef DGLL_RES_D
+    constexpr int D = (NC % DGLL_RES_D == 0 || DGLL_RES_D % NC == 0) ? DGLL_RES_D : NC;    // probe builds: forced ring depth
+#else
+    constexpr int D = 1;      // measured (tools/probes/res_trace.hip, D = 1 / 2 / 4 / 8): 0.954 / 1.066 / 1.089 / 1.108 ms -- see DESIGN.md 4.3
+#endif
+    constexpr int NWG_T = NTW * CS;
+    const size_t lds = (size_t)NC * NWG_T * 32 * 128 + 8 * 32 * 80 + NWG_T * 32 * 4;
+    auto kern = &gemm_bf16_res_kernel<NTW, NC, CS, COLSPLIT, D, PLAIN>;
+    static hipError_t raised = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (raised != hipSuccess) return raised;
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+        if (n_cu <= 0) n_cu = 256;
+        n_cu = n_cu / 16 * 16;                              // whole groups of 8 XCDs x COLSPLIT partners
+        if (n_cu <= 0) n_cu = 16;
+    }
+    const int per_cu = lds > 80 * 1024 ? 1 : 2;
+    dim3 grid((uint32_t)(n_cu * per_cu));
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, a);
+    return hipGetLastError();
+}
+
+// resident-weights kernel for this shape?  nt = 32-column tiles of N, n_chunks = 64-k chunks of K1 + K2
+static bool res_applies(int nt, int n_chunks) {
+    if (n_chunks < 1 || n_chunks > 8) return false;
+    if (nt > 4 && n_chunks > 4) return nt <= 8;            // 256 columns x 512 k: two workgroups of 128 columns
+    return (size_t)n_chunks * (nt <= 2 ? 2 : nt <= 4 ? 4 : 8) * 32 * 128 <= 128 * 1024;
+}
+
+static hipError_t launch_mfma_res_dispatch(const MfmaGemmArgs& a, int nt, int n_chunks, hipStream_t s) {
+#define RES_NC(NTW, CS, COLSPLIT)                                                      \
+    switch (n_chunks) {                                                                \
+        case 1: return launch_mfma_res<NTW, 1, CS, COLSPLIT>(a, s);                    \
+        case 2: return launch_mfma_res<NTW, 2, CS, COLSPLIT>(a, s);                    \
+        case 3: return launch_mfma_res<NTW, 3, CS, COLSPLIT>(a, s);                    \
+        case 4: return launch_mfma_res<NTW, 4, CS, COLSPLIT>(a, s);                    \
+        case 5: return launch_mfma_res<NTW, 5, CS, COLSPLIT>(a, s);                    \
+        case 6: return launch_mfma_res<NTW, 6, CS, COLSPLIT>(a, s);                    \
+        case 7: return launch_mfma_res<NTW, 7, CS, COLSPLIT>(a, s);                    \
+        default: return launch_mfma_res<NTW, 8, CS, COLSPLIT>(a, s);                   \
+    }
+    if (nt <= 2) { RES_NC(2, 1, 1) }                        // N <= 64: one wave per row group, all columns
+    if (nt <= 4) { RES_NC(4, 1, 1) }                        // N <= 128
+    if (n_chunks <= 4) { RES_NC(4, 2, 1) }                  // N <= 256, K <= 256: two waves per row group
+    RES_NC(4, 1, 2)                                         // N <= 256, K <= 512: two workgroups per row block
+#undef RES_NC
+}
+
 template <int NT, int NC>
 static hipError_t launch_mfma_w8_nc(const MfmaGemmArgs& a, hipStream_t s) {
     const size_t lds = std::max<size_t>(2 * (size_t)NT * 32 * kWPitch, (size_t)8 * 32 * (NT * 64 + 16));
@@ -778,10 +1188,16 @@ static int transform_bf16_impl(void* stream, const void* A1, int64_t lda1, int K
     const int nt = (N + 31) / 32;
     hipError_t e;
     const int n_chunks = (K1 + kChunkK - 1) / kChunkK + (A2 ? (K2 + kChunkK - 1) / kChunkK : 0);
-    a.no_rotate = g_tune_mfma_kperm == 2;      // 2: persistent kernel without chunk rotation, 3: persistent kernel always
+    a.no_rotate = g_tune_mfma_kperm == 2;
     // Which kernel: measured on MI355X at M = 2.45 M (tools/transform_probe.py, interleaved): the persistent 8-wave kernel wins
     // where a block carries a long reduction (K1 + K2 = 512: 1.15 vs 1.2 - 1.4 ms) or few output columns (N <= 64: 0.67 vs
     // 0.72 ms); the 4-wave kernel wins the short single products (K = 256 -> 256: 0.82 vs 0.86 ms; K = 100: 0.73 vs 0.89 ms).
+    if ((g_tune_mfma_kperm == 0 || g_tune_mfma_kperm == 4) && !a.mask && res_applies(nt, n_chunks) &&
+        a.ldw[0] == (a.pairs > 1 ? a.ldw[1] : a.ldw[0])) {
+        e = launch_mfma_res_dispatch(a, nt, n_chunks, s);
+        if (e != hipSuccess) return hip_fail(e, "gemm_bf16_res_kernel launch");
+        return DGLL_OK;
+    }
     const bool use_w8 = g_tune_mfma_kperm == 0 ? (n_chunks >= 8 || nt <= 2) : g_tune_mfma_kperm != 1;
     if (!use_w8 || a.mask || n_chunks > 8) {   // also: the input-mask form and reductions longer than 512 (rolled loop)
         if (nt <= 2) e = launch_mfma<2>(a, s);

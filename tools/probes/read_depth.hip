@@ -1,0 +1,60 @@
+// Micro-benchmark: HBM read rate vs (waves per CU) x (loads in flight per wave), persistent grid, fragment-shaped loads of
+// two [M, 256] bf16 operands (the fused transform's activation traffic: 8 chunks of 128 bytes per row group).
+//   DEPTH = chunks in flight per wave (4 loads each); WPB = waves per block; one block per CU (LDS-limited).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+
+template <int DEPTH, int WPB>
+__global__ __launch_bounds__(64 * WPB) void rd(const uint4* __restrict__ x0, const uint4* __restrict__ x1, int64_t M, uint32_t* out) {
+    extern __shared__ char lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t groups = M / 32;
+    uint32_t acc = 0;
+    for (int64_t g = (int64_t)blockIdx.x * WPB + wave; g < groups; g += (int64_t)gridDim.x * WPB) {
+        const int64_t row = g * 32 + (lane & 31);
+        uint4 v[DEPTH][4];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            if (c >= DEPTH) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) acc += v[c % DEPTH][kk].x ^ v[c % DEPTH][kk].w;
+            }
+            const uint4* x = c < 4 ? x0 : x1;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) v[c % DEPTH][kk] = x[row * 32 + (c & 3) * 8 + 2 * kk + (lane >> 5)];
+        }
+#pragma unroll
+        for (int c = 8; c < 8 + DEPTH; ++c)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) acc += v[c % DEPTH][kk].x ^ v[c % DEPTH][kk].w;
+    }
+    if (acc == 0x12345678u) out[0] = acc + lds[0];
+}
+
+template <int DEPTH, int WPB>
+void run(const uint4* x0, const uint4* x1, int64_t M, uint32_t* out, int blocks_per_cu) {
+    const size_t lds = blocks_per_cu == 1 ? 100 * 1024 : (blocks_per_cu == 2 ? 70 * 1024 : 36 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&rd<DEPTH, WPB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    dim3 grid(256 * blocks_per_cu);
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    rd<DEPTH, WPB><<<grid, 64 * WPB, lds>>>(x0, x1, M, out);
+    hipEventRecord(a);
+    for (int i = 0; i < 5; ++i) rd<DEPTH, WPB><<<grid, 64 * WPB, lds>>>(x0, x1, M, out);
+    hipEventRecord(b); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b); ms /= 5;
+    printf("  %2d waves/CU (%d blocks x %d waves), %d chunks (%2d KB) in flight per wave: %.3f ms  %.2f TB/s\n",
+           WPB * blocks_per_cu, blocks_per_cu, WPB, DEPTH, DEPTH * 4, ms, (double)M * 1024 / 1e9 / ms);
+}
+
+int main() {
+    const int64_t M = 2449029 / 32 * 32;
+    uint4 *x0, *x1; uint32_t* out;
+    hipMalloc(&x0, M * 512); hipMalloc(&x1, M * 512); hipMalloc(&out, 4);
+    hipMemset(x0, 1, M * 512); hipMemset(x1, 2, M * 512);
+    printf("two operands of %.2f GB\n", (double)M * 512 / 1e9);
+    run<1, 8>(x0, x1, M, out, 1); run<2, 8>(x0, x1, M, out, 1); run<4, 8>(x0, x1, M, out, 1); run<6, 8>(x0, x1, M, out, 1);
+    run<1, 8>(x0, x1, M, out, 2); run<2, 8>(x0, x1, M, out, 2); run<4, 8>(x0, x1, M, out, 2);
+    run<1, 8>(x0, x1, M, out, 4); run<2, 8>(x0, x1, M, out, 4);
+    return 0;
+}
