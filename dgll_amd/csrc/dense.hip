@@ -672,44 +672,47 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_w8_kernel(const MfmaGemmArgs
 
 // =====================================================================================================================
 // Resident-weights variant ("res"): the weights of the WHOLE reduction live in LDS for the lifetime of a persistent
-// workgroup (128 KiB, 128-byte rows XOR-swizzled: no padding), staged once.  What that removes from the main loop:
-//   * the per-chunk weight fetch + stage + s_barrier -- waves never synchronise with each other again, so a wave is never
-//     parked behind the slowest load of seven others (the 8-wave kernel above: 50 % of wave cycles in s_waitcnt / barrier);
-//   * the weight loads from every wave's in-order vmcnt queue -- with only activation loads in the queue a D-deep in-place
-//     register ring really runs D chunks ahead (`s_waitcnt vmcnt(4 (D - 1))`); with a weight load issued every phase, waiting
-//     for it drains every older activation load and the ring collapses to one chunk of run-ahead.
-// A wave owns 32 rows x 128 columns (64 accumulator registers), which leaves room for a 6-deep ring (24 KiB of activation
-// loads in flight per wave, 192 KiB per CU).  128 KiB of LDS holds NC x NWG x 128 bytes: all 256 columns for NC <= 4 chunks
-// (two waves per row group, CS = 2), 128 columns for NC = 8 (COLSPLIT = 2: two workgroups, on the same XCD and walking the
-// same row blocks, each produce half of the columns; the partner's activation reads hit that XCD's L2).
-// The epilogue transposes one 32 x 32 tile at a time through a wave-private 2.5 KiB LDS scratch: no barrier either.
-template <int OUTSTANDING>
-__device__ __forceinline__ void res_wait(u32x4_t (&areg)[4]) {
-    static_assert(OUTSTANDING % 4 == 0 && OUTSTANDING <= 28, "whole activation sets, at most seven in flight");
-#define RES_WAIT_ASM(TXT) asm volatile(TXT : "+v"(areg[0]), "+v"(areg[1]), "+v"(areg[2]), "+v"(areg[3]) :: "memory");
-    if constexpr (OUTSTANDING == 0) { RES_WAIT_ASM("s_waitcnt vmcnt(0)") }
-    else if constexpr (OUTSTANDING == 4) { RES_WAIT_ASM("s_waitcnt vmcnt(4)") }
-    else if constexpr (OUTSTANDING == 8) { RES_WAIT_ASM("s_waitcnt vmcnt(8)") }
-    else if constexpr (OUTSTANDING == 12) { RES_WAIT_ASM("s_waitcnt vmcnt(12)") }
-    else if constexpr (OUTSTANDING == 16) { RES_WAIT_ASM("s_waitcnt vmcnt(16)") }
-    else if constexpr (OUTSTANDING == 20) { RES_WAIT_ASM("s_waitcnt vmcnt(20)") }
-    else if constexpr (OUTSTANDING == 24) { RES_WAIT_ASM("s_waitcnt vmcnt(24)") }
-    else { RES_WAIT_ASM("s_waitcnt vmcnt(28)") }
-#undef RES_WAIT_ASM
+// workgroup (128 KiB, 128-byte rows XOR-swizzled: no padding), staged once; the main loop has no barrier and no weight
+// traffic.  A wave owns RG row groups of 32 rows x NTW column tiles of 32 (RG = 2, NTW = 4: 64 rows x 128 columns, 128
+// accumulator registers; every weight fragment read from LDS feeds RG MFMAs).  128 KiB of LDS holds NC x NWG x 128 bytes:
+// all 256 columns for NC <= 4 chunks (two waves per row group, CS = 2), 128 columns for NC = 8 (COLSPLIT = 2: two
+// workgroups, on the same XCD and walking the same row blocks, each produce half of the columns; the partner's activation
+// reads hit that XCD's L2).  What measurement settled, in the order it was found (tools/probes/):
+//   * the epilogue must not issue a vector-memory LOAD the compiler can see (bias, row scale, gate, addend): hipcc waits
+//     for it with vmcnt(0) -- it cannot see the inline-asm activation loads queued ahead of it -- and drains the prefetch of
+//     the next block (19 k of a block's 34 k cycles).  PLAIN epilogues read the bias from LDS and load nothing;
+//   * activation loads in the MFMA fragment shape (lane = row: 32 rows x 32 bytes per instruction, four instructions per
+//     128-byte line) cap the L1 path at 6.5-7 TB/s and get slower with every chunk in flight; every row block is read twice
+//     here (two workgroups or two waves), hence the 3.3 TB/s plateau of every earlier variant.  Loads are "half-line shaped"
+//     now (16 rows x 64 contiguous bytes per instruction, 10-12 TB/s at L1) and a wave-private 2 KiB LDS tile turns two
+//     of them into the fragments;
+//   * ring depth: one or two chunks.  More in flight only queues (D = 1 / 2 / 4 / 8: 0.95 / 1.07 / 1.09 / 1.11 ms with
+//     fragment loads; 0.92 / 0.87 / 0.88 with half-line loads);
+//   * LDS bandwidth is the next limit (weights 16 KiB + tile 8 KiB per wave and chunk at RG = 1: 83 % of 128 B/clk), which
+//     is what RG = 2 is for.
+// The epilogue transposes one 32 x 32 tile at a time through the same wave-private LDS tile: no barrier either.
+// registers of a chunk (per ring slot): index 4 g + 2 h + j -- row group g, 32-k half h, rows 16 j ..
+template <int OUTSTANDING, int NR>
+__device__ __forceinline__ void res_wait(u32x4_t (&r)[NR]) {
+    static_assert(NR == 4 || NR == 8, "one or two row groups per wave");
+    static_assert(OUTSTANDING >= 0 && OUTSTANDING < 64, "vmcnt is a 6-bit counter");
+    if constexpr (NR == 4)
+        asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) : "i"(OUTSTANDING) : "memory");
+    else
+        asm volatile("s_waitcnt vmcnt(%8)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])
+                     : "i"(OUTSTANDING) : "memory");
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// ---- the steady-state ring --------------------------------------------------------------------------------------------
+// ---- the ring ---------------------------------------------------------------------------------------------------------
 // Every phase consumes one 64-k chunk from ring slot P % D and refills that slot with the chunk D phases ahead -- ACROSS row
-// blocks: the tail phases of a block already fetch the head of the next one, so the number of loads in flight never drops to
-// zero at a block boundary and never jumps by a whole block's worth after it (the first version issued the next block's
-// D x 4 loads in one burst after the last phase: 6.6 k cycles of issue back-pressure per block, tools/probes/res_trace.hip).
-// Slot arithmetic stays compile-time because the loop body is a "super-iteration" of Q x NC phases with D | Q x NC.
+// blocks: the tail phases of a block already fetch the head of the next one.  Slot arithmetic stays compile-time because the
+// loop body is a "super-iteration" of Q x NC phases with D | Q x NC.
 struct ResCtx {                 // wave-uniform (SGPRs) except a_voff
     const bf16_t* A[2];
     int64_t lda[2];
     uint32_t ldab[2], tail[2];  // bytes per row; bytes of a row that are read (K rounded up to 8 elements)
-    uint32_t a_voff[2];         // per lane: its row inside the block (+ its 16-byte half)
+    uint32_t a_voff[2][4];      // per lane [operand][2 g + j]: row 32 g + 16 j + lane / 4 of the wave's rows, piece lane % 4 of a half line
     int64_t M, n_blocks, stride;
     int chunks0, K0, K1, rotate;
 };
@@ -732,19 +735,27 @@ __device__ __forceinline__ int res_rot(const ResCtx& x, int64_t blk, int c) {   
     return c >= NC ? c - NC : c;
 }
 
-__device__ __forceinline__ void res_trim(const ResCtx& x, int cc, int half, u32x4_t (&areg)[4]) {   // see w8_trim_acts
+// register 4 g + 2 h + j of a chunk: for lane l, the 16-byte piece l % 4 of the 64-byte half h of row 32 g + 16 j + l / 4
+template <int NR>
+__device__ __forceinline__ void res_trim(const ResCtx& x, int cc, int lane, u32x4_t (&areg)[NR]) {   // zero what lies past K
     const bool second = cc >= x.chunks0;
     const int k0 = (second ? cc - x.chunks0 : cc) * kChunkK;
     const int K = second ? x.K1 : x.K0;
-    if (k0 + kChunkK <= K) return;
+    if (k0 + kChunkK <= K) return;                    // wave-uniform: only an operand's last chunk can be ragged
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-        const uint4 v = mask_tail(make_uint4(areg[kk][0], areg[kk][1], areg[kk][2], areg[kk][3]), K - (k0 + half * 8 + kk * 16));
-        areg[kk] = u32x4_t{v.x, v.y, v.z, v.w};
+    for (int i = 0; i < NR; ++i) {
+        const uint4 v = mask_tail(make_uint4(areg[i][0], areg[i][1], areg[i][2], areg[i][3]), K - (k0 + ((i >> 1) & 1) * 32 + (lane & 3) * 8));
+        areg[i] = u32x4_t{v.x, v.y, v.z, v.w};
     }
 }
 
-struct ResIssue { i32x4_t r; uint32_t voff, k0b; };
+struct ResIssue { i32x4_t r; uint32_t voff[4], k0b; };
+struct ResLane {             // per-lane coordinates + the wave's LDS tile (transposition buffer of the main loop, staging of the epilogue)
+    int lane, half, l32, rgroup, n_col0;
+    int tw_off[2], tr_off[2];   // tile byte offsets: this lane's two writes (j) and two fragment reads (e) of a 32-k half
+    char* scratch;
+    const float* bias_w;
+};
 
 template <int NC, int ROWS>
 __device__ __forceinline__ ResIssue res_target(const ResCtx& x, int64_t blk, int c) {
@@ -752,59 +763,91 @@ __device__ __forceinline__ ResIssue res_target(const ResCtx& x, int64_t blk, int
     const bool second = cc >= x.chunks0;
     ResIssue t;
     t.r = res_rsrc<ROWS>(x, second, blk);
-    t.voff = second ? x.a_voff[1] : x.a_voff[0];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t.voff[i] = second ? x.a_voff[1][i] : x.a_voff[0][i];
     t.k0b = (uint32_t)((second ? cc - x.chunks0 : cc) * kChunkK * 2);
     return t;
 }
 
-__device__ __forceinline__ void res_issue1(const ResIssue& t, int kk, u32x4_t& dst) {
-    switch (kk) {
-        case 0: asm_bufload16<0>(dst, t.voff, t.r, t.k0b); break;
-        case 1: asm_bufload16<32>(dst, t.voff, t.r, t.k0b); break;
-        case 2: asm_bufload16<64>(dst, t.voff, t.r, t.k0b); break;
-        default: asm_bufload16<96>(dst, t.voff, t.r, t.k0b); break;
-    }
+__device__ __forceinline__ void res_issue1(const ResIssue& t, int i, u32x4_t& dst) {   // register i = 4 g + 2 h + j
+    const uint32_t voff = t.voff[(i >> 2) * 2 + (i & 1)];
+    if ((i & 2) == 0) asm_bufload16<0>(dst, voff, t.r, t.k0b);
+    else asm_bufload16<64>(dst, voff, t.r, t.k0b);
 }
 
 #ifdef DGLL_RES_TRACE
-#define RES_TRACE(EV) do { if (a.trace && blockIdx.x < 16 && t_blk < 4 && lane == 0)                                     \
+#define RES_TRACE(EV) do { if (a.trace && blockIdx.x < 16 && t_blk < 4 && lane == 0 && wave < 8)                                   \
         a.trace[(((int64_t)blockIdx.x * 8 + wave) * 4 + t_blk) * 16 + (EV)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define RES_TRACE(EV) do { } while (0)
 #endif
 
-// phase P of the super-iteration that starts at row block blk0: chunk P % NC of block blk0 + (P / NC) stride
-template <int NTW, int NC, int D, int ROWS, int P>
-__device__ __forceinline__ void res_phase(const MfmaGemmArgs& a, const ResCtx& x, int64_t blk0, int half, const char* wlane,
-                                          int chunk_bytes, f32x16_t (&acc)[NTW], u32x4_t (&A)[D][4], const int (&slot_off)[4],
-                                          int t_blk, int lane, int wave) {
-    constexpr int S = P % D;
-    const int cc = res_rot<NC>(x, blk0 + (P / NC) * x.stride, P % NC);
-    res_trim(x, cc, half, A[S]);
-    const ResIssue nxt = res_target<NC, ROWS>(x, blk0 + ((P + D) / NC) * x.stride, (P + D) % NC);
-    const char* base = wlane + cc * chunk_bytes;
+// One 32-k half of a chunk through the wave's LDS tile ([32 rows][64 bytes], 16-byte slot q of row r at q ^ ((r >> 1) & 3):
+// conflict-free both ways): the two landed registers of every row group go in, two MFMA fragments (lane = row) come out, and
+// the registers are refilled by the loads of the chunk D phases ahead.  One wave, in-order LDS: write -> read -> next write
+// needs no wait and no barrier.
+template <int RG, int H>
+__device__ __forceinline__ void res_transpose(const ResLane& L, u32x4_t (&areg)[4 * RG], const ResIssue& nxt, uint4 (&f)[RG][2]) {
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-        const bf16x8_t xf = __builtin_bit_cast(bf16x8_t, A[S][kk]);
-#pragma unroll
-        for (int t = 0; t < NTW; ++t) {
-            const uint4 wv = *reinterpret_cast<const uint4*>(base + t * 32 * 128 + slot_off[kk]);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wv), xf, acc[t], 0, 0, 0);
-        }
-        res_issue1(nxt, kk, A[S][kk]);              // into the register its last MFMA just vacated
+    for (int g = 0; g < RG; ++g) {
+        *reinterpret_cast<u32x4_t*>(L.scratch + L.tw_off[0]) = areg[4 * g + 2 * H];
+        *reinterpret_cast<u32x4_t*>(L.scratch + L.tw_off[1]) = areg[4 * g + 2 * H + 1];
+        f[g][0] = *reinterpret_cast<const uint4*>(L.scratch + L.tr_off[0]);
+        f[g][1] = *reinterpret_cast<const uint4*>(L.scratch + L.tr_off[1]);
+        res_issue1(nxt, 4 * g + 2 * H, areg[4 * g + 2 * H]);
+        res_issue1(nxt, 4 * g + 2 * H + 1, areg[4 * g + 2 * H + 1]);
     }
-    res_wait<4 * (D - 1)>(A[(P + 1) % D]);          // the next phase's chunk has landed; D - 1 younger sets may still fly
-    RES_TRACE(2 + P % NC);
-    (void)t_blk; (void)lane; (void)wave; (void)a;
 }
 
-template <int NTW, int NC, int D, int ROWS, int P, int PEND>
-__device__ __forceinline__ void res_phases(const MfmaGemmArgs& a, const ResCtx& x, int64_t blk0, int half, const char* wlane,
-                                           int chunk_bytes, f32x16_t (&acc)[NTW], u32x4_t (&A)[D][4], const int (&slot_off)[4],
-                                           int t_blk, int lane, int wave) {
+template <int NTW, int RG, int H>
+__device__ __forceinline__ void res_mfmas(const char* base, const int (&slot_off)[4], const uint4 (&f)[RG][2], f32x16_t (&acc)[RG][NTW]) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            const bf16x8_t wv = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(base + t * 32 * 128 + slot_off[2 * H + e]));
+#pragma unroll
+            for (int g = 0; g < RG; ++g)
+#if defined(DGLL_RES_ABL) && (DGLL_RES_ABL & 2)
+                if (t == 0) acc[g][t][e] += __builtin_bit_cast(float, f[g][e].x) + __builtin_bit_cast(float, ((const uint4*)(base + t * 32 * 128 + slot_off[2 * H + e]))->x);
+#else
+                acc[g][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, __builtin_bit_cast(bf16x8_t, f[g][e]), acc[g][t], 0, 0, 0);
+#endif
+        }
+    }
+}
+
+// phase P of the super-iteration that starts at row block blk0: chunk P % NC of block blk0 + (P / NC) stride.
+// (Measured and dropped: software-pipelining the halves -- second half transposed before the first half's MFMAs, the next
+// chunk's first half before the second half's -- was 5-7 % SLOWER; the two extra scheduling fences cost more than the LDS
+// round trips they hide, which the other waves of the SIMD already cover.)
+template <int NTW, int RG, int NC, int D, int ROWS, int P>
+__device__ __forceinline__ void res_phase(const MfmaGemmArgs& a, const ResCtx& x, int64_t blk0, const ResLane& L, const char* wlane,
+                                          int chunk_bytes, f32x16_t (&acc)[RG][NTW], u32x4_t (&A)[D][4 * RG], const int (&slot_off)[4],
+                                          int t_blk, int wave) {
+    constexpr int S = P % D;
+    const int lane = L.lane;
+    const int cc = res_rot<NC>(x, blk0 + (P / NC) * x.stride, P % NC);
+    res_trim<4 * RG>(x, cc, lane, A[S]);
+    const ResIssue nxt = res_target<NC, ROWS>(x, blk0 + ((P + D) / NC) * x.stride, (P + D) % NC);
+    const char* base = wlane + cc * chunk_bytes;
+    uint4 f[RG][2];
+    res_transpose<RG, 0>(L, A[S], nxt, f);
+    res_mfmas<NTW, RG, 0>(base, slot_off, f, acc);
+    res_transpose<RG, 1>(L, A[S], nxt, f);
+    res_mfmas<NTW, RG, 1>(base, slot_off, f, acc);
+    res_wait<4 * RG * (D - 1), 4 * RG>(A[(P + 1) % D]);   // the next phase's chunk has landed; D - 1 younger sets may still fly
+    RES_TRACE(2 + P % NC);
+    (void)t_blk; (void)wave; (void)a;
+}
+
+template <int NTW, int RG, int NC, int D, int ROWS, int P, int PEND>
+__device__ __forceinline__ void res_phases(const MfmaGemmArgs& a, const ResCtx& x, int64_t blk0, const ResLane& L, const char* wlane,
+                                           int chunk_bytes, f32x16_t (&acc)[RG][NTW], u32x4_t (&A)[D][4 * RG], const int (&slot_off)[4],
+                                           int t_blk, int wave) {
     if constexpr (P < PEND) {
-        res_phase<NTW, NC, D, ROWS, P>(a, x, blk0, half, wlane, chunk_bytes, acc, A, slot_off, t_blk, lane, wave);
-        res_phases<NTW, NC, D, ROWS, P + 1, PEND>(a, x, blk0, half, wlane, chunk_bytes, acc, A, slot_off, t_blk, lane, wave);
+        res_phase<NTW, RG, NC, D, ROWS, P>(a, x, blk0, L, wlane, chunk_bytes, acc, A, slot_off, t_blk, wave);
+        res_phases<NTW, RG, NC, D, ROWS, P + 1, PEND>(a, x, blk0, L, wlane, chunk_bytes, acc, A, slot_off, t_blk, wave);
     }
 }
 
@@ -867,8 +910,8 @@ __device__ __forceinline__ void res_epilogue(const MfmaGemmArgs& a, char* scratc
             }
             *reinterpret_cast<uint2*>(scratch + l32 * kPitch + nl * 2) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the whole wave's tile is in the scratch (one wave: no barrier)
-        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_wave_barrier();                       // compiler fence only: one wave's LDS operations execute in order,
+                                                               // so the reads below see the whole tile without a wait
 #pragma unroll
         for (int it = 0; it < 2; ++it) {                       // 32 rows x 4 vectors of 16 bytes = 128 vectors, two per lane
             const int idx = it * kWave + lane;
@@ -878,6 +921,9 @@ __device__ __forceinline__ void res_epilogue(const MfmaGemmArgs& a, char* scratc
             if (grow >= a.M || n >= a.N) continue;
             uint4 d = *reinterpret_cast<const uint4*>(scratch + r * kPitch + nl * 2);
             bf16_t* o = static_cast<bf16_t*>(a.out) + grow * a.ldo + n;
+#if defined(DGLL_RES_ABL) && (DGLL_RES_ABL & 1)
+            if (d.x != 0x12345678u) continue;                          // probe: no stores
+#endif
             if (n + 8 <= a.N && vec_rows) {
                 if constexpr (!PLAIN) { if (a.out_gate) d = relu_mask(d, *reinterpret_cast<const uint4*>(a.out_gate + grow * a.ldgate + n)); }
                 *reinterpret_cast<uint4*>(o) = d;
@@ -892,63 +938,68 @@ __device__ __forceinline__ void res_epilogue(const MfmaGemmArgs& a, char* scratc
                 }
             }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // reads done before the next tile overwrites the scratch
-        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_wave_barrier();                       // (same: the next tile's writes queue behind these reads)
     }
 }
 
-struct ResLane { int lane, half, l32, rgroup, n_col0; char* scratch; const float* bias_w; };
-
 // blocks QI .. Q-1 of a super-iteration; true = the last row block of this workgroup has been written
-template <int NTW, int NC, int D, int ROWS, int Q, bool PLAIN, int QI>
+template <int NTW, int RG, int NC, int D, int ROWS, int Q, bool PLAIN, int QI>
 __device__ __forceinline__ bool res_blocks(const MfmaGemmArgs& a, const ResCtx& x, int64_t blk0, const ResLane& L, const char* wlane,
-                                           int chunk_bytes, u32x4_t (&A)[D][4], const int (&slot_off)[4], int& t_blk, int wave) {
+                                           int chunk_bytes, u32x4_t (&A)[D][4 * RG], const int (&slot_off)[4], int& t_blk, int wave) {
     if constexpr (QI < Q) {
         const int lane = L.lane;
         RES_TRACE(0);
-        f32x16_t acc[NTW];
+        f32x16_t acc[RG][NTW];
 #pragma unroll
-        for (int t = 0; t < NTW; ++t)
+        for (int g = 0; g < RG; ++g)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-        res_phases<NTW, NC, D, ROWS, QI * NC, QI * NC + NC>(a, x, blk0, L.half, wlane, chunk_bytes, acc, A, slot_off, t_blk, lane, wave);
+            for (int t = 0; t < NTW; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[g][t][r] = 0.0f;
+        res_phases<NTW, RG, NC, D, ROWS, QI * NC, QI * NC + NC>(a, x, blk0, L, wlane, chunk_bytes, acc, A, slot_off, t_blk, wave);
         const int64_t blk = blk0 + QI * x.stride;
-        const int64_t m0 = blk * ROWS + L.rgroup * 32;
-        const int64_t row = m0 + L.l32;
-        const int64_t row_ld = row < a.M ? row : a.M - 1;
-        {   // opaque copies of the lane coordinates: what the epilogue derives from them (staging addresses, the store loop's
+        RES_TRACE(11);
+#pragma unroll
+        for (int g = 0; g < RG; ++g) {
+            const int64_t m0 = blk * ROWS + (L.rgroup * RG + g) * 32;
+            const int64_t row = m0 + L.l32;
+            const int64_t row_ld = row < a.M ? row : a.M - 1;
+            // opaque copies of the lane coordinates: what the epilogue derives from them (staging addresses, the store loop's
             // row / column pairs) would otherwise be hoisted out of the persistent loop and stay live through the main loop
             int e_lane = L.lane, e_half = L.half, e_l32 = L.l32, e_n0 = L.n_col0;
             asm volatile("" : "+v"(e_lane), "+v"(e_half), "+v"(e_l32), "+s"(e_n0));
-            RES_TRACE(11);
-            res_epilogue<NTW, PLAIN>(a, L.scratch, L.bias_w, acc, m0, row, row_ld, e_n0, e_lane, e_half, e_l32);
-            RES_TRACE(12);
+            res_epilogue<NTW, PLAIN>(a, L.scratch, L.bias_w, acc[g], m0, row, row_ld, e_n0, e_lane, e_half, e_l32);
         }
+        RES_TRACE(12);
         ++t_blk;
         if (blk + x.stride >= x.n_blocks) return true;
-        return res_blocks<NTW, NC, D, ROWS, Q, PLAIN, QI + 1>(a, x, blk0, L, wlane, chunk_bytes, A, slot_off, t_blk, wave);
+        return res_blocks<NTW, RG, NC, D, ROWS, Q, PLAIN, QI + 1>(a, x, blk0, L, wlane, chunk_bytes, A, slot_off, t_blk, wave);
     } else {
         return false;
     }
 }
 
-template <int NC, int D, int ROWS, int P>
-__device__ __forceinline__ void res_prologue(const ResCtx& x, int64_t blk0, u32x4_t (&A)[D][4]) {
+template <int RG, int NC, int D, int ROWS, int P>
+__device__ __forceinline__ void res_prologue(const ResCtx& x, int64_t blk0, u32x4_t (&A)[D][4 * RG]) {
     if constexpr (P < D) {
         const ResIssue t = res_target<NC, ROWS>(x, blk0 + (P / NC) * x.stride, P % NC);
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) res_issue1(t, kk, A[P][kk]);
-        res_prologue<NC, D, ROWS, P + 1>(x, blk0, A);
+        for (int h = 0; h < 2; ++h)                      // queue order: (chunk, h0) before (chunk, h1), as the phases issue them
+#pragma unroll
+            for (int g = 0; g < RG; ++g)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) res_issue1(t, 4 * g + 2 * h + j, A[P][4 * g + 2 * h + j]);
+        res_prologue<RG, NC, D, ROWS, P + 1>(x, blk0, A);
     }
 }
 
-template <int NTW, int NC, int CS, int COLSPLIT, int D, bool PLAIN>
-__global__ __launch_bounds__(512, 2) void gemm_bf16_res_kernel(const MfmaGemmArgs a) {
+template <int NTW, int RG, int NC, int CS, int COLSPLIT, int D, bool PLAIN, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_bf16_res_kernel(const MfmaGemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     static_assert(D % NC == 0 || NC % D == 0, "ring slots must line up from one super-iteration to the next");
     constexpr int Q = D > NC ? D / NC : 1;              // row blocks per super-iteration
     constexpr int NWG_T = NTW * CS;                     // 32-column tiles this workgroup produces
-    constexpr int kRows = 256 / CS;                     // rows per block
+    constexpr int kRows = NW * 32 * RG / CS;            // rows per block
     constexpr int kChunkBytes = NWG_T * 32 * 128;       // one 64-k chunk of this workgroup's weight rows
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -969,14 +1020,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_res_kernel(const MfmaGemmArg
         const bf16_t* w = second ? a.Wt[1] : a.Wt[0];
         const int64_t ldw = second ? a.ldw[1] : a.ldw[0];
         const int k0 = (second ? c - chunks0 : c) * kChunkK;
-        for (int v = tid; v < NWG_T * 32 * 8; v += 512) {
+        for (int v = tid; v < NWG_T * 32 * 8; v += NW * 64) {
             const int nl = v >> 3, slot = v & 7;
             const u32x4_t val = *reinterpret_cast<const u32x4_t*>(w + (int64_t)(n_wg0 + nl) * ldw + k0 + slot * 8);
             *reinterpret_cast<u32x4_t*>(smem + c * kChunkBytes + nl * 128 + ((slot ^ ((nl >> 1) & 7)) * 16)) = val;
         }
     }
-    float* bias_l = reinterpret_cast<float*>(smem + NC * kChunkBytes + 8 * 32 * 80);   // this workgroup's columns (zeros: no bias)
-    for (int n = tid; n < NWG_T * 32; n += 512) bias_l[n] = (a.bias && n_wg0 + n < a.N) ? a.bias[n_wg0 + n] : 0.0f;
+    float* bias_l = reinterpret_cast<float*>(smem + NC * kChunkBytes + NW * 32 * 80);   // this workgroup's columns (zeros: no bias)
+    for (int n = tid; n < NWG_T * 32; n += NW * 64) bias_l[n] = (a.bias && n_wg0 + n < a.N) ? a.bias[n_wg0 + n] : 0.0f;
     __syncthreads();                                    // the only barrier of the kernel; every staging load has landed
     const char* wlane = smem + (t0 * 32 + l32) * 128;
     const int swz = (l32 >> 1) & 7;                      // (tile * 32 + l32) >> 1 & 7 == (l32 >> 1) & 7
@@ -989,9 +1040,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_res_kernel(const MfmaGemmArg
     x.lda[0] = a.lda[0]; x.lda[1] = a.pairs > 1 ? a.lda[1] : a.lda[0];
     x.ldab[0] = (uint32_t)(x.lda[0] * 2); x.ldab[1] = (uint32_t)(x.lda[1] * 2);
     x.tail[0] = (uint32_t)((a.K[0] + 7) / 8) * 16; x.tail[1] = (uint32_t)(((a.pairs > 1 ? a.K[1] : a.K[0]) + 7) / 8) * 16;
-    const uint32_t rin = (uint32_t)(rgroup * 32 + l32);
-    x.a_voff[0] = rin * x.ldab[0] + (uint32_t)half * 16;
-    x.a_voff[1] = rin * x.ldab[1] + (uint32_t)half * 16;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                        // i = 2 g + j
+        const uint32_t rin = (uint32_t)((rgroup * RG + (i >> 1)) * 32 + 16 * (i & 1) + (lane >> 2));
+        x.a_voff[0][i] = rin * x.ldab[0] + (uint32_t)(lane & 3) * 16;
+        x.a_voff[1][i] = rin * x.ldab[1] + (uint32_t)(lane & 3) * 16;
+    }
     x.M = a.M; x.n_blocks = (a.M + kRows - 1) / kRows; x.stride = n_pairs;
     x.chunks0 = chunks0; x.K0 = a.K[0]; x.K1 = a.K[1]; x.rotate = g_rot_enabled(a) ? 1 : 0;
 
@@ -999,15 +1053,21 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_res_kernel(const MfmaGemmArg
     L.lane = lane; L.half = half; L.l32 = l32; L.rgroup = rgroup; L.n_col0 = n_wg0 + t0 * 32;
     L.scratch = smem + NC * kChunkBytes + wave * (32 * 80);
     L.bias_w = bias_l + t0 * 32;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = 16 * j + (lane >> 2);
+        L.tw_off[j] = r * 64 + (((lane & 3) ^ ((r >> 1) & 3)) * 16);
+        L.tr_off[j] = l32 * 64 + (((2 * j + half) ^ ((l32 >> 1) & 3)) * 16);
+    }
 
     int64_t blk = pair;
     if (blk >= x.n_blocks) return;                      // more workgroups than row blocks (tiny M): nothing to do
-    u32x4_t A[D][4];
-    res_prologue<NC, D, kRows, 0>(x, blk, A);
-    res_wait<4 * (D - 1)>(A[0]);
+    u32x4_t A[D][4 * RG];
+    res_prologue<RG, NC, D, kRows, 0>(x, blk, A);
+    res_wait<4 * RG * (D - 1), 4 * RG>(A[0]);
     int t_blk = 0;
     for (;;) {
-        if (res_blocks<NTW, NC, D, kRows, Q, PLAIN, 0>(a, x, blk, L, wlane, kChunkBytes, A, slot_off, t_blk, wave)) break;
+        if (res_blocks<NTW, RG, NC, D, kRows, Q, PLAIN, 0>(a, x, blk, L, wlane, kChunkBytes, A, slot_off, t_blk, wave)) break;
         blk += Q * x.stride;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the loads issued past the last block (zero-byte descriptors)
@@ -1028,11 +1088,21 @@ static hipError_t launch_mfma_res_p(const MfmaGemmArgs& a, hipStream_t s) {
 #ifdef DGLL_RES_D
     constexpr int D = (NC % DGLL_RES_D == 0 || DGLL_RES_D % NC == 0) ? DGLL_RES_D : NC;    // probe builds: forced ring depth
 #else
-    constexpr int D = 1;      // measured (tools/probes/res_trace.hip, D = 1 / 2 / 4 / 8): 0.954 / 1.066 / 1.089 / 1.108 ms -- see DESIGN.md 4.3
+    constexpr int D = 1;      // measured (tools/probes/res_trace.hip): more chunks in flight only queue -- see the header above
+#endif
+#ifdef DGLL_RES_RG
+    constexpr int RG = DGLL_RES_RG;
+#else
+    constexpr int RG = 2;
+#endif
+#ifdef DGLL_RES_NW
+    constexpr int NW = DGLL_RES_NW;
+#else
+    constexpr int NW = 8;
 #endif
     constexpr int NWG_T = NTW * CS;
-    const size_t lds = (size_t)NC * NWG_T * 32 * 128 + 8 * 32 * 80 + NWG_T * 32 * 4;
-    auto kern = &gemm_bf16_res_kernel<NTW, NC, CS, COLSPLIT, D, PLAIN>;
+    const size_t lds = (size_t)NC * NWG_T * 32 * 128 + NW * 32 * 80 + NWG_T * 32 * 4;
+    auto kern = &gemm_bf16_res_kernel<NTW, RG, NC, CS, COLSPLIT, D, PLAIN, NW>;
     static hipError_t raised = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (raised != hipSuccess) return raised;
@@ -1047,7 +1117,7 @@ static hipError_t launch_mfma_res_p(const MfmaGemmArgs& a, hipStream_t s) {
     }
     const int per_cu = lds > 80 * 1024 ? 1 : 2;
     dim3 grid((uint32_t)(n_cu * per_cu));
-    hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, a);
+    hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, s, a);
     return hipGetLastError();
 }
 
