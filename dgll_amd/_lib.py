@@ -83,6 +83,10 @@ SIGNATURES = {
                                              _vp, _i64, _i32, _i64, _i32, _i32, _vp, _vp, _i64, _vp]),
     "dgll_hip_transform_bf16_add": (_i32, [_vp, _vp, _i64, _i32, _vp, _i64, _vp, _i64, _i32, _vp, _i64, _i32, _vp, _i64,
                                            _vp, _i64, _i32, _i64, _i32, _i32, _vp, _vp, _i64, _vp, _vp, _i64]),
+    "dgll_hip_transform_bf16_dual": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _i64, _i32, _vp, _i64, _vp, _i64, _i64, _i32]),
+    "dgll_hip_grad_weight_workspace": (_i64, [_i32, _i32, _i32]),
+    "dgll_hip_grad_weight_bf16": (_i32, [_vp, _vp, _i64, _i32, _vp, _i64, _i32, _vp, _i64, _i32, _i64, _vp, _i64, _i32, _vp, _i64,
+                                         _vp, _i64]),
     "dgll_hip_softmax_xent": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _i64, _vp, _i64, _i32]),
     "dgll_hip_softmax_xent_soft": (_i32, [_vp, _vp, _i64, _i32, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i32]),
     "launch_gcn_fused_kernel": (None, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32]),

@@ -131,6 +131,8 @@ struct MfmaGemmArgs {
     int no_rotate;          // diagnostics: 1 = every block walks the reduction from chunk 0
     const bf16_t* addend;   // optional bf16 [M, N] added before the activation (the aggregated term of a transform-first layer)
     int64_t ldadd;
+    void* out2;             // dual form (resident-weights kernel, COLSPLIT = 2): out = A[0].Wt[0]^T and out2 = A[0].Wt[1]^T, A[0] read once
+    int64_t ldo2;
 #ifdef DGLL_RES_TRACE
     unsigned long long* trace;   // probe builds only (tools/probes/res_trace.hip): [wg < 16][wave 8][block < 4][16 events]
 #endif
@@ -993,9 +995,17 @@ __device__ __forceinline__ void res_prologue(const ResCtx& x, int64_t blk0, u32x
     }
 }
 
-template <int NTW, int RG, int NC, int CS, int COLSPLIT, int D, bool PLAIN, int NW>
-__global__ __launch_bounds__(NW * 64) void gemm_bf16_res_kernel(const MfmaGemmArgs a) {
+template <int NTW, int RG, int NC, int CS, int COLSPLIT, int D, bool PLAIN, int NW, bool DUAL>
+__global__ __launch_bounds__(NW * 64) void gemm_bf16_res_kernel(const MfmaGemmArgs a_in) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    static_assert(!DUAL || COLSPLIT == 2, "the dual form hands the second weight matrix to the second column share");
+    MfmaGemmArgs a = a_in;
+    if (DUAL) {                                         // share 1 computes the SAME rows against Wt[1] into out2: everything below
+        if (((blockIdx.x >> 3) % COLSPLIT) == 1) {      // sees one ordinary single-pair product (block-uniform selects)
+            a.Wt[0] = a.Wt[1]; a.ldw[0] = a.ldw[1]; a.out = a.out2; a.ldo = a.ldo2;
+        }
+        a.pairs = 1;
+    }
     static_assert(D % NC == 0 || NC % D == 0, "ring slots must line up from one super-iteration to the next");
     constexpr int Q = D > NC ? D / NC : 1;              // row blocks per super-iteration
     constexpr int NWG_T = NTW * CS;                     // 32-column tiles this workgroup produces
@@ -1011,7 +1021,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_res_kernel(const MfmaGemmAr
     const int share = COLSPLIT == 1 ? 0 : (bid >> 3) % COLSPLIT;
     const int pair = COLSPLIT == 1 ? bid : (bid >> 3) / COLSPLIT * 8 + (bid & 7);
     const int n_pairs = COLSPLIT == 1 ? (int)gridDim.x : (int)gridDim.x / COLSPLIT;
-    const int n_wg0 = share * NWG_T * 32;               // first global column of this workgroup
+    const int n_wg0 = DUAL ? 0 : share * NWG_T * 32;    // first global column of this workgroup
     const int chunks0 = (a.K[0] + kChunkK - 1) / kChunkK;
 
     // ---- stage ALL weights of this workgroup's columns once: [chunk][row n][8 slots of 16 bytes, slot ^ ((n >> 1) & 7)]
@@ -1073,7 +1083,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_res_kernel(const MfmaGemmAr
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the loads issued past the last block (zero-byte descriptors)
 }
 
-template <int NTW, int NC, int CS, int COLSPLIT, bool PLAIN>
+template <int NTW, int NC, int CS, int COLSPLIT, bool PLAIN, bool DUAL = false>
 static hipError_t launch_mfma_res_p(const MfmaGemmArgs& a, hipStream_t s);
 
 template <int NTW, int NC, int CS, int COLSPLIT>
@@ -1082,7 +1092,7 @@ static hipError_t launch_mfma_res(const MfmaGemmArgs& a, hipStream_t s) {
     return plain ? launch_mfma_res_p<NTW, NC, CS, COLSPLIT, true>(a, s) : launch_mfma_res_p<NTW, NC, CS, COLSPLIT, false>(a, s);
 }
 
-template <int NTW, int NC, int CS, int COLSPLIT, bool PLAIN>
+template <int NTW, int NC, int CS, int COLSPLIT, bool PLAIN, bool DUAL>
 static hipError_t launch_mfma_res_p(const MfmaGemmArgs& a, hipStream_t s) {
     // ring depth: D | NC or NC | D (slot arithmetic)
 #ifdef DGLL_RES_D
@@ -1102,7 +1112,7 @@ static hipError_t launch_mfma_res_p(const MfmaGemmArgs& a, hipStream_t s) {
 #endif
     constexpr int NWG_T = NTW * CS;
     const size_t lds = (size_t)NC * NWG_T * 32 * 128 + NW * 32 * 80 + NWG_T * 32 * 4;
-    auto kern = &gemm_bf16_res_kernel<NTW, RG, NC, CS, COLSPLIT, D, PLAIN, NW>;
+    auto kern = &gemm_bf16_res_kernel<NTW, RG, NC, CS, COLSPLIT, D, PLAIN, NW, DUAL>;
     static hipError_t raised = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (raised != hipSuccess) return raised;
@@ -1217,6 +1227,36 @@ DGLL_API int dgll_hip_transform_bf16_add(void* stream, const void* A1, int64_t l
                                          int64_t ldgate, const float* row_scale, const void* addend, int64_t ldadd) {
     return transform_bf16_impl(stream, A1, lda1, K1, Wt1, ldw1, A2, lda2, K2, Wt2, ldw2, wt_rows, relu_mask, ldm, out, ldo,
                                out_dtype, M, N, relu, bias, out_gate, ldgate, row_scale, addend, ldadd);
+}
+
+DGLL_API int dgll_hip_transform_bf16_dual(void* stream, const void* A, int64_t lda, int K, const void* Wt1, const void* Wt2,
+                                          int64_t ldw, int wt_rows, void* out1, int64_t ldo1, void* out2, int64_t ldo2, int64_t M,
+                                          int N) {
+    DGLL_REQUIRE(M >= 0 && N >= 0 && K >= 0, "negative size");
+    if (M == 0 || N == 0) return DGLL_OK;
+    DGLL_REQUIRE(A && Wt1 && Wt2 && out1 && out2 && K > 0, "NULL operand");
+    DGLL_REQUIRE(N <= 256 && K <= 256, "dgll_hip_transform_bf16_dual: N, K <= 256 (both weight matrices stay resident in LDS)");
+    DGLL_REQUIRE(wt_rows >= 256, "Wt1 / Wt2 must be zero-padded to 256 rows");
+    DGLL_REQUIRE(aligned16(A) && (lda * 2) % 16 == 0 && lda >= ((K + 7) / 8) * 8, "A: 16-byte aligned rows");
+    DGLL_REQUIRE(aligned16(Wt1) && aligned16(Wt2) && (ldw * 2) % 16 == 0 && ldw >= ((K + 63) / 64) * 64,
+                 "Wt must be zero-padded to a multiple of 64 columns");
+    DGLL_REQUIRE(ldo1 >= N && ldo2 >= N, "output leading dimension");
+    MfmaGemmArgs a{};
+    a.A[0] = static_cast<const bf16_t*>(A); a.lda[0] = lda; a.K[0] = K;
+    a.A[1] = a.A[0]; a.lda[1] = lda; a.K[1] = 0;
+    a.Wt[0] = static_cast<const bf16_t*>(Wt1); a.Wt[1] = static_cast<const bf16_t*>(Wt2); a.ldw[0] = a.ldw[1] = ldw;
+    a.pairs = 1;
+    a.out = out1; a.ldo = ldo1; a.out2 = out2; a.ldo2 = ldo2; a.M = M; a.N = N;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e;
+    switch ((K + kChunkK - 1) / kChunkK) {             // 256 columns per workgroup (two waves per row group), two workgroups per row block
+        case 1: e = launch_mfma_res_p<4, 1, 2, 2, true, true>(a, s); break;
+        case 2: e = launch_mfma_res_p<4, 2, 2, 2, true, true>(a, s); break;
+        case 3: e = launch_mfma_res_p<4, 3, 2, 2, true, true>(a, s); break;
+        default: e = launch_mfma_res_p<4, 4, 2, 2, true, true>(a, s); break;
+    }
+    if (e != hipSuccess) return hip_fail(e, "gemm_bf16_res_kernel (dual) launch");
+    return DGLL_OK;
 }
 
 static int transform_bf16_impl(void* stream, const void* A1, int64_t lda1, int K1, const void* Wt1, int64_t ldw1,

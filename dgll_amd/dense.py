@@ -13,11 +13,11 @@ from . import _lib
 _SLABS = 256
 
 
-def _pad_wt(wt):
+def _pad_wt(wt, rows=None):
     """[N, K] -> zero-padded bf16 [64 | 128 | 256 rows, 64*ceil(K/64) columns] as dgll_hip_transform_bf16 wants its
     weights (the kernel is instantiated for 2, 4 or 8 column tiles of 32 and stages that many rows)."""
     n, k = wt.shape
-    rows = 64 if n <= 64 else 128 if n <= 128 else 256
+    rows = rows or (64 if n <= 64 else 128 if n <= 128 else 256)
     out = torch.zeros((rows, -(-k // 64) * 64), dtype=torch.bfloat16, device=wt.device)
     out[:n, :k] = wt
     return out
@@ -65,9 +65,67 @@ def transform_bf16(a1, wt1, a2=None, wt2=None, relu=False, out_dtype=torch.bfloa
     return out
 
 
+def transform_bf16_dual(a, wt1, wt2):
+    """(a . wt1^T, a . wt2^T) in one MFMA launch that reads `a` once: the two input gradients g.Ws^T, g.Wn^T of a SAGE
+    layer.  wt1, wt2: [N, K] with N, K <= 256; a: bf16 [M, K], 16-byte aligned rows."""
+    n, m = wt1.shape[0], a.shape[0]
+    if wt2.shape != wt1.shape or n > 256 or a.shape[1] > 256:
+        raise ValueError("transform_bf16_dual: two [N <= 256, K <= 256] weight matrices of one shape")
+    p1, p2 = _pad_wt(wt1, rows=256), _pad_wt(wt2, rows=256)
+    ld = -(-n // 8) * 8
+    outs = [torch.empty((m, ld), dtype=torch.bfloat16, device=a.device) for _ in range(2)]
+    o1, o2 = (o[:, :n] if ld != n else o for o in outs)
+    with torch.cuda.device(a.device):
+        code = _lib.lib.dgll_hip_transform_bf16_dual(
+            torch.cuda.current_stream(a.device).cuda_stream, a.data_ptr(), a.stride(0), a.shape[1], p1.data_ptr(), p2.data_ptr(),
+            p1.stride(0), p1.shape[0], o1.data_ptr(), o1.stride(0), o2.data_ptr(), o2.stride(0), m, n)
+    _lib.check(code, "dgll_hip_transform_bf16_dual")
+    return o1, o2
+
+
+def input_grads(g, wsd, wnd):
+    """(g . Ws^T, g . Wn^T) for weights stored [in, out]: one MFMA launch for tall bf16 gradients, else two library GEMMs."""
+    if g.shape[0] >= 64 * _SLABS and _mfma_ok(g) and wsd.shape == wnd.shape and max(wsd.shape) <= 256:
+        return transform_bf16_dual(g, wsd, wnd)
+    return torch.mm(g, wsd.t()), torch.mm(g, wnd.t())
+
+
+_GW_WORKSPACE = {}
+
+
+def _gradw_ok(*mats):
+    return all(m is not None and m.is_cuda and m.dtype == torch.bfloat16 and m.dim() == 2 and m.stride(1) == 1
+               and m.stride(0) % 8 == 0 and m.data_ptr() % 16 == 0 and m.shape[1] <= 256 for m in mats)
+
+
+def _grad_weight_hip(x1, x2, g):
+    """(x1^T . g, x2^T . g) fp32 on the split-K MFMA kernel (csrc/gradw.hip): g is read once for both products."""
+    m, n = g.shape
+    k1, k2 = x1.shape[1], (x2.shape[1] if x2 is not None else 0)
+    types = (-(-k1 // 64) + -(-k2 // 64) + 3) // 4
+    n_cu = torch.cuda.get_device_properties(g.device).multi_processor_count
+    slabs = max(1, min(4096, n_cu // types, -(-m // 16)))
+    need = int(_lib.lib.dgll_hip_grad_weight_workspace(k1, k2, slabs))
+    key = (g.device.index, torch.cuda.current_stream(g.device).cuda_stream)
+    ws = _GW_WORKSPACE.get(key)
+    if ws is None or ws.numel() * 4 < need:
+        ws = _GW_WORKSPACE[key] = torch.empty(need // 4, dtype=torch.float32, device=g.device)
+    d1 = torch.empty((k1, n), dtype=torch.float32, device=g.device)
+    d2 = torch.empty((k2, n), dtype=torch.float32, device=g.device) if x2 is not None else None
+    code = _lib.lib.dgll_hip_grad_weight_bf16(
+        torch.cuda.current_stream(g.device).cuda_stream, x1.data_ptr(), x1.stride(0), k1,
+        x2.data_ptr() if x2 is not None else None, x2.stride(0) if x2 is not None else 0, k2, g.data_ptr(), g.stride(0), n, m,
+        ws.data_ptr(), ws.numel() * 4, slabs, d1.data_ptr(), d1.stride(0), d2.data_ptr() if d2 is not None else None,
+        d2.stride(0) if d2 is not None else 0)
+    _lib.check(code, "dgll_hip_grad_weight_bf16")
+    return d1, d2
+
+
 def grad_weight(x, g):
     """x^T . g  for x [M, K], g [M, N] -> fp32 [K, N], split over M."""
     m = x.shape[0]
+    if m >= 64 * _SLABS and _gradw_ok(x, g):
+        return _grad_weight_hip(x, None, g)[0]
     if m < 64 * _SLABS:
         return torch.mm(x.t(), g).float()
     rows = m // _SLABS
@@ -78,6 +136,13 @@ def grad_weight(x, g):
     if main < m:
         out += torch.mm(x[main:].t(), g[main:]).float()
     return out
+
+
+def grad_weight_pair(x1, x2, g):
+    """(x1^T . g, x2^T . g): the two weight gradients of a SAGE layer share g -- one launch reads it once."""
+    if x1.shape[0] >= 64 * _SLABS and _gradw_ok(x1, x2, g):
+        return _grad_weight_hip(x1, x2, g)
+    return grad_weight(x1, g), grad_weight(x2, g)
 
 
 def column_sum(g, slabs=2048):
@@ -120,11 +185,16 @@ class _SageTransform(torch.autograd.Function):
         if ctx.relu:
             g = torch.ops.aten.threshold_backward(g.contiguous(), out, 0)   # one vectorised pass: g where out > 0
         g = g.contiguous()
-        # single-product input gradients: the library GEMM is faster than the un-fused MFMA kernel (0.6 vs 1.1 ms)
-        gh = torch.mm(g, wsd.t()) if ctx.needs_input_grad[0] else None
-        gagg = torch.mm(g, wnd.t()) if ctx.needs_input_grad[1] else None
-        gws = grad_weight(h, g) if ctx.needs_input_grad[2] else None
-        gwn = grad_weight(agg, g) if ctx.needs_input_grad[3] else None
+        if ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
+            gh, gagg = input_grads(g, wsd, wnd)
+        else:
+            gh = torch.mm(g, wsd.t()) if ctx.needs_input_grad[0] else None
+            gagg = torch.mm(g, wnd.t()) if ctx.needs_input_grad[1] else None
+        if ctx.needs_input_grad[2] and ctx.needs_input_grad[3]:
+            gws, gwn = grad_weight_pair(h, agg, g)
+        else:
+            gws = grad_weight(h, g) if ctx.needs_input_grad[2] else None
+            gwn = grad_weight(agg, g) if ctx.needs_input_grad[3] else None
         return gh, gagg, gws, gwn, None
 
 

@@ -42,16 +42,18 @@ class _SageGraphLayer(torch.autograd.Function):
         g = g.contiguous()
         if ctx.relu and not ctx.grad_is_gated:
             g = torch.ops.aten.threshold_backward(g, out, 0)
-        gws = dense.grad_weight(h, g) if ctx.needs_input_grad[1] else None
-        gwn = dense.grad_weight(agg, g) if ctx.needs_input_grad[2] else None
+        if ctx.needs_input_grad[1] and ctx.needs_input_grad[2]:
+            gws, gwn = dense.grad_weight_pair(h, agg, g)   # one launch: g read once for both products
+        else:
+            gws = dense.grad_weight(h, g) if ctx.needs_input_grad[1] else None
+            gwn = dense.grad_weight(agg, g) if ctx.needs_input_grad[2] else None
         gh = None
         if ctx.needs_input_grad[0]:
-            gh = torch.mm(g, wsd.t())                      # self path
+            gh, gagg = dense.input_grads(g, wsd, wnd)      # self path, neighbour path: one MFMA launch, g read once
             gt, _ = graph.transpose()
             tval = gt.val
             # (folding 1/deg into this product's rows -- transform_bf16(row_scale=) -- so that the SpMM runs unweighted was
-            # measured: SpMM 5.21 -> 5.12 ms, but the MFMA kernel takes 0.70 ms against the library's 0.53: no net gain)
-            gagg = torch.mm(g, wnd.t())
+            # measured: SpMM 5.21 -> 5.12 ms, but the transform got slower by more: no net gain)
             if ctx.reduce == "mean":
                 scale = graph.mean_scale_transposed()
                 tval = scale if tval is None else tval * scale

@@ -253,6 +253,25 @@ int dgll_hip_transform_bf16_add(void* stream, const void* A1, int64_t lda1, int 
                                 int N, int relu, const float* bias, const void* out_gate, int64_t ldgate,
                                 const float* row_scale, const void* addend, int64_t ldadd);
 
+/* Two products of ONE activation matrix: out1 = A.Wt1^T and out2 = A.Wt2^T, A read once -- the two input gradients
+ * g.Ws^T and g.Wn^T of a SAGE layer (what autograd derives for sageconv.py:72-75's `src @ W` pair).  bf16 A [M, lda],
+ * Wt1 / Wt2 [wt_rows >= 256, ldw] zero-padded as dgll_hip_transform_bf16 wants them, bf16 out1 / out2 [M, ldo >= N];
+ * K, N <= 256.                                                                                                      */
+int dgll_hip_transform_bf16_dual(void* stream, const void* A, int64_t lda, int K, const void* Wt1, const void* Wt2,
+                                 int64_t ldw, int wt_rows, void* out1, int64_t ldo1, void* out2, int64_t ldo2, int64_t M,
+                                 int N);
+
+/* ---- weight gradients of the dense transform: dW1 = X1^T . G and (optionally) dW2 = X2^T . G ---------------------
+ * What autograd derives for `self.W(h)` / `neigh @ self.W` (sageconv.py:41,72-75; gcnconv.py:30; the reference leaves it
+ * to two library GEMMs that each read G).  bf16 X1 [M, ldx1 >= K1], X2 [M, ldx2 >= K2] (NULL / K2 = 0: one product),
+ * G [M, ldg >= N]; fp32 dW1 [K1, lddw1 >= N], dW2 [K2, lddw2 >= N]; K1, K2, N <= 256; rows 16-byte aligned (bases, and leading
+ * dimensions multiples of 8).  Split over `n_slabs` row slabs (1..4096) whose partials are summed in slab order (deterministic);
+ * `workspace`: dgll_hip_grad_weight_workspace(K1, K2, n_slabs) bytes of device memory.  M = 0 writes zeros.        */
+int64_t dgll_hip_grad_weight_workspace(int K1, int K2, int n_slabs);
+int dgll_hip_grad_weight_bf16(void* stream, const void* X1, int64_t ldx1, int K1, const void* X2, int64_t ldx2, int K2,
+                              const void* G, int64_t ldg, int N, int64_t M, void* workspace, int64_t workspace_bytes,
+                              int n_slabs, float* dW1, int64_t lddw1, float* dW2, int64_t lddw2);
+
 /* ---- the loss at the end of the path: softmax cross-entropy with class-index targets ---------------------------
  * nn.CrossEntropyLoss on the last layer's output (Evaluation/PPI/train_gcn.py:27,45), one pass per direction:
  * row_loss[i] = logsumexp(z_i) - z_i[label_i]  and/or  grad[i, c] = *grad_scale * (softmax(z_i)[c] - [c == label_i]).
