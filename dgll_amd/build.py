@@ -19,7 +19,10 @@ OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libdgll_hip.so")
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
-         "-ffp-contract=fast", "-pthread"]
+         "-ffp-contract=fast", "-pthread",
+         # `#pragma unroll` is a request, honoured up to this many instructions (default 16384): the transform kernels'
+         # epilogues (4 tiles x 2 row groups, ragged paths included) need more, and a rolled loop puts their arrays in scratch
+         "-mllvm", "-pragma-unroll-threshold=131072"]
 
 
 def _hipcc():

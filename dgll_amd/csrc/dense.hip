@@ -867,10 +867,49 @@ __device__ __forceinline__ void res_epilogue(const MfmaGemmArgs& a, char* scratc
     if constexpr (!PLAIN) rs = a.row_scale ? a.row_scale[row_ld] : 1.0f;
     constexpr int kPitch = 80;                                  // 64 bytes of bf16 + 16: conflict-free 8-byte writes
     const bool vec_rows = (a.ldo & 7) == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15u) == 0;
+    // Non-plain epilogues: fetch what TWO tiles need from global memory up front -- their gate vectors
+    // (row-store layout) and the addend pieces (accumulator layout, 8 bytes per lane and column group) -- with
+    // unconditional, address-clamped loads: one wait for the lot instead of one exposed round trip per tile (and no
+    // branch around a load, which would make hipcc wait per element).  Columns past N but inside the padded leading
+    // dimension are read and never stored.
+    bool gate_fast = false, add_fast = false;
+    if constexpr (!PLAIN) {
+        gate_fast = !a.out_f32 && a.out_gate && (a.ldgate & 7) == 0 && (reinterpret_cast<uintptr_t>(a.out_gate) & 15u) == 0;
+        add_fast = !a.out_f32 && a.addend && (a.ldadd & 3) == 0 && (reinterpret_cast<uintptr_t>(a.addend) & 7u) == 0;
+    }
+    constexpr int TP = NTW >= 2 ? 2 : 1;                        // tiles fetched for at a time (registers: 2 x (8 + 8) per lane)
 #pragma unroll
-    for (int t = 0; t < NTW; ++t) {
+    for (int tp = 0; tp < NTW; tp += TP) {
+    uint4 gate_v[TP][2];
+    uint2 add_v[TP][4];
+    if constexpr (!PLAIN) {
+        if (gate_fast) {
+#pragma unroll
+            for (int u = 0; u < TP; ++u)
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const int idx = it * kWave + lane;
+                    const int64_t grow = m0 + (idx >> 2);
+                    const int n = n0 + (tp + u) * 32 + (idx & 3) * 8;
+                    gate_v[u][it] = *reinterpret_cast<const uint4*>(a.out_gate + (grow < a.M ? grow : a.M - 1) * a.ldgate +
+                                                                    (n + 8 <= a.ldgate ? n : 0));
+                }
+        }
+        if (add_fast) {
+#pragma unroll
+            for (int u = 0; u < TP; ++u)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n = n0 + (tp + u) * 32 + g * 8 + half * 4;
+                    add_v[u][g] = *reinterpret_cast<const uint2*>(a.addend + row_ld * a.ldadd + (n + 4 <= a.ldadd ? n : 0));
+                }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < TP; ++u) {
+        const int t = tp + u;
         const int nt0 = n0 + t * 32;
-        if (nt0 >= a.N) break;                                  // wave-uniform
+        if (nt0 >= a.N) continue;                               // wave-uniform
         if (!PLAIN && a.out_f32) {
             if (row < a.M) {
 #pragma unroll
@@ -906,7 +945,14 @@ __device__ __forceinline__ void res_epilogue(const MfmaGemmArgs& a, char* scratc
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 float xv = acc[t][g * 4 + i] * rs + b4[i];
-                if constexpr (!PLAIN) { if (a.addend && n + i < a.N) xv += bf16_to_f32(a.addend[row_ld * a.ldadd + n + i]); }
+                if constexpr (!PLAIN) {
+                    if (add_fast) {
+                        const uint32_t w = i < 2 ? add_v[u][g].x : add_v[u][g].y;
+                        xv += __builtin_bit_cast(float, (i & 1) ? (w & 0xffff0000u) : (w << 16));
+                    } else if (a.addend && n + i < a.N) {
+                        xv += bf16_to_f32(a.addend[row_ld * a.ldadd + n + i]);
+                    }
+                }
                 if (a.relu) xv = fmaxf(xv, 0.0f);
                 v[i] = xv;
             }
@@ -927,7 +973,10 @@ __device__ __forceinline__ void res_epilogue(const MfmaGemmArgs& a, char* scratc
             if (d.x != 0x12345678u) continue;                          // probe: no stores
 #endif
             if (n + 8 <= a.N && vec_rows) {
-                if constexpr (!PLAIN) { if (a.out_gate) d = relu_mask(d, *reinterpret_cast<const uint4*>(a.out_gate + grow * a.ldgate + n)); }
+                if constexpr (!PLAIN) {
+                    if (gate_fast) d = relu_mask(d, gate_v[u][it]);
+                    else if (a.out_gate) d = relu_mask(d, *reinterpret_cast<const uint4*>(a.out_gate + grow * a.ldgate + n));
+                }
                 *reinterpret_cast<uint4*>(o) = d;
             } else {
                 const uint32_t w[4] = {d.x, d.y, d.z, d.w};
@@ -941,6 +990,7 @@ __device__ __forceinline__ void res_epilogue(const MfmaGemmArgs& a, char* scratc
             }
         }
         __builtin_amdgcn_wave_barrier();                       // (same: the next tile's writes queue behind these reads)
+    }
     }
 }
 

@@ -35,7 +35,10 @@ def sregs(tok):
 def main():
     with tempfile.TemporaryDirectory() as tmp:
         out = os.path.join(tmp, "dense.s")
-        subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+        sys.path.insert(0, ROOT)
+        from dgll_amd.build import FLAGS                        # the library's own flags: the audit reads what ships
+        subprocess.run(["hipcc"] + [f for f in FLAGS if f not in ("-fPIC", "-pthread")] +
+                       ["-I", os.path.join(ROOT, "include"), "-S", "--cuda-device-only",
                         os.path.join(ROOT, "dgll_amd", "csrc", "dense.hip"), "-o", out], check=True, stderr=subprocess.DEVNULL)
         txt = open(out).read()
     names = re.findall(r"^(_ZN4dgll\d+gemm_bf16_(?:w8|res)_kernel\S+):", txt, re.M)
