@@ -347,18 +347,13 @@ static hipError_t launch_mfma(const MfmaGemmArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-// ---- the shipped variant: 256 rows per workgroup (8 wavefronts), activations prefetched TWO chunks ahead -------------
-// Same fragment mapping as above.  What changes is what is in flight per CU: the 4-wave kernel keeps one chunk of
-// activations (4 KB per wave, 32 KB per CU with two workgroups) in flight behind the MFMAs and re-reads the 32 KB weight
-// chunk from L2 for every 128 rows -- measured latency-bound at 3.6 TB/s.  Here one workgroup of 8 waves shares each staged
-// weight chunk (half the L2 traffic, half the staging registers per thread) and the registers that frees hold a SECOND
-// chunk of activations in flight: 8 KB of activations + 4 KB of weights per wave, 96 KB per CU.  The three activation
-// register sets rotate by NAME (the loop is unrolled three-fold): copying a set would make the compiler wait for its loads.
-// Every vector-memory operation of the main loop is issued from inline assembly and waited for BY HAND: hipcc's own
-// s_waitcnt insertion merges the pending-load state at the loop header and ends up waiting for (almost) everything in
-// front of the first MFMA of an iteration (observed: vmcnt(3) with 13 loads queued), which serialises a two-deep prefetch.
-// An asm load is invisible to that pass; its destination registers are only touched again after the hand-placed wait that
-// names them as read-write operands (cdna_hip_programming.md section 5.7, forms (ii)/(iii)).
+// ---- helpers of the persistent kernel below -------------------------------------------------------------------------
+// Every vector-memory LOAD of its main loop is issued from inline assembly and waited for BY HAND: hipcc's own s_waitcnt
+// insertion merges the pending-load state at the loop header and ends up waiting for (almost) everything in front of the
+// first MFMA of an iteration, which serialises any prefetch.  An asm load is invisible to that pass; its destination
+// registers are only touched again after the hand-placed wait that names them as read-write operands
+// (cdna_hip_programming.md section 5.7, forms (ii)/(iii)).  (Round 2 also carried an 8-wave kernel that re-staged the
+// weights per chunk behind barriers; the resident-weights kernel replaced it everywhere and it was deleted.)
 typedef __attribute__((ext_vector_type(4))) int i32x4_t;
 
 __device__ __forceinline__ bool g_rot_enabled(const MfmaGemmArgs& a) { return a.no_rotate == 0; }
@@ -376,300 +371,6 @@ __device__ __forceinline__ i32x4_t make_rsrc(const void* base, uint32_t bytes) {
 template <int IMM>
 __device__ __forceinline__ void asm_bufload16(u32x4_t& dst, uint32_t voff, i32x4_t rsrc, uint32_t soff) {
     asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" : "=v"(dst) : "v"(voff), "s"(rsrc), "s"(soff), "i"(IMM) : "memory");
-}
-
-struct W8Ctx {           // wave-uniform state of one workgroup (SGPRs) + the per-lane offsets (3 VGPRs)
-    i32x4_t wr[2];       // weight matrices of the two operand pairs
-    i32x4_t ar[2];       // activation matrices, re-based to the current 256-row block
-    uint32_t w_voff;     // this thread's first weight vector: row tid/8, part tid%8
-    uint32_t a_voff[2];  // this lane's activation row inside the block (+ its 16-byte half)
-    uint32_t w_step[2];  // bytes between a thread's consecutive weight vectors (64 rows)
-    int chunks0, K0, K1;
-    int rot, nc;         // this block walks the reduction starting at chunk `rot` (and wraps): (a) neighbouring CUs, which run
-};                       // in near lock-step, then read DIFFERENT 128-byte columns of their rows at any one time instead of all
-                         // hitting the same address bits [7:9) -- the same few memory channels; (b) being block-dependent, the
-                         // chunk addressing cannot be hoisted out of the persistent loop (one descriptor / offset per chunk,
-                         // live for the whole kernel, otherwise)
-
-template <int NT, int WV>
-__device__ __forceinline__ void w8_issue_weights(const W8Ctx& x, int c, u32x4_t (&wreg)[WV]) {
-    c += x.rot;
-    if (c >= x.nc) c -= x.nc;
-    const bool second = c >= x.chunks0;
-    const i32x4_t r = second ? x.wr[1] : x.wr[0];
-    const uint32_t step = second ? x.w_step[1] : x.w_step[0];
-    const uint32_t k0b = (uint32_t)((second ? c - x.chunks0 : c) * kChunkK * 2);
-#pragma unroll
-    for (int i = 0; i < WV; ++i) asm_bufload16<0>(wreg[i], x.w_voff, r, k0b + i * step);
-}
-
-// this lane's four activation vectors of chunk c: 16 bytes at k = k0 + half*8 + kk*16
-__device__ __forceinline__ void w8_issue_act(const W8Ctx& x, int c, int kk, u32x4_t& dst) {
-    c += x.rot;
-    if (c >= x.nc) c -= x.nc;
-    const bool second = c >= x.chunks0;
-    const i32x4_t r = second ? x.ar[1] : x.ar[0];
-    const uint32_t voff = second ? x.a_voff[1] : x.a_voff[0];
-    const uint32_t k0b = (uint32_t)((second ? c - x.chunks0 : c) * kChunkK * 2);
-    switch (kk) {
-        case 0: asm_bufload16<0>(dst, voff, r, k0b); break;
-        case 1: asm_bufload16<32>(dst, voff, r, k0b); break;
-        case 2: asm_bufload16<64>(dst, voff, r, k0b); break;
-        default: asm_bufload16<96>(dst, voff, r, k0b); break;
-    }
-}
-
-__device__ __forceinline__ void w8_issue_acts(const W8Ctx& x, int c, u32x4_t (&areg)[4]) {
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) w8_issue_act(x, c, kk, areg[kk]);
-}
-
-// zero what lies past the end of the row (the bytes between K and the end of the chunk belong to the padding or to the next
-// row: uninitialised pad columns may hold NaN bit patterns, which the weight's zero padding would not stop)
-__device__ __forceinline__ void w8_trim_acts(const W8Ctx& x, int c, int half, u32x4_t (&areg)[4]) {
-    c += x.rot;
-    if (c >= x.nc) c -= x.nc;
-    const bool second = c >= x.chunks0;
-    const int k0 = (second ? c - x.chunks0 : c) * kChunkK;
-    const int K = second ? x.K1 : x.K0;
-    if (k0 + kChunkK <= K) return;                    // wave-uniform: only an operand's last chunk can be ragged
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-        const uint4 v = mask_tail(make_uint4(areg[kk][0], areg[kk][1], areg[kk][2], areg[kk][3]), K - (k0 + half * 8 + kk * 16));
-        areg[kk] = u32x4_t{v.x, v.y, v.z, v.w};
-    }
-}
-
-template <int WV, int OUTSTANDING>
-__device__ __forceinline__ void w8_wait(u32x4_t (&wreg)[WV], u32x4_t (&areg)[4]) {
-    // all but the newest OUTSTANDING (0 or 4) vector-memory operations have landed; the operands tie the staged weights
-    // and the next chunk's activations to this point, so nothing reads those registers earlier
-    static_assert(OUTSTANDING == 0 || OUTSTANDING == 4, "the loop leaves nothing or one activation set in flight");
-#define W8_WAIT_ASM(TXT)                                                                                                      \
-    if constexpr (WV == 1) asm volatile(TXT : "+v"(wreg[0]), "+v"(areg[0]), "+v"(areg[1]), "+v"(areg[2]), "+v"(areg[3]) :: "memory"); \
-    else if constexpr (WV == 2) asm volatile(TXT : "+v"(wreg[0]), "+v"(wreg[1]), "+v"(areg[0]), "+v"(areg[1]), "+v"(areg[2]), "+v"(areg[3]) :: "memory"); \
-    else asm volatile(TXT : "+v"(wreg[0]), "+v"(wreg[1]), "+v"(wreg[2]), "+v"(wreg[3]), "+v"(areg[0]), "+v"(areg[1]), "+v"(areg[2]), "+v"(areg[3]) :: "memory");
-    if constexpr (OUTSTANDING == 4) { W8_WAIT_ASM("s_waitcnt vmcnt(4)") }
-    else { W8_WAIT_ASM("s_waitcnt vmcnt(0)") }
-#undef W8_WAIT_ASM
-    __builtin_amdgcn_sched_barrier(0);
-}
-
-// One chunk of the main loop.  LA: prefetch the activations of chunk c + 2 -- vector kk into the register CUR[kk] just
-// vacated by its last MFMA, so two register sets give a two-chunk run-ahead; LW: fetch, wait for and stage the weights of
-// chunk c + 1.  The flags are template parameters (no branch around an asm load: a branch would leave the allocator free to
-// insert a copy of an in-flight register at the merge).  Queue on entry: A(c+1)[4]; on exit with LA: A(c+2)[4] only.
-template <int NT, int WV, bool LA, bool LW>
-__device__ __forceinline__ void w8_phase(const W8Ctx& x, int c, int tid, int half, int l32, char* smem, f32x16_t (&acc)[NT],
-                                         u32x4_t (&CUR)[4], u32x4_t (&NEXT)[4], u32x4_t (&wreg)[WV]) {
-    constexpr int kBufBytes = NT * 32 * kWPitch;
-    if constexpr (LW) w8_issue_weights<NT, WV>(x, c + 1, wreg);
-    w8_trim_acts(x, c, half, CUR);
-    const char* base = smem + (c & 1) * kBufBytes + l32 * kWPitch + half * 16;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-        const bf16x8_t xf = __builtin_bit_cast(bf16x8_t, CUR[kk]);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const uint4 wv = *reinterpret_cast<const uint4*>(base + t * 32 * kWPitch + kk * 32);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wv), xf, acc[t], 0, 0, 0);
-        }
-        if constexpr (LA) w8_issue_act(x, c + 2, kk, CUR[kk]);
-    }
-    if constexpr (LW) {
-        if constexpr (LA) w8_wait<WV, 4>(wreg, NEXT);
-        else w8_wait<WV, 0>(wreg, NEXT);
-        char* dst = smem + ((c + 1) & 1) * kBufBytes;
-#pragma unroll
-        for (int i = 0; i < WV; ++i) {
-            const int v = tid + i * 512;
-            *reinterpret_cast<u32x4_t*>(dst + (v >> 3) * kWPitch + (v & 7) * 16) = wreg[i];
-        }
-        __syncthreads();
-    }
-}
-
-// The chunk count NC (<= 8: K1 + K2 <= 512) is a template parameter and the chunk loop is unrolled completely: straight-line
-// code with no loop-carried register sets and no merge points, so the allocator has no reason to copy or spill a register
-// an asm load is still writing.  (A rolled loop with `break`s / tail branches made hipcc keep one copy of the 128
-// accumulator registers per exit path: 300 - 1600 spilled registers.)
-template <int NT, int WV, int NC, int C>
-__device__ __forceinline__ void w8_unrolled(const W8Ctx& x, int tid, int half, int l32, char* smem, f32x16_t (&acc)[NT],
-                                            u32x4_t (&P)[4], u32x4_t (&Q)[4], u32x4_t (&wreg)[WV]) {
-    if constexpr (C < NC) {
-        if constexpr (C % 2 == 0) w8_phase<NT, WV, (C + 2 < NC), (C + 1 < NC)>(x, C, tid, half, l32, smem, acc, P, Q, wreg);
-        else w8_phase<NT, WV, (C + 2 < NC), (C + 1 < NC)>(x, C, tid, half, l32, smem, acc, Q, P, wreg);
-        w8_unrolled<NT, WV, NC, C + 1>(x, tid, half, l32, smem, acc, P, Q, wreg);
-    }
-}
-
-// Epilogue of one 256-row block: scale / bias / addend / activation, then (bf16) a transpose through LDS so that stores --
-// and the optional output gate's loads -- are whole 16-byte vectors along rows.
-template <int NT>
-__device__ __forceinline__ void w8_epilogue(const MfmaGemmArgs& a, char* smem, f32x16_t (&acc)[NT], int64_t m0, int64_t row,
-                                            int64_t row_ld, int lane, int wave, int half, int l32) {
-    const float rs = a.row_scale ? a.row_scale[row_ld] : 1.0f;
-    if (!a.out_f32) {
-        constexpr int kOPitch = NT * 64 + 16;
-        __syncthreads();
-        char* mine = smem + wave * 32 * kOPitch;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int n = t * 32 + g * 8 + half * 4;
-                float v[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float x = acc[t][g * 4 + i] * rs;
-                    if (a.bias && n + i < a.N) x += a.bias[n + i];
-                    if (a.addend && n + i < a.N) x += bf16_to_f32(a.addend[row_ld * a.ldadd + n + i]);
-                    if (a.relu) x = fmaxf(x, 0.0f);
-                    v[i] = x;
-                }
-                *reinterpret_cast<uint2*>(mine + l32 * kOPitch + n * 2) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-            }
-        }
-        __syncthreads();
-        constexpr int kVecs = NT * 4;
-        const bool vec_rows = (a.ldo & 7) == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15u) == 0;
-#pragma unroll 4
-        for (int it = 0; it < 32 * kVecs / kWave; ++it) {
-            const int idx = it * kWave + lane;
-            const int r = idx / kVecs, n = (idx % kVecs) * 8;
-            const int64_t grow = m0 + r;
-            if (grow >= a.M || n >= a.N) continue;
-            uint4 d = *reinterpret_cast<const uint4*>(mine + r * kOPitch + n * 2);
-            bf16_t* o = static_cast<bf16_t*>(a.out) + grow * a.ldo + n;
-            if (n + 8 <= a.N && vec_rows) {
-                if (a.out_gate) d = relu_mask(d, *reinterpret_cast<const uint4*>(a.out_gate + grow * a.ldgate + n));
-                *reinterpret_cast<uint4*>(o) = d;
-            } else {
-                const uint32_t w[4] = {d.x, d.y, d.z, d.w};
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    if (n + e >= a.N) continue;
-                    bf16_t b = (bf16_t)((w[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
-                    if (a.out_gate && !(bf16_to_f32(a.out_gate[grow * a.ldgate + n + e]) > 0.0f)) b = 0;
-                    o[e] = b;
-                }
-            }
-        }
-        return;
-    }
-    if (row >= a.M) return;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int n = t * 32 + g * 8 + half * 4;
-            if (n >= a.N) continue;
-            float v[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float x = acc[t][g * 4 + i] * rs;
-                if (a.bias && n + i < a.N) x += a.bias[n + i];
-                if (a.addend && n + i < a.N) x += bf16_to_f32(a.addend[row * a.ldadd + n + i]);
-                if (a.relu) x = fmaxf(x, 0.0f);
-                v[i] = x;
-            }
-            if (a.out_gate) {
-                const bf16_t* gp = a.out_gate + row * a.ldgate + n;
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (n + i < a.N && !(bf16_to_f32(gp[i]) > 0.0f)) v[i] = 0.0f;
-            }
-            float* o = static_cast<float*>(a.out) + row * a.ldo + n;
-            if (n + 4 <= a.N && (a.ldo & 3) == 0) *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-            else
-                for (int i = 0; i < 4; ++i) if (n + i < a.N) o[i] = v[i];
-        }
-    }
-}
-
-template <int NT, int NC>
-__global__ __launch_bounds__(512, 2) void gemm_bf16_w8_kernel(const MfmaGemmArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int WV = NT / 2;                          // weight vectors per thread per chunk (512 threads)
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int half = lane >> 5, l32 = lane & 31;
-    const int64_t n_blocks = (a.M + 255) / 256;
-
-    W8Ctx x;
-    x.chunks0 = (a.K[0] + kChunkK - 1) / kChunkK;       // the host checked chunks0 + chunks1 == NC
-    x.K0 = a.K[0]; x.K1 = a.K[1];
-    x.wr[0] = make_rsrc(a.Wt[0], (uint32_t)(NT * 32 * a.ldw[0] * 2));
-    x.wr[1] = a.pairs > 1 ? make_rsrc(a.Wt[1], (uint32_t)(NT * 32 * a.ldw[1] * 2)) : x.wr[0];
-    x.w_step[0] = (uint32_t)(64 * a.ldw[0] * 2);
-    x.w_step[1] = (uint32_t)(64 * a.ldw[1] * 2);
-    const uint32_t lda0b = (uint32_t)(a.lda[0] * 2), lda1b = (uint32_t)(a.lda[1] * 2);
-    // per-lane offsets.  Weights: row tid/8 of the chunk, 16-byte part tid%8 (ldw is the same for a thread's WV vectors up to
-    // w_step).  Activations: row (wave*32 + l32) of the 256-row block, half = which 16 bytes of each 32-byte k-step.
-    x.w_voff = (uint32_t)(tid >> 3) * (uint32_t)(a.ldw[0] * 2) + (uint32_t)(tid & 7) * 16;
-    const uint32_t rin = (uint32_t)(wave * 32 + l32);
-    x.a_voff[0] = rin * lda0b + (uint32_t)half * 16;
-    x.a_voff[1] = rin * lda1b + (uint32_t)half * 16;
-    // (the second pair's weight rows use ldw[1]: the host passes equal leading dimensions for both padded weight matrices)
-
-    // PERSISTENT: one workgroup per CU walks the 256-row blocks.  With the whole LDS taken by one workgroup a CU is either
-    // multiplying or storing; so that HBM does not idle through every epilogue (~45 % of a block's time), the first loads
-    // of the NEXT block -- W(0), A(0), A(1) -- are issued before the epilogue of the current one and land during it.
-    auto rebase = [&](int64_t blk) {     // activation descriptors of block blk: rows past M read as zeros (range check)
-        const int64_t r0 = blk * 256;
-        const int64_t rows = a.M - r0 < 256 ? a.M - r0 : 256;
-        x.ar[0] = make_rsrc(a.A[0] + r0 * a.lda[0], (uint32_t)((rows - 1) * lda0b + ((a.K[0] + 7) / 8) * 16));
-        x.ar[1] = a.pairs > 1 ? make_rsrc(a.A[1] + r0 * a.lda[1], (uint32_t)((rows - 1) * lda1b + ((a.K[1] + 7) / 8) * 16)) : x.ar[0];
-    };
-    int64_t blk = blockIdx.x;
-    rebase(blk);
-    x.nc = NC;
-    x.rot = g_rot_enabled(a) ? (int)(blk % NC) : 0;
-    u32x4_t wreg[WV];
-    u32x4_t P[4], Q[4];
-    w8_issue_weights<NT, WV>(x, 0, wreg);
-    w8_issue_acts(x, 0, P);
-    if constexpr (NC > 1) w8_issue_acts(x, 1, Q);
-    for (;;) {
-        // queue: W(0) A(0) [A(1)] of this block
-        if constexpr (NC > 1) w8_wait<WV, 4>(wreg, P);
-        else w8_wait<WV, 0>(wreg, P);
-#pragma unroll
-        for (int i = 0; i < WV; ++i) {
-            const int v = tid + i * 512;
-            *reinterpret_cast<u32x4_t*>(smem + (v >> 3) * kWPitch + (v & 7) * 16) = wreg[i];
-        }
-        __syncthreads();
-        f32x16_t acc[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-        w8_unrolled<NT, WV, NC, 0>(x, tid, half, l32, smem, acc, P, Q, wreg);
-
-        const int64_t m0 = blk * 256 + wave * 32;
-        const int64_t row = m0 + l32;
-        const int64_t row_ld = row < a.M ? row : a.M - 1;
-        const int64_t next = blk + gridDim.x;
-        const bool has_next = next < n_blocks;
-        x.rot = g_rot_enabled(a) ? (int)((has_next ? next : blk) % NC) : 0;
-        rebase(has_next ? next : blk);                       // the last round re-reads its own first chunks (unused): the
-        w8_issue_weights<NT, WV>(x, 0, wreg);                // loads are issued unconditionally -- no branch around an asm load
-        w8_issue_acts(x, 0, P);
-        if constexpr (NC > 1) w8_issue_acts(x, 1, Q);
-
-        {   // opaque copies of the lane coordinates: everything the epilogue derives from them (32 staging addresses, the
-            // store loop's row / column pairs) would otherwise be hoisted out of the persistent loop and stay live -- in
-            // registers the main loop needs -- for the whole kernel
-            int e_lane = lane, e_half = half, e_l32 = l32, e_wave = wave;
-            asm volatile("" : "+v"(e_lane), "+v"(e_half), "+v"(e_l32), "+s"(e_wave));
-            w8_epilogue<NT>(a, smem, acc, m0, row, row_ld, e_lane, e_wave, e_half, e_l32);
-        }
-        if (!has_next) break;
-        __syncthreads();                                     // every wave is done with the LDS before W(0) is staged over it
-        blk = next;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the unused loads of the last round
 }
 
 // =====================================================================================================================
@@ -1207,45 +908,9 @@ static hipError_t launch_mfma_res_dispatch(const MfmaGemmArgs& a, int nt, int n_
 #undef RES_NC
 }
 
-template <int NT, int NC>
-static hipError_t launch_mfma_w8_nc(const MfmaGemmArgs& a, hipStream_t s) {
-    const size_t lds = std::max<size_t>(2 * (size_t)NT * 32 * kWPitch, (size_t)8 * 32 * (NT * 64 + 16));
-    if (lds > 48 * 1024) {
-        static hipError_t raised = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_w8_kernel<NT, NC>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (raised != hipSuccess) return raised;
-    }
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-        if (n_cu <= 0) n_cu = 256;
-    }
-    const int64_t n_blocks = (a.M + 255) / 256;
-    const int per_cu = lds > 80 * 1024 ? 1 : 2;             // workgroups that fit a CU's 160 KiB of LDS
-    dim3 grid((uint32_t)std::min<int64_t>(n_blocks, (int64_t)n_cu * per_cu));
-    hipLaunchKernelGGL((gemm_bf16_w8_kernel<NT, NC>), grid, dim3(512), lds, s, a);
-    return hipGetLastError();
-}
-
-template <int NT>
-static hipError_t launch_mfma_w8(const MfmaGemmArgs& a, int n_chunks, hipStream_t s) {
-    switch (n_chunks) {
-        case 1: return launch_mfma_w8_nc<NT, 1>(a, s);
-        case 2: return launch_mfma_w8_nc<NT, 2>(a, s);
-        case 3: return launch_mfma_w8_nc<NT, 3>(a, s);
-        case 4: return launch_mfma_w8_nc<NT, 4>(a, s);
-        case 5: return launch_mfma_w8_nc<NT, 5>(a, s);
-        case 6: return launch_mfma_w8_nc<NT, 6>(a, s);
-        case 7: return launch_mfma_w8_nc<NT, 7>(a, s);
-        default: return launch_mfma_w8_nc<NT, 8>(a, s);
-    }
-}
-
 }  // namespace dgll
 
-int g_tune_mfma_kperm = 0;   // dgll_hip_debug_tune(4, v): 0 = per-shape choice (shipped), 1 = 4-wave kernel, 2 / 3 = persistent 8-wave kernel
+int g_tune_mfma_kperm = 0;   // dgll_hip_debug_tune(4, v): 0 = per-shape choice (shipped), 1 = 4-wave kernel always, 2 = no chunk rotation
 
 static int transform_bf16_impl(void* stream, const void* A1, int64_t lda1, int K1, const void* Wt1, int64_t ldw1,
                                const void* A2, int64_t lda2, int K2, const void* Wt2, int64_t ldw2, int wt_rows,
@@ -1349,25 +1014,18 @@ static int transform_bf16_impl(void* stream, const void* A1, int64_t lda1, int K
     hipError_t e;
     const int n_chunks = (K1 + kChunkK - 1) / kChunkK + (A2 ? (K2 + kChunkK - 1) / kChunkK : 0);
     a.no_rotate = g_tune_mfma_kperm == 2;
-    // Which kernel: measured on MI355X at M = 2.45 M (tools/transform_probe.py, interleaved): the persistent 8-wave kernel wins
-    // where a block carries a long reduction (K1 + K2 = 512: 1.15 vs 1.2 - 1.4 ms) or few output columns (N <= 64: 0.67 vs
-    // 0.72 ms); the 4-wave kernel wins the short single products (K = 256 -> 256: 0.82 vs 0.86 ms; K = 100: 0.73 vs 0.89 ms).
-    if ((g_tune_mfma_kperm == 0 || g_tune_mfma_kperm == 4) && !a.mask && res_applies(nt, n_chunks) &&
-        a.ldw[0] == (a.pairs > 1 ? a.ldw[1] : a.ldw[0])) {
+    // Which kernel (tools/transform_probe.py, M = 2.45 M): the persistent resident-weights kernel wherever the weights of the
+    // whole reduction fit LDS (K1 + K2 <= 512) -- fused 256+256 -> 256: 0.90 ms against 1.2-1.4 for the 4-wave kernel, single
+    // 256 -> 256: 0.59 against 0.82, 256 -> 47: 0.37 against 0.40.  The 4-wave kernel keeps the input-mask form and longer
+    // reductions (weights staged per chunk).
+    if (g_tune_mfma_kperm != 1 && !a.mask && res_applies(nt, n_chunks) && a.ldw[0] == (a.pairs > 1 ? a.ldw[1] : a.ldw[0])) {
         e = launch_mfma_res_dispatch(a, nt, n_chunks, s);
         if (e != hipSuccess) return hip_fail(e, "gemm_bf16_res_kernel launch");
         return DGLL_OK;
     }
-    const bool use_w8 = g_tune_mfma_kperm == 0 ? (n_chunks >= 8 || nt <= 2) : g_tune_mfma_kperm != 1;
-    if (!use_w8 || a.mask || n_chunks > 8) {   // also: the input-mask form and reductions longer than 512 (rolled loop)
-        if (nt <= 2) e = launch_mfma<2>(a, s);
-        else if (nt <= 4) e = launch_mfma<4>(a, s);
-        else e = launch_mfma<8>(a, s);
-    } else {
-        if (nt <= 2) e = launch_mfma_w8<2>(a, n_chunks, s);
-        else if (nt <= 4) e = launch_mfma_w8<4>(a, n_chunks, s);
-        else e = launch_mfma_w8<8>(a, n_chunks, s);
-    }
+    if (nt <= 2) e = launch_mfma<2>(a, s);
+    else if (nt <= 4) e = launch_mfma<4>(a, s);
+    else e = launch_mfma<8>(a, s);
     if (e != hipSuccess) return hip_fail(e, "gemm_bf16_nt_kernel launch");
     return DGLL_OK;
 }

@@ -41,7 +41,7 @@ def main():
                        ["-I", os.path.join(ROOT, "include"), "-S", "--cuda-device-only",
                         os.path.join(ROOT, "dgll_amd", "csrc", "dense.hip"), "-o", out], check=True, stderr=subprocess.DEVNULL)
         txt = open(out).read()
-    names = re.findall(r"^(_ZN4dgll\d+gemm_bf16_(?:w8|res)_kernel\S+):", txt, re.M)
+    names = re.findall(r"^(_ZN4dgll\d+gemm_bf16_res_kernel\S+):", txt, re.M)
     total = 0
     for name in names:
         i = txt.index(name + ":")

@@ -14,7 +14,7 @@ h = ops.alloc_features(M, K, torch.bfloat16, dev); h.copy_(torch.randn(M, K, dev
 agg = ops.alloc_features(M, K, torch.bfloat16, dev); agg.copy_(torch.randn(M, K, device=dev))
 ws = torch.randn(K, N, device=dev).to(torch.bfloat16).t().contiguous()
 wn = torch.randn(K, N, device=dev).to(torch.bfloat16).t().contiguous()
-for variant in (4, 3):
+for variant in (0, 1):
     _lib.lib.dgll_hip_debug_tune(4, variant)
     for _ in range(3):
         dense.transform_bf16(h, ws, agg, wn, relu=True)

@@ -21,7 +21,7 @@ import csv,glob,collections
 agg=collections.defaultdict(lambda: collections.defaultdict(list))
 for f in sorted(glob.glob("$OUT/pmc_*.csv")):
     for r in csv.DictReader(open(f)):
-        k="res" if "res_kernel" in r["Kernel_Name"] else ("w8" if "w8" in r["Kernel_Name"] else "nt4")
+        k="res" if "res_kernel" in r["Kernel_Name"] else "nt4"
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
         agg[k]["dur_ns"].append(int(r["End_Timestamp"])-int(r["Start_Timestamp"]))
 for k,v in agg.items():

@@ -33,7 +33,7 @@ for K, N in [(256, 256), (100, 256), (256, 47)]:
 
     ideal = (2 * M * K + M * N) * 2 / 5e12 * 1e3
     from dgll_amd import _lib
-    for variant in (1, 3, 4, 1, 3, 4):   # 1 = the 4-wave kernel, 3 = the persistent 8-wave kernel, 4 = the resident-weights kernel
+    for variant in (1, 0, 1, 0):   # 1 = the 4-wave kernel, 0 = the shipped choice (the resident-weights kernel)
         _lib.lib.dgll_hip_debug_tune(4, variant)
         tf, ts = t(lambda: dense.transform_bf16(h, wst, agg, wnt, relu=True)), t(lambda: dense.transform_bf16(h, wst))
         print("   variant=%d  fused %.3f ms (%.2f TB/s)  single %.3f ms (%.2f TB/s)" % (
