@@ -485,8 +485,8 @@ __device__ __forceinline__ void res_issue1(const ResIssue& t, int i, u32x4_t& ds
 #define RES_TRACE(EV) do { } while (0)
 #endif
 
-// One 32-k half of a chunk through the wave's LDS tile ([32 rows][64 bytes], 16-byte slot q of row r at q ^ ((r >> 1) & 3):
-// conflict-free both ways): the two landed registers of every row group go in, two MFMA fragments (lane = row) come out, and
+// One 32-k half of a chunk through the wave's LDS tile ([32 rows][64 bytes], 16-byte slot q of row r at q ^ ((r >> 2) & 3):
+// conflict-free both ways -- tools/probes/lds_pattern.hip; (r >> 1) & 3 costs the b128 reads 4 extra cycles): the two landed registers of every row group go in, two MFMA fragments (lane = row) come out, and
 // the registers are refilled by the loads of the chunk D phases ahead.  One wave, in-order LDS: write -> read -> next write
 // needs no wait and no barrier.
 template <int RG, int H>
@@ -817,8 +817,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_res_kernel(const MfmaGemmAr
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int r = 16 * j + (lane >> 2);
-        L.tw_off[j] = r * 64 + (((lane & 3) ^ ((r >> 1) & 3)) * 16);
-        L.tr_off[j] = l32 * 64 + (((2 * j + half) ^ ((l32 >> 1) & 3)) * 16);
+        L.tw_off[j] = r * 64 + (((lane & 3) ^ ((r >> 2) & 3)) * 16);
+        L.tr_off[j] = l32 * 64 + (((2 * j + half) ^ ((l32 >> 2) & 3)) * 16);
     }
 
     int64_t blk = pair;

@@ -190,22 +190,30 @@ __global__ __launch_bounds__(512) void gradw_splitk_kernel(const GradWArgs a) {
             }
 }
 
-// dW[k][n] = sum over slabs, in slab order; one thread per output element of [X1 | X2]^T . G
+// dW[k][n] = sum over slabs in a FIXED order (deterministic): a 256-thread block owns 64 consecutive columns of one row of
+// [X1 | X2]^T . G; its four waves each add every fourth slab in slab order, then the four partial sums are added in wave order.
 __global__ __launch_bounds__(256) void gradw_reduce_kernel(const float* __restrict__ partial, int n_slabs, int kc_total, int kslabs0,
                                                            int K0, int K1, int N, float* __restrict__ dW0, int64_t ld0,
                                                            float* __restrict__ dW1, int64_t ld1) {
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int n = (int)(idx & 255), kc = (int)(idx >> 8);
-    if (kc >= kc_total || n >= N) return;
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int kc = blockIdx.x >> 2, n = (blockIdx.x & 3) * 64 + lane;
     const bool second = kc >= kslabs0 * 64;
     const int k = second ? kc - kslabs0 * 64 : kc;
-    if (k >= (second ? K1 : K0)) return;
+    if (k >= (second ? K1 : K0) || (blockIdx.x & 3) * 64 >= N) return;         // block-uniform
     float s = 0.0f;
-    const float* p = partial + (int64_t)kc * 256 + n;
-    const int64_t stride = (int64_t)kc_total * 256;
-    for (int t = 0; t < n_slabs; ++t) s += p[t * stride];
-    if (second) dW1[(int64_t)k * ld1 + n] = s;
-    else dW0[(int64_t)k * ld0 + n] = s;
+    if (n < N) {
+        const float* p = partial + (int64_t)kc * 256 + n;
+        const int64_t stride = (int64_t)kc_total * 256;
+        for (int t = w; t < n_slabs; t += 4) s += p[t * stride];
+    }
+    part[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && n < N) {
+        const float v = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+        if (second) dW1[(int64_t)k * ld1 + n] = v;
+        else dW0[(int64_t)k * ld0 + n] = v;
+    }
 }
 
 }  // namespace dgll
@@ -261,8 +269,7 @@ DGLL_API int dgll_hip_grad_weight_bf16(void* stream, const void* X1, int64_t ldx
     hipLaunchKernelGGL(gradw_splitk_kernel, grid, dim3(512), 2 * kGwTile, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "gradw_splitk_kernel launch");
-    const int64_t outs = (int64_t)ks_total * 64 * 256;
-    hipLaunchKernelGGL(gradw_reduce_kernel, dim3((uint32_t)((outs + 255) / 256)), dim3(256), 0, s, a.partial, used, ks_total * 64,
+    hipLaunchKernelGGL(gradw_reduce_kernel, dim3((uint32_t)(ks_total * 64 * 4)), dim3(256), 0, s, a.partial, used, ks_total * 64,
                        a.kslabs[0], K1, K2, N, dW1, lddw1, dW2, lddw2);
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "gradw_reduce_kernel launch");
