@@ -361,11 +361,14 @@ class _DistSageLayer(torch.autograd.Function):
                     gagg = gagg * inv.unsqueeze(1).to(gagg.dtype)
             state = _aggregate_backward_start(engine, gagg)
         # everything below up to the finish overlaps the exchange
-        gws = dense.grad_weight(h, g) if ctx.needs_input_grad[1] else None
-        gwn = dense.grad_weight(agg, g) if ctx.needs_input_grad[2] else None
+        if ctx.needs_input_grad[1] and ctx.needs_input_grad[2]:
+            gws, gwn = dense.grad_weight_pair(h, agg, g)                          # one launch, g read once
+        else:
+            gws = dense.grad_weight(h, g) if ctx.needs_input_grad[1] else None
+            gwn = dense.grad_weight(agg, g) if ctx.needs_input_grad[2] else None
         gh = None
         if state is not None:
-            _, gh = engine.rows_of(torch.mm(g, wsd.t()))                          # self path
+            _, gh = engine.rows_of(dense.input_grad(g, wsd))                      # self path
             gate = h if (ctx.gate_input and h.stride(1) == 1) else None
             gh = _aggregate_backward_finish(engine, state, into=gh, gate=gate)
             if ctx.gate_input and gate is None:

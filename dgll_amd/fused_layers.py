@@ -82,7 +82,7 @@ class _SageGraphLayerTransformFirst(torch.autograd.Function):
         aggz = ops.spmm_raw(graph, z, reduce=reduce)
         if dense._mfma_ok(h) and aggz.dtype == torch.bfloat16 and aggz.stride(1) == 1 and ws.shape[1] <= 256:
             # act(agg + h.Ws) in ONE MFMA launch: the aggregated term rides in the epilogue (library: addmm + ReLU pass)
-            out = dense.transform_bf16(h, wsd.t(), relu=relu, addend=aggz)
+            out = dense.transform_bf16(h, wsd.t(), relu=relu, addend=aggz, ld_align=64 if ws.shape[1] < 64 else None)
         else:
             out = torch.addmm(aggz, h, wsd)
             if relu:
@@ -98,11 +98,15 @@ class _SageGraphLayerTransformFirst(torch.autograd.Function):
         # the (masked) gradient in a buffer whose rows start on a 128-byte line: it is gathered and fed to the MFMA kernel
         line = 128 // g.element_size()
         pad = line if g.shape[1] < line else (16 // g.element_size())
-        gm = ops.alloc_features(g.shape[0], g.shape[1], g.dtype, g.device, pad_to=pad)
-        if ctx.relu and not ctx.grad_is_gated:
-            torch.ops.aten.threshold_backward.grad_input(g, out, 0, grad_input=gm)
+        masked = ctx.relu and not ctx.grad_is_gated
+        if not masked and g.stride(1) == 1 and g.stride(0) % pad == 0 and g.data_ptr() % 16 == 0:
+            gm = g                                             # already laid out that way (the loss kernel's gradient is)
         else:
-            gm.copy_(g)
+            gm = ops.alloc_features(g.shape[0], g.shape[1], g.dtype, g.device, pad_to=pad)
+            if masked:
+                torch.ops.aten.threshold_backward.grad_input(g, out, 0, grad_input=gm)
+            else:
+                gm.copy_(g)
         # d/dz of reduce_A(z): A^T . g (1/deg folded into a scaled copy of the narrow gradient)
         if ctx.reduce == "mean":
             gp = ops.alloc_features(g.shape[0], g.shape[1], g.dtype, g.device, pad_to=pad)

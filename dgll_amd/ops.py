@@ -262,7 +262,10 @@ class _CrossEntropy(torch.autograd.Function):
         z, target, count = ctx.saved_tensors
         per_row = ctx.reduction == "none"
         scale = (g.float() / count if count is not None else g.float()).reshape(-1) if not per_row else None
-        grad = torch.empty_like(z)
+        # rows of the gradient start on 16-byte (narrow bf16 logits: 128-byte) boundaries: the layer below gathers it and feeds
+        # it to the MFMA kernels as it is, without a re-layout pass over [N, C]
+        line = 128 // z.element_size()
+        grad = alloc_features(z.shape[0], z.shape[1], z.dtype, z.device, pad_to=line if z.shape[1] < line else 16 // z.element_size())
         _xent_launch(z, target, ctx.soft, None, grad, scale)
         if per_row:
             grad = grad * g.to(grad.dtype).unsqueeze(1)

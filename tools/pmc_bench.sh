@@ -25,6 +25,6 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
   rm -rf /tmp/pmc_${TAG}_$tag
   rocprofv3 --kernel-trace --pmc $grp --output-format csv -d /tmp/pmc_${TAG}_$tag -o p -- python3 $R/bench.py $BENCH_ARGS --no-extra-graphs > $OUT/pmc_$tag.json 2> $OUT/pmc_$tag.log
   f=$(find /tmp/pmc_${TAG}_$tag -name '*counter_collection.csv' | head -1)
-  [ -n "$f" ] && grep -E "Counter_Name|spmm_csr_kernel|spmm_long_finalize|gemm_bf16" $f > $OUT/pmc_$tag.csv
+  [ -n "$f" ] && grep -E "Counter_Name|spmm_csr_kernel|spmm_long_finalize|gemm_bf16|gradw_" $f > $OUT/pmc_$tag.csv
 done
 ls -la $OUT
