@@ -95,3 +95,39 @@ def test_transform_dual_matches_two_products(m, k, n):
             assert float(d.max()) <= 2.0 ** -6 * float(single.float().abs().max())
         ref = a.double().cpu() @ w.double().cpu().t()
         assert float((o.double().cpu() - ref).abs().max()) <= 1e-2 * float(ref.abs().max()) + 1e-3
+
+
+def test_grad_weight_edge_cases():
+    """Empty and tiny reductions, more slabs than rows, and the argument checks of the C entry point."""
+    from dgll_amd import _lib, dense
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(11)
+    for m in (1, 15, 17, 100):                       # fewer rows than one 32-row step / than the slab count
+        x = torch.randn(m, 64, device=dev).to(torch.bfloat16)
+        g = torch.randn(m, 72, device=dev).to(torch.bfloat16)
+        got = dense._grad_weight_hip(x, None, g)[0]
+        assert float((got.double().cpu() - _ref(x, g)).abs().max()) <= 1e-3 * max(1.0, float(_ref(x, g).abs().max()))
+    x0 = torch.zeros(0, 64, device=dev, dtype=torch.bfloat16)
+    g0 = torch.zeros(0, 72, device=dev, dtype=torch.bfloat16)
+    z = dense._grad_weight_hip(x0, None, g0)[0]
+    assert z.shape == (64, 72) and float(z.abs().max()) == 0.0
+    # a leading dimension that is not a multiple of 8 elements is refused, not mis-read
+    x = torch.randn(64, 60, device=dev).to(torch.bfloat16)
+    g = torch.randn(64, 64, device=dev).to(torch.bfloat16)
+    with pytest.raises(_lib.DgllHipError):
+        dense._grad_weight_hip(x, None, g)
+    assert not dense._gradw_ok(x)                     # ... and the public wrappers never send it there
+    ref = _ref(x, g)
+    assert float((dense.grad_weight(x, g).double().cpu() - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
+
+
+def test_transform_dual_argument_checks():
+    from dgll_amd import dense
+
+    dev = torch.device("cuda:0")
+    a = torch.randn(128, 64, device=dev).to(torch.bfloat16)
+    with pytest.raises(ValueError):
+        dense.transform_bf16_dual(a, torch.randn(32, 64, device=dev), torch.randn(48, 64, device=dev))
+    o1, o2 = dense.transform_bf16_dual(a, torch.randn(40, 64, device=dev), torch.randn(40, 64, device=dev))
+    assert o1.shape == (128, 40) and o2.shape == (128, 40)
