@@ -230,11 +230,17 @@ DGLL_API int dgll_hip_grad_weight_bf16(void* stream, const void* X1, int64_t ldx
                                        const void* G, int64_t ldg, int N, int64_t M, void* workspace, int64_t workspace_bytes,
                                        int n_slabs, float* dW1, int64_t lddw1, float* dW2, int64_t lddw2) {
     DGLL_REQUIRE(M >= 0 && N >= 0 && K1 >= 0 && K2 >= 0, "negative size");
-    DGLL_REQUIRE(X1 && G && dW1 && K1 > 0 && N > 0, "NULL operand");
+    DGLL_REQUIRE(dW1 && K1 > 0 && N > 0 && (M == 0 || (X1 && G)), "NULL operand");    // an empty reduction may come with NULL inputs
     DGLL_REQUIRE(K1 <= 256 && K2 <= 256 && N <= 256, "dgll_hip_grad_weight_bf16 handles K1, K2, N <= 256");
-    DGLL_REQUIRE((K2 == 0) == (X2 == nullptr) && (K2 == 0 || dW2), "second operand incomplete");
+    DGLL_REQUIRE((M == 0 || (K2 == 0) == (X2 == nullptr)) && (K2 == 0 || dW2), "second operand incomplete");
     DGLL_REQUIRE(n_slabs >= 1 && n_slabs <= 4096, "n_slabs");
     DGLL_REQUIRE(workspace && workspace_bytes >= dgll_hip_grad_weight_workspace(K1, K2, n_slabs), "workspace too small");
+    if (M == 0) {                                             // empty reduction: zeros
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        for (int k = 0; k < K1; ++k) DGLL_HIP_TRY(hipMemsetAsync(dW1 + (int64_t)k * lddw1, 0, (size_t)N * sizeof(float), s));
+        for (int k = 0; k < K2; ++k) DGLL_HIP_TRY(hipMemsetAsync(dW2 + (int64_t)k * lddw2, 0, (size_t)N * sizeof(float), s));
+        return DGLL_OK;
+    }
     // 16-byte loads: rows start on 16-byte boundaries
     DGLL_REQUIRE(aligned16(X1) && (ldx1 & 7) == 0 && ldx1 >= K1, "X1: 16-byte aligned rows (leading dimension a multiple of 8)");
     DGLL_REQUIRE(!X2 || (aligned16(X2) && (ldx2 & 7) == 0 && ldx2 >= K2), "X2: 16-byte aligned rows (leading dimension a multiple of 8)");
@@ -253,11 +259,6 @@ DGLL_API int dgll_hip_grad_weight_bf16(void* stream, const void* X1, int64_t ldx
     DGLL_REQUIRE(a.rows_per_slab * std::max(std::max(ldx1, ldx2), ldg) * 2 < (int64_t)1 << 32, "slab larger than 4 GiB: use more slabs");
     a.partial = static_cast<float*>(workspace);
     const int ks_total = a.kslabs[0] + a.kslabs[1];
-    if (M == 0) {                                             // empty reduction: zeros
-        for (int k = 0; k < K1; ++k) DGLL_HIP_TRY(hipMemsetAsync(dW1 + (int64_t)k * lddw1, 0, (size_t)N * sizeof(float), s));
-        for (int k = 0; k < K2; ++k) DGLL_HIP_TRY(hipMemsetAsync(dW2 + (int64_t)k * lddw2, 0, (size_t)N * sizeof(float), s));
-        return DGLL_OK;
-    }
     // slabs past the end of M (tiny M) would leave their partials unwritten: shrink the slab count instead
     const int used = (int)((M + a.rows_per_slab - 1) / a.rows_per_slab);
     a.n_slabs = used;

@@ -266,7 +266,7 @@ int dgll_hip_transform_bf16_dual(void* stream, const void* A, int64_t lda, int K
  * to two library GEMMs that each read G).  bf16 X1 [M, ldx1 >= K1], X2 [M, ldx2 >= K2] (NULL / K2 = 0: one product),
  * G [M, ldg >= N]; fp32 dW1 [K1, lddw1 >= N], dW2 [K2, lddw2 >= N]; K1, K2, N <= 256; rows 16-byte aligned (bases, and leading
  * dimensions multiples of 8).  Split over `n_slabs` row slabs (1..4096) whose partials are summed in slab order (deterministic);
- * `workspace`: dgll_hip_grad_weight_workspace(K1, K2, n_slabs) bytes of device memory.  M = 0 writes zeros.        */
+ * `workspace`: dgll_hip_grad_weight_workspace(K1, K2, n_slabs) bytes of device memory.  M = 0 (inputs may be NULL) writes zeros.      */
 int64_t dgll_hip_grad_weight_workspace(int K1, int K2, int n_slabs);
 int dgll_hip_grad_weight_bf16(void* stream, const void* X1, int64_t ldx1, int K1, const void* X2, int64_t ldx2, int K2,
                               const void* G, int64_t ldg, int N, int64_t M, void* workspace, int64_t workspace_bytes,
