@@ -141,3 +141,38 @@ def test_rmat27_int64_rowptr_path_is_exact(cuda_device):
     assert torch.equal(deg[small].long(), g.degrees()[small])
     del g, deg
     torch.cuda.empty_cache()
+
+
+def test_dense_backward_products_at_full_size(cuda_device):
+    """The MFMA weight-gradient and dual input-gradient kernels at the products row count (2 449 029 rows, 256 columns):
+    exact integer cases, additivity over a row split, the adjoint identity <g.W^T, x> = <g, x.W> that ties the two kernels
+    together, bit-identical reruns."""
+    from dgll_amd import dense
+
+    dev = cuda_device
+    m = 2_449_029
+    torch.manual_seed(1)
+    # small integers: every product and every partial sum is exact in bf16 x bf16 -> fp32 (|sum| < 2^24)
+    x = torch.randint(-2, 3, (m, 256), device=dev).to(torch.bfloat16)
+    g = torch.randint(-2, 3, (m, 256), device=dev).to(torch.bfloat16)
+    d1, d2 = dense.grad_weight_pair(x, g, g)                       # x^T.g and g^T.g
+    assert torch.equal(dense.grad_weight_pair(x, g, g)[0], d1)     # rerun: bit-identical
+    assert torch.equal(d2, d2.t())                                 # a Gram matrix is symmetric -- exactly, on integers
+    # additivity over a row split (exact on integers, whatever the slab boundaries)
+    h = m // 2 + 7
+    top, bot = dense.grad_weight(x[:h], g[:h]), dense.grad_weight(x[h:], g[h:])
+    assert torch.equal(top + bot, d1)
+    # column sums through a ones operand, against an integer reduction
+    ones = torch.ones(m, 64, device=dev, dtype=torch.bfloat16)
+    s = dense.grad_weight(ones, g)
+    assert torch.equal(s[0].long(), g.long().sum(0)) and torch.equal(s[0], s[63])
+    # adjoint identity between the input-gradient and the weight-gradient kernels, <g.W^T, y> = <y^T.g, W>, taken at
+    # y = the input-gradient kernel's own output so that both sides are a large positive number (a random y makes them a
+    # cancelling sum of 6e8 terms whose bf16 rounding noise is as large as the value)
+    gr = torch.randn(m, 256, device=dev).to(torch.bfloat16)
+    w = (torch.randn(256, 256, device=dev) / 16).to(torch.bfloat16)              # stored [in, out]
+    gx, gx2 = dense.transform_bf16_dual(gr, w, w)                                # g . W^T, bf16, twice
+    assert torch.equal(gx, gx2)
+    lhs = float((gx.double() ** 2).sum())                                        # <round(g.W^T), gx>
+    rhs = float((dense.grad_weight(gx, gr).double() * w.double()).sum())         # <gx^T.g, W> = <g.W^T, gx>
+    assert abs(lhs - rhs) <= 1e-3 * abs(rhs), (lhs, rhs)
