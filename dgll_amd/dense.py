@@ -90,6 +90,12 @@ def input_grads(g, wsd, wnd):
     return torch.mm(g, wsd.t()), torch.mm(g, wnd.t())
 
 
+def _rows(g):
+    """g with contiguous rows, keeping a padded leading dimension (a `.contiguous()` would squeeze a 16-byte aligned
+    [N, 47] view of a [N, 48] buffer into unaligned 94-byte rows and push the products below off the MFMA kernels)."""
+    return g if g.dim() == 2 and g.stride(1) == 1 else g.contiguous()
+
+
 def input_grad(g, wd):
     """g . W^T for a weight stored [in, out]: the MFMA kernel for tall bf16 gradients, else torch.mm."""
     if g.shape[0] >= 64 * _SLABS and _mfma_ok(g) and max(wd.shape) <= 256 and wd.shape[0] % 8 == 0:
@@ -226,7 +232,7 @@ class _Linear(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, wd = ctx.saved_tensors
-        g = g.contiguous()
+        g = _rows(g)
         gx = input_grad(g, wd) if ctx.needs_input_grad[0] else None
         gw = grad_weight(x, g) if ctx.needs_input_grad[1] else None
         return gx, gw
@@ -256,7 +262,7 @@ class _SkinnyLinear(torch.autograd.Function):
     def backward(ctx, g):
         x, wd = ctx.saved_tensors
         gd = g.to(x.dtype).contiguous()
-        gx = torch.mm(gd, wd.t()) if ctx.needs_input_grad[0] else None
+        gx = input_grad(gd, wd) if ctx.needs_input_grad[0] else None
         gw = grad_weight(x, gd) if ctx.needs_input_grad[1] else None
         return gx, gw
 
