@@ -1,3 +1,5 @@
+// NOTE: superseded by read_ring.hip.  hipcc hoists all 32 loads of a row group ahead of their uses here, so the DEPTH parameter is
+// NOT enforced (every variant has the same loads in flight) -- which is why this probe reads 4.4-4.6 TB/s whatever the setting.
 // Micro-benchmark: HBM read rate vs (waves per CU) x (loads in flight per wave), persistent grid, fragment-shaped loads of
 // two [M, 256] bf16 operands (the fused transform's activation traffic: 8 chunks of 128 bytes per row group).
 //   DEPTH = chunks in flight per wave (4 loads each); WPB = waves per block; one block per CU (LDS-limited).
