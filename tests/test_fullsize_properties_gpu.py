@@ -143,6 +143,30 @@ def test_rmat27_int64_rowptr_path_is_exact(cuda_device):
     torch.cuda.empty_cache()
 
 
+def test_rmat27_sized_transform_is_exact_on_integers(cuda_device):
+    """BASELINE config 5's dense half, S = X.W (gcnconv.py:30) at 134 217 728 rows x 128 bf16 columns on one GPU: with
+    entries in {-1, 0, 1} every product and every partial sum is an integer of magnitude <= 128 -- exact in fp32 and in the
+    bf16 output -- so the MFMA kernel must reproduce an fp32 product bit for bit on any slice of rows."""
+    from dgll_amd import dense
+
+    dev = cuda_device
+    m = 1 << 27
+    torch.manual_seed(27)
+    x = torch.randint(-1, 2, (m, 128), device=dev, dtype=torch.int8).to(torch.bfloat16)
+    w = torch.randint(-1, 2, (128, 128), device=dev, dtype=torch.int8).to(torch.bfloat16)        # stored [out, in]
+    y = dense.transform_bf16(x, w)
+    assert y.shape == (m, 128) and y.dtype == torch.bfloat16
+    for lo, hi in ((0, 4096), (m // 3, m // 3 + 4096), (m - 4096, m), ((1 << 26) - 2048, (1 << 26) + 2048)):
+        ref = (x[lo:hi].float() @ w.float().t()).to(torch.bfloat16)
+        assert torch.equal(y[lo:hi], ref)
+    # a checksum over ALL rows: column sums of y against column sums of x pushed through w (integers, exact in fp64)
+    ysum = y.double().sum(0)
+    xsum = x.double().sum(0)
+    assert torch.equal(ysum, xsum @ w.double().t())
+    del x, y
+    torch.cuda.empty_cache()
+
+
 def test_dense_backward_products_at_full_size(cuda_device):
     """The MFMA weight-gradient and dual input-gradient kernels at the products row count (2 449 029 rows, 256 columns):
     exact integer cases, additivity over a row split, the adjoint identity <g.W^T, x> = <g, x.W> that ties the two kernels

@@ -61,3 +61,21 @@ for method in (["degree", "random"] if g.nnz >= (1 << 30) else ["lpa", "degree",
     timed(g2, "reorder(%s), %.1f s:" % (method, dt))
     del g2, perm, y2
     torch.cuda.empty_cache()
+
+# the dense half of config 5 (S = X.W, gcnconv.py:30) at the same row count
+from dgll_amd import dense  # noqa: E402
+
+del x
+torch.cuda.empty_cache()
+xs = torch.randn(g.n_rows, F, device=dev).to(torch.bfloat16)
+w = (torch.randn(F, F, device=dev) / F ** 0.5).to(torch.bfloat16)
+dense.transform_bf16(xs, w)
+torch.cuda.synchronize()
+a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+a.record()
+for _ in range(3):
+    dense.transform_bf16(xs, w)
+b.record()
+torch.cuda.synchronize()
+ms = a.elapsed_time(b) / 3
+print("MFMA transform [%d, %d] . [%d, %d] bf16: %.1f ms, %.2f TB/s" % (g.n_rows, F, F, F, ms, g.n_rows * F * 2 * 2 / ms / 1e9), flush=True)
