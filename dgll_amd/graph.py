@@ -205,8 +205,9 @@ class CSRGraph:
         if self.n_rows != self.n_cols:
             raise ValueError("reorder needs a square adjacency (one id space for rows and columns)")
         if method == "lpa" and self.nnz >= _reorder._LARGE_NNZ:
-            method = "random"         # label propagation sorts the edge list in one call; beyond 2^30 edges only break the id order
-                                      # (measured on RMAT-25 / 27: random 69 / 66 %, hubs-first 64 / 64 %, generator ids 56 / 54 % of 8 TB/s)
+            method = "degree"         # label propagation sorts the edge list in one call; beyond 2^30 edges: hubs first (what
+                                      # "lpa" degenerates to on a structure-free graph).  RMAT-25 / 27, F = 128 bf16, final
+                                      # round-2 kernels: hubs-first 86 / 86 %, random 67 / 70 %, generator ids 41 / 53 % of 8 TB/s
         perm = _reorder.locality_order(self.rowptr, self.col, self.n_rows, method=method, seed=seed, sweeps=sweeps)
         return _reorder.relabel(self, perm), perm
 

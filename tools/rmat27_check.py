@@ -50,7 +50,7 @@ def timed(graph, label):
 
 timed(g, "generator's (RMAT) ids:")
 # the engine's locality pass: above 2^30 edges label propagation's edge sort does not fit one call, so the pass is the hub-first
-# order ("degree") -- what "lpa" degenerates to on a structure-free graph anyway -- or a plain random relabelling
+# order ("degree", the engine's default there) -- what "lpa" degenerates to on a structure-free graph anyway; "random" for comparison
 for method in (["degree", "random"] if g.nnz >= (1 << 30) else ["lpa", "degree", "random"]):
     t0 = time.time()
     g2, perm = g.reorder(method=method)
