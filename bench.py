@@ -375,6 +375,18 @@ def main():
                        "epilogue": extra, "G_edges_per_s": tag_nnz / (avg_ms * 1e-3) / 1e9,
                        "algorithmic_bytes": b_alg, "algorithmic_GBps": b_alg / (avg_ms * 1e-3) / 1e9,
                        "frac_algorithmic": b_alg / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+    # the dense kernels next to the aggregation (all hand-written MFMA: no library GEMM in the step), same HIP-event timing
+    dense_table = {}
+    for tag, (cnt, avg_ms) in launches.items():
+        if tag[0] not in ("transform", "transform_dual", "grad_weight"):
+            continue
+        kind, m, k1, k2, n_out, extra = tag
+        b_alg = m * (k1 + k2 + n_out) * 2 + (m * n_out * 2 if ("gate" in extra or "addend" in extra) else 0)
+        name = "%s M=%d K=%d%s N=%d%s" % (kind, m, k1, ("+%d" % k2) if k2 else "", n_out, (" " + extra) if extra else "")
+        dense_table[name] = {"count": cnt, "avg_ms": avg_ms, "algorithmic_bytes": b_alg,
+                             "algorithmic_GBps": b_alg / (avg_ms * 1e-3) / 1e9,
+                             "frac_of_hbm_peak": b_alg / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                             "frac_of_streaming_ceiling_5500": b_alg / (avg_ms * 1e-3) / 1e9 / 5500.0}
     # headline = the LONGEST hidden-width SpMM launch of the step (forward mean aggregation or the weighted, gated,
     # accumulating transposed launch of the backward pass, whichever takes longer)
     roofline = None
@@ -427,7 +439,8 @@ def main():
         "epoch_time_s": ms_per_step / 1e3, "loss": global_loss,
         "roofline": roofline,
         "spmm_launch_table": table,
-    }
+        "dense_launch_table": dense_table,   # bytes = 2 (K1 + K2 + N) per row (+ 2 N for a gate / addend operand); the 5.5 TB/s
+    }                                        # "streaming ceiling" is what a trivial 2R:1W kernel reaches (tools/probes/rw_mix.hip)
     if trace:
         result["warmup_loss_trace"] = trace
     if world == 1 and not args.no_extra and not args.dataset:

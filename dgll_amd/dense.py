@@ -23,6 +23,14 @@ def _pad_wt(wt, rows=None):
     return out
 
 
+def _timed(tag, device):
+    """HIP-event bracket of one launch for bench.py's tables (ops.LaunchTimer); None when no timer is active."""
+    from . import ops
+
+    timer = ops.LaunchTimer.active
+    return timer.start(tag, device) if timer is not None else None
+
+
 def _mfma_ok(*mats):
     return all(m is None or (m.is_cuda and m.dtype == torch.bfloat16 and m.dim() == 2 and m.stride(1) == 1
                              and m.stride(0) % 8 == 0 and m.data_ptr() % 16 == 0) for m in mats)
@@ -51,6 +59,9 @@ def transform_bf16(a1, wt1, a2=None, wt2=None, relu=False, out_dtype=torch.bfloa
             raise ValueError("out_gate must be bf16 [M, N] with contiguous rows")
         if addend is not None and (addend.dtype != torch.bfloat16 or addend.shape != (m, n) or addend.stride(1) != 1):
             raise ValueError("addend must be bf16 [M, N] with contiguous rows")
+        end = _timed(("transform", m, a1.shape[1], a2.shape[1] if a2 is not None else 0, n,
+                      "+".join(t for t, on in (("gate", out_gate is not None), ("addend", addend is not None),
+                                               ("row_scale", row_scale is not None), ("mask", mask is not None)) if on)), a1.device)
         code = _lib.lib.dgll_hip_transform_bf16_add(
             torch.cuda.current_stream(a1.device).cuda_stream, a1.data_ptr(), a1.stride(0), a1.shape[1], p1.data_ptr(),
             p1.stride(0), a2.data_ptr() if a2 is not None else None, a2.stride(0) if a2 is not None else 0,
@@ -61,6 +72,8 @@ def transform_bf16(a1, wt1, a2=None, wt2=None, relu=False, out_dtype=torch.bfloa
             out_gate.data_ptr() if out_gate is not None else None, out_gate.stride(0) if out_gate is not None else 0,
             row_scale.data_ptr() if row_scale is not None else None,
             addend.data_ptr() if addend is not None else None, addend.stride(0) if addend is not None else 0)
+        if end is not None:
+            end.record(torch.cuda.current_stream(a1.device))
     _lib.check(code, "dgll_hip_transform_bf16")
     return out
 
@@ -76,9 +89,12 @@ def transform_bf16_dual(a, wt1, wt2):
     outs = [torch.empty((m, ld), dtype=torch.bfloat16, device=a.device) for _ in range(2)]
     o1, o2 = (o[:, :n] if ld != n else o for o in outs)
     with torch.cuda.device(a.device):
+        end = _timed(("transform_dual", m, a.shape[1], 0, 2 * n, ""), a.device)
         code = _lib.lib.dgll_hip_transform_bf16_dual(
             torch.cuda.current_stream(a.device).cuda_stream, a.data_ptr(), a.stride(0), a.shape[1], p1.data_ptr(), p2.data_ptr(),
             p1.stride(0), p1.shape[0], o1.data_ptr(), o1.stride(0), o2.data_ptr(), o2.stride(0), m, n)
+        if end is not None:
+            end.record(torch.cuda.current_stream(a.device))
     _lib.check(code, "dgll_hip_transform_bf16_dual")
     return o1, o2
 
@@ -125,11 +141,14 @@ def _grad_weight_hip(x1, x2, g):
         ws = _GW_WORKSPACE[key] = torch.empty(need // 4, dtype=torch.float32, device=g.device)
     d1 = torch.empty((k1, n), dtype=torch.float32, device=g.device)
     d2 = torch.empty((k2, n), dtype=torch.float32, device=g.device) if x2 is not None else None
+    end = _timed(("grad_weight", m, k1, k2, n, ""), g.device)
     code = _lib.lib.dgll_hip_grad_weight_bf16(
         torch.cuda.current_stream(g.device).cuda_stream, x1.data_ptr(), x1.stride(0), k1,
         x2.data_ptr() if x2 is not None else None, x2.stride(0) if x2 is not None else 0, k2, g.data_ptr(), g.stride(0), n, m,
         ws.data_ptr(), ws.numel() * 4, slabs, d1.data_ptr(), d1.stride(0), d2.data_ptr() if d2 is not None else None,
         d2.stride(0) if d2 is not None else 0)
+    if end is not None:
+        end.record(torch.cuda.current_stream(g.device))
     _lib.check(code, "dgll_hip_grad_weight_bf16")
     return d1, d2
 
