@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Headline benchmark: aggregated edges/s (+ epoch time) of full-graph 3-layer GraphSAGE training on an
-ogbn-products-shaped synthetic graph, hidden = 256, bf16 storage / fp32 accumulation (BASELINE.json `metric`).
+"""Benchmark of the aggregation hot path.  The default run is BASELINE.json's headline: aggregated edges/s (+ epoch time)
+of full-graph 3-layer GraphSAGE training on an ogbn-products-sized synthetic graph, hidden = 256, bf16 storage / fp32
+accumulation.
 
     python bench.py --gpus N --steps K --warmup W        N = 1: in-process.  N > 1 without WORLD_SIZE in the environment:
                                                          the parent starts N ranks itself (before touching the GPU) through
@@ -10,17 +11,27 @@ ogbn-products-shaped synthetic graph, hidden = 256, bf16 storage / fp32 accumula
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W        (one rank per GPU, RCCL; WORLD_SIZE must equal --gpus)
 
-A step = one pass of the hot path over the whole graph: forward through three sageConv layers (mean neighbour
-aggregation = CSR SpMM in libdgll_hip.so, then the dense transforms), cross-entropy over all nodes, backward
-(SpMM on the transposed CSR for every layer whose input needs a gradient), Adam update.  One step is one epoch.
-"aggregated edges" counts nnz once per SpMM-type launch (3 forward + 2 backward per step).
+--workload picks the BASELINE.json config that is measured (one JSON line each, same fields):
+    sage       (default) config 3: full-graph 3-layer GraphSAGE, products size.  A step = forward through three sageConv
+               layers (mean aggregation = CSR SpMM in libdgll_hip.so, then the MFMA transforms), cross-entropy over all
+               nodes, backward (SpMM on the transposed CSR), Adam.  One step is one epoch.  5 SpMM-type launches per step.
+    gat        config 4: full-graph 2-layer SpGAT, 8 heads x 32 -> 47 classes, the same graph + self-loops.  6 gather passes
+               per step (forward, backward over rows, backward over the transposed rows; two layers).
+    minibatch  config 2: Reddit-shaped graph, sampled 3-layer GraphSAGE (fan-out 25-10-10, batch 1024, hidden 256 bf16)
+               through the bit-exact host sampler, the hot-node feature cache (PARTIAL: pinned-host leg carries traffic) and
+               the mini-batch queue.  A step = one batch.
+    rmat27     config 5 on ONE GPU: RMAT-27 (134 M nodes, > 2^31 nonzeros), F = 128 bf16: a step = one mean-SpMM pass + the
+               dense X.W of the same layer (gcnconv.py:30-31).  --scale N for a smaller RMAT.
 
-Workload: exactly ogbn-products' size (2 449 029 nodes, 61 859 140 undirected = 123 718 280 directed edges), 64 planted
-communities holding 90 % of the edges, node ids RANDOMLY PERMUTED (what a raw dataset looks like).  The engine's own
-one-off locality pass (CSRGraph.reorder, --reorder) relabels the nodes before training, as the METIS relabelling of
-BASELINE config 3 does; --reorder none measures the raw order, --no-permute the generator's community-sorted order.
+Workload (sage / gat): exactly ogbn-products' size (2 449 029 nodes, 61 859 140 undirected = 123 718 280 directed edges), 64
+planted communities holding 90 % of the edges, node ids RANDOMLY PERMUTED (what a raw dataset looks like).  The engine's own
+one-off locality pass (CSRGraph.reorder, --reorder) relabels the nodes before training, as the METIS relabelling of BASELINE
+config 3 does; --reorder none measures the raw order, --no-permute the generator's community-sorted order.
 
-Rank 0 prints ONE JSON line; see DESIGN.md section 6 for the fields (`roofline`, `cpu_baseline`).
+Rank 0 prints ONE JSON line; DESIGN.md section 6 explains every field.  `roofline.frac` has ONE definition, named in
+`roofline.frac_definition`: HBM-side counter traffic of that very launch (profiles/traffic.json -- rocprofv3 FETCH_SIZE /
+WRITE_SIZE over this program, corrected by the ratios calibrated in the same pass, and only when the entry was collected
+with THIS build of libdgll_hip.so) / the live launch time / peak; without a matching entry, the section-8(d) formula.
 """
 import argparse
 import json
@@ -37,6 +48,7 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+METRIC = "aggregated edges/sec + epoch time, 3-layer GraphSAGE ogbn-products, 1/2/4/8 GPU"
 
 
 def parse_args(argv=None):
@@ -44,11 +56,13 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", choices=["sage", "gat", "minibatch", "rmat27"], default="sage")
     ap.add_argument("--nodes", type=int, default=2_449_029, help="ogbn-products node count")
     ap.add_argument("--undirected-edges", type=int, default=61_859_140, help="ogbn-products undirected edge count")
     ap.add_argument("--in-feats", type=int, default=100)
     ap.add_argument("--hidden", type=int, default=256)
     ap.add_argument("--classes", type=int, default=47)
+    ap.add_argument("--heads", type=int, default=8, help="gat: attention heads of the hidden layer (hidden / heads columns each)")
     ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--feat-align", type=int, default=64,
@@ -72,12 +86,27 @@ def parse_args(argv=None):
     ap.add_argument("--dataset", default=None,
                     help="run a REAL dataset instead of the synthetic graph when its files are present: a .npz edge-list dump, a "
                          "directory with reddit_data.npz / reddit_graph.npz, or an OGB raw directory (dgll_amd/data/formats.py)")
+    # minibatch (config 2) / rmat27 (config 5)
+    ap.add_argument("--mb-nodes", type=int, default=232_965)
+    ap.add_argument("--mb-undirected-edges", type=int, default=57_300_000, help="Reddit: 114.6 M directed edges")
+    ap.add_argument("--mb-feats", type=int, default=602)
+    ap.add_argument("--mb-classes", type=int, default=41)
+    ap.add_argument("--mb-batch", type=int, default=1024)
+    ap.add_argument("--mb-fanouts", default="25,10,10")
+    ap.add_argument("--mb-cache-frac", type=float, default=0.5, help="fraction of the nodes whose features sit in the HBM cache")
+    ap.add_argument("--scale", type=int, default=27, help="rmat27: RMAT scale (27 = config 5; smaller for a quick run)")
     return ap.parse_args(argv)
 
 
 def alg_bytes(nnz, n_rows, feat, x_bytes, y_bytes, weighted):
     """every edge is charged one full feature-row read."""
     return nnz * (feat * x_bytes + 4 + (4 if weighted else 0)) + n_rows * (feat * y_bytes + 8)
+
+
+def gat_alg_bytes(nnz, n_rows, feat, esz, heads):
+    """SURVEY.md section 8(d), fused GAT pass: per edge one feature row + the column id + one score per head; per row the
+    output row, the row pointer, one score and one row sum per head."""
+    return nnz * (feat * esz + 4 + 4 * heads) + n_rows * (feat * esz + 8 + 8 * heads)
 
 
 def _free_port():
@@ -119,7 +148,41 @@ def spawn_ranks(args):
     return 0
 
 
-def cpu_baseline(graph, feat, sample_rows, seed):
+# ---------------------------------------------------------------------------------------------------- host / CPU side
+def host_info():
+    """Threads torch will use, physical cores, CPU model (the GPU box's host; printed with every cpu_baseline)."""
+    model, pairs = "unknown", set()
+    try:
+        phys = core = None
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name") and model == "unknown":
+                    model = line.split(":", 1)[1].strip()
+                elif line.startswith("physical id"):
+                    phys = line.split(":", 1)[1].strip()
+                elif line.startswith("core id"):
+                    core = line.split(":", 1)[1].strip()
+                elif not line.strip():
+                    if phys is not None and core is not None:
+                        pairs.add((phys, core))
+                    phys = core = None
+    except OSError:
+        pass
+    threads = os.cpu_count() or 1
+    return {"threads": threads, "physical_cores": len(pairs) or threads, "cpu_model": model}
+
+
+def median3(fn):
+    fn()                                                              # warm-up
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return sorted(ts)[1]
+
+
+def cpu_baseline_spmm(graph, feat, sample_rows, seed):
     """BASELINE.md section 5 on the GPU box's host cores, on a bounded sample of the SAME tensors (the first `sample_rows`
     rows of the adjacency the GPU ran, the same feature width, fp32): the reference's own op -- torch.spmm on a COO tensor
     (dgll/nn/Convolution/gcnconv.py:31, restated in oracle/torch_ref.spmm_coo) -- plus torch.sparse.mm on CSR and the C
@@ -128,6 +191,7 @@ def cpu_baseline(graph, feat, sample_rows, seed):
 
     from oracle import cref, torch_ref
 
+    host = host_info()
     rows = min(sample_rows, graph.n_rows)
     rowptr_t = graph.rowptr[:rows + 1].cpu()
     nnz = int(rowptr_t[-1])
@@ -135,118 +199,340 @@ def cpu_baseline(graph, feat, sample_rows, seed):
     rng = np.random.default_rng(seed)
     x = rng.standard_normal((graph.n_cols, feat), dtype=np.float32)
     xt = torch.from_numpy(x)
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
-    cref.set_num_threads(cores)
+    torch.set_num_threads(host["threads"])
+    cref.set_num_threads(host["threads"])
     deg = (rowptr_t[1:] - rowptr_t[:-1])
     row_t = torch.repeat_interleave(torch.arange(rows), deg)
     val_t = (1.0 / deg.clamp(min=1).to(torch.float32))[row_t]              # mean = D^-1 A, utils.py:171
     col64 = col_t.to(torch.int64)
-
-    def median3(fn):
-        fn()                                                              # warm-up
-        ts = []
-        for _ in range(3):
-            t0 = time.perf_counter()
-            fn()
-            ts.append(time.perf_counter() - t0)
-        return sorted(ts)[1]
-
     t_coo = median3(lambda: torch_ref.spmm_coo(row_t, col64, val_t, xt, rows))
     csr = torch.sparse_csr_tensor(rowptr_t, col64, val_t, size=(rows, graph.n_cols))
     t_csr = median3(lambda: torch.sparse.mm(csr, xt))
     rp, cc = rowptr_t.numpy(), col_t.numpy()
     t_c = median3(lambda: cref.spmm_csr(rp, cc, None, x, reduce="mean"))
-    try:
-        with open("/proc/cpuinfo") as f:
-            model = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), "unknown")
-    except OSError:
-        model = "unknown"
     return {
-        "value": nnz / t_coo, "unit": "edges/s", "cores": cores, "kind": "port",
+        "value": nnz / t_coo, "unit": "edges/s", "cores": host["threads"], "kind": "port",
         "sample": "mean-SpMM of the first %d rows (%d edges) of the benchmark's own adjacency against all %d feature rows, "
                   "F=%d fp32; value = the reference's op torch.spmm(adj_coo, X) (gcnconv.py:31) as restated in "
                   "oracle/torch_ref.spmm_coo; 1 warm-up + median of 3" % (rows, nnz, graph.n_cols, feat),
         "torch_sparse_mm_csr_edges_per_s": nnz / t_csr,
         "oracle_c_openmp_csr_edges_per_s": nnz / t_c,
         "algorithmic_GBps": alg_bytes(nnz, rows, feat, 4, 4, True) / t_coo / 1e9,
-        "torch_version": torch.__version__, "cpu_model": model, "threads": cores,
+        "torch_version": torch.__version__, "cpu_model": host["cpu_model"], "threads": host["threads"],
+        "physical_cores": host["physical_cores"],
         "seconds_per_run": {"torch_spmm_coo": t_coo, "torch_sparse_mm_csr": t_csr, "oracle_c_openmp": t_c},
     }
 
 
-def workload_signature(args, nnz):
-    return {"nodes": args.nodes, "nnz": nnz, "locality": args.locality, "permuted_ids": not args.no_permute,
-            "reorder": args.reorder, "hidden": args.hidden, "dtype": args.dtype}
+def cpu_baseline_gat(graph, heads, fo, alpha, sample_rows, seed):
+    """The fused GAT forward pass on the host cores, first `sample_rows` rows of the benchmark's adjacency (with its
+    self-loops) against all nodes' transformed features, fp32: the reference's op sequence of sparseGatConv.forward
+    (gatconv.py:111-148: per-edge scores, exp(-leakyrelu), two sparse products, division, ELU) restated on the index lists
+    (oracle/torch_ref.py, segment sums by index_add) -- the reference itself needs a dense N x N adjacency (gatconv.py:115)
+    and cannot run at this size -- plus the C oracle (oracle/oracle.c, OpenMP)."""
+    import ctypes as C
+
+    import numpy as np
+
+    from oracle import cref
+
+    host = host_info()
+    rows = min(sample_rows, graph.n_rows)
+    rowptr_t = graph.rowptr[:rows + 1].cpu()
+    nnz = int(rowptr_t[-1])
+    col_t = graph.col[:nnz].cpu()
+    rng = np.random.default_rng(seed)
+    width = heads * fo
+    h = rng.standard_normal((graph.n_cols, width), dtype=np.float32)
+    s = rng.standard_normal((graph.n_cols, heads), dtype=np.float32)
+    t = rng.standard_normal((graph.n_cols, heads), dtype=np.float32)
+    torch.set_num_threads(host["threads"])
+    cref.set_num_threads(host["threads"])
+    ht, st, tt = torch.from_numpy(h), torch.from_numpy(s), torch.from_numpy(t)
+    row_t = torch.repeat_interleave(torch.arange(rows), rowptr_t[1:] - rowptr_t[:-1])
+    col64 = col_t.to(torch.int64)
+
+    def torch_heads():
+        outs = []
+        for k in range(heads):                                            # the reference runs its heads one by one (gatconv.py:196)
+            hk = ht[:, k * fo:(k + 1) * fo]
+            e = torch.exp(-torch.nn.functional.leaky_relu(st[:rows, k][row_t] + tt[:, k][col64], alpha))
+            den = torch.zeros(rows).index_add_(0, row_t, e)
+            num = torch.zeros(rows, fo).index_add_(0, row_t, e[:, None] * hk[col64])
+            outs.append(torch.nn.functional.elu(num / den[:, None]))
+        return torch.cat(outs, 1)
+
+    t_torch = median3(torch_heads)
+    out = np.empty((rows, width), dtype=np.float32)
+    rp, cc = np.ascontiguousarray(rowptr_t.numpy()), np.ascontiguousarray(col_t.numpy())
+    lib = cref.lib()
+
+    def oracle_pass():
+        lib.oracle_gat_fwd_f32(rp.ctypes.data_as(C.c_void_p), cc.ctypes.data_as(C.c_void_p), h.ctypes.data_as(C.c_void_p),
+                               C.c_int64(width), s.ctypes.data_as(C.c_void_p), t.ctypes.data_as(C.c_void_p),
+                               out.ctypes.data_as(C.c_void_p), C.c_int64(width), None, None, C.c_int64(rows), C.c_int(heads),
+                               C.c_int(fo), C.c_float(alpha), C.c_int(1), C.c_int(0))
+
+    t_c = median3(oracle_pass)
+    return {
+        "value": nnz / t_torch, "unit": "edges/s", "cores": host["threads"], "kind": "port",
+        "sample": "fused GAT forward pass (%d heads x %d, fp32) over the first %d rows (%d edges) of the benchmark's adjacency "
+                  "against all %d nodes; value = sparseGatConv.forward's op sequence (gatconv.py:111-148) restated on index lists "
+                  "with torch CPU ops, heads one by one as gatconv.py:196; 1 warm-up + median of 3" % (heads, fo, rows, nnz, graph.n_cols),
+        "oracle_c_openmp_edges_per_s": nnz / t_c,
+        "algorithmic_GBps": gat_alg_bytes(nnz, rows, width, 4, heads) / t_torch / 1e9,
+        "torch_version": torch.__version__, "cpu_model": host["cpu_model"], "threads": host["threads"],
+        "physical_cores": host["physical_cores"],
+        "seconds_per_run": {"torch_index_add_heads": t_torch, "oracle_c_openmp": t_c},
+    }
 
 
-def main():
-    args = parse_args()
+# ---------------------------------------------------------------------------------------------------- roofline record
+def build_stamp():
+    from dgll_amd import build as hip_build
+
+    try:
+        with open(hip_build.STAMP) as f:
+            return f.read().strip()
+    except OSError:
+        return None
+
+
+def spmm_kernel_fragment(feat, dtype_name, weighted, extra):
+    """Name fragment of the spmm_csr_kernel instantiation a launch of this kind runs (wave-per-row variant, 16-byte rows)."""
+    bf = "bfloat16" in dtype_name
+    epv = 8 if bf else 4
+    vecs = -(-feat // epv)
+    lpr = 4
+    while lpr < 64 and lpr < vecs:
+        lpr <<= 1
+    t = "unsigned short" if bf else "float"
+    return "spmm_csr_kernel<%s, %s, %d, %d, %s, 4, %s>" % (t, t, epv, lpr, "true" if weighted else "false", "true" if extra else "false")
+
+
+def gat_kernel_fragment(heads, fo, dtype_name, kind):
+    """gat2_kernel instantiation of a pass (kind 0 forward, 1 rows, 2 transposed rows) -- edge.hip's gat2_pick."""
+    bf = "bfloat16" in dtype_name
+    epv = 8 if bf else 4
+    vph = fo // epv
+    lph = 1
+    while lph < vph:
+        lph <<= 1
+    nh = 1
+    for cand in (8, 4, 2, 1):
+        if cand * lph > 64 or (cand > 2 and heads % cand) or (cand > 1 and cand // 2 >= heads):
+            continue
+        nh = cand
+        break
+    while nh * lph < 4:
+        lph <<= 1
+    t = "unsigned short" if bf else "float"
+    return "gat2_kernel<%s, %s, %d, %d, %d, 4, %d>" % (t, t, epv, nh * lph, nh, kind)
+
+
+def load_traffic(sig, fragment):
+    """Counter traffic of one launch kind from profiles/traffic.json: the entry must match the workload signature, the kernel
+    instantiation AND the build stamp of the libdgll_hip.so that is loaded now -- a stale entry yields None."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            entries = json.load(f).get("entries", [])
+    except (OSError, ValueError):
+        return None
+    stamp = build_stamp()
+    for e in entries:
+        w = e.get("workload", {})
+        if e.get("kernel_fragment") == fragment and e.get("build_stamp") == stamp and stamp and \
+                all(w.get(k) == v for k, v in sig.items()):
+            return e
+    return None
+
+
+def roofline_record(dom, sig, kernel_desc, compulsory, world, extra=None):
+    """One `roofline` object.  `achieved` = algorithmic bytes (section 8(d)) / average live launch time.  `frac`: ONE definition,
+    named in frac_definition."""
+    achieved = dom["algorithmic_GBps"]
+    rec = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+           "frac_algorithmic": achieved / HBM_PEAK_GBPS, "traffic": None,
+           "kernel": kernel_desc, "kernel_fragment": dom["kernel_fragment"], "launches_timed": dom["count"],
+           "avg_launch_ms": dom["avg_ms"], "algorithmic_bytes_per_launch": dom["algorithmic_bytes"],
+           "compulsory_bytes_per_launch": compulsory, "edges_per_s_this_kernel": dom["nnz"] / (dom["avg_ms"] * 1e-3),
+           "build_stamp": build_stamp()}
+    entry = load_traffic(sig, dom["kernel_fragment"]) if world == 1 else None
+    if entry is not None:
+        rec["traffic"] = entry["hbm_bytes_per_launch"]
+        rec["traffic_source"] = {k: entry.get(k) for k in ("round", "fetch_size_kib", "write_size_kib", "ratio_read", "ratio_write",
+                                                           "l2_hit_rate", "avg_ns_under_pmc")}
+        hbm = entry["hbm_bytes_per_launch"] / (dom["avg_ms"] * 1e-3) / 1e9
+        rec["achieved_hbm_counters"] = hbm
+        rec["frac_hbm_counters"] = hbm / HBM_PEAK_GBPS
+        rec["frac"] = rec["frac_hbm_counters"]
+        rec["frac_definition"] = ("HBM-side counter bytes per launch (profiles/traffic.json: FETCH_SIZE / ratio_read + WRITE_SIZE / "
+                                  "ratio_write, same build) / live launch time / peak")
+    else:
+        rec["frac"] = rec["frac_algorithmic"]
+        rec["frac_definition"] = "algorithmic bytes (SURVEY 8(d) formula) / live launch time / peak (no counter pass for this build)"
+    if extra:
+        rec.update(extra)
+    return rec
+
+
+def launch_tables(launches, local_rows, heads_of=None):
+    """Per launch kind of the timed steps (HIP events on the launch stream, ops.LaunchTimer): gather passes and dense kernels."""
+    table, dense_table = {}, {}
+    for tag, (cnt, avg_ms) in launches.items():
+        if tag[0] == "spmm":
+            _, feat, dt, weighted, tag_nnz = tag[:5]
+            extra = tag[5] if len(tag) > 5 else ""
+            xb = 2 if "bfloat16" in dt else 4
+            b_alg = alg_bytes(tag_nnz, local_rows, feat, xb, xb, weighted)
+            name = "spmm F=%d %s %s%s nnz=%d" % (feat, dt.replace("torch.", ""), "weighted" if weighted else "unweighted",
+                                                 (" " + extra) if extra else "", tag_nnz)
+            table[name] = {"count": cnt, "avg_ms": avg_ms, "nnz": tag_nnz, "feat": feat, "weighted": bool(weighted),
+                           "epilogue": extra, "kernel_fragment": spmm_kernel_fragment(feat, dt, weighted, bool(extra))}
+        elif tag[0] == "gat":
+            _, kind, heads, fo, dt, tag_nnz, packed = tag
+            xb = 2 if "bfloat16" in dt else 4
+            b_alg = gat_alg_bytes(tag_nnz, local_rows, heads * fo, xb, heads)
+            name = "gat %s %d heads x %d %s%s nnz=%d" % (kind, heads, fo, dt.replace("torch.", ""), (" " + packed) if packed else "", tag_nnz)
+            table[name] = {"count": cnt, "avg_ms": avg_ms, "nnz": tag_nnz, "feat": heads * fo, "heads": heads, "pass": kind,
+                           "scores_in_row_padding": bool(packed),
+                           "kernel_fragment": gat_kernel_fragment(heads, fo, dt, {"fwd": 0, "bwd_rows": 1, "bwd_cols": 2}[kind])}
+        elif tag[0] in ("transform", "transform_dual", "grad_weight"):
+            kind, m, k1, k2, n_out, extra = tag
+            b_alg = m * (k1 + k2 + n_out) * 2 + (m * n_out * 2 if ("gate" in extra or "addend" in extra) else 0)
+            name = "%s M=%d K=%d%s N=%d%s" % (kind, m, k1, ("+%d" % k2) if k2 else "", n_out, (" " + extra) if extra else "")
+            dense_table[name] = {"count": cnt, "avg_ms": avg_ms, "algorithmic_bytes": b_alg,
+                                 "algorithmic_GBps": b_alg / (avg_ms * 1e-3) / 1e9,
+                                 "frac_of_hbm_peak": b_alg / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                 "frac_of_streaming_ceiling_5500": b_alg / (avg_ms * 1e-3) / 1e9 / 5500.0}
+            continue
+        else:
+            continue
+        table[name].update({"G_edges_per_s": tag_nnz / (avg_ms * 1e-3) / 1e9, "algorithmic_bytes": b_alg,
+                            "algorithmic_GBps": b_alg / (avg_ms * 1e-3) / 1e9,
+                            "frac_algorithmic": b_alg / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS})
+    return table, dense_table
+
+
+def workload_signature(args, nnz, **over):
+    sig = {"workload": args.workload, "nodes": args.nodes, "nnz": nnz, "locality": args.locality,
+           "permuted_ids": not args.no_permute, "reorder": args.reorder, "hidden": args.hidden, "dtype": args.dtype}
+    sig.update(over)
+    return sig
+
+
+# ---------------------------------------------------------------------------------------------------- process set-up
+class Ctx:
+    pass
+
+
+def setup(args):
     env_world = os.environ.get("WORLD_SIZE")
     if args.gpus > 1 and env_world is None:
         sys.exit(spawn_ranks(args))
-    world = int(env_world or "1")
-    if world != args.gpus:
-        print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+    c = Ctx()
+    c.world = int(env_world or "1")
+    if c.world != args.gpus:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, c.world), file=sys.stderr)
         sys.exit(2)
-    rank = int(os.environ.get("RANK", "0"))
+    c.rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    backend = None
-    if world > 1:
+    c.backend = None
+    if c.world > 1:
         import torch.distributed as dist
 
         # "nccl" is RCCL on ROCm.  DGLL_BENCH_BACKEND=gloo lets several ranks share one GPU (functional check of
         # the multi-rank path on a 1-GPU box; never used for reported numbers).
-        backend = os.environ.get("DGLL_BENCH_BACKEND", "nccl")
+        c.backend = os.environ.get("DGLL_BENCH_BACKEND", "nccl")
         local_rank = local_rank % torch.cuda.device_count()
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend=backend)
+        dist.init_process_group(backend=c.backend)
         assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
-
-    import dgll_amd
-    from dgll_amd import nn as dnn
-    from dgll_amd import ops, synth
-
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    esz = 2 if dtype == torch.bfloat16 else 4
+    c.dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(c.dev)
+    c.dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    c.esz = 2 if c.dtype == torch.bfloat16 else 4
     torch.manual_seed(args.seed)
+    return c
 
-    # ---- workload: the same seeded graph on every rank -------------------------------------------------
-    gen = torch.Generator(device=dev)
+
+def barrier(c):
+    if c.world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+
+
+def timed_steps(args, c, step):
+    """W untimed steps, then exactly K steps between barrier + synchronize; MAX over ranks.  Returns (elapsed s, last loss,
+    launch summary, warm-up loss trace)."""
+    from dgll_amd import ops
+
+    trace = []
+    for _ in range(args.warmup):
+        wl = step()
+        if os.environ.get("DGLL_BENCH_TRACE_LOSS"):      # debugging aid: per-step global loss (costs a sync + all-reduce)
+            g = wl.detach().double() / c.world
+            if c.world > 1:
+                torch.distributed.all_reduce(g)
+            trace.append(float(g))
+            if c.rank == 0:
+                print("warm-up loss %.6f" % float(g), file=sys.stderr)
+    barrier(c)
+    loss = None
+    with ops.LaunchTimer() as timer:
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = step()
+        barrier(c)
+        elapsed = time.perf_counter() - t0
+    if c.world > 1:
+        t = torch.tensor([elapsed], device=c.dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed, loss, timer, trace
+
+
+def build_products_graph(args, c, self_loops=False):
+    """The products-sized graph (or --dataset), the engine's reordering, labels and input features in engine order."""
+    from dgll_amd import synth
+
+    gen = torch.Generator(device=c.dev)
     gen.manual_seed(args.seed + 1)
     if args.dataset:
         from dgll_amd.data import formats
 
         dg = formats.load_node_dataset(args.dataset, symmetrise=True) if not os.path.exists(os.path.join(args.dataset, "reddit_data.npz")) \
             else formats.load_node_dataset(args.dataset)
-        full = dg.to_csr(dev)
-        feats_all = dg.features.to(dev)
-        labels_all = dg.labels.to(dev).long()
+        full = dg.to_csr(c.dev)
+        if self_loops:
+            import dgll_amd
+
+            row = torch.cat([full.row_index(), torch.arange(full.n_rows, device=c.dev)])
+            col = torch.cat([full.col.long(), torch.arange(full.n_rows, device=c.dev)])
+            full = dgll_amd.CSRGraph.from_coo(row, col, None, (full.n_rows, full.n_cols))
+            full.val = None
+        feats_all = dg.features.to(c.dev)
+        labels_all = dg.labels.to(c.dev).long()
         args.nodes, args.in_feats, args.classes = full.n_rows, int(feats_all.shape[1]), int(labels_all.max()) + 1
         del dg
     else:
-        full = synth.products_like_graph(dev, seed=args.seed, n=args.nodes, n_undirected=args.undirected_edges,
-                                         locality=args.locality, exact=not args.inexact_edges, permute_ids=not args.no_permute)
-        labels_all = torch.randint(0, args.classes, (full.n_rows,), generator=gen, device=dev)
-        feats_all = torch.randn(full.n_rows, args.in_feats, generator=gen, device=dev)
-    n, nnz = full.n_rows, full.nnz
-    model = dnn.GraphSage(args.in_feats, [args.hidden, args.hidden, args.classes], None).to(dev)
-
-    # ---- the engine's one-off locality pass (outside the timed steps, like a METIS relabelling) -----------
-    reorder_s = 0.0
-    bounds = None
+        full = synth.products_like_graph(c.dev, seed=args.seed, n=args.nodes, n_undirected=args.undirected_edges,
+                                         locality=args.locality, exact=not args.inexact_edges, permute_ids=not args.no_permute,
+                                         self_loops=self_loops)
+        labels_all = torch.randint(0, args.classes, (full.n_rows,), generator=gen, device=c.dev)
+        feats_all = torch.randn(full.n_rows, args.in_feats, generator=gen, device=c.dev)
+    reorder_s, bounds = 0.0, None
     if args.reorder != "none":
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        if world > 1:
+        if c.world > 1:
             # partition + order in one pass: communities packed into `world` parts of equal edge count (the place METIS has in
             # the reference's pipeline), each part in locality order; deterministic, so every rank derives the same relabelling
             from dgll_amd import partition as dpart
             from dgll_amd import reorder as dreorder
 
-            perm, bounds = dpart.partition_and_order(full, world, seed=args.seed)
+            perm, bounds = dpart.partition_and_order(full, c.world, seed=args.seed)
             full = dreorder.relabel(full, perm)
         else:
             full, perm = full.reorder(method=args.reorder, seed=args.seed)     # new row i = old row perm[i]
@@ -254,32 +540,73 @@ def main():
         reorder_s = time.perf_counter() - t0
         labels_all = labels_all[perm]
         feats_all = feats_all[perm]
+    return full, feats_all, labels_all, reorder_s, bounds
 
-    racom = opt_wrap = None
-    if world > 1:
-        from dgll_amd import dist as ddist
 
-        if bounds is None:
-            bounds = [(n * r) // world for r in range(world + 1)]
-        # every rank keeps ONLY its own row block (what it would load from its part file) and learns what its peers need
-        # from one exchange of halo ids
-        b0, b1 = bounds[rank], bounds[rank + 1]
-        e0, e1 = int(full.rowptr[b0]), int(full.rowptr[b1])
-        own_rowptr, own_col = full.rowptr[b0:b1 + 1].clone(), full.col[e0:e1].clone()
-        del full
-        torch.cuda.empty_cache()
-        part = ddist.partition_rows(own_rowptr, own_col, None, bounds, rank)
-        del own_rowptr, own_col
-        engine = ddist.DistGraph(part, dev)
-        x_local = ops.alloc_features(part.n_own, args.in_feats, dtype, dev, pad_to=args.feat_align)
-        x_local.copy_(engine.permute_to_local(feats_all[part.own_begin:part.own_end]).to(dtype))
-        labels = engine.permute_to_local(labels_all[part.own_begin:part.own_end])
+def make_engine(args, c, full, feats_all, labels_all, bounds):
+    """Multi-rank: every rank keeps ONLY its own row block (what it would load from its part file) and learns what its peers
+    need from one exchange of halo ids.  Returns (engine, x_local, labels)."""
+    from dgll_amd import dist as ddist
+    from dgll_amd import ops
+
+    n = full.n_rows
+    if bounds is None:
+        bounds = [(n * r) // c.world for r in range(c.world + 1)]
+    b0, b1 = bounds[c.rank], bounds[c.rank + 1]
+    e0, e1 = int(full.rowptr[b0]), int(full.rowptr[b1])
+    own_rowptr, own_col = full.rowptr[b0:b1 + 1].clone(), full.col[e0:e1].clone()
+    del full
+    torch.cuda.empty_cache()
+    part = ddist.partition_rows(own_rowptr, own_col, None, bounds, c.rank)
+    del own_rowptr, own_col
+    engine = ddist.DistGraph(part, c.dev)
+    x_local = ops.alloc_features(part.n_own, args.in_feats, c.dtype, c.dev, pad_to=args.feat_align)
+    x_local.copy_(engine.permute_to_local(feats_all[part.own_begin:part.own_end]).to(c.dtype))
+    labels = engine.permute_to_local(labels_all[part.own_begin:part.own_end])
+    return engine, x_local, labels
+
+
+def base_result(args, c, value, elapsed, workload_text, config):
+    ms = elapsed / args.steps * 1e3
+    cfg = {"workload": workload_text, "workload_id": args.workload}
+    cfg.update(config)
+    cfg.update({"ranks": c.world, "backend": c.backend})
+    return {"metric": METRIC, "value": value, "unit": "edges/s", "n_gpus": c.world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype,
+            "data": ("real: " + args.dataset) if args.dataset else "synthetic", "config": cfg, "epoch_time_s": ms / 1e3}
+
+
+def calibrate_launches(args, c, n):
+    """Three launches with KNOWN bytes in the gather kernels' own access pattern (identity gather of n rows: streaming read +
+    write of n * hidden * esz bytes each): the PMC passes turn them into the FETCH_SIZE / WRITE_SIZE correction ratios."""
+    import dgll_amd
+    from dgll_amd import ops
+
+    ident = dgll_amd.CSRGraph.fixed_fanout(n, 1, c.dev)
+    xc = ops.alloc_features(n, args.hidden, c.dtype, c.dev)
+    xc.copy_(torch.randn(n, args.hidden, device=c.dev).to(c.dtype))
+    for _ in range(3):
+        ops.spmm_raw(ident, xc, reduce="sum")
+    del ident, xc
+
+
+# ---------------------------------------------------------------------------------------------------- workload: sage
+def run_sage(args, c):
+    from dgll_amd import dist as ddist
+    from dgll_amd import nn as dnn
+    from dgll_amd import ops
+
+    full, feats_all, labels_all, reorder_s, bounds = build_products_graph(args, c)
+    n, nnz = full.n_rows, full.nnz
+    model = dnn.GraphSage(args.in_feats, [args.hidden, args.hidden, args.classes], None).to(c.dev)
+    racom = opt_wrap = engine = None
+    if c.world > 1:
+        engine, x_local, labels = make_engine(args, c, full, feats_all, labels_all, bounds)
         placed_input = engine.place_input_halo(x_local)     # input features of halo nodes live with the partition
         graph_for_cpu = None
     else:
-        engine = None
-        x_local = ops.alloc_features(n, args.in_feats, dtype, dev, pad_to=args.feat_align)
-        x_local.copy_(feats_all.to(dtype))
+        x_local = ops.alloc_features(n, args.in_feats, c.dtype, c.dev, pad_to=args.feat_align)
+        x_local.copy_(feats_all.to(c.dtype))
         labels = labels_all
         graph_for_cpu = full
         full.plan()
@@ -287,15 +614,16 @@ def main():
         full.mean_scale_transposed()
     del feats_all
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
-    if world > 1:
+    if c.world > 1:
         if args.racom_async:
-            opt_wrap = ddist.RaCoMOptimizer(opt, model.parameters(), dev, staleness=1,
-                                            sync_every=ddist.racom_sync_period(n, world))
+            opt_wrap = ddist.RaCoMOptimizer(opt, model.parameters(), c.dev, staleness=1,
+                                            sync_every=ddist.racom_sync_period(n, c.world))
         else:
-            racom = ddist.RaCoM(model.parameters(), dev)
+            racom = ddist.RaCoM(model.parameters(), c.dev)
     # forward: 3 layers; backward: layers 2 and 3 (the input features need no gradient).  The last layer narrows
     # (256 -> 47), so it aggregates the 47-wide product X.W_n instead of the 256-wide input (mean is linear).
-    spmm_launches_per_step = 3 + 2
+    passes = 3 + 2
+    world = c.world
 
     def step():
         opt.zero_grad(set_to_none=True)
@@ -314,162 +642,74 @@ def main():
             opt.step()
         return loss
 
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-
-    if args.calibrate and world == 1:
-        ident = dgll_amd.CSRGraph.fixed_fanout(n, 1, dev)
-        xc = ops.alloc_features(n, args.hidden, dtype, dev)
-        xc.copy_(torch.randn(n, args.hidden, device=dev).to(dtype))
-        for _ in range(3):
-            ops.spmm_raw(ident, xc, reduce="sum")            # streaming read + write of n*hidden*esz bytes each: known bytes
-        del ident, xc
-    trace = []
-    for _ in range(args.warmup):
-        wl = step()
-        if os.environ.get("DGLL_BENCH_TRACE_LOSS"):      # debugging aid: per-step global loss (costs a sync + all-reduce)
-            g = wl.detach().double() / world
-            if world > 1:
-                torch.distributed.all_reduce(g)
-            trace.append(float(g))
-            if rank == 0:
-                print("warm-up loss %.6f" % float(g), file=sys.stderr)
-    barrier()
-    with ops.LaunchTimer() as timer:
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            loss = step()
-        barrier()
-        elapsed = time.perf_counter() - t0
+    if args.calibrate and c.world == 1:
+        calibrate_launches(args, c, n)
+    elapsed, loss, timer, trace = timed_steps(args, c, step)
     if opt_wrap is not None:
         opt_wrap.flush()
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
-    global_loss = loss.detach().double() / world      # this rank's share of the mean loss
-    if world > 1:
+    global_loss = loss.detach().double() / c.world      # this rank's share of the mean loss
+    if c.world > 1:
         torch.distributed.all_reduce(global_loss)
-    global_loss = float(global_loss)
-    ms_per_step = elapsed / args.steps * 1e3
-    value = spmm_launches_per_step * nnz * args.steps / elapsed
-
-    if rank != 0:
-        return
-    # ---- roofline: every SpMM-type launch of the timed steps, HIP events on the launch stream (ops.LaunchTimer) ----
-    launches = timer.summary()
+    if c.rank != 0:
+        return None
     local_rows = n if engine is None else engine.part.n_own
-    table = {}
-    for tag, (cnt, avg_ms) in launches.items():
-        if tag[0] != "spmm":
-            continue
-        _, feat, dt, weighted, tag_nnz = tag[:5]
-        extra = tag[5] if len(tag) > 5 else ""
-        xb = 2 if "bfloat16" in dt else 4
-        b_alg = alg_bytes(tag_nnz, local_rows, feat, xb, xb, weighted)
-        name = "spmm F=%d %s %s%s nnz=%d" % (feat, dt.replace("torch.", ""), "weighted" if weighted else "unweighted",
-                                             (" " + extra) if extra else "", tag_nnz)
-        table[name] = {"count": cnt, "avg_ms": avg_ms, "nnz": tag_nnz, "feat": feat, "weighted": bool(weighted),
-                       "epilogue": extra, "G_edges_per_s": tag_nnz / (avg_ms * 1e-3) / 1e9,
-                       "algorithmic_bytes": b_alg, "algorithmic_GBps": b_alg / (avg_ms * 1e-3) / 1e9,
-                       "frac_algorithmic": b_alg / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
-    # the dense kernels next to the aggregation (all hand-written MFMA: no library GEMM in the step), same HIP-event timing
-    dense_table = {}
-    for tag, (cnt, avg_ms) in launches.items():
-        if tag[0] not in ("transform", "transform_dual", "grad_weight"):
-            continue
-        kind, m, k1, k2, n_out, extra = tag
-        b_alg = m * (k1 + k2 + n_out) * 2 + (m * n_out * 2 if ("gate" in extra or "addend" in extra) else 0)
-        name = "%s M=%d K=%d%s N=%d%s" % (kind, m, k1, ("+%d" % k2) if k2 else "", n_out, (" " + extra) if extra else "")
-        dense_table[name] = {"count": cnt, "avg_ms": avg_ms, "algorithmic_bytes": b_alg,
-                             "algorithmic_GBps": b_alg / (avg_ms * 1e-3) / 1e9,
-                             "frac_of_hbm_peak": b_alg / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                             "frac_of_streaming_ceiling_5500": b_alg / (avg_ms * 1e-3) / 1e9 / 5500.0}
+    table, dense_table = launch_tables(timer.summary(), local_rows)
     # headline = the LONGEST hidden-width SpMM launch of the step (forward mean aggregation or the weighted, gated,
     # accumulating transposed launch of the backward pass, whichever takes longer)
     roofline = None
     wide = {k: v for k, v in table.items() if v["feat"] == args.hidden}
     if wide:
-        dom_name = max(wide, key=lambda k: wide[k]["avg_ms"])
-        dom = wide[dom_name]
-        sig = workload_signature(args, nnz)
-        traffic = load_traffic(sig, dom) if world == 1 else None
-        achieved = dom["algorithmic_GBps"]
-        frac_alg = achieved / HBM_PEAK_GBPS
+        dom = wide[max(wide, key=lambda k: wide[k]["avg_ms"])]
         n_cols_touched = n if engine is None else engine.part.n_own + engine.part.n_halo
-        roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": frac_alg, "frac_algorithmic": frac_alg, "traffic": traffic,
-                    "kernel": "spmm_csr_kernel bf16 %s%s, F=%d (the longest SpMM-type launch of the step)" % (
-                        "weighted" if dom["weighted"] else "unweighted", (" " + dom["epilogue"]) if dom["epilogue"] else "",
-                        args.hidden),
-                    "launches_timed": dom["count"], "avg_launch_ms": dom["avg_ms"],
-                    "algorithmic_bytes_per_launch": dom["algorithmic_bytes"],
-                    # SURVEY 8(d)'s compulsory lower bound: every index once, every feature / output row once
-                    "compulsory_bytes_per_launch": dom["nnz"] * (8 if dom["weighted"] else 4) + n_cols_touched * args.hidden * esz
-                                                   + local_rows * (args.hidden * esz + 8),
-                    "edges_per_s_this_kernel": dom["nnz"] / (dom["avg_ms"] * 1e-3)}
-        if traffic is not None:
-            hbm = traffic / (dom["avg_ms"] * 1e-3) / 1e9
-            roofline["achieved_hbm_counters"] = hbm
-            roofline["frac_hbm_counters"] = hbm / HBM_PEAK_GBPS
-        if frac_alg > 1.0:
-            # the section-8(d) formula charges every edge a full row read; a value above the peak means part of those reads
-            # were served by L2 / Infinity Cache.  `frac` then carries the HBM-side counter traffic (profiles/traffic.json,
-            # rocprofv3 FETCH_SIZE x2 + WRITE_SIZE of this very launch) divided by the live launch time -- or null.
-            roofline["frac"] = roofline.get("frac_hbm_counters")
-            roofline["note"] = ("algorithmic bytes / time exceeds the HBM peak (cache-served re-reads): frac = HBM-counter "
-                                "traffic / launch time / peak; frac_algorithmic keeps the formula's value")
-    result = {
-        "metric": "aggregated edges/sec + epoch time, 3-layer GraphSAGE ogbn-products, 1/2/4/8 GPU",
-        "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": args.dtype, "data": ("real: " + args.dataset) if args.dataset else "synthetic",
-        "config": {"workload": "full-graph 3-layer GraphSAGE (mean aggr, %d-%d-%d-%d) training step on an ogbn-products-sized "
-                               "synthetic graph: %d nodes, nnz %d, 64 planted communities (locality %.2f), node ids %s, "
-                               "engine reorder: %s" % (args.in_feats, args.hidden, args.hidden, args.classes, n, nnz,
-                                                       args.locality, "community-sorted" if args.no_permute else "randomly permuted",
-                                                       args.reorder),
-                   "nodes": n, "nnz": nnz, "hidden": args.hidden, "locality": args.locality,
-                   "permuted_ids": not args.no_permute, "reorder": args.reorder, "reorder_seconds_one_off": reorder_s,
-                   "parallelism": "1-D row partition x%d" % world, "spmm_launches_per_step": spmm_launches_per_step,
-                   "ranks": world, "backend": backend,
-                   "gradient_sharing": None if world == 1 else ("RaCoM async (staleness 1)" if opt_wrap is not None else "RaCoM sync")},
-        "epoch_time_s": ms_per_step / 1e3, "loss": global_loss,
-        "roofline": roofline,
-        "spmm_launch_table": table,
-        "dense_launch_table": dense_table,   # bytes = 2 (K1 + K2 + N) per row (+ 2 N for a gate / addend operand); the 5.5 TB/s
-    }                                        # "streaming ceiling" is what a trivial 2R:1W kernel reaches (tools/probes/rw_mix.hip)
+        compulsory = dom["nnz"] * (8 if dom["weighted"] else 4) + n_cols_touched * args.hidden * c.esz + local_rows * (args.hidden * c.esz + 8)
+        roofline = roofline_record(dom, workload_signature(args, nnz),
+                                   "spmm_csr_kernel %s %s%s, F=%d (the longest SpMM-type launch of the step)" % (
+                                       args.dtype, "weighted" if dom["weighted"] else "unweighted",
+                                       (" " + dom["epilogue"]) if dom["epilogue"] else "", args.hidden), compulsory, c.world)
+    result = base_result(
+        args, c, passes * nnz * args.steps / elapsed, elapsed,
+        "full-graph 3-layer GraphSAGE (mean aggr, %d-%d-%d-%d) training step on an ogbn-products-sized synthetic graph: %d nodes, "
+        "nnz %d, 64 planted communities (locality %.2f), node ids %s, engine reorder: %s" % (
+            args.in_feats, args.hidden, args.hidden, args.classes, n, nnz, args.locality,
+            "community-sorted" if args.no_permute else "randomly permuted", args.reorder),
+        {"nodes": n, "nnz": nnz, "hidden": args.hidden, "locality": args.locality, "permuted_ids": not args.no_permute,
+         "reorder": args.reorder, "reorder_seconds_one_off": reorder_s, "parallelism": "1-D row partition x%d" % c.world,
+         "spmm_launches_per_step": passes,
+         "gradient_sharing": None if c.world == 1 else ("RaCoM async (staleness 1)" if opt_wrap is not None else "RaCoM sync")})
+    result.update({"loss": float(global_loss), "roofline": roofline, "spmm_launch_table": table,
+                   # bytes = 2 (K1 + K2 + N) per row (+ 2 N for a gate / addend operand); the 5.5 TB/s "streaming ceiling" is what
+                   "dense_launch_table": dense_table})      # a trivial 2R:1W kernel reaches (tools/probes/rw_mix.hip)
     if trace:
         result["warmup_loss_trace"] = trace
-    if world == 1 and not args.no_extra and not args.dataset:
+    if c.world == 1 and not args.no_extra and not args.dataset:
         del model, opt
-        result["roofline_no_locality"] = extra_roofline(args, dev, dtype, esz, locality=0.0, permute=False, reorder=args.reorder,
+        result["roofline_no_locality"] = extra_roofline(args, c, locality=0.0, permute=False, reorder=args.reorder,
                                                         note="structure-free RMAT (locality 0: no communities), engine reorder '%s' as in "
                                                              "the headline run" % args.reorder)
         if args.reorder != "none":
-            result["roofline_no_locality_raw_order"] = extra_roofline(
-                args, dev, dtype, esz, locality=0.0, permute=False, reorder="none",
-                note="structure-free RMAT in the generator's own id order (hubs at low ids), no reordering: round 1's figure")
-            result["roofline_raw_order"] = extra_roofline(args, dev, dtype, esz, locality=args.locality, permute=not args.no_permute,
+            raw = extra_roofline(args, c, locality=0.0, permute=False, reorder="none",
+                                 note="structure-free RMAT in the generator's own id order (hubs at low ids), no reordering: round 1's figure")
+            result["roofline_no_locality_raw_order"] = raw
+            if roofline is not None:      # the most conservative reading: no structure, no reordering, section-8(d) formula
+                roofline["frac_conservative"] = raw["frac_algorithmic"]
+            result["roofline_raw_order"] = extra_roofline(args, c, locality=args.locality, permute=not args.no_permute,
                                                           reorder="none", note="the headline graph WITHOUT the engine's reordering pass")
-    if world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(graph_for_cpu, args.hidden, args.cpu_sample_rows, args.seed)
-    print(json.dumps(result))
+    if c.world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline_spmm(graph_for_cpu, args.hidden, args.cpu_sample_rows, args.seed)
+    return result
 
 
-def extra_roofline(args, dev, dtype, esz, locality, permute, reorder, note):
+def extra_roofline(args, c, locality, permute, reorder, note):
     """The forward hidden-width mean-SpMM on another variant of the graph (same size, same kernel), 10 back-to-back launches."""
     from dgll_amd import ops, synth
 
-    g = synth.products_like_graph(dev, seed=args.seed, n=args.nodes, n_undirected=args.undirected_edges, locality=locality,
+    g = synth.products_like_graph(c.dev, seed=args.seed, n=args.nodes, n_undirected=args.undirected_edges, locality=locality,
                                   exact=not args.inexact_edges, permute_ids=permute)
     if reorder != "none":
         g, _ = g.reorder(method=reorder, seed=args.seed)
     g.plan()
-    x = ops.alloc_features(g.n_cols, args.hidden, dtype, dev)
-    x.copy_(torch.randn(g.n_cols, args.hidden, device=dev).to(dtype))
+    x = ops.alloc_features(g.n_cols, args.hidden, c.dtype, c.dev)
+    x.copy_(torch.randn(g.n_cols, args.hidden, device=c.dev).to(c.dtype))
     for _ in range(2):
         ops.spmm_raw(g, x, reduce="mean")
     torch.cuda.synchronize()
@@ -481,36 +721,346 @@ def extra_roofline(args, dev, dtype, esz, locality, permute, reorder, note):
     b.record()
     torch.cuda.synchronize()
     ms = a.elapsed_time(b) / reps
-    b_alg = alg_bytes(g.nnz, g.n_rows, args.hidden, esz, esz, weighted=False)
-    achieved = b_alg / (ms * 1e-3) / 1e9
-    sig = dict(workload_signature(args, g.nnz), locality=locality, permuted_ids=permute, reorder=reorder)
-    traffic = load_traffic(sig, {"feat": args.hidden, "weighted": False, "epilogue": ""})
-    out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-           "frac_algorithmic": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-           "nnz": g.nnz, "avg_launch_ms": ms, "edges_per_s_this_kernel": g.nnz / (ms * 1e-3),
-           "note": "forward mean-SpMM F=%d, %s; %d back-to-back launches (timed with the long-row finalize)" % (args.hidden, note, reps)}
-    if traffic is not None:
-        out["frac_hbm_counters"] = traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS
-        if out["frac"] > 1.0:
-            out["frac"] = out["frac_hbm_counters"]
+    b_alg = alg_bytes(g.nnz, g.n_rows, args.hidden, c.esz, c.esz, weighted=False)
+    dom = {"count": reps, "avg_ms": ms, "nnz": g.nnz, "algorithmic_bytes": b_alg, "algorithmic_GBps": b_alg / (ms * 1e-3) / 1e9,
+           "kernel_fragment": spmm_kernel_fragment(args.hidden, str(c.dtype), False, False)}
+    sig = workload_signature(args, g.nnz, locality=locality, permuted_ids=permute, reorder=reorder)
+    compulsory = g.nnz * 4 + g.n_cols * args.hidden * c.esz + g.n_rows * (args.hidden * c.esz + 8)
+    return roofline_record(dom, sig, "spmm_csr_kernel %s unweighted, F=%d" % (args.dtype, args.hidden), compulsory, 1,
+                           extra={"nnz": g.nnz, "note": "forward mean-SpMM F=%d, %s; %d back-to-back launches (timed with the long-row "
+                                                        "finalize)" % (args.hidden, note, reps)})
+
+
+# ---------------------------------------------------------------------------------------------------- workload: gat
+def run_gat(args, c):
+    """BASELINE config 4: 2-layer SpGAT (gatconv.py:174-199), `heads` x (hidden / heads) -> classes, products-sized graph with
+    self-loops (rows without edges are NaN in the reference, gatconv.py:139-141), attention dropout inactive."""
+    from dgll_amd import dist as ddist
+    from dgll_amd import nn as dnn
+    from dgll_amd import ops
+
+    heads, fo = args.heads, args.hidden // args.heads
+    full, feats_all, labels_all, reorder_s, bounds = build_products_graph(args, c, self_loops=True)
+    n, nnz = full.n_rows, full.nnz
+    model = dnn.SpGAT(args.in_feats, fo, args.classes, dropout=0.0, alpha=0.2, nheads=heads).to(c.dev)
+    racom = engine = None
+    if c.world > 1:
+        engine, x_local, labels = make_engine(args, c, full, feats_all, labels_all, bounds)
+        graph_for_cpu = None
+        racom = ddist.RaCoM(model.parameters(), c.dev)
+    else:
+        x_local = ops.alloc_features(n, args.in_feats, c.dtype, c.dev, pad_to=args.feat_align)
+        x_local.copy_(feats_all.to(c.dtype))
+        labels = labels_all
+        graph_for_cpu = full
+        full.plan()
+        full.transpose()[0].plan()
+    del feats_all
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    passes = 2 * 3                # per layer: forward, backward over the rows of A, backward over the rows of A^T
+    world = c.world
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out = model(x_local, full) if engine is None else engine.spgat_forward(model, x_local)     # log_softmax, gatconv.py:199
+        # F.nll_loss of the reference's training loops, as its definition (torch's nll_loss kernels take 10 ms at this size)
+        loss = -out.gather(1, labels.unsqueeze(1)).float().sum() * (world / n)
+        loss.backward()
+        if racom is not None:
+            racom.all_reduce_and_wait()
+        opt.step()
+        return loss
+
+    if args.calibrate and c.world == 1:
+        calibrate_launches(args, c, n)
+    elapsed, loss, timer, trace = timed_steps(args, c, step)
+    global_loss = loss.detach().double() / c.world
+    if c.world > 1:
+        torch.distributed.all_reduce(global_loss)
+    if c.rank != 0:
+        return None
+    local_rows = n if engine is None else engine.part.n_own
+    table, dense_table = launch_tables(timer.summary(), local_rows)
+    roofline = None
+    wide = {k: v for k, v in table.items() if v["feat"] == args.hidden and "pass" in v}
+    if wide:
+        dom = wide[max(wide, key=lambda k: wide[k]["avg_ms"])]
+        n_cols_touched = n if engine is None else engine.part.n_own + engine.part.n_halo
+        compulsory = dom["nnz"] * 4 + n_cols_touched * (args.hidden * c.esz + 4 * heads) + local_rows * (args.hidden * c.esz + 8 + 4 * heads)
+        roofline = roofline_record(dom, workload_signature(args, nnz, heads=heads),
+                                   "gat2_kernel %s, %d heads x %d, pass %s (the longest gather pass of the step)" % (
+                                       args.dtype, heads, fo, dom["pass"]), compulsory, c.world)
+    result = base_result(
+        args, c, passes * nnz * args.steps / elapsed, elapsed,
+        "BASELINE config 4: full-graph 2-layer SpGAT (%d -> %d heads x %d -> %d, alpha 0.2, attention dropout off) training step on "
+        "the ogbn-products-sized synthetic graph + self-loops: %d nodes, nnz %d, locality %.2f, node ids %s, engine reorder: %s" % (
+            args.in_feats, heads, fo, args.classes, n, nnz, args.locality,
+            "community-sorted" if args.no_permute else "randomly permuted", args.reorder),
+        {"nodes": n, "nnz": nnz, "hidden": args.hidden, "heads": heads, "locality": args.locality, "permuted_ids": not args.no_permute,
+         "reorder": args.reorder, "reorder_seconds_one_off": reorder_s, "parallelism": "1-D row partition x%d" % c.world,
+         "gather_passes_per_step": passes})
+    result.update({"loss": float(global_loss), "roofline": roofline, "spmm_launch_table": table, "dense_launch_table": dense_table})
+    if trace:
+        result["warmup_loss_trace"] = trace
+    if c.world == 1 and not args.no_extra:
+        # the SpMM at the same width on the same graph, same build: what the GAT passes are judged against
+        x = ops.alloc_features(n, args.hidden, c.dtype, c.dev)
+        x.copy_(torch.randn(n, args.hidden, device=c.dev).to(c.dtype))
+        for _ in range(2):
+            ops.spmm_raw(full, x, reduce="mean")
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(10):
+            ops.spmm_raw(full, x, reduce="mean")
+        b.record()
+        torch.cuda.synchronize()
+        ms = a.elapsed_time(b) / 10
+        result["spmm_same_width_same_graph_ms"] = ms
+        result["gat_pass_over_spmm"] = {v["pass"]: v["avg_ms"] / ms for v in wide.values()}
+        del x
+    if c.world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline_gat(graph_for_cpu, heads, fo, 0.2, min(args.cpu_sample_rows, 20_000), args.seed)
+    return result
+
+
+# ---------------------------------------------------------------------------------------------------- workload: rmat27
+def run_rmat27(args, c):
+    """BASELINE config 5 on one GPU: Y = A . (X . W) of a GCN layer (gcnconv.py:30-31) at RMAT-27 size, F = 128 bf16, mean
+    weights: a step = the MFMA transform X.W + the SpMM over > 2^31 nonzeros (int64 row pointers)."""
+    from dgll_amd import dense, ops, synth
+
+    if c.world > 1:
+        raise SystemExit("bench.py --workload rmat27 measures one GPU (replicas only: the SpMM of config 5 shards by row block, "
+                         "every rank would run this same pass on its block)")
+    feat = 128
+    t0 = time.time()
+    g = synth.rmat_graph(args.scale, 16, seed=args.seed, device=c.dev, symmetric=False, weighted=False, self_loops=True)
+    torch.cuda.synchronize()
+    build_s = time.time() - t0
+    t0 = time.time()
+    reorder = "degree" if g.nnz >= (1 << 30) else "lpa"
+    if args.reorder != "none":
+        g, _ = g.reorder(method=reorder, seed=args.seed)
+    torch.cuda.synchronize()
+    reorder_s = time.time() - t0
+    torch.cuda.empty_cache()
+    g.plan()
+    n, nnz = g.n_rows, g.nnz
+    x = torch.randn(n, feat, device=c.dev).to(c.dtype)
+    w = (torch.randn(feat, feat, device=c.dev) / feat ** 0.5).to(c.dtype)
+    y = ops.alloc_features(n, feat, c.dtype, c.dev)
+
+    def step():
+        s = dense.transform_bf16(x, w.t()) if c.dtype == torch.bfloat16 else x @ w       # S = X.W      gcnconv.py:30
+        ops.spmm_raw(g, s, reduce="mean", out=y)                                           # Y = A.S      gcnconv.py:31
+        return y
+
+    for _ in range(args.warmup):
+        step()
+    barrier(c)
+    with ops.LaunchTimer() as timer:
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier(c)
+        elapsed = time.perf_counter() - t0
+    table, dense_table = launch_tables(timer.summary(), n)
+    dom = table[max(table, key=lambda k: table[k]["avg_ms"])]
+    compulsory = nnz * 4 + n * feat * c.esz * 2 + n * 8
+    roofline = roofline_record(dom, workload_signature(args, nnz, nodes=n, hidden=feat, scale=args.scale),
+                               "spmm_csr_kernel %s unweighted mean, F=%d, int64 row pointers" % (args.dtype, feat), compulsory, 1)
+    result = base_result(
+        args, c, nnz * args.steps / elapsed, elapsed,
+        "BASELINE config 5 on one GPU: GCN layer Y = A.(X.W) (gcnconv.py:30-31) on RMAT-%d (%d nodes, nnz %d%s, self-loops), F = %d, "
+        "engine reorder: %s" % (args.scale, n, nnz, " > 2^31" if nnz > 2 ** 31 else "", feat, reorder if args.reorder != "none" else "none"),
+        {"nodes": n, "nnz": nnz, "hidden": feat, "scale": args.scale, "reorder": reorder if args.reorder != "none" else "none",
+         "graph_build_seconds": build_s, "reorder_seconds_one_off": reorder_s, "parallelism": "single GPU",
+         "peak_memory_GB": torch.cuda.max_memory_allocated() / 1e9})
+    result.update({"roofline": roofline, "spmm_launch_table": table, "dense_launch_table": dense_table})
+    if not args.no_cpu_baseline:
+        del x, y
+        result["cpu_baseline"] = cpu_baseline_spmm(g, feat, min(args.cpu_sample_rows, 1_000_000), args.seed) if n <= (1 << 24) else \
+            cpu_baseline_rows_only(g, feat, min(args.cpu_sample_rows, 1_000_000), args.seed)
+    return result
+
+
+def cpu_baseline_rows_only(graph, feat, sample_rows, seed):
+    """Config 5's CPU baseline: the feature matrix of 134 M nodes does not fit a bounded run (68 GB fp32), so the sampled rows
+    gather from the first 2^24 nodes (columns folded) -- the same number of edges and row lengths, a smaller source matrix."""
+    import dgll_amd
+
+    fold = 1 << 24
+    rows = min(sample_rows, graph.n_rows)
+    rowptr = graph.rowptr[:rows + 1].clone()
+    nnz = int(rowptr[-1])
+    col = (graph.col[:nnz].long() % fold).to(torch.int32)
+    sub = dgll_amd.CSRGraph(rowptr, col, None, rows, fold, check=False)
+    out = cpu_baseline_spmm(sub, feat, rows, seed)
+    out["sample"] += " (config 5: column ids folded into the first 2^24 nodes so that the fp32 source matrix is 8.6 GB)"
     return out
 
 
-def load_traffic(sig, launch):
-    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes (profiles/traffic.json: entries keyed by
-    the workload signature and the launch kind), or None when no pass was collected for this exact workload."""
-    path = os.path.join(ROOT, "profiles", "traffic.json")
-    try:
-        with open(path) as f:
-            entries = json.load(f).get("entries", [])
-    except (OSError, ValueError):
-        return None
-    for e in entries:
-        w = e.get("workload", {})
-        if all(w.get(k) == v for k, v in sig.items()) and e.get("feat") == launch["feat"] and \
-                bool(e.get("weighted")) == bool(launch["weighted"]) and e.get("epilogue", "") == launch.get("epilogue", ""):
-            return e.get("hbm_bytes_per_launch")
-    return None
+# ---------------------------------------------------------------------------------------------------- workload: minibatch
+def run_minibatch(args, c):
+    """BASELINE config 2 shape: Reddit-sized synthetic graph (232 965 nodes, 114.6 M directed edges, F = 602, 41 classes),
+    3-layer GraphSAGE hidden 256 bf16, mini-batches of 1024 seeds with fan-out 25-10-10 (graphage.py:47-63):
+      host: bit-exact native sampler -> bounded queue on a side stream (buffer_queues.py:22-46)
+      GPU : one-launch hit/miss gather from the HBM hot-node cache + pinned host memory (storage.py:151-198), CSR blocks,
+            hop-pyramid forward / backward / Adam.
+    A step = one batch; W warm-up batches, K timed batches."""
+    import random
+
+    import numpy as np
+
+    from dgll_amd import nn as dnn
+    from dgll_amd import ops, synth
+    from dgll_amd.cache import GraphCacheServer
+    from dgll_amd.data import DGraph
+    from dgll_amd.dataloader import DataLoader
+    from dgll_amd.pipeline import MiniBatchPipeline
+    from dgll_amd.sampling import FastNeighborSampler
+
+    if c.world > 1:
+        raise SystemExit("bench.py --workload minibatch runs one GPU (data-parallel replicas would each run this loop on a share of the seeds)")
+    fanouts = [int(v) for v in args.mb_fanouts.split(",")]
+    L = len(fanouts)
+    g = synth.products_like_graph(c.dev, seed=1, n=args.mb_nodes, n_undirected=args.mb_undirected_edges, locality=0.0, exact=True)
+    indptr, indices = g.rowptr.cpu().numpy(), g.col.cpu().numpy().astype(np.int64)
+    deg = g.degrees().cpu()
+    nnz_graph = g.nnz
+    del g
+    torch.manual_seed(args.seed)
+    feats = torch.randn(args.mb_nodes, args.mb_feats).to(c.dtype)
+    labels = torch.randint(0, args.mb_classes, (args.mb_nodes,))
+    dg = DGraph.from_csr(indptr, indices, labels=labels, features=feats)
+    cache = GraphCacheServer(feats, gpuid=c.dev.index or 0)
+    cache.log = True
+    cache.auto_cache(deg, capacity=int(args.mb_cache_frac * args.mb_nodes))
+    n_batches = args.warmup + args.steps
+    train = torch.randperm(args.mb_nodes)[:n_batches * args.mb_batch]
+
+    class TimedSampler(FastNeighborSampler):
+        seconds, calls = 0.0, 0
+
+        def sample(self, g_, seeds):
+            t = time.perf_counter()
+            out = super().sample(g_, seeds)
+            TimedSampler.seconds += time.perf_counter() - t
+            TimedSampler.calls += 1
+            return out
+
+    loader = DataLoader(dg, train, TimedSampler(fanouts, defer_last_hop=True), batch_size=args.mb_batch)
+
+    def hop_ids(b):          # hop 0 = seeds, hop h+1 = sources sampled around hop h (subgs are outermost first)
+        return [b.output_nodes] + [b.subgraphs[L - 1 - h].src_nodes() for h in range(L)]
+
+    pipe = MiniBatchPipeline(loader, cache=cache, labels=labels, queue_size=4, device=c.dev, hops=hop_ids)
+    model = dnn.GraphSage(args.mb_feats, [args.hidden] * (L - 1) + [args.mb_classes], fanouts).to(c.dev)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    random.seed(args.seed)
+    timer_cm = ops.LaunchTimer()
+    done = edges = 0
+    gpu_ms = 0.0
+    t0 = None
+    events = []
+    loss = None
+    for b in pipe:
+        if done == args.warmup:
+            torch.cuda.synchronize()
+            timer_cm.__enter__()
+            t0 = time.perf_counter()
+            s0 = TimedSampler.seconds
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        blocks = [b.subgraphs[L - 1 - h].to_block(c.dev) for h in range(L)]
+        out = model.forward_sampled(b.features, blocks)
+        loss = ops.cross_entropy(out, b.labels)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        ev1.record()
+        if done >= args.warmup:
+            events.append((ev0, ev1))
+            # edges aggregated per batch: layer l runs over hops 0..L-l-1, each a gather over that hop's sampled edges (fwd + bwd)
+            per_hop = [b.subgraphs[L - 1 - h].num_src_nodes() for h in range(L)]
+            edges += sum(sum(per_hop[:L - l]) for l in range(L)) * 2
+        done += 1
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    timer_cm.__exit__(None, None, None)
+    sampler_s = TimedSampler.seconds - s0
+    gpu_ms = sum(a.elapsed_time(b_) for a, b_ in events) / max(len(events), 1)
+    table, dense_table = launch_tables(timer_cm.summary(), 0)
+    for v in table.values():           # blocks: rows differ per launch; the per-row term of the formula is left out (conservative)
+        v["note"] = "sampled blocks: algorithmic bytes count the per-edge term only"
+    roofline = None
+    wide = {k: v for k, v in table.items() if v["feat"] in (args.hidden, args.mb_feats)}
+    if wide:
+        dom = wide[max(wide, key=lambda k: wide[k]["avg_ms"] * wide[k]["count"])]
+        roofline = roofline_record(dom, workload_signature(args, nnz_graph, nodes=args.mb_nodes, batch=args.mb_batch),
+                                   "the gather launch kind with the largest total time in the timed batches: %s" % dom["kernel_fragment"],
+                                   None, 1)
+    steps = len(events)
+    args.steps = steps
+    result = base_result(
+        args, c, edges / elapsed, elapsed,
+        "BASELINE config 2 shape: sampled 3-layer GraphSAGE (hidden %d, %s) on a Reddit-sized synthetic graph (%d nodes, %d directed "
+        "edges, F = %d, %d classes), batch %d, fan-out %s, bit-exact host sampler + %d %% hot-node HBM cache + mini-batch queue; "
+        "a step = one batch" % (args.hidden, args.dtype, args.mb_nodes, nnz_graph, args.mb_feats, args.mb_classes, args.mb_batch,
+                                args.mb_fanouts, int(args.mb_cache_frac * 100)),
+        {"nodes": args.mb_nodes, "nnz": nnz_graph, "hidden": args.hidden, "batch": args.mb_batch, "fanouts": fanouts,
+         "cache_fraction": args.mb_cache_frac, "parallelism": "single GPU"})
+    result.update({"loss": float(loss), "batches_per_s": steps / elapsed, "gpu_side_ms_per_batch": gpu_ms,
+                   "host_sampler_ms_per_batch": sampler_s / max(steps, 1) * 1e3, "cache_miss_rate": cache.get_miss_rate(),
+                   "epoch_time_s_153431_train_nodes": elapsed / steps * (153_431 / args.mb_batch),
+                   "roofline": roofline, "spmm_launch_table": table, "dense_launch_table": dense_table})
+    if not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline_sampler(indptr, indices, fanouts, args.mb_batch, args.seed)
+    return result
+
+
+def cpu_baseline_sampler(indptr, indices, fanouts, batch, seed):
+    """Config 2's host path timed alone: the reference's pure-Python sampler loop (base_sampler.py:30-58: random.sample per
+    seed, hops in reversed(fanouts) order) as restated in oracle/sampler.py, on a few batches, against which the native
+    bit-exact sampler of the pipeline is reported."""
+    import random
+
+    import numpy as np
+
+    from oracle import sampler as osampler
+
+    host = host_info()
+    rng = np.random.default_rng(seed)
+    seeds = rng.integers(0, len(indptr) - 1, size=batch).tolist()
+
+    class Adj:          # adjacency lists on demand (the reference holds python lists per node, dgraph.py:49-62)
+        def __getitem__(self, v):
+            return indices[indptr[v]:indptr[v + 1]].tolist()
+
+    random.seed(seed)
+    t0 = time.perf_counter()
+    _, _, layers = osampler.sample(Adj(), seeds, fanouts)
+    dt = time.perf_counter() - t0
+    n_edges = sum(len(src) for src, _ in layers)
+    return {"value": n_edges / dt, "unit": "edges/s", "cores": 1, "kind": "port",
+            "sample": "one batch of %d seeds, fan-out %s, through the reference's sampler loop (base_sampler.py:30-58, dgllsampler.py:"
+                      "10-21) restated in oracle/sampler.py: %d sampled edges in %.2f s, single Python thread (the reference's own "
+                      "CPU path of config 2 is this host loop; the GPU-side figures are in the line's other fields)" % (
+                          batch, fanouts, n_edges, dt),
+            "cpu_model": host["cpu_model"], "threads": 1, "physical_cores": host["physical_cores"]}
+
+
+WORKLOADS = {"sage": run_sage, "gat": run_gat, "rmat27": run_rmat27, "minibatch": run_minibatch}
+
+
+def main():
+    args = parse_args()
+    c = setup(args)
+    import dgll_amd  # noqa: F401  (loads libdgll_hip.so; raises if it cannot be built)
+
+    result = WORKLOADS[args.workload](args, c)
+    if c.rank == 0 and result is not None:
+        print(json.dumps(result))
 
 
 if __name__ == "__main__":

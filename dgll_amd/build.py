@@ -88,6 +88,7 @@ def _build_locked(force, verbose):
     srcs, hdrs = sources(), headers()
     if not force and is_current():
         return LIB
+    digest = source_digest()          # what is compiled now: an edit made WHILE hipcc runs must not be stamped as built
     if not srcs:
         raise RuntimeError("no HIP sources under " + CSRC)
     os.makedirs(OBJDIR, exist_ok=True)
@@ -123,7 +124,7 @@ def _build_locked(force, verbose):
             raise RuntimeError("link failed:\n%s\n%s" % (res.stdout, res.stderr))
         os.replace(tmp, LIB)              # atomic: a concurrent dlopen sees the old or the new library, never a partial one
     with open(STAMP + ".tmp", "w") as f:
-        f.write(source_digest())
+        f.write(digest)
     os.replace(STAMP + ".tmp", STAMP)     # the stamp goes last
     return LIB
 

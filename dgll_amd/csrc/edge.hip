@@ -16,121 +16,9 @@
 #include <algorithm>
 
 #include "common.hpp"
+#include "edge_args.hpp"
 
 namespace dgll {
-
-struct EdgeArgs {
-    const int64_t* rowptr;
-    const int32_t* col;
-    const int64_t* perm;        // A^T edge slot -> A edge slot (only to index edge_scale from the transposed pass)
-    const void* H;              // gathered matrix [n_cols, ld]
-    int64_t ldh;
-    const void* G;              // row-side matrix [n_rows, ld] (sddmm: grad_out; gat_bwd_rows: grad_out)
-    int64_t ldg;
-    const void* O;              // forward output [n_rows, ld] (gat_bwd_rows)
-    int64_t ldo;
-    void* Y;                    // main output matrix
-    int64_t ldy;
-    const float* S;             // [*, heads] row-side scores
-    const float* T;             // [*, heads] gathered-side scores
-    const float* M;             // [*, heads] row maxima (mode 1) or NULL
-    const float* DEN;           // [*, heads] denominators
-    const float* DD;            // [*, heads] d(denominator)
-    const float* edge_scale;    // [nnz, heads] dropout multipliers or NULL
-    float* out_a;               // fp32 [*, heads] output (rowsum / ds / dt)
-    float* out_b;               // fp32 [*, heads] output (rowmax / dden)
-    float* edge_out;            // fp32 [nnz] (sddmm)
-    int64_t n_rows;
-    int heads, fo, feat;        // feat = heads * fo
-    float alpha, sign;          // leaky-relu slope; -1: exp(-lrelu) (sparseGatConv), +1: softmax(+lrelu) (gatConv)
-    int apply_elu, use_max;
-    int raw, accumulate;        // partitioned use: raw = leave the row un-normalised (num, den); accumulate = add what is already there
-    int32_t* arg_out;           // segment_max: int32 [n_rows, ld] source row of the maximum
-    // long-row schedule (threshold == 0: none): chunk work items come first in the grid, partials go to `ws`
-    int threshold;
-    int64_t n_chunks;
-    const int64_t* chunk_begin;
-    const int64_t* chunk_end;
-    const int64_t* chunk_row;
-    float* ws;                  // [n_chunks, ws_ld]: [0, feat) vector partial | [ws_vec, +heads) scalar | [+heads, +2 heads) max
-    int ws_ld, ws_vec;
-    uint32_t chunk_blocks;
-    int rows_per_wave;          // consecutive rows one wavefront handles before retiring (row items only)
-};
-
-// Work item of this wavefront: a whole (short) row, or one chunk of a long row.
-struct WorkItem {
-    int64_t row, b, e, chunk;   // chunk < 0: whole row
-    bool valid, first, done;    // first: the item starts at the row's first edge (writes the per-row outputs);
-};                              // done: nothing more for this wavefront; !valid && !done: skip to the next row
-
-// r-th item of this wavefront (r < rows_per_wave for row items; chunk items are a single item).
-__device__ __forceinline__ WorkItem resolve_item(const EdgeArgs& a, int wave, int r) {
-    WorkItem w;
-    w.chunk = -1;
-    w.first = true;
-    w.done = false;
-    const uint32_t bid = blockIdx.x;
-    if (bid < a.chunk_blocks) {
-        const int64_t c = __builtin_amdgcn_readfirstlane((int)(bid * kWavesPerBlock + wave));
-        w.valid = r == 0 && c < a.n_chunks;
-        if (!w.valid) { w.row = w.b = w.e = 0; w.done = true; return w; }
-        w.chunk = c;
-        w.row = uniform64(a.chunk_row[c]);
-        w.b = uniform64(a.chunk_begin[c]);
-        w.e = uniform64(a.chunk_end[c]);
-        w.first = w.b == uniform64(a.rowptr[w.row]);
-        return w;
-    }
-    w.row = ((int64_t)(bid - a.chunk_blocks) * kWavesPerBlock + wave) * a.rows_per_wave + r;
-    w.valid = w.row < a.n_rows;
-    if (!w.valid) { w.b = w.e = 0; w.done = true; return w; }
-    w.b = uniform64(a.rowptr[w.row]);
-    w.e = uniform64(a.rowptr[w.row + 1]);
-    if (a.threshold > 0 && w.e - w.b > a.threshold) w.valid = false;   // handled as chunks
-    return w;
-}
-
-__device__ __forceinline__ float lrelu(float z, float alpha) { return z > 0.0f ? z : alpha * z; }
-
-template <typename T> __device__ __forceinline__ float load_scalar(const T* p);
-template <> __device__ __forceinline__ float load_scalar<float>(const float* p) { return *p; }
-template <> __device__ __forceinline__ float load_scalar<bf16_t>(const bf16_t* p) { return bf16_to_f32(*p); }
-
-// sum over the `lph` adjacent lanes that hold one head's columns (lph is a power of two <= 64)
-__device__ __forceinline__ float head_sum(float v, int lph) {
-    for (int off = 1; off < lph; off <<= 1) v += __shfl_xor(v, off);
-    return v;
-}
-
-template <int LPR>
-__device__ __forceinline__ float slot_sum(float v) {
-#pragma unroll
-    for (int off = LPR; off < kWave; off <<= 1) v += __shfl_xor(v, off);
-    return v;
-}
-template <int LPR>
-__device__ __forceinline__ float slot_max(float v) {
-#pragma unroll
-    for (int off = LPR; off < kWave; off <<= 1) v = fmaxf(v, __shfl_xor(v, off));
-    return v;
-}
-
-// Iterates the edges [b, e) of one row in coalesced batches of 64; `body(j0, nb, cur_col, k0)` is called once
-// per batch with the lane-distributed column ids (lane l holds edge k0 + l).
-template <typename Body>
-__device__ __forceinline__ void for_each_batch(const int32_t* __restrict__ col, int64_t b, int64_t e, int lane, Body body) {
-    int my_col = 0;
-    if (b + lane < e) my_col = col[b + lane];
-    for (int64_t k0 = b; k0 < e; k0 += kWave) {
-        const int64_t left = e - k0;
-        const int nb = left < kWave ? (int)left : kWave;
-        const int cur_col = my_col;
-        const int64_t kn = k0 + kWave + lane;
-        if (kn < e) my_col = col[kn];
-        body(nb, cur_col, k0);
-    }
-}
 
 // ------------------------------------------------------------------------------------------------ SDDMM
 // edge_out[k] = sum_f G[row(k), f] * H[col[k], f]            (gatconv.py:76-78)
@@ -729,18 +617,9 @@ static bool vec_ok(const void* p, int64_t ld, int esz) { return aligned16(p) && 
 
 }  // namespace dgll
 
-int g_tune_gat_unroll = 2;   // dgll_hip_debug_tune(7, v): gathers in flight per lane in the two GAT backward passes (bf16)
+int g_tune_gat_gen = 0;      // dgll_hip_debug_tune(9, v): 1 = first-generation GAT kernels only
 
 using namespace dgll;
-
-static int check_heads(int heads, int fo, int epv, int* lph_out) {
-    DGLL_REQUIRE(heads > 0 && fo > 0, "heads/fo must be positive");
-    DGLL_REQUIRE(fo % epv == 0, "per-head width must be a multiple of the 16-byte vector (pad on the host)");
-    const int lph = fo / epv;
-    DGLL_REQUIRE((lph & (lph - 1)) == 0 && lph <= 64, "per-head width / vector must be a power of two <= 64 (pad on the host)");
-    *lph_out = lph;
-    return DGLL_OK;
-}
 
 DGLL_API int dgll_hip_sddmm_csr(void* stream, const int64_t* rowptr, const int32_t* col, const void* G, int64_t ldg,
                                 const void* B, int64_t ldb, int dtype, float* edge_out, int64_t n_rows, int feat) {
@@ -818,32 +697,99 @@ static int gat_finalize(const EdgeArgs& a, const dgll_csr_plan* plan, int kind, 
 }
 
 static int gat_common(EdgeArgs& a, const int64_t* rowptr, const int32_t* col, int64_t n_rows, int heads, int fo, int dtype,
-                      float alpha, int mode, int apply_elu, int* lph, int* lpr, dim3* grid) {
+                      float alpha, int mode, int apply_elu) {
     DGLL_REQUIRE(rowptr && col, "NULL CSR");
     DGLL_REQUIRE(dtype == DGLL_F32 || dtype == DGLL_BF16, "dtype");
     DGLL_REQUIRE(mode == 0 || mode == 1, "mode");
     const int epv = dtype == DGLL_BF16 ? 8 : 4;
-    int rc = check_heads(heads, fo, epv, lph);
-    if (rc != DGLL_OK) return rc;
+    DGLL_REQUIRE(heads > 0 && fo > 0, "heads/fo must be positive");
+    DGLL_REQUIRE(fo % epv == 0, "per-head width must be a multiple of the 16-byte vector (pad on the host)");
     a.rowptr = rowptr; a.col = col; a.n_rows = n_rows; a.heads = heads; a.fo = fo; a.feat = heads * fo;
     a.alpha = alpha; a.sign = mode == 0 ? -1.0f : 1.0f; a.use_max = mode; a.apply_elu = apply_elu;
+    a.vph = fo / epv; a.tstride = heads; a.sd_out = nullptr; a.sd_stride = 0;
+    return DGLL_OK;
+}
+
+// Launch geometry of the second-generation kernels (gat_kernel.hpp): `nh` heads per wavefront on `lpr` = nh * lanes-per-head
+// lanes per row.  They cover sparseGatConv's form -- exp(-leakyrelu), no max subtraction, no attention-dropout multipliers --
+// for any per-head width that is a multiple of the 16-byte vector.  False: the first-generation kernels run.
+static bool gat2_pick(const EdgeArgs& a, int* lpr, int* nh, uint32_t* grid_y) {
+    if (g_tune_gat_gen == 1 || a.edge_scale || a.use_max || a.M) return false;
+    int lph = 1;
+    while (lph < a.vph) lph <<= 1;
+    if (lph > kWave) return false;
+    // blocks of 4 / 8 heads are read as float4s: whole blocks, 16-byte aligned
+    const bool vec = a.heads % 4 == 0 && a.tstride % 4 == 0 && aligned16(a.T) && (!a.DD || aligned16(a.DD));
+    int n = 1;
+    for (int cand = 8; cand >= 1; cand >>= 1) {
+        if (cand * lph > kWave) continue;
+        if (cand > 2 && !(vec && a.heads % cand == 0)) continue;
+        if (cand > 1 && cand / 2 >= a.heads) continue;      // would leave half the wavefront's heads idle
+        n = cand;
+        break;
+    }
+    while (n * lph < 4) lph <<= 1;                           // at least 4 lanes per row slot (idle lanes inside a head)
+    *lpr = n * lph; *nh = n; *grid_y = (uint32_t)((a.heads + n - 1) / n);
+    return true;
+}
+
+// Geometry of the first-generation kernels: per-head width a power-of-two number of vectors.
+static int gat1_pick(const EdgeArgs& a, int epv, int* lph, int* lpr, uint32_t* grid_y) {
+    *lph = a.fo / epv;
+    DGLL_REQUIRE((*lph & (*lph - 1)) == 0 && *lph <= 64,
+                 "per-head width / vector must be a power of two <= 64 for the max-subtracted / dropout form (pad on the host)");
+    if (a.tstride != a.heads || a.sd_out) {
+        set_error("strided score arrays need the second-generation kernels (mode 0, no attention dropout)");
+        return DGLL_ERR_UNSUPPORTED;
+    }
     const int vecs = a.feat / epv;
     *lpr = pick_lpr(vecs);
     if (*lpr < *lph) *lpr = *lph;
-    *grid = dim3((uint32_t)((n_rows + kWavesPerBlock - 1) / kWavesPerBlock), (uint32_t)((vecs + *lpr - 1) / *lpr));
+    *grid_y = (uint32_t)((vecs + *lpr - 1) / *lpr);
     return DGLL_OK;
 }
 
 static int gat_fwd_impl(void* stream, const dgll_csr_plan* plan, const int64_t* rowptr, const int32_t* col,
-                        const void* H, int64_t ldh, const float* S, const float* T, const float* edge_scale, void* out,
+                        const void* H, int64_t ldh, const float* S, const float* T, int t_stride, const float* edge_scale, void* out,
                         int64_t ldo, int dtype, float* rowsum, float* rowmax, int64_t n_rows, int heads, int fo,
-                        float alpha, int apply_elu, int mode, void* workspace, size_t workspace_bytes, int raw, int accumulate);
+                        float alpha, int apply_elu, int mode, void* workspace, size_t workspace_bytes, int raw, int accumulate) {
+    if (n_rows <= 0) return DGLL_OK;
+    EdgeArgs a{};
+    int rc = gat_common(a, rowptr, col, n_rows, heads, fo, dtype, alpha, mode, apply_elu);
+    if (rc != DGLL_OK) return rc;
+    DGLL_REQUIRE(H && S && T && out && rowsum, "NULL argument");
+    DGLL_REQUIRE(mode == 0 || rowmax, "mode 1 needs a rowmax output");
+    const int esz = dtype == DGLL_BF16 ? 2 : 4, epv = 16 / esz;
+    DGLL_REQUIRE(vec_ok(H, ldh, esz) && vec_ok(out, ldo, esz) && ldh >= a.feat && ldo >= a.feat, "H/out must be 16-byte aligned");
+    a.H = H; a.ldh = ldh; a.S = S; a.T = T; a.tstride = t_stride > 0 ? t_stride : heads; a.edge_scale = edge_scale; a.Y = out; a.ldy = ldo;
+    a.out_a = rowsum; a.out_b = mode == 1 ? rowmax : nullptr;
+    DGLL_REQUIRE(mode == 0 || (!raw && !accumulate), "split (raw / accumulate) launches support mode 0 only");
+    a.raw = raw; a.accumulate = accumulate;
+    dim3 grid(1, 1, 1);
+    rc = gat_schedule(a, plan, n_rows, workspace, workspace_bytes, &grid, esz);
+    if (rc != DGLL_OK) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int lpr, nh, lph;
+    if (gat2_pick(a, &lpr, &nh, &grid.y)) {
+        if (!gat2_launch_0(dtype, lpr, nh, grid, s, a)) { set_error("no second-generation GAT kernel for this head layout"); return DGLL_ERR_UNSUPPORTED; }
+    } else {
+        rc = gat1_pick(a, epv, &lph, &lpr, &grid.y);
+        if (rc != DGLL_OK) return rc;
+#define CALL(L)                                                                                                                \
+    if (dtype == DGLL_F32) hipLaunchKernelGGL((gat_fwd_kernel<float, float, 4, L, 4>), grid, dim3(kBlock), 0, s, a, lph);      \
+    else hipLaunchKernelGGL((gat_fwd_kernel<bf16_t, bf16_t, 8, L, 4>), grid, dim3(kBlock), 0, s, a, lph);
+        DGLL_LPR_SWITCH(lpr, CALL)
+#undef CALL
+    }
+    DGLL_HIP_TRY(hipGetLastError());
+    return dtype == DGLL_F32 ? gat_finalize<float>(a, plan, 0, s) : gat_finalize<bf16_t>(a, plan, 0, s);
+}
 
 DGLL_API int dgll_hip_gat_fwd(void* stream, const dgll_csr_plan* plan, const int64_t* rowptr, const int32_t* col,
                               const void* H, int64_t ldh, const float* S, const float* T, const float* edge_scale, void* out,
                               int64_t ldo, int dtype, float* rowsum, float* rowmax, int64_t n_rows, int heads, int fo,
                               float alpha, int apply_elu, int mode, void* workspace, size_t workspace_bytes) {
-    return gat_fwd_impl(stream, plan, rowptr, col, H, ldh, S, T, edge_scale, out, ldo, dtype, rowsum, rowmax, n_rows, heads, fo,
+    return gat_fwd_impl(stream, plan, rowptr, col, H, ldh, S, T, 0, edge_scale, out, ldo, dtype, rowsum, rowmax, n_rows, heads, fo,
                         alpha, apply_elu, mode, workspace, workspace_bytes, 0, 0);
 }
 
@@ -851,109 +797,124 @@ DGLL_API int dgll_hip_gat_fwd_ex(void* stream, const dgll_csr_plan* plan, const 
                                  const void* H, int64_t ldh, const float* S, const float* T, const float* edge_scale, void* out,
                                  int64_t ldo, int dtype, float* rowsum, int64_t n_rows, int heads, int fo, float alpha,
                                  int apply_elu, void* workspace, size_t workspace_bytes, int raw, int accumulate) {
-    return gat_fwd_impl(stream, plan, rowptr, col, H, ldh, S, T, edge_scale, out, ldo, dtype, rowsum, nullptr, n_rows, heads, fo,
+    return gat_fwd_impl(stream, plan, rowptr, col, H, ldh, S, T, 0, edge_scale, out, ldo, dtype, rowsum, nullptr, n_rows, heads, fo,
                         alpha, apply_elu, 0, workspace, workspace_bytes, raw, accumulate);
 }
 
-static int gat_fwd_impl(void* stream, const dgll_csr_plan* plan, const int64_t* rowptr, const int32_t* col,
-                        const void* H, int64_t ldh, const float* S, const float* T, const float* edge_scale, void* out,
-                        int64_t ldo, int dtype, float* rowsum, float* rowmax, int64_t n_rows, int heads, int fo,
-                        float alpha, int apply_elu, int mode, void* workspace, size_t workspace_bytes, int raw, int accumulate) {
-    if (n_rows <= 0) return DGLL_OK;
-    EdgeArgs a{};
-    int lph, lpr;
-    dim3 grid;
-    int rc = gat_common(a, rowptr, col, n_rows, heads, fo, dtype, alpha, mode, apply_elu, &lph, &lpr, &grid);
-    if (rc != DGLL_OK) return rc;
-    DGLL_REQUIRE(H && S && T && out && rowsum, "NULL argument");
-    DGLL_REQUIRE(mode == 0 || rowmax, "mode 1 needs a rowmax output");
-    const int esz = dtype == DGLL_BF16 ? 2 : 4;
-    DGLL_REQUIRE(vec_ok(H, ldh, esz) && vec_ok(out, ldo, esz) && ldh >= a.feat && ldo >= a.feat, "H/out must be 16-byte aligned");
-    a.H = H; a.ldh = ldh; a.S = S; a.T = T; a.edge_scale = edge_scale; a.Y = out; a.ldy = ldo;
-    a.out_a = rowsum; a.out_b = mode == 1 ? rowmax : nullptr;
-    DGLL_REQUIRE(mode == 0 || (!raw && !accumulate), "split (raw / accumulate) launches support mode 0 only");
-    a.raw = raw; a.accumulate = accumulate;
-    rc = gat_schedule(a, plan, n_rows, workspace, workspace_bytes, &grid, esz);
-    if (rc != DGLL_OK) return rc;
-    hipStream_t s = static_cast<hipStream_t>(stream);
-#define CALL(L)                                                                                                                \
-    if (dtype == DGLL_F32) hipLaunchKernelGGL((gat_fwd_kernel<float, float, 4, L, 4>), grid, dim3(kBlock), 0, s, a, lph);      \
-    else hipLaunchKernelGGL((gat_fwd_kernel<bf16_t, bf16_t, 8, L, 4>), grid, dim3(kBlock), 0, s, a, lph);
-    DGLL_LPR_SWITCH(lpr, CALL)
-#undef CALL
-    DGLL_HIP_TRY(hipGetLastError());
-    return dtype == DGLL_F32 ? gat_finalize<float>(a, plan, 0, s) : gat_finalize<bf16_t>(a, plan, 0, s);
+DGLL_API int dgll_hip_gat_fwd_strided(void* stream, const dgll_csr_plan* plan, const int64_t* rowptr, const int32_t* col,
+                                      const void* H, int64_t ldh, const float* S, const float* T, int t_stride, void* out,
+                                      int64_t ldo, int dtype, float* rowsum, int64_t n_rows, int heads, int fo, float alpha,
+                                      int apply_elu, void* workspace, size_t workspace_bytes) {
+    DGLL_REQUIRE(t_stride >= heads, "t_stride must be at least heads");
+    return gat_fwd_impl(stream, plan, rowptr, col, H, ldh, S, T, t_stride, nullptr, out, ldo, dtype, rowsum, nullptr, n_rows, heads,
+                        fo, alpha, apply_elu, 0, workspace, workspace_bytes, 0, 0);
 }
 
 // Pass 1 of the backward (rows of A or of one column-half of A): DN, DD (written unless `accumulate`) and grad_S (+=).
+static int gat_bwd_rows_impl(void* stream, const dgll_csr_plan* plan, const int64_t* rowptr, const int32_t* col,
+                             const void* H, int64_t ldh, const float* S, const float* T, int t_stride, const float* edge_scale,
+                             const void* out, int64_t ldo, const void* grad_out, int64_t ldg, int dtype,
+                             const float* rowsum, const float* rowmax, void* dn, int64_t ldn, float* dd, float* sd_out,
+                             int sd_stride, float* grad_S, int64_t n_rows, int heads, int fo, float alpha, int apply_elu,
+                             int mode, int accumulate, void* workspace, size_t workspace_bytes) {
+    if (n_rows <= 0) return DGLL_OK;
+    EdgeArgs a{};
+    int rc = gat_common(a, rowptr, col, n_rows, heads, fo, dtype, alpha, mode, apply_elu);
+    if (rc != DGLL_OK) return rc;
+    DGLL_REQUIRE(H && S && T && out && grad_out && rowsum && dn && (dd || sd_out) && grad_S, "NULL argument");
+    DGLL_REQUIRE(mode == 0 || rowmax, "mode 1 needs the forward's rowmax");
+    const int esz = dtype == DGLL_BF16 ? 2 : 4, epv = 16 / esz;
+    DGLL_REQUIRE(vec_ok(H, ldh, esz) && vec_ok(out, ldo, esz) && vec_ok(grad_out, ldg, esz) && vec_ok(dn, ldn, esz),
+                 "matrices must be 16-byte aligned with padded leading dimensions");
+    a.H = H; a.ldh = ldh; a.S = S; a.T = T; a.tstride = t_stride > 0 ? t_stride : heads; a.M = mode == 1 ? rowmax : nullptr;
+    a.DEN = rowsum; a.edge_scale = edge_scale;
+    a.G = grad_out; a.ldg = ldg; a.O = out; a.ldo = ldo; a.Y = dn; a.ldy = ldn; a.out_a = grad_S; a.out_b = dd;
+    a.sd_out = sd_out; a.sd_stride = sd_stride;
+    a.accumulate = accumulate;
+    dim3 grid(1, 1, 1);
+    rc = gat_schedule(a, plan, n_rows, workspace, workspace_bytes, &grid, esz);
+    if (rc != DGLL_OK) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int lpr, nh, lph;
+    if (gat2_pick(a, &lpr, &nh, &grid.y)) {
+        if (!gat2_launch_1(dtype, lpr, nh, grid, s, a)) { set_error("no second-generation GAT kernel for this head layout"); return DGLL_ERR_UNSUPPORTED; }
+    } else {
+        rc = gat1_pick(a, epv, &lph, &lpr, &grid.y);
+        if (rc != DGLL_OK) return rc;
+        DGLL_REQUIRE(dd, "the first-generation rows pass writes dd");
+#define CALL(L)                                                                                                              \
+    if (dtype == DGLL_F32) hipLaunchKernelGGL((gat_bwd_rows_kernel<float, 4, L, 2>), grid, dim3(kBlock), 0, s, a, lph);      \
+    else hipLaunchKernelGGL((gat_bwd_rows_kernel<bf16_t, 8, L, 2>), grid, dim3(kBlock), 0, s, a, lph);
+        DGLL_LPR_SWITCH(lpr, CALL)
+#undef CALL
+    }
+    DGLL_HIP_TRY(hipGetLastError());
+    return gat_finalize<float>(a, plan, 1, s);
+}
+
 DGLL_API int dgll_hip_gat_bwd_rows(void* stream, const dgll_csr_plan* plan, const int64_t* rowptr, const int32_t* col,
                                    const void* H, int64_t ldh, const float* S, const float* T, const float* edge_scale,
                                    const void* out, int64_t ldo, const void* grad_out, int64_t ldg, int dtype,
                                    const float* rowsum, const float* rowmax, void* dn, int64_t ldn, float* dd, float* grad_S,
                                    int64_t n_rows, int heads, int fo, float alpha, int apply_elu, int mode, int accumulate,
                                    void* workspace, size_t workspace_bytes) {
-    if (n_rows <= 0) return DGLL_OK;
-    EdgeArgs a{};
-    int lph, lpr;
-    dim3 grid;
-    int rc = gat_common(a, rowptr, col, n_rows, heads, fo, dtype, alpha, mode, apply_elu, &lph, &lpr, &grid);
-    if (rc != DGLL_OK) return rc;
-    DGLL_REQUIRE(H && S && T && out && grad_out && rowsum && dn && dd && grad_S, "NULL argument");
-    DGLL_REQUIRE(mode == 0 || rowmax, "mode 1 needs the forward's rowmax");
-    const int esz = dtype == DGLL_BF16 ? 2 : 4;
-    DGLL_REQUIRE(vec_ok(H, ldh, esz) && vec_ok(out, ldo, esz) && vec_ok(grad_out, ldg, esz) && vec_ok(dn, ldn, esz),
-                 "matrices must be 16-byte aligned with padded leading dimensions");
-    a.H = H; a.ldh = ldh; a.S = S; a.T = T; a.M = mode == 1 ? rowmax : nullptr; a.DEN = rowsum; a.edge_scale = edge_scale;
-    a.G = grad_out; a.ldg = ldg; a.O = out; a.ldo = ldo; a.Y = dn; a.ldy = ldn; a.out_a = grad_S; a.out_b = dd;
-    a.accumulate = accumulate;
-    rc = gat_schedule(a, plan, n_rows, workspace, workspace_bytes, &grid, esz);
-    if (rc != DGLL_OK) return rc;
-    hipStream_t s = static_cast<hipStream_t>(stream);
-#define CALL(L)                                                                                                              \
-    if (dtype == DGLL_F32) hipLaunchKernelGGL((gat_bwd_rows_kernel<float, 4, L, 2>), grid, dim3(kBlock), 0, s, a, lph);      \
-    else if (g_tune_gat_unroll == 4) hipLaunchKernelGGL((gat_bwd_rows_kernel<bf16_t, 8, L, 4>), grid, dim3(kBlock), 0, s, a, lph); \
-    else hipLaunchKernelGGL((gat_bwd_rows_kernel<bf16_t, 8, L, 2>), grid, dim3(kBlock), 0, s, a, lph);
-    DGLL_LPR_SWITCH(lpr, CALL)
-#undef CALL
-    DGLL_HIP_TRY(hipGetLastError());
-    return gat_finalize<float>(a, plan, 1, s);
+    DGLL_REQUIRE(dd, "NULL dd");
+    return gat_bwd_rows_impl(stream, plan, rowptr, col, H, ldh, S, T, 0, edge_scale, out, ldo, grad_out, ldg, dtype, rowsum, rowmax,
+                             dn, ldn, dd, nullptr, 0, grad_S, n_rows, heads, fo, alpha, apply_elu, mode, accumulate, workspace,
+                             workspace_bytes);
 }
 
 // Pass 2 of the backward over a transposed structure (rows = source nodes j, columns = destination rows i):
 // grad_H[j] = sum_i w_ij scale_ij DN[i], grad_T[j] = sum_i dz_ij.  Hrow / T_row belong to the rows of this pass, DN / S_col /
-// DD / M_col to its columns.
+// DD / M_col to its columns (`col_stride` floats per node for S_col and dd_col; 0 = heads).
+static int gat_bwd_cols_impl(void* stream, const dgll_csr_plan* t_plan, const int64_t* t_rowptr, const int32_t* t_col,
+                             const int64_t* t_perm, const void* dn, int64_t ldn, const void* Hrow, int64_t ldh,
+                             const float* T_row, const float* S_col, const float* dd_col, int col_stride, const float* rowmax_col,
+                             const float* edge_scale, void* grad_H, int64_t ldgh, float* grad_T, int dtype,
+                             int64_t n_rows_t, int heads, int fo, float alpha, int mode, void* workspace,
+                             size_t workspace_bytes) {
+    if (n_rows_t <= 0) return DGLL_OK;
+    EdgeArgs t{};
+    int rc = gat_common(t, t_rowptr, t_col, n_rows_t, heads, fo, dtype, alpha, mode, 0);
+    if (rc != DGLL_OK) return rc;
+    DGLL_REQUIRE(dn && Hrow && T_row && S_col && dd_col && grad_H && grad_T, "NULL argument");
+    DGLL_REQUIRE(mode == 0 || rowmax_col, "mode 1 needs the forward's rowmax");
+    DGLL_REQUIRE(!edge_scale || t_perm, "edge_scale needs the transpose permutation");
+    const int esz = dtype == DGLL_BF16 ? 2 : 4, epv = 16 / esz;
+    DGLL_REQUIRE(vec_ok(dn, ldn, esz) && vec_ok(Hrow, ldh, esz) && vec_ok(grad_H, ldgh, esz),
+                 "matrices must be 16-byte aligned with padded leading dimensions");
+    t.perm = t_perm; t.H = dn; t.ldh = ldn; t.G = Hrow; t.ldg = ldh; t.S = T_row; t.T = S_col; t.DD = dd_col;
+    t.tstride = col_stride > 0 ? col_stride : heads;
+    t.M = mode == 1 ? rowmax_col : nullptr; t.edge_scale = edge_scale; t.Y = grad_H; t.ldy = ldgh; t.out_a = grad_T;
+    t.out_b = nullptr;
+    dim3 grid(1, 1, 1);
+    rc = gat_schedule(t, t_plan, n_rows_t, workspace, workspace_bytes, &grid, esz);
+    if (rc != DGLL_OK) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int lpr, nh, lph;
+    if (gat2_pick(t, &lpr, &nh, &grid.y)) {
+        if (!gat2_launch_2(dtype, lpr, nh, grid, s, t)) { set_error("no second-generation GAT kernel for this head layout"); return DGLL_ERR_UNSUPPORTED; }
+    } else {
+        rc = gat1_pick(t, epv, &lph, &lpr, &grid.y);
+        if (rc != DGLL_OK) return rc;
+#define CALL(L)                                                                                                                  \
+    if (dtype == DGLL_F32) hipLaunchKernelGGL((gat_bwd_cols_kernel<float, float, 4, L, 2>), grid, dim3(kBlock), 0, s, t, lph);   \
+    else hipLaunchKernelGGL((gat_bwd_cols_kernel<bf16_t, bf16_t, 8, L, 2>), grid, dim3(kBlock), 0, s, t, lph);
+        DGLL_LPR_SWITCH(lpr, CALL)
+#undef CALL
+    }
+    DGLL_HIP_TRY(hipGetLastError());
+    return dtype == DGLL_F32 ? gat_finalize<float>(t, t_plan, 2, s) : gat_finalize<bf16_t>(t, t_plan, 2, s);
+}
+
 DGLL_API int dgll_hip_gat_bwd_cols(void* stream, const dgll_csr_plan* t_plan, const int64_t* t_rowptr, const int32_t* t_col,
                                    const int64_t* t_perm, const void* dn, int64_t ldn, const void* Hrow, int64_t ldh,
                                    const float* T_row, const float* S_col, const float* dd_col, const float* rowmax_col,
                                    const float* edge_scale, void* grad_H, int64_t ldgh, float* grad_T, int dtype,
                                    int64_t n_rows_t, int heads, int fo, float alpha, int mode, void* workspace,
                                    size_t workspace_bytes) {
-    if (n_rows_t <= 0) return DGLL_OK;
-    EdgeArgs t{};
-    int lph, lpr;
-    dim3 grid;
-    int rc = gat_common(t, t_rowptr, t_col, n_rows_t, heads, fo, dtype, alpha, mode, 0, &lph, &lpr, &grid);
-    if (rc != DGLL_OK) return rc;
-    DGLL_REQUIRE(dn && Hrow && T_row && S_col && dd_col && grad_H && grad_T, "NULL argument");
-    DGLL_REQUIRE(mode == 0 || rowmax_col, "mode 1 needs the forward's rowmax");
-    DGLL_REQUIRE(!edge_scale || t_perm, "edge_scale needs the transpose permutation");
-    const int esz = dtype == DGLL_BF16 ? 2 : 4;
-    DGLL_REQUIRE(vec_ok(dn, ldn, esz) && vec_ok(Hrow, ldh, esz) && vec_ok(grad_H, ldgh, esz),
-                 "matrices must be 16-byte aligned with padded leading dimensions");
-    t.perm = t_perm; t.H = dn; t.ldh = ldn; t.G = Hrow; t.ldg = ldh; t.S = T_row; t.T = S_col; t.DD = dd_col;
-    t.M = mode == 1 ? rowmax_col : nullptr; t.edge_scale = edge_scale; t.Y = grad_H; t.ldy = ldgh; t.out_a = grad_T;
-    t.out_b = nullptr;
-    rc = gat_schedule(t, t_plan, n_rows_t, workspace, workspace_bytes, &grid, esz);
-    if (rc != DGLL_OK) return rc;
-    hipStream_t s = static_cast<hipStream_t>(stream);
-#define CALL(L)                                                                                                                  \
-    if (dtype == DGLL_F32) hipLaunchKernelGGL((gat_bwd_cols_kernel<float, float, 4, L, 2>), grid, dim3(kBlock), 0, s, t, lph);   \
-    else if (g_tune_gat_unroll == 4) hipLaunchKernelGGL((gat_bwd_cols_kernel<bf16_t, bf16_t, 8, L, 4>), grid, dim3(kBlock), 0, s, t, lph); \
-    else hipLaunchKernelGGL((gat_bwd_cols_kernel<bf16_t, bf16_t, 8, L, 2>), grid, dim3(kBlock), 0, s, t, lph);
-    DGLL_LPR_SWITCH(lpr, CALL)
-#undef CALL
-    DGLL_HIP_TRY(hipGetLastError());
-    return dtype == DGLL_F32 ? gat_finalize<float>(t, t_plan, 2, s) : gat_finalize<bf16_t>(t, t_plan, 2, s);
+    return gat_bwd_cols_impl(stream, t_plan, t_rowptr, t_col, t_perm, dn, ldn, Hrow, ldh, T_row, S_col, dd_col, 0, rowmax_col,
+                             edge_scale, grad_H, ldgh, grad_T, dtype, n_rows_t, heads, fo, alpha, mode, workspace, workspace_bytes);
 }
 
 DGLL_API int dgll_hip_gat_bwd(void* stream, const dgll_csr_plan* plan, const dgll_csr_plan* t_plan,
@@ -975,6 +936,53 @@ DGLL_API int dgll_hip_gat_bwd(void* stream, const dgll_csr_plan* plan, const dgl
     return dgll_hip_gat_bwd_cols(stream, t_plan, t_rowptr, t_col, t_perm, dn_scratch, ldn, H, ldh, T, S, dd_scratch, rowmax,
                                  edge_scale, grad_H, ldgh, grad_T, dtype, n_cols, heads, fo, alpha, mode, workspace,
                                  workspace_bytes);
+}
+
+// Both backward passes of the sparseGatConv form (mode 0, no attention dropout) with strided score arrays:
+//   T            gathered by the rows pass at T[j * t_stride + head] -- a compact [n_cols, heads] array (t_stride = heads) or
+//                a slot in the padding of the H rows themselves (then the score costs no extra cache line per edge);
+//   sd_scratch   fp32, `sd_stride` floats per destination row: the rows pass leaves {s_i[0:heads], dd_i[0:heads]} side by side
+//                there and the transposed pass gathers both with one line fill -- a separate [n_rows, 2 * heads] buffer
+//                (sd_stride = 2 * heads) or a slot in the padding of the dn_scratch rows.
+DGLL_API int dgll_hip_gat_bwd_rows_strided(void* stream, const dgll_csr_plan* plan, const int64_t* rowptr, const int32_t* col,
+                                           const void* H, int64_t ldh, const float* S, const float* T, int t_stride,
+                                           const void* out, int64_t ldo, const void* grad_out, int64_t ldg, int dtype,
+                                           const float* rowsum, void* dn_scratch, int64_t ldn, float* sd_scratch, int sd_stride,
+                                           float* grad_S, int64_t n_rows, int heads, int fo, float alpha, int apply_elu,
+                                           void* workspace, size_t workspace_bytes) {
+    DGLL_REQUIRE(sd_scratch && sd_stride >= 2 * heads && t_stride >= heads, "bad strided score arguments");
+    return gat_bwd_rows_impl(stream, plan, rowptr, col, H, ldh, S, T, t_stride, nullptr, out, ldo, grad_out, ldg, dtype, rowsum,
+                             nullptr, dn_scratch, ldn, nullptr, sd_scratch, sd_stride, grad_S, n_rows, heads, fo, alpha,
+                             apply_elu, 0, 0, workspace, workspace_bytes);
+}
+
+DGLL_API int dgll_hip_gat_bwd_cols_strided(void* stream, const dgll_csr_plan* t_plan, const int64_t* t_rowptr,
+                                           const int32_t* t_col, const void* dn_scratch, int64_t ldn, const void* H,
+                                           int64_t ldh, const float* T_rows, const float* sd_scratch, int sd_stride,
+                                           void* grad_H, int64_t ldgh, float* grad_T, int dtype, int64_t n_cols, int heads,
+                                           int fo, float alpha, void* workspace, size_t workspace_bytes) {
+    DGLL_REQUIRE(sd_scratch && sd_stride >= 2 * heads && T_rows, "bad strided score arguments");
+    return gat_bwd_cols_impl(stream, t_plan, t_rowptr, t_col, nullptr, dn_scratch, ldn, H, ldh, T_rows, sd_scratch,
+                             sd_scratch + heads, sd_stride, nullptr, nullptr, grad_H, ldgh, grad_T, dtype, n_cols, heads, fo,
+                             alpha, 0, workspace, workspace_bytes);
+}
+
+DGLL_API int dgll_hip_gat_bwd_strided(void* stream, const dgll_csr_plan* plan, const dgll_csr_plan* t_plan,
+                                      const int64_t* rowptr, const int32_t* col, const int64_t* t_rowptr, const int32_t* t_col,
+                                      const void* H, int64_t ldh, const float* S, const float* T, int t_stride,
+                                      const float* T_rows, const void* out, int64_t ldo, const void* grad_out, int64_t ldg,
+                                      int dtype, const float* rowsum, void* dn_scratch, int64_t ldn, float* sd_scratch,
+                                      int sd_stride, void* grad_H, int64_t ldgh, float* grad_S, float* grad_T, int64_t n_rows,
+                                      int64_t n_cols, int heads, int fo, float alpha, int apply_elu, void* workspace,
+                                      size_t workspace_bytes) {
+    DGLL_REQUIRE(t_rowptr && t_col, "NULL transposed CSR");
+    int rc = dgll_hip_gat_bwd_rows_strided(stream, plan, rowptr, col, H, ldh, S, T, t_stride, out, ldo, grad_out, ldg, dtype,
+                                           rowsum, dn_scratch, ldn, sd_scratch, sd_stride, grad_S, n_rows, heads, fo, alpha,
+                                           apply_elu, workspace, workspace_bytes);
+    if (rc != DGLL_OK) return rc;
+    // the same workspace is reused: pass 2 is stream-ordered after pass 1
+    return dgll_hip_gat_bwd_cols_strided(stream, t_plan, t_rowptr, t_col, dn_scratch, ldn, H, ldh, T_rows, sd_scratch, sd_stride,
+                                         grad_H, ldgh, grad_T, dtype, n_cols, heads, fo, alpha, workspace, workspace_bytes);
 }
 
 DGLL_API int dgll_hip_segment_max(void* stream, const int64_t* rowptr, const int32_t* col, const void* X, int64_t ldx,

@@ -1,0 +1,358 @@
+// gat_kernel.hpp -- the three gather passes of the fused multi-head GAT layer for gfx950, second generation.
+// Included by gat_fwd.hip / gat_bwd_rows.hip / gat_bwd_cols.hip (one translation unit per pass: they compile in parallel).
+//
+// Reference semantics (under /root/reference/dgll/nn/Convolution/):
+//   sparseGatConv.forward  gatconv.py:111-148   e_ij = exp(-leakyrelu(a1.h_i + a2.h_j)); out_i = sum_j e_ij h_j / sum_j e_ij; elu
+//   SpecialSpmmFunction    gatconv.py:60-81     the two backward products (here: two more gather passes, nothing per edge stored)
+//   SpGAT                  gatconv.py:174-199   `nheads` independent heads -- all of them in ONE launch here
+// (the max-subtracted softmax of the dense-adjacency gatConv, gatconv.py:30-54, and attention dropout stay on edge.hip's
+// first-generation kernels.)
+//
+// Where the time of these passes goes (MI355X, 8 heads x 32 bf16, products-sized graph; tools/gat_ab.py): like the SpMM they are
+// bound by cache-line fills per edge -- 4 lines for the 512-byte feature row, plus ONE line for every separate per-node array
+// that is gathered per edge (the neighbour's scores T[j, :]; in the transposed pass S[i, :] and DD[i, :]).  Hence:
+//   * every per-(edge, head) scalar -- the weight w_ij = exp(..) and its derivative factor -- is computed ONCE, by the lane
+//     that owns the edge in the coalesced 64-edge index batch, from one vector load of the neighbour's score row, and handed
+//     to the gathering lanes through a wave-private LDS record array (first generation: each of the 4 lanes of a head issued
+//     its own 4-byte gather and its own exponential: 32 scalar gathers + 32 v_exp per lane and batch instead of 2 + 8);
+//   * the backward passes do not reduce <DN_i, h_j> across the lanes of a head per EDGE (two ds_bpermute each):
+//         ds_i = sum_j c_ij (dot_ij + dd_i) = head_sum( sum_j c_ij * partial_dot_ij ) + dd_i * sum_j c_ij
+//     a lane accumulates its partial dot products weighted by c_ij; the cross-lane sum happens once per ROW;
+//   * {s_i, dd_i} are stored side by side (`sd_out`) so that the transposed pass pays one line fill for both, and any of the
+//     gathered score arrays may live in the PADDING of the feature rows themselves (`tstride`: a 47-class output row is 94 of
+//     128 bytes) -- then the score costs no line fill at all;
+//   * the rounds are branch- and mask-free (records of a batch's idle tail are zero, their columns repeat the last valid one)
+//     and the next row's index batch is requested before the current row's gathers.
+// LDS use: wave-private, written and read by the same wavefront (in-order DS queue: no barrier, no s_waitcnt between rows).
+#pragma once
+#include <algorithm>
+#include <type_traits>
+
+#include "edge_args.hpp"
+
+namespace dgll {
+
+namespace {
+
+constexpr int kRecStride = kWave + 1;   // one pad entry per head row: the 8 heads a half-wave reads land in different banks
+
+// NH consecutive per-head scalars of one node (row stride `stride` floats).  Blocks of 4 or 8 heads are read as float4s (the
+// host guarantees whole, 16-byte aligned blocks); 1 or 2 heads per wavefront as guarded scalars.
+template <int NH>
+__device__ __forceinline__ void load_heads(const float* __restrict__ base, int64_t node, int stride, int heads, int h0, float (&out)[NH]) {
+    const float* p = base + node * stride + h0;
+    if constexpr (NH % 4 == 0) {
+#pragma unroll
+        for (int q = 0; q < NH / 4; ++q) {
+            const float4 t = reinterpret_cast<const float4*>(p)[q];
+            out[4 * q + 0] = t.x; out[4 * q + 1] = t.y; out[4 * q + 2] = t.z; out[4 * q + 3] = t.w;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < NH; ++k) out[k] = (h0 + k < heads) ? p[k] : 0.0f;
+    }
+}
+
+template <int NH>
+__device__ __forceinline__ void load_heads_uniform(const float* __restrict__ base, int64_t row, int heads, int h0, float (&out)[NH]) {
+#pragma unroll
+    for (int k = 0; k < NH; ++k) out[k] = base[row * heads + (h0 + k < heads ? h0 + k : heads - 1)];
+}
+
+template <int LPH>
+__device__ __forceinline__ float head_sum_c(float v) {
+#pragma unroll
+    for (int off = 1; off < LPH; off <<= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+}  // namespace
+
+// KIND 0: forward.  KIND 1: backward over the rows of A (DN, DD, grad_S).  KIND 2: backward over the rows of A^T (grad_H, grad_T).
+// See edge.hip for the argument roles of each pass (they are unchanged).  Records (one per edge and head, wave-private LDS):
+//   KIND 0: w_ij            KIND 1: c_ij = w_ij * sign * lrelu'(z_ij)            KIND 2: { w_ij, c_ij } and dd_i * c_ij
+template <typename XT, typename YT, int EPV, int LPR, int NH, int U, int KIND>
+__global__ __launch_bounds__(kBlock) void gat2_kernel(const EdgeArgs a) {
+    typedef VecIO<XT, EPV> IO;
+    typedef typename std::conditional<KIND == 2, float2, float>::type rec_t;   // KIND 2: {w_ij, c_ij}, plus dd_i * c_ij in rec1
+    constexpr int SLOTS = kWave / LPR;
+    constexpr int LPH = LPR / NH;                                  // lanes per head
+    constexpr bool BF = sizeof(XT) == 2;
+    __shared__ rec_t rec_all[kWavesPerBlock][NH * kRecStride];
+    __shared__ float rec1_all[KIND == 2 ? kWavesPerBlock : 1][KIND == 2 ? NH * kRecStride : 1];
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    rec_t* __restrict__ rec = rec_all[wave];
+    const int sub = lane % LPR, slot = lane / LPR;
+    const int hk = sub / LPH, hs = sub % LPH;                      // this lane's head among the wave's NH heads, its vector in the head
+    const int h0 = (int)blockIdx.y * NH;                           // first head of this column block
+    const bool col_ok = h0 + hk < a.heads && hs < a.vph;           // a head may use fewer vectors than it has lanes (fo = 48: 6 of 8)
+    const int head = col_ok ? h0 + hk : 0;
+    const int c0 = col_ok ? head * a.fo + hs * EPV : 0;
+    const XT* hcol = static_cast<const XT*>(a.H) + (col_ok ? c0 : 0);
+    const uint32_t ld32 = (uint32_t)a.ldh;
+    const rec_t* __restrict__ my_rec = rec + hk * kRecStride;
+    float* __restrict__ rec1 = rec1_all[KIND == 2 ? wave : 0];
+    const float* __restrict__ my_rec1 = rec1 + hk * kRecStride;
+
+    WorkItem it = resolve_item(a, wave, 0);
+    int col_first = 0;                                             // the item's first index batch (lane = edge), prefetched
+    if (it.valid && it.b + lane < it.e) col_first = __builtin_nontemporal_load(a.col + it.b + lane);
+  for (int r = 0; !it.done; ++r) {
+    // the NEXT item's bounds and first index batch are requested before this item's gathers: a row's dependent chain
+    // (row pointers -> indices -> score rows -> gathers) then starts at the score rows
+    WorkItem nx;
+    nx.done = true; nx.valid = false; nx.first = true; nx.row = nx.b = nx.e = 0; nx.chunk = -1;
+    if (r + 1 < a.rows_per_wave) nx = resolve_item(a, wave, r + 1);
+    int col_next_item = 0;
+    if (nx.valid && nx.b + lane < nx.e) col_next_item = __builtin_nontemporal_load(a.col + nx.b + lane);
+   if (it.valid) {
+    const int64_t row = it.row, b = it.b, e = it.e;
+
+    // ---- wave-uniform per-row scalars of the wave's heads
+    float su[NH];
+    load_heads_uniform<NH>(a.S, row, a.heads, h0, su);
+
+    // ---- per-row prologue of the backward passes
+    float dn[EPV];                     // KIND 1: DN_i (this lane's columns)
+    uint32_t rp[4] = {0u, 0u, 0u, 0u}; // bf16: DN_i (KIND 1) or h_j (KIND 2) as packed pairs for v_dot2
+    float hj[EPV];                     // KIND 2 fp32: h_j
+    float dd = 0.0f;
+    if constexpr (KIND == 1) {
+        const float inv_den = 1.0f / a.DEN[row * a.heads + head];
+        float g[EPV], o[EPV];
+        IO::unpack(col_ok ? IO::load(static_cast<const XT*>(a.G) + row * a.ldg + c0) : IO::zero(), g);
+        IO::unpack(col_ok ? IO::load(static_cast<const XT*>(a.O) + row * a.ldo + c0) : IO::zero(), o);
+        float part = 0.0f;
+#pragma unroll
+        for (int i = 0; i < EPV; ++i) {
+            float dhp = g[i], hp = o[i];
+            if (a.apply_elu && o[i] <= 0.0f) {  // out = expm1(hp): elu'(hp) = out + 1, hp = log1p(out)
+                const float op1 = o[i] + 1.0f;    // saturated ELU (out == -1): gradient 0, and 0 * log(0) must stay 0
+                dhp = g[i] * op1;
+                // bf16 storage: the hardware logarithm (absolute error ~1e-7 on a value rounded to 8 bits anyway); fp32: log1pf
+                hp = op1 > 0.0f ? (BF ? __logf(op1) : log1pf(o[i])) : 0.0f;
+            }
+            part = fmaf(dhp, hp, part);
+            dn[i] = dhp * inv_den;
+        }
+        dd = -head_sum_c<LPH>(part) * inv_den;
+        if (slot == 0 && col_ok && it.first && !a.accumulate) {   // per-row outputs: written once (row itself / first chunk, first launch)
+            VecIO<XT, EPV>::store(static_cast<XT*>(a.Y) + row * a.ldy + c0, dn);
+            if (hs == 0) {
+                if (a.out_b) a.out_b[row * a.heads + head] = dd;
+                if (a.sd_out) {   // {s_i, dd_i} side by side where the transposed pass gathers them with ONE line fill per edge
+                    a.sd_out[row * a.sd_stride + head] = a.S[row * a.heads + head];
+                    a.sd_out[row * a.sd_stride + a.heads + head] = dd;
+                }
+            }
+        }
+        if constexpr (BF) {  // the transposed pass re-reads DN in storage precision: use the same rounded values here
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rp[q] = pack_bf16x2(dn[2 * q], dn[2 * q + 1]);
+        }
+    }
+    if constexpr (KIND == 2) {
+        const typename IO::raw_t raw = col_ok ? IO::load(static_cast<const XT*>(a.G) + row * a.ldg + c0) : IO::zero();
+        if constexpr (BF) { rp[0] = raw.x; rp[1] = raw.y; rp[2] = raw.z; rp[3] = raw.w; }
+        else IO::unpack(raw, hj);
+    }
+
+    float acc[EPV];
+#pragma unroll
+    for (int i = 0; i < EPV; ++i) acc[i] = 0.0f;
+    float sa = 0.0f, sb = 0.0f;        // KIND 0: sb = denominator.  KIND 1/2: sa = sum c * partial dot, sb = sum c (or dd * c)
+
+    int col_cur = col_first;
+    for (int64_t k0 = b; k0 < e; k0 += kWave) {
+        const int64_t left = e - k0;
+        const int nb = left < kWave ? (int)left : kWave;
+        const bool live = lane < nb;
+        int col_nxt = 0;                                        // next index batch of this row
+        {
+            const int64_t kn = k0 + kWave + lane;
+            if (kn < e) col_nxt = __builtin_nontemporal_load(a.col + kn);
+        }
+        // -- record phase: lane = edge.  (Measured alternative for 8 heads, lane = (edge, half) so that one load instruction
+        // covers 32 edges with two adjacent lanes per 32-byte score row: forward unchanged, transposed pass 6.4 -> 7.8 ms.)
+        {
+            float tv[NH], dv[NH];
+            load_heads<NH>(a.T, col_cur, a.tstride, a.heads, h0, tv);        // idle lanes hold column 0: a valid row
+            if constexpr (KIND == 2) load_heads<NH>(a.DD, col_cur, a.tstride, a.heads, h0, dv);
+#pragma unroll
+            for (int k = 0; k < NH; ++k) {
+                const float z = su[k] + tv[k];
+                float w = __expf(a.sign * lrelu(z, a.alpha));
+                w = (live && h0 + k < a.heads) ? w : 0.0f;
+                const float cc = w * a.sign * (z > 0.0f ? 1.0f : a.alpha);
+                if constexpr (KIND == 0) rec[k * kRecStride + lane] = w;
+                if constexpr (KIND == 1) rec[k * kRecStride + lane] = cc;
+                if constexpr (KIND == 2) { rec[k * kRecStride + lane] = make_float2(w, cc); rec1[k * kRecStride + lane] = dv[k] * cc; }
+            }
+        }
+        // idle lanes of the last batch repeat its last valid column (same cache lines as a live request; their records are zero)
+        const int last_col = __builtin_amdgcn_readlane(col_cur, nb - 1);
+        const int gcol = live ? col_cur : last_col;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // -- gather rounds: lane = (slot, columns)
+        for (int j = 0; j < nb; j += SLOTS * U) {
+            typename IO::raw_t v[U];
+            rec_t rr[U];
+            float r1[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = j + u * SLOTS + slot;
+                const int cj = __shfl(gcol, idx);
+                v[u] = IO::load(hcol + (uint64_t)(uint32_t)cj * ld32);
+                rr[u] = my_rec[idx];
+                if constexpr (KIND == 2) r1[u] = my_rec1[idx];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if constexpr (KIND == 0) {
+                    sb += rr[u];
+                    float f[EPV];
+                    IO::unpack(v[u], f);
+#pragma unroll
+                    for (int i = 0; i < EPV; ++i) acc[i] = fmaf(rr[u], f[i], acc[i]);
+                } else {
+                    float dot = 0.0f;
+                    if constexpr (BF) {   // <DN_i, h_j> on the packed pairs (v_dot2c_f32_bf16, fp32 accumulate)
+                        const uint32_t hv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            dot = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, rp[q]), __builtin_bit_cast(bf16x2_t, hv[q]), dot, false);
+                    }
+                    if constexpr (KIND == 1) {
+                        if constexpr (!BF) {
+                            float f[EPV];
+                            IO::unpack(v[u], f);
+#pragma unroll
+                            for (int i = 0; i < EPV; ++i) dot = fmaf(dn[i], f[i], dot);
+                        }
+                        sa = fmaf(dot, rr[u], sa);
+                        sb += rr[u];
+                    } else {
+                        float f[EPV];
+                        IO::unpack(v[u], f);
+                        if constexpr (!BF) {
+#pragma unroll
+                            for (int i = 0; i < EPV; ++i) dot = fmaf(f[i], hj[i], dot);
+                        }
+                        sa = fmaf(dot, rr[u].y, sa);
+                        sb += r1[u];
+#pragma unroll
+                        for (int i = 0; i < EPV; ++i) acc[i] = fmaf(rr[u].x, f[i], acc[i]);
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        col_cur = col_nxt;
+    }
+
+    // ---- row epilogues
+    if constexpr (KIND == 0) {
+#pragma unroll
+        for (int i = 0; i < EPV; ++i) acc[i] = slot_sum<LPR>(acc[i]);
+        float den = slot_sum<LPR>(sb);
+        if (it.chunk >= 0) {  // partial of a long row: (acc, den, local max) -> workspace, combined by gat_long_finalize_kernel
+            if (slot == 0 && col_ok) {
+                float* wsp = a.ws + it.chunk * a.ws_ld;
+#pragma unroll
+                for (int i = 0; i < EPV; ++i) wsp[c0 + i] = acc[i];
+                if (hs == 0) {
+                    wsp[a.ws_vec + head] = den;
+                    wsp[a.ws_vec + a.heads + head] = 0.0f;     // local maximum: unused without max subtraction
+                }
+            }
+        } else {
+            if (slot == 0 && col_ok) {
+                YT* yrow = static_cast<YT*>(a.Y) + row * a.ldy + c0;
+                if (a.accumulate) {   // second half of a split adjacency: the first launch left (num, den) of the other columns here
+                    den += a.out_a[row * a.heads + head];
+#pragma unroll
+                    for (int i = 0; i < EPV; ++i) acc[i] += load_scalar<YT>(yrow + i);
+                }
+                if (!a.raw) {
+                    const float inv = 1.0f / den;  // 0/0 -> NaN for edgeless rows, as gatconv.py:139
+#pragma unroll
+                    for (int i = 0; i < EPV; ++i) {
+                        float v = acc[i] * inv;
+                        if (a.apply_elu) v = v > 0.0f ? v : (BF ? __expf(v) - 1.0f : expm1f(v));
+                        acc[i] = v;
+                    }
+                }
+                VecIO<YT, EPV>::store(yrow, acc);
+            }
+            // the per-(row, head) scalars are written after every lane has read the previous launch's denominator
+            __builtin_amdgcn_wave_barrier();
+            if (slot == 0 && col_ok && hs == 0) {
+                a.out_a[row * a.heads + head] = den;
+            }
+        }
+    }
+    if constexpr (KIND == 1) {
+        const float ds = head_sum_c<LPH>(slot_sum<LPR>(sa)) + dd * slot_sum<LPR>(sb);
+        if (slot == 0 && col_ok && hs == 0) {
+            if (it.chunk >= 0) a.ws[it.chunk * a.ws_ld + a.ws_vec + head] = ds;
+            else a.out_a[row * a.heads + head] = (a.accumulate ? a.out_a[row * a.heads + head] : 0.0f) + ds;
+        }
+    }
+    if constexpr (KIND == 2) {
+#pragma unroll
+        for (int i = 0; i < EPV; ++i) acc[i] = slot_sum<LPR>(acc[i]);
+        const float dt = head_sum_c<LPH>(slot_sum<LPR>(sa)) + slot_sum<LPR>(sb);
+        if (slot == 0 && col_ok) {
+            if (it.chunk >= 0) {
+                float* wsp = a.ws + it.chunk * a.ws_ld;
+#pragma unroll
+                for (int i = 0; i < EPV; ++i) wsp[c0 + i] = acc[i];
+                if (hs == 0) wsp[a.ws_vec + head] = dt;
+            } else {
+                VecIO<YT, EPV>::store(static_cast<YT*>(a.Y) + row * a.ldy + c0, acc);
+                if (hs == 0) a.out_a[row * a.heads + head] = dt;
+            }
+        }
+    }
+   }
+    it = nx;
+    col_first = col_next_item;
+  }
+}
+
+// ---- dispatch: (lanes per row, heads per wavefront) pairs with 1 <= LPR / NH ------------------------------------------------
+template <typename XT, typename YT, int EPV, int LPR, int KIND>
+static bool gat2_launch_nh(const EdgeArgs& a, int nh, dim3 grid, hipStream_t s) {
+#define DGLL_GAT2(NHV) hipLaunchKernelGGL((gat2_kernel<XT, YT, EPV, LPR, NHV, 4, KIND>), grid, dim3(kBlock), 0, s, a); return true
+    switch (nh) {
+        case 1: DGLL_GAT2(1);
+        case 2: DGLL_GAT2(2);
+        case 4: DGLL_GAT2(4);
+        case 8: if constexpr (LPR >= 8) { DGLL_GAT2(8); } return false;
+        default: return false;
+    }
+#undef DGLL_GAT2
+}
+
+template <typename XT, typename YT, int EPV, int KIND>
+static bool gat2_launch_lpr(const EdgeArgs& a, int lpr, int nh, dim3 grid, hipStream_t s) {
+    switch (lpr) {
+        case 4: return gat2_launch_nh<XT, YT, EPV, 4, KIND>(a, nh, grid, s);
+        case 8: return gat2_launch_nh<XT, YT, EPV, 8, KIND>(a, nh, grid, s);
+        case 16: return gat2_launch_nh<XT, YT, EPV, 16, KIND>(a, nh, grid, s);
+        case 32: return gat2_launch_nh<XT, YT, EPV, 32, KIND>(a, nh, grid, s);
+        case 64: return gat2_launch_nh<XT, YT, EPV, 64, KIND>(a, nh, grid, s);
+        default: return false;
+    }
+}
+
+template <int KIND>
+static bool gat2_launch_kind(int dtype, int lpr, int nh, dim3 grid, hipStream_t s, const EdgeArgs& a) {
+    if (dtype == DGLL_F32) return gat2_launch_lpr<float, float, 4, KIND>(a, lpr, nh, grid, s);
+    return gat2_launch_lpr<bf16_t, bf16_t, 8, KIND>(a, lpr, nh, grid, s);
+}
+
+}  // namespace dgll

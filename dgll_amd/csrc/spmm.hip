@@ -618,7 +618,7 @@ DGLL_API int dgll_hip_csr_plan_create(void* stream, const int64_t* rowptr, int64
 }
 
 extern int g_tune_mfma_kperm;   // dense.hip
-extern int g_tune_gat_unroll;   // edge.hip
+extern int g_tune_gat_gen;      // edge.hip
 
 DGLL_API int dgll_hip_debug_tune(int key, int value) {
     switch (key) {
@@ -628,7 +628,8 @@ DGLL_API int dgll_hip_debug_tune(int key, int value) {
         case 3: g_tune_threshold = value; break;
         case 4: g_tune_mfma_kperm = value; break;
         case 5: g_tune_rowslot = value; break;
-        case 7: g_tune_gat_unroll = value; break;
+        case 7: break;                              // (retired: unroll depth of the first-generation GAT backward passes)
+        case 9: g_tune_gat_gen = value; break;
         default: set_error("unknown tuning key"); return DGLL_ERR_INVALID;
     }
     return DGLL_OK;

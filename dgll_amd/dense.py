@@ -280,9 +280,18 @@ class _SkinnyLinear(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, wd = ctx.saved_tensors
-        gd = g.to(x.dtype).contiguous()
+        n = g.shape[1]
+        if n % 8 and _mfma_ok(x) and x.shape[0] >= 64 * _SLABS:
+            # a handful of columns: rows of 2 * heads bf16 are not 16-byte aligned.  Zero-padded to 8 columns both products
+            # run on the MFMA kernels (the extra [M, 8] matrix is noise next to x) instead of library GEMMs
+            pad = -n % 8
+            gd = torch.zeros((g.shape[0], n + pad), dtype=x.dtype, device=g.device)
+            gd[:, :n] = g
+            wd = torch.nn.functional.pad(wd, (0, pad))
+        else:
+            gd = g.to(x.dtype).contiguous()
         gx = input_grad(gd, wd) if ctx.needs_input_grad[0] else None
-        gw = grad_weight(x, gd) if ctx.needs_input_grad[1] else None
+        gw = grad_weight(x, gd)[:, :n] if ctx.needs_input_grad[1] else None
         return gx, gw
 
 

@@ -27,13 +27,6 @@ from ...graph import CSRGraph, as_csr_graph
 _CHECK_NAN = os.environ.get("DGLL_CHECK_NAN", "0") == "1"
 
 
-def _pad_heads(h, heads, fo, fo_pad):
-    """[N, heads*fo] -> [N, heads*fo_pad] with zero columns appended to every head."""
-    if fo_pad == fo:
-        return h
-    return F.nn.functional.pad(h.view(h.shape[0], heads, fo), (0, fo_pad - fo)).reshape(h.shape[0], heads * fo_pad)
-
-
 def _unpad_heads(out, heads, fo, fo_pad):
     if fo_pad == fo:
         return out
@@ -51,19 +44,29 @@ def _fused_heads(x, adj, Ws, a1s, a2s, alpha, concat, mode, dropout, training):
     """Shared GPU path: Ws [heads][Fin, fo], a1s/a2s [heads][fo] -> [N, heads*fo]."""
     heads, fo = len(Ws), Ws[0].shape[1]
     graph = as_csr_graph(adj)
+    edge_scale = _attention_dropout(graph, heads, dropout, training, x.device)
+    # sparseGatConv's form without attention dropout runs on the second-generation kernels: any per-head width that is a
+    # whole number of 16-byte vectors; the max-subtracted / dropout forms need a power of two of them
+    strided = mode == 0 and edge_scale is None
+    fo_pad = ops.head_width_padded(fo, x.dtype, pow2=not strided)
+    # The per-head padding is applied to the WEIGHTS (a [Fin, heads*fo_pad] matrix with zero columns), not to the activations:
+    # the transform then writes the padded layout directly, with exact zeros, and no [N, heads*fo] matrix is copied.
+    if fo_pad != fo:
+        Ws = [F.nn.functional.pad(W, (0, fo_pad - fo)) for W in Ws]
     W = (Ws[0] if heads == 1 else F.cat(Ws, dim=1))
     h = dense.linear(x, W)                                                     # gatconv.py:31,117 for every head at once
-    # per-node scores for every head as ONE skinny GEMM: [N, heads*fo] . blockdiag(a1_k | a2_k) -> [N, 2*heads]
+    # per-node scores for every head as ONE skinny GEMM: [N, heads*fo_pad] . blockdiag(a1_k | a2_k) -> [N, 2*heads]
     # (the reference forms a[:fo].h_i + a[fo:].h_j per edge from a materialised [2*fo, E] matrix, gatconv.py:122-125)
-    A = h.new_zeros(heads * fo, 2 * heads)
+    A = h.new_zeros(heads * fo_pad, 2 * heads)
     for k in range(heads):
-        A[k * fo:(k + 1) * fo, k] = a1s[k].to(h.dtype)
-        A[k * fo:(k + 1) * fo, heads + k] = a2s[k].to(h.dtype)
+        A[k * fo_pad:k * fo_pad + fo, k] = a1s[k].to(h.dtype)
+        A[k * fo_pad:k * fo_pad + fo, heads + k] = a2s[k].to(h.dtype)
     st = dense.skinny_linear(h, A)                                             # fp32 [N, 2*heads]
     s, t = st[:, :heads], st[:, heads:]
-    fo_pad = ops.head_width_padded(fo, h.dtype)
-    out = ops.gat_aggregate(graph, _pad_heads(h, heads, fo, fo_pad), s, t, heads, alpha, apply_elu=concat, mode=mode,
-                            edge_scale=_attention_dropout(graph, heads, dropout, training, h.device))
+    # h is this function's own temporary (dense.linear allocates narrow rows on 128-byte lines): its row padding may carry
+    # the per-node scores the gather passes fetch per edge
+    out = ops.gat_aggregate(graph, h, s, t, heads, alpha, apply_elu=concat, mode=mode, edge_scale=edge_scale,
+                            pack_scores=strided)
     out = _unpad_heads(out, heads, fo, fo_pad)
     if _CHECK_NAN:
         assert not F.isnan(out).any()
@@ -228,7 +231,13 @@ class _MultiHead(F.nn.Module):
         x = _heads(x, adj, [att.W for att in self.attentions], [h[0] for h in halves], [h[1] for h in halves],
                    first.alpha, True, self.mode, self.dropout, self.training)
         x = F.dropout(x, self.dropout, training=self.training)
-        x = F.elu(self.out_att(x, adj))
+        if x.is_cuda:       # elu(out_att(x)): the ELU (and its backward) ride in the aggregation kernel's epilogue
+            out = self.out_att
+            a1, a2 = out._split_a()
+            x = _heads(x, adj, [out.W], [a1], [a2], out.alpha, True, self.mode,
+                       out.dropout if isinstance(out.dropout, float) else out.dropout.p, self.training)
+        else:
+            x = F.elu(self.out_att(x, adj))
         return F.log_softmax(x, dim=1)
 
 

@@ -112,14 +112,129 @@ def segment_max(graph, x):
 
 
 # ------------------------------------------------------------------------------------------------ fused GAT
-def head_width_padded(fo, dtype):
-    """Per-head column count the kernels need: a power-of-two number of 16-byte vectors."""
+def head_width_padded(fo, dtype, pow2=True):
+    """Per-head column count the kernels need: a whole number of 16-byte vectors -- a power of two of them for the
+    first-generation kernels (max-subtracted softmax, attention dropout), any number for sparseGatConv's form."""
     epv = _epv(dtype)
     vecs = -(-fo // epv)
+    if not pow2:
+        return vecs * epv
     p = 1
     while p < vecs:
         p <<= 1
     return p * epv
+
+
+def _row_slot(x, byte_off, n_floats):
+    """fp32 [rows, n_floats] alias of the bytes [byte_off, byte_off + 4 n_floats) of every row of `x`'s storage -- a slot in
+    the padding between a row's last column and the next row (the caller owns that padding)."""
+    esz = x.element_size()
+    base, stride = x.storage_offset() * esz + byte_off, x.stride(0) * esz
+    if base % 4 or stride % 4 or byte_off + 4 * n_floats > stride:
+        raise ValueError("no room for a %d-float slot at byte %d of %d-byte rows" % (n_floats, byte_off, stride))
+    return torch.empty(0, dtype=torch.float32, device=x.device).set_(x.untyped_storage(), base // 4, (x.shape[0], n_floats),
+                                                                    (stride // 4, 1))
+
+
+def _empty_like_rows(n, like):
+    """[n, like.shape[1]] with `like`'s row stride (the same padding behind every row)."""
+    buf = torch.empty((n, like.stride(0)), dtype=like.dtype, device=like.device)
+    return buf[:, :like.shape[1]] if like.stride(0) != like.shape[1] else buf
+
+
+class _GatAggregateStrided(torch.autograd.Function):
+    """sparseGatConv's form (exp(-leakyrelu), no attention dropout) on the second-generation kernels
+    (dgll_hip_gat_fwd_strided / _bwd_strided).  These passes are bound by cache-line fills per edge, so per-node scalars that
+    are gathered per edge live next to what is gathered anyway: with `pack_scores` (the caller owns the padding behind h's
+    rows) T sits in the padding of the feature rows -- a 47-class output row is 96 of 128 bytes -- and the backward keeps
+    {s_i, dd_i} in the padding of its DN rows; without room they are compact / side-by-side arrays."""
+
+    @staticmethod
+    def forward(ctx, h, s, t, graph, heads, fo, alpha, apply_elu, pack_scores):
+        _require_cuda(h, s, t, graph.rowptr)
+        dev = h.device
+        h = _ready(h)
+        esz, width = h.element_size(), heads * fo
+        s = s.to(torch.float32).contiguous()
+        t = t.to(torch.float32).contiguous()
+        packed = bool(pack_scores) and (h.stride(0) - width) * esz >= 4 * heads
+        if packed:
+            t_gather = _row_slot(h, width * esz, heads)
+            t_gather.copy_(t)
+        else:
+            t_gather = t
+        out = _empty_like_rows(graph.n_rows, h)
+        rowsum = torch.empty((graph.n_rows, heads), dtype=torch.float32, device=dev)
+        plan = graph.plan()
+        ws_bytes = int(_lib.lib.dgll_hip_gat_workspace_bytes(plan, heads, fo))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
+        timer = _launch_timer()
+        end = timer.start(("gat", "fwd", heads, fo, str(h.dtype), graph.nnz, "packed" if packed else ""), dev) if timer else None
+        with torch.cuda.device(dev):
+            code = _lib.lib.dgll_hip_gat_fwd_strided(
+                _stream(dev), plan, graph.rowptr.data_ptr(), graph.col.data_ptr(), h.data_ptr(), h.stride(0), s.data_ptr(),
+                t_gather.data_ptr(), t_gather.stride(0), out.data_ptr(), out.stride(0), _dtype_code(h), rowsum.data_ptr(),
+                graph.n_rows, heads, fo, float(alpha), int(apply_elu), ws.data_ptr() if ws is not None else None, ws_bytes)
+        if end is not None:
+            end.record(torch.cuda.current_stream(dev))
+        _lib.check(code, "dgll_hip_gat_fwd_strided")
+        ctx.graph, ctx.cfg, ctx.packed = graph, (heads, fo, float(alpha), int(apply_elu)), packed
+        ctx.save_for_backward(h, s, t, out, rowsum)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        h, s, t, out, rowsum = ctx.saved_tensors
+        graph = ctx.graph
+        heads, fo, alpha, apply_elu = ctx.cfg
+        dev, esz, width = h.device, h.element_size(), heads * fo
+        g = _ready(g.to(h.dtype))
+        gt, _ = graph.transpose()
+        dn = _empty_like_rows(graph.n_rows, h)
+        if ctx.packed:
+            t_gather = _row_slot(h, width * esz, heads)          # written by the forward; h's padding is ours
+        else:
+            t_gather = t
+        if ctx.packed and (dn.stride(0) - width) * esz >= 8 * heads:
+            sd = _row_slot(dn, width * esz, 2 * heads)
+        else:
+            sd = torch.empty((graph.n_rows, 2 * heads), dtype=torch.float32, device=dev)
+        grad_h = _empty_like_rows(graph.n_cols, h)
+        grad_s = torch.empty((graph.n_rows, heads), dtype=torch.float32, device=dev)
+        grad_t = torch.empty((graph.n_cols, heads), dtype=torch.float32, device=dev)
+        plan, t_plan = graph.plan(), gt.plan()
+        ws_bytes = max(int(_lib.lib.dgll_hip_gat_workspace_bytes(plan, heads, fo)),
+                       int(_lib.lib.dgll_hip_gat_workspace_bytes(t_plan, heads, fo)))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
+        timer = _launch_timer()
+        tag = (heads, fo, str(h.dtype), graph.nnz, "packed" if ctx.packed else "")
+        wsp = ws.data_ptr() if ws is not None else None
+        with torch.cuda.device(dev):
+            st = _stream(dev)
+            end = timer.start(("gat", "bwd_rows") + tag, dev) if timer else None
+            code = _lib.lib.dgll_hip_gat_bwd_rows_strided(
+                st, plan, graph.rowptr.data_ptr(), graph.col.data_ptr(), h.data_ptr(), h.stride(0), s.data_ptr(),
+                t_gather.data_ptr(), t_gather.stride(0), out.data_ptr(), out.stride(0), g.data_ptr(), g.stride(0), _dtype_code(h),
+                rowsum.data_ptr(), dn.data_ptr(), dn.stride(0), sd.data_ptr(), sd.stride(0), grad_s.data_ptr(), graph.n_rows,
+                heads, fo, alpha, apply_elu, wsp, ws_bytes)
+            if end is not None:
+                end.record(torch.cuda.current_stream(dev))
+            _lib.check(code, "dgll_hip_gat_bwd_rows_strided")
+            end = timer.start(("gat", "bwd_cols") + tag, dev) if timer else None
+            code = _lib.lib.dgll_hip_gat_bwd_cols_strided(
+                st, t_plan, gt.rowptr.data_ptr(), gt.col.data_ptr(), dn.data_ptr(), dn.stride(0), h.data_ptr(), h.stride(0),
+                t.data_ptr(), sd.data_ptr(), sd.stride(0), grad_h.data_ptr(), grad_h.stride(0), grad_t.data_ptr(), _dtype_code(h),
+                graph.n_cols, heads, fo, alpha, wsp, ws_bytes)
+            if end is not None:
+                end.record(torch.cuda.current_stream(dev))
+            _lib.check(code, "dgll_hip_gat_bwd_cols_strided")
+        return grad_h, grad_s, grad_t, None, None, None, None, None, None
+
+
+def _launch_timer():
+    from .ops import LaunchTimer
+
+    return LaunchTimer.active
 
 
 class _GatAggregate(torch.autograd.Function):
@@ -181,14 +296,19 @@ class _GatAggregate(torch.autograd.Function):
         return grad_h, grad_s, grad_t, None, None, None, None, None, None, None
 
 
-def gat_aggregate(graph, h, s, t, heads, alpha, apply_elu=True, mode=0, edge_scale=None):
-    """Fused multi-head edge-softmax + aggregation.  h: [N, heads*fo] with fo already padded per
-    `head_width_padded`; s, t: [N, heads]."""
+def gat_aggregate(graph, h, s, t, heads, alpha, apply_elu=True, mode=0, edge_scale=None, pack_scores=False):
+    """Fused multi-head edge-softmax + aggregation.  h: [N, heads*fo] with fo already padded per `head_width_padded`
+    (pow2=False suffices for mode 0 without edge_scale); s, t: [N, heads].  pack_scores: the caller owns the padding behind
+    h's rows (h.stride(0) > h.shape[1]) and lets the kernels keep per-node scores there."""
     if not isinstance(graph, CSRGraph):
         raise TypeError("gat_aggregate expects a CSRGraph")
     fo = h.shape[1] // heads
-    if fo * heads != h.shape[1] or head_width_padded(fo, h.dtype) != fo:
-        raise ValueError("per-head width %d is not padded for the kernels (need %d)" % (fo, head_width_padded(fo, h.dtype)))
+    strided = mode == 0 and edge_scale is None
+    if fo * heads != h.shape[1] or head_width_padded(fo, h.dtype, pow2=not strided) != fo:
+        raise ValueError("per-head width %d is not padded for the kernels (need %d)"
+                         % (fo, head_width_padded(fo, h.dtype, pow2=not strided)))
+    if strided:
+        return _GatAggregateStrided.apply(h, s, t, graph, heads, fo, alpha, apply_elu, pack_scores)
     return _GatAggregate.apply(h, s, t, edge_scale, graph, heads, fo, alpha, apply_elu, mode)
 
 

@@ -170,6 +170,43 @@ int dgll_hip_gat_bwd_cols(void* stream, const dgll_csr_plan* t_plan, const int64
                           const float* edge_scale, void* grad_H, int64_t ldgh, float* grad_T, int dtype,
                           int64_t n_rows_t, int heads, int fo, float alpha, int mode, void* workspace, size_t workspace_bytes);
 
+/* sparseGatConv's form (mode 0, no attention dropout) with STRIDED score arrays -- the layout the gather passes are
+ * fastest with.  These passes are bound by cache-line fills per edge: four for a 512-byte feature row plus one for every
+ * separate per-node array gathered per edge.  So:
+ *   T           is read at T[j * t_stride + head]: a compact [n_cols, heads] array (t_stride = heads), or a slot in the
+ *               PADDING of the H rows themselves (a 47-class output row is 94 of 128 bytes: T = (float*)((char*)H + 96),
+ *               t_stride = ldh * elem_size / 4) -- the score then shares the row's cache line and costs nothing;
+ *   sd_scratch  fp32 scratch, sd_stride floats per destination row (>= 2 * heads): the rows pass leaves
+ *               {s_i[0:heads], dd_i[0:heads]} side by side there and the transposed pass gathers both with ONE line fill
+ *               -- a separate [n_rows, 2 * heads] buffer or a slot in the padding of the dn_scratch rows;
+ *   T_rows      the compact [n_cols, heads] T for the row side of the transposed pass.
+ * `fo` (per-head width) may be any multiple of the 16-byte vector (8 bf16 / 4 fp32 elements): a head that does not fill its
+ * power-of-two lane group leaves lanes idle, no columns are padded.  Gradients w.r.t. H, S, T as dgll_hip_gat_bwd.      */
+int dgll_hip_gat_fwd_strided(void* stream, const dgll_csr_plan* plan, const int64_t* rowptr, const int32_t* col,
+                             const void* H, int64_t ldh, const float* S, const float* T, int t_stride, void* out,
+                             int64_t ldo, int dtype, float* rowsum, int64_t n_rows, int heads, int fo, float alpha,
+                             int apply_elu, void* workspace, size_t workspace_bytes);
+/* the two passes of dgll_hip_gat_bwd_strided one by one (rows of A: DN, {s, dd}, grad_S; then rows of A^T: grad_H, grad_T) */
+int dgll_hip_gat_bwd_rows_strided(void* stream, const dgll_csr_plan* plan, const int64_t* rowptr, const int32_t* col,
+                                  const void* H, int64_t ldh, const float* S, const float* T, int t_stride,
+                                  const void* out, int64_t ldo, const void* grad_out, int64_t ldg, int dtype,
+                                  const float* rowsum, void* dn_scratch, int64_t ldn, float* sd_scratch, int sd_stride,
+                                  float* grad_S, int64_t n_rows, int heads, int fo, float alpha, int apply_elu,
+                                  void* workspace, size_t workspace_bytes);
+int dgll_hip_gat_bwd_cols_strided(void* stream, const dgll_csr_plan* t_plan, const int64_t* t_rowptr,
+                                  const int32_t* t_col, const void* dn_scratch, int64_t ldn, const void* H,
+                                  int64_t ldh, const float* T_rows, const float* sd_scratch, int sd_stride,
+                                  void* grad_H, int64_t ldgh, float* grad_T, int dtype, int64_t n_cols, int heads,
+                                  int fo, float alpha, void* workspace, size_t workspace_bytes);
+int dgll_hip_gat_bwd_strided(void* stream, const dgll_csr_plan* plan, const dgll_csr_plan* t_plan,
+                             const int64_t* rowptr, const int32_t* col, const int64_t* t_rowptr, const int32_t* t_col,
+                             const void* H, int64_t ldh, const float* S, const float* T, int t_stride,
+                             const float* T_rows, const void* out, int64_t ldo, const void* grad_out, int64_t ldg,
+                             int dtype, const float* rowsum, void* dn_scratch, int64_t ldn, float* sd_scratch,
+                             int sd_stride, void* grad_H, int64_t ldgh, float* grad_S, float* grad_T, int64_t n_rows,
+                             int64_t n_cols, int heads, int fo, float alpha, int apply_elu, void* workspace,
+                             size_t workspace_bytes);
+
 /* ---- a3 (max): Y[i,f] = max_k X[col[k], f], arg[i,f] = the source row holding it (-1 / 0.0 for empty rows) --
  * NeighborAggregator's "max" (sageconv.py:37-38).  Y and arg share the leading dimension ldy; X/Y 16-byte
  * aligned with padded leading dimensions.                                                                   */

@@ -2,9 +2,9 @@
 # rocprofv3 evidence for bench.py's roofline, collected on THE SAME command bench.py's default run uses (same build,
 # same graph, same kernels): one --kernel-trace --stats pass (per-kernel durations) and one --pmc pass per counter
 # group (kernel-trace only, as gpurun requires; FETCH_SIZE and WRITE_SIZE cannot share a pass -- TCC has 4 slots).
-#   usage (on the GPU box, from the repo root):  bash tools/pmc_bench.sh <tag> [bench.py args...]
+#   usage (on the GPU box, from the repo root):  bash tools/pmc_bench.sh <tag> [bench.py args, e.g. --workload gat]
 # writes gpurun_out/<tag>/{kernel_stats.csv, bench_under_rocprof.json, pmc_<group>.csv}; tools/pmc_parse.py turns the
-# counter files into profiles/traffic.json entries.
+# counter files into profiles/traffic.json entries (stamped with the build they were collected on).
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=${1:-pmc}
@@ -16,7 +16,7 @@ cd /tmp
 BENCH_ARGS="--steps 3 --warmup 2 --no-cpu-baseline --calibrate $*"
 rm -rf /tmp/kt_$TAG
 # the kernel-trace pass runs bench.py's default timed region only (no calibration launches, no extra graphs), so that the
-# AverageNs of each spmm_csr_kernel instantiation is directly the figure bench.py's HIP events report for that launch kind
+# AverageNs of each kernel instantiation is directly the figure bench.py's HIP events report for that launch kind
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$TAG -o p -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra-graphs $* > $OUT/bench_under_rocprof.json 2> $OUT/kernel_trace.log
 f=$(find /tmp/kt_$TAG -name '*kernel_stats.csv' | head -1)
 [ -n "$f" ] && cp $f $OUT/kernel_stats.csv
@@ -25,6 +25,6 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
   rm -rf /tmp/pmc_${TAG}_$tag
   rocprofv3 --kernel-trace --pmc $grp --output-format csv -d /tmp/pmc_${TAG}_$tag -o p -- python3 $R/bench.py $BENCH_ARGS --no-extra-graphs > $OUT/pmc_$tag.json 2> $OUT/pmc_$tag.log
   f=$(find /tmp/pmc_${TAG}_$tag -name '*counter_collection.csv' | head -1)
-  [ -n "$f" ] && grep -E "Counter_Name|spmm_csr_kernel|spmm_long_finalize|gemm_bf16|gradw_" $f > $OUT/pmc_$tag.csv
+  [ -n "$f" ] && grep -E "Counter_Name|spmm_csr_kernel|spmm_rowslot|spmm_long_finalize|gat2_kernel|gat_long_finalize|gat_fwd_kernel|gat_bwd|gemm_bf16|gradw_" $f > $OUT/pmc_$tag.csv
 done
 ls -la $OUT

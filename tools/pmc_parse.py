@@ -1,28 +1,28 @@
 #!/usr/bin/env python3
 """Turn the counter files of tools/pmc_bench.sh into profiles/traffic.json entries.
 
-    python tools/pmc_parse.py gpurun_out/<tag> [--round r02] [--write]
+    python tools/pmc_parse.py gpurun_out/<tag> [--round r03] [--write]
 
-Per kernel name: mean FETCH_SIZE / WRITE_SIZE (KiB) over the launches of the timed + warm-up steps, skipping the first
-step (cold caches) -- except for the three calibration launches (identity gather, `--calibrate`: the FIRST three launches
-of the F = hidden unweighted kernel), which give the gfx950 FETCH_SIZE correction on a known byte count in the kernel's
-own access pattern (MI355X_MICROARCH.md, HBM section: FETCH_SIZE reports 1/2 of a wide coalesced read).
-hbm_bytes = FETCH_SIZE_KiB * 1024 * correction + WRITE_SIZE_KiB * 1024.
+Per launch kind of bench.py's `spmm_launch_table` (matched to a kernel by its `kernel_fragment`): mean FETCH_SIZE / WRITE_SIZE
+(KiB) over the launches of the timed + warm-up steps, skipping the first step (cold caches).  The three calibration launches
+(`bench.py --calibrate`: an identity gather with KNOWN bytes, the FIRST three launches of the unweighted hidden-width SpMM
+kernel) give the correction ratios of this very pass (MI355X_MICROARCH.md, HBM section: FETCH_SIZE reports about 1/2 of a wide
+coalesced read on gfx950 -- the measured ratio is applied, not a flat 2):
+    hbm_bytes = FETCH_SIZE_KiB * 1024 / ratio_read + WRITE_SIZE_KiB * 1024 / ratio_write.
+Every entry carries the build stamp of the libdgll_hip.so the pass ran (bench.py prints it in roofline.build_stamp); bench.py
+uses an entry only when workload, kernel AND stamp match.
 """
 import argparse
 import csv
 import json
 import os
 import sys
-from collections import OrderedDict, defaultdict
+from collections import OrderedDict
 
 
 def read(path):
-    rows = []
     with open(path) as f:
-        for r in csv.DictReader(f):
-            rows.append(r)
-    return rows
+        return list(csv.DictReader(f))
 
 
 def per_kernel(rows, counter):
@@ -40,7 +40,7 @@ def per_kernel(rows, counter):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("dir")
-    ap.add_argument("--round", default="r02")
+    ap.add_argument("--round", default="r03")
     ap.add_argument("--write", action="store_true", help="merge the entries into profiles/traffic.json")
     args = ap.parse_args()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -58,6 +58,7 @@ def main():
     if not bench:
         sys.exit("no bench JSON line found in " + args.dir)
     cfg = bench["config"]
+    stamp = (bench.get("roofline") or {}).get("build_stamp")
     n, hidden = cfg["nodes"], cfg["hidden"]
     esz = 2 if bench["dtype"] == "bf16" else 4
     fetch = per_kernel(read(os.path.join(args.dir, "pmc_FETCH_SIZE.csv")), "FETCH_SIZE")
@@ -68,24 +69,33 @@ def main():
         hit, miss = per_kernel(rows, "TCC_HIT_sum"), per_kernel(rows, "TCC_MISS_sum")
     except OSError:
         pass
-    # calibration: the first three launches of the unweighted F = hidden kernel read n*hidden*esz + n*12 bytes (rows,
+    # calibration: the first three launches of the unweighted F = hidden SpMM kernel read n*hidden*esz + n*12 bytes (rows,
     # rowptr, col) and write n*hidden*esz
-    calib_kernel = next((k for k in fetch if "spmm_csr_kernel" in k and ", false, 4, false>" in k and ", 32," in k), None)
-    correction, calib = 2.0, None
+    t = "unsigned short" if esz == 2 else "float"
+    calib_frag = "spmm_csr_kernel<%s, %s, %d, 32, false, 4, false>" % (t, t, 16 // esz)
+    calib_kernel = next((k for k in fetch if calib_frag in k), None)
+    ratio_r, ratio_w, calib = 0.5, 1.0, None
     if calib_kernel and len(fetch[calib_kernel]) >= 3:
         known_r = n * hidden * esz + n * 12
         known_w = n * hidden * esz
         fr = sum(v for _, v, _ in fetch[calib_kernel][:3]) / 3 * 1024
         wr = sum(v for _, v, _ in write[calib_kernel][:3]) / 3 * 1024
-        calib = {"kernel": calib_kernel, "known_read_bytes": known_r, "reported_fetch_bytes": fr, "ratio_read": fr / known_r,
-                 "known_write_bytes": known_w, "reported_write_bytes": wr, "ratio_write": wr / known_w}
-        print("calibration: FETCH_SIZE reports %.3f of the known read, WRITE_SIZE %.3f of the known write" % (fr / known_r, wr / known_w))
+        ratio_r, ratio_w = fr / known_r, wr / known_w
+        calib = {"kernel": calib_kernel, "known_read_bytes": known_r, "reported_fetch_bytes": fr, "ratio_read": ratio_r,
+                 "known_write_bytes": known_w, "reported_write_bytes": wr, "ratio_write": ratio_w}
+        print("calibration: FETCH_SIZE reports %.3f of the known read, WRITE_SIZE %.3f of the known write" % (ratio_r, ratio_w))
+    else:
+        print("NO calibration launches found: falling back to ratio_read 0.5 / ratio_write 1.0")
+    sig = {"workload": cfg.get("workload_id", "sage"), "nodes": n, "nnz": cfg["nnz"], "locality": cfg["locality"],
+           "permuted_ids": cfg["permuted_ids"], "reorder": cfg["reorder"], "hidden": hidden, "dtype": bench["dtype"]}
+    if "heads" in cfg:
+        sig["heads"] = cfg["heads"]
     entries = []
-    sig = {"nodes": n, "nnz": cfg["nnz"], "locality": cfg["locality"], "permuted_ids": cfg["permuted_ids"],
-           "reorder": cfg["reorder"], "hidden": hidden, "dtype": bench["dtype"]}
-    table = bench["spmm_launch_table"]
-    for kname in fetch:
-        if "spmm_csr_kernel" not in kname:
+    for name, v in bench["spmm_launch_table"].items():
+        frag = v.get("kernel_fragment")
+        kname = next((k for k in fetch if frag and frag in k), None)
+        if kname is None:
+            print("no counter rows for %s (%s)" % (name, frag))
             continue
         skip = 3 if kname == calib_kernel and calib else 0
         fl, wl = fetch[kname][skip:], write.get(kname, [])[skip:]
@@ -93,33 +103,19 @@ def main():
         fl, wl = fl[per_step:], wl[per_step:]          # drop the first (cold) step
         if not fl or not wl:
             continue
-        fk = sum(v for _, v, _ in fl) / len(fl)
-        wk = sum(v for _, v, _ in wl) / len(wl)
+        fk = sum(x for _, x, _ in fl) / len(fl)
+        wk = sum(x for _, x, _ in wl) / len(wl)
         ns = sum(d for _, _, d in fl) / len(fl)
-        weighted = ", true, 4," in kname
-        extra = kname.rstrip().endswith("true>(dgll::SpmmArgs)")
-        lpr = int(kname.split("<")[1].split(",")[3])
-        e = {"round": args.round, "kernel_name": kname, "workload": sig, "weighted": weighted, "lanes_per_row": lpr,
-             "launches_averaged": len(fl), "fetch_size_kib": fk, "write_size_kib": wk, "fetch_correction": correction,
-             "hbm_bytes_per_launch": int(fk * 1024 * correction + wk * 1024), "avg_ns_under_pmc": ns}
+        e = {"round": args.round, "kernel_name": kname, "kernel_fragment": frag, "launch": name, "workload": sig, "build_stamp": stamp,
+             "launches_averaged": len(fl), "fetch_size_kib": fk, "write_size_kib": wk, "ratio_read": ratio_r, "ratio_write": ratio_w,
+             "hbm_bytes_per_launch": int(fk * 1024 / ratio_r + wk * 1024 / ratio_w), "avg_ns_under_pmc": ns,
+             "algorithmic_bytes_per_launch": v["algorithmic_bytes"]}
         if kname in hit and kname in miss:
-            h = sum(v for _, v, _ in hit[kname][skip:][per_step:])
-            m = sum(v for _, v, _ in miss[kname][skip:][per_step:])
+            h = sum(x for _, x, _ in hit[kname][skip:][per_step:])
+            m = sum(x for _, x, _ in miss[kname][skip:][per_step:])
             e["l2_hit_rate"] = h / max(h + m, 1)
-        # match to bench's launch table: width from lanes-per-row (F = hidden -> 32 lanes of 8 bf16), weights, epilogue
-        for name, v in table.items():
-            vecs = -(-v["feat"] // (16 // esz))
-            l = 4
-            while l < 64 and l < vecs:
-                l <<= 1
-            if l == lpr and v["weighted"] == weighted and bool(v["epilogue"]) == extra:
-                e["feat"], e["epilogue"], e["launch"] = v["feat"], v["epilogue"], name
-                e["algorithmic_bytes_per_launch"] = v["algorithmic_bytes"]
-                break
         entries.append(e)
-        print("%-110s fetch %.0f KiB write %.0f KiB -> %.2f GB/launch (%s)" % (kname[:110], fk, wk, e["hbm_bytes_per_launch"] / 1e9, e.get("launch")))
-    out = {"calibration": calib, "entries": entries}
-    print(json.dumps(out)[:400] + " ...")
+        print("%-70s fetch %.0f KiB write %.0f KiB -> %.2f GB/launch, %.3f ms under PMC" % (name[:70], fk, wk, e["hbm_bytes_per_launch"] / 1e9, ns / 1e6))
     if args.write:
         path = os.path.join(root, "profiles", "traffic.json")
         try:
@@ -128,14 +124,15 @@ def main():
         except (OSError, ValueError):
             cur = {}
         keep = [e for e in cur.get("entries", []) if e.get("workload") != sig]
-        cur = {"_comment": "HBM-side traffic per launch from rocprofv3 --pmc passes over bench.py itself (tools/pmc_bench.sh, "
-                           "parsed by tools/pmc_parse.py); hbm_bytes = FETCH_SIZE KiB * 1024 * correction + WRITE_SIZE KiB * 1024; "
-                           "the correction (2.0) is checked per pass on the known-byte calibration launches (`calibrations`).",
-               "calibrations": [c for c in cur.get("calibrations", []) if c.get("workload") != sig] + ([dict(calib, workload=sig, round=args.round)] if calib else []),
+        cur = {"_comment": "HBM-side traffic per launch from rocprofv3 --pmc passes over bench.py itself (tools/pmc_bench.sh, parsed "
+                           "by tools/pmc_parse.py); hbm_bytes = FETCH_SIZE KiB * 1024 / ratio_read + WRITE_SIZE KiB * 1024 / ratio_write "
+                           "with the ratios calibrated in the same pass on known-byte launches (`calibrations`).  bench.py uses an "
+                           "entry only when workload, kernel_fragment AND build_stamp match the running build.",
+               "calibrations": [c for c in cur.get("calibrations", []) if c.get("workload") != sig] + ([dict(calib, workload=sig, round=args.round, build_stamp=stamp)] if calib else []),
                "entries": keep + entries}
         with open(path, "w") as f:
             json.dump(cur, f, indent=1)
-        print("wrote", path)
+        print("wrote", path, "(%d entries for this workload, build %s)" % (len(entries), (stamp or "?")[:12]))
 
 
 if __name__ == "__main__":
