@@ -990,15 +990,40 @@ def run_minibatch(args, c):
     timer_cm.__exit__(None, None, None)
     sampler_s = TimedSampler.seconds - s0
     gpu_ms = sum(a.elapsed_time(b_) for a, b_ in events) / max(len(events), 1)
-    table, dense_table = launch_tables(timer_cm.summary(), 0)
-    for v in table.values():           # blocks: rows differ per launch; the per-row term of the formula is left out (conservative)
-        v["note"] = "sampled blocks: algorithmic bytes count the per-edge term only"
+    # sampled blocks differ in size from batch to batch: launches are grouped by kind (width, dtype, weights), their edges and
+    # times summed; algorithmic bytes count the per-edge term only (the row counts of the blocks are not in the tags)
+    torch.cuda.synchronize()
+    groups, dense_groups = {}, {}
+    for tag, a_, b_ in timer_cm.records:
+        ms = a_.elapsed_time(b_)
+        if tag[0] == "spmm":
+            key = (tag[1], tag[2], bool(tag[3]), tag[5] if len(tag) > 5 else "")
+            g_ = groups.setdefault(key, [0, 0.0, 0])
+            g_[0] += 1; g_[1] += ms; g_[2] += tag[4]
+        elif tag[0] in ("transform", "transform_dual", "grad_weight"):
+            key = (tag[0], tag[2], tag[3], tag[4], tag[5])
+            g_ = dense_groups.setdefault(key, [0, 0.0, 0])
+            g_[0] += 1; g_[1] += ms; g_[2] += tag[1]
+    table, dense_table = {}, {}
+    for (feat, dt, weighted, extra), (cnt, ms, edges_) in groups.items():
+        xb = 2 if "bfloat16" in dt else 4
+        b_alg = edges_ * (feat * xb + 4 + (4 if weighted else 0))
+        table["spmm F=%d %s %s%s (all block sizes)" % (feat, dt.replace("torch.", ""), "weighted" if weighted else "unweighted",
+                                                      (" " + extra) if extra else "")] = {
+            "count": cnt, "total_ms": ms, "avg_ms": ms / cnt, "nnz": edges_ // cnt, "edges_total": edges_, "feat": feat,
+            "weighted": weighted, "epilogue": extra, "kernel_fragment": spmm_kernel_fragment(feat, dt, weighted, bool(extra)),
+            "algorithmic_bytes": b_alg // cnt, "algorithmic_GBps": b_alg / (ms * 1e-3) / 1e9,
+            "frac_algorithmic": b_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "G_edges_per_s": edges_ / (ms * 1e-3) / 1e9}
+    for (kind, k1, k2, n_out, extra), (cnt, ms, rows_) in dense_groups.items():
+        b_alg = rows_ * (k1 + k2 + n_out) * 2
+        dense_table["%s K=%d%s N=%d%s (all block sizes)" % (kind, k1, ("+%d" % k2) if k2 else "", n_out, (" " + extra) if extra else "")] = {
+            "count": cnt, "total_ms": ms, "avg_ms": ms / cnt, "rows_total": rows_, "algorithmic_GBps": b_alg / (ms * 1e-3) / 1e9}
     roofline = None
-    wide = {k: v for k, v in table.items() if v["feat"] in (args.hidden, args.mb_feats)}
-    if wide:
-        dom = wide[max(wide, key=lambda k: wide[k]["avg_ms"] * wide[k]["count"])]
+    if table:
+        dom = table[max(table, key=lambda k: table[k]["total_ms"])]
         roofline = roofline_record(dom, workload_signature(args, nnz_graph, nodes=args.mb_nodes, batch=args.mb_batch),
-                                   "the gather launch kind with the largest total time in the timed batches: %s" % dom["kernel_fragment"],
+                                   "the gather launch kind with the largest total time in the timed batches (%s), all block sizes pooled; "
+                                   "these launches are short (tens of microseconds): launch-bound, not bandwidth-bound" % dom["kernel_fragment"],
                                    None, 1)
     steps = len(events)
     args.steps = steps
@@ -1010,7 +1035,7 @@ def run_minibatch(args, c):
                                 args.mb_fanouts, int(args.mb_cache_frac * 100)),
         {"nodes": args.mb_nodes, "nnz": nnz_graph, "hidden": args.hidden, "batch": args.mb_batch, "fanouts": fanouts,
          "cache_fraction": args.mb_cache_frac, "parallelism": "single GPU"})
-    result.update({"loss": float(loss), "batches_per_s": steps / elapsed, "gpu_side_ms_per_batch": gpu_ms,
+    result.update({"loss": float(loss.detach()), "batches_per_s": steps / elapsed, "gpu_side_ms_per_batch": gpu_ms,
                    "host_sampler_ms_per_batch": sampler_s / max(steps, 1) * 1e3, "cache_miss_rate": cache.get_miss_rate(),
                    "epoch_time_s_153431_train_nodes": elapsed / steps * (153_431 / args.mb_batch),
                    "roofline": roofline, "spmm_launch_table": table, "dense_launch_table": dense_table})

@@ -84,22 +84,42 @@ class GraphCacheServer:
         self.cache_fix_data(nids, self.get_feat_from_server(nids), is_full=False)
 
     def record_access(self, nids, stream=None):
-        """Accumulate how often every node is fetched (device-side, no host sync) for `refresh_from_access`."""
+        """Accumulate how often every node is fetched (device-side, no host sync) for `refresh_from_access`.  The counter
+        vector is shared between the stream that records (the pipeline's loading stream) and the one that refreshes: every
+        update is bracketed by events (`_access_event`), never by a host synchronisation."""
         stream = torch.cuda.current_stream(self.device) if stream is None else stream
-        with torch.cuda.stream(stream):
+        with self._pending_lock:
             if getattr(self, "_access", None) is None:
-                self._access = torch.zeros(self.node_num, dtype=torch.int64, device=self.device)
+                with torch.cuda.stream(stream):
+                    self._access = torch.zeros(self.node_num, dtype=torch.int64, device=self.device)
+            access, prev = self._access, getattr(self, "_access_event", None)
+        with torch.cuda.stream(stream):
+            if prev is not None:
+                stream.wait_event(prev)                    # a refresh on another stream may just have decayed the counts
             nids = nids.to(self.device, dtype=torch.int64, non_blocking=True)
-            self._access.index_add_(0, nids, torch.ones_like(nids))
+            access.index_add_(0, nids, torch.ones_like(nids))
+            ev = torch.cuda.Event()
+            ev.record(stream)
+        with self._pending_lock:
+            self._access_event = ev
 
     def refresh_from_access(self, decay=0.5):
         """Re-populate the cache with the nodes fetched most often since the last refresh (the empirical version of the global
-        sample: it follows the training set's actual neighbourhood distribution); counts are decayed, not cleared."""
+        sample: it follows the training set's actual neighbourhood distribution); counts are decayed IN PLACE, not cleared."""
         if getattr(self, "_access", None) is None or self.capability >= self.node_num:
             return
-        nids = torch.topk(self._access, self.capability).indices
+        cur = torch.cuda.current_stream(self.device)
+        with self._pending_lock:
+            access, prev = self._access, getattr(self, "_access_event", None)
+        if prev is not None:
+            cur.wait_event(prev)                           # the loading stream's last index_add_
+        nids = torch.topk(access, self.capability).indices
         self.cache_fix_data(nids, self.get_feat_from_server(nids), is_full=False)
-        self._access = (self._access.to(torch.float64) * decay).to(torch.int64)
+        access.copy_((access.to(torch.float64) * decay).to(torch.int64))
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        with self._pending_lock:
+            self._access_event = ev
 
     def get_feat_from_server(self, nids, to_gpu=False):
         """Rows of the host feature store for local ids `nids` (storage.py:100-125)."""
@@ -108,15 +128,26 @@ class GraphCacheServer:
         return rows.to(self.device, non_blocking=True) if to_gpu else rows
 
     def cache_fix_data(self, nids, data, is_full=False):
+        """storage.py:127-148.  Safe DURING iteration (the pipeline's loading thread fetches on its own stream while the
+        training thread refreshes): the new (slot map, cache block) pair is built off to the side on the caller's stream and
+        published as ONE tuple together with the event that marks it complete; a fetch snapshots the tuple under the lock,
+        makes its stream wait for that event and `record_stream`s both tensors, so the old pair is neither half-written
+        nor recycled by the allocator while a gather still reads it."""
         rows = nids.size(0)
         assert rows == data.size(0)                                            # storage.py:142-143
-        self.localid2cacheid.fill_(-1)
-        self.localid2cacheid[nids] = torch.arange(rows, device=self.device)
-        self.cached_num = rows
-        self.gpu_fix_cache = data.to(self.device).contiguous()
-        self.gpu_flag.zero_()
-        self.gpu_flag[nids] = True
-        self.full_cached = is_full
+        cur = torch.cuda.current_stream(self.device)
+        slot_map = torch.full((self.node_num,), -1, dtype=torch.int64, device=self.device)
+        slot_map[nids] = torch.arange(rows, device=self.device)
+        block = data.to(self.device).contiguous()
+        flag = torch.zeros(self.node_num, dtype=torch.bool, device=self.device)
+        flag[nids] = True
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        with self._pending_lock:
+            self._state = (slot_map, block, ready)
+            self.localid2cacheid, self.gpu_fix_cache, self.gpu_flag = slot_map, block, flag
+            self.cached_num = rows
+            self.full_cached = is_full
 
     # ---- the hot call ----------------------------------------------------------------------------------------
     def fetch_data(self, nids, out=None, stream=None):
@@ -134,8 +165,11 @@ class GraphCacheServer:
                 out = torch.empty((n, self.total_dim), dtype=self.features.dtype, device=self.device)
             if n == 0:
                 return out
-            cache = self.gpu_fix_cache
+            with self._pending_lock:
+                slot_map, cache, ready = getattr(self, "_state", (None, None, None))
             use_map = cache is not None
+            if ready is not None:
+                stream.wait_event(ready)          # the pair may have been installed by another stream a moment ago
             host_map = self.nid_map          # full_cached: every id hits, the map is never consulted
             counter = None
             if self.log and use_map:
@@ -144,13 +178,20 @@ class GraphCacheServer:
                 code = _lib.lib.dgll_hip_gather_rows_mapped(
                     stream.cuda_stream, cache.data_ptr() if use_map else None, cache.stride(0) if use_map else 0,
                     self.features.data_ptr(), self.features.stride(0), nids.data_ptr(),
-                    self.localid2cacheid.data_ptr() if use_map else None,
+                    slot_map.data_ptr() if use_map else None,
                     host_map.data_ptr() if host_map is not None else None, out.data_ptr(), out.stride(0), n,
                     self.total_dim, _dtype_code(out), counter.data_ptr() if counter is not None else None)
             _lib.check(code, "dgll_hip_gather_rows_mapped")
+            if use_map:                           # a refresh may drop the pair while this gather still runs on `stream`
+                slot_map.record_stream(stream)
+                cache.record_stream(stream)
             if self.log:
+                done = None
+                if counter is not None:
+                    done = torch.cuda.Event()
+                    done.record(stream)           # the counter is final once THIS stream has passed the gather
                 with self._pending_lock:
-                    self._pending.append((counter, n))
+                    self._pending.append((counter, n, done))
         return out
 
     # ---- accounting (storage.py:213-220) -----------------------------------------------------------------------
@@ -162,7 +203,9 @@ class GraphCacheServer:
         """Fold the device-side miss counters of the logged fetches into the totals (the only host read-back)."""
         with self._pending_lock:
             pending, self._pending = self._pending, []
-        for counter, n in pending:
+        for counter, n, done in pending:
+            if done is not None:
+                done.synchronize()                # written on the loading stream: wait for that stream, not the current one
             self.log_miss_rate(int(counter.item()) if counter is not None else 0, n)
 
     def get_miss_rate(self):

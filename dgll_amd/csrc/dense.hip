@@ -864,18 +864,28 @@ static hipError_t launch_mfma_res_p(const MfmaGemmArgs& a, hipStream_t s) {
     constexpr int NWG_T = NTW * CS;
     const size_t lds = (size_t)NC * NWG_T * 32 * 128 + NW * 32 * 80 + NWG_T * 32 * 4;
     auto kern = &gemm_bf16_res_kernel<NTW, RG, NC, CS, COLSPLIT, D, PLAIN, NW, DUAL>;
-    static hipError_t raised = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (raised != hipSuccess) return raised;
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-        if (n_cu <= 0) n_cu = 256;
-        n_cu = n_cu / 16 * 16;                              // whole groups of 8 XCDs x COLSPLIT partners
-        if (n_cu <= 0) n_cu = 16;
+    // both the LDS attribute and the CU count are per device (single-process multi-device use): cached per device id
+    static bool raised_on[64] = {};
+    static int n_cu_of[64] = {};
+    int dev = 0;
+    hipError_t ge = hipGetDevice(&dev);
+    if (ge != hipSuccess) return ge;
+    const int slot = (dev >= 0 && dev < 64) ? dev : 0;
+    if (!raised_on[slot] || slot != dev) {
+        hipError_t re = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (re != hipSuccess) return re;
+        raised_on[slot] = slot == dev;
     }
+    if (n_cu_of[slot] == 0 || slot != dev) {
+        hipDeviceProp_t prop;
+        int n = 0;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+        n = n / 16 * 16;                                    // whole groups of 8 XCDs x COLSPLIT partners
+        if (n <= 0) n = 16;
+        n_cu_of[slot] = n;
+    }
+    const int n_cu = n_cu_of[slot];
     const int per_cu = lds > 80 * 1024 ? 1 : 2;
     dim3 grid((uint32_t)(n_cu * per_cu));
     hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, s, a);

@@ -255,8 +255,10 @@ DGLL_API int dgll_hip_grad_weight_bf16(void* stream, const void* X1, int64_t ldx
     a.n_slabs = n_slabs;
     const int64_t per = (M + n_slabs - 1) / n_slabs;
     a.rows_per_slab = std::max<int64_t>(16 * kGwU, (per + 16 * kGwU - 1) / (16 * kGwU) * (16 * kGwU));
-    // the range check is a 32-bit byte count per slab
-    DGLL_REQUIRE(a.rows_per_slab * std::max(std::max(ldx1, ldx2), ldg) * 2 < (int64_t)1 << 32, "slab larger than 4 GiB: use more slabs");
+    // the loader's byte offsets inside a slab are 32-bit and run up to three prefetch steps (16 * kGwU rows each) past the
+    // slab's end before the out-of-range test zeroes them: that overshoot must not wrap either
+    DGLL_REQUIRE((a.rows_per_slab + 4 * 16 * kGwU) * std::max(std::max(ldx1, ldx2), ldg) * 2 < (int64_t)1 << 32,
+                 "slab (plus the prefetch overshoot) larger than 4 GiB: use more slabs");
     a.partial = static_cast<float*>(workspace);
     const int ks_total = a.kslabs[0] + a.kslabs[1];
     // slabs past the end of M (tiny M) would leave their partials unwritten: shrink the slab count instead
@@ -264,9 +266,15 @@ DGLL_API int dgll_hip_grad_weight_bf16(void* stream, const void* X1, int64_t ldx
     a.n_slabs = used;
     // waves idle in the upper half of G's columns (N <= 128) leave their partial columns unwritten: the reduce kernel never reads n >= N
     dim3 grid((uint32_t)used, (uint32_t)((ks_total + 3) / 4));
-    static hipError_t raised = hipFuncSetAttribute(reinterpret_cast<const void*>(&gradw_splitk_kernel),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kGwTile);
-    if (raised != hipSuccess) return hip_fail(raised, "gradw_splitk_kernel LDS size");
+    // the attribute is per device: raise it once for each device a launch is issued on (single-process multi-device use)
+    static bool raised_on[64] = {};
+    int dev = 0;
+    DGLL_HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || !raised_on[dev]) {
+        DGLL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gradw_splitk_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kGwTile));
+        if (dev >= 0 && dev < 64) raised_on[dev] = true;
+    }
     hipLaunchKernelGGL(gradw_splitk_kernel, grid, dim3(512), 2 * kGwTile, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "gradw_splitk_kernel launch");

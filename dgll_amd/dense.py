@@ -134,6 +134,9 @@ def _grad_weight_hip(x1, x2, g):
     types = (-(-k1 // 64) + -(-k2 // 64) + 3) // 4
     n_cu = torch.cuda.get_device_properties(g.device).multi_processor_count
     slabs = max(1, min(4096, n_cu // types, -(-m // 16)))
+    ld_max = max(x1.stride(0), x2.stride(0) if x2 is not None else 0, g.stride(0))
+    while slabs < 4096 and (-(-m // slabs) + 256) * ld_max * 2 >= (1 << 32) - (1 << 20):   # the kernel's uint32 byte offsets
+        slabs *= 2
     need = int(_lib.lib.dgll_hip_grad_weight_workspace(k1, k2, slabs))
     key = (g.device.index, torch.cuda.current_stream(g.device).cuda_stream)
     ws = _GW_WORKSPACE.get(key)
@@ -141,14 +144,15 @@ def _grad_weight_hip(x1, x2, g):
         ws = _GW_WORKSPACE[key] = torch.empty(need // 4, dtype=torch.float32, device=g.device)
     d1 = torch.empty((k1, n), dtype=torch.float32, device=g.device)
     d2 = torch.empty((k2, n), dtype=torch.float32, device=g.device) if x2 is not None else None
-    end = _timed(("grad_weight", m, k1, k2, n, ""), g.device)
-    code = _lib.lib.dgll_hip_grad_weight_bf16(
-        torch.cuda.current_stream(g.device).cuda_stream, x1.data_ptr(), x1.stride(0), k1,
-        x2.data_ptr() if x2 is not None else None, x2.stride(0) if x2 is not None else 0, k2, g.data_ptr(), g.stride(0), n, m,
-        ws.data_ptr(), ws.numel() * 4, slabs, d1.data_ptr(), d1.stride(0), d2.data_ptr() if d2 is not None else None,
-        d2.stride(0) if d2 is not None else 0)
-    if end is not None:
-        end.record(torch.cuda.current_stream(g.device))
+    with torch.cuda.device(g.device):       # the launch (and its event bracket) belong to g's device, whatever is current
+        end = _timed(("grad_weight", m, k1, k2, n, ""), g.device)
+        code = _lib.lib.dgll_hip_grad_weight_bf16(
+            torch.cuda.current_stream(g.device).cuda_stream, x1.data_ptr(), x1.stride(0), k1,
+            x2.data_ptr() if x2 is not None else None, x2.stride(0) if x2 is not None else 0, k2, g.data_ptr(), g.stride(0), n, m,
+            ws.data_ptr(), ws.numel() * 4, slabs, d1.data_ptr(), d1.stride(0), d2.data_ptr() if d2 is not None else None,
+            d2.stride(0) if d2 is not None else 0)
+        if end is not None:
+            end.record(torch.cuda.current_stream(g.device))
     _lib.check(code, "dgll_hip_grad_weight_bf16")
     return d1, d2
 

@@ -94,6 +94,12 @@ def _host_heads(x, adj, Ws, a1s, a2s, alpha, concat, mode, dropout, training):
         if training and dropout > 0.0:
             w = F.dropout(w, dropout, training=True)    # on the attention weights (gatconv.py:37,132)
         hp = F.zeros(n, h.shape[1], dtype=h.dtype).index_add_(0, row, w.unsqueeze(1) * h[col]) / den.unsqueeze(1)
+        empty = den == 0
+        if bool(empty.any()):
+            if mode == 1:   # gatConv masks with -9e15 (gatconv.py:34-35): a row without edges attends uniformly to ALL nodes
+                hp = F.where(empty.unsqueeze(1), h.mean(0, keepdim=True).expand_as(hp), hp)
+            else:           # sparseGatConv divides 0 / 0 and asserts (gatconv.py:139-141)
+                assert not F.isnan(hp).any()
         outs.append(F.elu(hp) if concat else hp)
     return outs[0] if len(outs) == 1 else F.cat(outs, dim=1)
 

@@ -70,6 +70,8 @@ class _SegmentMax(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, graph):
         _require_cuda(x, graph.rowptr)
+        if x.shape[0] != graph.n_cols:      # the backward walks the transposed structure: one row pointer per source row
+            raise ValueError("X has %d rows but the adjacency gathers from %d" % (x.shape[0], graph.n_cols))
         xs = _ready(x)
         feat = x.shape[1]
         y = _empty_padded(graph.n_rows, feat, x.dtype, x.device)

@@ -107,6 +107,55 @@ def test_cache_with_nid_map_and_pipeline_on_gpu(cuda_device):
     assert torch.equal(srv2.fetch_data(ids).cpu(), feats[perm[ids.cpu()]])
 
 
+@pytest.mark.gpu
+def test_cache_refresh_during_iteration_never_serves_a_wrong_row(cuda_device):
+    """The docstrings invite re-drawing the cached set periodically; the pipeline's loading thread fetches on its own stream
+    at the same time.  Every fetched row must equal features[id] whatever pair (slot map, cache block) the fetch snapshot
+    (published atomically, old pair kept alive by record_stream), the access counters survive the cross-stream hand-over,
+    and the miss counters are read after the stream that wrote them."""
+    from dgll_amd.cache import GraphCacheServer
+
+    n, dim = 20000, 64
+    torch.manual_seed(3)
+    feats = torch.randn(n, dim).to(torch.bfloat16)
+    feats[:, 0] = (torch.arange(n) % 251).to(torch.bfloat16)      # a column that identifies the row exactly
+    srv = GraphCacheServer(feats, gpuid=0)
+    srv.log = True
+    srv.global_sampling_cache(torch.rand(n) + 0.1, capacity=4000, seed=1)
+    load_stream = torch.cuda.Stream(device=cuda_device)
+    stop, errors, fetched = threading.Event(), [], [0]
+
+    def loader():
+        gen = torch.Generator().manual_seed(7)
+        try:
+            while not stop.is_set():
+                ids = torch.randint(0, n, (4096,), generator=gen)
+                out = srv.fetch_data(ids, stream=load_stream)
+                srv.record_access(ids, stream=load_stream)
+                load_stream.synchronize()
+                if not torch.equal(out.cpu(), feats[ids]):
+                    errors.append("wrong rows after %d fetches" % fetched[0])
+                    return
+                fetched[0] += 1
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    t = threading.Thread(target=loader)
+    t.start()
+    for i in range(30):
+        if i % 2:
+            srv.refresh()
+        else:
+            srv.refresh_from_access()
+        time.sleep(0.01)
+    stop.set()
+    t.join()
+    assert not errors, errors
+    assert fetched[0] > 5
+    rate = srv.get_miss_rate()
+    assert 0.5 < rate < 0.95           # 4000 of 20000 nodes cached: most fetches miss, none is lost from the count
+
+
 def test_adaptive_queue_grows_when_the_consumer_starves_and_shrinks_when_the_producer_idles():
     """README.md:29 "adaptive queue-sizing strategy to balance computation and memory efficiency"."""
     from dgll_amd.pipeline import AdaptiveQueue
