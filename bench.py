@@ -390,6 +390,18 @@ def launch_tables(launches, local_rows, heads_of=None):
                                                  (" " + extra) if extra else "", tag_nnz)
             table[name] = {"count": cnt, "avg_ms": avg_ms, "nnz": tag_nnz, "feat": feat, "weighted": bool(weighted),
                            "epilogue": extra, "kernel_fragment": spmm_kernel_fragment(feat, dt, weighted, bool(extra))}
+        elif tag[0] == "fused_sage":
+            # aggregate -> transform in one launch: the SpMM's section-8(d) bytes (every edge one feature row; the aggregated row is
+            # still written for the backward pass) plus the transform's own operands (self rows read, output rows written)
+            _, rows, feat, k1, n_out, tag_nnz = tag
+            b_alg = alg_bytes(tag_nnz, local_rows, feat, 2, 2, False) + rows * (k1 + n_out) * 2
+            name = "fused aggregate->transform F=%d K1=%d N=%d bfloat16 nnz=%d" % (feat, k1, n_out, tag_nnz)
+            vecs = -(-feat // 8)
+            lpr = 8
+            while lpr < 32 and lpr < vecs:
+                lpr <<= 1
+            table[name] = {"count": cnt, "avg_ms": avg_ms, "nnz": tag_nnz, "feat": feat, "weighted": False, "epilogue": "fused transform",
+                           "kernel_fragment": "fused_sage_kernel<%d, false, %d, 4>" % (lpr, 2 if n_out > 128 else 1)}
         elif tag[0] == "gat":
             _, kind, heads, fo, dt, tag_nnz, packed = tag
             xb = 2 if "bfloat16" in dt else 4

@@ -58,6 +58,8 @@ SIGNATURES = {
                                     _i32, _vp, _vp, _sz, _vp, _i32]),
     "dgll_hip_spmm_csr_gated": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _i64, _i32, _i64, _i64, _i32, _i32,
                                        _i32, _vp, _vp, _sz, _vp, _i32, _vp, _i64]),
+    "dgll_hip_sage_fused_forward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _i64, _i32, _vp, _i64, _vp, _i64, _i32,
+                                           _vp, _i32, _vp, _i64, _i32, _vp, _i64, _i64, _i64, _vp, _sz]),
     "dgll_hip_sddmm_csr": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i32, _vp, _i64, _i32]),
     "dgll_hip_gat_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i64, _i32, _i32,
                                 C.c_float, _i32, _i32, _vp, _sz]),

@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "gather.hpp"
 #include <type_traits>
 
 namespace dgll {
@@ -67,90 +68,6 @@ struct SpmmArgs {
     const void* gate;         // optional [n_rows, ldg] of Y's type: outputs are zeroed where gate <= 0 (fused ReLU backward)
     int64_t ldg;
 };
-
-// Accumulate edges [b, e) of one row into acc (this lane's EPV columns starting at xcol).
-template <typename XT, int EPV, int LPR, bool HAS_VAL, int U>
-__device__ __forceinline__ void gather_edges(const int32_t* __restrict__ col, const float* __restrict__ val,
-                                             const XT* __restrict__ xcol, int64_t ldx, int64_t b, int64_t e,
-                                             int lane, float (&acc)[EPV]) {
-    typedef VecIO<XT, EPV> IO;
-    constexpr int SLOTS = kWave / LPR;
-    const int slot = lane / LPR;
-
-    int my_col = 0;
-    float my_val = 0.0f;
-    if (b + lane < e) {
-        my_col = __builtin_nontemporal_load(col + b + lane);   // indices and weights are streamed once: keep them
-        if (HAS_VAL) my_val = __builtin_nontemporal_load(val + b + lane);   // from displacing feature rows in L2
-    }
-    for (int64_t k0 = b; k0 < e; k0 += kWave) {
-        const int64_t left = e - k0;
-        const int nb = left < kWave ? (int)left : kWave;
-        const int cur_col = my_col;
-        const float cur_val = my_val;
-        // prefetch the next batch of indices while this one is consumed
-        const int64_t kn = k0 + kWave + lane;
-        if (kn < e) {
-            my_col = __builtin_nontemporal_load(col + kn);
-            if (HAS_VAL) my_val = __builtin_nontemporal_load(val + kn);
-        }
-        // Row offsets are formed with ONE 32x32->64 multiply (v_mad_u64_u32): column ids and the leading dimension both
-        // fit 32 bits.  Full rounds need no masking; only the last, partial round clamps and zeroes its idle slots.
-        const uint32_t ld32 = (uint32_t)ldx;
-        int j = 0;
-        for (; j + SLOTS * U <= nb; j += SLOTS * U) {
-            int c[U];
-            float w[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int src = j + u * SLOTS + slot;
-                c[u] = __shfl(cur_col, src);
-                w[u] = HAS_VAL ? __shfl(cur_val, src) : 1.0f;
-            }
-            typename IO::raw_t v[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) v[u] = IO::load(xcol + (uint64_t)(uint32_t)c[u] * ld32);
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                float f[EPV];
-                IO::unpack(v[u], f);
-#pragma unroll
-                for (int i = 0; i < EPV; ++i) acc[i] = HAS_VAL ? fmaf(w[u], f[i], acc[i]) : acc[i] + f[i];
-            }
-        }
-        if (j < nb) {
-            // the U gathers are still issued back to back with no branch in between: an out-of-range slot re-reads the
-            // batch's last valid edge (same cache lines as a live request) and is zeroed after the load
-            int c[U];
-            float w[U];
-            bool ok[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int idx = j + u * SLOTS + slot;
-                ok[u] = idx < nb;
-                const int src = ok[u] ? idx : nb - 1;
-                c[u] = __shfl(cur_col, src);
-                w[u] = HAS_VAL ? __shfl(cur_val, src) : 1.0f;
-            }
-            typename IO::raw_t v[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) v[u] = IO::load(xcol + (uint64_t)(uint32_t)c[u] * ld32);
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                float f[EPV];
-                IO::unpack(ok[u] ? v[u] : IO::zero(), f);
-#pragma unroll
-                for (int i = 0; i < EPV; ++i) acc[i] = HAS_VAL ? fmaf(w[u], f[i], acc[i]) : acc[i] + f[i];
-            }
-        }
-    }
-    // combine the slots: lanes that differ only in the slot bits hold the same columns
-#pragma unroll
-    for (int off = LPR; off < kWave; off <<= 1) {
-#pragma unroll
-        for (int i = 0; i < EPV; ++i) acc[i] += __shfl_xor(acc[i], off);
-    }
-}
 
 template <typename T> __device__ __forceinline__ float load_one(const T* p);
 template <> __device__ __forceinline__ float load_one<float>(const float* p) { return *p; }
@@ -653,18 +570,13 @@ DGLL_API size_t dgll_hip_csr_plan_workspace_bytes(const dgll_csr_plan* p, int fe
 DGLL_API int64_t dgll_hip_csr_plan_num_long_rows(const dgll_csr_plan* p) { return p ? p->n_long : 0; }
 DGLL_API int64_t dgll_hip_csr_plan_num_chunks(const dgll_csr_plan* p) { return p ? p->n_chunks : 0; }
 
-static int spmm_csr_impl(void* stream, const dgll_csr_plan* plan, const int64_t* rowptr, const int32_t* col,
-                         const float* val, const void* X, int64_t ldx, int x_dtype, void* Y, int64_t ldy,
-                         int y_dtype, int64_t n_rows, int64_t n_cols, int feat, int reduce, int epilogue,
-                         const float* bias, void* workspace, size_t workspace_bytes, const float* row_scale, int accumulate,
-                         const void* gate, int64_t ldg);
 
 DGLL_API int dgll_hip_spmm_csr(void* stream, const dgll_csr_plan* plan, const int64_t* rowptr, const int32_t* col,
                                const float* val, const void* X, int64_t ldx, int x_dtype, void* Y, int64_t ldy,
                                int y_dtype, int64_t n_rows, int64_t n_cols, int feat, int reduce, int epilogue,
                                const float* bias, void* workspace, size_t workspace_bytes) {
-    return spmm_csr_impl(stream, plan, rowptr, col, val, X, ldx, x_dtype, Y, ldy, y_dtype, n_rows, n_cols, feat, reduce,
-                         epilogue, bias, workspace, workspace_bytes, nullptr, 0, nullptr, 0);
+    return dgll_spmm_csr_impl(stream, plan, rowptr, col, val, X, ldx, x_dtype, Y, ldy, y_dtype, n_rows, n_cols, feat, reduce,
+                              epilogue, bias, workspace, workspace_bytes, nullptr, 0, nullptr, 0, 0);
 }
 
 DGLL_API int dgll_hip_spmm_csr_ex(void* stream, const dgll_csr_plan* plan, const int64_t* rowptr, const int32_t* col,
@@ -672,8 +584,8 @@ DGLL_API int dgll_hip_spmm_csr_ex(void* stream, const dgll_csr_plan* plan, const
                                   int y_dtype, int64_t n_rows, int64_t n_cols, int feat, int reduce, int epilogue,
                                   const float* bias, void* workspace, size_t workspace_bytes, const float* row_scale,
                                   int accumulate) {
-    return spmm_csr_impl(stream, plan, rowptr, col, val, X, ldx, x_dtype, Y, ldy, y_dtype, n_rows, n_cols, feat, reduce,
-                         epilogue, bias, workspace, workspace_bytes, row_scale, accumulate, nullptr, 0);
+    return dgll_spmm_csr_impl(stream, plan, rowptr, col, val, X, ldx, x_dtype, Y, ldy, y_dtype, n_rows, n_cols, feat, reduce,
+                              epilogue, bias, workspace, workspace_bytes, row_scale, accumulate, nullptr, 0, 0);
 }
 
 DGLL_API int dgll_hip_spmm_csr_gated(void* stream, const dgll_csr_plan* plan, const int64_t* rowptr, const int32_t* col,
@@ -681,15 +593,17 @@ DGLL_API int dgll_hip_spmm_csr_gated(void* stream, const dgll_csr_plan* plan, co
                                      int y_dtype, int64_t n_rows, int64_t n_cols, int feat, int reduce, int epilogue,
                                      const float* bias, void* workspace, size_t workspace_bytes, const float* row_scale,
                                      int accumulate, const void* gate, int64_t ldg) {
-    return spmm_csr_impl(stream, plan, rowptr, col, val, X, ldx, x_dtype, Y, ldy, y_dtype, n_rows, n_cols, feat, reduce,
-                         epilogue, bias, workspace, workspace_bytes, row_scale, accumulate, gate, ldg);
+    return dgll_spmm_csr_impl(stream, plan, rowptr, col, val, X, ldx, x_dtype, Y, ldy, y_dtype, n_rows, n_cols, feat, reduce,
+                              epilogue, bias, workspace, workspace_bytes, row_scale, accumulate, gate, ldg, 0);
 }
 
-static int spmm_csr_impl(void* stream, const dgll_csr_plan* plan, const int64_t* rowptr, const int32_t* col,
-                         const float* val, const void* X, int64_t ldx, int x_dtype, void* Y, int64_t ldy,
-                         int y_dtype, int64_t n_rows, int64_t n_cols, int feat, int reduce, int epilogue,
-                         const float* bias, void* workspace, size_t workspace_bytes, const float* row_scale, int accumulate,
-                         const void* gate, int64_t ldg) {
+// only_long != 0: just the rows longer than the plan's threshold (their chunk items + the finalize pass) -- the fused
+// aggregate -> transform kernel (fused_sage.hip) gathers every other row itself.
+int dgll_spmm_csr_impl(void* stream, const dgll_csr_plan* plan, const int64_t* rowptr, const int32_t* col,
+                       const float* val, const void* X, int64_t ldx, int x_dtype, void* Y, int64_t ldy,
+                       int y_dtype, int64_t n_rows, int64_t n_cols, int feat, int reduce, int epilogue,
+                       const float* bias, void* workspace, size_t workspace_bytes, const float* row_scale, int accumulate,
+                       const void* gate, int64_t ldg, int only_long) {
     DGLL_REQUIRE(n_rows >= 0 && n_cols >= 0 && feat >= 0, "negative size");
     DGLL_REQUIRE(!gate || ldg >= feat, "gate leading dimension smaller than feat");
     DGLL_REQUIRE(accumulate >= 0 && accumulate <= 2, "accumulate: 0, 1 (add Y before the epilogue) or 2 (add the epilogue's result to Y)");
@@ -740,8 +654,9 @@ static int spmm_csr_impl(void* stream, const dgll_csr_plan* plan, const int64_t*
         a.rows_per_wave = std::min(std::max(rpw, 1), 8);
         if (g_tune_rows_per_wave > 0) a.rows_per_wave = g_tune_rows_per_wave;
     }
+    if (only_long && (!plan || plan->n_long == 0)) return DGLL_OK;
     const int64_t waves = (n_rows + a.rows_per_wave - 1) / a.rows_per_wave;
-    const int64_t row_blocks = (waves + kWavesPerBlock - 1) / kWavesPerBlock;
+    const int64_t row_blocks = only_long ? 0 : (waves + kWavesPerBlock - 1) / kWavesPerBlock;
     int64_t chunk_blocks = (a.n_chunks + kWavesPerBlock - 1) / kWavesPerBlock;
     chunk_blocks = (chunk_blocks + kXcds - 1) / kXcds * kXcds;  // keep (block % 8) == XCD for the row blocks
     DGLL_REQUIRE(row_blocks + chunk_blocks < (int64_t)0x7fffffff, "grid too large");
@@ -765,7 +680,7 @@ static int spmm_csr_impl(void* stream, const dgll_csr_plan* plan, const int64_t*
         // 128: -24 %; F = 256 (two slots): +6 %, and at 51 edges per row the wave-per-row kernel wins everywhere (+11 .. +32 %:
         // a slot walks its row U edges at a time, a whole wavefront 64).
         const double avg_len = plan ? (double)plan->nnz / (double)std::max<int64_t>(n_rows, 1) : 1e9;
-        rowslot = lpr <= 32 && g_tune_rowslot != 1 && (g_tune_rowslot == 2 || (lpr <= 16 && avg_len <= 24.0));
+        rowslot = !only_long && lpr <= 32 && g_tune_rowslot != 1 && (g_tune_rowslot == 2 || (lpr <= 16 && avg_len <= 24.0));
         if (rowslot) {
             const int slots = kWave / lpr;
             a.rows_per_wave = std::max(a.rows_per_wave, 1);

@@ -78,6 +78,60 @@ def transform_bf16(a1, wt1, a2=None, wt2=None, relu=False, out_dtype=torch.bfloa
     return out
 
 
+def fused_ok(graph, x, n_out, h_self=None):
+    """Shapes / layouts the fused aggregate -> transform kernel (csrc/fused_sage.hip) takes."""
+    return (_mfma_ok(x, h_self) and x.shape[1] <= 256 and n_out <= 256 and getattr(graph, "is_cuda", False)
+            and (graph.val is None or graph.val.dtype == torch.float32) and x.shape[0] == graph.n_cols
+            and (h_self is None or h_self.shape[0] == graph.n_rows))
+
+
+def sage_fused_forward(graph, x, reduce, h_self, wt_self, wt_nbr, relu, bias=None, keep_agg=False, ld_align=None):
+    """(out, agg) with out = act(h_self . wt_self^T + reduce_A(x) . wt_nbr^T + bias) from ONE launch: a workgroup aggregates a
+    32-row tile into LDS and feeds it to the MFMAs (dgll_hip_sage_fused_forward).  wt_*: [N, K] (transposed weights, any float
+    dtype); wt_nbr None: the aggregate is added instead of transformed (x.shape[1] == N).  agg: the aggregated rows
+    [n_rows, feat] bf16 when keep_agg (the weight gradient needs them), else None."""
+    from . import ops
+
+    dev = x.device
+    feat = x.shape[1]
+    n = wt_nbr.shape[0] if wt_nbr is not None else (wt_self.shape[0] if wt_self is not None else feat)
+    p1 = _pad_wt(wt_self) if h_self is not None else None
+    p2 = _pad_wt(wt_nbr) if wt_nbr is not None else None
+    w_rows = (p1 if p1 is not None else p2).shape[0]
+    if p1 is not None and p2 is not None and p1.shape[0] != p2.shape[0]:
+        raise ValueError("both weight matrices must have N rows")
+    ld_align = ld_align or 8
+    ld = -(-n // ld_align) * ld_align
+    store = torch.empty((graph.n_rows, ld), dtype=torch.bfloat16, device=dev)
+    out = store[:, :n] if ld != n else store
+    plan = graph.plan()
+    long_rows = graph.num_long_rows() > 0
+    agg = None
+    if keep_agg or long_rows:
+        agg = ops.alloc_features(graph.n_rows, feat, torch.bfloat16, dev)
+    ws_bytes = graph.workspace_bytes(feat) if long_rows else 0
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
+    if bias is not None:
+        bias = bias.detach().float().contiguous()
+    val = graph.val
+    with torch.cuda.device(dev):
+        end = _timed(("fused_sage", graph.n_rows, feat, h_self.shape[1] if h_self is not None else 0, n, graph.nnz), dev)
+        code = _lib.lib.dgll_hip_sage_fused_forward(
+            torch.cuda.current_stream(dev).cuda_stream, plan, graph.rowptr.data_ptr(), graph.col.data_ptr(),
+            val.data_ptr() if val is not None else None, x.data_ptr(), x.stride(0), feat,
+            _lib.REDUCE_MEAN if reduce == "mean" else _lib.REDUCE_SUM,
+            h_self.data_ptr() if h_self is not None else None, h_self.stride(0) if h_self is not None else 0,
+            h_self.shape[1] if h_self is not None else 0, p1.data_ptr() if p1 is not None else None,
+            p1.stride(0) if p1 is not None else 0, p2.data_ptr() if p2 is not None else None, p2.stride(0) if p2 is not None else 0,
+            w_rows, bias.data_ptr() if bias is not None else None, int(relu), out.data_ptr(), out.stride(0), n,
+            agg.data_ptr() if agg is not None else None, agg.stride(0) if agg is not None else 0, graph.n_rows, graph.n_cols,
+            ws.data_ptr() if ws is not None else None, ws_bytes)
+        if end is not None:
+            end.record(torch.cuda.current_stream(dev))
+    _lib.check(code, "dgll_hip_sage_fused_forward")
+    return out, (agg if keep_agg else None)
+
+
 def transform_bf16_dual(a, wt1, wt2):
     """(a . wt1^T, a . wt2^T) in one MFMA launch that reads `a` once: the two input gradients g.Ws^T, g.Wn^T of a SAGE
     layer.  wt1, wt2: [N, K] with N, K <= 256; a: bf16 [M, K], 16-byte aligned rows."""

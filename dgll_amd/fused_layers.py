@@ -13,6 +13,16 @@ import torch
 from . import dense, ops
 
 
+# The fused aggregate -> transform kernel (csrc/fused_sage.hip: gather a 64-row tile into LDS, MFMA it against weights streamed
+# from L2) is correct and tested, but MEASURED SLOWER than the two launches it replaces on MI355X (products-sized graph, F = 256,
+# tools/fused_probe.py): 6.70 ms against SpMM 4.35 + transform 0.88 ms; without the self operand (the reference kernel's
+# relu(A.X.W) shape) 5.70 ms.  The gather needs every wavefront slot and register the CU has to keep enough loads in flight,
+# and whatever the tile does besides gathering (sixteen dependent L2 round trips for the weight fragments, under a memory
+# system the gathers keep saturated) comes straight out of that.  So the layers run SpMM + MFMA transform; set True to route
+# them through the fused launch.
+FUSE_AGGREGATE_TRANSFORM = False
+
+
 def _aligned(t):
     return (t.stride(0) * t.element_size()) % 16 == 0 and t.data_ptr() % 16 == 0 and t.stride(1) == 1
 
@@ -22,15 +32,20 @@ class _SageGraphLayer(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, h, ws, wn, graph, reduce, relu, grad_is_gated=False, gate_input=False):
-        agg = ops.spmm_raw(graph, h, reduce=reduce)
         wsd, wnd = ws.to(h.dtype), wn.to(h.dtype)
         ctx.grad_is_gated, ctx.gate_input = grad_is_gated, gate_input
-        if dense._mfma_ok(h, agg) and ws.shape[1] <= 256:
-            out = dense.transform_bf16(h, wsd.t(), agg, wnd.t(), relu=relu)
+        if FUSE_AGGREGATE_TRANSFORM and dense.fused_ok(graph, h, ws.shape[1], h):
+            # ONE launch: a workgroup aggregates a 32-row tile into LDS and feeds it to the MFMAs; the aggregated rows are
+            # written (the weight gradient needs them) but never read back (csrc/fused_sage.hip)
+            out, agg = dense.sage_fused_forward(graph, h, reduce, h, wsd.t(), wnd.t(), relu, keep_agg=True)
         else:
-            out = torch.addmm(torch.mm(h, wsd), agg, wnd)
-            if relu:
-                out.relu_()
+            agg = ops.spmm_raw(graph, h, reduce=reduce)
+            if dense._mfma_ok(h, agg) and ws.shape[1] <= 256:
+                out = dense.transform_bf16(h, wsd.t(), agg, wnd.t(), relu=relu)
+            else:
+                out = torch.addmm(torch.mm(h, wsd), agg, wnd)
+                if relu:
+                    out.relu_()
         ctx.graph, ctx.reduce, ctx.relu = graph, reduce, relu
         ctx.save_for_backward(h, agg, wsd, wnd, out if relu else None)
         return out
@@ -79,6 +94,12 @@ class _SageGraphLayerTransformFirst(torch.autograd.Function):
         # the narrow product is gathered next: one 128-byte line per row (ld_align) instead of rows straddling two lines
         z = (dense.transform_bf16(h, wnd.t(), ld_align=64 if wn.shape[1] < 64 else None)
              if (dense._mfma_ok(h) and wn.shape[1] <= 256) else torch.mm(h, wnd))
+        if FUSE_AGGREGATE_TRANSFORM and wn.shape[1] == ws.shape[1] and dense.fused_ok(graph, z, ws.shape[1], h):
+            # act(reduce_A(z) + h.Ws) in one launch: the aggregate of the narrow product never leaves the workgroup
+            out, _ = dense.sage_fused_forward(graph, z, reduce, h, wsd.t(), None, relu, ld_align=64 if ws.shape[1] < 64 else None)
+            ctx.graph, ctx.reduce, ctx.relu = graph, reduce, relu
+            ctx.save_for_backward(h, wsd, wnd, out if relu else None)
+            return out
         aggz = ops.spmm_raw(graph, z, reduce=reduce)
         if dense._mfma_ok(h) and aggz.dtype == torch.bfloat16 and aggz.stride(1) == 1 and ws.shape[1] <= 256:
             # act(agg + h.Ws) in ONE MFMA launch: the aggregated term rides in the epilogue (library: addmm + ReLU pass)

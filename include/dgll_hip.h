@@ -207,6 +207,26 @@ int dgll_hip_gat_bwd_strided(void* stream, const dgll_csr_plan* plan, const dgll
                              int64_t n_cols, int heads, int fo, float alpha, int apply_elu, void* workspace,
                              size_t workspace_bytes);
 
+/* ---- a10 / a4 as ONE launch: aggregate -> transform (bf16 storage, fp32 accumulation) ------------------------------------
+ *   out[i, :] = act( A1[i, :K1] . W1 + reduce_{j in row i} X[j, :feat] . W2 + bias )
+ * The MI355X form of the reference's only native kernel, relu(A.X.W) in one launch
+ * (dgll/FusedKernel/gcn_fused_kernel.cu:5-74; A1 == NULL gives exactly that shape), and of sageConv's
+ * act(src.W_s + mean(nbr).W_n) (sageconv.py:33-41,70-83): a workgroup gathers and reduces a tile of 32 destination rows
+ * into LDS and feeds it to the MFMAs directly -- the aggregated matrix is never read back from HBM.
+ *   Wt1 / Wt2     the TRANSPOSED weights, bf16, zero-padded to [w_rows >= 32 * ceil(N / 32), 64 * ceil(K / 64)] (ldw*: row
+ *                 stride in elements).  Wt2 == NULL: the aggregate is ADDED to the output instead (feat == N) -- the
+ *                 narrowing layer, whose neighbour product is aggregated after its transform;
+ *   agg_out       optional [n_rows, ldagg] bf16: the aggregated rows (training keeps them for the weight gradient
+ *                 agg^T . g).  REQUIRED when the plan has rows longer than its threshold: those are aggregated first by the
+ *                 SpMM's chunk path into agg_out and loaded from there (workspace as for dgll_hip_spmm_csr);
+ *   feat, N <= 256; X / A1 / out / agg_out rows 16-byte aligned; val NULL = unit edge values.                        */
+int dgll_hip_sage_fused_forward(void* stream, const dgll_csr_plan* plan, const int64_t* rowptr, const int32_t* col,
+                                const float* val, const void* X, int64_t ldx, int feat, int reduce,
+                                const void* A1, int64_t lda1, int K1, const void* Wt1, int64_t ldw1,
+                                const void* Wt2, int64_t ldw2, int w_rows, const float* bias, int relu, void* out,
+                                int64_t ldo, int N, void* agg_out, int64_t ldagg, int64_t n_rows, int64_t n_cols,
+                                void* workspace, size_t workspace_bytes);
+
 /* ---- a3 (max): Y[i,f] = max_k X[col[k], f], arg[i,f] = the source row holding it (-1 / 0.0 for empty rows) --
  * NeighborAggregator's "max" (sageconv.py:37-38).  Y and arg share the leading dimension ldy; X/Y 16-byte
  * aligned with padded leading dimensions.                                                                   */
