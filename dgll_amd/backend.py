@@ -8,6 +8,7 @@ an adjacency on the GPU is multiplied by the hand-written gfx950 kernels:
 
     F.spmm(adj, dense)          gcnconv.py:31, gcn.py:39
     F.sparse.mm(adj, dense)     Evaluation/PPI/gcn_model.py:76 (via torch.sparse.mm)
+    F.mm / F.matmul (2-D)       gcnconv.py:30, sageconv.py:41,72, gatconv.py:31,117 -> the MFMA / fp32 matrix-core kernels
 
 CPU tensors take torch's own CPU op, exactly as they do in the reference (its plumbing configuration, BASELINE
 config 1, is CPU-only); a GPU tensor never falls back to anything.
@@ -46,6 +47,24 @@ def spmm(adj, dense):
         adj = torch.sparse_csr_tensor(adj.rowptr, adj.col.long(),
                                       adj.val if adj.val is not None else torch.ones(adj.nnz), adj.shape)
     return torch.spmm(adj, dense)
+
+
+def mm(a, b):
+    """x . W (gcnconv.py:30, gatconv.py:31,117): GPU matrices run on the hand-written dense kernels, with autograd."""
+    if a.is_cuda and a.dim() == 2 and b.dim() == 2:
+        from . import dense
+
+        return dense.linear(a, b)
+    return torch.mm(a, b)
+
+
+def matmul(a, b):
+    """F.matmul of sageconv.py:41,72: as `mm` for two GPU matrices, torch.matmul for everything else (host, batched)."""
+    if a.is_cuda and a.dim() == 2 and b.dim() == 2:
+        from . import dense
+
+        return dense.linear(a, b)
+    return torch.matmul(a, b)
 
 
 class _Sparse(types.ModuleType):

@@ -153,11 +153,74 @@ def transform_bf16_dual(a, wt1, wt2):
     return o1, o2
 
 
+def _as_rows16(x):
+    """x with unit column stride and 16-byte aligned rows: itself when it already is, else one copy into a padded buffer."""
+    epv = 16 // x.element_size()
+    if (x.dim() == 2 and x.stride(1) == 1 and x.stride(0) >= x.shape[1] and x.stride(0) % epv == 0 and x.data_ptr() % 16 == 0):
+        return x
+    ld = -(-x.shape[1] // epv) * epv
+    buf = torch.empty((x.shape[0], ld), dtype=x.dtype, device=x.device)
+    out = buf[:, :x.shape[1]] if ld != x.shape[1] else buf
+    out.copy_(x)
+    return out
+
+
+def _mm_f32(a, wt, relu, bias, addend):
+    """fp32 product on dgll_hip_mm_f32 (v_mfma_f32_32x32x2_f32: exact fp32 arithmetic), 256 output columns per launch."""
+    a = a if a.stride(1) == 1 else a.contiguous()
+    wt = wt.to(torch.float32).contiguous()
+    m, k = a.shape
+    n = wt.shape[0]
+    out = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    if addend is not None:
+        addend = addend.to(torch.float32)
+        addend = addend if addend.stride(1) == 1 else addend.contiguous()
+    if bias is not None:
+        bias = bias.detach().to(torch.float32).contiguous()
+    with torch.cuda.device(a.device):
+        stream = torch.cuda.current_stream(a.device).cuda_stream
+        for n0 in range(0, n, 256):
+            nn = min(256, n - n0)
+            code = _lib.lib.dgll_hip_mm_f32(
+                stream, a.data_ptr(), a.stride(0), wt.data_ptr() + n0 * k * 4, k, out.data_ptr() + n0 * 4, out.stride(0), m, nn, k,
+                bias.data_ptr() + n0 * 4 if bias is not None else None, int(relu),
+                addend.data_ptr() + n0 * 4 if addend is not None else None, addend.stride(0) if addend is not None else 0)
+            _lib.check(code, "dgll_hip_mm_f32")
+    return out
+
+
+def mm_nt(a, wt, relu=False, bias=None, addend=None):
+    """act(a . wt^T + addend + bias) for a [M, K], wt [N, K] on the hand-written kernels: bf16 on the MFMA transform (rows are
+    re-laid out to 16-byte alignment when they are not; more than 256 output columns run as 256-column launches), fp32 on the
+    fp32 matrix-core kernel.  Host tensors (the layers' CPU logic) use torch."""
+    if not a.is_cuda:
+        out = a @ wt.t().to(a.dtype)
+        if addend is not None:
+            out = out + addend
+        if bias is not None:
+            out = out + bias
+        return torch.relu(out) if relu else out
+    if a.dtype == torch.float32:
+        return _mm_f32(a, wt, relu, bias, addend)
+    if a.dtype != torch.bfloat16:
+        raise TypeError("dgll_amd dense products take float32 or bfloat16 matrices, got %s" % a.dtype)
+    a = _as_rows16(a)
+    if addend is not None:
+        addend = addend.to(torch.bfloat16)
+        addend = addend if addend.stride(1) == 1 else addend.contiguous()
+    n = wt.shape[0]
+    if n <= 256:
+        return transform_bf16(a, wt, relu=relu, bias=bias, addend=addend)
+    parts = [transform_bf16(a, wt[n0:n0 + 256], relu=relu, bias=None if bias is None else bias[n0:n0 + 256],
+                            addend=None if addend is None else addend[:, n0:n0 + 256]) for n0 in range(0, n, 256)]
+    return torch.cat(parts, dim=1)
+
+
 def input_grads(g, wsd, wnd):
-    """(g . Ws^T, g . Wn^T) for weights stored [in, out]: one MFMA launch for tall bf16 gradients, else two library GEMMs."""
+    """(g . Ws^T, g . Wn^T) for weights stored [in, out]: one MFMA launch that reads g once for tall bf16 gradients, else two."""
     if g.shape[0] >= 64 * _SLABS and _mfma_ok(g) and wsd.shape == wnd.shape and max(wsd.shape) <= 256:
         return transform_bf16_dual(g, wsd, wnd)
-    return torch.mm(g, wsd.t()), torch.mm(g, wnd.t())
+    return mm_nt(g, wsd), mm_nt(g, wnd)
 
 
 def _rows(g):
@@ -167,10 +230,8 @@ def _rows(g):
 
 
 def input_grad(g, wd):
-    """g . W^T for a weight stored [in, out]: the MFMA kernel for tall bf16 gradients, else torch.mm."""
-    if g.shape[0] >= 64 * _SLABS and _mfma_ok(g) and max(wd.shape) <= 256 and wd.shape[0] % 8 == 0:
-        return transform_bf16(g, wd)
-    return torch.mm(g, wd.t())
+    """g . W^T for a weight stored [in, out] (the transposed weight of this product is W itself)."""
+    return mm_nt(g, wd)
 
 
 _GW_WORKSPACE = {}
@@ -211,26 +272,47 @@ def _grad_weight_hip(x1, x2, g):
     return d1, d2
 
 
+def _grad_weight_f32(x, g):
+    """fp32 x^T . g on dgll_hip_grad_weight_f32 (slab partials summed in slab order)."""
+    x = x.to(torch.float32)
+    g = g.to(torch.float32)
+    x = x if x.stride(1) == 1 else x.contiguous()
+    g = g if g.stride(1) == 1 else g.contiguous()
+    m, k = x.shape
+    n = g.shape[1]
+    slabs = max(1, min(256, -(-m // 256)))
+    need = int(_lib.lib.dgll_hip_grad_weight_f32_workspace(k, n, slabs))
+    ws = torch.empty(need // 4, dtype=torch.float32, device=x.device)
+    out = torch.empty((k, n), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        code = _lib.lib.dgll_hip_grad_weight_f32(torch.cuda.current_stream(x.device).cuda_stream, x.data_ptr(), x.stride(0),
+                                                 g.data_ptr(), g.stride(0), out.data_ptr(), out.stride(0), m, k, n, ws.data_ptr(),
+                                                 need, slabs)
+    _lib.check(code, "dgll_hip_grad_weight_f32")
+    return out
+
+
 def grad_weight(x, g):
-    """x^T . g  for x [M, K], g [M, N] -> fp32 [K, N], split over M."""
-    m = x.shape[0]
-    if m >= 64 * _SLABS and _gradw_ok(x, g):
+    """x^T . g  for x [M, K], g [M, N] -> fp32 [K, N]: the split-K MFMA kernel for bf16 (operands re-laid out to 16-byte rows
+    when needed, 256 x 256 output blocks), the fp32 slab kernel for fp32; host tensors use torch."""
+    if not x.is_cuda:
+        return torch.mm(x.t(), g.to(x.dtype)).float()
+    if x.dtype == torch.float32 or g.dtype == torch.float32:
+        return _grad_weight_f32(x, g)
+    x, g = _as_rows16(x), _as_rows16(g.to(x.dtype))
+    k, n = x.shape[1], g.shape[1]
+    if k <= 256 and n <= 256:
         return _grad_weight_hip(x, None, g)[0]
-    if m < 64 * _SLABS:
-        return torch.mm(x.t(), g).float()
-    rows = m // _SLABS
-    main = rows * _SLABS
-    xs = x[:main].view(_SLABS, rows, x.shape[1])
-    gs = g[:main].view(_SLABS, rows, g.shape[1])
-    out = torch.bmm(xs.transpose(1, 2), gs).float().sum(0)
-    if main < m:
-        out += torch.mm(x[main:].t(), g[main:]).float()
+    out = torch.empty((k, n), dtype=torch.float32, device=x.device)
+    for k0 in range(0, k, 256):
+        for n0 in range(0, n, 256):
+            out[k0:k0 + 256, n0:n0 + 256] = _grad_weight_hip(x[:, k0:k0 + 256], None, g[:, n0:n0 + 256])[0]
     return out
 
 
 def grad_weight_pair(x1, x2, g):
     """(x1^T . g, x2^T . g): the two weight gradients of a SAGE layer share g -- one launch reads it once."""
-    if x1.shape[0] >= 64 * _SLABS and _gradw_ok(x1, x2, g):
+    if _gradw_ok(x1, x2, g):
         return _grad_weight_hip(x1, x2, g)
     return grad_weight(x1, g), grad_weight(x2, g)
 
@@ -262,9 +344,7 @@ class _SageTransform(torch.autograd.Function):
         if ctx.mfma:   # one MFMA launch: both products, the add and the ReLU, every activation row read once
             out = transform_bf16(h, wsd.t(), agg, wnd.t(), relu=relu)
         else:
-            out = torch.addmm(torch.mm(h, wsd), agg, wnd)
-            if relu:
-                out.relu_()
+            out = mm_nt(agg, wnd.t(), relu=relu, addend=mm_nt(h, wsd.t()))
         ctx.relu = relu
         ctx.save_for_backward(h, agg, wsd, wnd, out if relu else None)
         return out
@@ -278,8 +358,8 @@ class _SageTransform(torch.autograd.Function):
         if ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
             gh, gagg = input_grads(g, wsd, wnd)
         else:
-            gh = torch.mm(g, wsd.t()) if ctx.needs_input_grad[0] else None
-            gagg = torch.mm(g, wnd.t()) if ctx.needs_input_grad[1] else None
+            gh = mm_nt(g, wsd) if ctx.needs_input_grad[0] else None
+            gagg = mm_nt(g, wnd) if ctx.needs_input_grad[1] else None
         if ctx.needs_input_grad[2] and ctx.needs_input_grad[3]:
             gws, gwn = grad_weight_pair(h, agg, g)
         else:
@@ -293,7 +373,7 @@ def sage_transform(h, agg, ws, wn, relu):
 
 
 class _Linear(torch.autograd.Function):
-    """x . w, g . w^T and x^T . g on the MFMA kernels (bf16, dimensions <= 256, tall operands); torch.mm otherwise."""
+    """x . w, g . w^T and x^T . g on the hand-written kernels (bf16 MFMA transform / split-K, fp32 matrix-core kernels)."""
 
     @staticmethod
     def forward(ctx, x, w):
@@ -302,7 +382,7 @@ class _Linear(torch.autograd.Function):
             # narrow outputs feed a gather: give every row its own 128-byte line (a 94-byte row would straddle two)
             out = transform_bf16(x, wd.t(), ld_align=64 if wd.shape[1] < 64 else None)
         else:
-            out = torch.mm(x, wd)
+            out = mm_nt(x, wd.t())
         ctx.save_for_backward(x, wd)
         return out
 
@@ -331,7 +411,7 @@ class _SkinnyLinear(torch.autograd.Function):
         if _mfma_ok(x) and wd.shape[1] <= 256:
             out = transform_bf16(x, wd.t(), out_dtype=torch.float32)
         else:
-            out = torch.mm(x, wd).float()
+            out = mm_nt(x, wd.t()).float()
         ctx.save_for_backward(x, wd)
         return out
 
@@ -367,9 +447,7 @@ class _AddLinearAct(torch.autograd.Function):
         if _mfma_ok(x) and addend.dtype == torch.bfloat16 and addend.stride(1) == 1 and wd.shape[1] <= 256:
             out = transform_bf16(x, wd.t(), relu=relu, addend=addend)      # one MFMA launch instead of addmm + ReLU pass
         else:
-            out = torch.addmm(addend, x, wd)
-            if relu:
-                out.relu_()
+            out = mm_nt(x, wd.t(), relu=relu, addend=addend)
         ctx.relu = relu
         ctx.save_for_backward(x, wd, out if relu else None)
         return out

@@ -333,9 +333,7 @@ class _DistSageLayer(torch.autograd.Function):
         if h.is_cuda and dense._mfma_ok(h, agg) and ws.shape[1] <= 256:
             out = dense.transform_bf16(h, wsd.t(), agg, wnd.t(), relu=relu)
         else:
-            out = torch.addmm(torch.mm(h, wsd), agg, wnd)
-            if relu:
-                out.relu_()
+            out = dense.mm_nt(agg, wnd.t(), relu=relu, addend=dense.mm_nt(h, wsd.t()))
         ctx.engine, ctx.reduce, ctx.relu = engine, reduce, relu
         ctx.grad_is_gated, ctx.gate_input = grad_is_gated, gate_input
         ctx.save_for_backward(h, agg, wsd, wnd, out if relu else None)
@@ -356,7 +354,7 @@ class _DistSageLayer(torch.autograd.Function):
             if inv is not None and g.is_cuda and dense._mfma_ok(g) and wnd.shape[0] <= 256:
                 gagg = dense.transform_bf16(g, wnd, row_scale=inv)                 # (g.Wn^T) / deg in one kernel
             else:
-                gagg = torch.mm(g, wnd.t())
+                gagg = dense.mm_nt(g, wnd)
                 if inv is not None:
                     gagg = gagg * inv.unsqueeze(1).to(gagg.dtype)
             state = _aggregate_backward_start(engine, gagg)
@@ -385,14 +383,12 @@ class _DistSageLayerTransformFirst(torch.autograd.Function):
 
         wsd, wnd = ws.to(h.dtype), wn.to(h.dtype)
         z = (dense.transform_bf16(h, wnd.t(), ld_align=64 if wn.shape[1] < 64 else None)
-             if (h.is_cuda and dense._mfma_ok(h) and wn.shape[1] <= 256) else torch.mm(h, wnd))
+             if (h.is_cuda and dense._mfma_ok(h) and wn.shape[1] <= 256) else dense.mm_nt(h, wnd.t()))
         aggz = _aggregate_forward(engine, z, reduce)
         if h.is_cuda and dense._mfma_ok(h) and aggz.dtype == torch.bfloat16 and aggz.stride(1) == 1 and ws.shape[1] <= 256:
             out = dense.transform_bf16(h, wsd.t(), relu=relu, addend=aggz)
         else:
-            out = torch.addmm(aggz, h, wsd)
-            if relu:
-                out.relu_()
+            out = dense.mm_nt(h, wsd.t(), relu=relu, addend=aggz)
         ctx.engine, ctx.reduce, ctx.relu = engine, reduce, relu
         ctx.grad_is_gated, ctx.gate_input = grad_is_gated, gate_input
         ctx.save_for_backward(h, wsd, wnd, out if relu else None)
@@ -423,8 +419,7 @@ class _DistSageLayerTransformFirst(torch.autograd.Function):
             if g.is_cuda and dense._mfma_ok(gm, gz) and wsd.shape[0] <= 256 and (not ctx.gate_input or h.stride(1) == 1):
                 gh = dense.transform_bf16(gm, wsd, gz, wnd, out_gate=h if ctx.gate_input else None)
             else:
-                gh = torch.mm(gm, wsd.t())
-                gh.addmm_(gz, wnd.t())
+                gh = dense.mm_nt(gz, wnd, addend=dense.mm_nt(gm, wsd))
                 if ctx.gate_input:
                     gh = torch.ops.aten.threshold_backward(gh, h, 0)
         return gh, gws, gwn, None, None, None, None, None

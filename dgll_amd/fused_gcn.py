@@ -11,7 +11,7 @@ row and races on shared memory, which is not reproduced.
 """
 import torch
 
-from . import _lib, ops
+from . import _lib, dense, ops
 from .graph import CSRGraph
 
 
@@ -60,13 +60,13 @@ def gcn_fused_backward(grad_output, row_ptr, col_idx, values, X, W, num_neighbor
     g = _graph(row_ptr, col_idx, values)
     Xa, Wa = X[:, :F].float(), W[:F].float()
     AX = ops.spmm_raw(g, Xa)
-    mask = torch.mm(AX, Wa) > 0                                  # the ReLU of the forward (gcn_fused_kernel.cu:66)
+    mask = dense.mm_nt(AX, Wa.t()) > 0                           # the ReLU of the forward (gcn_fused_kernel.cu:66)
     G = grad_output.float() * mask
     grad_W = torch.zeros_like(W)
-    grad_W[:F] = torch.mm(AX.t(), G)
+    grad_W[:F] = dense.grad_weight(AX, G)
     grad_X = torch.zeros_like(X)
     gt, _ = g.transpose()
-    grad_X[:, :F] = ops.spmm_raw(gt, torch.mm(G, Wa.t()))
+    grad_X[:, :F] = ops.spmm_raw(gt, dense.mm_nt(G, Wa))
     return [grad_X, grad_W]
 
 

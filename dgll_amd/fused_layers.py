@@ -43,9 +43,7 @@ class _SageGraphLayer(torch.autograd.Function):
             if dense._mfma_ok(h, agg) and ws.shape[1] <= 256:
                 out = dense.transform_bf16(h, wsd.t(), agg, wnd.t(), relu=relu)
             else:
-                out = torch.addmm(torch.mm(h, wsd), agg, wnd)
-                if relu:
-                    out.relu_()
+                out = dense.mm_nt(agg, wnd.t(), relu=relu, addend=dense.mm_nt(h, wsd.t()))
         ctx.graph, ctx.reduce, ctx.relu = graph, reduce, relu
         ctx.save_for_backward(h, agg, wsd, wnd, out if relu else None)
         return out
@@ -93,7 +91,7 @@ class _SageGraphLayerTransformFirst(torch.autograd.Function):
         ctx.grad_is_gated, ctx.gate_input = grad_is_gated, gate_input
         # the narrow product is gathered next: one 128-byte line per row (ld_align) instead of rows straddling two lines
         z = (dense.transform_bf16(h, wnd.t(), ld_align=64 if wn.shape[1] < 64 else None)
-             if (dense._mfma_ok(h) and wn.shape[1] <= 256) else torch.mm(h, wnd))
+             if (dense._mfma_ok(h) and wn.shape[1] <= 256) else dense.mm_nt(h, wnd.t()))
         if FUSE_AGGREGATE_TRANSFORM and wn.shape[1] == ws.shape[1] and dense.fused_ok(graph, z, ws.shape[1], h):
             # act(reduce_A(z) + h.Ws) in one launch: the aggregate of the narrow product never leaves the workgroup
             out, _ = dense.sage_fused_forward(graph, z, reduce, h, wsd.t(), None, relu, ld_align=64 if ws.shape[1] < 64 else None)
@@ -105,9 +103,7 @@ class _SageGraphLayerTransformFirst(torch.autograd.Function):
             # act(agg + h.Ws) in ONE MFMA launch: the aggregated term rides in the epilogue (library: addmm + ReLU pass)
             out = dense.transform_bf16(h, wsd.t(), relu=relu, addend=aggz, ld_align=64 if ws.shape[1] < 64 else None)
         else:
-            out = torch.addmm(aggz, h, wsd)
-            if relu:
-                out.relu_()
+            out = dense.mm_nt(h, wsd.t(), relu=relu, addend=aggz)
         ctx.graph, ctx.reduce, ctx.relu = graph, reduce, relu
         ctx.save_for_backward(h, wsd, wnd, out if relu else None)
         return out
@@ -144,8 +140,7 @@ class _SageGraphLayerTransformFirst(torch.autograd.Function):
                 # g.Ws^T + gz.Wn^T and the ReLU mask of the layer below: one MFMA launch, every operand read once
                 gh = dense.transform_bf16(gm, wsd, gz, wnd, out_gate=h if ctx.gate_input else None)
             else:
-                gh = torch.mm(gm, wsd.t())
-                gh.addmm_(gz, wnd.t())                                # both paths in one GEMM epilogue, in place
+                gh = dense.mm_nt(gz, wnd, addend=dense.mm_nt(gm, wsd))
                 if ctx.gate_input:
                     gh = torch.ops.aten.threshold_backward(gh, h, 0)
         return gh, gws, gwn, None, None, None, None, None

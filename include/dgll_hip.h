@@ -279,6 +279,18 @@ int dgll_host_translate_neighbors(const int64_t* indptr, const int64_t* indices,
 int dgll_hip_gemm_f32(void* stream, const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
                       int64_t M, int N, int K, const float* bias, int relu);
 
+/* ---- fp32 dense products on the matrix cores (the 1e-4 parity path of the layers) -------------------------------------------
+ * dgll_hip_mm_f32:  C[M, N] = act(A[M, K] . Wt[N, K]^T + addend + bias), everything fp32, v_mfma_f32_32x32x2_f32 (fp32 inputs, fp32
+ * accumulation: exact fp32 FMA arithmetic).  Wt is the weight TRANSPOSED ([N, K] row-major; for an input gradient g . W^T pass
+ * Wt := W).  N <= 256 per call (split columns on the host); any alignment (16-byte aligned rows take float4 loads).
+ * dgll_hip_grad_weight_f32:  dW[K, N] = X[M, K]^T . G[M, N]: the long reduction is split over `slabs` row slabs whose partials
+ * (workspace: dgll_hip_grad_weight_f32_workspace bytes) are summed in slab order -- deterministic, no atomics.             */
+int dgll_hip_mm_f32(void* stream, const float* A, int64_t lda, const float* Wt, int64_t ldw, float* C, int64_t ldc,
+                    int64_t M, int N, int K, const float* bias, int relu, const float* addend, int64_t ldadd);
+int64_t dgll_hip_grad_weight_f32_workspace(int K, int N, int slabs);
+int dgll_hip_grad_weight_f32(void* stream, const float* X, int64_t ldx, const float* G, int64_t ldg, float* dW,
+                             int64_t lddw, int64_t M, int K, int N, void* workspace, int64_t workspace_bytes, int slabs);
+
 /* ---- bf16 MFMA transform: out[M,N] = act( A1[M,K1].Wt1[N,K1]^T (+ A2[M,K2].Wt2[N,K2]^T) + bias ) -------------
  * The dense W-transform next to the aggregation on matrix cores (v_mfma_f32_32x32x16_bf16, fp32 accumulation):
  * sageConv's act(src.W_s + agg.W_n) in ONE pass (sageconv.py:71-82), gcnConv / GAT x.W (gcnconv.py:30,
