@@ -162,7 +162,12 @@ class GraphCacheServer:
             nids = nids.to(self.device, dtype=torch.int64, non_blocking=True)
             n = int(nids.numel())
             if out is None:
-                out = torch.empty((n, self.total_dim), dtype=self.features.dtype, device=self.device)
+                # rows start on 16-byte boundaries (602 bf16 columns -> a leading dimension of 608): what consumes them -- the
+                # MFMA transform, the split-K weight gradient -- then reads them as they are instead of re-laying them out
+                epv = 16 // self.features.element_size()
+                ld = -(-self.total_dim // epv) * epv
+                store = torch.empty((n, ld), dtype=self.features.dtype, device=self.device)
+                out = store[:, :self.total_dim] if ld != self.total_dim else store
             if n == 0:
                 return out
             with self._pending_lock:
@@ -220,7 +225,10 @@ def gather_rows(x, idx, out=None):
     """x[idx] for a device (or pinned host) matrix x through the HIP gather kernel (dgraph.py:105)."""
     dev = idx.device
     if out is None:
-        out = torch.empty((idx.numel(), x.shape[1]), dtype=x.dtype, device=dev)
+        epv = 16 // x.element_size()
+        ld = -(-x.shape[1] // epv) * epv
+        store = torch.empty((idx.numel(), ld), dtype=x.dtype, device=dev)
+        out = store[:, :x.shape[1]] if ld != x.shape[1] else store
     with torch.cuda.device(dev):
         code = _lib.lib.dgll_hip_gather_rows(torch.cuda.current_stream(dev).cuda_stream, None, 0, x.data_ptr(), x.stride(0),
                                              idx.data_ptr(), None, out.data_ptr(), out.stride(0), int(idx.numel()), x.shape[1],

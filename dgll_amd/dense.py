@@ -248,7 +248,8 @@ def _grad_weight_hip(x1, x2, g):
     k1, k2 = x1.shape[1], (x2.shape[1] if x2 is not None else 0)
     types = (-(-k1 // 64) + -(-k2 // 64) + 3) // 4
     n_cu = torch.cuda.get_device_properties(g.device).multi_processor_count
-    slabs = max(1, min(4096, n_cu // types, -(-m // 16)))
+    slabs = max(1, min(4096, n_cu // types, -(-m // 1024)))     # at least ~1024 rows per slab: short operands (sampled blocks)
+                                                                 # would otherwise pay for summing hundreds of near-empty partials
     ld_max = max(x1.stride(0), x2.stride(0) if x2 is not None else 0, g.stride(0))
     while slabs < 4096 and (-(-m // slabs) + 256) * ld_max * 2 >= (1 << 32) - (1 << 20):   # the kernel's uint32 byte offsets
         slabs *= 2
@@ -304,9 +305,15 @@ def grad_weight(x, g):
     if k <= 256 and n <= 256:
         return _grad_weight_hip(x, None, g)[0]
     out = torch.empty((k, n), dtype=torch.float32, device=x.device)
-    for k0 in range(0, k, 256):
-        for n0 in range(0, n, 256):
-            out[k0:k0 + 256, n0:n0 + 256] = _grad_weight_hip(x[:, k0:k0 + 256], None, g[:, n0:n0 + 256])[0]
+    for n0 in range(0, n, 256):
+        gs = g[:, n0:n0 + 256]
+        for k0 in range(0, k, 512):          # two 256-column blocks of x per launch: g is read once for both
+            x1 = x[:, k0:k0 + 256]
+            x2 = x[:, k0 + 256:k0 + 512] if k0 + 256 < k else None
+            d1, d2 = _grad_weight_hip(x1, x2, gs)
+            out[k0:k0 + 256, n0:n0 + 256] = d1
+            if d2 is not None:
+                out[k0 + 256:k0 + 512, n0:n0 + 256] = d2
     return out
 
 
