@@ -84,10 +84,27 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t nblocks) {
 // fast path (global_load_dwordx4) and sizeof(T) on the any-alignment path.
 template <typename T, int EPV> struct VecIO;
 
+// streaming forms of a 16-byte access: data that is touched once by a launch (a row of its own operand or result, as opposed
+// to the gathered rows that are re-read many times) should not displace the gathered rows in L2
+__device__ __forceinline__ uint4 load16_nt(const void* p) {
+    typedef __attribute__((ext_vector_type(4))) unsigned int u4;
+    const u4 v = __builtin_nontemporal_load(reinterpret_cast<const u4*>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void store16_nt(void* p, uint4 d) {
+    typedef __attribute__((ext_vector_type(4))) unsigned int u4;
+    const u4 v = {d.x, d.y, d.z, d.w};
+    __builtin_nontemporal_store(v, reinterpret_cast<u4*>(p));
+}
+
 template <> struct VecIO<float, 4> {
     typedef uint4 raw_t;
     static __device__ __forceinline__ raw_t zero() { return make_uint4(0, 0, 0, 0); }
     static __device__ __forceinline__ raw_t load(const float* p) { return *reinterpret_cast<const uint4*>(p); }
+    static __device__ __forceinline__ raw_t load_nt(const float* p) { return load16_nt(p); }
+    static __device__ __forceinline__ void store_nt(float* p, const float (&f)[4]) {
+        store16_nt(p, make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3])));
+    }
     static __device__ __forceinline__ void unpack(const raw_t& r, float (&f)[4]) {
         f[0] = __uint_as_float(r.x); f[1] = __uint_as_float(r.y); f[2] = __uint_as_float(r.z); f[3] = __uint_as_float(r.w);
     }
@@ -106,6 +123,7 @@ template <> struct VecIO<bf16_t, 8> {
     typedef uint4 raw_t;
     static __device__ __forceinline__ raw_t zero() { return make_uint4(0, 0, 0, 0); }
     static __device__ __forceinline__ raw_t load(const bf16_t* p) { return *reinterpret_cast<const uint4*>(p); }
+    static __device__ __forceinline__ raw_t load_nt(const bf16_t* p) { return load16_nt(p); }
     static __device__ __forceinline__ void unpack(const raw_t& r, float (&f)[8]) {
         f[0] = bf16_lo(r.x); f[1] = bf16_hi(r.x); f[2] = bf16_lo(r.y); f[3] = bf16_hi(r.y);
         f[4] = bf16_lo(r.z); f[5] = bf16_hi(r.z); f[6] = bf16_lo(r.w); f[7] = bf16_hi(r.w);

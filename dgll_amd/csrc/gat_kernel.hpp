@@ -121,8 +121,8 @@ __global__ __launch_bounds__(kBlock) void gat2_kernel(const EdgeArgs a) {
     if constexpr (KIND == 1) {
         const float inv_den = 1.0f / a.DEN[row * a.heads + head];
         float g[EPV], o[EPV];
-        IO::unpack(col_ok ? IO::load(static_cast<const XT*>(a.G) + row * a.ldg + c0) : IO::zero(), g);
-        IO::unpack(col_ok ? IO::load(static_cast<const XT*>(a.O) + row * a.ldo + c0) : IO::zero(), o);
+        IO::unpack(col_ok ? IO::load_nt(static_cast<const XT*>(a.G) + row * a.ldg + c0) : IO::zero(), g);   // row-side operands: streamed
+        IO::unpack(col_ok ? IO::load_nt(static_cast<const XT*>(a.O) + row * a.ldo + c0) : IO::zero(), o);
         float part = 0.0f;
 #pragma unroll
         for (int i = 0; i < EPV; ++i) {
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(kBlock) void gat2_kernel(const EdgeArgs a) {
         }
         dd = -head_sum_c<LPH>(part) * inv_den;
         if (slot == 0 && col_ok && it.first && !a.accumulate) {   // per-row outputs: written once (row itself / first chunk, first launch)
-            VecIO<XT, EPV>::store(static_cast<XT*>(a.Y) + row * a.ldy + c0, dn);
+            VecIO<XT, EPV>::store_nt(static_cast<XT*>(a.Y) + row * a.ldy + c0, dn);
             if (hs == 0) {
                 if (a.out_b) a.out_b[row * a.heads + head] = dd;
                 if (a.sd_out) {   // {s_i, dd_i} side by side where the transposed pass gathers them with ONE line fill per edge
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(kBlock) void gat2_kernel(const EdgeArgs a) {
         }
     }
     if constexpr (KIND == 2) {
-        const typename IO::raw_t raw = col_ok ? IO::load(static_cast<const XT*>(a.G) + row * a.ldg + c0) : IO::zero();
+        const typename IO::raw_t raw = col_ok ? IO::load_nt(static_cast<const XT*>(a.G) + row * a.ldg + c0) : IO::zero();
         if constexpr (BF) { rp[0] = raw.x; rp[1] = raw.y; rp[2] = raw.z; rp[3] = raw.w; }
         else IO::unpack(raw, hj);
     }
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(kBlock) void gat2_kernel(const EdgeArgs a) {
                         acc[i] = v;
                     }
                 }
-                VecIO<YT, EPV>::store(yrow, acc);
+                VecIO<YT, EPV>::store_nt(yrow, acc);
             }
             // the per-(row, head) scalars are written after every lane has read the previous launch's denominator
             __builtin_amdgcn_wave_barrier();
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(kBlock) void gat2_kernel(const EdgeArgs a) {
                 for (int i = 0; i < EPV; ++i) wsp[c0 + i] = acc[i];
                 if (hs == 0) wsp[a.ws_vec + head] = dt;
             } else {
-                VecIO<YT, EPV>::store(static_cast<YT*>(a.Y) + row * a.ldy + c0, acc);
+                VecIO<YT, EPV>::store_nt(static_cast<YT*>(a.Y) + row * a.ldy + c0, acc);
                 if (hs == 0) a.out_a[row * a.heads + head] = dt;
             }
         }

@@ -94,3 +94,42 @@ def test_bench_refuses_a_world_size_that_contradicts_gpus():
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SHAPE, capture_output=True, text=True,
                          timeout=300, env=env)
     assert res.returncode == 2 and "WORLD_SIZE" in res.stderr
+
+
+def test_bench_eight_ranks_on_one_gpu():
+    """The world-size-8 shape of BASELINE config 3 end to end (8 ranks share the one GPU over gloo: a functional run of the
+    partitioner, the halo exchange with seven peers, RaCoM and the JSON contract -- never a reported number)."""
+    env = dict(os.environ, DGLL_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"] + SHAPE, capture_output=True, text=True,
+                         timeout=1500, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    d = _last_json(res.stdout)
+    assert d["n_gpus"] == 8 and d["config"]["ranks"] == 8 and d["scaling"] == "strong" and "cpu_baseline" not in d
+    one = getattr(test_bench_single_rank_contract, "loss", None)
+    if one is not None:
+        assert abs(d["loss"] - one) < 3e-2 * abs(one)
+
+
+def test_bench_gat_workload_one_and_two_ranks():
+    """bench.py --workload gat (BASELINE config 4): the JSON contract with the GAT roofline formula, per-pass launch rows and
+    the GAT cpu_baseline; two ranks (gloo, one GPU) reach the same loss through the partitioned edge-softmax."""
+    shape = ["--workload", "gat", "--nodes", "20000", "--undirected-edges", "200000", "--hidden", "64", "--heads", "8", "--classes", "10",
+             "--in-feats", "40", "--steps", "2", "--warmup", "1", "--cpu-sample-rows", "2000"]
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + shape, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    d = _last_json(res.stdout)
+    assert d["config"]["workload_id"] == "gat" and d["config"]["gather_passes_per_step"] == 6 and d["roofline"]["bound"] == "hbm"
+    passes = {v["pass"] for v in d["spmm_launch_table"].values() if "pass" in v}
+    assert passes == {"fwd", "bwd_rows", "bwd_cols"}
+    assert "gat2_kernel" in d["roofline"]["kernel_fragment"] and d["roofline"]["frac_definition"]
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0 and "gat_pass_over_spmm" in d
+    env = dict(os.environ, DGLL_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    res2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + shape, capture_output=True, text=True,
+                          timeout=900, env=env)
+    assert res2.returncode == 0, res2.stderr[-3000:]
+    d2 = _last_json(res2.stdout)
+    assert d2["n_gpus"] == 2 and abs(d2["loss"] - d["loss"]) < 3e-2 * abs(d["loss"])

@@ -118,7 +118,7 @@ def test_racom_async_queue_and_periodic_sync():
     mp.spawn(_racom_worker, args=(2, _free_port()), nprocs=2, join=True)
 
 
-@pytest.mark.parametrize("world,weighted,feat", [(2, False, 12), (2, True, 7), (3, False, 5)])
+@pytest.mark.parametrize("world,weighted,feat", [(2, False, 12), (2, True, 7), (3, False, 5), (8, False, 6)])
 def test_partitioned_aggregation_matches_single_process(world, weighted, feat):
     mp.spawn(_worker, args=(world, _free_port(), weighted, feat), nprocs=world, join=True)
 
@@ -172,7 +172,7 @@ def _rows_worker(rank, world, port):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_partition_from_own_row_block_equals_the_full_graph_construction(world):
     mp.spawn(_rows_worker, args=(world, _free_port()), nprocs=world, join=True)
 
@@ -235,6 +235,6 @@ def _ddp_worker(rank, world, port):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4, 3])
+@pytest.mark.parametrize("world", [2, 4, 3, 8])
 def test_racom_sync_form_equals_ddp_bit_for_bit(world):
     mp.spawn(_ddp_worker, args=(world, _free_port()), nprocs=world, join=True)
