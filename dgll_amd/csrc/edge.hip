@@ -399,7 +399,14 @@ __global__ __launch_bounds__(kBlock) void gat_long_finalize_kernel(const EdgeArg
             float sacc = 0.0f;
             for (int c = cb; c < ce; ++c) sacc += a.ws[(int64_t)c * a.ws_ld + off];
             if (vec) {
-                if (kind == 2) store_one<YT>(static_cast<YT*>(a.Y) + row * a.ldy + f, sacc);
+                if (kind == 2) {
+                    if (a.attn1) {      // the scores' own contribution to grad_H (see edge_args.hpp): the head's dt first
+                        float dt = 0.0f;
+                        for (int c = cb; c < ce; ++c) dt += a.ws[(int64_t)c * a.ws_ld + a.ws_vec + head];
+                        sacc += a.gs_rows[row * a.heads + head] * a.attn1[f] + dt * a.attn2[f];
+                    }
+                    store_one<YT>(static_cast<YT*>(a.Y) + row * a.ldy + f, sacc);
+                }
             } else {
                 my_head = head;
                 my_den = ((kind == 1 && a.accumulate) ? a.out_a[row * a.heads + head] : 0.0f) + sacc;
@@ -463,6 +470,11 @@ __global__ __launch_bounds__(kBlock) void gat_long_finalize_wave_kernel(const Ed
             }
             float o[4] = {v.x, v.y, v.z, v.w};
             YT* y = static_cast<YT*>(a.Y) + row * a.ldy + f;
+            if (kind == 2 && a.attn1) {      // the scores' own contribution to grad_H (edge_args.hpp); `den` is the head's dt here
+                const float gs = a.gs_rows[row * a.heads + head];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] += gs * a.attn1[f + i] + den * a.attn2[f + i];
+            }
             if (kind == 0) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -872,7 +884,8 @@ static int gat_bwd_cols_impl(void* stream, const dgll_csr_plan* t_plan, const in
                              const float* T_row, const float* S_col, const float* dd_col, int col_stride, const float* rowmax_col,
                              const float* edge_scale, void* grad_H, int64_t ldgh, float* grad_T, int dtype,
                              int64_t n_rows_t, int heads, int fo, float alpha, int mode, void* workspace,
-                             size_t workspace_bytes) {
+                             size_t workspace_bytes, const float* attn1 = nullptr, const float* attn2 = nullptr,
+                             const float* grad_S_rows = nullptr) {
     if (n_rows_t <= 0) return DGLL_OK;
     EdgeArgs t{};
     int rc = gat_common(t, t_rowptr, t_col, n_rows_t, heads, fo, dtype, alpha, mode, 0);
@@ -885,6 +898,8 @@ static int gat_bwd_cols_impl(void* stream, const dgll_csr_plan* t_plan, const in
                  "matrices must be 16-byte aligned with padded leading dimensions");
     t.perm = t_perm; t.H = dn; t.ldh = ldn; t.G = Hrow; t.ldg = ldh; t.S = T_row; t.T = S_col; t.DD = dd_col;
     t.tstride = col_stride > 0 ? col_stride : heads;
+    DGLL_REQUIRE(!attn1 || (attn2 && grad_S_rows), "the score-gradient epilogue needs a1, a2 and the rows' grad_S");
+    t.attn1 = attn1; t.attn2 = attn2; t.gs_rows = grad_S_rows;
     t.M = mode == 1 ? rowmax_col : nullptr; t.edge_scale = edge_scale; t.Y = grad_H; t.ldy = ldgh; t.out_a = grad_T;
     t.out_b = nullptr;
     dim3 grid(1, 1, 1);
@@ -897,6 +912,7 @@ static int gat_bwd_cols_impl(void* stream, const dgll_csr_plan* t_plan, const in
     } else {
         rc = gat1_pick(t, epv, &lph, &lpr, &grid.y);
         if (rc != DGLL_OK) return rc;
+        DGLL_REQUIRE(!attn1, "the score-gradient epilogue needs the second-generation kernels");
 #define CALL(L)                                                                                                                  \
     if (dtype == DGLL_F32) hipLaunchKernelGGL((gat_bwd_cols_kernel<float, float, 4, L, 2>), grid, dim3(kBlock), 0, s, t, lph);   \
     else hipLaunchKernelGGL((gat_bwd_cols_kernel<bf16_t, bf16_t, 8, L, 2>), grid, dim3(kBlock), 0, s, t, lph);
@@ -960,11 +976,12 @@ DGLL_API int dgll_hip_gat_bwd_cols_strided(void* stream, const dgll_csr_plan* t_
                                            const int32_t* t_col, const void* dn_scratch, int64_t ldn, const void* H,
                                            int64_t ldh, const float* T_rows, const float* sd_scratch, int sd_stride,
                                            void* grad_H, int64_t ldgh, float* grad_T, int dtype, int64_t n_cols, int heads,
-                                           int fo, float alpha, void* workspace, size_t workspace_bytes) {
+                                           int fo, float alpha, void* workspace, size_t workspace_bytes,
+                                           const float* attn1, const float* attn2, const float* grad_S_rows) {
     DGLL_REQUIRE(sd_scratch && sd_stride >= 2 * heads && T_rows, "bad strided score arguments");
     return gat_bwd_cols_impl(stream, t_plan, t_rowptr, t_col, nullptr, dn_scratch, ldn, H, ldh, T_rows, sd_scratch,
                              sd_scratch + heads, sd_stride, nullptr, nullptr, grad_H, ldgh, grad_T, dtype, n_cols, heads, fo,
-                             alpha, 0, workspace, workspace_bytes);
+                             alpha, 0, workspace, workspace_bytes, attn1, attn2, grad_S_rows);
 }
 
 DGLL_API int dgll_hip_gat_bwd_strided(void* stream, const dgll_csr_plan* plan, const dgll_csr_plan* t_plan,
@@ -982,7 +999,8 @@ DGLL_API int dgll_hip_gat_bwd_strided(void* stream, const dgll_csr_plan* plan, c
     if (rc != DGLL_OK) return rc;
     // the same workspace is reused: pass 2 is stream-ordered after pass 1
     return dgll_hip_gat_bwd_cols_strided(stream, t_plan, t_rowptr, t_col, dn_scratch, ldn, H, ldh, T_rows, sd_scratch, sd_stride,
-                                         grad_H, ldgh, grad_T, dtype, n_cols, heads, fo, alpha, workspace, workspace_bytes);
+                                         grad_H, ldgh, grad_T, dtype, n_cols, heads, fo, alpha, workspace, workspace_bytes,
+                                         nullptr, nullptr, nullptr);
 }
 
 DGLL_API int dgll_hip_segment_max(void* stream, const int64_t* rowptr, const int32_t* col, const void* X, int64_t ldx,

@@ -46,6 +46,11 @@ struct EdgeArgs {
     int tstride;                // node stride, in floats, of the gathered-side score arrays T / DD (compact arrays: heads)
     float* sd_out;              // rows pass, optional: {s_i, dd_i} written side by side, s at [row * sd_stride + head],
     int sd_stride;              //   dd at [row * sd_stride + heads + head]
+    // transposed pass, optional: the scores' own contribution to grad_H is added in the epilogue,
+    //   grad_H[j, f] += grad_S[j, head(f)] * attn1[f] + grad_T[j, head(f)] * attn2[f]        (S = H.a1, T = H.a2 per head)
+    const float* attn1;         // fp32 [heads * fo]: a1 of every head, laid out like a row of H
+    const float* attn2;         // fp32 [heads * fo]
+    const float* gs_rows;       // fp32 [n_rows of this pass, heads]: grad_S of the pass's rows (from the rows pass)
 };
 
 // Work item of this wavefront: a whole (short) row, or one chunk of a long row.

@@ -80,6 +80,7 @@ __global__ __launch_bounds__(kBlock) void gat2_kernel(const EdgeArgs a) {
     constexpr bool BF = sizeof(XT) == 2;
     __shared__ rec_t rec_all[kWavesPerBlock][NH * kRecStride];
     __shared__ float rec1_all[KIND == 2 ? kWavesPerBlock : 1][KIND == 2 ? NH * kRecStride : 1];
+    __shared__ float attn_all[KIND == 2 ? 2 : 1][KIND == 2 ? LPR * EPV : 1];   // a1 | a2 of this column block (score-gradient epilogue)
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     rec_t* __restrict__ rec = rec_all[wave];
@@ -95,6 +96,17 @@ __global__ __launch_bounds__(kBlock) void gat2_kernel(const EdgeArgs a) {
     float* __restrict__ rec1 = rec1_all[KIND == 2 ? wave : 0];
     const float* __restrict__ my_rec1 = rec1 + hk * kRecStride;
 
+    if constexpr (KIND == 2) {
+        if (a.attn1) {      // staged once per workgroup: the epilogue of every row reads them (from global memory it cost 0.6 ms per pass)
+            for (int i = threadIdx.x; i < LPR * EPV; i += kBlock) {
+                const int hh = h0 + i / (LPH * EPV), cc = i % (LPH * EPV);
+                const bool ok = hh < a.heads && cc < a.fo;
+                attn_all[0][i] = ok ? a.attn1[hh * a.fo + cc] : 0.0f;
+                attn_all[1][i] = ok ? a.attn2[hh * a.fo + cc] : 0.0f;
+            }
+            __syncthreads();
+        }
+    }
     WorkItem it = resolve_item(a, wave, 0);
     int col_first = 0;                                             // the item's first index batch (lane = edge), prefetched
     if (it.valid && it.b + lane < it.e) col_first = __builtin_nontemporal_load(a.col + it.b + lane);
@@ -152,7 +164,9 @@ __global__ __launch_bounds__(kBlock) void gat2_kernel(const EdgeArgs a) {
             for (int q = 0; q < 4; ++q) rp[q] = pack_bf16x2(dn[2 * q], dn[2 * q + 1]);
         }
     }
+    float gs_row = 0.0f;               // KIND 2: grad_S of this row's head (score-gradient epilogue), requested before the gather
     if constexpr (KIND == 2) {
+        if (a.attn1 && it.chunk < 0) gs_row = a.gs_rows[row * a.heads + head];
         const typename IO::raw_t raw = col_ok ? IO::load_nt(static_cast<const XT*>(a.G) + row * a.ldg + c0) : IO::zero();
         if constexpr (BF) { rp[0] = raw.x; rp[1] = raw.y; rp[2] = raw.z; rp[3] = raw.w; }
         else IO::unpack(raw, hj);
@@ -312,6 +326,12 @@ __global__ __launch_bounds__(kBlock) void gat2_kernel(const EdgeArgs a) {
                 for (int i = 0; i < EPV; ++i) wsp[c0 + i] = acc[i];
                 if (hs == 0) wsp[a.ws_vec + head] = dt;
             } else {
+                if (a.attn1) {   // d(scores)/dH: S = H.a1, T = H.a2 per head -- their gradients land here instead of in a GEMM + add
+                    const float* p1 = attn_all[0] + sub * EPV;
+                    const float* p2 = attn_all[KIND == 2 ? 1 : 0] + sub * EPV;
+#pragma unroll
+                    for (int i = 0; i < EPV; ++i) acc[i] += gs_row * p1[i] + dt * p2[i];
+                }
                 VecIO<YT, EPV>::store_nt(static_cast<YT*>(a.Y) + row * a.ldy + c0, acc);
                 if (hs == 0) a.out_a[row * a.heads + head] = dt;
             }

@@ -61,12 +61,16 @@ def _fused_heads(x, adj, Ws, a1s, a2s, alpha, concat, mode, dropout, training):
     for k in range(heads):
         A[k * fo_pad:k * fo_pad + fo, k] = a1s[k].to(h.dtype)
         A[k * fo_pad:k * fo_pad + fo, heads + k] = a2s[k].to(h.dtype)
-    st = dense.skinny_linear(h, A)                                             # fp32 [N, 2*heads]
-    s, t = st[:, :heads], st[:, heads:]
-    # h is this function's own temporary (dense.linear allocates narrow rows on 128-byte lines): its row padding may carry
-    # the per-node scores the gather passes fetch per edge
-    out = ops.gat_aggregate(graph, h, s, t, heads, alpha, apply_elu=concat, mode=mode, edge_scale=edge_scale,
-                            pack_scores=strided)
+    if strided and graph.n_rows == graph.n_cols:
+        # scores + aggregation as ONE autograd node (ops.gat_layer): the scores' own gradient w.r.t. h rides in the epilogue of
+        # the transposed gather pass.  h is this function's own temporary (dense.linear allocates narrow rows on 128-byte
+        # lines): its row padding may carry the per-node scores the gather passes fetch per edge
+        out = ops.gat_layer(graph, h, A, heads, alpha, apply_elu=concat, pack_scores=True)
+    else:
+        st = dense.skinny_linear(h, A)                                         # fp32 [N, 2*heads]
+        s, t = st[:, :heads], st[:, heads:]
+        out = ops.gat_aggregate(graph, h, s, t, heads, alpha, apply_elu=concat, mode=mode, edge_scale=edge_scale,
+                                pack_scores=strided)
     out = _unpad_heads(out, heads, fo, fo_pad)
     if _CHECK_NAN:
         assert not F.isnan(out).any()

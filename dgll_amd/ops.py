@@ -281,4 +281,4 @@ def cross_entropy(logits, labels, reduction="mean"):
     return _CrossEntropy.apply(logits, labels, reduction)
 
 
-from .ops_edge import gat_aggregate, head_width_padded, sddmm_raw, segment_max  # noqa: E402,F401
+from .ops_edge import gat_aggregate, gat_layer, head_width_padded, sddmm_raw, segment_max  # noqa: E402,F401

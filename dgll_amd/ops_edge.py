@@ -144,42 +144,99 @@ def _empty_like_rows(n, like):
     return buf[:, :like.shape[1]] if like.stride(0) != like.shape[1] else buf
 
 
+def _gat_strided_forward(h, s, t, graph, heads, fo, alpha, apply_elu, pack_scores):
+    """Forward gather pass on dgll_hip_gat_fwd_strided.  Returns (h with aligned rows, s, t, out, rowsum, packed)."""
+    _require_cuda(h, s, t, graph.rowptr)
+    dev = h.device
+    h = _ready(h)
+    esz, width = h.element_size(), heads * fo
+    s = s.to(torch.float32).contiguous()
+    t = t.to(torch.float32).contiguous()
+    packed = bool(pack_scores) and (h.stride(0) - width) * esz >= 4 * heads
+    if packed:
+        t_gather = _row_slot(h, width * esz, heads)
+        t_gather.copy_(t)
+    else:
+        t_gather = t
+    out = _empty_like_rows(graph.n_rows, h)
+    rowsum = torch.empty((graph.n_rows, heads), dtype=torch.float32, device=dev)
+    plan = graph.plan()
+    ws_bytes = int(_lib.lib.dgll_hip_gat_workspace_bytes(plan, heads, fo))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
+    timer = _launch_timer()
+    end = timer.start(("gat", "fwd", heads, fo, str(h.dtype), graph.nnz, "packed" if packed else ""), dev) if timer else None
+    with torch.cuda.device(dev):
+        code = _lib.lib.dgll_hip_gat_fwd_strided(
+            _stream(dev), plan, graph.rowptr.data_ptr(), graph.col.data_ptr(), h.data_ptr(), h.stride(0), s.data_ptr(),
+            t_gather.data_ptr(), t_gather.stride(0), out.data_ptr(), out.stride(0), _dtype_code(h), rowsum.data_ptr(),
+            graph.n_rows, heads, fo, float(alpha), int(apply_elu), ws.data_ptr() if ws is not None else None, ws_bytes)
+    if end is not None:
+        end.record(torch.cuda.current_stream(dev))
+    _lib.check(code, "dgll_hip_gat_fwd_strided")
+    return h, s, t, out, rowsum, packed
+
+
+def _gat_strided_backward(g, h, s, t, out, rowsum, graph, heads, fo, alpha, apply_elu, packed, attn=None):
+    """Both backward gather passes (dgll_hip_gat_bwd_rows_strided, _cols_strided).  attn = (a1, a2) fp32 [heads * fo]: the
+    scores are S = H.a1, T = H.a2 per head and their contribution to grad_h is added by the second pass's epilogue.
+    Returns (grad_h, grad_s, grad_t)."""
+    dev, esz, width = h.device, h.element_size(), heads * fo
+    g = _ready(g.to(h.dtype))
+    gt, _ = graph.transpose()
+    dn = _empty_like_rows(graph.n_rows, h)
+    t_gather = _row_slot(h, width * esz, heads) if packed else t       # written by the forward; h's padding is ours
+    if packed and (dn.stride(0) - width) * esz >= 8 * heads:
+        sd = _row_slot(dn, width * esz, 2 * heads)
+    else:
+        sd = torch.empty((graph.n_rows, 2 * heads), dtype=torch.float32, device=dev)
+    grad_h = _empty_like_rows(graph.n_cols, h)
+    grad_s = torch.empty((graph.n_rows, heads), dtype=torch.float32, device=dev)
+    grad_t = torch.empty((graph.n_cols, heads), dtype=torch.float32, device=dev)
+    plan, t_plan = graph.plan(), gt.plan()
+    ws_bytes = max(int(_lib.lib.dgll_hip_gat_workspace_bytes(plan, heads, fo)),
+                   int(_lib.lib.dgll_hip_gat_workspace_bytes(t_plan, heads, fo)))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
+    timer = _launch_timer()
+    tag = (heads, fo, str(h.dtype), graph.nnz, "packed" if packed else "")
+    wsp = ws.data_ptr() if ws is not None else None
+    a1 = a2 = None
+    if attn is not None:
+        if graph.n_rows != graph.n_cols:
+            raise ValueError("the score-gradient epilogue needs a square adjacency (grad_S of the rows the transposed pass owns)")
+        a1, a2 = (v.detach().to(torch.float32).contiguous() for v in attn)
+    with torch.cuda.device(dev):
+        st = _stream(dev)
+        end = timer.start(("gat", "bwd_rows") + tag, dev) if timer else None
+        code = _lib.lib.dgll_hip_gat_bwd_rows_strided(
+            st, plan, graph.rowptr.data_ptr(), graph.col.data_ptr(), h.data_ptr(), h.stride(0), s.data_ptr(),
+            t_gather.data_ptr(), t_gather.stride(0), out.data_ptr(), out.stride(0), g.data_ptr(), g.stride(0), _dtype_code(h),
+            rowsum.data_ptr(), dn.data_ptr(), dn.stride(0), sd.data_ptr(), sd.stride(0), grad_s.data_ptr(), graph.n_rows,
+            heads, fo, alpha, apply_elu, wsp, ws_bytes)
+        if end is not None:
+            end.record(torch.cuda.current_stream(dev))
+        _lib.check(code, "dgll_hip_gat_bwd_rows_strided")
+        end = timer.start(("gat", "bwd_cols") + tag, dev) if timer else None
+        code = _lib.lib.dgll_hip_gat_bwd_cols_strided(
+            st, t_plan, gt.rowptr.data_ptr(), gt.col.data_ptr(), dn.data_ptr(), dn.stride(0), h.data_ptr(), h.stride(0),
+            t.data_ptr(), sd.data_ptr(), sd.stride(0), grad_h.data_ptr(), grad_h.stride(0), grad_t.data_ptr(), _dtype_code(h),
+            graph.n_cols, heads, fo, alpha, wsp, ws_bytes, a1.data_ptr() if a1 is not None else None,
+            a2.data_ptr() if a2 is not None else None, grad_s.data_ptr() if a1 is not None else None)
+        if end is not None:
+            end.record(torch.cuda.current_stream(dev))
+        _lib.check(code, "dgll_hip_gat_bwd_cols_strided")
+    return grad_h, grad_s, grad_t
+
+
 class _GatAggregateStrided(torch.autograd.Function):
     """sparseGatConv's form (exp(-leakyrelu), no attention dropout) on the second-generation kernels
-    (dgll_hip_gat_fwd_strided / _bwd_strided).  These passes are bound by cache-line fills per edge, so per-node scalars that
-    are gathered per edge live next to what is gathered anyway: with `pack_scores` (the caller owns the padding behind h's
-    rows) T sits in the padding of the feature rows -- a 47-class output row is 96 of 128 bytes -- and the backward keeps
+    (dgll_hip_gat_fwd_strided / _bwd_*_strided).  These passes are bound by cache-line fills per edge, so per-node scalars
+    that are gathered per edge live next to what is gathered anyway: with `pack_scores` (the caller owns the padding behind
+    h's rows) T sits in the padding of the feature rows -- a 47-class output row is 96 of 128 bytes -- and the backward keeps
     {s_i, dd_i} in the padding of its DN rows; without room they are compact / side-by-side arrays."""
 
     @staticmethod
     def forward(ctx, h, s, t, graph, heads, fo, alpha, apply_elu, pack_scores):
-        _require_cuda(h, s, t, graph.rowptr)
-        dev = h.device
-        h = _ready(h)
-        esz, width = h.element_size(), heads * fo
-        s = s.to(torch.float32).contiguous()
-        t = t.to(torch.float32).contiguous()
-        packed = bool(pack_scores) and (h.stride(0) - width) * esz >= 4 * heads
-        if packed:
-            t_gather = _row_slot(h, width * esz, heads)
-            t_gather.copy_(t)
-        else:
-            t_gather = t
-        out = _empty_like_rows(graph.n_rows, h)
-        rowsum = torch.empty((graph.n_rows, heads), dtype=torch.float32, device=dev)
-        plan = graph.plan()
-        ws_bytes = int(_lib.lib.dgll_hip_gat_workspace_bytes(plan, heads, fo))
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
-        timer = _launch_timer()
-        end = timer.start(("gat", "fwd", heads, fo, str(h.dtype), graph.nnz, "packed" if packed else ""), dev) if timer else None
-        with torch.cuda.device(dev):
-            code = _lib.lib.dgll_hip_gat_fwd_strided(
-                _stream(dev), plan, graph.rowptr.data_ptr(), graph.col.data_ptr(), h.data_ptr(), h.stride(0), s.data_ptr(),
-                t_gather.data_ptr(), t_gather.stride(0), out.data_ptr(), out.stride(0), _dtype_code(h), rowsum.data_ptr(),
-                graph.n_rows, heads, fo, float(alpha), int(apply_elu), ws.data_ptr() if ws is not None else None, ws_bytes)
-        if end is not None:
-            end.record(torch.cuda.current_stream(dev))
-        _lib.check(code, "dgll_hip_gat_fwd_strided")
+        h, s, t, out, rowsum, packed = _gat_strided_forward(h, s, t, graph, heads, fo, alpha, apply_elu, pack_scores)
         ctx.graph, ctx.cfg, ctx.packed = graph, (heads, fo, float(alpha), int(apply_elu)), packed
         ctx.save_for_backward(h, s, t, out, rowsum)
         return out
@@ -187,50 +244,51 @@ class _GatAggregateStrided(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         h, s, t, out, rowsum = ctx.saved_tensors
-        graph = ctx.graph
         heads, fo, alpha, apply_elu = ctx.cfg
-        dev, esz, width = h.device, h.element_size(), heads * fo
-        g = _ready(g.to(h.dtype))
-        gt, _ = graph.transpose()
-        dn = _empty_like_rows(graph.n_rows, h)
-        if ctx.packed:
-            t_gather = _row_slot(h, width * esz, heads)          # written by the forward; h's padding is ours
-        else:
-            t_gather = t
-        if ctx.packed and (dn.stride(0) - width) * esz >= 8 * heads:
-            sd = _row_slot(dn, width * esz, 2 * heads)
-        else:
-            sd = torch.empty((graph.n_rows, 2 * heads), dtype=torch.float32, device=dev)
-        grad_h = _empty_like_rows(graph.n_cols, h)
-        grad_s = torch.empty((graph.n_rows, heads), dtype=torch.float32, device=dev)
-        grad_t = torch.empty((graph.n_cols, heads), dtype=torch.float32, device=dev)
-        plan, t_plan = graph.plan(), gt.plan()
-        ws_bytes = max(int(_lib.lib.dgll_hip_gat_workspace_bytes(plan, heads, fo)),
-                       int(_lib.lib.dgll_hip_gat_workspace_bytes(t_plan, heads, fo)))
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
-        timer = _launch_timer()
-        tag = (heads, fo, str(h.dtype), graph.nnz, "packed" if ctx.packed else "")
-        wsp = ws.data_ptr() if ws is not None else None
-        with torch.cuda.device(dev):
-            st = _stream(dev)
-            end = timer.start(("gat", "bwd_rows") + tag, dev) if timer else None
-            code = _lib.lib.dgll_hip_gat_bwd_rows_strided(
-                st, plan, graph.rowptr.data_ptr(), graph.col.data_ptr(), h.data_ptr(), h.stride(0), s.data_ptr(),
-                t_gather.data_ptr(), t_gather.stride(0), out.data_ptr(), out.stride(0), g.data_ptr(), g.stride(0), _dtype_code(h),
-                rowsum.data_ptr(), dn.data_ptr(), dn.stride(0), sd.data_ptr(), sd.stride(0), grad_s.data_ptr(), graph.n_rows,
-                heads, fo, alpha, apply_elu, wsp, ws_bytes)
-            if end is not None:
-                end.record(torch.cuda.current_stream(dev))
-            _lib.check(code, "dgll_hip_gat_bwd_rows_strided")
-            end = timer.start(("gat", "bwd_cols") + tag, dev) if timer else None
-            code = _lib.lib.dgll_hip_gat_bwd_cols_strided(
-                st, t_plan, gt.rowptr.data_ptr(), gt.col.data_ptr(), dn.data_ptr(), dn.stride(0), h.data_ptr(), h.stride(0),
-                t.data_ptr(), sd.data_ptr(), sd.stride(0), grad_h.data_ptr(), grad_h.stride(0), grad_t.data_ptr(), _dtype_code(h),
-                graph.n_cols, heads, fo, alpha, wsp, ws_bytes)
-            if end is not None:
-                end.record(torch.cuda.current_stream(dev))
-            _lib.check(code, "dgll_hip_gat_bwd_cols_strided")
+        grad_h, grad_s, grad_t = _gat_strided_backward(g, h, s, t, out, rowsum, ctx.graph, heads, fo, alpha, apply_elu, ctx.packed)
         return grad_h, grad_s, grad_t, None, None, None, None, None, None
+
+
+class _GatLayerStrided(torch.autograd.Function):
+    """The whole attention layer after the transform: scores S = H.a1, T = H.a2 per head (one skinny product
+    H . blockdiag(a1 | a2), gatconv.py:122-125 without the [2 fo, E] edge matrix), then the aggregation above.  As ONE autograd
+    node the backward needs no [n, 2 heads] x [2 heads, heads * fo] product and no add over [n, heads * fo] for the scores'
+    contribution to grad_H: the transposed gather pass adds grad_S * a1 + grad_T * a2 in its epilogue."""
+
+    @staticmethod
+    def forward(ctx, h, A, graph, heads, fo, alpha, apply_elu, pack_scores):
+        from . import dense
+
+        h = _ready(h)
+        Ad = A.detach().to(h.dtype)
+        st = (dense.transform_bf16(h, Ad.t(), out_dtype=torch.float32) if (dense._mfma_ok(h) and Ad.shape[1] <= 256)
+              else dense.mm_nt(h, Ad.t()).float())
+        h, s, t, out, rowsum, packed = _gat_strided_forward(h, st[:, :heads], st[:, heads:], graph, heads, fo, alpha, apply_elu,
+                                                            pack_scores)
+        ctx.graph, ctx.cfg, ctx.packed = graph, (heads, fo, float(alpha), int(apply_elu)), packed
+        ctx.save_for_backward(h, Ad, s, t, out, rowsum)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import dense
+
+        h, Ad, s, t, out, rowsum = ctx.saved_tensors
+        heads, fo, alpha, apply_elu = ctx.cfg
+        # block-diagonal A: column k holds a1 of head k in rows k fo .. (k + 1) fo, column heads + k holds a2
+        a1 = Ad[:, :heads].float().sum(1)
+        a2 = Ad[:, heads:].float().sum(1)
+        grad_h, grad_s, grad_t = _gat_strided_backward(g, h, s, t, out, rowsum, ctx.graph, heads, fo, alpha, apply_elu, ctx.packed,
+                                                       attn=(a1, a2) if ctx.needs_input_grad[0] else None)
+        grad_A = None
+        if ctx.needs_input_grad[1]:      # dA = H^T . [grad_S | grad_T], columns padded to a 16-byte row for the split-K kernel
+            n = 2 * heads
+            pad = -n % 8
+            gst = torch.zeros((h.shape[0], n + pad), dtype=h.dtype, device=h.device)
+            gst[:, :heads] = grad_s
+            gst[:, heads:n] = grad_t
+            grad_A = dense.grad_weight(h, gst)[:, :n]
+        return (grad_h if ctx.needs_input_grad[0] else None), grad_A, None, None, None, None, None, None
 
 
 def _launch_timer():
@@ -312,6 +370,17 @@ def gat_aggregate(graph, h, s, t, heads, alpha, apply_elu=True, mode=0, edge_sca
     if strided:
         return _GatAggregateStrided.apply(h, s, t, graph, heads, fo, alpha, apply_elu, pack_scores)
     return _GatAggregate.apply(h, s, t, edge_scale, graph, heads, fo, alpha, apply_elu, mode)
+
+
+def gat_layer(graph, h, A, heads, alpha, apply_elu=True, pack_scores=False):
+    """sparseGatConv after its transform as one autograd node: h [N, heads*fo] (per-head width a whole number of 16-byte
+    vectors), A [heads*fo, 2*heads] = blockdiag(a1_k | a2_k).  GPU, mode 0, no attention dropout."""
+    if not isinstance(graph, CSRGraph):
+        raise TypeError("gat_layer expects a CSRGraph")
+    fo = h.shape[1] // heads
+    if fo * heads != h.shape[1] or head_width_padded(fo, h.dtype, pow2=False) != fo:
+        raise ValueError("per-head width %d is not a whole number of 16-byte vectors" % fo)
+    return _GatLayerStrided.apply(h, A, graph, heads, fo, alpha, apply_elu, pack_scores)
 
 
 # ------------------------------------------------------------------------------------------------ split launches

@@ -193,11 +193,16 @@ int dgll_hip_gat_bwd_rows_strided(void* stream, const dgll_csr_plan* plan, const
                                   const float* rowsum, void* dn_scratch, int64_t ldn, float* sd_scratch, int sd_stride,
                                   float* grad_S, int64_t n_rows, int heads, int fo, float alpha, int apply_elu,
                                   void* workspace, size_t workspace_bytes);
+/* attn1 / attn2 / grad_S_rows (all three or none): when the scores are S = H.a1, T = H.a2 per head (gatconv.py:122-125), their
+ * own contribution to grad_H is added in the epilogue -- grad_H[j, f] += grad_S[j, head(f)] * attn1[f] + grad_T[j, head(f)] *
+ * attn2[f], attn* fp32 [heads * fo] laid out like a row of H, grad_S_rows fp32 [n_cols, heads] from the rows pass -- instead of
+ * in a separate [n, 2 heads] x [2 heads, heads * fo] product and an add over [n, heads * fo].                              */
 int dgll_hip_gat_bwd_cols_strided(void* stream, const dgll_csr_plan* t_plan, const int64_t* t_rowptr,
                                   const int32_t* t_col, const void* dn_scratch, int64_t ldn, const void* H,
                                   int64_t ldh, const float* T_rows, const float* sd_scratch, int sd_stride,
                                   void* grad_H, int64_t ldgh, float* grad_T, int dtype, int64_t n_cols, int heads,
-                                  int fo, float alpha, void* workspace, size_t workspace_bytes);
+                                  int fo, float alpha, void* workspace, size_t workspace_bytes,
+                                  const float* attn1, const float* attn2, const float* grad_S_rows);
 int dgll_hip_gat_bwd_strided(void* stream, const dgll_csr_plan* plan, const dgll_csr_plan* t_plan,
                              const int64_t* rowptr, const int32_t* col, const int64_t* t_rowptr, const int32_t* t_col,
                              const void* H, int64_t ldh, const float* S, const float* T, int t_stride,
