@@ -122,7 +122,11 @@ class sageConv(F.nn.Module):
         of x_src, the usual block convention)."""
         if x_dst is None:
             x_dst = x_src[:block.n_rows]
-        if self.transform_first(x_src):
+        # A sampled block whose source rows each belong to exactly ONE edge (identity_cols: the reference's neighbour lists keep
+        # duplicates, dgllsampler.py:17) is aggregated FIRST whatever the widths: the reduction shrinks the row count by the
+        # fan-out before any product, and the weight gradient then runs over the destination rows, not over fan-out times as many
+        # sources.  (The narrow-product-first order pays when source rows are shared by many edges: the full graph.)
+        if self.transform_first(x_src) and not getattr(block, "identity_cols", False):
             # mean/sum are linear: reduce(X).W_n == reduce(X.W_n).  When the layer narrows (hidden < input) aggregate
             # the NARROW product -- fewer bytes per gathered edge in the forward and in the backward gather.
             z = dense.linear(x_src, self.neighborAgg.weight)

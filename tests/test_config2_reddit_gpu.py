@@ -202,11 +202,13 @@ def test_bf16_gradients_match_cpu_autograd_of_the_oracle(reddit_batch):
     assert float((got - ref_out.detach()).abs().max()) <= 2.0 ** -6 * max(float(ref_out.detach().abs().max()), rms)
     assert abs(float(loss.detach()) - float(ref_loss.detach())) < 2e-3 * abs(float(ref_loss.detach()))
 
-    def close(name, a, ref, tol=4e-2):
+    def close(name, a, ref, tol=5e-2):
         """bf16 backward vs the fp32 backward of the oracle.  Two things separate them: every stored gradient is rounded
         to bf16 (2^-9 relative per stage, three layers), and a ReLU gate can differ where a pre-activation is within
         rounding of zero -- harmless forward, but it switches one whole term of a gradient sum on or off.  So: the relative
-        L2 error is small, and all but a sliver of the entries are within `tol` of the gradient's scale."""
+        L2 error is small, and all but a sliver of the entries are within `tol` of the gradient's scale.  (Sampled blocks are
+        aggregated BEFORE the transform, the reference's own order, sageconv.py:33-41: the 602-wide mean is then stored in bf16,
+        measured 4.4e-2 on the first layer's weights against 3.6e-2 for the narrow-product-first order.)"""
         a, ref = a.detach().float().cpu(), ref.detach()
         scale = float(ref.abs().max())
         assert scale > 0, name
