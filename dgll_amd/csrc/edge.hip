@@ -629,7 +629,7 @@ static bool vec_ok(const void* p, int64_t ld, int esz) { return aligned16(p) && 
 
 }  // namespace dgll
 
-int g_tune_gat_gen = 0;      // dgll_hip_debug_tune(9, v): 1 = first-generation GAT kernels only
+int g_tune_gat_gen = 0;      // dgll_hip_debug_tune(9, v): 1 = first-generation GAT kernels only, 2 = second generation without the in-row form
 
 using namespace dgll;
 
@@ -745,6 +745,15 @@ static bool gat2_pick(const EdgeArgs& a, int* lpr, int* nh, uint32_t* grid_y) {
     return true;
 }
 
+// One head whose gathered-side scores sit right behind the last column of the gathered rows (same stride): the gather itself
+// can bring them along (gat2_kernel INROW).  `second`: an array that must sit one float after `first` (dd after s), or NULL.
+static bool gat2_inrow(const EdgeArgs& a, int lpr, int nh, int esz, const float* first, const float* second) {
+    if (g_tune_gat_gen == 2 || nh != 1 || a.heads != 1 || a.vph >= lpr) return false;
+    const char* slot = static_cast<const char*>(a.H) + (size_t)a.feat * esz;
+    return reinterpret_cast<const char*>(first) == slot && (int64_t)a.tstride * 4 == a.ldh * esz &&
+           (!second || second == first + 1) && (a.ldh - a.feat) * esz >= (second ? 8 : 4);
+}
+
 // Geometry of the first-generation kernels: per-head width a power-of-two number of vectors.
 static int gat1_pick(const EdgeArgs& a, int epv, int* lph, int* lpr, uint32_t* grid_y) {
     *lph = a.fo / epv;
@@ -783,7 +792,7 @@ static int gat_fwd_impl(void* stream, const dgll_csr_plan* plan, const int64_t* 
     hipStream_t s = static_cast<hipStream_t>(stream);
     int lpr, nh, lph;
     if (gat2_pick(a, &lpr, &nh, &grid.y)) {
-        if (!gat2_launch_0(dtype, lpr, nh, grid, s, a)) { set_error("no second-generation GAT kernel for this head layout"); return DGLL_ERR_UNSUPPORTED; }
+        if (!gat2_launch_0(dtype, lpr, nh, grid, s, a, gat2_inrow(a, lpr, nh, esz, a.T, nullptr))) { set_error("no second-generation GAT kernel for this head layout"); return DGLL_ERR_UNSUPPORTED; }
     } else {
         rc = gat1_pick(a, epv, &lph, &lpr, &grid.y);
         if (rc != DGLL_OK) return rc;
@@ -849,7 +858,7 @@ static int gat_bwd_rows_impl(void* stream, const dgll_csr_plan* plan, const int6
     hipStream_t s = static_cast<hipStream_t>(stream);
     int lpr, nh, lph;
     if (gat2_pick(a, &lpr, &nh, &grid.y)) {
-        if (!gat2_launch_1(dtype, lpr, nh, grid, s, a)) { set_error("no second-generation GAT kernel for this head layout"); return DGLL_ERR_UNSUPPORTED; }
+        if (!gat2_launch_1(dtype, lpr, nh, grid, s, a, gat2_inrow(a, lpr, nh, esz, a.T, nullptr))) { set_error("no second-generation GAT kernel for this head layout"); return DGLL_ERR_UNSUPPORTED; }
     } else {
         rc = gat1_pick(a, epv, &lph, &lpr, &grid.y);
         if (rc != DGLL_OK) return rc;
@@ -908,7 +917,7 @@ static int gat_bwd_cols_impl(void* stream, const dgll_csr_plan* t_plan, const in
     hipStream_t s = static_cast<hipStream_t>(stream);
     int lpr, nh, lph;
     if (gat2_pick(t, &lpr, &nh, &grid.y)) {
-        if (!gat2_launch_2(dtype, lpr, nh, grid, s, t)) { set_error("no second-generation GAT kernel for this head layout"); return DGLL_ERR_UNSUPPORTED; }
+        if (!gat2_launch_2(dtype, lpr, nh, grid, s, t, gat2_inrow(t, lpr, nh, esz, t.T, t.DD))) { set_error("no second-generation GAT kernel for this head layout"); return DGLL_ERR_UNSUPPORTED; }
     } else {
         rc = gat1_pick(t, epv, &lph, &lpr, &grid.y);
         if (rc != DGLL_OK) return rc;

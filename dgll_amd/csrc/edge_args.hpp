@@ -128,9 +128,10 @@ __device__ __forceinline__ void for_each_batch(const int32_t* __restrict__ col, 
 }
 
 // gat_fwd.hip / gat_bwd_rows.hip / gat_bwd_cols.hip: second-generation GAT passes (0 forward, 1 backward over the rows of A,
-// 2 backward over the rows of A^T) for `nh` heads per wavefront on `lpr` lanes per row.  False: no such instantiation.
-bool gat2_launch_0(int dtype, int lpr, int nh, dim3 grid, hipStream_t s, const EdgeArgs& a);
-bool gat2_launch_1(int dtype, int lpr, int nh, dim3 grid, hipStream_t s, const EdgeArgs& a);
-bool gat2_launch_2(int dtype, int lpr, int nh, dim3 grid, hipStream_t s, const EdgeArgs& a);
+// 2 backward over the rows of A^T) for `nh` heads per wavefront on `lpr` lanes per row; inrow: the gathered-side scores sit
+// in the padding of the gathered rows and arrive with the gather (one head).  False: no such instantiation.
+bool gat2_launch_0(int dtype, int lpr, int nh, dim3 grid, hipStream_t s, const EdgeArgs& a, bool inrow);
+bool gat2_launch_1(int dtype, int lpr, int nh, dim3 grid, hipStream_t s, const EdgeArgs& a, bool inrow);
+bool gat2_launch_2(int dtype, int lpr, int nh, dim3 grid, hipStream_t s, const EdgeArgs& a, bool inrow);
 
 }  // namespace dgll

@@ -2,7 +2,7 @@
 #include "gat_kernel.hpp"
 
 namespace dgll {
-bool gat2_launch_1(int dtype, int lpr, int nh, dim3 grid, hipStream_t s, const EdgeArgs& a) {
-    return gat2_launch_kind<1>(dtype, lpr, nh, grid, s, a);
+bool gat2_launch_1(int dtype, int lpr, int nh, dim3 grid, hipStream_t s, const EdgeArgs& a, bool inrow) {
+    return gat2_launch_kind<1>(dtype, lpr, nh, grid, s, a, inrow);
 }
 }  // namespace dgll

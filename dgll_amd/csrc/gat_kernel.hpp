@@ -71,7 +71,11 @@ __device__ __forceinline__ float head_sum_c(float v) {
 // KIND 0: forward.  KIND 1: backward over the rows of A (DN, DD, grad_S).  KIND 2: backward over the rows of A^T (grad_H, grad_T).
 // See edge.hip for the argument roles of each pass (they are unchanged).  Records (one per edge and head, wave-private LDS):
 //   KIND 0: w_ij            KIND 1: c_ij = w_ij * sign * lrelu'(z_ij)            KIND 2: { w_ij, c_ij } and dd_i * c_ij
-template <typename XT, typename YT, int EPV, int LPR, int NH, int U, int KIND>
+// INROW (one head, scores in the padding of the gathered rows themselves): the lane group's first idle lane reads the 16 bytes
+// behind the row's last column WITH the row -- t_j (or {s_i, dd_i} in the transposed pass) arrives with the gather, is broadcast
+// inside the lane group, and the record phase (a dependent load per batch, the LDS hand-over) disappears: for 8-lane rows the
+// passes are bound by exactly that per-row latency chain.
+template <typename XT, typename YT, int EPV, int LPR, int NH, int U, int KIND, bool INROW = false>
 __global__ __launch_bounds__(kBlock) void gat2_kernel(const EdgeArgs a) {
     typedef VecIO<XT, EPV> IO;
     typedef typename std::conditional<KIND == 2, float2, float>::type rec_t;   // KIND 2: {w_ij, c_ij}, plus dd_i * c_ij in rec1
@@ -90,7 +94,9 @@ __global__ __launch_bounds__(kBlock) void gat2_kernel(const EdgeArgs a) {
     const bool col_ok = h0 + hk < a.heads && hs < a.vph;           // a head may use fewer vectors than it has lanes (fo = 48: 6 of 8)
     const int head = col_ok ? h0 + hk : 0;
     const int c0 = col_ok ? head * a.fo + hs * EPV : 0;
-    const XT* hcol = static_cast<const XT*>(a.H) + (col_ok ? c0 : 0);
+    // INROW: the first idle lane of the group fetches the score slot behind the row's last column
+    const XT* hcol = static_cast<const XT*>(a.H) + (col_ok ? c0 : ((INROW && hs == a.vph) ? a.feat : 0));
+    const int tlane = (lane & ~(LPR - 1)) + a.vph;
     const uint32_t ld32 = (uint32_t)a.ldh;
     const rec_t* __restrict__ my_rec = rec + hk * kRecStride;
     float* __restrict__ rec1 = rec1_all[KIND == 2 ? wave : 0];
@@ -189,7 +195,7 @@ __global__ __launch_bounds__(kBlock) void gat2_kernel(const EdgeArgs a) {
         }
         // -- record phase: lane = edge.  (Measured alternative for 8 heads, lane = (edge, half) so that one load instruction
         // covers 32 edges with two adjacent lanes per 32-byte score row: forward unchanged, transposed pass 6.4 -> 7.8 ms.)
-        {
+        if constexpr (!INROW) {
             float tv[NH], dv[NH];
             load_heads<NH>(a.T, col_cur, a.tstride, a.heads, h0, tv);        // idle lanes hold column 0: a valid row
             if constexpr (KIND == 2) load_heads<NH>(a.DD, col_cur, a.tstride, a.heads, h0, dv);
@@ -219,8 +225,26 @@ __global__ __launch_bounds__(kBlock) void gat2_kernel(const EdgeArgs a) {
                 const int idx = j + u * SLOTS + slot;
                 const int cj = __shfl(gcol, idx);
                 v[u] = IO::load(hcol + (uint64_t)(uint32_t)cj * ld32);
-                rr[u] = my_rec[idx];
-                if constexpr (KIND == 2) r1[u] = my_rec1[idx];
+                if constexpr (!INROW) {
+                    rr[u] = my_rec[idx];
+                    if constexpr (KIND == 2) r1[u] = my_rec1[idx];
+                }
+            }
+            if constexpr (INROW) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const float tx = __shfl(__uint_as_float(v[u].x), tlane);       // t_j (KIND 0 / 1) or s_i (KIND 2)
+                    const float z = su[0] + tx;
+                    float w = __expf(a.sign * lrelu(z, a.alpha));
+                    w = (j + u * SLOTS + slot < nb) ? w : 0.0f;
+                    const float cc = w * a.sign * (z > 0.0f ? 1.0f : a.alpha);
+                    if constexpr (KIND == 0) rr[u] = w;
+                    if constexpr (KIND == 1) rr[u] = cc;
+                    if constexpr (KIND == 2) {
+                        rr[u] = make_float2(w, cc);
+                        r1[u] = __shfl(__uint_as_float(v[u].y), tlane) * cc;    // dd_i sits next to s_i
+                    }
+                }
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -245,6 +269,7 @@ __global__ __launch_bounds__(kBlock) void gat2_kernel(const EdgeArgs a) {
 #pragma unroll
                             for (int i = 0; i < EPV; ++i) dot = fmaf(dn[i], f[i], dot);
                         }
+                        if constexpr (INROW) dot = col_ok ? dot : 0.0f;   // the score lane holds score bits, not features: 0 x NaN
                         sa = fmaf(dot, rr[u], sa);
                         sb += rr[u];
                     } else {
@@ -254,6 +279,7 @@ __global__ __launch_bounds__(kBlock) void gat2_kernel(const EdgeArgs a) {
 #pragma unroll
                             for (int i = 0; i < EPV; ++i) dot = fmaf(f[i], hj[i], dot);
                         }
+                        if constexpr (INROW) dot = col_ok ? dot : 0.0f;
                         sa = fmaf(dot, rr[u].y, sa);
                         sb += r1[u];
 #pragma unroll
@@ -345,10 +371,12 @@ __global__ __launch_bounds__(kBlock) void gat2_kernel(const EdgeArgs a) {
 
 // ---- dispatch: (lanes per row, heads per wavefront) pairs with 1 <= LPR / NH ------------------------------------------------
 template <typename XT, typename YT, int EPV, int LPR, int KIND>
-static bool gat2_launch_nh(const EdgeArgs& a, int nh, dim3 grid, hipStream_t s) {
+static bool gat2_launch_nh(const EdgeArgs& a, int nh, dim3 grid, hipStream_t s, bool inrow) {
 #define DGLL_GAT2(NHV) hipLaunchKernelGGL((gat2_kernel<XT, YT, EPV, LPR, NHV, 4, KIND>), grid, dim3(kBlock), 0, s, a); return true
     switch (nh) {
-        case 1: DGLL_GAT2(1);
+        case 1:
+            if (inrow) { hipLaunchKernelGGL((gat2_kernel<XT, YT, EPV, LPR, 1, 4, KIND, true>), grid, dim3(kBlock), 0, s, a); return true; }
+            DGLL_GAT2(1);
         case 2: DGLL_GAT2(2);
         case 4: DGLL_GAT2(4);
         case 8: if constexpr (LPR >= 8) { DGLL_GAT2(8); } return false;
@@ -358,21 +386,21 @@ static bool gat2_launch_nh(const EdgeArgs& a, int nh, dim3 grid, hipStream_t s) 
 }
 
 template <typename XT, typename YT, int EPV, int KIND>
-static bool gat2_launch_lpr(const EdgeArgs& a, int lpr, int nh, dim3 grid, hipStream_t s) {
+static bool gat2_launch_lpr(const EdgeArgs& a, int lpr, int nh, dim3 grid, hipStream_t s, bool inrow) {
     switch (lpr) {
-        case 4: return gat2_launch_nh<XT, YT, EPV, 4, KIND>(a, nh, grid, s);
-        case 8: return gat2_launch_nh<XT, YT, EPV, 8, KIND>(a, nh, grid, s);
-        case 16: return gat2_launch_nh<XT, YT, EPV, 16, KIND>(a, nh, grid, s);
-        case 32: return gat2_launch_nh<XT, YT, EPV, 32, KIND>(a, nh, grid, s);
-        case 64: return gat2_launch_nh<XT, YT, EPV, 64, KIND>(a, nh, grid, s);
+        case 4: return gat2_launch_nh<XT, YT, EPV, 4, KIND>(a, nh, grid, s, inrow);
+        case 8: return gat2_launch_nh<XT, YT, EPV, 8, KIND>(a, nh, grid, s, inrow);
+        case 16: return gat2_launch_nh<XT, YT, EPV, 16, KIND>(a, nh, grid, s, inrow);
+        case 32: return gat2_launch_nh<XT, YT, EPV, 32, KIND>(a, nh, grid, s, inrow);
+        case 64: return gat2_launch_nh<XT, YT, EPV, 64, KIND>(a, nh, grid, s, inrow);
         default: return false;
     }
 }
 
 template <int KIND>
-static bool gat2_launch_kind(int dtype, int lpr, int nh, dim3 grid, hipStream_t s, const EdgeArgs& a) {
-    if (dtype == DGLL_F32) return gat2_launch_lpr<float, float, 4, KIND>(a, lpr, nh, grid, s);
-    return gat2_launch_lpr<bf16_t, bf16_t, 8, KIND>(a, lpr, nh, grid, s);
+static bool gat2_launch_kind(int dtype, int lpr, int nh, dim3 grid, hipStream_t s, const EdgeArgs& a, bool inrow) {
+    if (dtype == DGLL_F32) return gat2_launch_lpr<float, float, 4, KIND>(a, lpr, nh, grid, s, inrow);
+    return gat2_launch_lpr<bf16_t, bf16_t, 8, KIND>(a, lpr, nh, grid, s, inrow);
 }
 
 }  // namespace dgll

@@ -16,16 +16,21 @@ namespace dgll {
 template <typename XT, int EPV, int LPR, bool HAS_VAL, int U>
 __device__ __forceinline__ void gather_edges(const int32_t* __restrict__ col, const float* __restrict__ val,
                                              const XT* __restrict__ xcol, int64_t ldx, int64_t b, int64_t e,
-                                             int lane, float (&acc)[EPV]) {
+                                             int lane, float (&acc)[EPV], bool preloaded = false, int first_col = 0,
+                                             float first_val = 0.0f) {
     typedef VecIO<XT, EPV> IO;
     constexpr int SLOTS = kWave / LPR;
     const int slot = lane / LPR;
 
-    int my_col = 0;
-    float my_val = 0.0f;
-    if (b + lane < e) {
-        my_col = __builtin_nontemporal_load(col + b + lane);   // indices and weights are streamed once: keep them
-        if (HAS_VAL) my_val = __builtin_nontemporal_load(val + b + lane);   // from displacing feature rows in L2
+    int my_col = first_col;               // preloaded: the caller requested the row's first index batch a row ago
+    float my_val = first_val;
+    if (!preloaded) {
+        my_col = 0;
+        my_val = 0.0f;
+        if (b + lane < e) {
+            my_col = __builtin_nontemporal_load(col + b + lane);   // indices and weights are streamed once: keep them
+            if (HAS_VAL) my_val = __builtin_nontemporal_load(val + b + lane);   // from displacing feature rows in L2
+        }
     }
     for (int64_t k0 = b; k0 < e; k0 += kWave) {
         const int64_t left = e - k0;

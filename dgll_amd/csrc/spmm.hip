@@ -176,7 +176,7 @@ __device__ __forceinline__ void finish_row(YT* __restrict__ y, int c0, int feat,
     }
 }
 
-template <typename XT, typename YT, int EPV, int LPR, bool HAS_VAL, int U, bool EXTRA>
+template <typename XT, typename YT, int EPV, int LPR, bool HAS_VAL, int U, bool EXTRA, bool PF = false>
 __global__ __launch_bounds__(kBlock) void spmm_csr_kernel(const SpmmArgs a) {
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -205,10 +205,37 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_kernel(const SpmmArgs a) {
     bid -= a.chunk_blocks;
     if (a.flags & 1) bid = xcd_remap(bid, a.row_blocks);
     const int64_t row0 = ((int64_t)bid * kWavesPerBlock + wave) * a.rows_per_wave;
+    // flags bit 2: the NEXT row's first index batch is requested before this row's gathers (one dependent load less per row)
+    constexpr bool pf = PF;        // (a template parameter: the two extra live registers cost the default variant a wavefront per SIMD)
+    int64_t nb_ = 0, ne_ = 0;
+    int ncol = 0;
+    float nval = 0.0f;
+    if (pf && row0 < a.n_rows) {
+        nb_ = uniform64(a.rowptr[row0]); ne_ = uniform64(a.rowptr[row0 + 1]);
+        if (nb_ + lane < ne_) {
+            ncol = __builtin_nontemporal_load(a.col + nb_ + lane);
+            if (HAS_VAL) nval = __builtin_nontemporal_load(a.val + nb_ + lane);
+        }
+    }
     for (int r = 0; r < a.rows_per_wave; ++r) {
         const int64_t row = row0 + r;
         if (row >= a.n_rows) return;
-        const int64_t b = uniform64(a.rowptr[row]), e = uniform64(a.rowptr[row + 1]);
+        int64_t b, e;
+        int fcol = 0;
+        float fval = 0.0f;
+        if (pf) {
+            b = nb_; e = ne_; fcol = ncol; fval = nval;
+            if (r + 1 < a.rows_per_wave && row + 1 < a.n_rows) {
+                nb_ = e; ne_ = uniform64(a.rowptr[row + 2]);
+                ncol = 0; nval = 0.0f;
+                if (nb_ + lane < ne_) {
+                    ncol = __builtin_nontemporal_load(a.col + nb_ + lane);
+                    if (HAS_VAL) nval = __builtin_nontemporal_load(a.val + nb_ + lane);
+                }
+            }
+        } else {
+            b = uniform64(a.rowptr[row]); e = uniform64(a.rowptr[row + 1]);
+        }
         if (a.threshold > 0 && e - b > a.threshold) continue;  // handled as chunks
         if constexpr (EXTRA) {
             if (a.accumulate == 2 && e == b) continue;         // increment form: nothing to add to this row
@@ -224,7 +251,7 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_kernel(const SpmmArgs a) {
         if constexpr (EXTRA) {
             grow = a.gate ? static_cast<const YT*>(a.gate) + row * a.ldg : nullptr;
         }
-        gather_edges<XT, EPV, LPR, HAS_VAL, U>(a.col, a.val, xcol, a.ldx, b, e, lane, acc);
+        gather_edges<XT, EPV, LPR, HAS_VAL, U>(a.col, a.val, xcol, a.ldx, b, e, lane, acc, pf, fcol, fval);
         if constexpr (EXTRA) {
             if (writer && full) {
                 if (a.accumulate) prev.load(yrow + c0);
@@ -392,6 +419,18 @@ static int g_tune_rowslot = 0;       // 0 = automatic choice of the row-per-slot
 template <typename XT, typename YT, int EPV, int LPR, int U>
 static hipError_t launch_u(const SpmmArgs& a, dim3 grid, hipStream_t s) {
     const bool extra = a.accumulate || a.gate;
+    if constexpr (LPR == 32 && U == 4 && sizeof(XT) == 2 && sizeof(YT) == 2) {
+        if (a.flags & 4) {       // diagnostics (dgll_hip_debug_tune(2, 4)): next-row index prefetch
+            if (a.val) {
+                if (extra) hipLaunchKernelGGL((spmm_csr_kernel<XT, YT, EPV, LPR, true, U, true, true>), grid, dim3(kBlock), 0, s, a);
+                else hipLaunchKernelGGL((spmm_csr_kernel<XT, YT, EPV, LPR, true, U, false, true>), grid, dim3(kBlock), 0, s, a);
+            } else {
+                if (extra) hipLaunchKernelGGL((spmm_csr_kernel<XT, YT, EPV, LPR, false, U, true, true>), grid, dim3(kBlock), 0, s, a);
+                else hipLaunchKernelGGL((spmm_csr_kernel<XT, YT, EPV, LPR, false, U, false, true>), grid, dim3(kBlock), 0, s, a);
+            }
+            return hipGetLastError();
+        }
+    }
     if (a.val) {
         if (extra) hipLaunchKernelGGL((spmm_csr_kernel<XT, YT, EPV, LPR, true, U, true>), grid, dim3(kBlock), 0, s, a);
         else hipLaunchKernelGGL((spmm_csr_kernel<XT, YT, EPV, LPR, true, U, false>), grid, dim3(kBlock), 0, s, a);
