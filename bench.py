@@ -307,11 +307,11 @@ def spmm_kernel_fragment(feat, dtype_name, weighted, extra):
     while lpr < 64 and lpr < vecs:
         lpr <<= 1
     t = "unsigned short" if bf else "float"
-    return "spmm_csr_kernel<%s, %s, %d, %d, %s, 4, %s>" % (t, t, epv, lpr, "true" if weighted else "false", "true" if extra else "false")
+    return "spmm_csr_kernel<%s, %s, %d, %d, %s, 4, %s, false>" % (t, t, epv, lpr, "true" if weighted else "false", "true" if extra else "false")
 
 
-def gat_kernel_fragment(heads, fo, dtype_name, kind):
-    """gat2_kernel instantiation of a pass (kind 0 forward, 1 rows, 2 transposed rows) -- edge.hip's gat2_pick."""
+def gat_kernel_fragment(heads, fo, dtype_name, kind, packed=False):
+    """gat2_kernel instantiation of a pass (kind 0 forward, 1 rows, 2 transposed rows) -- edge.hip's gat2_pick / gat2_inrow."""
     bf = "bfloat16" in dtype_name
     epv = 8 if bf else 4
     vph = fo // epv
@@ -327,7 +327,8 @@ def gat_kernel_fragment(heads, fo, dtype_name, kind):
     while nh * lph < 4:
         lph <<= 1
     t = "unsigned short" if bf else "float"
-    return "gat2_kernel<%s, %s, %d, %d, %d, 4, %d>" % (t, t, epv, nh * lph, nh, kind)
+    inrow = packed and heads == 1 and nh == 1 and vph < lph        # scores behind the row's last column, an idle lane to fetch them
+    return "gat2_kernel<%s, %s, %d, %d, %d, 4, %d, %s>" % (t, t, epv, nh * lph, nh, kind, "true" if inrow else "false")
 
 
 def load_traffic(sig, fragment):
@@ -409,7 +410,7 @@ def launch_tables(launches, local_rows, heads_of=None):
             name = "gat %s %d heads x %d %s%s nnz=%d" % (kind, heads, fo, dt.replace("torch.", ""), (" " + packed) if packed else "", tag_nnz)
             table[name] = {"count": cnt, "avg_ms": avg_ms, "nnz": tag_nnz, "feat": heads * fo, "heads": heads, "pass": kind,
                            "scores_in_row_padding": bool(packed),
-                           "kernel_fragment": gat_kernel_fragment(heads, fo, dt, {"fwd": 0, "bwd_rows": 1, "bwd_cols": 2}[kind])}
+                           "kernel_fragment": gat_kernel_fragment(heads, fo, dt, {"fwd": 0, "bwd_rows": 1, "bwd_cols": 2}[kind], bool(packed))}
         elif tag[0] in ("transform", "transform_dual", "grad_weight"):
             kind, m, k1, k2, n_out, extra = tag
             b_alg = m * (k1 + k2 + n_out) * 2 + (m * n_out * 2 if ("gate" in extra or "addend" in extra) else 0)

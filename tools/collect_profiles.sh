@@ -1,0 +1,16 @@
+#!/bin/bash
+# Copy the summaries of tools/pmc_bench.sh runs into profiles/ (tracked) and rebuild profiles/traffic.json.
+#   usage: bash tools/collect_profiles.sh <sage-tag> <gat-tag> [round]       e.g.  r03t_sage r03t_gat r03
+set -eu
+SAGE=$1; GAT=$2; R=${3:-r03}
+python tools/pmc_parse.py gpurun_out/$GAT --round $R --write | tail -8
+python tools/pmc_parse.py gpurun_out/$SAGE --round $R --write | tail -6
+cp gpurun_out/$SAGE/kernel_stats.csv profiles/${R}_bench_kernel_stats.csv
+cp gpurun_out/$SAGE/bench_under_rocprof.json profiles/${R}_bench_under_rocprof.json
+cp gpurun_out/$GAT/kernel_stats.csv profiles/${R}_gat_kernel_stats.csv
+cp gpurun_out/$GAT/bench_under_rocprof.json profiles/${R}_gat_bench_under_rocprof.json
+for c in FETCH_SIZE WRITE_SIZE TCC_HIT_sum_TCC_MISS_sum; do
+  cp gpurun_out/$SAGE/pmc_$c.csv profiles/${R}_pmc_$c.csv
+  cp gpurun_out/$GAT/pmc_$c.csv profiles/${R}_gat_pmc_$c.csv
+done
+grep -c Cijk profiles/${R}_bench_kernel_stats.csv profiles/${R}_gat_kernel_stats.csv || true

@@ -72,7 +72,7 @@ def main():
     # calibration: the first three launches of the unweighted F = hidden SpMM kernel read n*hidden*esz + n*12 bytes (rows,
     # rowptr, col) and write n*hidden*esz
     t = "unsigned short" if esz == 2 else "float"
-    calib_frag = "spmm_csr_kernel<%s, %s, %d, 32, false, 4, false>" % (t, t, 16 // esz)
+    calib_frag = "spmm_csr_kernel<%s, %s, %d, 32, false, 4, false, false>" % (t, t, 16 // esz)
     calib_kernel = next((k for k in fetch if calib_frag in k), None)
     ratio_r, ratio_w, calib = 0.5, 1.0, None
     if calib_kernel and len(fetch[calib_kernel]) >= 3:
