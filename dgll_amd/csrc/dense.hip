@@ -7,6 +7,8 @@
 
 #include "common.hpp"
 
+int g_tune_res_per_cu = 0;    // dgll_hip_debug_tune(11, v): workgroups per CU of the resident-weights transform (0 = default)
+
 namespace dgll {
 
 constexpr int TM = 64, TN = 64, TK = 16;   // 64x64 output tile per 256-thread block, 4x4 outputs per thread
@@ -886,7 +888,8 @@ static hipError_t launch_mfma_res_p(const MfmaGemmArgs& a, hipStream_t s) {
         n_cu_of[slot] = n;
     }
     const int n_cu = n_cu_of[slot];
-    const int per_cu = lds > 80 * 1024 ? 1 : 2;
+    int per_cu = lds > 80 * 1024 ? 1 : 2;
+    if (g_tune_res_per_cu > 0 && (size_t)g_tune_res_per_cu * lds <= 160 * 1024) per_cu = g_tune_res_per_cu;   // diagnostics
     dim3 grid((uint32_t)(n_cu * per_cu));
     hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, s, a);
     return hipGetLastError();
