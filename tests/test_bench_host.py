@@ -1,0 +1,109 @@
+"""Host logic of bench.py and the profile tooling (no GPU): the section-8(d) byte formulas, the single definition of
+roofline.frac, and the tamper evidence of profiles/traffic.json -- an entry is used only when workload signature, kernel
+instantiation AND build stamp match the running build."""
+import importlib.util
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.fixture()
+def bench(tmp_path, monkeypatch):
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    (tmp_path / "profiles").mkdir()
+    monkeypatch.setattr(mod, "ROOT", str(tmp_path))
+    monkeypatch.setattr(mod, "build_stamp", lambda: "stamp-A")
+    return mod
+
+
+def test_algorithmic_byte_formulas(bench):
+    # per edge F*s + 4 (+4 weighted), per row F*s + 8
+    assert bench.alg_bytes(10, 3, 256, 2, 2, False) == 10 * 516 + 3 * 520
+    assert bench.alg_bytes(10, 3, 256, 4, 4, True) == 10 * 1032 + 3 * 1032
+    # products layer of BASELINE.md: 65.1 GB
+    assert abs(bench.alg_bytes(123_718_280, 2_449_029, 256, 2, 2, False) / 1e9 - 65.1) < 0.05
+    # fused GAT pass: nnz (F s + 4 + 4 heads) + n (F s + 8 + 8 heads)
+    assert bench.gat_alg_bytes(10, 3, 256, 2, 8) == 10 * (512 + 4 + 32) + 3 * (512 + 8 + 64)
+
+
+def test_kernel_fragments_name_the_instantiations(bench):
+    assert bench.spmm_kernel_fragment(256, "torch.bfloat16", True, True) == \
+        "spmm_csr_kernel<unsigned short, unsigned short, 8, 32, true, 4, true, false>"
+    assert bench.spmm_kernel_fragment(47, "torch.bfloat16", False, False) == \
+        "spmm_csr_kernel<unsigned short, unsigned short, 8, 8, false, 4, false, false>"
+    assert bench.spmm_kernel_fragment(100, "torch.float32", False, False) == "spmm_csr_kernel<float, float, 4, 32, false, 4, false, false>"
+    # 8 heads x 32 bf16: 4 lanes per head, 8 heads per wavefront; 1 head x 48 with scores in the row padding: the in-row form
+    assert bench.gat_kernel_fragment(8, 32, "torch.bfloat16", 2) == "gat2_kernel<unsigned short, unsigned short, 8, 32, 8, 4, 2, false>"
+    assert bench.gat_kernel_fragment(1, 48, "torch.bfloat16", 0, packed=True) == "gat2_kernel<unsigned short, unsigned short, 8, 8, 1, 4, 0, true>"
+    assert bench.gat_kernel_fragment(1, 48, "torch.bfloat16", 0, packed=False).endswith("0, false>")
+    assert bench.gat_kernel_fragment(3, 24, "torch.bfloat16", 1) == "gat2_kernel<unsigned short, unsigned short, 8, 8, 2, 4, 1, false>"
+
+
+def _dom(frag, ms=5.0, b_alg=65.6e9):
+    return {"count": 10, "avg_ms": ms, "nnz": 123_718_280, "algorithmic_bytes": b_alg, "algorithmic_GBps": b_alg / (ms * 1e-3) / 1e9,
+            "kernel_fragment": frag}
+
+
+def test_frac_has_one_definition_and_stale_traffic_is_refused(bench, tmp_path):
+    frag = "spmm_csr_kernel<unsigned short, unsigned short, 8, 32, true, 4, true, false>"
+    sig = {"workload": "sage", "nodes": 1, "nnz": 2, "locality": 0.9, "permuted_ids": True, "reorder": "lpa", "hidden": 256, "dtype": "bf16"}
+    entry = {"workload": dict(sig), "kernel_fragment": frag, "build_stamp": "stamp-A", "hbm_bytes_per_launch": 31.4e9, "round": "r03",
+             "ratio_read": 0.531, "ratio_write": 1.0}
+    with open(tmp_path / "profiles" / "traffic.json", "w") as f:
+        json.dump({"entries": [entry]}, f)
+    rec = bench.roofline_record(_dom(frag), sig, "k", 3.5e9, world=1)
+    # counter traffic / live time / peak -- and the formula's value next to it
+    assert rec["traffic"] == 31.4e9 and abs(rec["frac"] - 31.4e9 / 5e-3 / 1e9 / 8000.0) < 1e-12
+    assert rec["frac"] == rec["frac_hbm_counters"] and "counter" in rec["frac_definition"]
+    assert abs(rec["frac_algorithmic"] - 65.6e9 / 5e-3 / 1e9 / 8000.0) < 1e-12 and rec["achieved"] == rec["frac_algorithmic"] * 8000.0
+    # another build of the library: the entry must not be used
+    bench.build_stamp = lambda: "stamp-B"
+    rec = bench.roofline_record(_dom(frag), sig, "k", 3.5e9, world=1)
+    assert rec["traffic"] is None and rec["frac"] == rec["frac_algorithmic"] and "formula" in rec["frac_definition"]
+    bench.build_stamp = lambda: "stamp-A"
+    # another workload / another kernel: no match either; multi-rank runs never take counter traffic
+    assert bench.roofline_record(_dom(frag), dict(sig, nnz=3), "k", 0, world=1)["traffic"] is None
+    assert bench.roofline_record(_dom(frag.replace("true, 4, true", "false, 4, false")), sig, "k", 0, world=1)["traffic"] is None
+    assert bench.roofline_record(_dom(frag), sig, "k", 0, world=2)["traffic"] is None
+
+
+def test_pmc_parse_applies_the_ratios_calibrated_in_the_same_pass(tmp_path):
+    """tools/pmc_parse.py on a synthetic counter pass: three calibration launches with known bytes give ratio_read 0.5,
+    the launch kind's bytes are FETCH / ratio_read + WRITE / ratio_write, the cold first step is dropped, and the entry
+    carries the bench line's build stamp."""
+    n, hidden = 1000, 256
+    calib = "void dgll::spmm_csr_kernel<unsigned short, unsigned short, 8, 32, false, 4, false, false>(dgll::SpmmArgs)"
+    kern = "void dgll::spmm_csr_kernel<unsigned short, unsigned short, 8, 32, true, 4, true, false>(dgll::SpmmArgs)"
+    known_r, known_w = n * hidden * 2 + n * 12, n * hidden * 2
+    hdr = '"Correlation_Id","Dispatch_Id","Kernel_Name","Counter_Name","Counter_Value","Start_Timestamp","End_Timestamp"\n'
+
+    def rows(counter, calib_kib, kib_list):
+        out, d = hdr, 1
+        for _ in range(3):
+            out += '%d,%d,"%s","%s",%f,0,1000\n' % (d, d, calib, counter, calib_kib); d += 1
+        for v in kib_list:
+            out += '%d,%d,"%s","%s",%f,0,5000\n' % (d, d, kern, counter, v); d += 1
+        return out
+
+    d = tmp_path / "pass"
+    d.mkdir()
+    # 5 steps (2 warm-up + 3 timed), one launch each; the first (cold) value is an outlier that must be dropped
+    (d / "pmc_FETCH_SIZE.csv").write_text(rows("FETCH_SIZE", known_r * 0.5 / 1024, [999999, 100, 100, 100, 100]))
+    (d / "pmc_WRITE_SIZE.csv").write_text(rows("WRITE_SIZE", known_w / 1024, [999999, 40, 40, 40, 40]))
+    frag = "spmm_csr_kernel<unsigned short, unsigned short, 8, 32, true, 4, true, false>"
+    line = {"dtype": "bf16", "steps": 3, "warmup": 2, "roofline": {"build_stamp": "stamp-X"},
+            "config": {"workload_id": "sage", "nodes": n, "nnz": 5, "locality": 0.9, "permuted_ids": True, "reorder": "lpa", "hidden": hidden},
+            "spmm_launch_table": {"spmm F=256 weighted": {"kernel_fragment": frag, "algorithmic_bytes": 123}}}
+    (d / "pmc_FETCH_SIZE.json").write_text(json.dumps(line) + "\n")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_parse.py"), str(d)], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    assert "FETCH_SIZE reports 0.500 of the known read, WRITE_SIZE 1.000" in res.stdout
+    # 100 KiB / 0.5 + 40 KiB / 1.0 = 240 KiB = 0.00 GB: check through the printed per-launch line
+    assert "fetch 100 KiB write 40 KiB" in res.stdout
