@@ -216,6 +216,19 @@ def mm_nt(a, wt, relu=False, bias=None, addend=None):
     return torch.cat(parts, dim=1)
 
 
+def mm2_nt(a1, wt1, a2, wt2, relu=False):
+    """act(a1 . wt1^T + a2 . wt2^T): both products accumulate in fp32 before anything is stored.  bf16 operands whose rows are
+    not 16-byte aligned are re-laid out once and take the two-product MFMA launch (256 output columns at a time) -- the sum
+    of two separately stored bf16 products rounds the first one to 8 bits before the add, which showed as a 4-5 % relative
+    error of the first layer's gradients at the Reddit shape (602-column rows; tests/test_config2_reddit_gpu.py)."""
+    if not (a1.is_cuda and a1.dtype == torch.bfloat16 and a2.dtype == torch.bfloat16):
+        return mm_nt(a2, wt2, relu=relu, addend=mm_nt(a1, wt1))      # fp32: the addend stays fp32 (exact); host: torch
+    a1, a2 = _as_rows16(a1), _as_rows16(a2)
+    n = wt1.shape[0]
+    parts = [transform_bf16(a1, wt1[n0:n0 + 256], a2, wt2[n0:n0 + 256], relu=relu) for n0 in range(0, n, 256)]
+    return parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
+
+
 def input_grads(g, wsd, wnd):
     """(g . Ws^T, g . Wn^T) for weights stored [in, out]: one MFMA launch that reads g once for tall bf16 gradients, else two."""
     if g.shape[0] >= 64 * _SLABS and _mfma_ok(g) and wsd.shape == wnd.shape and max(wsd.shape) <= 256:
@@ -351,7 +364,7 @@ class _SageTransform(torch.autograd.Function):
         if ctx.mfma:   # one MFMA launch: both products, the add and the ReLU, every activation row read once
             out = transform_bf16(h, wsd.t(), agg, wnd.t(), relu=relu)
         else:
-            out = mm_nt(agg, wnd.t(), relu=relu, addend=mm_nt(h, wsd.t()))
+            out = mm2_nt(h, wsd.t(), agg, wnd.t(), relu=relu)
         ctx.relu = relu
         ctx.save_for_backward(h, agg, wsd, wnd, out if relu else None)
         return out

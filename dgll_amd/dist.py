@@ -333,7 +333,7 @@ class _DistSageLayer(torch.autograd.Function):
         if h.is_cuda and dense._mfma_ok(h, agg) and ws.shape[1] <= 256:
             out = dense.transform_bf16(h, wsd.t(), agg, wnd.t(), relu=relu)
         else:
-            out = dense.mm_nt(agg, wnd.t(), relu=relu, addend=dense.mm_nt(h, wsd.t()))
+            out = dense.mm2_nt(h, wsd.t(), agg, wnd.t(), relu=relu)
         ctx.engine, ctx.reduce, ctx.relu = engine, reduce, relu
         ctx.grad_is_gated, ctx.gate_input = grad_is_gated, gate_input
         ctx.save_for_backward(h, agg, wsd, wnd, out if relu else None)
@@ -419,7 +419,7 @@ class _DistSageLayerTransformFirst(torch.autograd.Function):
             if g.is_cuda and dense._mfma_ok(gm, gz) and wsd.shape[0] <= 256 and (not ctx.gate_input or h.stride(1) == 1):
                 gh = dense.transform_bf16(gm, wsd, gz, wnd, out_gate=h if ctx.gate_input else None)
             else:
-                gh = dense.mm_nt(gz, wnd, addend=dense.mm_nt(gm, wsd))
+                gh = dense.mm2_nt(gm, wsd, gz, wnd)
                 if ctx.gate_input:
                     gh = torch.ops.aten.threshold_backward(gh, h, 0)
         return gh, gws, gwn, None, None, None, None, None

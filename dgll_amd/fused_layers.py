@@ -43,7 +43,7 @@ class _SageGraphLayer(torch.autograd.Function):
             if dense._mfma_ok(h, agg) and ws.shape[1] <= 256:
                 out = dense.transform_bf16(h, wsd.t(), agg, wnd.t(), relu=relu)
             else:
-                out = dense.mm_nt(agg, wnd.t(), relu=relu, addend=dense.mm_nt(h, wsd.t()))
+                out = dense.mm2_nt(h, wsd.t(), agg, wnd.t(), relu=relu)
         ctx.graph, ctx.reduce, ctx.relu = graph, reduce, relu
         ctx.save_for_backward(h, agg, wsd, wnd, out if relu else None)
         return out
@@ -140,7 +140,7 @@ class _SageGraphLayerTransformFirst(torch.autograd.Function):
                 # g.Ws^T + gz.Wn^T and the ReLU mask of the layer below: one MFMA launch, every operand read once
                 gh = dense.transform_bf16(gm, wsd, gz, wnd, out_gate=h if ctx.gate_input else None)
             else:
-                gh = dense.mm_nt(gz, wnd, addend=dense.mm_nt(gm, wsd))
+                gh = dense.mm2_nt(gm, wsd, gz, wnd)
                 if ctx.gate_input:
                     gh = torch.ops.aten.threshold_backward(gh, h, 0)
         return gh, gws, gwn, None, None, None, None, None

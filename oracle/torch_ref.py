@@ -50,10 +50,12 @@ def sage_block(rowptr, col, x_dst, x_src, weight, nbr_weight, aggr="mean", act=T
     n = rowptr.numel() - 1
     row, colv = _rows(rowptr), col.long()
     deg = (rowptr[1:] - rowptr[:-1]).clamp(min=1).to(x_src.dtype)
-    val = (1.0 / deg)[row] if aggr == "mean" else torch.ones(row.numel(), dtype=x_src.dtype)
 
     def reduce(m):
-        return torch.zeros(n, m.shape[1], dtype=m.dtype).index_add_(0, row, val[:, None] * m[colv])
+        # sum, THEN scale (torch.mean's order, sageconv.py:33-36; oracle.c:70 the same): scaling every term first is not
+        # correctly rounded where a mean of bf16-quantised rows lands on a bf16 rounding tie, which is not rare
+        total = torch.zeros(n, m.shape[1], dtype=m.dtype).index_add_(0, row, m[colv])
+        return total * (1.0 / deg)[:, None] if aggr == "mean" else total
 
     if transform_first:
         nh = store(reduce(store(x_src @ nbr_weight)))

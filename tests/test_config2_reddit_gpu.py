@@ -148,17 +148,23 @@ def test_bf16_forward_matches_the_oracle(reddit_batch):
 
 
 @pytest.mark.gpu
-def test_bf16_gradients_match_cpu_autograd_of_the_oracle(reddit_batch):
-    """Forward (tight: bf16 storage rounding emulated at the points where the GPU path stores a tensor) and backward
-    (input-feature and parameter gradients) vs CPU autograd of oracle/torch_ref.sage_block."""
+@pytest.mark.parametrize("storage", ["bf16", "fp32"])
+def test_gradients_match_cpu_autograd_of_the_oracle(reddit_batch, storage):
+    """Forward and backward (input-feature and parameter gradients) vs CPU autograd of oracle/torch_ref.sage_block, at the
+    Reddit shape.  bf16: the oracle rounds to bf16 exactly where the GPU path stores a tensor, so the first layer's outputs
+    must agree entry for entry (up to fp32 accumulation order at a rounding boundary) and the gradients differ by the bf16
+    rounding of stored gradients only.  fp32: the same comparison with fp32 storage everywhere."""
     from oracle import torch_ref
 
     r = reddit_batch
     b, dev = r["batch"], r["dev"]
     model = _model(dev)
     L = 3
+    fp32 = storage == "fp32"
+    rnd = (lambda t: t.clone()) if fp32 else _bf16_round
+    store = (lambda t: t) if fp32 else _store
     blocks = [b.subgraphs[L - 1 - h].to_block(dev) for h in range(L)]
-    xs = [f.detach().clone().requires_grad_() for f in b.features]
+    xs = [(f.detach().float() if fp32 else f.detach().clone()).requires_grad_() for f in b.features]
     out = model.forward_sampled(xs, blocks)
     loss = torch.nn.functional.cross_entropy(out.float(), b.labels)
     loss.backward()
@@ -171,8 +177,8 @@ def test_bf16_gradients_match_cpu_autograd_of_the_oracle(reddit_batch):
     hid = cx
     kept = {}
     for l, layer in enumerate(model.gcn):
-        ws = _bf16_round(layer.weight.detach().cpu()).requires_grad_()
-        wn = _bf16_round(layer.neighborAgg.weight.detach().cpu()).requires_grad_()
+        ws = rnd(layer.weight.detach().cpu()).requires_grad_()
+        wn = rnd(layer.neighborAgg.weight.detach().cpu()).requires_grad_()
         params.append((ws, wn))
         nxt = []
         for hop in range(L - l):
@@ -184,13 +190,28 @@ def test_bf16_gradients_match_cpu_autograd_of_the_oracle(reddit_batch):
                     from oracle import cref
 
                     agg0 = torch.from_numpy(cref.spmm_csr(ptrs[hop].numpy(), col.numpy(), None, src.detach().numpy(), reduce="mean"))
-                agg0 = _bf16_round(agg0).requires_grad_()
+                agg0 = rnd(agg0).requires_grad_()
                 kept["agg"] = agg0
                 z = hid[hop] @ ws + agg0 @ wn
-                nxt.append(_store(torch.relu(z) if layer.activation is not None else z))
+                nxt.append(store(torch.relu(z) if layer.activation is not None else z))
                 continue
+            # the order of the GPU path: sampled blocks (every source row in one edge) are aggregated before the transform
+            first = layer.transform_first(b.features[hop + 1]) and not blocks[hop].identity_cols
             nxt.append(torch_ref.sage_block(ptrs[hop], col, hid[hop], src, ws, wn, act=layer.activation is not None,
-                                            transform_first=layer.transform_first(b.features[hop + 1]), store=_store))
+                                            transform_first=first, store=store))
+        if l == 0 and not fp32:
+            # first layer, hop by hop: same bf16 operands, fp32 accumulation on both sides, one rounding -- the stored outputs
+            # agree except where accumulation order decides a rounding boundary, and no ReLU gate differs.  (This caught two
+            # things: a fallback that stored the self term in bf16 before adding the neighbour term when rows were not 16-byte
+            # aligned -- 602 columns -- and an oracle mean that scaled every term instead of the sum.)
+            with torch.no_grad():
+                for hop in range(L):
+                    gpu = layer.forward_block(blocks[hop], xs[hop + 1], xs[hop]).float().cpu()
+                    ref = nxt[hop].detach()
+                    equal = float((gpu == ref).float().mean())
+                    flips = float(((gpu > 0) != (ref > 0)).float().mean())
+                    print("layer 0 hop %d: %.5f of the stored outputs identical, ReLU gates that differ %.1e" % (hop, equal, flips))
+                    assert equal >= 0.999 and flips <= 1e-5, (hop, equal, flips)
         hid = nxt
     ref_out = hid[0]
     ref_loss = torch.nn.functional.cross_entropy(ref_out, b.labels.cpu())
@@ -202,19 +223,18 @@ def test_bf16_gradients_match_cpu_autograd_of_the_oracle(reddit_batch):
     assert float((got - ref_out.detach()).abs().max()) <= 2.0 ** -6 * max(float(ref_out.detach().abs().max()), rms)
     assert abs(float(loss.detach()) - float(ref_loss.detach())) < 2e-3 * abs(float(ref_loss.detach()))
 
-    def close(name, a, ref, tol=5e-2):
-        """bf16 backward vs the fp32 backward of the oracle.  Two things separate them: every stored gradient is rounded
-        to bf16 (2^-9 relative per stage, three layers), and a ReLU gate can differ where a pre-activation is within
-        rounding of zero -- harmless forward, but it switches one whole term of a gradient sum on or off.  So: the relative
-        L2 error is small, and all but a sliver of the entries are within `tol` of the gradient's scale.  (Sampled blocks are
-        aggregated BEFORE the transform, the reference's own order, sageconv.py:33-41: the 602-wide mean is then stored in bf16,
-        measured 4.4e-2 on the first layer's weights against 3.6e-2 for the narrow-product-first order.)"""
+    def close(name, a, ref, tol=1e-3 if fp32 else 1.5e-2):
+        """bf16 backward vs the fp32 backward of the oracle: forward values and gates agree (above), so what separates the two
+        is the rounding of every stored gradient to bf16 -- measured 0.9e-4 ... 5e-3 relative L2, growing towards the first
+        layer; 1.5e-2 allowed.  (Before the two fixes named above this comparison sat at 4-5e-2 and was explained away as
+        gate noise.)  fp32: 2e-7 ... 1.1e-4 measured."""
         a, ref = a.detach().float().cpu(), ref.detach()
         scale = float(ref.abs().max())
         assert scale > 0, name
         rel_l2 = float((a - ref).norm() / ref.norm())
-        assert rel_l2 <= tol, "%s: relative L2 error %.3e" % (name, rel_l2)
         outliers = float(((a - ref).abs() > tol * scale).float().mean())
+        print("%-32s relative L2 error %.3e, outliers %.2e" % (name, rel_l2, outliers))      # shown by pytest -s / on failure
+        assert rel_l2 <= tol, "%s: relative L2 error %.3e" % (name, rel_l2)
         assert outliers <= 2e-3, "%s: %.2e of the entries are off by more than %.0e of the scale" % (name, outliers, tol)
 
     for l, layer in enumerate(model.gcn):
