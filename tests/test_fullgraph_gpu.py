@@ -209,3 +209,65 @@ def test_mfma_transform_relu_mask_and_nan_pads(cuda_device):
     ref = (a.float() * (mask.float() > 0)) @ w.float()
     assert torch.isfinite(out).all()
     np.testing.assert_allclose(out.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-3)
+
+
+def test_bf16_bench_configuration_against_the_storage_emulating_oracle(cuda_device):
+    """The bench configuration (100-256-256-47, bf16, full graph) against CPU autograd of oracle/torch_ref.sage_block with bf16
+    rounding applied exactly where the GPU path stores a tensor: every layer's stored output must agree entry for entry (up to
+    fp32 accumulation order at a rounding boundary) and the gradients of forward_graph -- gates fused into the SpMM / MFMA
+    epilogues -- differ by the bf16 rounding of stored gradients only.  (The same construction at the Reddit shape exposed a
+    two-launch fallback that rounded one product before the add: tests/test_config2_reddit_gpu.py.)"""
+    from dgll_amd import fused_layers, ops
+    from oracle import torch_ref
+
+    dev = cuda_device
+    g_cpu, model, x = _setup(dev, n_scale=13, fin=100, hidden=(256, 256, 47))
+    g = g_cpu.to(dev)
+    m = model.to(dev)
+    rnd = lambda t: t.to(torch.bfloat16).float()                     # noqa: E731
+    store = lambda t: t + (rnd(t.detach()) - t.detach())             # noqa: E731  (straight-through gradient)
+    xb = ops.alloc_features(g.n_rows, 100, torch.bfloat16, dev)
+    xb.copy_(x.to(dev))
+    gout = torch.randn(g.n_rows, 47).to(torch.bfloat16)
+
+    # ---- oracle
+    cx = xb.float().cpu().requires_grad_()
+    params, hid, outs = [], cx, []
+    for layer in m.gcn:
+        ws = rnd(layer.weight.detach().cpu()).requires_grad_()
+        wn = rnd(layer.neighborAgg.weight.detach().cpu()).requires_grad_()
+        params.append((ws, wn))
+        hid = torch_ref.sage_block(g_cpu.rowptr, g_cpu.col, hid, hid, ws, wn, act=layer.activation is not None,
+                                   transform_first=layer.hidden_dim < layer.input_dim, store=store)
+        outs.append(hid)
+    (hid * gout.float()).sum().backward()
+
+    # ---- layer by layer: stored outputs
+    with torch.no_grad():
+        h = xb
+        for l, layer in enumerate(m.gcn):
+            h = fused_layers.sage_graph_layer(layer, g, h)
+            ref = outs[l].detach()
+            equal = float((h.float().cpu() == ref).float().mean())
+            flips = float(((h.float().cpu() > 0) != (ref > 0)).float().mean()) if layer.activation is not None else 0.0
+            print("layer %d: %.5f of the stored outputs identical, gates that differ %.1e" % (l, equal, flips))
+            assert equal >= 0.999 and flips <= 2e-5, (l, equal, flips)            # measured 0.99955 ... 0.99997, no gate
+
+    # ---- the fused step: gradients
+    store_x = ops.alloc_features(g.n_rows, 100, torch.bfloat16, dev)
+    store_x.copy_(xb)
+    xin = store_x.requires_grad_()
+    out = m.forward_graph(g, xin)
+    assert float((out.float().cpu() == outs[-1].detach()).float().mean()) >= 0.995
+    (out.float() * gout.to(dev).float()).sum().backward()
+
+    def close(name, a, ref, tol=1e-2):                               # measured 0.7e-4 ... 3.7e-3
+        a, ref = a.detach().float().cpu(), ref.detach()
+        rel = float((a - ref).norm() / ref.norm())
+        print("%-28s relative L2 error %.3e" % (name, rel))
+        assert rel <= tol, (name, rel)
+
+    for l, layer in enumerate(m.gcn):
+        close("layer %d weight" % l, layer.weight.grad, params[l][0].grad)
+        close("layer %d neighborAgg.weight" % l, layer.neighborAgg.weight.grad, params[l][1].grad)
+    close("input features", xin.grad, cx.grad)
