@@ -151,10 +151,14 @@ __global__ __launch_bounds__(kBlock) void gat2_kernel(const EdgeArgs a) {
                 // bf16 storage: the hardware logarithm (absolute error ~1e-7 on a value rounded to 8 bits anyway); fp32: log1pf
                 hp = op1 > 0.0f ? (BF ? __logf(op1) : log1pf(o[i])) : 0.0f;
             }
-            part = fmaf(dhp, hp, part);
             dn[i] = dhp * inv_den;
+            // bf16: the dot products below and the transposed pass see DN in storage precision; dd_i = -DN_i . hp_i must be formed
+            // from the SAME rounded values, or the cancellation in ds_i = sum_j c_ij (DN_i . h_j + dd_i) leaves the rounding of DN
+            // un-cancelled (measured: grad_s 8e-3 of float64 on the same operands, tools/gat_grad_precision.py)
+            if constexpr (BF) dn[i] = bf16_to_f32(f32_to_bf16(dn[i]));
+            part = fmaf(dn[i], hp, part);
         }
-        dd = -head_sum_c<LPH>(part) * inv_den;
+        dd = -head_sum_c<LPH>(part);
         if (slot == 0 && col_ok && it.first && !a.accumulate) {   // per-row outputs: written once (row itself / first chunk, first launch)
             VecIO<XT, EPV>::store_nt(static_cast<XT*>(a.Y) + row * a.ldy + c0, dn);
             if (hs == 0) {

@@ -663,7 +663,7 @@ class DistGraph:
                            model.attentions[0].alpha, True)
         a1, a2 = model.out_att._split_a()
         x = torch.nn.functional.elu(self.gat_layer(x, [model.out_att.W], [a1], [a2], model.out_att.alpha, False))
-        return torch.log_softmax(x, dim=1)
+        return torch.log_softmax(x, dim=1, dtype=torch.float32 if x.dtype == torch.bfloat16 else None)
 
     def sage_forward(self, model, x_local, placed_input=None):
         """Full-graph GraphSage forward on this rank's rows (x_local in local row order).  `placed_input`: handle from

@@ -61,4 +61,5 @@ class GCN(F.nn.Module):
     def forward(self, x, adj):
         hidden = self.gcn1(x, adj, relu=True)                 # F.relu(self.gcn1(x, adj)), gcnconv.py:54
         hidden = F.dropout(hidden, self.dropout, training=self.training)
-        return F.log_softmax(self.gcn2(hidden, adj), dim=1)
+        out = self.gcn2(hidden, adj)
+        return F.log_softmax(out, dim=1, dtype=F.float32 if out.dtype == F.bfloat16 else None)   # fp32 log-probabilities (gatconv.py note)
