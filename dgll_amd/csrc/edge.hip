@@ -209,17 +209,15 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_rows_kernel(const EdgeArgs a, 
                 dhp = g[i] * op1;
                 hp = op1 > 0.0f ? log1pf(o[i]) : 0.0f;
             }
-            part = fmaf(dhp, hp, part);
             dn[i] = dhp * inv_den;
+            // bf16: dd_i = -DN_i . hp_i from the ROUNDED DN_i the dot products (and the transposed pass) use -- see gat_kernel.hpp
+            if (sizeof(XT) == 2) dn[i] = bf16_to_f32(f32_to_bf16(dn[i]));
+            part = fmaf(dn[i], hp, part);
         }
-        dd = -head_sum(part, lph) * inv_den;
+        dd = -head_sum(part, lph);
         if (slot == 0 && col_ok && it.first && !a.accumulate) {   // per-row outputs: written once (row itself / first chunk, first launch)
             VecIO<XT, EPV>::store(static_cast<XT*>(a.Y) + row * a.ldy + c0, dn);
             if ((sub % lph) == 0) a.out_b[row * a.heads + head] = dd;
-        }
-        if (sizeof(XT) == 2) {  // the transposed pass re-reads DN in storage precision: use the same rounded values here
-#pragma unroll
-            for (int i = 0; i < EPV; ++i) dn[i] = bf16_to_f32(f32_to_bf16(dn[i]));
         }
     }
     uint32_t dnp[4] = {0u, 0u, 0u, 0u};   // DN_i as packed bf16 pairs for the dot2 path (exact: dn was rounded above)
