@@ -126,6 +126,7 @@ struct MfmaGemmArgs {
     int64_t ldo;
     int64_t M;
     int N, relu, out_f32, pairs;
+    int pad_store;          // bf16 output whose row padding [N, ldo) belongs to the output: whole 16-byte vectors are stored, zeros past N
     const float* bias;
     const bf16_t* out_gate; // optional [M, N]: outputs are zeroed where out_gate <= 0 (the consumer's ReLU backward)
     int64_t ldgate;
@@ -287,13 +288,16 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_bf16_nt_kernel(const MfmaGemmA
             const int idx = it * kWave + lane;
             const int r = idx / kVecs, n = (idx % kVecs) * 8;
             const int64_t grow = m0 + r;
-            if (grow >= a.M || n >= a.N) continue;
+            const int n_store = a.pad_store ? (int)a.ldo : a.N;      // as in the resident-weights kernel's epilogue
+            if (grow >= a.M || n >= n_store) continue;
             uint4 d = *reinterpret_cast<const uint4*>(mine + r * kOPitch + n * 2);
             bf16_t* o = static_cast<bf16_t*>(a.out) + grow * a.ldo + n;
-            if (n + 8 <= a.N && vec_rows) {
+            const bool pad_vec = a.pad_store && n + 8 > a.N && n + 8 <= a.ldo;
+            if (pad_vec) d = mask_tail(d, a.N > n ? a.N - n : 0);
+            if ((n + 8 <= a.N || pad_vec) && vec_rows) {
                 if (a.out_gate) d = relu_mask(d, *reinterpret_cast<const uint4*>(a.out_gate + grow * a.ldgate + n));
                 *reinterpret_cast<uint4*>(o) = d;
-            } else {
+            } else if (n < a.N) {
                 const uint32_t w[4] = {d.x, d.y, d.z, d.w};
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
@@ -612,7 +616,10 @@ __device__ __forceinline__ void res_epilogue(const MfmaGemmArgs& a, char* scratc
     for (int u = 0; u < TP; ++u) {
         const int t = tp + u;
         const int nt0 = n0 + t * 32;
-        if (nt0 >= a.N) continue;                               // wave-uniform
+        // columns that may be written: with pad_store the row padding too (zeros) -- a 47-column row on a 128-byte pitch is then
+        // written as whole lines with 16-byte stores (256 -> 47: 3.6 -> see DESIGN 4.3; seven 2-byte stores per row before)
+        const int n_store = a.pad_store ? (int)a.ldo : a.N;
+        if (nt0 >= n_store) continue;                           // wave-uniform
         if (!PLAIN && a.out_f32) {
             if (row < a.M) {
 #pragma unroll
@@ -669,19 +676,21 @@ __device__ __forceinline__ void res_epilogue(const MfmaGemmArgs& a, char* scratc
             const int r = idx >> 2, nl = (idx & 3) * 8;
             const int n = nt0 + nl;
             const int64_t grow = m0 + r;
-            if (grow >= a.M || n >= a.N) continue;
+            if (grow >= a.M || n >= n_store) continue;
             uint4 d = *reinterpret_cast<const uint4*>(scratch + r * kPitch + nl * 2);
             bf16_t* o = static_cast<bf16_t*>(a.out) + grow * a.ldo + n;
 #if defined(DGLL_RES_ABL) && (DGLL_RES_ABL & 1)
             if (d.x != 0x12345678u) continue;                          // probe: no stores
 #endif
-            if (n + 8 <= a.N && vec_rows) {
+            const bool pad_vec = a.pad_store && n + 8 > a.N && n + 8 <= a.ldo;    // a vector that reaches into the row padding
+            if (pad_vec) d = mask_tail(d, a.N > n ? a.N - n : 0);
+            if ((n + 8 <= a.N || pad_vec) && vec_rows) {
                 if constexpr (!PLAIN) {
                     if (gate_fast) d = relu_mask(d, gate_v[u][it]);
                     else if (a.out_gate) d = relu_mask(d, *reinterpret_cast<const uint4*>(a.out_gate + grow * a.ldgate + n));
                 }
                 *reinterpret_cast<uint4*>(o) = d;
-            } else {
+            } else if (n < a.N) {
                 const uint32_t w[4] = {d.x, d.y, d.z, d.w};
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
@@ -851,7 +860,8 @@ static hipError_t launch_mfma_res_p(const MfmaGemmArgs& a, hipStream_t s) {
 #ifdef DGLL_RES_D
     constexpr int D = (NC % DGLL_RES_D == 0 || DGLL_RES_D % NC == 0) ? DGLL_RES_D : NC;    // probe builds: forced ring depth
 #else
-    constexpr int D = 1;      // measured (tools/probes/res_trace.hip): more chunks in flight only queue -- see the header above
+    constexpr int D = 1;      // measured (tools/probes/res_trace.hip): more chunks in flight only queue -- see the header above; round 3,
+                              // narrow outputs with the whole reduction of a row block in flight (D = NC): 256 -> 47 0.317 -> 0.34 ms
 #endif
 #ifdef DGLL_RES_RG
     constexpr int RG = DGLL_RES_RG;
@@ -1015,7 +1025,9 @@ static int transform_bf16_impl(void* stream, const void* A1, int64_t lda1, int K
     }
     if (relu_mask) DGLL_REQUIRE(aligned16(relu_mask) && (ldm * 2) % 16 == 0, "mask alignment");
     a.mask = static_cast<const bf16_t*>(relu_mask); a.ldm = ldm;
-    a.out = out; a.ldo = ldo; a.M = M; a.N = N; a.relu = relu; a.out_f32 = out_dtype == DGLL_F32; a.bias = bias;
+    a.out = out; a.ldo = ldo; a.M = M; a.N = N; a.relu = relu & 1; a.out_f32 = out_dtype == DGLL_F32; a.bias = bias;
+    // relu bit 1: the caller owns the row padding [N, ldo) of a bf16 output and lets the kernel write zeros there
+    a.pad_store = (relu & 2) && out_dtype == DGLL_BF16 && (ldo % 8) == 0 && aligned16(out) ? 1 : 0;
     DGLL_REQUIRE(!out_gate || (ldgate >= N && aligned16(out_gate) && (ldgate * 2) % 16 == 0),
                  "out_gate: bf16 [M, ldgate >= N], 16-byte aligned rows");
     a.out_gate = static_cast<const bf16_t*>(out_gate); a.ldgate = ldgate;

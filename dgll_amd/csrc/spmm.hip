@@ -575,7 +575,7 @@ DGLL_API int dgll_hip_csr_plan_create(void* stream, const int64_t* rowptr, int64
 
 extern int g_tune_mfma_kperm;   // dense.hip
 extern int g_tune_gat_gen;      // edge.hip
-extern int g_tune_res_per_cu;   // dense.hip
+extern int g_tune_res_per_cu;
 
 DGLL_API int dgll_hip_debug_tune(int key, int value) {
     switch (key) {

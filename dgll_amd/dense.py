@@ -68,7 +68,9 @@ def transform_bf16(a1, wt1, a2=None, wt2=None, relu=False, out_dtype=torch.bfloa
             a2.shape[1] if a2 is not None else 0, p2.data_ptr() if p2 is not None else None,
             p2.stride(0) if p2 is not None else 0, p1.shape[0], mask.data_ptr() if mask is not None else None,
             mask.stride(0) if mask is not None else 0, out.data_ptr(), out.stride(0),
-            _lib.BF16 if out_dtype == torch.bfloat16 else _lib.F32, m, n, int(relu), bias.data_ptr() if bias is not None else None,
+            _lib.BF16 if out_dtype == torch.bfloat16 else _lib.F32, m, n,
+            int(relu) | 2,      # bit 1: `store` is this function's own allocation, its row padding may be written (zeros)
+            bias.data_ptr() if bias is not None else None,
             out_gate.data_ptr() if out_gate is not None else None, out_gate.stride(0) if out_gate is not None else 0,
             row_scale.data_ptr() if row_scale is not None else None,
             addend.data_ptr() if addend is not None else None, addend.stride(0) if addend is not None else 0)

@@ -303,7 +303,10 @@ int dgll_hip_grad_weight_f32(void* stream, const float* X, int64_t ldx, const fl
  * ReLU backward: A1 is zeroed where the mask is <= 0).  A*: bf16 row-major, 16-byte aligned, lda a multiple of 8.
  * Wt*: the weight TRANSPOSED, bf16, zero padded to [64 rows if N <= 64, 128 if N <= 128, else 256] x
  * [ld >= 64*ceil(K/64) columns] (the kernel stages 2, 4 or 8 column tiles of 32 rows of Wt).  N <= 256.
- * out: bf16 or fp32 [M, ldo].  A2/Wt2/relu_mask/bias may be NULL.                                              */
+ * out: bf16 or fp32 [M, ldo].  A2/Wt2/relu_mask/bias may be NULL.
+ * relu: bit 0 = fuse max(., 0); bit 1 (bf16 output, ldo a multiple of 8, 16-byte aligned) = the row padding [N, ldo)
+ * belongs to the output and is written with zeros: rows are stored as whole 16-byte vectors / whole lines (a 47-column
+ * row on a 128-byte pitch: 256 -> 47 runs at the speed of 256 -> 64 instead of 25 % slower).                         */
 int dgll_hip_transform_bf16(void* stream, const void* A1, int64_t lda1, int K1, const void* Wt1, int64_t ldw1,
                             const void* A2, int64_t lda2, int K2, const void* Wt2, int64_t ldw2, int wt_rows,
                             const void* relu_mask, int64_t ldm, void* out, int64_t ldo, int out_dtype,

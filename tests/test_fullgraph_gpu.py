@@ -211,6 +211,45 @@ def test_mfma_transform_relu_mask_and_nan_pads(cuda_device):
     np.testing.assert_allclose(out.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-3)
 
 
+@pytest.mark.parametrize("K,N,ld_align,extra", [(256, 47, 64, ""), (256, 47, 64, "addend"), (256, 47, 8, "gate"), (640, 47, 64, ""),
+                                                (100, 33, 64, "addend"), (64, 8, 64, ""), (256, 130, 8, "")])
+def test_mfma_transform_writes_the_row_padding_with_zeros(cuda_device, K, N, ld_align, extra):
+    """relu bit 1 of dgll_hip_transform_bf16* (set by dense.transform_bf16, which allocates the output): rows are stored as whole
+    16-byte vectors up to the padded width; the padding columns come out as exact zeros whatever the addend's / gate's own padding
+    holds, the [M, N] result is unchanged.  Without the bit (a caller's own buffer) the padding is not touched."""
+    from dgll_amd import _lib, dense
+
+    dev = cuda_device
+    torch.manual_seed(K + N)
+    M = 1000
+    a = dense._as_rows16(torch.randn(M, K, device=dev).to(torch.bfloat16))      # 16-byte aligned rows (K = 100: 104-column pitch)
+    w = (torch.randn(N, K, device=dev) * 0.1).to(torch.bfloat16)
+    ld = -(-N // ld_align) * ld_align
+    side = torch.full((M, ld), float("nan"), device=dev, dtype=torch.bfloat16)      # addend / gate with NaN in ITS padding
+    side[:, :N] = torch.randn(M, N, device=dev)
+    kw = {"addend": side[:, :N]} if extra == "addend" else {"out_gate": side[:, :N]} if extra == "gate" else {}
+    out = dense.transform_bf16(a, w, relu=True, ld_align=ld_align, **kw)
+    z = a.float() @ w.float().t()
+    if extra == "addend":
+        z = z + side[:, :N].float()
+    ref = torch.relu(z)
+    if extra == "gate":
+        ref = ref * (side[:, :N].float() > 0)
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref.cpu().numpy(), rtol=1e-2, atol=2e-2)
+    whole = out.as_strided((M, out.stride(0)), (out.stride(0), 1))
+    assert out.stride(0) == ld and bool((whole[:, N:] == 0).all())
+    # the C entry point without the bit, into a caller's buffer: nothing beyond column N is written
+    mine = torch.full((M, ld), float("nan"), device=dev, dtype=torch.bfloat16)
+    p1 = dense._pad_wt(w)
+    code = _lib.lib.dgll_hip_transform_bf16(torch.cuda.current_stream(dev).cuda_stream, a.data_ptr(), a.stride(0), K, p1.data_ptr(),
+                                            p1.stride(0), None, 0, 0, None, 0, p1.shape[0], None, 0, mine.data_ptr(), ld, _lib.BF16, M, N, 1,
+                                            None)
+    _lib.check(code, "dgll_hip_transform_bf16")
+    assert bool(torch.isnan(mine[:, N:]).all()) and bool(torch.isfinite(mine[:, :N]).all())
+    if not extra:
+        assert torch.equal(mine[:, :N], out)
+
+
 def test_bf16_bench_configuration_against_the_storage_emulating_oracle(cuda_device):
     """The bench configuration (100-256-256-47, bf16, full graph) against CPU autograd of oracle/torch_ref.sage_block with bf16
     rounding applied exactly where the GPU path stores a tensor: every layer's stored output must agree entry for entry (up to
