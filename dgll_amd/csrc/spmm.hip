@@ -721,7 +721,10 @@ int dgll_spmm_csr_impl(void* stream, const dgll_csr_plan* plan, const int64_t* r
         // 128: -24 %; F = 256 (two slots): +6 %, and at 51 edges per row the wave-per-row kernel wins everywhere (+11 .. +32 %:
         // a slot walks its row U edges at a time, a whole wavefront 64).
         const double avg_len = plan ? (double)plan->nnz / (double)std::max<int64_t>(n_rows, 1) : 1e9;
-        rowslot = !only_long && lpr <= 32 && g_tune_rowslot != 1 && (g_tune_rowslot == 2 || (lpr <= 16 && avg_len <= 24.0));
+        // Round 3: at F = 256 (two slots) it wins once rows are VERY short -- 3.2 edges per row, the transposed halo half of an 8-way
+        // partition (678 k rows, 2.1 M edges): 0.49 -> 0.39 ms (tools/scaling_trace.py); hence <= 4.5 edges for 32 lanes per row.
+        rowslot = !only_long && lpr <= 32 && g_tune_rowslot != 1 &&
+                  (g_tune_rowslot == 2 || (lpr <= 16 && avg_len <= 24.0) || (lpr == 32 && avg_len <= 4.5));
         if (rowslot) {
             const int slots = kWave / lpr;
             a.rows_per_wave = std::max(a.rows_per_wave, 1);

@@ -499,6 +499,124 @@ class DistGatAggregate(torch.autograd.Function):
         return grad_h, grad_s, grad_t, None, None, None, None, None
 
 
+class _Placed(tuple):
+    """Handle of DistGraph.place_input_halo: (own rows, halo rows, all rows) of the input features as views of one buffer, plus
+    what is derived from them once per aggregation mode (DistGraph.input_aggregate_all)."""
+
+    def __new__(cls, items):
+        obj = super().__new__(cls, items)
+        obj.agg_all = {}
+        return obj
+
+
+class _DistSageInputLayerAll(torch.autograd.Function):
+    """The FIRST layer, act(x.Ws + reduce_A(x).Wn), on this rank's own rows AND on its halo rows.
+
+    The first layer's inputs depend on no parameter: x of a halo node is placed once (place_input_halo) and so is its aggregated
+    input row reduce_A(x)_j, which the owner computes (input_aggregate_all).  With both on the rank, the halo nodes' first-layer
+    output is RECOMPUTED here -- (n_own + n_halo) rows of a K = F_in transform -- instead of being received every step as
+    n_halo rows of hidden width: at 8 ranks of the bench graph that is 0.15 ms of MFMA work against 347 MB over the links per
+    direction and step.  The backward mirrors it: the gradient that reaches a halo node's first-layer output stays on this rank
+    and goes straight into this rank's PARTIAL weight gradient (x_j and its aggregate are here; the layer has no input gradient);
+    the gradient all-reduce the ranks do anyway sums the partials.  The owner applies the same ReLU mask to the same output, and
+    the mask is linear in the gradient, so the sum over ranks equals the owner-side reduction of the exchange it replaces."""
+
+    @staticmethod
+    def forward(ctx, ws, wn, engine, reduce, relu, grad_is_gated, placed):
+        from . import dense
+
+        p = engine.part
+        x_all = placed[2]
+        agg_all = engine.input_aggregate_all(placed, reduce)
+        scale = p.inv_deg if reduce == "mean" else None
+        engine.spmm(p.merged, x_all, agg_all[:p.n_own], row_scale=scale)        # this rank's rows: aggregated every step
+        wsd, wnd = ws.to(x_all.dtype), wn.to(x_all.dtype)
+        if x_all.is_cuda and dense._mfma_ok(x_all, agg_all) and ws.shape[1] <= 256:
+            out = dense.transform_bf16(x_all, wsd.t(), agg_all, wnd.t(), relu=relu)
+        else:
+            out = dense.mm2_nt(x_all, wsd.t(), agg_all, wnd.t(), relu=relu)
+        ctx.relu, ctx.grad_is_gated = relu, grad_is_gated
+        ctx.save_for_backward(x_all, agg_all, out if relu else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import dense
+
+        x_all, agg_all, out = ctx.saved_tensors
+        g = dense._rows(g)
+        if ctx.relu and not ctx.grad_is_gated:
+            g = torch.ops.aten.threshold_backward(g, out, 0)
+        if ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
+            gws, gwn = dense.grad_weight_pair(x_all, agg_all, g)                # own + halo rows: this rank's partial
+        else:
+            gws = dense.grad_weight(x_all, g) if ctx.needs_input_grad[0] else None
+            gwn = dense.grad_weight(agg_all, g) if ctx.needs_input_grad[1] else None
+        return gws, gwn, None, None, None, None, None
+
+
+class _DistSageLayerOnAll(torch.autograd.Function):
+    """act(h.Ws + reduce_A(h).Wn) for a layer whose input arrives for own AND halo rows (h_all, from _DistSageInputLayerAll):
+    one pass over the merged adjacency forward, the two transposed halves backward -- no exchange in either direction.  The
+    gradient it returns covers all n_own + n_halo rows (the self path only the own ones)."""
+
+    @staticmethod
+    def forward(ctx, h_all, ws, wn, engine, reduce, relu, grad_is_gated, gate_input):
+        from . import dense
+
+        p = engine.part
+        scale = p.inv_deg if reduce == "mean" else None
+        _, agg = engine.alloc_rows(p.n_own, h_all.shape[1], h_all.dtype)
+        engine.spmm(p.merged, h_all, agg, row_scale=scale)
+        h = h_all[:p.n_own]
+        wsd, wnd = ws.to(h.dtype), wn.to(h.dtype)
+        if h.is_cuda and dense._mfma_ok(h, agg) and ws.shape[1] <= 256:
+            out = dense.transform_bf16(h, wsd.t(), agg, wnd.t(), relu=relu)
+        else:
+            out = dense.mm2_nt(h, wsd.t(), agg, wnd.t(), relu=relu)
+        ctx.engine, ctx.reduce, ctx.relu = engine, reduce, relu
+        ctx.grad_is_gated, ctx.gate_input = grad_is_gated, gate_input
+        ctx.save_for_backward(h_all, agg, wsd, wnd, out if relu else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import dense
+
+        h_all, agg, wsd, wnd, out = ctx.saved_tensors
+        engine = ctx.engine
+        p = engine.part
+        h = h_all[:p.n_own]
+        g = g.contiguous()
+        if ctx.relu and not ctx.grad_is_gated:
+            g = torch.ops.aten.threshold_backward(g, out, 0)
+        gh_all = None
+        if ctx.needs_input_grad[0]:
+            inv = p.inv_deg if ctx.reduce == "mean" else None
+            if inv is not None and g.is_cuda and dense._mfma_ok(g) and wnd.shape[0] <= 256:
+                gagg = dense.transform_bf16(g, wnd, row_scale=inv)                 # (g.Wn^T) / deg in one kernel
+            else:
+                gagg = dense.mm_nt(g, wnd)
+                if inv is not None:
+                    gagg = gagg * inv.unsqueeze(1).to(gagg.dtype)
+            _, gagg = engine.rows_of(gagg)
+            _, gh_all = engine.alloc_rows(p.n_own + p.n_halo, h_all.shape[1], h_all.dtype)
+            gh_all[:p.n_own].copy_(dense.input_grad(g, wsd))                       # self path: own rows only
+            gate = h_all if (ctx.gate_input and h_all.stride(1) == 1) else None
+            engine.spmm(engine.transposed(p.local), gagg, gh_all[:p.n_own], accumulate=True,
+                        gate=gate[:p.n_own] if gate is not None else None)
+            if p.n_halo:   # what the exchange used to carry back to the owners stays here (see _DistSageInputLayerAll)
+                engine.spmm(engine.transposed(p.halo), gagg, gh_all[p.n_own:], gate=gate[p.n_own:] if gate is not None else None)
+            if ctx.gate_input and gate is None:
+                gh_all = torch.ops.aten.threshold_backward(gh_all, h_all, 0)
+        if ctx.needs_input_grad[1] and ctx.needs_input_grad[2]:
+            gws, gwn = dense.grad_weight_pair(h, agg, g)
+        else:
+            gws = dense.grad_weight(h, g) if ctx.needs_input_grad[1] else None
+            gwn = dense.grad_weight(agg, g) if ctx.needs_input_grad[2] else None
+        return gh_all, gws, gwn, None, None, None, None, None
+
+
 class DistGraph:
     """Per-rank engine: owns the Partition, the communication stream and the kernels' scratch."""
 
@@ -508,6 +626,7 @@ class DistGraph:
         self.exchange = _Exchange(part, group)
         self._spmm_fn = spmm_fn
         self.comm_stream = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
+        self.halo_recompute = True       # sage_forward: first layer recomputed on halo rows instead of exchanged (set False to compare)
         if self.device.type == "cuda":   # build the schedules up front, not inside the first timed step
             for g in (part.local, part.halo):
                 g.plan()
@@ -616,7 +735,27 @@ class DistGraph:
         if self.device.type == "cuda":
             torch.cuda.current_stream(self.device).synchronize()
             p.merged.plan()
-        return (h_view, all_view[p.n_own:], all_view)
+        return _Placed((all_view[:p.n_own], all_view[p.n_own:], all_view))
+
+    def input_aggregate_all(self, placed, reduce="mean"):
+        """[n_own + n_halo, F] rows of reduce_A(x): the first n_own are this rank's (the caller re-computes them every step --
+        no work of the model is skipped), the rest belong to the halo nodes and are received ONCE from their owners: like the
+        input features themselves they depend on no parameter.  Collective on first use (every rank calls it at the same point
+        of its first forward)."""
+        if reduce in placed.agg_all:
+            return placed.agg_all[reduce]
+        p = self.part
+        x_all = placed[2]
+        store, view = self.alloc_rows(p.n_own + p.n_halo, x_all.shape[1], x_all.dtype)
+        self.spmm(p.merged, x_all, view[:p.n_own], row_scale=p.inv_deg if reduce == "mean" else None)
+        send_store = store[:p.n_own].index_select(0, p.send_idx) if p.send_idx.numel() else store[:0]
+        with self.comm_scope():
+            self.exchange.wait(self.exchange.start(send_store, store[p.n_own:]))
+        self.join_comm()
+        if self.device.type == "cuda":
+            torch.cuda.current_stream(self.device).synchronize()
+        placed.agg_all[reduce] = view
+        return view
 
     def aggregate_static(self, placed, reduce="mean"):
         """Aggregation of input features whose halo rows were placed once (no gradient flows to raw features)."""
@@ -675,7 +814,22 @@ class DistGraph:
         # as in GraphSage.forward_graph: layer i returns the gradient of its input already masked by layer i-1's ReLU
         gates = [i > 0 and fusable[i] and fusable[i - 1] and layers[i - 1].activation is not None for i in range(len(layers))]
         h = x_local
+        first = 0
+        # Layers 0 and 1 without any per-step exchange: the first layer is evaluated on own AND halo rows (its inputs are static,
+        # _DistSageInputLayerAll), the second aggregates over the merged adjacency.  Only layers from the third on exchange.
+        if (self.halo_recompute and isinstance(placed_input, _Placed) and len(layers) >= 2 and not x_local.requires_grad
+                and self.part.merged is not None and all(fused_layers.can_fuse(layers[i], True) for i in (0, 1))
+                and not layers[0].transform_first(x_local) and layers[1].hidden_dim >= layers[1].input_dim):
+            relu0, relu1 = layers[0].activation is not None, layers[1].activation is not None
+            h_all = _DistSageInputLayerAll.apply(layers[0].weight, layers[0].neighborAgg.weight, self, layers[0].aggr_neighbor_method,
+                                                 relu0, relu0, placed_input)          # layer 1 returns its gradient masked
+            gated1 = bool(len(layers) > 2 and gates[2] and relu1)
+            h = _DistSageLayerOnAll.apply(h_all, layers[1].weight, layers[1].neighborAgg.weight, self,
+                                          layers[1].aggr_neighbor_method, relu1, gated1, relu0)
+            first = 2
         for li, layer in enumerate(layers):
+            if li < first:
+                continue
             reduce = layer.aggr_neighbor_method
             static = li == 0 and placed_input is not None and not x_local.requires_grad and not layer.transform_first(h)
             if fusable[li]:

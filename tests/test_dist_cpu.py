@@ -238,3 +238,71 @@ def _ddp_worker(rank, world, port):
 @pytest.mark.parametrize("world", [2, 4, 3, 8])
 def test_racom_sync_form_equals_ddp_bit_for_bit(world):
     mp.spawn(_ddp_worker, args=(world, _free_port()), nprocs=world, join=True)
+
+
+def _sage_model_worker(rank, world, port):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dgll_amd import dist as ddist
+        from dgll_amd import nn as dnn
+        from dgll_amd import synth
+        from oracle import torch_ref
+
+        torch.manual_seed(0)
+        full = synth.rmat_graph(9, 6, seed=7, device="cpu", symmetric=True, weighted=False)
+        n = full.n_rows
+        model = dnn.GraphSage(12, [24, 24, 5], None).double()
+        x = torch.randn(n, 12, dtype=torch.float64)
+        gout = torch.randn(n, 5, dtype=torch.float64)
+        # single-process reference: the oracle's layer formula on the whole graph
+        h = x
+        for layer in model.gcn:
+            h = torch_ref.sage_block(full.rowptr, full.col, h, h, layer.weight, layer.neighborAgg.weight, act=layer.activation is not None)
+        (h * gout).sum().backward()
+        ref_out = h.detach()
+        ref_grads = [p.grad.clone() for p in model.parameters()]
+
+        part = ddist.partition_contiguous(full, world, rank, ddist.nnz_balanced_bounds(full, world))
+        engine = ddist.DistGraph(part, "cpu", spmm_fn=_cpu_spmm)
+        engine.verify()
+        blk = slice(part.own_begin, part.own_end)
+        results = {}
+        for recompute in (True, False):
+            model.zero_grad()
+            engine.halo_recompute = recompute
+            placed = engine.place_input_halo(x[blk].clone())
+            out = engine.sage_forward(model, x[blk].clone(), placed)
+            np.testing.assert_allclose(out.detach().numpy(), ref_out[blk].numpy(), rtol=5e-5, atol=1e-5)   # the engine's 1/deg is fp32
+            (out * gout[blk]).sum().backward()
+            ddist.RaCoM(model.parameters(), "cpu").all_reduce_and_wait()            # averages the ranks' (partial) gradients
+            for p, r in zip(model.parameters(), ref_grads):
+                np.testing.assert_allclose((p.grad * world).numpy(), r.numpy(), rtol=1e-4, atol=1e-5 * float(r.abs().max()))
+            results[recompute] = [p.grad.clone() for p in model.parameters()]
+        for a, b in zip(results[True], results[False]):
+            np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=1e-4, atol=1e-5 * float(b.abs().max()))   # host weight gradients are fp32
+        # exchanges per step (forward + backward): the third layer's two with the recompute, the second layer's two more without
+        calls = []
+        start = engine.exchange.start
+        engine.exchange.start = lambda *a, **k: (calls.append(tuple(a[0].shape)), start(*a, **k))[1]
+        per_step = {}
+        for recompute in (True, False):
+            engine.halo_recompute = recompute
+            placed = engine.place_input_halo(x[blk].clone())
+            if recompute:
+                engine.input_aggregate_all(placed, "mean")                            # the one-time placements, outside the step
+            calls.clear()
+            out = engine.sage_forward(model, x[blk].clone(), placed)
+            (out * gout[blk]).sum().backward()
+            per_step[recompute] = len(calls)
+        assert per_step == {True: 2, False: 4}, per_step
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_first_layer_recomputed_on_halo_rows_equals_the_exchange(world):
+    """DistGraph.sage_forward with placed inputs: the first layer is evaluated on own + halo rows and the second aggregates over
+    the merged adjacency, so layers 0 and 1 exchange nothing per step (dist._DistSageInputLayerAll).  Outputs and the all-reduced
+    parameter gradients equal the single-process model and the exchanging path; the per-step exchanges left are the third layer's."""
+    mp.spawn(_sage_model_worker, args=(world, _free_port()), nprocs=world, join=True)
