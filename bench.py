@@ -595,11 +595,19 @@ def calibrate_launches(args, c, n):
     import dgll_amd
     from dgll_amd import ops
 
+    from dgll_amd import _lib
+
     ident = dgll_amd.CSRGraph.fixed_fanout(n, 1, c.dev)
     xc = ops.alloc_features(n, args.hidden, c.dtype, c.dev)
     xc.copy_(torch.randn(n, args.hidden, device=c.dev).to(c.dtype))
-    for _ in range(3):
-        ops.spmm_raw(ident, xc, reduce="sum")
+    # one-edge rows would be handed to the row-per-slot kernel: the calibration must run on the wave-per-row kernel the measured
+    # launches use (tools/pmc_parse.py looks for it by name)
+    _lib.check(_lib.lib.dgll_hip_debug_tune(5, 1), "tune")
+    try:
+        for _ in range(3):
+            ops.spmm_raw(ident, xc, reduce="sum")
+    finally:
+        _lib.check(_lib.lib.dgll_hip_debug_tune(5, 0), "tune")
     del ident, xc
 
 

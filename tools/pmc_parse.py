@@ -84,6 +84,8 @@ def main():
         calib = {"kernel": calib_kernel, "known_read_bytes": known_r, "reported_fetch_bytes": fr, "ratio_read": ratio_r,
                  "known_write_bytes": known_w, "reported_write_bytes": wr, "ratio_write": ratio_w}
         print("calibration: FETCH_SIZE reports %.3f of the known read, WRITE_SIZE %.3f of the known write" % (ratio_r, ratio_w))
+        if not (0.3 <= ratio_r <= 1.2 and 0.7 <= ratio_w <= 1.3):
+            raise SystemExit("implausible calibration (%.3f / %.3f): the first three launches of %s are not the known-byte launches" % (ratio_r, ratio_w, calib_kernel))
     else:
         print("NO calibration launches found: falling back to ratio_read 0.5 / ratio_write 1.0")
     sig = {"workload": cfg.get("workload_id", "sage"), "nodes": n, "nnz": cfg["nnz"], "locality": cfg["locality"],
