@@ -767,6 +767,7 @@ def run_gat(args, c):
     racom = engine = None
     if c.world > 1:
         engine, x_local, labels = make_engine(args, c, full, feats_all, labels_all, bounds)
+        placed_input = engine.place_input_halo(x_local)     # input features of halo nodes live with the partition
         graph_for_cpu = None
         racom = ddist.RaCoM(model.parameters(), c.dev)
     else:
@@ -783,7 +784,7 @@ def run_gat(args, c):
 
     def step():
         opt.zero_grad(set_to_none=True)
-        out = model(x_local, full) if engine is None else engine.spgat_forward(model, x_local)     # log_softmax, gatconv.py:199
+        out = model(x_local, full) if engine is None else engine.spgat_forward(model, x_local, placed_input)     # log_softmax
         # F.nll_loss of the reference's training loops, as its definition (torch's nll_loss kernels take 10 ms at this size)
         loss = -out.gather(1, labels.unsqueeze(1)).float().sum() * (world / n)
         loss.backward()

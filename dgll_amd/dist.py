@@ -433,7 +433,10 @@ class DistGatAggregate(torch.autograd.Function):
     owners -- overlapped with the column pass over local^T; returned pieces are reduced in fixed order."""
 
     @staticmethod
-    def forward(ctx, h_own, s_own, t_own, engine, heads, fo, alpha, apply_elu):
+    def forward(ctx, h_own, s_own, t_own, engine, heads, fo, alpha, apply_elu, halo_local=False):
+        """halo_local: h / s / t arrive for own AND halo rows ([n_own + n_halo, ...]: the first layer, whose transform of the
+        statically placed halo inputs was evaluated on this rank) -- nothing is exchanged in either direction; the gradients of
+        the halo rows are returned to the caller, whose autograd turns them into this rank's partial weight gradients."""
         from . import ops_edge as oe
 
         p = engine.part
@@ -443,21 +446,26 @@ class DistGatAggregate(torch.autograd.Function):
         s_own = s_own.detach().float().contiguous()
         t_own = t_own.detach().float().contiguous()
         has_halo = p.n_halo > 0
-        send_h = h_store.index_select(0, p.send_idx) if p.send_idx.numel() else h_store[:0]
-        send_t = t_own.index_select(0, p.send_idx) if p.send_idx.numel() else t_own[:0]
-        halo_store, halo_h = engine.alloc_rows(p.n_halo, feat, dtype)
-        halo_t = torch.empty((p.n_halo, heads), dtype=torch.float32, device=dev)
         _, out = engine.alloc_rows(p.n_own, feat, dtype)
         rowsum = torch.empty((p.n_own, heads), dtype=torch.float32, device=dev)
-        with engine.comm_scope():
-            reqs = engine.exchange.start(send_h, halo_store, more=((send_t, halo_t),))
-        oe.gat_fwd_part(p.local, h_view, s_own, t_own, out, rowsum, heads, fo, alpha, apply_elu, raw=has_halo, accumulate=False)
-        with engine.comm_scope():
-            engine.exchange.wait(reqs)
-        engine.join_comm()
+        if halo_local:
+            h_view, halo_h = h_view[:p.n_own], h_view[p.n_own:]
+            s_own, t_own, halo_t = s_own[:p.n_own], t_own[:p.n_own], t_own[p.n_own:]
+            oe.gat_fwd_part(p.local, h_view, s_own, t_own, out, rowsum, heads, fo, alpha, apply_elu, raw=has_halo, accumulate=False)
+        else:
+            send_h = h_store.index_select(0, p.send_idx) if p.send_idx.numel() else h_store[:0]
+            send_t = t_own.index_select(0, p.send_idx) if p.send_idx.numel() else t_own[:0]
+            halo_store, halo_h = engine.alloc_rows(p.n_halo, feat, dtype)
+            halo_t = torch.empty((p.n_halo, heads), dtype=torch.float32, device=dev)
+            with engine.comm_scope():
+                reqs = engine.exchange.start(send_h, halo_store, more=((send_t, halo_t),))
+            oe.gat_fwd_part(p.local, h_view, s_own, t_own, out, rowsum, heads, fo, alpha, apply_elu, raw=has_halo, accumulate=False)
+            with engine.comm_scope():
+                engine.exchange.wait(reqs)
+            engine.join_comm()
         if has_halo:
             oe.gat_fwd_part(p.halo, halo_h, s_own, halo_t, out, rowsum, heads, fo, alpha, apply_elu, raw=False, accumulate=True)
-        ctx.engine, ctx.cfg = engine, (heads, fo, alpha, apply_elu)
+        ctx.engine, ctx.cfg, ctx.halo_local = engine, (heads, fo, alpha, apply_elu), halo_local
         ctx.save_for_backward(h_view, halo_h, s_own, t_own, halo_t, out, rowsum)
         return out
 
@@ -478,6 +486,17 @@ class DistGatAggregate(torch.autograd.Function):
         oe.gat_bwd_rows_part(p.local, h_view, s_own, t_own, out, gv, rowsum, dn, dd, grad_s, heads, fo, alpha, apply_elu, False)
         if p.n_halo:
             oe.gat_bwd_rows_part(p.halo, halo_h, s_own, halo_t, out, gv, rowsum, dn, dd, grad_s, heads, fo, alpha, apply_elu, True)
+        if ctx.halo_local:      # gradients of own and halo rows side by side; nothing travels
+            _, gh_all = engine.alloc_rows(p.n_own + p.n_halo, feat, dtype)
+            gt_all = torch.empty((p.n_own + p.n_halo, heads), dtype=torch.float32, device=dev)
+            gs_all = torch.zeros((p.n_own + p.n_halo, heads), dtype=torch.float32, device=dev)   # a halo node's s is never used here
+            gs_all[:p.n_own] = grad_s
+            if p.n_halo:
+                oe.gat_bwd_cols_part(engine.transposed(p.halo), dn, halo_h, halo_t, s_own, dd, gh_all[p.n_own:], gt_all[p.n_own:],
+                                     heads, fo, alpha)
+            oe.gat_bwd_cols_part(engine.transposed(p.local), dn, h_view, t_own, s_own, dd, gh_all[:p.n_own], gt_all[:p.n_own],
+                                 heads, fo, alpha)
+            return gh_all, gs_all, gt_all, None, None, None, None, None, None
         n_send = int(p.send_idx.numel())
         gh_halo_store, gh_halo = engine.alloc_rows(p.n_halo, feat, dtype)
         gt_halo = torch.empty((p.n_halo, heads), dtype=torch.float32, device=dev)
@@ -496,7 +515,7 @@ class DistGatAggregate(torch.autograd.Function):
         if n_send:     # fixed-order reduction of the returned pieces at the owner
             engine.spmm(p.send_reduce, recv_gh, grad_h, accumulate=2)
             engine.spmm(p.send_reduce, recv_gt, grad_t, accumulate=2)
-        return grad_h, grad_s, grad_t, None, None, None, None, None
+        return grad_h, grad_s, grad_t, None, None, None, None, None, None
 
 
 class _Placed(tuple):
@@ -776,9 +795,10 @@ class DistGraph:
         the one place a relabelling partitioner would hook in)."""
         return x_block
 
-    def gat_layer(self, x, Ws, a1s, a2s, alpha, concat):
+    def gat_layer(self, x, Ws, a1s, a2s, alpha, concat, halo_local=False):
         """One (multi-head) sparseGatConv layer on this rank's rows: the partitioned twin of
-        nn.Convolution.gatconv._fused_heads (mode 0, attention dropout inactive)."""
+        nn.Convolution.gatconv._fused_heads (mode 0, attention dropout inactive).  halo_local: x holds own AND halo rows
+        (statically placed inputs): the transform and the scores are evaluated for both, nothing is exchanged."""
         from . import dense, ops
 
         heads, fo = len(Ws), Ws[0].shape[1]
@@ -790,16 +810,19 @@ class DistGraph:
         st = dense.skinny_linear(h, A)
         fo_pad = ops.head_width_padded(fo, h.dtype)
         hp = h if fo_pad == fo else torch.nn.functional.pad(h.view(-1, heads, fo), (0, fo_pad - fo)).reshape(-1, heads * fo_pad)
-        out = DistGatAggregate.apply(hp, st[:, :heads], st[:, heads:], self, heads, fo_pad, alpha, concat)
+        out = DistGatAggregate.apply(hp, st[:, :heads], st[:, heads:], self, heads, fo_pad, alpha, concat, halo_local)
         return out if fo_pad == fo else out.view(-1, heads, fo_pad)[:, :, :fo].reshape(-1, heads * fo)
 
-    def spgat_forward(self, model, x_local):
-        """SpGAT.forward (gatconv.py:194-199) on this rank's rows; input/attention dropout must be inactive."""
+    def spgat_forward(self, model, x_local, placed_input=None):
+        """SpGAT.forward (gatconv.py:194-199) on this rank's rows; input/attention dropout must be inactive.  placed_input
+        (place_input_halo): the first layer's transform x.W is evaluated on the halo rows too instead of exchanging its
+        heads * nhid-wide result every step (dist._DistSageInputLayerAll has the argument; here it needs no placed aggregate)."""
         if model.training and model.dropout > 0:
             raise NotImplementedError("the partitioned GAT path runs with dropout inactive (eval mode or p = 0)")
         halves = [att._split_a() for att in model.attentions]
-        x = self.gat_layer(x_local, [att.W for att in model.attentions], [h[0] for h in halves], [h[1] for h in halves],
-                           model.attentions[0].alpha, True)
+        local = self.halo_recompute and isinstance(placed_input, _Placed) and not x_local.requires_grad
+        x = self.gat_layer(placed_input[2] if local else x_local, [att.W for att in model.attentions], [h[0] for h in halves],
+                           [h[1] for h in halves], model.attentions[0].alpha, True, halo_local=local)
         a1, a2 = model.out_att._split_a()
         x = torch.nn.functional.elu(self.gat_layer(x, [model.out_att.W], [a1], [a2], model.out_att.alpha, False))
         return torch.log_softmax(x, dim=1, dtype=torch.float32 if x.dtype == torch.bfloat16 else None)

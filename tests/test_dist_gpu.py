@@ -95,12 +95,16 @@ def _gat_worker(rank, world, port):
         engine = ddist.DistGraph(part, dev)
         engine.verify()
         blk = slice(part.own_begin, part.own_end)
-        out = engine.spgat_forward(model, x[blk].contiguous())
-        torch.testing.assert_close(out, ref[blk], rtol=1e-4, atol=1e-4)
-        (out * gout[blk]).sum().backward()
-        ddist.RaCoM(model.parameters(), dev).all_reduce_and_wait()
-        for p, r in zip(model.parameters(), ref_grads):
-            torch.testing.assert_close(p.grad * world, r, rtol=2e-3, atol=2e-3 * float(r.abs().max()))
+        for placed in (None, engine.place_input_halo(x[blk].contiguous())):
+            # placed: the first layer's transform is evaluated on the halo rows as well and nothing of it is exchanged; the halo
+            # rows' gradients become this rank's partial weight gradients (summed by the all-reduce below)
+            model.zero_grad()
+            out = engine.spgat_forward(model, x[blk].contiguous(), placed)
+            torch.testing.assert_close(out, ref[blk], rtol=1e-4, atol=1e-4)
+            (out * gout[blk]).sum().backward()
+            ddist.RaCoM(model.parameters(), dev).all_reduce_and_wait()
+            for p, r in zip(model.parameters(), ref_grads):
+                torch.testing.assert_close(p.grad * world, r, rtol=2e-3, atol=2e-3 * float(r.abs().max()))
     finally:
         dist.destroy_process_group()
 
