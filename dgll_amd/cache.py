@@ -199,6 +199,58 @@ class GraphCacheServer:
                     self._pending.append((counter, n, done))
         return out
 
+    def aggregate_data(self, nids, rowptr, reduce="mean", stream=None):
+        """[len(rowptr) - 1, D] rows: row i = mean (or sum) of the features of nids[rowptr[i]:rowptr[i+1]] -- fetch_data fused with
+        the neighbour reduction of the layer that consumes the rows (sageconv.py:33-36).  For the OUTERMOST hop of a sampled batch,
+        whose features enter the model through that reduction only: its fan-out x batch rows are read from the HBM cache / the pinned
+        host store by the reducing kernel and never written (dgll_hip_aggregate_rows_mapped).  Stream semantics, cache-refresh safety
+        and miss accounting as fetch_data (every id counts as one try)."""
+        if reduce not in ("mean", "sum"):
+            raise ValueError("aggregate_data reduces with 'mean' or 'sum'")
+        stream = torch.cuda.current_stream(self.device) if stream is None else stream
+        with torch.cuda.stream(stream):
+            nids = nids.to(self.device, dtype=torch.int64, non_blocking=True)
+            rowptr = rowptr.to(self.device, dtype=torch.int64, non_blocking=True)
+            n_rows = int(rowptr.numel()) - 1
+            esz = self.features.element_size()
+            epv = 16 // esz
+            ld = -(-self.total_dim // epv) * epv
+            store = torch.zeros((n_rows, ld), dtype=self.features.dtype, device=self.device) if ld != self.total_dim else \
+                torch.empty((n_rows, ld), dtype=self.features.dtype, device=self.device)
+            out = store[:, :self.total_dim] if ld != self.total_dim else store
+            if n_rows <= 0:
+                return out
+            if (self.total_dim * esz) % 4 != 0 or (self.features.stride(0) * esz) % 4 != 0:
+                raise ValueError("aggregate_data needs 4-byte granular feature rows (fetch_data + a block reduction handle the rest)")
+            with self._pending_lock:
+                slot_map, cache, ready = getattr(self, "_state", (None, None, None))
+            use_map = cache is not None
+            if ready is not None:
+                stream.wait_event(ready)
+            host_map = self.nid_map
+            counter = None
+            if self.log and use_map:
+                counter = torch.zeros(1, dtype=torch.int64, device=self.device)
+            with torch.cuda.device(self.device):
+                code = _lib.lib.dgll_hip_aggregate_rows_mapped(
+                    stream.cuda_stream, cache.data_ptr() if use_map else None, cache.stride(0) if use_map else 0,
+                    self.features.data_ptr(), self.features.stride(0), nids.data_ptr(),
+                    slot_map.data_ptr() if use_map else None, host_map.data_ptr() if host_map is not None else None,
+                    rowptr.data_ptr(), out.data_ptr(), out.stride(0), n_rows, self.total_dim, _dtype_code(out),
+                    _lib.REDUCE_MEAN if reduce == "mean" else _lib.REDUCE_SUM, counter.data_ptr() if counter is not None else None)
+            _lib.check(code, "dgll_hip_aggregate_rows_mapped")
+            if use_map:
+                slot_map.record_stream(stream)
+                cache.record_stream(stream)
+            if self.log:
+                done = None
+                if counter is not None:
+                    done = torch.cuda.Event()
+                    done.record(stream)
+                with self._pending_lock:
+                    self._pending.append((counter, int(nids.numel()), done))
+        return out
+
     # ---- accounting (storage.py:213-220) -----------------------------------------------------------------------
     def log_miss_rate(self, miss_num, total_num):
         self.try_num += total_num

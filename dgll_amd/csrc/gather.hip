@@ -52,6 +52,107 @@ __global__ __launch_bounds__(kBlock) void gather_rows_kernel(const GatherArgs a,
     if (a.miss_count && lane == 0 && misses) atomicAdd(a.miss_count, (unsigned long long)misses);
 }
 
+// ---- aggregate straight out of the cache: out[i, :] = reduce_{k in [rowptr[i], rowptr[i+1])} row(idx[k]) ---------------------------------
+// The outermost hop of a sampled mini-batch enters the model through its MEAN only (sageconv.py:33-36 on neighbor_node_features
+// of the last hop): gathering its fan-out x batch rows into a matrix (fetch_data) only to reduce them in the next launch writes
+// and re-reads the largest tensor of the batch.  Here the reduction reads the HBM cache / the pinned host rows directly -- one
+// wavefront per destination row, neighbours NB at a time, fp32 accumulation -- and only the reduced [n_rows, F] rows are written.
+struct AggregateArgs {
+    const void* cache; const void* host;
+    const int64_t* idx; const int64_t* slot; const int64_t* host_map; const int64_t* rowptr;
+    void* out;
+    int64_t ldc, ldh, ldo, n_rows;
+    int row_bytes, mean;
+    unsigned long long* miss_count;
+};
+
+template <typename T, int VEC> struct AggIO;
+template <> struct AggIO<bf16_t, 16> {
+    typedef uint4 raw_t;
+    static __device__ __forceinline__ void add(const raw_t& r, float (&acc)[8]) {
+        const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { acc[2 * q] += __uint_as_float(w[q] << 16); acc[2 * q + 1] += __uint_as_float(w[q] & 0xffff0000u); }
+    }
+    static __device__ __forceinline__ raw_t pack(const float (&acc)[8], float sc) {
+        return make_uint4(pack_bf16x2(acc[0] * sc, acc[1] * sc), pack_bf16x2(acc[2] * sc, acc[3] * sc),
+                          pack_bf16x2(acc[4] * sc, acc[5] * sc), pack_bf16x2(acc[6] * sc, acc[7] * sc));
+    }
+};
+template <> struct AggIO<bf16_t, 4> {
+    typedef uint32_t raw_t;
+    static __device__ __forceinline__ void add(const raw_t& r, float (&acc)[2]) {
+        acc[0] += __uint_as_float(r << 16); acc[1] += __uint_as_float(r & 0xffff0000u);
+    }
+    static __device__ __forceinline__ raw_t pack(const float (&acc)[2], float sc) { return pack_bf16x2(acc[0] * sc, acc[1] * sc); }
+};
+template <> struct AggIO<float, 16> {
+    typedef float4 raw_t;
+    static __device__ __forceinline__ void add(const raw_t& r, float (&acc)[4]) { acc[0] += r.x; acc[1] += r.y; acc[2] += r.z; acc[3] += r.w; }
+    static __device__ __forceinline__ raw_t pack(const float (&acc)[4], float sc) { return make_float4(acc[0] * sc, acc[1] * sc, acc[2] * sc, acc[3] * sc); }
+};
+template <> struct AggIO<float, 4> {
+    typedef float raw_t;
+    static __device__ __forceinline__ void add(const raw_t& r, float (&acc)[1]) { acc[0] += r; }
+    static __device__ __forceinline__ raw_t pack(const float (&acc)[1], float sc) { return acc[0] * sc; }
+};
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(kBlock) void aggregate_rows_kernel(const AggregateArgs a) {
+    typedef AggIO<T, VEC> IO;
+    typedef typename IO::raw_t raw_t;
+    constexpr int EL = VEC / (int)sizeof(T);
+    constexpr int STEPS = VEC == 16 ? 2 : 5;       // bytes of a row handled per column block: STEPS * VEC * 64 (2048 / 1280)
+    constexpr int NB = VEC == 16 ? 4 : 2;          // neighbour rows in flight
+    constexpr int kBlockBytes = STEPS * VEC * kWave;
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int esz = (int)sizeof(T);
+    unsigned long long misses = 0;
+    for (int64_t i = (int64_t)blockIdx.x * kWavesPerBlock + wave; i < a.n_rows; i += (int64_t)gridDim.x * kWavesPerBlock) {
+        const int64_t b = a.rowptr[i], e = a.rowptr[i + 1];
+        const float scale = (a.mean && e > b) ? 1.0f / (float)(e - b) : 1.0f;
+        char* dst = static_cast<char*>(a.out) + i * a.ldo * esz;
+        for (int c0 = 0; c0 < a.row_bytes; c0 += kBlockBytes) {
+            float acc[STEPS][EL];
+#pragma unroll
+            for (int st = 0; st < STEPS; ++st)
+#pragma unroll
+                for (int q = 0; q < EL; ++q) acc[st][q] = 0.0f;
+            for (int64_t k = b; k < e; k += NB) {
+                raw_t v[NB][STEPS];
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    const int64_t kk = k + u < e ? k + u : e - 1;                    // the tail repeats the last neighbour (not added)
+                    const int64_t node = a.idx[kk];
+                    const int64_t s = a.slot ? a.slot[node] : -1;
+                    const char* src = (s >= 0) ? static_cast<const char*>(a.cache) + s * a.ldc * esz
+                                               : static_cast<const char*>(a.host) + (a.host_map ? a.host_map[node] : node) * a.ldh * esz;
+                    if (c0 == 0 && k + u < e && a.slot && s < 0) ++misses;
+#pragma unroll
+                    for (int st = 0; st < STEPS; ++st) {
+                        const int off = c0 + (st * kWave + lane) * VEC;
+                        if (off < a.row_bytes) v[u][st] = *reinterpret_cast<const raw_t*>(src + off);
+                        else v[u][st] = raw_t{};
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    if (k + u >= e) continue;                                        // wave-uniform
+#pragma unroll
+                    for (int st = 0; st < STEPS; ++st) IO::add(v[u][st], acc[st]);
+                }
+            }
+#pragma unroll
+            for (int st = 0; st < STEPS; ++st) {
+                const int off = c0 + (st * kWave + lane) * VEC;
+                if (off < a.row_bytes) *reinterpret_cast<raw_t*>(dst + off) = IO::pack(acc[st], scale);
+            }
+        }
+    }
+    if (a.miss_count && lane == 0 && misses) atomicAdd(a.miss_count, misses);
+}
+
 }  // namespace dgll
 
 using namespace dgll;
@@ -92,6 +193,45 @@ static int gather_rows_impl(void* stream, const void* cache, int64_t ldc, const 
     if (v16) hipLaunchKernelGGL(gather_rows_kernel<16>, dim3((uint32_t)blocks), dim3(kBlock), 0, s, a, esz);
     else if (v4) hipLaunchKernelGGL(gather_rows_kernel<4>, dim3((uint32_t)blocks), dim3(kBlock), 0, s, a, esz);
     else hipLaunchKernelGGL(gather_rows_kernel<2>, dim3((uint32_t)blocks), dim3(kBlock), 0, s, a, esz);
+    DGLL_HIP_TRY(hipGetLastError());
+    return DGLL_OK;
+}
+
+
+DGLL_API int dgll_hip_aggregate_rows_mapped(void* stream, const void* cache, int64_t ldc, const void* host, int64_t ldh,
+                                            const int64_t* idx, const int64_t* slot, const int64_t* host_map, const int64_t* rowptr,
+                                            void* out, int64_t ldo, int64_t n_rows, int feat, int dtype, int reduce,
+                                            unsigned long long* miss_count) {
+    if (n_rows <= 0 || feat <= 0) return DGLL_OK;
+    DGLL_REQUIRE(host && idx && rowptr && out, "NULL argument");
+    DGLL_REQUIRE(!slot || cache, "a slot map needs a cache matrix");
+    DGLL_REQUIRE(dtype == DGLL_F32 || dtype == DGLL_BF16, "dtype");
+    DGLL_REQUIRE(reduce == DGLL_REDUCE_SUM || reduce == DGLL_REDUCE_MEAN, "reduce");
+    const int esz = dtype == DGLL_BF16 ? 2 : 4;
+    DGLL_REQUIRE(ldh >= feat && ldo >= feat && (!slot || ldc >= feat), "leading dimension smaller than feat");
+    AggregateArgs a{};
+    a.cache = cache; a.host = host; a.idx = idx; a.slot = slot; a.host_map = host_map; a.rowptr = rowptr; a.out = out;
+    a.ldc = ldc; a.ldh = ldh; a.ldo = ldo; a.n_rows = n_rows; a.row_bytes = feat * esz; a.mean = reduce == DGLL_REDUCE_MEAN;
+    a.miss_count = miss_count;
+    auto ok = [&](const void* p, int64_t ld, int vec) {
+        return !p || ((reinterpret_cast<uintptr_t>(p) % vec) == 0 && (ld * esz) % vec == 0);
+    };
+    // 16-byte lanes when every row of every source starts on a 16-byte boundary (the row's last vector may reach into its padding:
+    // pitches are whole vectors), else 4-byte lanes; rows that are not even 4-byte granular are the caller's to fetch and reduce
+    const bool v16 = ok(cache, ldc, 16) && ok(host, ldh, 16) && ok(out, ldo, 16) && (!slot || ldc * esz >= ((a.row_bytes + 15) / 16) * 16) &&
+                     ldh * esz >= ((a.row_bytes + 15) / 16) * 16 && ldo * esz >= ((a.row_bytes + 15) / 16) * 16;
+    const bool v4 = a.row_bytes % 4 == 0 && ok(cache, ldc, 4) && ok(host, ldh, 4) && ok(out, ldo, 4);
+    DGLL_REQUIRE(v16 || v4, "rows must be at least 4-byte granular (even bf16 width, 4-byte aligned pitches)");
+    if (v16) a.row_bytes = ((a.row_bytes + 15) / 16) * 16;       // whole vectors: the padding columns are summed and written too
+    const int64_t blocks = std::min<int64_t>((n_rows + kWavesPerBlock - 1) / kWavesPerBlock, 256 * 32);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == DGLL_BF16) {
+        if (v16) hipLaunchKernelGGL((aggregate_rows_kernel<bf16_t, 16>), dim3((uint32_t)blocks), dim3(kBlock), 0, s, a);
+        else hipLaunchKernelGGL((aggregate_rows_kernel<bf16_t, 4>), dim3((uint32_t)blocks), dim3(kBlock), 0, s, a);
+    } else {
+        if (v16) hipLaunchKernelGGL((aggregate_rows_kernel<float, 16>), dim3((uint32_t)blocks), dim3(kBlock), 0, s, a);
+        else hipLaunchKernelGGL((aggregate_rows_kernel<float, 4>), dim3((uint32_t)blocks), dim3(kBlock), 0, s, a);
+    }
     DGLL_HIP_TRY(hipGetLastError());
     return DGLL_OK;
 }

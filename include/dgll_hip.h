@@ -263,6 +263,17 @@ int dgll_hip_gather_rows_mapped(void* stream, const void* cache, int64_t ldc, co
                                 const int64_t* idx, const int64_t* slot, const int64_t* host_map, void* out,
                                 int64_t ldo, int64_t n, int feat, int dtype, unsigned long long* miss_count);
 
+/* The reduction over a sampled block read STRAIGHT from the feature store:
+ *   out[i,:] = reduce_{k in [rowptr[i], rowptr[i+1])} row(idx[k]),  row(v) = cache[slot[v],:] if slot[v] >= 0 else host[host_map[v] or v,:]
+ * -- the K-axis mean of sageconv.py:33-36 over the outermost hop's neighbour features fused with GraphCacheServer.fetch_data
+ * (storage.py:151-198): the fan-out x batch gathered rows are never materialised.  reduce: DGLL_REDUCE_SUM / _MEAN (empty rows: 0).
+ * rowptr: int64 [n_rows + 1] over idx.  Rows must be 4-byte granular; 16-byte lanes are used when every pitch is a whole number of
+ * 16-byte vectors (the padding columns are then summed and written as well).  *miss_count as in dgll_hip_gather_rows.            */
+int dgll_hip_aggregate_rows_mapped(void* stream, const void* cache, int64_t ldc, const void* host, int64_t ldh,
+                                   const int64_t* idx, const int64_t* slot, const int64_t* host_map, const int64_t* rowptr,
+                                   void* out, int64_t ldo, int64_t n_rows, int feat, int dtype, int reduce,
+                                   unsigned long long* miss_count);
+
 /* ---- f1 (host code): one hop of the reference's neighbour sampler, bit-exact with CPython 3.10's random.sample -------
  * For every seed in order: all neighbours if deg <= fanout (or fanout < 0), else random.sample(neighbors, fanout)
  * (/root/reference/dgll/sampling/base_sampler.py:45-58), drawn from the MT19937 state passed in (`random.getstate()`:

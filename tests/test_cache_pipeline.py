@@ -73,6 +73,55 @@ def test_fetch_data_equals_indexing(cuda_device, dtype, dim):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dtype,dim,reduce", [(torch.bfloat16, 602, "mean"), (torch.bfloat16, 256, "sum"), (torch.float32, 100, "mean"),
+                                              (torch.float32, 7, "mean"), (torch.bfloat16, 50, "mean"), (torch.bfloat16, 1400, "mean")])
+def test_aggregate_data_equals_fetch_then_reduce(cuda_device, dtype, dim, reduce):
+    """GraphCacheServer.aggregate_data: the neighbour reduction read straight from the HBM cache / the pinned host rows ==
+    fetch_data followed by the per-row mean (sageconv.py:33-36) -- ragged rows, empty rows, hits and misses mixed inside a row,
+    rows wider than one column block; the miss accounting counts every id once."""
+    from dgll_amd.cache import GraphCacheServer
+
+    n = 4000
+    torch.manual_seed(dim)
+    feats = torch.randn(n, dim).to(dtype)
+    deg = torch.randint(0, 1000, (n,))
+    srv = GraphCacheServer(feats, gpuid=0)
+    srv.log = True
+    srv.auto_cache(deg, capacity=1000)
+    top = set(torch.argsort(deg, descending=True, stable=True)[:1000].tolist())
+    counts = torch.randint(0, 30, (700,))
+    counts[::50] = 0                                                       # rows without neighbours
+    counts[1] = 257                                                        # a long row
+    rowptr = torch.zeros(701, dtype=torch.int64)
+    rowptr[1:] = torch.cumsum(counts, 0)
+    ids = torch.randint(0, n, (int(rowptr[-1]),))
+    got = srv.aggregate_data(ids.to(cuda_device), rowptr, reduce=reduce)
+    assert got.shape == (700, dim) and got.dtype == dtype and (got.stride(0) * got.element_size()) % 16 == 0
+    rows = torch.repeat_interleave(torch.arange(700), counts)
+    ref = torch.zeros(700, dim, dtype=torch.float64).index_add_(0, rows, feats[ids].double())
+    if reduce == "mean":
+        ref = ref / counts.clamp(min=1).double()[:, None]
+    tol = 2.0 ** -8 if dtype == torch.bfloat16 else 1e-6
+    err = (got.double().cpu() - ref).abs()
+    assert float((err - tol * ref.abs()).max()) <= (2e-2 if dtype == torch.bfloat16 else 1e-5), float(err.max())
+    assert bool((got[::50] == 0).all())                                    # empty rows: zeros
+    expect_miss = sum(1 for v in ids.tolist() if v not in top)
+    assert abs(srv.get_miss_rate() - expect_miss / ids.numel()) < 1e-9
+    srv.auto_cache(deg, capacity=n)                                        # full cache: same result, no miss
+    again = srv.aggregate_data(ids.to(cuda_device), rowptr, reduce=reduce)
+    assert torch.equal(again, got) and srv.get_miss_rate() == 0.0
+
+
+@pytest.mark.gpu
+def test_aggregate_data_refuses_rows_that_are_not_4_byte_granular(cuda_device):
+    from dgll_amd.cache import GraphCacheServer
+
+    srv = GraphCacheServer(torch.randn(100, 5).to(torch.bfloat16), gpuid=0)
+    with pytest.raises(ValueError):
+        srv.aggregate_data(torch.arange(10, device=cuda_device), torch.tensor([0, 4, 10]))
+
+
+@pytest.mark.gpu
 def test_cache_with_nid_map_and_pipeline_on_gpu(cuda_device):
     from conftest import load_golden
     from dgll_amd.cache import GraphCacheServer
