@@ -178,13 +178,23 @@ class GraphSage(F.nn.Module):
                       for hop in range(self.num_layers - l)]
         return hidden[0]
 
-    def forward_sampled(self, node_feature_list, blocks):
+    def forward_sampled(self, node_feature_list, blocks, last_hop_reduced=None):
         """Hop pyramid driven by sampled CSR blocks (variable fan-out, e.g. DGLLNeighborSampler): blocks[hop] has one row
-        per node of hop `hop` and gathers from the rows of hop `hop + 1` (sugbraph.to_block())."""
-        hidden = node_feature_list
-        for l in range(self.num_layers):
+        per node of hop `hop` and gathers from the rows of hop `hop + 1` (sugbraph.to_block()).
+        last_hop_reduced: the first layer's neighbour reduction over the OUTERMOST block, already formed (by
+        GraphCacheServer.aggregate_data through MiniBatchPipeline(reduce_last_hop=...)): node_feature_list[-1] is then not
+        needed (None) -- those rows enter the model through this reduction only (sageconv.py:33-36)."""
+        hidden = list(node_feature_list)
+        L = self.num_layers
+        for l in range(L):
             layer = self.gcn[l]
-            hidden = [layer.forward_block(blocks[hop], hidden[hop + 1], hidden[hop]) for hop in range(self.num_layers - l)]
+            nxt = []
+            for hop in range(L - l):
+                if l == 0 and hop == L - 1 and last_hop_reduced is not None:
+                    nxt.append(layer.transform_block(hidden[hop], last_hop_reduced))
+                else:
+                    nxt.append(layer.forward_block(blocks[hop], hidden[hop + 1], hidden[hop]))
+            hidden = nxt
         return hidden[0]
 
     def forward_graph(self, graph, x):

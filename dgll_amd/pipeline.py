@@ -93,28 +93,36 @@ class AdaptiveQueue:
 
 
 class Batch:
-    __slots__ = ("input_nodes", "output_nodes", "subgraphs", "features", "labels", "ready", "step")
+    __slots__ = ("input_nodes", "output_nodes", "subgraphs", "features", "labels", "ready", "step", "last_hop_reduced")
 
     def __init__(self):
         self.input_nodes = self.output_nodes = self.subgraphs = self.features = self.labels = self.ready = None
+        self.last_hop_reduced = None
         self.step = 0
 
 
 class MiniBatchPipeline:
     def __init__(self, dataloader, cache=None, labels=None, queue_size=4, device="cuda", hops=None, memory_fraction=0.1,
-                 record_access=False):
+                 record_access=False, reduce_last_hop=None):
         """dataloader: dgll_amd.dataloader.DataLoader; cache: GraphCacheServer (None: features come from
         dataloader.Dgraph.get_features on the host and are copied); hops: optional callable batch -> list of id tensors
         whose features are needed (default: the input nodes only, graphage.py:52).
         queue_size: an int fixes the bound of the loaded-batch queue (MQGCN.py:98 uses 4); "auto" starts at 4 and lets it
         adapt (AdaptiveQueue), never holding more loaded batches than fit in `memory_fraction` of the free device memory.
-        record_access: feed the cache's access counters (GraphCacheServer.refresh_from_access)."""
+        record_access: feed the cache's access counters (GraphCacheServer.refresh_from_access).
+        reduce_last_hop: "mean" / "sum" (needs `cache` and `hops`): the outermost hop's features are not fetched; the batch
+        carries their per-destination reduction over the outermost sampled block instead (Batch.last_hop_reduced, features[-1] is
+        None) -- GraphCacheServer.aggregate_data reads the cache / the pinned host rows directly, and a queued batch is an order of
+        magnitude smaller.  For GraphSage.forward_sampled(..., last_hop_reduced=...)."""
         self.dataloader, self.cache, self.labels = dataloader, cache, labels
         self.device = torch.device(device)
         adaptive = queue_size == "auto"
         self.queue = AdaptiveQueue(4 if adaptive else int(queue_size), adaptive=adaptive)      # loaded batches
         self.sampled = AdaptiveQueue(2, adaptive=False)           # sampled, not yet loaded: a short hand-over queue
         self.memory_fraction, self.record_access = memory_fraction, record_access
+        if reduce_last_hop is not None and (cache is None or hops is None or reduce_last_hop not in ("mean", "sum")):
+            raise ValueError("reduce_last_hop ('mean' / 'sum') needs a GraphCacheServer and a `hops` callback")
+        self.reduce_last_hop = reduce_last_hop
         self._memory_bound_set = False
         self.hops = hops
         self.load_stream = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None   # d_stream
@@ -146,14 +154,22 @@ class MiniBatchPipeline:
                 id_lists = self.hops(b) if self.hops is not None else [inp]
                 if self.load_stream is not None:
                     with torch.cuda.stream(self.load_stream):
-                        b.features = [self._fetch(ids) for ids in id_lists]
+                        if self.reduce_last_hop is not None:
+                            # outermost hop (subgraphs are outermost first): reduced straight out of the cache, never fetched
+                            b.features = [self._fetch(ids) for ids in id_lists[:-1]] + [None]
+                            if self.record_access:
+                                self.cache.record_access(id_lists[-1], stream=self.load_stream)
+                            b.last_hop_reduced = self.cache.aggregate_data(id_lists[-1], b.subgraphs[0].indptr,
+                                                                           reduce=self.reduce_last_hop, stream=self.load_stream)
+                        else:
+                            b.features = [self._fetch(ids) for ids in id_lists]
                         if self.labels is not None:
                             b.labels = self.labels[outp].to(self.device, non_blocking=True)
                         b.ready = torch.cuda.Event()
                         b.ready.record(self.load_stream)
                     if not self._memory_bound_set:          # first loaded batch: how many of these fit in the memory budget
                         self._memory_bound_set = True
-                        nbytes = sum(t.numel() * t.element_size() for t in b.features)
+                        nbytes = sum(t.numel() * t.element_size() for t in list(b.features) + [b.last_hop_reduced] if t is not None)
                         free, _total = torch.cuda.mem_get_info(self.device)
                         self.queue.set_memory_bound(nbytes, self.memory_fraction * free)
                 else:
@@ -193,8 +209,9 @@ class MiniBatchPipeline:
                 # The tensors were allocated on the load stream and are consumed on `cur`: tell the caching allocator, or
                 # the block returns to the load stream's pool when the consumer drops the batch -- while forward/backward
                 # kernels reading it may still be queued -- and the loader's next gather could be written into it.
-                for t in b.features or ():
-                    t.record_stream(cur)
+                for t in list(b.features or ()) + [b.last_hop_reduced]:
+                    if t is not None:
+                        t.record_stream(cur)
                 if b.labels is not None and b.labels.is_cuda:
                     b.labels.record_stream(cur)
             yield b

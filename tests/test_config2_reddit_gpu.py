@@ -148,6 +148,52 @@ def test_bf16_forward_matches_the_oracle(reddit_batch):
 
 
 @pytest.mark.gpu
+def test_outermost_hop_reduced_out_of_the_cache_equals_fetch_then_reduce(reddit_batch):
+    """MiniBatchPipeline(reduce_last_hop="mean"): the batch carries the mean of the outermost hop's features per destination row
+    (GraphCacheServer.aggregate_data: read from the HBM cache and, for the 75 % of the nodes that are not cached, from pinned host
+    memory) instead of the 2.5 M fetched rows.  Same batch, same model: the reduced rows equal the block mean of the fetched rows to
+    bf16 rounding ties, the model output is the same to the tight forward tolerance, the parameter gradients agree."""
+    from dgll_amd.dataloader import DataLoader
+    from dgll_amd.pipeline import MiniBatchPipeline
+    from dgll_amd.sampling import FastNeighborSampler
+    from oracle import cref
+
+    r = reddit_batch
+    b, dev = r["batch"], r["dev"]
+    L = len(FANOUTS)
+
+    def hop_ids(bb):
+        return [bb.output_nodes] + [bb.subgraphs[L - 1 - h].src_nodes() for h in range(L)]
+
+    loader = DataLoader(r["dg"], r["seeds"], FastNeighborSampler(FANOUTS, defer_last_hop=True), batch_size=BATCH)
+    pipe = MiniBatchPipeline(loader, cache=r["cache"], labels=r["labels"], queue_size=4, device=dev, hops=hop_ids, reduce_last_hop="mean")
+    random.seed(7)
+    fused = list(pipe)[0]
+    assert fused.features[-1] is None and torch.equal(fused.subgraphs[0].indptr, b.subgraphs[0].indptr)
+    assert all(torch.equal(a, c) for a, c in zip(fused.features[:-1], b.features[:-1]))
+    red = fused.last_hop_reduced
+    assert red.shape == (b.features[L - 1].shape[0], FEATS) and red.dtype == torch.bfloat16
+    ptr = b.subgraphs[0].indptr.numpy()
+    ref = cref.spmm_csr(ptr, np.arange(b.features[L].shape[0], dtype=np.int32), None, b.features[L].float().cpu().numpy(), reduce="mean")
+    ref = torch.from_numpy(ref).to(torch.bfloat16)
+    same = float((red.cpu() == ref).float().mean())
+    assert same >= 0.999 and float((red.float().cpu() - ref.float()).abs().max()) <= 2.0 ** -7 * float(ref.float().abs().max())
+
+    outs, grads = [], []
+    for batch, kw in ((b, {}), (fused, {"last_hop_reduced": red})):
+        model = _model(dev)
+        blocks = [batch.subgraphs[L - 1 - h].to_block(dev) for h in range(L)]
+        out = model.forward_sampled(batch.features, blocks, **kw)
+        torch.nn.functional.cross_entropy(out.float(), batch.labels).backward()
+        outs.append(out.detach().float())
+        grads.append([p.grad.clone() for p in model.parameters()])
+    assert float((outs[0] - outs[1]).abs().max()) <= 2.0 ** -6 * float(outs[0].abs().max())
+    for ga, gb in zip(*grads):
+        assert float((ga - gb).norm() / gb.norm()) <= 1e-2
+    r["cache"].get_miss_rate()          # drain this test's fetch log: the accounting test reads the counters of ITS fetches only
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("storage", ["bf16", "fp32"])
 def test_gradients_match_cpu_autograd_of_the_oracle(reddit_batch, storage):
     """Forward and backward (input-feature and parameter gradients) vs CPU autograd of oracle/torch_ref.sage_block, at the
