@@ -966,6 +966,11 @@ def run_minibatch(args, c):
     cache = GraphCacheServer(feats, gpuid=c.dev.index or 0)
     cache.log = True
     cache.auto_cache(deg, capacity=int(args.mb_cache_frac * args.mb_nodes))
+    # The producers run up to six batches ahead (queue of 4 loaded + 2 sampled): a short timed region would be served from that
+    # backlog and report the consumer's speed, not the pipeline's.  Steady state needs the backlog to be a small share of the batches
+    # timed: at least 8 warm-up and 64 timed batches here, whatever --steps / --warmup say (the JSON line carries the counts used).
+    args.warmup = max(args.warmup, 8)
+    args.steps = max(args.steps, 64)
     n_batches = args.warmup + args.steps
     train = torch.randperm(args.mb_nodes)[:n_batches * args.mb_batch]
 

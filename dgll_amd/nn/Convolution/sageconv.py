@@ -186,6 +186,8 @@ class GraphSage(F.nn.Module):
         needed (None) -- those rows enter the model through this reduction only (sageconv.py:33-36)."""
         hidden = list(node_feature_list)
         L = self.num_layers
+        if self._hops_batchable(hidden, blocks, last_hop_reduced):
+            return self._forward_sampled_batched(hidden, blocks, last_hop_reduced)
         for l in range(L):
             layer = self.gcn[l]
             nxt = []
@@ -197,6 +199,61 @@ class GraphSage(F.nn.Module):
             hidden = nxt
         return hidden[0]
 
+    batch_hops = True      # forward_sampled: one transform / one pair of weight gradients per LAYER instead of per (layer, hop)
+
+    def _hops_batchable(self, hidden, blocks, last_hop_reduced):
+        """Every hop of a layer goes through the same weights: on the GPU, with the standard layer configuration and blocks that
+        are aggregated before the transform, the hops' rows are stacked and a layer is ONE transform forward and ONE pair of
+        weight-gradient launches backward (a 3-layer model on 3 hops: 6 transforms and 12-16 weight-gradient launches become 3
+        and 3-4; each of them was at the ~20 us floor of a launch on a few thousand rows)."""
+        first = hidden[0]
+        if not (self.batch_hops and first.is_cuda and self.num_layers >= 2):
+            return False
+        for l, layer in enumerate(self.gcn):
+            if (layer.aggr_hid_method != "sum" or layer.neighborAgg.use_bias or layer.aggr_neighbor_method not in ("mean", "sum")
+                    or layer.activation not in (None, F.relu)):
+                return False
+        # every block is reduced BEFORE the transform (identity columns), or the layer does not narrow
+        return all(getattr(b, "identity_cols", False) for b in blocks[:self.num_layers])
+
+    @staticmethod
+    def _stack_rows(parts):
+        """One [sum rows, F] tensor holding the parts' rows in order: the parts themselves when they already are consecutive row
+        slices of one buffer (the pipeline fetches the hops with one gather), else a copy."""
+        if len(parts) == 1:
+            return parts[0]
+        a = parts[0]
+        esz, ld = a.element_size(), a.stride(0)
+        adjacent = a.dim() == 2 and a.stride(1) == 1 and not a.requires_grad
+        ptr = a.data_ptr()
+        for t in parts:
+            adjacent = adjacent and t.dim() == 2 and t.stride(1) == 1 and t.stride(0) == ld and t.shape[1] == a.shape[1] \
+                and t.data_ptr() == ptr and not t.requires_grad and t.dtype == a.dtype
+            ptr += t.shape[0] * ld * esz
+        if adjacent:
+            return a.as_strided((sum(t.shape[0] for t in parts), a.shape[1]), (ld, 1))
+        return F.cat(list(parts), dim=0)
+
+    def _forward_sampled_batched(self, hidden, blocks, last_hop_reduced):
+        L = self.num_layers
+        sizes = [h.shape[0] for h in hidden[:L]]                      # rows of hops 0 .. L-1 (hop L only feeds a reduction)
+        parent = None                                                 # rows of hops 0 .. n_h of the current layer's input, stacked
+        for l in range(L):
+            layer = self.gcn[l]
+            n_h = L - l                                               # destination hops 0 .. n_h - 1
+            offs = [0]
+            for hop in range(n_h + (1 if l > 0 else 0)):
+                offs.append(offs[-1] + sizes[hop])
+            src = (lambda hop: hidden[hop]) if l == 0 else (lambda hop: parent[offs[hop]:offs[hop + 1]])
+            aggs = []
+            for hop in range(n_h):
+                if l == 0 and hop == L - 1 and last_hop_reduced is not None:
+                    aggs.append(last_hop_reduced)
+                else:
+                    aggs.append(layer.neighborAgg.reduce_block(blocks[hop], src(hop + 1)))
+            x_dst = self._stack_rows([hidden[hop] for hop in range(n_h)]) if l == 0 else parent[:offs[n_h]]
+            parent = layer.transform_block(x_dst, self._stack_rows(aggs))     # hops 0 .. n_h - 1 of the next layer's input
+        return parent
     def forward_graph(self, graph, x):
         """Full-graph form (BASELINE configs 3 and 5): every layer aggregates over the whole adjacency `graph`
         (a CSRGraph), h <- layer(h_self = h, neighbours of each node gathered from h)."""

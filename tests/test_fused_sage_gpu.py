@@ -119,3 +119,59 @@ def test_graphsage_forward_graph_is_the_same_with_and_without_the_fused_kernel(c
     assert float((o1 - o2).abs().max()) <= 3e-2 * float(o2.abs().max())
     for a, b in zip(g1, g2):
         assert float((a - b).abs().max()) <= 4e-2 * float(b.abs().max()) + 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_sampled_forward_with_the_hops_stacked_equals_the_per_hop_loop(cuda_device, dtype):
+    """GraphSage.forward_sampled stacks the hops of a layer (one transform, one pair of weight gradients per layer) when the blocks
+    are aggregate-first; with batch_hops = False it runs the reference's per-(layer, hop) loop (sageconv.py:103-114).  Same outputs,
+    same parameter and input gradients -- with separately allocated hop features, with hop features that are consecutive slices of
+    one fetched buffer, and with the outermost hop arriving already reduced."""
+    from dgll_amd import nn as dnn
+    from dgll_amd import ops
+    from dgll_amd.graph import CSRGraph
+
+    dev = cuda_device
+    torch.manual_seed(0)
+    fan = [5, 3, 4]
+    sizes = [64]
+    for k in fan:
+        sizes.append(sizes[-1] * k)
+    F_in = 40
+    model = dnn.GraphSage(F_in, [32, 32, 7], fan).to(dev)
+    blocks = [CSRGraph.fixed_fanout(sizes[h], fan[h], dev) for h in range(3)]
+    for b in blocks:
+        b.identity_cols = True
+    one = ops.alloc_features(sum(sizes[:3]), F_in, dtype, dev)
+    one.copy_(torch.randn(sum(sizes[:3]), F_in, device=dev))
+    outer = ops.alloc_features(sizes[3], F_in, dtype, dev)
+    outer.copy_(torch.randn(sizes[3], F_in, device=dev))
+    o = [0, sizes[0], sizes[0] + sizes[1], sum(sizes[:3])]
+    views = [one[o[h]:o[h + 1]] for h in range(3)]
+    tol = dict(rtol=1e-4, atol=1e-5) if dtype == torch.float32 else dict(rtol=3e-2, atol=3e-2)
+
+    def run(batch, feats, reduced=None):
+        model.batch_hops = batch
+        model.zero_grad()
+        xs = [f.detach().clone().requires_grad_() if own else f for f, own in feats]
+        out = model.forward_sampled([x for x in xs], blocks, last_hop_reduced=reduced)
+        (out.float() ** 2).sum().backward()
+        return out.detach().float(), [p.grad.clone() for p in model.parameters()], [x.grad for x in xs if x is not None and x.requires_grad]
+
+    sep = [(v, True) for v in views] + [(outer, True)]
+    ref_out, ref_gp, ref_gx = run(False, sep)
+    out, gp, gx = run(True, sep)
+    torch.testing.assert_close(out, ref_out, **tol)
+    for a, b in zip(gp, ref_gp):
+        torch.testing.assert_close(a, b, rtol=tol["rtol"], atol=tol["atol"] * float(b.abs().max()))
+    for a, b in zip(gx, ref_gx):
+        torch.testing.assert_close(a.float(), b.float(), rtol=tol["rtol"], atol=tol["atol"] * float(b.float().abs().max()))
+    # consecutive slices of one buffer (no copy) + the outermost hop already reduced
+    reduced = model.gcn[0].neighborAgg.reduce_block(blocks[2], outer).detach()
+    out2, gp2, _ = run(True, [(v, False) for v in views] + [(None, False)], reduced)
+    torch.testing.assert_close(out2, ref_out, **tol)
+    for a, b in zip(gp2, ref_gp):
+        torch.testing.assert_close(a, b, rtol=tol["rtol"], atol=tol["atol"] * float(b.abs().max()))
+    assert dnn.GraphSage._stack_rows(views).data_ptr() == one.data_ptr()          # adjacency detected: a view, not a copy
+    model.batch_hops = True
