@@ -225,10 +225,10 @@ class GraphSage(F.nn.Module):
         a = parts[0]
         esz, ld = a.element_size(), a.stride(0)
         adjacent = a.dim() == 2 and a.stride(1) == 1 and not a.requires_grad
-        ptr = a.data_ptr()
-        for t in parts:
+        ptr, base = a.data_ptr(), a.untyped_storage().data_ptr()
+        for t in parts:     # same storage, same pitch, one right behind the other
             adjacent = adjacent and t.dim() == 2 and t.stride(1) == 1 and t.stride(0) == ld and t.shape[1] == a.shape[1] \
-                and t.data_ptr() == ptr and not t.requires_grad and t.dtype == a.dtype
+                and t.data_ptr() == ptr and t.untyped_storage().data_ptr() == base and not t.requires_grad and t.dtype == a.dtype
             ptr += t.shape[0] * ld * esz
         if adjacent:
             return a.as_strided((sum(t.shape[0] for t in parts), a.shape[1]), (ld, 1))
