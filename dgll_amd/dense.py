@@ -39,19 +39,23 @@ def _mfma_ok(*mats):
 
 
 def transform_bf16(a1, wt1, a2=None, wt2=None, relu=False, out_dtype=torch.bfloat16, n_out=None, mask=None, bias=None,
-                   ld_align=None, out_gate=None, row_scale=None, addend=None):
+                   ld_align=None, out_gate=None, row_scale=None, addend=None, out=None):
     """out[M, N] = act(a1 . wt1^T (+ a2 . wt2^T)) on the MFMA kernel.  wt*: [N, K] weights (transposed), any float
     dtype; padded here.  a*: bf16 [M, K], 16-byte aligned rows.  out_gate: bf16 [M, N]; out is zeroed where it is <= 0.
     row_scale: fp32 [M] factor on the product (before bias / activation).  addend: bf16 [M, N] added before the
-    activation."""
+    activation.  out: write into this [M, N] tensor instead of allocating."""
     n = wt1.shape[0] if n_out is None else n_out
     m = a1.shape[0]
     p1 = _pad_wt(wt1)
     p2 = _pad_wt(wt2) if a2 is not None else None
-    ld_align = ld_align or (8 if out_dtype == torch.bfloat16 else 4)
-    ld = -(-n // ld_align) * ld_align
-    store = torch.empty((m, ld), dtype=out_dtype, device=a1.device)
-    out = store[:, :n] if ld != n else store
+    own_store = out is None       # `out`: a caller's [M, N] buffer (rows of a larger matrix, say); its padding is not ours to write
+    if own_store:
+        ld_align = ld_align or (8 if out_dtype == torch.bfloat16 else 4)
+        ld = -(-n // ld_align) * ld_align
+        store = torch.empty((m, ld), dtype=out_dtype, device=a1.device)
+        out = store[:, :n] if ld != n else store
+    elif out.shape != (m, n) or out.dtype != out_dtype or out.stride(1) != 1 or not out.is_cuda:
+        raise ValueError("transform_bf16: `out` must be a [M, N] device tensor of the output dtype with contiguous rows")
     if bias is not None:
         bias = bias.detach().float().contiguous()
     with torch.cuda.device(a1.device):
@@ -71,7 +75,7 @@ def transform_bf16(a1, wt1, a2=None, wt2=None, relu=False, out_dtype=torch.bfloa
             p2.stride(0) if p2 is not None else 0, p1.shape[0], mask.data_ptr() if mask is not None else None,
             mask.stride(0) if mask is not None else 0, out.data_ptr(), out.stride(0),
             _lib.BF16 if out_dtype == torch.bfloat16 else _lib.F32, m, n,
-            int(relu) | 2,      # bit 1: `store` is this function's own allocation, its row padding may be written (zeros)
+            int(relu) | (2 if own_store else 0),     # bit 1: `store` is this function's own allocation: its row padding may be written
             bias.data_ptr() if bias is not None else None,
             out_gate.data_ptr() if out_gate is not None else None, out_gate.stride(0) if out_gate is not None else 0,
             row_scale.data_ptr() if row_scale is not None else None,
@@ -193,7 +197,7 @@ def _mm_f32(a, wt, relu, bias, addend):
     return out
 
 
-def mm_nt(a, wt, relu=False, bias=None, addend=None):
+def mm_nt(a, wt, relu=False, bias=None, addend=None, out=None):
     """act(a . wt^T + addend + bias) for a [M, K], wt [N, K] on the hand-written kernels: bf16 on the MFMA transform (rows are
     re-laid out to 16-byte alignment when they are not; more than 256 output columns run as 256-column launches), fp32 on the
     fp32 matrix-core kernel.  Host tensors (the layers' CPU logic) use torch."""
@@ -214,7 +218,7 @@ def mm_nt(a, wt, relu=False, bias=None, addend=None):
         addend = addend if addend.stride(1) == 1 else addend.contiguous()
     n = wt.shape[0]
     if n <= 256:
-        return transform_bf16(a, wt, relu=relu, bias=bias, addend=addend)
+        return transform_bf16(a, wt, relu=relu, bias=bias, addend=addend, out=out)
     parts = [transform_bf16(a, wt[n0:n0 + 256], relu=relu, bias=None if bias is None else bias[n0:n0 + 256],
                             addend=None if addend is None else addend[:, n0:n0 + 256]) for n0 in range(0, n, 256)]
     return torch.cat(parts, dim=1)
@@ -246,9 +250,16 @@ def _rows(g):
     return g if g.dim() == 2 and g.stride(1) == 1 else g.contiguous()
 
 
-def input_grad(g, wd):
-    """g . W^T for a weight stored [in, out] (the transposed weight of this product is W itself)."""
-    return mm_nt(g, wd)
+def input_grad(g, wd, out=None):
+    """g . W^T for a weight stored [in, out] (the transposed weight of this product is W itself).  out: bf16 GPU products of at most
+    256 columns are written straight into it; anything else is computed and copied."""
+    if out is not None and g.is_cuda and g.dtype == torch.bfloat16 and wd.shape[0] <= 256 and out.dtype == torch.bfloat16:
+        return mm_nt(g, wd, out=out)
+    res = mm_nt(g, wd)
+    if out is not None:
+        out.copy_(res)
+        return out
+    return res
 
 
 _GW_WORKSPACE = {}

@@ -239,6 +239,19 @@ class _Exchange:
             dev_buf.copy_(host_buf)
 
 
+def _pack_rows(store, idx):
+    """store[idx] as a contiguous [len(idx), ld] block (the rows a rank sends): the HIP row gather on the GPU (16-byte lanes over
+    the padded rows; torch's index_select took 0.11 ms for the 87 MB of a 47-wide layer at 8 ranks), index_select elsewhere."""
+    if not idx.numel():
+        return store[:0]
+    if store.is_cuda and store.dtype in (torch.bfloat16, torch.float32) and store.dim() == 2 and store.stride(1) == 1:
+        from .cache import gather_rows
+
+        out = torch.empty((int(idx.numel()), store.shape[1]), dtype=store.dtype, device=store.device)
+        return gather_rows(store, idx, out=out)
+    return store.index_select(0, idx)
+
+
 def _aggregate_forward(engine, h_own, reduce):
     """out[row] = reduce_j A[row, j] h[j] over the partitioned adjacency (h_own: this rank's rows)."""
     p = engine.part
@@ -246,7 +259,7 @@ def _aggregate_forward(engine, h_own, reduce):
     scale = p.inv_deg if reduce == "mean" else None
     # exchange buffers hold whole (16-byte padded) rows so that every message is one contiguous block
     h_store, h_view = engine.rows_of(h_own)
-    send_store = h_store.index_select(0, p.send_idx) if p.send_idx.numel() else h_store[:0]
+    send_store = _pack_rows(h_store, p.send_idx)
     halo_store, halo_view = engine.alloc_rows(p.n_halo, feat, h_own.dtype)
     _, out = engine.alloc_rows(p.n_own, feat, h_own.dtype)
     with engine.comm_scope():
@@ -453,7 +466,7 @@ class DistGatAggregate(torch.autograd.Function):
             s_own, t_own, halo_t = s_own[:p.n_own], t_own[:p.n_own], t_own[p.n_own:]
             oe.gat_fwd_part(p.local, h_view, s_own, t_own, out, rowsum, heads, fo, alpha, apply_elu, raw=has_halo, accumulate=False)
         else:
-            send_h = h_store.index_select(0, p.send_idx) if p.send_idx.numel() else h_store[:0]
+            send_h = _pack_rows(h_store, p.send_idx)
             send_t = t_own.index_select(0, p.send_idx) if p.send_idx.numel() else t_own[:0]
             halo_store, halo_h = engine.alloc_rows(p.n_halo, feat, dtype)
             halo_t = torch.empty((p.n_halo, heads), dtype=torch.float32, device=dev)
@@ -620,7 +633,7 @@ class _DistSageLayerOnAll(torch.autograd.Function):
                     gagg = gagg * inv.unsqueeze(1).to(gagg.dtype)
             _, gagg = engine.rows_of(gagg)
             _, gh_all = engine.alloc_rows(p.n_own + p.n_halo, h_all.shape[1], h_all.dtype)
-            gh_all[:p.n_own].copy_(dense.input_grad(g, wsd))                       # self path: own rows only
+            dense.input_grad(g, wsd, out=gh_all[:p.n_own])                         # self path: own rows only, written in place
             gate = h_all if (ctx.gate_input and h_all.stride(1) == 1) else None
             engine.spmm(engine.transposed(p.local), gagg, gh_all[:p.n_own], accumulate=True,
                         gate=gate[:p.n_own] if gate is not None else None)
