@@ -71,10 +71,32 @@ def _fused_heads(x, adj, Ws, a1s, a2s, alpha, concat, mode, dropout, training):
         s, t = st[:, :heads], st[:, heads:]
         out = ops.gat_aggregate(graph, h, s, t, heads, alpha, apply_elu=concat, mode=mode, edge_scale=edge_scale,
                                 pack_scores=strided)
+    empty = _edgeless_rows(graph)
+    if empty is not None:
+        if mode == 1:
+            # gatConv masks with -9e15 and soft-maxes the whole row (gatconv.py:34-36): a row without edges attends uniformly to
+            # ALL nodes -- its output is the mean of Wh (through the activation); the kernels' 0 / 0 for that row is replaced
+            mean = h.float().mean(0, keepdim=True).to(h.dtype)
+            fill = F.elu(mean) if concat else mean
+            out = out.index_copy(0, empty, fill.expand(empty.numel(), -1))
+        else:
+            # sparseGatConv divides 0 by 0 for such a row and asserts (gatconv.py:139-141): so does this path
+            raise AssertionError("sparseGatConv: %d row(s) of the adjacency have no edge (h_prime would be NaN, gatconv.py:141)"
+                                 % int(empty.numel()))
     out = _unpad_heads(out, heads, fo, fo_pad)
     if _CHECK_NAN:
         assert not F.isnan(out).any()
     return out
+
+
+def _edgeless_rows(graph):
+    """int64 ids of the rows without any edge, or None (the usual case); looked up once per graph object."""
+    cached = getattr(graph, "_edgeless_rows", False)
+    if cached is False:
+        ids = F.nonzero(graph.degrees() == 0).reshape(-1)
+        cached = ids if int(ids.numel()) else None
+        graph._edgeless_rows = cached
+    return cached
 
 
 def _host_heads(x, adj, Ws, a1s, a2s, alpha, concat, mode, dropout, training):

@@ -170,3 +170,46 @@ def test_bf16_spgat_bench_configuration_against_the_storage_emulating_oracle(cud
         close("W of layer/head %d" % k, att.W.grad, ref_params[k][0].grad, 1e-2)
         close("a of layer/head %d" % k, att.a.grad, ref_params[k][1].grad, 2e-2)
     close("input features", xin.grad, cx.grad, 1e-2)
+
+
+@pytest.mark.parametrize("concat", [True, False])
+def test_gatconv_on_the_gpu_treats_an_edgeless_row_like_the_reference(cuda_device, concat):
+    """gatConv masks with -9e15 and soft-maxes the whole row (gatconv.py:34-36): a node without any edge attends uniformly to ALL
+    nodes.  The GPU layer (edges only, no dense N x N) must give that row the mean of Wh and route its gradient there; every other
+    row and all parameter gradients as the dense formula.  sparseGatConv asserts on such a graph, as gatconv.py:141 does."""
+    from dgll_amd.nn import gatConv, sparseGatConv
+
+    torch.manual_seed(1)
+    n = 40
+    g = torch.Generator().manual_seed(0)
+    adj = (torch.rand(n, n, generator=g) < 0.15).float()
+    adj = ((adj + adj.T + torch.eye(n)) > 0).float()
+    adj[7, :] = 0
+    x = torch.randn(n, 9)
+    layer = gatConv(9, 8, dropout=0.0, alpha=0.2, concat=concat).eval()
+
+    def dense(xx, W, a):
+        Wh = xx @ W
+        e = torch.nn.functional.leaky_relu(Wh @ a[:8] + (Wh @ a[8:]).T, 0.2)
+        hp = torch.softmax(torch.where(adj > 0, e, torch.full_like(e, -9e15)), dim=1) @ Wh
+        return torch.nn.functional.elu(hp) if concat else hp
+
+    xr = x.clone().requires_grad_()
+    Wr, ar = layer.W.detach().clone().requires_grad_(), layer.a.detach().clone().requires_grad_()
+    want = dense(xr, Wr, ar)
+    gout = torch.randn(n, 8)
+    (want * gout).sum().backward()
+
+    layer = layer.to(cuda_device)
+    xd = x.to(cuda_device).requires_grad_()
+    got = layer(xd, adj.to(cuda_device))
+    assert torch.isfinite(got).all()
+    torch.testing.assert_close(got.cpu(), want.detach(), rtol=1e-4, atol=1e-4)
+    (got * gout.to(cuda_device)).sum().backward()
+    torch.testing.assert_close(xd.grad.cpu(), xr.grad, rtol=2e-3, atol=2e-4)
+    torch.testing.assert_close(layer.W.grad.cpu(), Wr.grad, rtol=2e-3, atol=2e-4)
+    torch.testing.assert_close(layer.a.grad.cpu(), ar.grad, rtol=2e-3, atol=2e-4)
+
+    sp = sparseGatConv(9, 8, dropout=0.0, alpha=0.2).eval().to(cuda_device)
+    with pytest.raises(AssertionError):
+        sp(x.to(cuda_device), adj.to(cuda_device))
