@@ -83,6 +83,7 @@ SIGNATURES = {
                                 _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32, C.c_float, _i32,
                                 _i32, _vp, _sz]),
     "dgll_hip_gather_rows": (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp]),
+    "dgll_hip_pack_weight_bf16": (_i32, [_vp, _vp, _i32, _i64, _i64, _i32, _i32, _vp, _i64, _i32]),
     "dgll_hip_gather_rows_mapped": (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp]),
     "dgll_hip_aggregate_rows_mapped": (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp]),
     "dgll_host_sample_neighbors": (_i32, [_vp, C.POINTER(_i32), _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _i64,

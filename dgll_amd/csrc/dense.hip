@@ -935,6 +935,44 @@ static hipError_t launch_mfma_res_dispatch(const MfmaGemmArgs& a, int nt, int n_
 
 int g_tune_mfma_kperm = 0;   // dgll_hip_debug_tune(4, v): 0 = per-shape choice (shipped), 1 = 4-wave kernel always, 2 = no chunk rotation
 
+// ---- weight packing: [n, k] fp32 / bf16 with arbitrary element strides (a parameter or its transposed view) -> the zero-padded
+// bf16 [rows, ld] block the transform kernels stage.  ONE launch where the wrappers used to cast, zero-fill and copy (three).
+namespace dgll {
+template <typename T>
+__global__ __launch_bounds__(kBlock) void pack_weight_kernel(const T* __restrict__ src, int64_t sr, int64_t sc, int n, int k,
+                                                             bf16_t* __restrict__ dst, int64_t ld, int rows) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= (int64_t)rows * ld) return;
+    const int r = (int)(i / ld), c = (int)(i % ld);
+    float v = 0.0f;
+    if (r < n && c < k) {
+        if constexpr (sizeof(T) == 2) v = bf16_to_f32(src[r * sr + c * sc]);
+        else v = src[r * sr + c * sc];
+    }
+    dst[i] = f32_to_bf16(v);
+}
+}  // namespace dgll
+
+DGLL_API int dgll_hip_pack_weight_bf16(void* stream, const void* src, int src_dtype, int64_t stride_row, int64_t stride_col, int n,
+                                       int k, void* dst, int64_t ld, int rows) {
+    DGLL_REQUIRE(n >= 0 && k >= 0 && rows >= n && ld >= k, "shape");
+    if (rows == 0 || ld == 0) return DGLL_OK;
+    DGLL_REQUIRE(dst && (src || n == 0 || k == 0), "NULL argument");
+    DGLL_REQUIRE(src_dtype == DGLL_F32 || src_dtype == DGLL_BF16, "src_dtype");
+    const int64_t total = (int64_t)rows * ld;
+    const dim3 grid((uint32_t)((total + kBlock - 1) / kBlock));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (src_dtype == DGLL_F32)
+        hipLaunchKernelGGL((dgll::pack_weight_kernel<float>), grid, dim3(kBlock), 0, s, static_cast<const float*>(src), stride_row,
+                           stride_col, n, k, static_cast<bf16_t*>(dst), ld, rows);
+    else
+        hipLaunchKernelGGL((dgll::pack_weight_kernel<bf16_t>), grid, dim3(kBlock), 0, s, static_cast<const bf16_t*>(src), stride_row,
+                           stride_col, n, k, static_cast<bf16_t*>(dst), ld, rows);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "pack_weight_kernel launch");
+    return DGLL_OK;
+}
+
 static int transform_bf16_impl(void* stream, const void* A1, int64_t lda1, int K1, const void* Wt1, int64_t ldw1,
                                const void* A2, int64_t lda2, int K2, const void* Wt2, int64_t ldw2, int wt_rows,
                                const void* relu_mask, int64_t ldm, void* out, int64_t ldo, int out_dtype, int64_t M,

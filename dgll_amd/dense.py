@@ -17,12 +17,32 @@ _GW_MIN_ROWS = 256       # rows per slab of the split-K weight gradient below wh
 
 def _pad_wt(wt, rows=None):
     """[N, K] -> zero-padded bf16 [64 | 128 | 256 rows, 64*ceil(K/64) columns] as dgll_hip_transform_bf16 wants its
-    weights (the kernel is instantiated for 2, 4 or 8 column tiles of 32 and stages that many rows)."""
+    weights (the kernel is instantiated for 2, 4 or 8 column tiles of 32 and stages that many rows).  wt: fp32 or bf16, any
+    strides (a parameter's transposed view): cast, padding and layout are ONE launch (dgll_hip_pack_weight_bf16) -- the layers pass
+    their fp32 parameters straight through (`wcast`)."""
     n, k = wt.shape
     rows = rows or (64 if n <= 64 else 128 if n <= 128 else 256)
-    out = torch.zeros((rows, -(-k // 64) * 64), dtype=torch.bfloat16, device=wt.device)
+    ld = -(-k // 64) * 64
+    if wt.is_cuda and wt.dtype in (torch.float32, torch.bfloat16):
+        wt = wt.detach()
+        out = torch.empty((rows, ld), dtype=torch.bfloat16, device=wt.device)
+        with torch.cuda.device(wt.device):
+            code = _lib.lib.dgll_hip_pack_weight_bf16(torch.cuda.current_stream(wt.device).cuda_stream, wt.data_ptr(),
+                                                      _lib.F32 if wt.dtype == torch.float32 else _lib.BF16, wt.stride(0), wt.stride(1),
+                                                      n, k, out.data_ptr(), ld, rows)
+        _lib.check(code, "dgll_hip_pack_weight_bf16")
+        return out
+    out = torch.zeros((rows, ld), dtype=torch.bfloat16, device=wt.device)
     out[:n, :k] = wt
     return out
+
+
+def wcast(w, like):
+    """The weight in the form the products below take it: on the GPU path with bf16 activations the fp32 parameter ITSELF (the one
+    launch that packs it for the MFMA kernels also casts it: no bf16 copy is made per call), otherwise w.to(like.dtype)."""
+    if w.is_cuda and like.dtype == torch.bfloat16 and w.dtype == torch.float32:
+        return w
+    return w.to(like.dtype)
 
 
 def _timed(tag, device):
@@ -374,7 +394,7 @@ class _SageTransform(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, h, agg, ws, wn, relu):
-        wsd, wnd = ws.to(h.dtype), wn.to(h.dtype)
+        wsd, wnd = wcast(ws, h), wcast(wn, h)
         ctx.mfma = _mfma_ok(h, agg) and ws.shape[1] <= 256
         if ctx.mfma:   # one MFMA launch: both products, the add and the ReLU, every activation row read once
             out = transform_bf16(h, wsd.t(), agg, wnd.t(), relu=relu)
@@ -412,7 +432,7 @@ class _Linear(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w):
-        wd = w.to(x.dtype)
+        wd = wcast(w, x)
         if _mfma_ok(x) and wd.shape[1] <= 256:
             # narrow outputs feed a gather: give every row its own 128-byte line (a 94-byte row would straddle two)
             out = transform_bf16(x, wd.t(), ld_align=64 if wd.shape[1] < 64 else None)
@@ -442,7 +462,7 @@ class _SkinnyLinear(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w):
-        wd = w.to(x.dtype)
+        wd = wcast(w, x)
         if _mfma_ok(x) and wd.shape[1] <= 256:
             out = transform_bf16(x, wd.t(), out_dtype=torch.float32)
         else:
@@ -478,7 +498,7 @@ class _AddLinearAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, addend, x, w, relu):
-        wd = w.to(x.dtype)
+        wd = wcast(w, x)
         if _mfma_ok(x) and addend.dtype == torch.bfloat16 and addend.stride(1) == 1 and wd.shape[1] <= 256:
             out = transform_bf16(x, wd.t(), relu=relu, addend=addend)      # one MFMA launch instead of addmm + ReLU pass
         else:

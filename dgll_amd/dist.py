@@ -342,7 +342,7 @@ class _DistSageLayer(torch.autograd.Function):
         from . import dense
 
         agg = engine.aggregate_static(placed, reduce) if placed is not None else _aggregate_forward(engine, h, reduce)
-        wsd, wnd = ws.to(h.dtype), wn.to(h.dtype)
+        wsd, wnd = dense.wcast(ws, h), dense.wcast(wn, h)
         if h.is_cuda and dense._mfma_ok(h, agg) and ws.shape[1] <= 256:
             out = dense.transform_bf16(h, wsd.t(), agg, wnd.t(), relu=relu)
         else:
@@ -394,7 +394,7 @@ class _DistSageLayerTransformFirst(torch.autograd.Function):
     def forward(ctx, h, ws, wn, engine, reduce, relu, grad_is_gated, gate_input):
         from . import dense
 
-        wsd, wnd = ws.to(h.dtype), wn.to(h.dtype)
+        wsd, wnd = dense.wcast(ws, h), dense.wcast(wn, h)
         z = (dense.transform_bf16(h, wnd.t(), ld_align=64 if wn.shape[1] < 64 else None)
              if (h.is_cuda and dense._mfma_ok(h) and wn.shape[1] <= 256) else dense.mm_nt(h, wnd.t()))
         aggz = _aggregate_forward(engine, z, reduce)
@@ -562,7 +562,7 @@ class _DistSageInputLayerAll(torch.autograd.Function):
         agg_all = engine.input_aggregate_all(placed, reduce)
         scale = p.inv_deg if reduce == "mean" else None
         engine.spmm(p.merged, x_all, agg_all[:p.n_own], row_scale=scale)        # this rank's rows: aggregated every step
-        wsd, wnd = ws.to(x_all.dtype), wn.to(x_all.dtype)
+        wsd, wnd = dense.wcast(ws, x_all), dense.wcast(wn, x_all)
         if x_all.is_cuda and dense._mfma_ok(x_all, agg_all) and ws.shape[1] <= 256:
             out = dense.transform_bf16(x_all, wsd.t(), agg_all, wnd.t(), relu=relu)
         else:
@@ -601,7 +601,7 @@ class _DistSageLayerOnAll(torch.autograd.Function):
         _, agg = engine.alloc_rows(p.n_own, h_all.shape[1], h_all.dtype)
         engine.spmm(p.merged, h_all, agg, row_scale=scale)
         h = h_all[:p.n_own]
-        wsd, wnd = ws.to(h.dtype), wn.to(h.dtype)
+        wsd, wnd = dense.wcast(ws, h), dense.wcast(wn, h)
         if h.is_cuda and dense._mfma_ok(h, agg) and ws.shape[1] <= 256:
             out = dense.transform_bf16(h, wsd.t(), agg, wnd.t(), relu=relu)
         else:

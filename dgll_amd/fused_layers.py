@@ -32,7 +32,7 @@ class _SageGraphLayer(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, h, ws, wn, graph, reduce, relu, grad_is_gated=False, gate_input=False):
-        wsd, wnd = ws.to(h.dtype), wn.to(h.dtype)
+        wsd, wnd = dense.wcast(ws, h), dense.wcast(wn, h)
         ctx.grad_is_gated, ctx.gate_input = grad_is_gated, gate_input
         if FUSE_AGGREGATE_TRANSFORM and dense.fused_ok(graph, h, ws.shape[1], h):
             # ONE launch: a workgroup aggregates a 32-row tile into LDS and feeds it to the MFMAs; the aggregated rows are
@@ -87,7 +87,7 @@ class _SageGraphLayerTransformFirst(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, h, ws, wn, graph, reduce, relu, grad_is_gated=False, gate_input=False):
-        wsd, wnd = ws.to(h.dtype), wn.to(h.dtype)
+        wsd, wnd = dense.wcast(ws, h), dense.wcast(wn, h)
         ctx.grad_is_gated, ctx.gate_input = grad_is_gated, gate_input
         # the narrow product is gathered next: one 128-byte line per row (ld_align) instead of rows straddling two lines
         z = (dense.transform_bf16(h, wnd.t(), ld_align=64 if wn.shape[1] < 64 else None)

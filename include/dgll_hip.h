@@ -307,6 +307,11 @@ int64_t dgll_hip_grad_weight_f32_workspace(int K, int N, int slabs);
 int dgll_hip_grad_weight_f32(void* stream, const float* X, int64_t ldx, const float* G, int64_t ldg, float* dW,
                              int64_t lddw, int64_t M, int K, int N, void* workspace, int64_t workspace_bytes, int slabs);
 
+/* Wt operand of the transforms from a parameter: dst[r, c] = bf16(src[r*stride_row + c*stride_col]) for r < n, c < k, zero
+ * elsewhere, dst bf16 [rows >= n, ld >= k].  src fp32 or bf16, any element strides (pass a [K, N] parameter as its transposed view:
+ * stride_row = 1, stride_col = N) -- the cast, the zero padding and the layout in one launch.                                    */
+int dgll_hip_pack_weight_bf16(void* stream, const void* src, int src_dtype, int64_t stride_row, int64_t stride_col, int n, int k,
+                              void* dst, int64_t ld, int rows);
 /* ---- bf16 MFMA transform: out[M,N] = act( A1[M,K1].Wt1[N,K1]^T (+ A2[M,K2].Wt2[N,K2]^T) + bias ) -------------
  * The dense W-transform next to the aggregation on matrix cores (v_mfma_f32_32x32x16_bf16, fp32 accumulation):
  * sageConv's act(src.W_s + agg.W_n) in ONE pass (sageconv.py:71-82), gcnConv / GAT x.W (gcnconv.py:30,

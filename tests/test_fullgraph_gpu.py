@@ -372,3 +372,25 @@ def test_bf16_gcn_against_the_storage_emulating_oracle(cuda_device):
     close("gcn2.weight", model.gcn2.weight.grad, W2.grad, 1e-3)
     close("gcn2.bias", model.gcn2.bias.grad, b2.grad, 1e-3)
     close("input", xin.grad, cx.grad, 1e-2)                           # measured 1.7e-3 (its own bf16 rounding)
+
+
+@pytest.mark.parametrize("n,k,dtype,transposed", [(47, 256, torch.float32, True), (256, 100, torch.float32, True), (130, 602, torch.bfloat16, True),
+                                                  (8, 48, torch.float32, False), (256, 256, torch.bfloat16, False), (1, 1, torch.float32, True)])
+def test_weight_packing_is_cast_pad_and_layout_in_one_launch(cuda_device, n, k, dtype, transposed):
+    """dense._pad_wt (dgll_hip_pack_weight_bf16): the zero-padded bf16 block the transform kernels stage, from a parameter or its
+    transposed view, fp32 or bf16 -- equal to casting, zero-filling and copying with torch."""
+    from dgll_amd import dense
+
+    torch.manual_seed(n * 1000 + k)
+    base = torch.randn((k, n) if transposed else (n, k), device=cuda_device).to(dtype)
+    wt = base.t() if transposed else base
+    got = dense._pad_wt(wt)
+    rows = 64 if n <= 64 else 128 if n <= 128 else 256
+    want = torch.zeros((rows, -(-k // 64) * 64), dtype=torch.bfloat16, device=cuda_device)
+    want[:n, :k] = wt.to(torch.bfloat16)
+    assert got.shape == want.shape and got.dtype == torch.bfloat16 and torch.equal(got, want)
+    assert torch.equal(dense._pad_wt(wt, rows=256)[:rows], want[:rows]) and bool((dense._pad_wt(wt, rows=256)[n:] == 0).all())
+    # wcast: the fp32 parameter itself on the bf16 GPU path, a cast otherwise
+    act = torch.empty(1, dtype=torch.bfloat16, device=cuda_device)
+    assert dense.wcast(base, act) is base                      # fp32: packed (and cast) later; bf16: nothing to do
+    assert dense.wcast(base, act.float()).dtype == torch.float32
