@@ -44,8 +44,35 @@ def main():
     gen.manual_seed(1)
     feats = torch.randn(n, 100, generator=gen, device=dev)
     labels_all = torch.randint(0, 47, (n,), generator=gen, device=dev)
-    single_ms = float(os.environ.get("SINGLE_MS", "24.1"))      # bench.py --gpus 1 on the same box
-    print("single-process step (bench.py): %.1f ms" % single_ms)
+    # the single-GPU step of bench.py, measured here and now on the same box (the engine's reorder, same model, same loss)
+    def single_gpu_step_ms():
+        torch.manual_seed(0)
+        model = dnn.GraphSage(100, [256, 256, 47], None).to(dev)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+        full, perm = raw.reorder(seed=0)
+        full.plan(); full.transpose()[0].plan(); full.mean_scale_transposed()
+        x = ops.alloc_features(n, 100, torch.bfloat16, dev, pad_to=64)
+        x.copy_(feats[perm])
+        lab = labels_all[perm]
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            loss = ops.cross_entropy(model.forward_graph(full, x), lab, reduction="sum") * (1.0 / n)
+            loss.backward()
+            opt.step()
+
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            step()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / 10 * 1e3
+
+    single_ms = float(os.environ["SINGLE_MS"]) if "SINGLE_MS" in os.environ else single_gpu_step_ms()
+    torch.cuda.empty_cache()
+    print("single-GPU step (same model and graph, measured in this run): %.2f ms" % single_ms)
     for world in (2, 4, 8):
         torch.manual_seed(0)
         model = dnn.GraphSage(100, [256, 256, 47], None).to(dev)

@@ -51,3 +51,12 @@ for e in evs:
     if d >= 40:
         print("%9.1f us  +%8.1f us  %s" % (e.time_range.start - t0, d, e.name[:100]))
 print("N=%d kernel time %.3f ms, span %.3f ms, %d kernels" % (world, tot / 1e3, (evs[-1].time_range.end - t0) / 1e3, len(evs)))
+small = {}
+for e in evs:
+    d = e.time_range.end - e.time_range.start
+    if d < 40:
+        k = small.setdefault(e.name[:90], [0, 0.0])
+        k[0] += 1; k[1] += d
+print("kernels under 40 us: %d, %.3f ms in total" % (sum(v[0] for v in small.values()), sum(v[1] for v in small.values()) / 1e3))
+for name, (cnt, us) in sorted(small.items(), key=lambda kv: -kv[1][1])[:14]:
+    print("  %3d x %7.1f us  %s" % (cnt, us, name))
