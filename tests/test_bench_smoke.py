@@ -133,3 +133,33 @@ def test_bench_gat_workload_one_and_two_ranks():
     assert res2.returncode == 0, res2.stderr[-3000:]
     d2 = _last_json(res2.stdout)
     assert d2["n_gpus"] == 2 and abs(d2["loss"] - d["loss"]) < 3e-2 * abs(d["loss"])
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_bench_minibatch_and_rmat_workloads(fused):
+    """bench.py --workload minibatch (BASELINE config 2: sampler thread -> loader thread with the feature cache -> training) and
+    --workload rmat27 (config 5's shape at a small scale): the JSON contract, the steady-state window (at least 8 + 64 batches
+    whatever --steps says), the fields the judge reads, and that reducing the outermost hop straight out of the cache changes nothing
+    but the speed."""
+    shape = ["--workload", "minibatch", "--mb-nodes", "20000", "--mb-undirected-edges", "400000", "--mb-feats", "50", "--mb-classes", "7",
+             "--mb-batch", "64", "--mb-fanouts", "5,3,3", "--hidden", "64", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    if not fused:
+        shape.append("--mb-no-fused-last-hop")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + shape, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    d = _last_json(res.stdout)
+    assert d["config"]["workload_id"] == "minibatch" and d["steps"] == 64 and d["warmup"] == 8
+    assert d["config"]["outermost_hop"].startswith("reduced" if fused else "fetched")
+    for key in ("gpu_side_ms_per_batch", "host_sampler_ms_per_batch", "cache_miss_rate", "batches_per_s", "roofline"):
+        assert key in d, key
+    assert 0.0 < d["cache_miss_rate"] < 1.0 and d["loss"] == d["loss"]
+    prev = getattr(test_bench_minibatch_and_rmat_workloads, "loss", None)
+    if prev is not None:
+        assert abs(prev - d["loss"]) < 2e-2 * abs(prev)                 # same batches (seeded sampler), same model
+    test_bench_minibatch_and_rmat_workloads.loss = d["loss"]
+    if fused:
+        res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "rmat27", "--scale", "16", "--steps", "2",
+                              "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stderr[-3000:]
+        r = _last_json(res.stdout)
+        assert r["config"]["workload_id"] == "rmat27" and r["roofline"]["bound"] == "hbm" and r["value"] > 0
