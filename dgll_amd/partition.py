@@ -85,11 +85,18 @@ def relabel_by_parts(part_of_node, n_parts=None):
     return perm, bounds
 
 
-def partition_and_order(graph, n_parts, seed=0, sweeps=8):
-    """(perm, bounds) for the multi-GPU engine in one pass: parts from `community_parts`, and inside every part the
-    locality order of dgll_amd/reorder.py (communities contiguous, largest first; hubs first inside a community).  New node
-    i is old node perm[i]; part p owns [bounds[p], bounds[p+1])."""
+def partition_and_order(graph, n_parts, seed=0, sweeps=8, refine=True, imbalance=1.05, stats=None):
+    """(perm, bounds) for the multi-GPU engine in one pass: parts from `community_parts`, boundary-refined by `refine_parts`
+    (refine=False: the packed communities as they come), and inside every part the locality order of dgll_amd/reorder.py
+    (communities contiguous, largest first; hubs first inside a community).  New node i is old node perm[i]; part p owns
+    [bounds[p], bounds[p+1]).  `stats`: a dict that receives cut / balance before and after the refinement."""
     part, dense = community_parts(graph, n_parts, seed=seed, sweeps=sweeps, return_communities=True)
+    if stats is not None:
+        stats["before"] = partition_quality(graph, part, n_parts)
+    if refine and n_parts > 1:
+        part = refine_parts(graph, part, n_parts, imbalance=imbalance, seed=seed, log=None if stats is None else stats.setdefault("passes", []))
+        if stats is not None:
+            stats["after"] = partition_quality(graph, part, n_parts)
     n = graph.n_rows
     deg = graph.degrees()
     dmax = int(deg.max()) + 1 if n else 1
@@ -148,3 +155,91 @@ def community_parts(graph, n_parts, seed=0, sweeps=8, return_communities=False):
             done += took
             start = end
     return (part, dense) if return_communities else part
+
+
+def partition_quality(graph, part, n_parts):
+    """{'cut': share of the directed edges whose endpoints lie in different parts, 'balance': edges of the heaviest part over
+    the mean, 'rows': nodes per part, 'edges': edges per part}."""
+    deg = graph.degrees()
+    row_part = torch.repeat_interleave(part, deg)
+    cut = int((row_part != part[graph.col.long()]).sum())
+    edges = torch.zeros(n_parts, dtype=torch.int64, device=deg.device).index_add_(0, part, deg)
+    rows = torch.bincount(part, minlength=n_parts)
+    mean = max(float(edges.sum()) / max(n_parts, 1), 1.0)
+    return {"cut": cut / max(graph.nnz, 1), "cut_edges": cut, "balance": float(edges.max()) / mean,
+            "rows": rows.tolist(), "edges": edges.tolist()}
+
+
+def refine_parts(graph, part, n_parts, imbalance=1.05, passes=24, seed=0, log=None):
+    """Boundary refinement of a node -> part vector (the step METIS runs after its coarse partition; here after
+    `community_parts`, whose label-propagation communities are packed as they come: on the bench graph it leaves 13.1 % of the
+    edges cut where the generator's floor is 8.75 %).
+
+    Majority vote under a balance cap, on the device, all torch ops: every pass counts each node's neighbours per part
+    (one index_add over the edge list), proposes for every node the part that holds most of them, and moves the nodes with
+    a positive gain (neighbours in the target part minus neighbours in the own one) -- a seeded random half of them per
+    pass while the partition still changes a lot (two adjacent nodes swapping sides in the same pass would oscillate), all of
+    them at the end -- best gain first, as long as the target part stays under `imbalance` x the mean work (work of a node =
+    degree + 1, as in community_parts).  Stops when a pass improves the cut by less than 0.1 % of the edges.
+    Deterministic for a given seed."""
+    n = graph.n_rows
+    dev = graph.device
+    part = part.clone()
+    if n == 0 or n_parts < 2 or graph.nnz == 0:
+        return part
+    deg = graph.degrees()
+    work = deg + 1
+    cap = int(imbalance * float(work.sum()) / n_parts) + 1
+    row = graph.row_index()
+    col = graph.col.long()
+    ones = torch.ones(graph.nnz, dtype=torch.int32, device=dev)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed + 611953)
+    ids = torch.arange(n, device=dev)
+    prev_cut, half = None, True
+    best_cut, best_part = None, None
+    for it in range(passes):
+        cnt = torch.zeros(n * n_parts, dtype=torch.int32, device=dev)
+        cnt.index_add_(0, row * n_parts + part[col], ones)
+        cnt = cnt.view(n, n_parts)
+        own = cnt.gather(1, part.unsqueeze(1)).squeeze(1)
+        cut = int(deg.sum()) - int(own.sum())
+        if log is not None:
+            log.append({"pass": it, "cut": cut / graph.nnz, "half": half})
+        if best_cut is None or cut < best_cut:
+            best_cut, best_part = cut, part.clone()
+        if prev_cut is not None:
+            improved = prev_cut - cut
+            if half and improved < graph.nnz // 200:
+                half = False                      # the partition has settled: move every node that gains
+            elif not half and improved < graph.nnz // 1000:
+                break
+        prev_cut = cut
+        other = cnt.scatter(1, part.unsqueeze(1), -1)
+        best_cnt, best = other.max(1)
+        gain = (best_cnt - own).to(torch.int64)
+        del cnt, other
+        cand = gain > 0
+        if half:
+            cand &= torch.rand(n, generator=gen, device=dev) < 0.5
+        cidx = ids[cand]
+        if cidx.numel() == 0:
+            if not half:
+                break
+            half = False
+            continue
+        # best gain first inside every target part; accept the prefix that fits under the cap
+        g_c, b_c, w_c = gain[cidx], best[cidx], work[cidx]
+        gmax = int(g_c.max()) + 1
+        order = torch.argsort(b_c * gmax + (gmax - 1 - g_c), stable=True)
+        cidx, b_c, w_c = cidx[order], b_c[order], w_c[order]
+        load = torch.zeros(n_parts, dtype=torch.int64, device=dev).index_add_(0, part, work)
+        csum = torch.cumsum(w_c, 0)
+        seg_cnt = torch.bincount(b_c, minlength=n_parts)
+        seg_start = torch.cumsum(seg_cnt, 0) - seg_cnt
+        base = torch.where(seg_start > 0, csum[(seg_start - 1).clamp(min=0)], torch.zeros_like(seg_start))
+        base = torch.where(seg_cnt > 0, base, torch.zeros_like(base))
+        within = csum - base[b_c]
+        ok = within <= (cap - load)[b_c]
+        part[cidx[ok]] = b_c[ok]
+    return best_part if best_part is not None else part

@@ -82,3 +82,33 @@ def test_community_partitioner_splits_a_single_giant_community():
     part = partition.community_parts(g, 4)
     work = torch.zeros(4, dtype=torch.int64).index_add_(0, part, g.degrees() + 1)
     assert int(work.min()) > 0 and int(work.max()) < 1.6 * int(work.sum()) / 4
+
+
+def test_boundary_refinement_lowers_the_cut_under_the_balance_cap_and_is_deterministic():
+    """refine_parts after a deliberately bad start (planted communities dealt out by RANDOM halves): the majority vote has to
+    pull every community back together; the cut must fall to about the planted partition's, no part may exceed the cap, and
+    two runs with the same seed give the same vector."""
+    n, blocks, world = 6000, 8, 4
+    g = synth.products_like_graph("cpu", seed=2, n=n, n_undirected=90000, locality=0.9, n_blocks=blocks, exact=True, permute_ids=False)
+    block = -(-n // blocks)
+    planted = (torch.arange(n) // block) * world // blocks
+    q_planted = partition.partition_quality(g, planted, world)
+    gen = torch.Generator().manual_seed(0)
+    start = planted.clone()
+    flip = torch.rand(n, generator=gen) < 0.3                      # 30 % of the nodes start in a wrong part
+    start[flip] = torch.randint(0, world, (int(flip.sum()),), generator=gen)
+    q_start = partition.partition_quality(g, start, world)
+    log = []
+    refined = partition.refine_parts(g, start, world, imbalance=1.10, seed=5, log=log)
+    q = partition.partition_quality(g, refined, world)
+    assert q_start["cut"] > 2.0 * q_planted["cut"]
+    assert q["cut"] < 1.15 * q_planted["cut"], (q_start["cut"], q["cut"], q_planted["cut"])
+    work = torch.zeros(world, dtype=torch.int64).index_add_(0, refined, g.degrees() + 1)
+    assert int(work.max()) <= 1.10 * int(work.sum()) / world + 1
+    assert log and log[0]["cut"] == pytest.approx(q_start["cut"]) and min(e["cut"] for e in log) == pytest.approx(q["cut"])
+    assert torch.equal(refined, partition.refine_parts(g, start, world, imbalance=1.10, seed=5))
+    # partition_and_order runs it by default and reports both states
+    st = {}
+    g2 = synth.products_like_graph("cpu", seed=2, n=n, n_undirected=90000, locality=0.9, n_blocks=blocks, exact=True, permute_ids=True)
+    perm, bounds = partition.partition_and_order(g2, world, seed=0, stats=st)
+    assert st["after"]["cut"] <= st["before"]["cut"] and sorted(perm.tolist()) == list(range(n)) and bounds[-1] == n

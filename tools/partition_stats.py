@@ -18,8 +18,21 @@ dev = torch.device("cuda:0" if torch.cuda.is_available() else "cpu")
 raw = synth.products_like_graph(dev, seed=0, locality=args.locality, exact=True, permute_ids=True)
 n = raw.n_rows
 print("graph: %d nodes, nnz %d, %d nodes without edges" % (n, raw.nnz, int((raw.degrees() == 0).sum())))
+# the generator's own floor: its planted communities in contiguous ranges (same seed, ids NOT permuted: same edge set up to the
+# relabelling), split into equal contiguous parts -- what a perfect community finder + packer would cut
+planted = synth.products_like_graph(dev, seed=0, locality=args.locality, exact=True, permute_ids=False)
+block = -(-n // 64)
 for world in (2, 4, 8):
-    perm, bounds = dpart.partition_and_order(raw, world, seed=0)
+    pp = (torch.arange(n, device=dev) // block) * world // 64
+    q = dpart.partition_quality(planted, pp, world)
+    print("planted floor N=%d: cut %.2f %%, edge balance %.3f" % (world, 100 * q["cut"], q["balance"]))
+del planted
+for world in (2, 4, 8):
+    st = {}
+    perm, bounds = dpart.partition_and_order(raw, world, seed=0, stats=st)
+    print("N=%d partitioner: packed communities cut %.2f %% (balance %.3f) -> refined cut %.2f %% (balance %.3f) in %d passes %s" % (
+        world, 100 * st["before"]["cut"], st["before"]["balance"], 100 * st["after"]["cut"], st["after"]["balance"],
+        len(st["passes"]), [round(100 * x["cut"], 2) for x in st["passes"]]))
     g = dreorder.relabel(raw, perm)
     deg = g.degrees()
     rank_of_degree = torch.empty(n, dtype=torch.int64, device=dev)
