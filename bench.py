@@ -77,6 +77,7 @@ def parse_args(argv=None):
     ap.add_argument("--racom-async", action="store_true",
                     help="multi-rank: RaCoM asynchronous gradient sharing (the bucket all-reduce of step t overlaps step t+1; "
                          "applied one step late, drained every sync period) instead of the synchronous form")
+    ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam instead of the one-launch flat Adam (dgll_amd/optim.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-graphs", "--no-worst-case", dest="no_extra", action="store_true",
                     help="skip the extra SpMM measurements on the structure-free and raw-order graphs")
@@ -636,13 +637,19 @@ def run_sage(args, c):
         full.transpose()[0].plan()
         full.mean_scale_transposed()
     del feats_all
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    # Adam as ONE launch over flat parameter / gradient buffers (dgll_amd/optim.py: torch.optim.Adam's arithmetic): the weight-gradient
+    # kernels write into the gradient buffer, RaCoM all-reduces that buffer in place, the update kernel also emits the packed bf16
+    # weights of the MFMA transforms.  --torch-adam: torch.optim.Adam + per-parameter bucket copies, as in rounds 1-3.
+    from dgll_amd.optim import FlatAdam
+
+    params = list(model.parameters())
+    opt = torch.optim.Adam(params, lr=1e-3) if args.torch_adam else FlatAdam(params, lr=1e-3)
+    flat = None if args.torch_adam else opt
     if c.world > 1:
         if args.racom_async:
-            opt_wrap = ddist.RaCoMOptimizer(opt, model.parameters(), c.dev, staleness=1,
-                                            sync_every=ddist.racom_sync_period(n, c.world))
+            opt_wrap = ddist.RaCoMOptimizer(opt, params, c.dev, staleness=1, sync_every=ddist.racom_sync_period(n, c.world))
         else:
-            racom = ddist.RaCoM(model.parameters(), c.dev)
+            racom = ddist.RaCoM(params, c.dev, flat=flat)
     # forward: 3 layers; backward: layers 2 and 3 (the input features need no gradient).  The last layer narrows
     # (256 -> 47), so it aggregates the 47-wide product X.W_n instead of the 256-wide input (mean is linear).
     passes = 3 + 2
@@ -771,7 +778,6 @@ def run_gat(args, c):
         engine, x_local, labels = make_engine(args, c, full, feats_all, labels_all, bounds)
         placed_input = engine.place_input_halo(x_local)     # input features of halo nodes live with the partition
         graph_for_cpu = None
-        racom = ddist.RaCoM(model.parameters(), c.dev)
     else:
         x_local = ops.alloc_features(n, args.in_feats, c.dtype, c.dev, pad_to=args.feat_align)
         x_local.copy_(feats_all.to(c.dtype))
@@ -780,7 +786,12 @@ def run_gat(args, c):
         full.plan()
         full.transpose()[0].plan()
     del feats_all
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    from dgll_amd.optim import FlatAdam
+
+    params = list(model.parameters())
+    opt = torch.optim.Adam(params, lr=1e-3) if args.torch_adam else FlatAdam(params, lr=1e-3)
+    if c.world > 1:
+        racom = ddist.RaCoM(params, c.dev, flat=None if args.torch_adam else opt)
     passes = 2 * 3                # per layer: forward, backward over the rows of A, backward over the rows of A^T
     world = c.world
 

@@ -89,6 +89,10 @@ SIGNATURES = {
     "dgll_host_sample_neighbors": (_i32, [_vp, C.POINTER(_i32), _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _i64,
                                           C.POINTER(_i64)]),
     "dgll_host_translate_neighbors": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "dgll_host_mt_seed": (_i32, [_vp, _i64, _vp, C.POINTER(_i32)]),
+    "dgll_host_sample_batch_seeded": (_i32, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32]),
+    "dgll_hip_adam_flat": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _i64,
+                                  C.c_float, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dgll_hip_gemm_f32": (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _i32]),
     "dgll_hip_mm_f32": (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _i32, _vp, _i64]),
     "dgll_hip_grad_weight_f32_workspace": (_i64, [_i32, _i32, _i32]),

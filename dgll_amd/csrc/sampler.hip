@@ -82,15 +82,12 @@ struct MT19937 {
 // as j), which selects the same elements as running it on the values.  This phase touches only the generator, the
 // degree of each seed and a small scratch array, so it is cache-resident.  (2) PARALLEL (std::thread): translate positions to
 // neighbour ids, the memory-bound part (random reads into a multi-hundred-megabyte index array).
-DGLL_API int dgll_host_sample_neighbors(uint32_t* mt_state, int* mt_index, const int64_t* indptr, const int64_t* indices,
-                                        const int64_t* seeds, int64_t n_seeds, int64_t fanout, int64_t setsize,
-                                        int64_t* out_src, int64_t* out_dst, int64_t* out_counts, int64_t capacity,
-                                        int64_t* n_out) {
-    DGLL_REQUIRE(mt_state && mt_index && indptr && indices && (seeds || n_seeds == 0) && out_src && out_counts && n_out, "NULL argument");
-    DGLL_REQUIRE(*mt_index >= 0 && *mt_index <= 624, "bad generator index");
+namespace {
+int sample_hop(MT19937& rng, const int64_t* indptr, const int64_t* indices, const int64_t* seeds, int64_t n_seeds, int64_t fanout,
+               int64_t setsize, int64_t* out_src, int64_t* out_dst, int64_t* out_counts, int64_t capacity, int64_t* n_out,
+               int64_t max_threads) {
     static const bool profile = std::getenv("DGLL_SAMPLER_PROFILE") != nullptr;
     const auto t_begin = std::chrono::steady_clock::now();
-    MT19937 rng{mt_state, *mt_index};
     std::vector<uint32_t> pool;      // pool algorithm, on positions: kept equal to the identity between seeds (only the
                                      // entries a sample overwrote are restored, not all n re-initialised)
     std::vector<uint32_t> touched;   // pool positions a sample overwrote
@@ -156,7 +153,6 @@ DGLL_API int dgll_host_sample_neighbors(uint32_t* mt_state, int* mt_index, const
         at += take;
     }
     offset[n_seeds] = at;
-    *mt_index = rng.idx;
     *n_out = at;
     const auto t_phase1 = std::chrono::steady_clock::now();
     if (!out_dst) {   // positions only: the caller translates later (dgll_host_translate_neighbors), e.g. on another thread
@@ -177,7 +173,7 @@ DGLL_API int dgll_host_sample_neighbors(uint32_t* mt_state, int* mt_index, const
         }
     };
     const unsigned hw = std::thread::hardware_concurrency();
-    const int64_t n_threads = at < (1 << 16) ? 1 : std::min<int64_t>(hw ? hw : 1, 16);
+    const int64_t n_threads = at < (1 << 16) ? 1 : std::min<int64_t>(std::min<int64_t>(hw ? hw : 1, 16), std::max<int64_t>(max_threads, 1));
     if (n_threads <= 1) {
         translate(0, n_seeds);
     } else {   // plain std::thread (no OpenMP runtime next to torch's): contiguous seed ranges, disjoint output ranges
@@ -191,6 +187,81 @@ DGLL_API int dgll_host_sample_neighbors(uint32_t* mt_state, int* mt_index, const
         std::fprintf(stderr, "[dgll sampler] %lld seeds -> %lld edges: sequential draw phase %.2f ms, translation (%lld threads) %.2f ms\n",
                      (long long)n_seeds, (long long)at, std::chrono::duration<double, std::milli>(t_phase1 - t_begin).count(),
                      (long long)n_threads, std::chrono::duration<double, std::milli>(t_end - t_phase1).count());
+    }
+    return DGLL_OK;
+}
+
+// CPython's random.seed(int) (Modules/_randommodule.c: random_seed -> init_by_array over the 32-bit little-endian words of
+// abs(seed); init_genrand(19650218) first), restated; leaves the generator "exhausted" (index 624) as CPython does.
+void mt_init_by_array(uint32_t* mt, const uint32_t* key, int64_t key_len) {
+    constexpr int N = 624;
+    mt[0] = 19650218U;
+    for (int i = 1; i < N; i++) mt[i] = 1812433253U * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+    int64_t i = 1, j = 0;
+    for (int64_t k = (N > key_len ? N : key_len); k; k--) {
+        mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1664525U)) + key[j] + (uint32_t)j;
+        i++; j++;
+        if (i >= N) { mt[0] = mt[N - 1]; i = 1; }
+        if (j >= key_len) j = 0;
+    }
+    for (int k = N - 1; k; k--) {
+        mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1566083941U)) - (uint32_t)i;
+        i++;
+        if (i >= N) { mt[0] = mt[N - 1]; i = 1; }
+    }
+    mt[0] = 0x80000000U;
+}
+}  // namespace
+
+DGLL_API int dgll_host_sample_neighbors(uint32_t* mt_state, int* mt_index, const int64_t* indptr, const int64_t* indices,
+                                        const int64_t* seeds, int64_t n_seeds, int64_t fanout, int64_t setsize,
+                                        int64_t* out_src, int64_t* out_dst, int64_t* out_counts, int64_t capacity,
+                                        int64_t* n_out) {
+    DGLL_REQUIRE(mt_state && mt_index && indptr && indices && (seeds || n_seeds == 0) && out_src && out_counts && n_out, "NULL argument");
+    DGLL_REQUIRE(*mt_index >= 0 && *mt_index <= 624, "bad generator index");
+    MT19937 rng{mt_state, *mt_index};
+    const int code = sample_hop(rng, indptr, indices, seeds, n_seeds, fanout, setsize, out_src, out_dst, out_counts, capacity, n_out, 16);
+    if (code == DGLL_OK) *mt_index = rng.idx;
+    return code;
+}
+
+// random.seed(int) -> the 624-word state + index the calls above take: `key` = the 32-bit little-endian words of abs(seed)
+// ([0] for seed 0).  With it a sampler stream can live OUTSIDE the interpreter's global generator.
+DGLL_API int dgll_host_mt_seed(const uint32_t* key, int64_t key_len, uint32_t* mt_state, int* mt_index) {
+    DGLL_REQUIRE(key && key_len > 0 && mt_state && mt_index, "NULL argument");
+    mt_init_by_array(mt_state, key, key_len);
+    *mt_index = 624;
+    return DGLL_OK;
+}
+
+// A whole mini-batch under ITS OWN generator: what the reference's loop (dgllsampler.py:10-21 over base_sampler.py:45-58) draws
+// when `random.seed(seed)` is called right before the batch.  Batches seeded individually are independent of each other, so
+// several of them can be drawn CONCURRENTLY (one call per host thread; nothing here touches shared state), each still
+// bit-identical to the reference loop under the same seed -- the sequential single-stream mode (dgll_host_sample_neighbors on
+// the interpreter's generator) stays the default-compatible one.
+//   hops are given in SAMPLING order (the reference's reversed(fanouts)): hop h draws around the sources of hop h-1 (hop 0
+//   around `seeds`), duplicates kept.  fanouts[h] < 0 = every neighbour.  out_src[h] / out_dst[h] / out_counts[h]: caller-owned,
+//   capacity[h] edges / (number of hop seeds) counts.  defer_last != 0: the LAST hop keeps neighbour POSITIONS in out_src and
+//   leaves out_dst untouched (dgll_host_translate_neighbors, or a device-side translation, finishes it).
+//   max_threads bounds the helper threads of the id translation inside this call (1 when many batches run side by side).
+DGLL_API int dgll_host_sample_batch_seeded(const uint32_t* key, int64_t key_len, const int64_t* indptr, const int64_t* indices,
+                                           const int64_t* seeds, int64_t n_seeds, const int64_t* fanouts, const int64_t* setsizes,
+                                           int n_hops, int64_t* const* out_src, int64_t* const* out_dst, int64_t* const* out_counts,
+                                           const int64_t* capacity, int64_t* n_out, int defer_last, int max_threads) {
+    DGLL_REQUIRE(key && key_len > 0 && indptr && indices && (seeds || n_seeds == 0) && fanouts && setsizes && n_hops > 0 && out_src &&
+                 out_dst && out_counts && capacity && n_out, "NULL argument");
+    std::vector<uint32_t> state(624);
+    mt_init_by_array(state.data(), key, key_len);
+    MT19937 rng{state.data(), 624};
+    const int64_t* hop_seeds = seeds;
+    int64_t n_hop_seeds = n_seeds;
+    for (int h = 0; h < n_hops; ++h) {
+        const bool defer = defer_last && h == n_hops - 1;
+        const int code = sample_hop(rng, indptr, indices, hop_seeds, n_hop_seeds, fanouts[h], setsizes[h], out_src[h],
+                                    defer ? nullptr : out_dst[h], out_counts[h], capacity[h], &n_out[h], max_threads);
+        if (code != DGLL_OK) return code;
+        hop_seeds = out_src[h];
+        n_hop_seeds = n_out[h];
     }
     return DGLL_OK;
 }

@@ -384,9 +384,18 @@ __global__ __launch_bounds__(kBlock) void spmm_long_finalize_kernel(const SpmmAr
     const YT* gate = a.gate ? static_cast<const YT*>(a.gate) + row * a.ldg : nullptr;
     for (int f = lane * 4; f < a.feat; f += kWave * 4) {   // ws_ld is a multiple of 8 floats: the float4 stays in the row
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int c = cb; c < ce; ++c) {
-            const float4 p = *reinterpret_cast<const float4*>(a.ws + (int64_t)c * a.ws_ld + f);
-            s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+        // eight partial rows in flight, added in chunk order (a hub of some ten thousand edges has dozens of chunks: one dependent
+        // load per chunk made this kernel's run time the latency of the longest row -- 45-50 us per launch on an 8-way partition)
+        for (int c = cb; c < ce; c += 8) {
+            float4 p[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int cc = c + u < ce ? c + u : ce - 1;
+                p[u] = *reinterpret_cast<const float4*>(a.ws + (int64_t)cc * a.ws_ld + f);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (c + u < ce) { s.x += p[u].x; s.y += p[u].y; s.z += p[u].z; s.w += p[u].w; }
         }
         float v[4] = {s.x, s.y, s.z, s.w};
 #pragma unroll

@@ -19,7 +19,19 @@ def _pad_wt(wt, rows=None):
     """[N, K] -> zero-padded bf16 [64 | 128 | 256 rows, 64*ceil(K/64) columns] as dgll_hip_transform_bf16 wants its
     weights (the kernel is instantiated for 2, 4 or 8 column tiles of 32 and stages that many rows).  wt: fp32 or bf16, any
     strides (a parameter's transposed view): cast, padding and layout are ONE launch (dgll_hip_pack_weight_bf16) -- the layers pass
-    their fp32 parameters straight through (`wcast`)."""
+    their fp32 parameters straight through (`wcast`).  A parameter owned by optim.FlatAdam(pack_weights=True) needs no launch at
+    all: the optimizer's update kernel keeps both packed forms current and they are looked up here."""
+    if rows is None:
+        base = wt._base if wt._base is not None else wt
+        ref = getattr(base, "_dgll_flat", None)
+        if ref is not None:
+            hit = ref[0].packed_for(wt)
+            if hit is not None:
+                return hit
+    return _pack_now(wt, rows)
+
+
+def _pack_now(wt, rows=None):
     n, k = wt.shape
     rows = rows or (64 if n <= 64 else 128 if n <= 128 else 256)
     ld = -(-k // 64) * 64
@@ -290,8 +302,14 @@ def _gradw_ok(*mats):
                and m.stride(0) % 8 == 0 and m.data_ptr() % 16 == 0 and m.shape[1] <= 256 for m in mats)
 
 
-def _grad_weight_hip(x1, x2, g):
-    """(x1^T . g, x2^T . g) fp32 on the split-K MFMA kernel (csrc/gradw.hip): g is read once for both products."""
+def _out_ok(out, k, n, device):
+    return (out is not None and out.dtype == torch.float32 and out.shape == (k, n) and out.stride(1) == 1 and out.stride(0) >= n
+            and out.device == device)
+
+
+def _grad_weight_hip(x1, x2, g, out1=None, out2=None):
+    """(x1^T . g, x2^T . g) fp32 on the split-K MFMA kernel (csrc/gradw.hip): g is read once for both products.  out1 / out2:
+    fp32 [K, N] destinations (a parameter's slot of optim.FlatAdam's gradient buffer) written instead of fresh tensors."""
     m, n = g.shape
     k1, k2 = x1.shape[1], (x2.shape[1] if x2 is not None else 0)
     types = (-(-k1 // 64) + -(-k2 // 64) + 3) // 4
@@ -306,8 +324,8 @@ def _grad_weight_hip(x1, x2, g):
     ws = _GW_WORKSPACE.get(key)
     if ws is None or ws.numel() * 4 < need:
         ws = _GW_WORKSPACE[key] = torch.empty(need // 4, dtype=torch.float32, device=g.device)
-    d1 = torch.empty((k1, n), dtype=torch.float32, device=g.device)
-    d2 = torch.empty((k2, n), dtype=torch.float32, device=g.device) if x2 is not None else None
+    d1 = out1 if _out_ok(out1, k1, n, g.device) else torch.empty((k1, n), dtype=torch.float32, device=g.device)
+    d2 = (out2 if _out_ok(out2, k2, n, g.device) else torch.empty((k2, n), dtype=torch.float32, device=g.device)) if x2 is not None else None
     with torch.cuda.device(g.device):       # the launch (and its event bracket) belong to g's device, whatever is current
         end = _timed(("grad_weight", m, k1, k2, n, ""), g.device)
         code = _lib.lib.dgll_hip_grad_weight_bf16(
@@ -341,17 +359,31 @@ def _grad_weight_f32(x, g):
     return out
 
 
-def grad_weight(x, g):
+def _into(out, res):
+    if out is None or out is res:
+        return res
+    if out.shape != res.shape:
+        return res
+    out.copy_(res)
+    return out
+
+
+def grad_weight(x, g, out=None):
     """x^T . g  for x [M, K], g [M, N] -> fp32 [K, N]: the split-K MFMA kernel for bf16 (operands re-laid out to 16-byte rows
-    when needed, 256 x 256 output blocks), the fp32 slab kernel for fp32; host tensors use torch."""
+    when needed, 256 x 256 output blocks), the fp32 slab kernel for fp32; host tensors use torch.  out: fp32 [K, N] destination
+    (optim.grad_slot_of(parameter)): written by the kernel itself where it can be, copied into otherwise."""
     if not x.is_cuda:
-        return torch.mm(x.t(), g.to(x.dtype)).float()
+        return _into(out, torch.mm(x.t(), g.to(x.dtype)).float())
     if x.dtype == torch.float32 or g.dtype == torch.float32:
-        return _grad_weight_f32(x, g)
+        return _into(out, _grad_weight_f32(x, g))
     x, g = _as_rows16(x), _as_rows16(g.to(x.dtype))
     k, n = x.shape[1], g.shape[1]
     if k <= 256 and n <= 256:
-        return _grad_weight_hip(x, None, g)[0]
+        return _grad_weight_hip(x, None, g, out1=out)[0]
+    if out is not None and _out_ok(out, k, n, x.device):
+        res = grad_weight(x, g)
+        out.copy_(res)
+        return out
     out = torch.empty((k, n), dtype=torch.float32, device=x.device)
     for n0 in range(0, n, 256):
         gs = g[:, n0:n0 + 256]
@@ -365,11 +397,11 @@ def grad_weight(x, g):
     return out
 
 
-def grad_weight_pair(x1, x2, g):
+def grad_weight_pair(x1, x2, g, out1=None, out2=None):
     """(x1^T . g, x2^T . g): the two weight gradients of a SAGE layer share g -- one launch reads it once."""
     if _gradw_ok(x1, x2, g):
-        return _grad_weight_hip(x1, x2, g)
-    return grad_weight(x1, g), grad_weight(x2, g)
+        return _grad_weight_hip(x1, x2, g, out1=out1, out2=out2)
+    return grad_weight(x1, g, out=out1), grad_weight(x2, g, out=out2)
 
 
 def column_sum(g, slabs=2048):

@@ -24,6 +24,7 @@ import torch.distributed as dist
 
 from . import ops
 from .graph import CSRGraph
+from .optim import grad_slot_of
 
 
 class Partition:
@@ -349,6 +350,7 @@ class _DistSageLayer(torch.autograd.Function):
             out = dense.mm2_nt(h, wsd.t(), agg, wnd.t(), relu=relu)
         ctx.engine, ctx.reduce, ctx.relu = engine, reduce, relu
         ctx.grad_is_gated, ctx.gate_input = grad_is_gated, gate_input
+        ctx.wparams = (ws, wn)
         ctx.save_for_backward(h, agg, wsd, wnd, out if relu else None)
         return out
 
@@ -373,10 +375,11 @@ class _DistSageLayer(torch.autograd.Function):
             state = _aggregate_backward_start(engine, gagg)
         # everything below up to the finish overlaps the exchange
         if ctx.needs_input_grad[1] and ctx.needs_input_grad[2]:
-            gws, gwn = dense.grad_weight_pair(h, agg, g)                          # one launch, g read once
+            gws, gwn = dense.grad_weight_pair(h, agg, g, out1=grad_slot_of(ctx.wparams[0]),     # one launch, g read once
+                                              out2=grad_slot_of(ctx.wparams[1]))
         else:
-            gws = dense.grad_weight(h, g) if ctx.needs_input_grad[1] else None
-            gwn = dense.grad_weight(agg, g) if ctx.needs_input_grad[2] else None
+            gws = dense.grad_weight(h, g, out=grad_slot_of(ctx.wparams[0])) if ctx.needs_input_grad[1] else None
+            gwn = dense.grad_weight(agg, g, out=grad_slot_of(ctx.wparams[1])) if ctx.needs_input_grad[2] else None
         gh = None
         if state is not None:
             _, gh = engine.rows_of(dense.input_grad(g, wsd))                      # self path
@@ -404,6 +407,7 @@ class _DistSageLayerTransformFirst(torch.autograd.Function):
             out = dense.mm_nt(h, wsd.t(), relu=relu, addend=aggz)
         ctx.engine, ctx.reduce, ctx.relu = engine, reduce, relu
         ctx.grad_is_gated, ctx.gate_input = grad_is_gated, gate_input
+        ctx.wparams = (ws, wn)
         ctx.save_for_backward(h, wsd, wnd, out if relu else None)
         return out
 
@@ -413,20 +417,29 @@ class _DistSageLayerTransformFirst(torch.autograd.Function):
 
         h, wsd, wnd, out = ctx.saved_tensors
         engine = ctx.engine
-        _, gm = engine.alloc_rows(g.shape[0], g.shape[1], g.dtype)               # (masked) gradient in aligned rows
-        if ctx.relu and not ctx.grad_is_gated:
+        masked = ctx.relu and not ctx.grad_is_gated
+        if masked:                                                               # (masked) gradient in aligned rows
+            _, gm = engine.alloc_rows(g.shape[0], g.shape[1], g.dtype)
             torch.ops.aten.threshold_backward.grad_input(g, out, 0, grad_input=gm)
         else:
-            gm.copy_(g)
+            _, gm = engine.rows_of(g)            # the loss kernel's gradient already has 16-byte aligned rows: used as it is
         if ctx.reduce == "mean":
-            _, gp = engine.alloc_rows(g.shape[0], g.shape[1], g.dtype)
-            torch.mul(gm, engine.part.inv_deg.unsqueeze(1).to(g.dtype), out=gp)
+            # the 1 / deg of the mean on a scaled copy of the narrow gradient; over the WHOLE pitch of the rows when that is one
+            # contiguous block (a vectorised pass; the padding's product is never read) instead of a strided pass over the view
+            full = engine.full_pitch(gm)
+            if full is not None:
+                gp_full = torch.empty_like(full)
+                torch.mul(full, engine.part.inv_deg.unsqueeze(1).to(g.dtype), out=gp_full)
+                gp = gp_full[:, :g.shape[1]]
+            else:
+                _, gp = engine.alloc_rows(g.shape[0], g.shape[1], g.dtype)
+                torch.mul(gm, engine.part.inv_deg.unsqueeze(1).to(g.dtype), out=gp)
         else:
             gp = gm
         state = _aggregate_backward_start(engine, gp)
-        gws = dense.grad_weight(h, gm) if ctx.needs_input_grad[1] else None      # overlaps the exchange
+        gws = dense.grad_weight(h, gm, out=grad_slot_of(ctx.wparams[0])) if ctx.needs_input_grad[1] else None      # overlaps the exchange
         gz = _aggregate_backward_finish(engine, state)
-        gwn = dense.grad_weight(h, gz) if ctx.needs_input_grad[2] else None
+        gwn = dense.grad_weight(h, gz, out=grad_slot_of(ctx.wparams[1])) if ctx.needs_input_grad[2] else None
         gh = None
         if ctx.needs_input_grad[0]:
             if g.is_cuda and dense._mfma_ok(gm, gz) and wsd.shape[0] <= 256 and (not ctx.gate_input or h.stride(1) == 1):
@@ -568,6 +581,7 @@ class _DistSageInputLayerAll(torch.autograd.Function):
         else:
             out = dense.mm2_nt(x_all, wsd.t(), agg_all, wnd.t(), relu=relu)
         ctx.relu, ctx.grad_is_gated = relu, grad_is_gated
+        ctx.wparams = (ws, wn)
         ctx.save_for_backward(x_all, agg_all, out if relu else None)
         return out
 
@@ -580,10 +594,11 @@ class _DistSageInputLayerAll(torch.autograd.Function):
         if ctx.relu and not ctx.grad_is_gated:
             g = torch.ops.aten.threshold_backward(g, out, 0)
         if ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
-            gws, gwn = dense.grad_weight_pair(x_all, agg_all, g)                # own + halo rows: this rank's partial
+            gws, gwn = dense.grad_weight_pair(x_all, agg_all, g, out1=grad_slot_of(ctx.wparams[0]),   # own + halo rows: this rank's partial
+                                              out2=grad_slot_of(ctx.wparams[1]))
         else:
-            gws = dense.grad_weight(x_all, g) if ctx.needs_input_grad[0] else None
-            gwn = dense.grad_weight(agg_all, g) if ctx.needs_input_grad[1] else None
+            gws = dense.grad_weight(x_all, g, out=grad_slot_of(ctx.wparams[0])) if ctx.needs_input_grad[0] else None
+            gwn = dense.grad_weight(agg_all, g, out=grad_slot_of(ctx.wparams[1])) if ctx.needs_input_grad[1] else None
         return gws, gwn, None, None, None, None, None
 
 
@@ -608,6 +623,7 @@ class _DistSageLayerOnAll(torch.autograd.Function):
             out = dense.mm2_nt(h, wsd.t(), agg, wnd.t(), relu=relu)
         ctx.engine, ctx.reduce, ctx.relu = engine, reduce, relu
         ctx.grad_is_gated, ctx.gate_input = grad_is_gated, gate_input
+        ctx.wparams = (ws, wn)
         ctx.save_for_backward(h_all, agg, wsd, wnd, out if relu else None)
         return out
 
@@ -642,10 +658,10 @@ class _DistSageLayerOnAll(torch.autograd.Function):
             if ctx.gate_input and gate is None:
                 gh_all = torch.ops.aten.threshold_backward(gh_all, h_all, 0)
         if ctx.needs_input_grad[1] and ctx.needs_input_grad[2]:
-            gws, gwn = dense.grad_weight_pair(h, agg, g)
+            gws, gwn = dense.grad_weight_pair(h, agg, g, out1=grad_slot_of(ctx.wparams[0]), out2=grad_slot_of(ctx.wparams[1]))
         else:
-            gws = dense.grad_weight(h, g) if ctx.needs_input_grad[1] else None
-            gwn = dense.grad_weight(agg, g) if ctx.needs_input_grad[2] else None
+            gws = dense.grad_weight(h, g, out=grad_slot_of(ctx.wparams[0])) if ctx.needs_input_grad[1] else None
+            gwn = dense.grad_weight(agg, g, out=grad_slot_of(ctx.wparams[1])) if ctx.needs_input_grad[2] else None
         return gh_all, gws, gwn, None, None, None, None, None
 
 
@@ -688,21 +704,38 @@ class DistGraph:
         return -(-feat // epv) * epv
 
     def alloc_rows(self, n, feat, dtype):
-        """(storage [n, feat padded to 16 bytes] contiguous, view [n, feat])."""
+        """(storage [n, feat padded to 16 bytes] contiguous, view [n, feat]).  The padding columns are NOT initialised: every
+        consumer either masks what lies past `feat` (the MFMA transform's K tail, the gather kernels' ragged last vector) or
+        lets it flow into outputs nobody reads (the split-K weight gradient); zero-filling them cost eight strided fill launches
+        per step of the 47-wide layer."""
         ld = self._ld(feat, dtype)
         store = torch.empty((n, ld), dtype=dtype, device=self.device)
-        if ld != feat:
-            store[:, feat:].zero_()
         return store, (store[:, :feat] if ld != feat else store)
 
     def rows_of(self, h):
-        """(contiguous padded storage, view) holding h: h itself when it already is such a view, else a copy."""
+        """(padded rows [n, feat rounded up to 16 bytes], view [n, feat]) holding h: h ITSELF -- whatever its row pitch -- when its
+        rows start on 16-byte boundaries and the padding up to the rounded width lies inside its allocation (e.g. the narrow
+        product the MFMA transform writes on a 128-byte pitch), else a copy into fresh padded rows."""
         ld = self._ld(h.shape[1], h.dtype)
-        if h.stride(1) == 1 and h.stride(0) == ld and h.storage_offset() == 0 and (self.device.type == "cpu" or h.data_ptr() % 16 == 0):
-            return h.as_strided((h.shape[0], ld), (ld, 1)), h
+        esz = h.element_size()
+        if h.dim() == 2 and h.stride(1) == 1 and h.stride(0) >= ld and (h.stride(0) * esz) % 16 == 0 and \
+                (self.device.type == "cpu" or h.data_ptr() % 16 == 0) and \
+                (h.storage_offset() + max(h.shape[0] - 1, 0) * h.stride(0) + ld) * esz <= h.untyped_storage().nbytes():
+            return h.as_strided((h.shape[0], ld), (h.stride(0), 1), h.storage_offset()), h
         store, view = self.alloc_rows(h.shape[0], h.shape[1], h.dtype)
         view.copy_(h)
         return store, view
+
+    @staticmethod
+    def full_pitch(h):
+        """h's rows over their WHOLE pitch as one contiguous [n, pitch] alias (None when the last row's pitch runs past the
+        allocation or the rows are not a plain leading block of it)."""
+        if h.dim() != 2 or h.stride(1) != 1 or h.stride(0) < h.shape[1]:
+            return None
+        pitch = h.stride(0)
+        if (h.storage_offset() + h.shape[0] * pitch) * h.element_size() > h.untyped_storage().nbytes():
+            return None
+        return h.as_strided((h.shape[0], pitch), (pitch, 1), h.storage_offset())
 
     def spmm(self, graph, x, out, row_scale=None, accumulate=False, val=None, gate=None):
         if self._spmm_fn is not None:
@@ -897,10 +930,14 @@ class RaCoM:
     stream, averaged and copied back into .grad; `all_reduce_and_wait` is the synchronous form (identical to DDP),
     `launch` / `wait` let the caller overlap the reduction with other work."""
 
-    def __init__(self, params, device, group=None, average="reference"):
+    def __init__(self, params, device, group=None, average="reference", flat=None, in_place=True):
         """average: "reference" = all-reduce SUM, then divide by world_size (MQGCN.py:61-64); "ddp" = divide, then
         all-reduce SUM (torch DDP's order).  The two are bit-identical whenever world_size is a power of two -- every
-        configuration BASELINE names (1/2/4/8 GPUs) -- and differ in the last bit otherwise."""
+        configuration BASELINE names (1/2/4/8 GPUs) -- and differ in the last bit otherwise.
+        flat: an optim.FlatAdam that owns the parameters.  Its gradient buffer already IS the flattened bucket (the weight-gradient
+        kernels write their slots in place), so nothing is copied in or out: in_place=True all-reduces that buffer itself and
+        hands the 1 / world_size of the "reference" average to the optimizer's kernel (`grad_scale`: .grad then holds the SUM over
+        ranks); in_place=False (several reductions in flight, RaCoMOptimizer) moves the whole buffer with ONE copy each way."""
         if average not in ("reference", "ddp"):
             raise ValueError("average must be 'reference' or 'ddp'")
         self.average = average
@@ -908,23 +945,37 @@ class RaCoM:
         self.device = torch.device(device)
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        total = sum(p.numel() for p in self.params)
-        self.bucket = torch.zeros(total, dtype=torch.float32, device=self.device)
+        self.flat, self.in_place = flat, bool(in_place) and flat is not None
+        if flat is not None and [id(p) for p in self.params] != [id(p) for p in flat.params]:
+            raise ValueError("RaCoM(flat=...) must be given the parameters the FlatAdam owns, in its order")
+        if self.in_place:
+            self.bucket = flat.grad
+        else:
+            total = flat.total if flat is not None else sum(p.numel() for p in self.params)
+            self.bucket = torch.zeros(total, dtype=torch.float32, device=self.device)
         self.stream = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
         self._work = None
+        self.bytes_reduced = 0
 
     def launch(self):
-        views, off = [], 0
-        for p in self.params:
-            n = p.numel()
-            g = p.grad if p.grad is not None else torch.zeros_like(p)
-            views.append((p, off, n))
-            self.bucket[off:off + n].copy_(g.reshape(-1))
-            off += n
-        self._views = views
+        if self.flat is not None:
+            self.flat.gather_grads()                           # no launch when every gradient was written into its slot
+            if not self.in_place:
+                self.bucket.copy_(self.flat.grad)
+            self._views = None
+        else:
+            views, off = [], 0
+            for p in self.params:
+                n = p.numel()
+                g = p.grad if p.grad is not None else torch.zeros_like(p)
+                views.append((p, off, n))
+                self.bucket[off:off + n].copy_(g.reshape(-1))
+                off += n
+            self._views = views
         if self.world > 1 and self.average == "ddp":
             self.bucket.div_(self.world)
         if self.world > 1:
+            self.bytes_reduced += self.bucket.numel() * 4
             if self.stream is not None:
                 self.stream.wait_stream(torch.cuda.current_stream(self.device))
                 with torch.cuda.stream(self.stream):
@@ -938,6 +989,15 @@ class RaCoM:
             self._work = None
         if self.stream is not None:
             torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        if self.flat is not None:
+            if self.in_place:
+                self.flat.grad_scale = 1.0 / self.world if (self.world > 1 and self.average == "reference") else 1.0
+                return
+            if self.world > 1 and self.average == "reference":
+                self.bucket.div_(self.world)
+            self.flat.grad.copy_(self.bucket)
+            self.flat.grad_scale = 1.0
+            return
         if self.world > 1 and self.average == "reference":
             self.bucket.div_(self.world)                      # MQGCN.py:64
         for p, off, n in self._views:
@@ -973,7 +1033,10 @@ class RaCoMOptimizer:
     behaviour, MQGCN.py:55-79, and equals DDP."""
 
     def __init__(self, optimizer, params, device, staleness=1, sync_every=8, group=None, average="reference"):
+        from .optim import FlatAdam
+
         self.opt = optimizer
+        self.flat = optimizer if isinstance(optimizer, FlatAdam) else None     # its gradient buffer moves with one copy each way
         self.average = average
         self.params = [p for p in params if p.requires_grad]
         self.device, self.group = torch.device(device), group
@@ -983,7 +1046,8 @@ class RaCoMOptimizer:
         self.steps = 0
 
     def _bucket(self):
-        return self.free.pop() if self.free else RaCoM(self.params, self.device, self.group, average=self.average)
+        return self.free.pop() if self.free else RaCoM(self.params, self.device, self.group, average=self.average, flat=self.flat,
+                                                       in_place=False)
 
     def _apply_oldest(self):
         r = self.pending.pop(0)

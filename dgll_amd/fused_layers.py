@@ -11,6 +11,7 @@ the parameter gradients and the model-input gradient are exactly those of the un
 import torch
 
 from . import dense, ops
+from .optim import grad_slot_of
 
 
 # The fused aggregate -> transform kernel (csrc/fused_sage.hip: gather a 64-row tile into LDS, MFMA it against weights streamed
@@ -45,6 +46,7 @@ class _SageGraphLayer(torch.autograd.Function):
             else:
                 out = dense.mm2_nt(h, wsd.t(), agg, wnd.t(), relu=relu)
         ctx.graph, ctx.reduce, ctx.relu = graph, reduce, relu
+        ctx.wparams = (ws, wn)
         ctx.save_for_backward(h, agg, wsd, wnd, out if relu else None)
         return out
 
@@ -56,10 +58,11 @@ class _SageGraphLayer(torch.autograd.Function):
         if ctx.relu and not ctx.grad_is_gated:
             g = torch.ops.aten.threshold_backward(g, out, 0)
         if ctx.needs_input_grad[1] and ctx.needs_input_grad[2]:
-            gws, gwn = dense.grad_weight_pair(h, agg, g)   # one launch: g read once for both products
+            # one launch: g read once for both products; written into the optimizer's gradient slots when it owns the parameters
+            gws, gwn = dense.grad_weight_pair(h, agg, g, out1=grad_slot_of(ctx.wparams[0]), out2=grad_slot_of(ctx.wparams[1]))
         else:
-            gws = dense.grad_weight(h, g) if ctx.needs_input_grad[1] else None
-            gwn = dense.grad_weight(agg, g) if ctx.needs_input_grad[2] else None
+            gws = dense.grad_weight(h, g, out=grad_slot_of(ctx.wparams[0])) if ctx.needs_input_grad[1] else None
+            gwn = dense.grad_weight(agg, g, out=grad_slot_of(ctx.wparams[1])) if ctx.needs_input_grad[2] else None
         gh = None
         if ctx.needs_input_grad[0]:
             gh, gagg = dense.input_grads(g, wsd, wnd)      # self path, neighbour path: one MFMA launch, g read once
@@ -96,6 +99,7 @@ class _SageGraphLayerTransformFirst(torch.autograd.Function):
             # act(reduce_A(z) + h.Ws) in one launch: the aggregate of the narrow product never leaves the workgroup
             out, _ = dense.sage_fused_forward(graph, z, reduce, h, wsd.t(), None, relu, ld_align=64 if ws.shape[1] < 64 else None)
             ctx.graph, ctx.reduce, ctx.relu = graph, reduce, relu
+            ctx.wparams = (ws, wn)
             ctx.save_for_backward(h, wsd, wnd, out if relu else None)
             return out
         aggz = ops.spmm_raw(graph, z, reduce=reduce)
@@ -105,6 +109,7 @@ class _SageGraphLayerTransformFirst(torch.autograd.Function):
         else:
             out = dense.mm_nt(h, wsd.t(), relu=relu, addend=aggz)
         ctx.graph, ctx.reduce, ctx.relu = graph, reduce, relu
+        ctx.wparams = (ws, wn)
         ctx.save_for_backward(h, wsd, wnd, out if relu else None)
         return out
 
@@ -132,8 +137,8 @@ class _SageGraphLayerTransformFirst(torch.autograd.Function):
             gp = gm
         gt, _ = graph.transpose()
         gz = ops.spmm_raw(gt, gp, val=gt.val, reduce="sum")
-        gws = dense.grad_weight(h, gm) if ctx.needs_input_grad[1] else None
-        gwn = dense.grad_weight(h, gz) if ctx.needs_input_grad[2] else None
+        gws = dense.grad_weight(h, gm, out=grad_slot_of(ctx.wparams[0])) if ctx.needs_input_grad[1] else None
+        gwn = dense.grad_weight(h, gz, out=grad_slot_of(ctx.wparams[1])) if ctx.needs_input_grad[2] else None
         gh = None
         if ctx.needs_input_grad[0]:
             if dense._mfma_ok(gm, gz) and wsd.shape[0] <= 256 and (not ctx.gate_input or h.stride(1) == 1):

@@ -92,6 +92,67 @@ class AdaptiveQueue:
             return len(self._items)
 
 
+class OrderedHandoff:
+    """Hand-over between K producers that each own whole batches and ONE consumer that must see the batches in order: put(i, item)
+    blocks while i is more than `capacity` ahead of the next batch to be consumed; get() returns batch 0, 1, 2, ... (None after
+    close(n) once n batches were taken).  The reorder buffer of the multi-threaded sampling stage."""
+
+    def __init__(self, capacity):
+        self.capacity = int(capacity)
+        self._slots, self._next, self._total = {}, 0, None
+        self._cv = threading.Condition()
+
+    def put(self, index, item):
+        with self._cv:
+            while index >= self._next + self.capacity and self._total is None:
+                self._cv.wait()
+            self._slots[index] = item
+            self._cv.notify_all()
+
+    def close(self, total):
+        with self._cv:
+            self._total = int(total) if self._total is None else min(self._total, int(total))
+            self._cv.notify_all()
+
+    def get(self):
+        with self._cv:
+            while self._next not in self._slots:
+                if self._total is not None and self._next >= self._total:
+                    return None
+                self._cv.wait()
+            item = self._slots.pop(self._next)
+            self._next += 1
+            self._cv.notify_all()
+            return item
+
+
+class PinnedRing:
+    """A few page-locked int64 host buffers handed round: the outermost hop's positions / ids are written into one by the native
+    sampler and uploaded from it by an asynchronous DMA (a pageable source is staged by the runtime: the loading thread sat in that
+    copy for 2-3 ms per batch).  A buffer returns with the event that marks its upload complete and is reused after it."""
+
+    def __init__(self, n_buffers, capacity):
+        import queue
+
+        self._free = queue.Queue()
+        self.buffers = [torch.empty(int(capacity), dtype=torch.int64, pin_memory=True) for _ in range(int(n_buffers))]
+        for i in range(len(self.buffers)):
+            self._free.put((i, None))
+        self.capacity = int(capacity)
+
+    def acquire(self, n):
+        if n > self.capacity:
+            return None
+        i, event = self._free.get()
+        if event is not None:
+            event.synchronize()
+        return self.buffers[i].numpy()[:n], i
+
+    def release(self, token, event=None):
+        if token is not None:
+            self._free.put((token, event))
+
+
 class Batch:
     __slots__ = ("input_nodes", "output_nodes", "subgraphs", "features", "labels", "ready", "step", "last_hop_reduced")
 
@@ -103,7 +164,7 @@ class Batch:
 
 class MiniBatchPipeline:
     def __init__(self, dataloader, cache=None, labels=None, queue_size=4, device="cuda", hops=None, memory_fraction=0.1,
-                 record_access=False, reduce_last_hop=None):
+                 record_access=False, reduce_last_hop=None, sampler_threads=0, base_seed=0, epoch=0, device_graph=None):
         """dataloader: dgll_amd.dataloader.DataLoader; cache: GraphCacheServer (None: features come from
         dataloader.Dgraph.get_features on the host and are copied); hops: optional callable batch -> list of id tensors
         whose features are needed (default: the input nodes only, graphage.py:52).
@@ -123,6 +184,11 @@ class MiniBatchPipeline:
         if reduce_last_hop is not None and (cache is None or hops is None or reduce_last_hop not in ("mean", "sum")):
             raise ValueError("reduce_last_hop ('mean' / 'sum') needs a GraphCacheServer and a `hops` callback")
         self.reduce_last_hop = reduce_last_hop
+        self.sampler_threads, self.base_seed, self.epoch = int(sampler_threads), int(base_seed), int(epoch)
+        if self.sampler_threads > 0 and not hasattr(dataloader.sampler, "sample_seeded"):
+            raise ValueError("sampler_threads > 0 needs a sampler with sample_seeded (FastNeighborSampler)")
+        self.device_graph = device_graph
+        self._ring = None
         self._memory_bound_set = False
         self.hops = hops
         self.load_stream = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None   # d_stream
@@ -139,6 +205,78 @@ class MiniBatchPipeline:
         finally:
             self.sampled.put(_DONE)
 
+    def _sample_seeded_worker(self, t, handoff, n_batches):
+        """Thread t of K draws batches t, t + K, ... whole, each under its own seed; nothing is shared between the threads."""
+        from .sampling.fast_sampler import batch_seed
+
+        dl = self.dataloader
+        try:
+            for i in range(t, n_batches, self.sampler_threads):
+                seeds = dl.train_nodes[i * dl.batch_size:(i + 1) * dl.batch_size]
+                buf = self._ring.acquire if self._ring is not None else None
+                inp, outp, subgs = dl.sampler.sample_seeded(dl.Dgraph, seeds, batch_seed(self.base_seed, self.epoch, i), max_threads=1,
+                                                            last_hop_buffer=buf)
+                handoff.put(i, (i, inp, outp, subgs))
+        except BaseException as exc:  # noqa: BLE001
+            self._error = exc
+            handoff.close(0)
+
+    def _sample_threaded(self):
+        """Producer stage 1 in the per-batch-seeded mode: K workers -> OrderedHandoff -> the hand-over queue of the loader."""
+        n_batches = len(self.dataloader)
+        handoff = OrderedHandoff(capacity=2 * self.sampler_threads)
+        workers = [threading.Thread(target=self._sample_seeded_worker, args=(t, handoff, n_batches), name="dgll-sampler-%d" % t,
+                                    daemon=True) for t in range(self.sampler_threads)]
+        for w in workers:
+            w.start()
+        try:
+            taken = 0
+            while taken < n_batches:
+                item = handoff.get()
+                if item is None:
+                    break
+                self.sampled.put(item)
+                taken += 1
+        except BaseException as exc:  # noqa: BLE001
+            self._error = exc
+        finally:
+            handoff.close(0)
+            for w in workers:
+                w.join()
+            self.sampled.put(_DONE)
+
+    def _hop_ids(self, b):
+        """hops = "sampled": [seeds, sources around hop 0, ..., outermost sources]; the outermost list comes from the device-side
+        translation when the sampler left it as positions and the graph's index arrays are on the device."""
+        L = len(b.subgraphs)
+        ids = [b.output_nodes] + [b.subgraphs[L - 1 - h].src_nodes() for h in range(L - 1)]
+        last = b.subgraphs[0]
+        if self.device_graph is not None and self.load_stream is not None and getattr(last, "pending_positions", None) is not None \
+                and getattr(last, "_finish", None) is not None:
+            ids.append(self._translate_on_device(last))
+        else:
+            ids.append(last.src_nodes())
+            self._late_release = getattr(last, "buffer_token", None)    # a pinned buffer still to be uploaded: freed with b.ready
+        return ids
+
+    def _translate_on_device(self, sg):
+        """positions -> neighbour ids on the loading stream: ids[k] = indices[indptr[seed(k)] + position[k]]."""
+        indptr, indices = self.device_graph
+        hop_seeds, counts = sg.pending_positions
+        pos = sg._src
+        with torch.cuda.stream(self.load_stream):
+            seeds_d = hop_seeds.to(self.device, non_blocking=True)
+            cnt_d = counts.to(self.device, non_blocking=True)
+            pos_d = pos.to(self.device, non_blocking=True)
+            start = indptr[seeds_d]
+            ids = indices[torch.repeat_interleave(start, cnt_d, output_size=int(pos.numel())) + pos_d]
+            done = torch.cuda.Event()
+            done.record(self.load_stream)
+        if self._ring is not None:
+            self._ring.release(getattr(sg, "buffer_token", None), done)
+        sg.src_device = ids
+        return ids
+
     # ---- producer stage 2: feature loading --------------------------------------------------------------------
     def _load(self):
         try:
@@ -148,10 +286,14 @@ class MiniBatchPipeline:
                     break
                 b = Batch()
                 b.step, b.input_nodes, b.output_nodes, b.subgraphs = item
-                if hasattr(b.input_nodes, "resolve"):      # FastNeighborSampler(defer_last_hop=True): the outermost hop's
-                    b.input_nodes = b.input_nodes.resolve()    # positions become ids here, off the sampling thread
+                if self.hops == "sampled":
+                    id_lists = self._hop_ids(b)
+                    b.input_nodes = id_lists[-1]
+                else:
+                    if hasattr(b.input_nodes, "resolve"):      # FastNeighborSampler(defer_last_hop=True): the outermost hop's
+                        b.input_nodes = b.input_nodes.resolve()    # positions become ids here, off the sampling thread
+                    id_lists = self.hops(b) if self.hops is not None else [b.input_nodes]
                 inp, outp = b.input_nodes, b.output_nodes
-                id_lists = self.hops(b) if self.hops is not None else [inp]
                 if self.load_stream is not None:
                     with torch.cuda.stream(self.load_stream):
                         if self.reduce_last_hop is not None:
@@ -167,6 +309,9 @@ class MiniBatchPipeline:
                             b.labels = self.labels[outp].to(self.device, non_blocking=True)
                         b.ready = torch.cuda.Event()
                         b.ready.record(self.load_stream)
+                        if self._ring is not None and getattr(self, "_late_release", None) is not None:
+                            self._ring.release(self._late_release, b.ready)
+                            self._late_release = None
                     if not self._memory_bound_set:          # first loaded batch: how many of these fit in the memory budget
                         self._memory_bound_set = True
                         nbytes = sum(t.numel() * t.element_size() for t in list(b.features) + [b.last_hop_reduced] if t is not None)
@@ -187,7 +332,9 @@ class MiniBatchPipeline:
     def _fetch_many(self, id_lists):
         """Features of several id lists with ONE gather: the lists' rows are consecutive slices of one buffer (one id upload, one
         launch; GraphSage.forward_sampled stacks the hops of a layer without copying them)."""
-        if len(id_lists) <= 1:
+        if len(id_lists) <= 1 or self.cache is None:
+            # without a cache the rows come from Dgraph.get_features -- an indexing of a HOST tensor, which takes host ids: one
+            # fetch per list (joining them on the device, as below, would index a host tensor with device ids)
             return [self._fetch(ids) for ids in id_lists]
         sizes = [int(ids.numel()) for ids in id_lists]
         # the lists are joined ON THE DEVICE: a multi-threaded host torch.cat in this thread wakes the intra-op pool, whose spinning
@@ -201,13 +348,20 @@ class MiniBatchPipeline:
             if self.record_access:
                 self.cache.record_access(ids, stream=self.load_stream)
             return self.cache.fetch_data(ids, stream=self.load_stream)
-        feats = self.dataloader.Dgraph.get_features(ids)
+        feats = self.dataloader.Dgraph.get_features(ids.cpu() if isinstance(ids, torch.Tensor) and ids.is_cuda else ids)
         return feats.to(self.device, non_blocking=True)
 
     # ---- consumer side -----------------------------------------------------------------------------------------
     def __iter__(self):
         self._error = None
-        self._thread = threading.Thread(target=self._sample, name="dgll-sample-producer", daemon=True)
+        if self.sampler_threads > 0 and self.device_graph is not None and self.load_stream is not None and self._ring is None \
+                and getattr(self.dataloader.sampler, "defer_last_hop", False):
+            cap = self.dataloader.batch_size
+            for f in self.dataloader.sampler.fanouts:
+                cap *= int(f)
+            self._ring = PinnedRing(3 * self.sampler_threads + 4, cap)       # more buffers than batches can be in flight before the upload
+        self._thread = threading.Thread(target=self._sample_threaded if self.sampler_threads > 0 else self._sample,
+                                        name="dgll-sample-producer", daemon=True)
         self._loader = threading.Thread(target=self._load, name="dgll-feature-loader", daemon=True)
         self._thread.start()
         self._loader.start()

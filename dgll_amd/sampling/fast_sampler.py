@@ -23,6 +23,25 @@ def _setsize(k):
     return setsize
 
 
+def batch_seed(base_seed, epoch, batch):
+    """The seed of batch `batch` of epoch `epoch` in the per-batch-seeded mode:  (base_seed << 40) | (epoch << 20) | batch
+    (base_seed >= 0; epoch, batch < 2**20).  The reference's loop under random.seed(batch_seed(...)) right before that batch draws
+    the same ids (oracle/sampler.py; tests/test_sampler.py)."""
+    if base_seed < 0 or not (0 <= epoch < (1 << 20)) or not (0 <= batch < (1 << 20)):
+        raise ValueError("batch_seed needs base_seed >= 0 and epoch, batch in [0, 2**20)")
+    return (int(base_seed) << 40) | (int(epoch) << 20) | int(batch)
+
+
+def _seed_key(seed):
+    """random.seed(int): the 32-bit little-endian words of abs(seed), [0] for 0 (Modules/_randommodule.c)."""
+    n = abs(int(seed))
+    words = []
+    while n:
+        words.append(n & 0xffffffff)
+        n >>= 32
+    return np.array(words or [0], dtype=np.uint32)
+
+
 class _LazyInput:
     """Stands for `subgs[0].src_nodes()` (the input nodes of the batch) without forcing the deferred translation."""
 
@@ -83,6 +102,72 @@ class FastNeighborSampler(Base_sampler):
         sg = sugbraph(torch.from_numpy(src), torch.from_numpy(dst), torch.from_numpy(ptr), finish=finish)
         sg.max_degree = None if fanout is None else int(fanout)      # lets to_block() skip the long-row scan (host-only plan)
         return sg
+
+    def sample_seeded(self, g, seed_nodes, seed, max_threads=1, last_hop_buffer=None):
+        """The whole batch under ITS OWN generator, seeded as random.seed(seed) seeds the interpreter's: the ids the reference loop
+        draws right after that call.  Touches neither the global `random` state nor any shared scratch, and the native call runs
+        without the GIL: several threads may each draw whole batches at the same time (MiniBatchPipeline(sampler_threads=K)).
+        Returns what `sample` returns.  last_hop_buffer: optional callable(capacity) -> (int64 numpy array of that many entries,
+        token) supplying the outermost hop's id/position array (the pipeline hands out pinned host memory so that the upload is
+        an asynchronous DMA); the token is attached to the outermost sugbraph as `.buffer_token`."""
+        if any(f is None for f in self.fanouts):
+            raise ValueError("sample_seeded needs integer fan-outs")
+        indptr, indices = self._csr(g)
+        seeds = np.ascontiguousarray(seed_nodes.numpy() if isinstance(seed_nodes, torch.Tensor) else np.asarray(seed_nodes), dtype=np.int64)
+        order = [int(f) for f in reversed(self.fanouts)]
+        L = len(order)
+        fan = np.array(order, dtype=np.int64)
+        setsizes = np.array([_setsize(f) for f in order], dtype=np.int64)
+        caps, n_prev = [], len(seeds)
+        for f in order:                                  # upper bounds: every hop seed keeps at most `fanout` neighbours
+            caps.append(n_prev * f)
+            n_prev = n_prev * f
+        cap = np.array(caps, dtype=np.int64)
+        src = [np.empty(c, dtype=np.int64) for c in caps]
+        token = None
+        if last_hop_buffer is not None:
+            got = last_hop_buffer(caps[-1])
+            if got is not None:
+                src[-1], token = got
+        defer = bool(self.defer_last_hop)
+        dst = [np.empty(c, dtype=np.int64) for c in caps]
+        counts = [np.empty(len(seeds) if h == 0 else caps[h - 1], dtype=np.int64) for h in range(L)]
+        ptrs = lambda arrs: (C.c_void_p * L)(*[a.ctypes.data for a in arrs])      # noqa: E731
+        n_out = np.zeros(L, dtype=np.int64)
+        key = _seed_key(seed)
+        code = _lib.lib.dgll_host_sample_batch_seeded(
+            key.ctypes.data, len(key), indptr.ctypes.data, indices.ctypes.data, seeds.ctypes.data, len(seeds), fan.ctypes.data,
+            setsizes.ctypes.data, L, ptrs(src), ptrs(dst), ptrs(counts), cap.ctypes.data, n_out.ctypes.data, int(defer), int(max_threads))
+        _lib.check(code, "dgll_host_sample_batch_seeded")
+        subgs = []
+        hop_seeds = seeds
+        for h in range(L):
+            n_h = int(n_out[h])
+            cnt = counts[h][:len(hop_seeds)]
+            ptr = np.zeros(len(hop_seeds) + 1, dtype=np.int64)
+            np.cumsum(cnt, out=ptr[1:])
+            s_h, d_h = src[h][:n_h], dst[h][:n_h]
+            finish = None
+            if defer and h == L - 1:
+                finish = self._make_finish(indptr, indices, hop_seeds, cnt, s_h, d_h)
+            sg = sugbraph(torch.from_numpy(s_h), torch.from_numpy(d_h), torch.from_numpy(ptr), finish=finish)
+            sg.max_degree = order[h]
+            if finish is not None:     # what a device-side translation needs instead of the host one (MiniBatchPipeline(device_graph=))
+                sg.pending_positions = (torch.from_numpy(hop_seeds), torch.from_numpy(cnt))
+            if h == L - 1:
+                sg.buffer_token = token
+            subgs.insert(0, sg)
+            hop_seeds = s_h
+        return _LazyInput(subgs[0]) if defer else subgs[0].src_nodes(), seed_nodes, subgs
+
+    @staticmethod
+    def _make_finish(indptr, indices, seeds, counts, src, dst):
+        def finish():
+            _lib.check(_lib.lib.dgll_host_translate_neighbors(indptr.ctypes.data, indices.ctypes.data, seeds.ctypes.data, len(seeds),
+                                                              counts.ctypes.data, src.ctypes.data, dst.ctypes.data),
+                       "dgll_host_translate_neighbors")
+
+        return finish
 
     def sample(self, g, seed_nodes):
         output_nodes = seed_nodes

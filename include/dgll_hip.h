@@ -288,6 +288,32 @@ int dgll_host_sample_neighbors(uint32_t* mt_state, int* mt_index, const int64_t*
  * generator state, so a pipeline can run it on another thread while the next batch is being drawn.              */
 int dgll_host_translate_neighbors(const int64_t* indptr, const int64_t* indices, const int64_t* seeds, int64_t n_seeds,
                                   const int64_t* counts, int64_t* src_inout, int64_t* out_dst);
+/* random.seed(int) of CPython (init_by_array over `key` = the 32-bit little-endian words of abs(seed), [0] for 0) -> the 624-word
+ * state and index (624) the calls above take: a sampler stream that lives OUTSIDE the interpreter's global generator.          */
+int dgll_host_mt_seed(const uint32_t* key, int64_t key_len, uint32_t* mt_state, int* mt_index);
+/* A whole mini-batch under its own seed: what the reference's loop (dgllsampler.py:10-21 over base_sampler.py:45-58) draws when
+ * random.seed(seed) is called right before the batch.  Individually seeded batches are independent, so several host threads may
+ * each draw whole batches concurrently, every one bit-identical to the reference loop under its seed (the reference's loop is
+ * unseeded, base_sampler.py:56; its DataLoader-with-workers shape, MQGCN.py:114-128, gives every worker its own stream too).
+ * Hops in SAMPLING order (reversed(fanouts)): hop h draws around the sources of hop h-1 (hop 0 around `seeds`), duplicates kept;
+ * fanouts[h] < 0 = all neighbours; setsizes[h] as in dgll_host_sample_neighbors.  out_src/out_dst/out_counts: n_hops caller-owned
+ * arrays of capacity[h] edges (counts: one per hop seed).  defer_last: the last hop keeps POSITIONS in out_src[h], out_dst[h] is
+ * not written.  max_threads bounds the helper threads of the id translation inside this call.                                  */
+int dgll_host_sample_batch_seeded(const uint32_t* key, int64_t key_len, const int64_t* indptr, const int64_t* indices,
+                                  const int64_t* seeds, int64_t n_seeds, const int64_t* fanouts, const int64_t* setsizes, int n_hops,
+                                  int64_t* const* out_src, int64_t* const* out_dst, int64_t* const* out_counts,
+                                  const int64_t* capacity, int64_t* n_out, int defer_last, int max_threads);
+
+/* ---- the optimizer step of the training loops as ONE launch (torch.optim.Adam's arithmetic; MQGCN.py:141-144, train_gcn.py:26) --
+ * Adam over a flat fp32 parameter buffer: param/grad/exp_avg/exp_avg_sq [n]; `step` = 1, 2, ... (bias corrections formed in double
+ * on the host); grad_scale multiplies the gradient first (1 / world_size of the RaCoM average, MQGCN.py:64).  Segments (optional,
+ * at most 24): element range [seg_begin, seg_end) is a [rows, seg_cols] weight matrix whose updated values are ALSO written, as
+ * bf16, into seg_packed ([rows, seg_ld], W itself) and seg_packed_t ([cols, seg_ldt], W transposed) -- the zero-padded forms
+ * dgll_hip_transform_bf16 takes (what dgll_hip_pack_weight_bf16 produces per product otherwise); either pointer may be NULL.   */
+int dgll_hip_adam_flat(void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                       float beta1, float beta2, float eps, float weight_decay, int64_t step, float grad_scale, int n_segments,
+                       const int64_t* seg_begin, const int64_t* seg_end, const int* seg_cols, void* const* seg_packed,
+                       const int64_t* seg_ld, void* const* seg_packed_t, const int64_t* seg_ldt);
 
 /* ---- dense transform, exact fp32: C[M,N] = act(A[M,K].B[K,N] + bias) --------------------------------------
  * F.mm / F.matmul of gcnconv.py:30, sageconv.py:41,72, gatconv.py:31,117 for callers that only have the C ABI

@@ -293,3 +293,78 @@ def test_global_sampling_cache_and_access_driven_refresh(cuda_device):
     # capacity >= node count: everything cached
     srv.global_sampling_cache(deg, capacity=n)
     assert srv.full_cached
+
+
+def _zipf_graph(n, seed):
+    rng = np.random.default_rng(seed)
+    edges = []
+    for v in range(n):
+        deg = int(min(n - 1, rng.zipf(1.3))) if v % 9 else 0
+        edges.append(rng.choice(n, size=deg, replace=False).tolist())
+    return edges
+
+
+def test_per_batch_seeded_pipeline_with_sampler_threads_matches_the_reference_loop_batch_by_batch():
+    """MiniBatchPipeline(sampler_threads=K): K native sampler threads each own whole batches, batch b of epoch e is drawn under
+    batch_seed(base, e, b); batches arrive IN ORDER and every one is bit-equal to oracle/sampler.py (the reference's loop) run
+    right after random.seed(that seed).  Host tensors, no cache: features come from Dgraph.get_features per hop."""
+    from dgll_amd.data import DGraph
+    from dgll_amd.dataloader import DataLoader
+    from dgll_amd.pipeline import MiniBatchPipeline
+    from dgll_amd.sampling import FastNeighborSampler
+    from dgll_amd.sampling.fast_sampler import batch_seed
+    from oracle import sampler as osampler
+
+    n = 1500
+    edges = _zipf_graph(n, 3)
+    feats = torch.arange(n * 2, dtype=torch.float32).view(n, 2)
+    dg = DGraph(nodes=torch.arange(n), edges=edges, labels=torch.arange(n) % 5, features=feats)
+    fanouts = [5, 3]
+    train = torch.randperm(n, generator=torch.Generator().manual_seed(0))[:700]
+    for defer in (False, True):
+        loader = DataLoader(dg, train, FastNeighborSampler(fanouts, defer_last_hop=defer), batch_size=64)
+        pipe = MiniBatchPipeline(loader, labels=dg.labels, queue_size=3, device="cpu", hops="sampled", sampler_threads=4,
+                                 base_seed=11, epoch=2)
+        random.seed(1234)
+        before = random.getstate()
+        steps = []
+        for b in pipe:
+            i = b.step
+            seeds = train[i * 64:(i + 1) * 64]
+            random.seed(batch_seed(11, 2, i))
+            inp, outp, layers = osampler.sample(edges, seeds.tolist(), fanouts)
+            assert b.output_nodes.tolist() == outp and torch.as_tensor(b.input_nodes).tolist() == inp
+            for sg, (src, dst) in zip(b.subgraphs, layers):
+                assert sg.src_nodes().tolist() == src and sg.dst_nodes().tolist() == dst
+            # hop pyramid of features: hop 0 = seeds, hop 1 = sources around them, hop 2 = the outermost sources
+            assert len(b.features) == 3 and torch.equal(b.features[0], feats[seeds]) and torch.equal(b.features[2], feats[torch.tensor(inp)])
+            assert torch.equal(b.labels, dg.labels[seeds])
+            steps.append(i)
+            random.seed(1234)          # whatever the consumer does with the global generator, the batches do not depend on it
+        assert steps == list(range(len(loader)))
+    random.setstate(before)
+
+
+def test_ordered_handoff_returns_batches_in_order_and_bounds_the_run_ahead():
+    from dgll_amd.pipeline import OrderedHandoff
+
+    h = OrderedHandoff(capacity=3)
+    put_log = []
+
+    def producer(t):
+        for i in range(t, 20, 4):
+            time.sleep(0.001 * ((i * 7) % 5))
+            h.put(i, i * i)
+            put_log.append(i)
+
+    threads = [threading.Thread(target=producer, args=(t,)) for t in range(4)]
+    for t in threads:
+        t.start()
+    got = []
+    for k in range(20):
+        assert max(put_log + [0]) < k + 3 + 4          # nobody is more than capacity (+ one item in each producer's hand) ahead
+        got.append(h.get())
+    for t in threads:
+        t.join()
+    h.close(20)
+    assert got == [i * i for i in range(20)] and h.get() is None

@@ -168,3 +168,63 @@ def test_deferred_translation_gives_the_same_ids():
     for x, y in zip(a_sub, b_sub):
         assert torch.equal(x.src_nodes(), y.src_nodes()) and torch.equal(x.dst_nodes(), y.dst_nodes())
         assert torch.equal(x.indptr, y.indptr)
+
+
+def test_per_batch_seeded_sampler_is_bit_exact_under_random_seed_and_thread_safe():
+    """FastNeighborSampler.sample_seeded(g, seeds, s): the whole batch under its OWN generator, seeded as random.seed(s) seeds
+    the interpreter's -- ids bit-equal to the reference loop (oracle/sampler.py = base_sampler.py:45-58 + dgllsampler.py:10-21)
+    run right after random.seed(s), for small, huge and zero seeds (CPython's init_by_array over the 32-bit words of the int);
+    the global generator is not touched; eight threads drawing different batches at once give the same ids as one after another."""
+    import threading
+
+    from dgll_amd.sampling import FastNeighborSampler
+    from dgll_amd.sampling.fast_sampler import batch_seed
+    from oracle import sampler as osampler
+
+    rng = np.random.default_rng(1)
+    n = 2500
+    edges = []
+    for v in range(n):
+        deg = int(min(n - 1, rng.zipf(1.25))) if v % 13 else 0
+        edges.append(rng.choice(n, size=deg, replace=False).tolist())
+    dg = DGraph(nodes=torch.arange(n), edges=edges, labels=torch.zeros(n), features=torch.zeros(n, 1))
+    fanouts = [7, 3, 25]
+
+    def check(sampler, seeds, s, got):
+        random.seed(s)
+        inp, outp, layers = osampler.sample(edges, seeds.tolist(), fanouts)
+        g_inp, g_outp, subgs = got
+        g_inp = g_inp.resolve() if hasattr(g_inp, "resolve") else g_inp
+        assert g_inp.tolist() == inp and g_outp.tolist() == outp
+        for sg, (src, dst) in zip(subgs, layers):
+            assert sg.src_nodes().tolist() == src and sg.dst_nodes().tolist() == dst
+            assert int(sg.indptr[-1]) == len(src)
+
+    for defer in (False, True):
+        sampler = FastNeighborSampler(fanouts, defer_last_hop=defer)
+        for s in (0, 1, 12345, 2 ** 32 - 1, 2 ** 32, batch_seed(7, 3, 11), 2 ** 70 + 5, -9):
+            seeds = torch.from_numpy(rng.integers(0, n, size=64))
+            random.seed(99)
+            before = random.getstate()
+            got = sampler.sample_seeded(dg, seeds, s)
+            assert random.getstate() == before                     # the interpreter's generator is not involved
+            check(sampler, seeds, s, got)
+    # concurrency: every thread owns whole batches
+    sampler = FastNeighborSampler(fanouts, defer_last_hop=True)
+    batches = [torch.from_numpy(rng.integers(0, n, size=128)) for _ in range(16)]
+    out = [None] * len(batches)
+
+    def work(t):
+        for b in range(t, len(batches), 8):
+            out[b] = sampler.sample_seeded(dg, batches[b], batch_seed(0, 1, b))
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for b, seeds in enumerate(batches):
+        check(sampler, seeds, batch_seed(0, 1, b), out[b])
+    assert batch_seed(7, 3, 11) == (7 << 40) | (3 << 20) | 11
+    with pytest.raises(ValueError):
+        batch_seed(0, 0, 1 << 20)

@@ -8,6 +8,7 @@ import torch  # noqa: E402
 from torch.profiler import ProfilerActivity, profile  # noqa: E402
 
 from dgll_amd import dist as ddist, nn as dnn, ops, partition as dpart, reorder as dreorder, synth  # noqa: E402
+from dgll_amd.optim import FlatAdam  # noqa: E402
 from scaling_model import NullExchange  # noqa: E402
 
 world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
@@ -18,8 +19,11 @@ perm, bounds = dpart.partition_and_order(raw, world, seed=0)
 full = dreorder.relabel(raw, perm)
 del raw
 model = dnn.GraphSage(100, [256, 256, 47], None).to(dev)
-opt = torch.optim.Adam(model.parameters(), lr=1e-3)
-part = ddist.partition_contiguous(full, world, 0, bounds)
+params = list(model.parameters())
+opt = FlatAdam(params, lr=1e-3)
+racom = ddist.RaCoM(params, dev, flat=opt)
+rank = int(os.environ.get("MODEL_RANK", "0")) % world
+part = ddist.partition_contiguous(full, world, rank, bounds)
 engine = ddist.DistGraph(part, dev)
 engine.exchange = NullExchange(part)
 x = ops.alloc_features(part.n_own, 100, torch.bfloat16, dev, pad_to=64)
@@ -33,6 +37,7 @@ def step():
     out = engine.sage_forward(model, x, placed)
     loss = ops.cross_entropy(out, labels, reduction="sum") * (world / n)
     loss.backward()
+    racom.all_reduce_and_wait()
     opt.step()
 
 
@@ -50,13 +55,13 @@ for e in evs:
     tot += d
     if d >= 40:
         print("%9.1f us  +%8.1f us  %s" % (e.time_range.start - t0, d, e.name[:100]))
-print("N=%d kernel time %.3f ms, span %.3f ms, %d kernels" % (world, tot / 1e3, (evs[-1].time_range.end - t0) / 1e3, len(evs)))
+print("N=%d rank %d kernel time %.3f ms, span %.3f ms, %d kernels" % (world, rank, tot / 1e3, (evs[-1].time_range.end - t0) / 1e3, len(evs)))
 small = {}
 for e in evs:
     d = e.time_range.end - e.time_range.start
     if d < 40:
-        k = small.setdefault(e.name[:90], [0, 0.0])
+        k = small.setdefault(e.name[:230], [0, 0.0])
         k[0] += 1; k[1] += d
 print("kernels under 40 us: %d, %.3f ms in total" % (sum(v[0] for v in small.values()), sum(v[1] for v in small.values()) / 1e3))
-for name, (cnt, us) in sorted(small.items(), key=lambda kv: -kv[1][1])[:14]:
+for name, (cnt, us) in sorted(small.items(), key=lambda kv: -kv[1][1])[:24]:
     print("  %3d x %7.1f us  %s" % (cnt, us, name))
