@@ -81,6 +81,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-graphs", "--no-worst-case", dest="no_extra", action="store_true",
                     help="skip the extra SpMM measurements on the structure-free and raw-order graphs")
+    ap.add_argument("--other-workloads", choices=["auto", "on", "off"], default="auto",
+                    help="append compact records of the other BASELINE configs (gat = config 4, minibatch = config 2, rmat27 = config 5 on "
+                         "one GPU) to the default line as `other_workloads`, each measured by a child `bench.py --workload X` run after the "
+                         "headline; auto = on for the default single-GPU products-sized sage run")
     ap.add_argument("--calibrate", action="store_true",
                     help="launch the known-byte identity gather 3 times before the timed steps (PMC calibration rows)")
     ap.add_argument("--cpu-sample-rows", type=int, default=400_000)
@@ -97,6 +101,12 @@ def parse_args(argv=None):
     ap.add_argument("--mb-cache-frac", type=float, default=0.5, help="fraction of the nodes whose features sit in the HBM cache")
     ap.add_argument("--mb-no-fused-last-hop", action="store_true",
                     help="minibatch: fetch the outermost hop's rows and reduce them in the model instead of reducing them straight out of the cache")
+    ap.add_argument("--mb-sampler-threads", type=int, default=-1,
+                    help="minibatch: K native sampler threads, each drawing whole batches under per-batch seeds (bit-equal to the reference "
+                         "loop under random.seed(batch_seed(seed, epoch, b))); 0 = ONE sequential stream on the interpreter's generator "
+                         "(rounds 1-3); -1 = min(8, host threads / 4)")
+    ap.add_argument("--mb-host-translate", action="store_true",
+                    help="minibatch: turn the outermost hop's positions into ids on the host (16 threads) instead of by a device gather")
     ap.add_argument("--scale", type=int, default=27, help="rmat27: RMAT scale (27 = config 5; smaller for a quick run)")
     return ap.parse_args(argv)
 
@@ -185,6 +195,25 @@ def median3(fn):
     return sorted(ts)[1]
 
 
+def sample_rows_csr(graph, sample_rows, seed):
+    """(rows, host rowptr, host col, nnz) of `sample_rows` rows of `graph` drawn at random without replacement (seeded, kept in
+    ascending order).  The engine's reorder puts the hubs of every community first, so a PREFIX of the rows over-represents long
+    rows (round 3's sample: 56 edges per row against 50.5 on average); a random draw has the graph's own degree mix."""
+    n = graph.n_rows
+    if sample_rows >= n:
+        rp = graph.rowptr.cpu()
+        return n, rp, graph.col.cpu(), int(rp[-1])
+    gen = torch.Generator(device=graph.device)
+    gen.manual_seed(seed + 12345)
+    rows = torch.randperm(n, generator=gen, device=graph.device)[:sample_rows].sort().values
+    deg = graph.rowptr[rows + 1] - graph.rowptr[rows]
+    rowptr = torch.zeros(rows.numel() + 1, dtype=torch.int64, device=graph.device)
+    torch.cumsum(deg, 0, out=rowptr[1:])
+    nnz = int(rowptr[-1])
+    pos = torch.repeat_interleave(graph.rowptr[rows] - rowptr[:-1], deg, output_size=nnz) + torch.arange(nnz, device=graph.device)
+    return int(rows.numel()), rowptr.cpu(), graph.col[pos].cpu(), nnz
+
+
 def cpu_baseline_spmm(graph, feat, sample_rows, seed):
     """BASELINE.md section 5 on the GPU box's host cores, on a bounded sample of the SAME tensors (the first `sample_rows`
     rows of the adjacency the GPU ran, the same feature width, fp32): the reference's own op -- torch.spmm on a COO tensor
@@ -195,10 +224,7 @@ def cpu_baseline_spmm(graph, feat, sample_rows, seed):
     from oracle import cref, torch_ref
 
     host = host_info()
-    rows = min(sample_rows, graph.n_rows)
-    rowptr_t = graph.rowptr[:rows + 1].cpu()
-    nnz = int(rowptr_t[-1])
-    col_t = graph.col[:nnz].cpu()
+    rows, rowptr_t, col_t, nnz = sample_rows_csr(graph, sample_rows, seed)
     rng = np.random.default_rng(seed)
     x = rng.standard_normal((graph.n_cols, feat), dtype=np.float32)
     xt = torch.from_numpy(x)
@@ -215,7 +241,7 @@ def cpu_baseline_spmm(graph, feat, sample_rows, seed):
     t_c = median3(lambda: cref.spmm_csr(rp, cc, None, x, reduce="mean"))
     return {
         "value": nnz / t_coo, "unit": "edges/s", "cores": host["threads"], "kind": "port",
-        "sample": "mean-SpMM of the first %d rows (%d edges) of the benchmark's own adjacency against all %d feature rows, "
+        "sample": "mean-SpMM of %d rows DRAWN AT RANDOM (seeded; %d edges) from the benchmark's own (reordered) adjacency against all %d feature rows, "
                   "F=%d fp32; value = the reference's op torch.spmm(adj_coo, X) (gcnconv.py:31) as restated in "
                   "oracle/torch_ref.spmm_coo; 1 warm-up + median of 3" % (rows, nnz, graph.n_cols, feat),
         "torch_sparse_mm_csr_edges_per_s": nnz / t_csr,
@@ -240,10 +266,7 @@ def cpu_baseline_gat(graph, heads, fo, alpha, sample_rows, seed):
     from oracle import cref
 
     host = host_info()
-    rows = min(sample_rows, graph.n_rows)
-    rowptr_t = graph.rowptr[:rows + 1].cpu()
-    nnz = int(rowptr_t[-1])
-    col_t = graph.col[:nnz].cpu()
+    rows, rowptr_t, col_t, nnz = sample_rows_csr(graph, sample_rows, seed)
     rng = np.random.default_rng(seed)
     width = heads * fo
     h = rng.standard_normal((graph.n_cols, width), dtype=np.float32)
@@ -279,7 +302,7 @@ def cpu_baseline_gat(graph, heads, fo, alpha, sample_rows, seed):
     t_c = median3(oracle_pass)
     return {
         "value": nnz / t_torch, "unit": "edges/s", "cores": host["threads"], "kind": "port",
-        "sample": "fused GAT forward pass (%d heads x %d, fp32) over the first %d rows (%d edges) of the benchmark's adjacency "
+        "sample": "fused GAT forward pass (%d heads x %d, fp32) over %d rows drawn at random (seeded; %d edges) from the benchmark's adjacency "
                   "against all %d nodes; value = sparseGatConv.forward's op sequence (gatconv.py:111-148) restated on index lists "
                   "with torch CPU ops, heads one by one as gatconv.py:196; 1 warm-up + median of 3" % (heads, fo, rows, nnz, graph.n_cols),
         "oracle_c_openmp_edges_per_s": nnz / t_c,
@@ -362,20 +385,26 @@ def roofline_record(dom, sig, kernel_desc, compulsory, world, extra=None):
            "avg_launch_ms": dom["avg_ms"], "algorithmic_bytes_per_launch": dom["algorithmic_bytes"],
            "compulsory_bytes_per_launch": compulsory, "edges_per_s_this_kernel": dom["nnz"] / (dom["avg_ms"] * 1e-3),
            "build_stamp": build_stamp()}
+    # `frac` is ALWAYS achieved / peak with `achieved` = the section-8(d) algorithmic bytes / the live launch time -- the contract's
+    # definition; it exceeds 1 when caches serve re-reads (every edge is charged a full feature row).  Next to it, always present:
+    #   frac_l2_miss_path  bytes the L2s requested from the fabric for this launch kind (rocprofv3 FETCH_SIZE / WRITE_SIZE, corrected by
+    #                      the ratios calibrated in the same pass; Infinity-Cache hits are INCLUDED: an upper bound on DRAM traffic)
+    #                      / live launch time / peak; null unless profiles/traffic.json holds an entry for this workload, kernel
+    #                      instantiation and build;
+    #   frac_conservative  (sage headline only, filled in by the caller) structure-free graph in raw id order, formula.
+    rec["frac"] = rec["frac_algorithmic"]
+    rec["frac_definition"] = "algorithmic bytes (SURVEY 8(d): every edge one full feature row) / live launch time / peak; > 1 = cache-served re-reads"
+    rec["frac_l2_miss_path"] = None
     entry = load_traffic(sig, dom["kernel_fragment"]) if world == 1 else None
     if entry is not None:
         rec["traffic"] = entry["hbm_bytes_per_launch"]
         rec["traffic_source"] = {k: entry.get(k) for k in ("round", "fetch_size_kib", "write_size_kib", "ratio_read", "ratio_write",
                                                            "l2_hit_rate", "avg_ns_under_pmc")}
         hbm = entry["hbm_bytes_per_launch"] / (dom["avg_ms"] * 1e-3) / 1e9
-        rec["achieved_hbm_counters"] = hbm
-        rec["frac_hbm_counters"] = hbm / HBM_PEAK_GBPS
-        rec["frac"] = rec["frac_hbm_counters"]
-        rec["frac_definition"] = ("HBM-side counter bytes per launch (profiles/traffic.json: FETCH_SIZE / ratio_read + WRITE_SIZE / "
-                                  "ratio_write, same build) / live launch time / peak")
-    else:
-        rec["frac"] = rec["frac_algorithmic"]
-        rec["frac_definition"] = "algorithmic bytes (SURVEY 8(d) formula) / live launch time / peak (no counter pass for this build)"
+        rec["achieved_l2_miss_path"] = hbm
+        rec["frac_l2_miss_path"] = hbm / HBM_PEAK_GBPS
+        rec["frac_l2_miss_path_definition"] = ("counter bytes per launch (profiles/traffic.json: FETCH_SIZE / ratio_read + WRITE_SIZE / "
+                                               "ratio_write, same build; includes Infinity-Cache hits) / live launch time / peak")
     if extra:
         rec.update(extra)
     return rec
@@ -576,6 +605,7 @@ def make_engine(args, c, full, feats_all, labels_all, bounds):
     part = ddist.partition_rows(own_rowptr, own_col, None, bounds, c.rank)
     del own_rowptr, own_col
     engine = ddist.DistGraph(part, c.dev)
+    engine.verify()          # exchange lists agree across ranks + the start-up self-test of the chosen exchange form (DGLL_EXCHANGE)
     x_local = ops.alloc_features(part.n_own, args.in_feats, c.dtype, c.dev, pad_to=args.feat_align)
     x_local.copy_(engine.permute_to_local(feats_all[part.own_begin:part.own_end]).to(c.dtype))
     labels = engine.permute_to_local(labels_all[part.own_begin:part.own_end])
@@ -678,8 +708,10 @@ def run_sage(args, c):
     if opt_wrap is not None:
         opt_wrap.flush()
     global_loss = loss.detach().double() / c.world      # this rank's share of the mean loss
+    per_rank = None
     if c.world > 1:
         torch.distributed.all_reduce(global_loss)
+        per_rank = per_rank_diagnostics(c, engine, step, racom=racom, opt_wrap=opt_wrap)
     if c.rank != 0:
         return None
     local_rows = n if engine is None else engine.part.n_own
@@ -711,6 +743,9 @@ def run_sage(args, c):
                    "dense_launch_table": dense_table})      # a trivial 2R:1W kernel reaches (tools/probes/rw_mix.hip)
     if trace:
         result["warmup_loss_trace"] = trace
+    if per_rank is not None:
+        result["per_rank"] = per_rank
+        result["config"]["exchange_form"] = engine.exchange.form
     if c.world == 1 and not args.no_extra and not args.dataset:
         del model, opt
         result["roofline_no_locality"] = extra_roofline(args, c, locality=0.0, permute=False, reorder=args.reorder,
@@ -985,26 +1020,37 @@ def run_minibatch(args, c):
     n_batches = args.warmup + args.steps
     train = torch.randperm(args.mb_nodes)[:n_batches * args.mb_batch]
 
+    k_threads = args.mb_sampler_threads if args.mb_sampler_threads >= 0 else max(1, min(8, (os.cpu_count() or 4) // 4))
+    lock = __import__("threading").Lock()
+
     class TimedSampler(FastNeighborSampler):
         seconds, calls = 0.0, 0
 
-        def sample(self, g_, seeds):
+        def _timed(self, fn, *a, **kw):
             t = time.perf_counter()
-            out = super().sample(g_, seeds)
-            TimedSampler.seconds += time.perf_counter() - t
-            TimedSampler.calls += 1
+            out = fn(*a, **kw)
+            dt = time.perf_counter() - t
+            with lock:
+                TimedSampler.seconds += dt
+                TimedSampler.calls += 1
             return out
 
+        def sample(self, g_, seeds):
+            return self._timed(super().sample, g_, seeds)
+
+        def sample_seeded(self, g_, seeds, seed, **kw):
+            return self._timed(super().sample_seeded, g_, seeds, seed, **kw)
+
     loader = DataLoader(dg, train, TimedSampler(fanouts, defer_last_hop=True), batch_size=args.mb_batch)
-
-    def hop_ids(b):          # hop 0 = seeds, hop h+1 = sources sampled around hop h (subgs are outermost first)
-        return [b.output_nodes] + [b.subgraphs[L - 1 - h].src_nodes() for h in range(L)]
-
+    # the graph's index arrays in HBM (0.9 GB of int64): the outermost hop leaves the host as neighbour POSITIONS and becomes ids by a
+    # device gather on the loading stream
+    device_graph = None if args.mb_host_translate else (torch.from_numpy(indptr).to(c.dev), torch.from_numpy(indices).to(c.dev))
     # the outermost hop's mean is formed straight out of the feature cache (its 2.2 M gathered rows are never written): the loading
     # stage moves half the bytes, the consumer skips the widest block reduction, a queued batch is ten times smaller
     fuse_last = not args.mb_no_fused_last_hop
-    pipe = MiniBatchPipeline(loader, cache=cache, labels=labels, queue_size=4, device=c.dev, hops=hop_ids,
-                             reduce_last_hop="mean" if fuse_last else None)
+    pipe = MiniBatchPipeline(loader, cache=cache, labels=labels, queue_size=4, device=c.dev, hops="sampled",
+                             reduce_last_hop="mean" if fuse_last else None, sampler_threads=k_threads, base_seed=args.seed, epoch=0,
+                             device_graph=device_graph)
     model = dnn.GraphSage(args.mb_feats, [args.hidden] * (L - 1) + [args.mb_classes], fanouts).to(c.dev)
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
     random.seed(args.seed)
@@ -1014,12 +1060,21 @@ def run_minibatch(args, c):
     t0 = None
     events = []
     loss = None
+    # the consumer's kernels go to a HIGH-priority stream: the loading stream's gathers (normal priority) overlap them and, left to
+    # themselves, stretched half of the batches from 2.2 to 4.5-5 ms (round 3's six records)
+    compute = torch.cuda.Stream(c.dev, priority=-1)
+    compute.wait_stream(torch.cuda.current_stream(c.dev))
+    stream_ctx = torch.cuda.stream(compute)
+    stream_ctx.__enter__()
+    cpu_busy = 0.0
     for b in pipe:
         if done == args.warmup:
             torch.cuda.synchronize()
             timer_cm.__enter__()
             t0 = time.perf_counter()
             s0 = TimedSampler.seconds
+            l0, cpu_busy = pipe.load_seconds, 0.0
+        t_body = time.perf_counter()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
         blocks = [b.subgraphs[L - 1 - h].to_block(c.dev) for h in range(L)]
@@ -1035,11 +1090,15 @@ def run_minibatch(args, c):
             per_hop = [b.subgraphs[L - 1 - h].num_src_nodes() for h in range(L)]
             edges += sum(sum(per_hop[:L - l]) for l in range(L)) * 2
         done += 1
+        cpu_busy += time.perf_counter() - t_body
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    stream_ctx.__exit__(None, None, None)
     timer_cm.__exit__(None, None, None)
     sampler_s = TimedSampler.seconds - s0
-    gpu_ms = sum(a.elapsed_time(b_) for a, b_ in events) / max(len(events), 1)
+    per_batch = sorted(a.elapsed_time(b_) for a, b_ in events)
+    gpu_ms = sum(per_batch) / max(len(per_batch), 1)
+    pct = lambda q: per_batch[min(len(per_batch) - 1, int(q * len(per_batch)))] if per_batch else None    # noqa: E731
     # sampled blocks differ in size from batch to batch: launches are grouped by kind (width, dtype, weights), their edges and
     # times summed; algorithmic bytes count the per-edge term only (the row counts of the blocks are not in the tags)
     torch.cuda.synchronize()
@@ -1087,7 +1146,18 @@ def run_minibatch(args, c):
          "cache_fraction": args.mb_cache_frac, "outermost_hop": "reduced out of the cache" if fuse_last else "fetched, reduced in the model",
          "parallelism": "single GPU"})
     result.update({"loss": float(loss.detach()), "batches_per_s": steps / elapsed, "gpu_side_ms_per_batch": gpu_ms,
-                   "host_sampler_ms_per_batch": sampler_s / max(steps, 1) * 1e3, "cache_miss_rate": cache.get_miss_rate(),
+                   "gpu_side_ms_per_batch_p50": pct(0.5), "gpu_side_ms_per_batch_p95": pct(0.95), "gpu_side_ms_per_batch_max": per_batch[-1],
+                   "host_sampler_ms_per_batch": sampler_s / max(steps, 1) * 1e3,
+                   "host_sampler_threads": k_threads,
+                   # where the batch period goes on the host: the consumer thread's own time per batch (issuing ~110 launches through
+                   # Python), the loading thread's, and what is left of the period = the consumer waiting for a batch
+                   "consumer_host_ms_per_batch": cpu_busy / max(steps, 1) * 1e3,
+                   "loader_host_ms_per_batch": (pipe.load_seconds - l0) / max(steps, 1) * 1e3,
+                   "loaded_queue_starved_s": pipe.queue._starved,
+                   "sampler_mode": ("per-batch seeds, %d native sampler threads (batch b under random.seed(batch_seed(%d, 0, b)))" % (
+                       k_threads, args.seed)) if k_threads > 0 else "one sequential stream on the interpreter's generator",
+                   "outermost_hop_translation": "host" if device_graph is None else "device gather from pinned positions",
+                   "cache_miss_rate": cache.get_miss_rate(),
                    "epoch_time_s_153431_train_nodes": elapsed / steps * (153_431 / args.mb_batch),
                    "roofline": roofline, "spmm_launch_table": table, "dense_launch_table": dense_table})
     if not args.no_cpu_baseline:
@@ -1126,6 +1196,105 @@ def cpu_baseline_sampler(indptr, indices, fanouts, batch, seed):
             "cpu_model": host["cpu_model"], "threads": 1, "physical_cores": host["physical_cores"]}
 
 
+def per_rank_diagnostics(c, engine, step, racom=None, opt_wrap=None):
+    """N > 1, after the timed steps: what every rank did per step -- its own wall time, how long its compute stream sat waiting for
+    an exchange (the EXPOSED part of the halo traffic), bytes it sent, kernels it ran.  Gathered to rank 0 for the line, so that the
+    first run on real links says where the time went."""
+    import torch.distributed as dist
+    from torch.profiler import ProfilerActivity, profile
+
+    reps = 3
+    engine.exchange.bytes_sent = engine.exchange.bytes_received = engine.exchange.calls = 0
+    engine.wait_events = []
+    if racom is not None:
+        racom.bytes_reduced = 0
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        step()
+    torch.cuda.synchronize()
+    wall_ms = (time.perf_counter() - t0) / reps * 1e3
+    reduced = (racom.bytes_reduced / reps) if racom is not None else 0
+    wait_ms = engine.exposed_wait_ms() / reps
+    engine.wait_events = None
+    sent, calls = engine.exchange.bytes_sent / reps, engine.exchange.calls / reps
+    dist.barrier()
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        step()
+        torch.cuda.synchronize()
+    kern = [e for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA]
+    p = engine.part
+    mine = {"rank": c.rank, "step_ms": wall_ms, "exchange_wait_ms": wait_ms, "compute_ms": wall_ms - wait_ms,
+            "bytes_sent_per_step": sent, "exchanges_per_step": calls, "kernels_per_step": len(kern),
+            "kernel_ms_per_step": sum(e.time_range.end - e.time_range.start for e in kern) / 1e3,
+            "own_rows": p.n_own, "halo_rows": p.n_halo, "local_edges": p.local.nnz, "halo_edges": p.halo.nnz,
+            "gradient_bytes_all_reduced_per_step": reduced}
+    everyone = [None] * c.world
+    dist.all_gather_object(everyone, mine)
+    return everyone
+
+
+OTHER_WORKLOADS = {        # child command line tails and wall-clock bounds (seconds); the driver allows the whole run 30 minutes
+    "gat": (["--steps", "10", "--warmup", "3", "--no-extra-graphs"], 420),
+    "minibatch": ([], 420),
+    "rmat27": (["--steps", "5", "--warmup", "2"], 600),
+}
+
+
+def compact_record(d):
+    """What the default line keeps of a child run: the contract fields, `roofline` and `cpu_baseline` trimmed to their contract keys
+    (+ the kernel and the frac definitions), and the workload's own headline figures.  `bench.py --workload X` prints the full record."""
+    keep = {k: d.get(k) for k in ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "data", "epoch_time_s", "loss")}
+    keep["workload"] = d.get("config", {}).get("workload")
+    r = d.get("roofline") or {}
+    keep["roofline"] = {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "frac_definition", "frac_l2_miss_path",
+                                              "kernel", "kernel_fragment", "avg_launch_ms", "algorithmic_bytes_per_launch", "build_stamp")} if r else None
+    cb = d.get("cpu_baseline") or {}
+    keep["cpu_baseline"] = {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "sample", "oracle_c_openmp_csr_edges_per_s",
+                                                   "oracle_c_openmp_edges_per_s", "cpu_model")} if cb else None
+    for k in ("gat_pass_over_spmm", "spmm_same_width_same_graph_ms", "batches_per_s", "gpu_side_ms_per_batch", "gpu_side_ms_per_batch_p50",
+              "gpu_side_ms_per_batch_p95", "host_sampler_ms_per_batch", "host_sampler_threads", "sampler_mode", "consumer_host_ms_per_batch",
+              "loader_host_ms_per_batch", "cache_miss_rate", "epoch_time_s_153431_train_nodes"):
+        if k in d:
+            keep[k] = d[k]
+    cfg = d.get("config", {})
+    for k in ("nodes", "nnz", "hidden", "heads", "batch", "fanouts", "scale", "peak_memory_GB"):
+        if k in cfg:
+            keep.setdefault("config", {})[k] = cfg[k]
+    launches = {name: round(v["avg_ms"], 4) for name, v in (d.get("spmm_launch_table") or {}).items()}
+    if launches:
+        keep["gather_launch_ms"] = launches
+    return keep
+
+
+def run_other_workloads(args):
+    """The other BASELINE configs, each in a CHILD process (`bench.py --workload X`, started after this process has finished its own
+    measurement and released its device memory), one after the other; a child that fails or overruns leaves an `error` record and
+    never takes the headline with it."""
+    torch.cuda.empty_cache()
+    overrides = json.loads(os.environ.get("DGLL_BENCH_OTHER_ARGS", "{}"))      # tests: small shapes
+    out = {}
+    for name, (tail, limit) in OTHER_WORKLOADS.items():
+        extra = overrides.get(name, tail)
+        if extra is None:
+            continue
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", name, "--seed", str(args.seed)] + list(extra)
+        t0 = time.perf_counter()
+        try:
+            res = subprocess.run(cmd, capture_output=True, text=True, timeout=limit)
+            line = next((ln for ln in reversed(res.stdout.splitlines()) if ln.startswith("{") and '"metric"' in ln), None)
+            if res.returncode != 0 or line is None:
+                out[name] = {"error": "exit code %d" % res.returncode, "stderr_tail": res.stderr[-600:]}
+            else:
+                out[name] = compact_record(json.loads(line))
+        except subprocess.TimeoutExpired:
+            out[name] = {"error": "no result within %d s" % limit}
+        out[name]["wall_seconds"] = time.perf_counter() - t0
+        out[name]["command"] = "python bench.py --workload %s %s" % (name, " ".join(extra))
+    return out
+
+
 WORKLOADS = {"sage": run_sage, "gat": run_gat, "rmat27": run_rmat27, "minibatch": run_minibatch}
 
 
@@ -1136,6 +1305,10 @@ def main():
 
     result = WORKLOADS[args.workload](args, c)
     if c.rank == 0 and result is not None:
+        default_shape = (args.workload == "sage" and c.world == 1 and not args.dataset and args.nodes == 2_449_029
+                         and args.undirected_edges == 61_859_140 and args.dtype == "bf16")
+        if args.other_workloads == "on" or (args.other_workloads == "auto" and default_shape):
+            result["other_workloads"] = run_other_workloads(args)
         print(json.dumps(result))
 
 

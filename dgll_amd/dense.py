@@ -21,13 +21,12 @@ def _pad_wt(wt, rows=None):
     strides (a parameter's transposed view): cast, padding and layout are ONE launch (dgll_hip_pack_weight_bf16) -- the layers pass
     their fp32 parameters straight through (`wcast`).  A parameter owned by optim.FlatAdam(pack_weights=True) needs no launch at
     all: the optimizer's update kernel keeps both packed forms current and they are looked up here."""
-    if rows is None:
-        base = wt._base if wt._base is not None else wt
-        ref = getattr(base, "_dgll_flat", None)
-        if ref is not None:
-            hit = ref[0].packed_for(wt)
-            if hit is not None:
-                return hit
+    base = wt._base if wt._base is not None else wt
+    ref = getattr(base, "_dgll_flat", None)
+    if ref is not None:
+        hit = ref[0].packed_for(wt)
+        if hit is not None and (rows is None or hit.shape[0] == rows):
+            return hit
     return _pack_now(wt, rows)
 
 

@@ -19,6 +19,11 @@ supplies the partitioned full-graph path BASELINE.json's configs 3 and 5 name:
   * `RaCoM`: all parameter gradients flattened into ONE bucket, all-reduced on a dedicated stream, averaged
     (MQGCN.py:63-64: sum / world_size), and applied when ready; `sync_every` = 1 reproduces DDP exactly.
 """
+import os
+import sys
+import threading
+import time
+
 import torch
 import torch.distributed as dist
 
@@ -41,6 +46,7 @@ class Partition:
         self.send_counts = None    # python list, rows sent to each rank
         self.recv_counts = None    # python list, halo rows received from each rank
         self.send_reduce = None    # CSRGraph [n_own, sum(send_counts)]: owner-side deterministic reduction of returned grads
+        self.halo_ids = None       # int64 [n_halo] GLOBAL ids of the halo rows, ascending (== grouped by owner rank)
         self.merged = None         # CSRGraph [n_own, n_own + n_halo]: both halves over ONE column space (own rows first, then
                                    # the halo rows) -- for operands whose halo is already in place (the static input features)
         self.nnz = 0
@@ -71,6 +77,7 @@ def _split_block(p, rowptr, col, val, bounds, dev):
     owned = (col >= p.own_begin) & (col < p.own_end)
     halo_ids = torch.unique(col[~owned])                       # sorted by global id == grouped by owner rank
     p.n_halo = int(halo_ids.numel())
+    p.halo_ids = halo_ids
     owner = torch.bucketize(halo_ids, bounds_t[1:], right=True)
     p.recv_counts = torch.bincount(owner, minlength=world).tolist()
 
@@ -195,31 +202,116 @@ def nnz_balanced_bounds(graph, world):
 
 
 # ----------------------------------------------------------------------------------------------------------------
+class ExchangeWatchdog:
+    """First contact with a transport can hang (a grouped send/recv whose peers disagree, an IPC set-up that never completes): the
+    host then sits in a synchronize() for ever and the job dies without a word.  Every exchange registers an event recorded behind
+    it; a daemon thread polls the pending events and, when one is still incomplete `timeout` seconds after it was queued, prints
+    the phase name and EXITS THE PROCESS with code 3 (never re-executes anything).  DGLL_EXCHANGE_TIMEOUT_S (default 120, 0 =
+    off).  Host-tensor exchanges (gloo on CPU) block in wait() and are bracketed by `guard()` instead."""
+
+    def __init__(self, timeout=None, rank=0):
+        self.timeout = float(os.environ.get("DGLL_EXCHANGE_TIMEOUT_S", "120")) if timeout is None else float(timeout)
+        self.rank = rank
+        self._pending = []
+        self._lock = threading.Lock()
+        self._thread = None
+        self.on_timeout = self._die            # tests replace it
+
+    def _die(self, phase, age):
+        print("dgll_amd.dist: rank %d: exchange phase '%s' did not complete within %.0f s -- exiting (code 3)" % (self.rank, phase, age),
+              file=sys.stderr, flush=True)
+        os._exit(3)
+
+    def _run(self):
+        while True:
+            time.sleep(min(1.0, max(self.timeout / 4, 0.01)))
+            now = time.monotonic()
+            with self._lock:
+                keep = []
+                for phase, probe, t0 in self._pending:
+                    if probe():
+                        continue
+                    if now - t0 > self.timeout:
+                        self.on_timeout(phase, now - t0)
+                        continue
+                    keep.append((phase, probe, t0))
+                self._pending = keep
+
+    def _ensure_thread(self):
+        if self._thread is None and self.timeout > 0:
+            self._thread = threading.Thread(target=self._run, name="dgll-exchange-watchdog", daemon=True)
+            self._thread.start()
+
+    def watch_event(self, phase, event):
+        """event: a torch.cuda.Event recorded behind the exchange on its stream."""
+        if self.timeout <= 0:
+            return
+        self._ensure_thread()
+        with self._lock:
+            self._pending.append((phase, event.query, time.monotonic()))
+
+    def guard(self, phase):
+        """Context manager around a host-blocking wait."""
+        wd = self
+
+        class _G:
+            def __enter__(self_g):
+                self_g.done = False
+                if wd.timeout > 0:
+                    wd._ensure_thread()
+                    with wd._lock:
+                        wd._pending.append((phase, lambda: self_g.done, time.monotonic()))
+
+            def __exit__(self_g, *exc):
+                self_g.done = True
+
+        return _G()
+
+
 class _Exchange:
-    """Grouped point-to-point halo exchange.
+    """Halo exchange of packed row blocks, two interchangeable forms (DGLL_EXCHANGE = p2p | alltoall, default p2p):
+
+      p2p       one grouped batch of point-to-point send/recv to all peers at once (xGMI is point-to-point: every link is driven
+                concurrently, no ring)                                                     -- dist.batch_isend_irecv
+      alltoall  the same packed buffers through ONE all-to-all-v collective with per-peer row counts   -- dist.all_to_all_single
+                (the fallback when the grouped p2p form misbehaves on a given RCCL / driver combination)
 
     RCCL ("nccl"): device buffers, stream-ordered -- the product path.  gloo has no device send/recv (it would read the
     device pointer from the host with no ordering against the GPU kernels that fill the buffer: silent races), so for
     device tensors on gloo -- the functional multi-rank tests that share one GPU -- the rows are staged through host
     memory explicitly: copy out (synchronising), send/recv on CPU tensors, copy back on the communication stream."""
 
-    def __init__(self, part, group=None):
+    def __init__(self, part, group=None, form=None, watchdog=None):
         self.part, self.group = part, group
+        self.form = (form or os.environ.get("DGLL_EXCHANGE", "p2p")).lower()
+        if self.form not in ("p2p", "alltoall"):
+            raise ValueError("DGLL_EXCHANGE must be 'p2p' or 'alltoall', got %r" % self.form)
+        self.watchdog = watchdog if watchdog is not None else ExchangeWatchdog(rank=part.rank)
+        self.bytes_sent = self.bytes_received = self.calls = 0
+        self.phase = "exchange"
 
     def _staged(self, t):
         return t.is_cuda and self.part.world > 1 and dist.is_initialized() and dist.get_backend(self.group) != "nccl"
 
     def start(self, send_buf, recv_buf, reverse=False, more=()):
-        """One grouped call moving `send_buf` rows to their peers and filling `recv_buf`; `more` = further
+        """One exchange moving `send_buf` rows to their peers and filling `recv_buf`; `more` = further
         (send, recv) pairs with the same row layout (e.g. the fp32 score rows next to the feature rows)."""
         p = self.part
         s_counts, r_counts = (p.recv_counts, p.send_counts) if reverse else (p.send_counts, p.recv_counts)
-        opsl, copy_back = [], []
+        opsl, works, copy_back = [], [], []
+        self.calls += 1
         for sb, rb in ((send_buf, recv_buf),) + tuple(more):
+            self.bytes_sent += sb.numel() * sb.element_size()
+            self.bytes_received += rb.numel() * rb.element_size()
             if self._staged(sb) or self._staged(rb):
                 host_recv = torch.empty(rb.shape, dtype=rb.dtype, device="cpu")
                 copy_back.append((rb, host_recv))
                 sb, rb = sb.cpu(), host_recv                 # .cpu() waits for the kernels that produced the rows
+            if self.form == "alltoall":
+                if p.world > 1:
+                    works.append(dist.all_to_all_single(rb, sb.contiguous(), output_split_sizes=list(r_counts),
+                                                        input_split_sizes=list(s_counts), group=self.group, async_op=True))
+                continue
             so = ro = 0
             for q in range(p.world):
                 if s_counts[q]:
@@ -228,14 +320,22 @@ class _Exchange:
                     opsl.append(dist.P2POp(dist.irecv, rb[ro:ro + r_counts[q]], q, self.group))
                 so += s_counts[q]
                 ro += r_counts[q]
-        reqs = dist.batch_isend_irecv(opsl) if opsl else []
+        reqs = works + (dist.batch_isend_irecv(opsl) if opsl else [])
         return (reqs, copy_back)
 
-    @staticmethod
-    def wait(handle):
+    def wait(self, handle):
         reqs, copy_back = handle
-        for r in reqs:
-            r.wait()
+        device_side = bool(reqs) and torch.cuda.is_available() and dist.is_initialized() and dist.get_backend(self.group) == "nccl"
+        if device_side:
+            for r in reqs:
+                r.wait()                                     # stream-ordered: returns at once; a hang shows up behind it
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self.watchdog.watch_event(self.phase, ev)
+        else:
+            with self.watchdog.guard(self.phase):
+                for r in reqs:
+                    r.wait()
         for dev_buf, host_buf in copy_back:
             dev_buf.copy_(host_buf)
 
@@ -674,6 +774,7 @@ class DistGraph:
         self.exchange = _Exchange(part, group)
         self._spmm_fn = spmm_fn
         self.comm_stream = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
+        self.wait_events = None          # set to [] to have join_comm() time the compute stream's stall behind every exchange
         self.halo_recompute = True       # sage_forward: first layer recomputed on halo rows instead of exchanged (set False to compare)
         if self.device.type == "cuda":   # build the schedules up front, not inside the first timed step
             for g in (part.local, part.halo):
@@ -683,8 +784,11 @@ class DistGraph:
                 part.send_reduce.plan()
 
     def verify(self):
-        """Cross-check the locally derived exchange lists across ranks (a mismatch would otherwise hang the first
-        send/recv): every rank must see the same graph, and what r sends to q must be what q expects from r."""
+        """Before anything is timed: (1) cross-check the locally derived exchange lists across ranks (a mismatch would otherwise
+        hang the first send/recv): every rank must see the same graph, and what r sends to q must be what q expects from r;
+        (2) SELF-TEST of the chosen exchange form (DGLL_EXCHANGE): a rank-stamped pattern -- (global row id, sender rank) per row --
+        travels through the very code path of the halo exchange, on the communication stream, to every peer and back (the
+        transposed direction), and is checked value by value; the watchdog turns a hang into an exit with the phase name."""
         if not dist.is_initialized() or self.part.world == 1:
             return
         p = self.part
@@ -697,6 +801,40 @@ class DistGraph:
             if row[p.world + p.rank] != p.send_counts[q]:
                 raise RuntimeError("halo exchange lists disagree: rank %d sends %d rows to rank %d, which expects %d "
                                    "(the ranks did not build the same graph)" % (p.rank, p.send_counts[q], q, row[p.world + p.rank]))
+        self.self_test()
+
+    def self_test(self):
+        p, ex = self.part, self.exchange
+        dev = self.device
+        owner = torch.repeat_interleave(torch.arange(p.world, device=dev), torch.tensor(p.recv_counts, device=dev))
+        dest = torch.repeat_interleave(torch.arange(p.world, device=dev), torch.tensor(p.send_counts, device=dev))
+        sent_ids = p.send_idx.to(dev) + p.own_begin
+        phase, ex.phase = ex.phase, "start-up self-test (%s)" % ex.form
+        try:
+            # forward direction: owners -> halo slots
+            send = torch.stack([sent_ids, torch.full_like(sent_ids, p.rank)], dim=1).contiguous()
+            recv = torch.full((p.n_halo, 2), -1, dtype=torch.int64, device=dev)
+            with self.comm_scope():
+                ex.wait(ex.start(send, recv))
+            self.join_comm()
+            want = torch.stack([p.halo_ids.to(dev), owner], dim=1)
+            # transposed direction: halo slots -> owners
+            back = torch.full((int(p.send_idx.numel()), 2), -1, dtype=torch.int64, device=dev)
+            with self.comm_scope():
+                ex.wait(ex.start(torch.stack([p.halo_ids.to(dev), torch.full_like(owner, p.rank)], dim=1).contiguous(), back, reverse=True))
+            self.join_comm()
+            want_back = torch.stack([sent_ids, dest], dim=1)
+            if dev.type == "cuda":
+                with ex.watchdog.guard(ex.phase + ": synchronize"):
+                    torch.cuda.current_stream(dev).synchronize()
+            bad = int((recv != want).any(dim=1).sum()), int((back != want_back).any(dim=1).sum())
+        finally:
+            ex.phase = phase
+        if bad[0] or bad[1]:
+            raise RuntimeError("rank %d: the '%s' exchange delivered %d of %d halo rows and %d of %d returned rows wrong in the start-up "
+                               "self-test (set DGLL_EXCHANGE=%s to try the other form)" % (
+                                   p.rank, ex.form, bad[0], p.n_halo, bad[1], int(p.send_idx.numel()), "alltoall" if ex.form == "p2p" else "p2p"))
+        ex.bytes_sent = ex.bytes_received = ex.calls = 0
 
     # ---- helpers used by DistAggregate
     def _ld(self, feat, dtype):
@@ -777,7 +915,22 @@ class DistGraph:
 
     def join_comm(self):
         if self.comm_stream is not None:
-            torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
+            cur = torch.cuda.current_stream(self.device)
+            if self.wait_events is not None:      # bench: how long the compute stream sits in this wait = the EXPOSED exchange time
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(cur)
+                cur.wait_stream(self.comm_stream)
+                b.record(cur)
+                self.wait_events.append((a, b))
+            else:
+                cur.wait_stream(self.comm_stream)
+
+    def exposed_wait_ms(self):
+        """Sum of the compute stream's stalls in join_comm() since `wait_events = []` was set (synchronises)."""
+        if not self.wait_events:
+            return 0.0
+        torch.cuda.current_stream(self.device).synchronize()
+        return float(sum(a.elapsed_time(b) for a, b in self.wait_events))
 
     # ---- layer-level API
     def aggregate(self, h_own, reduce="mean"):

@@ -194,6 +194,7 @@ class MiniBatchPipeline:
         self.load_stream = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None   # d_stream
         self._thread = None
         self._error = None
+        self.load_seconds, self.load_batches = 0.0, 0
 
     # ---- producer stage 1: sampling (buffer_queues.py:22-46) ---------------------------------------------------
     def _sample(self):
@@ -274,7 +275,9 @@ class MiniBatchPipeline:
             done.record(self.load_stream)
         if self._ring is not None:
             self._ring.release(getattr(sg, "buffer_token", None), done)
-        sg.src_device = ids
+        # the pinned buffer goes back to the ring: from here on the subgraph holds its source ids ON THE DEVICE (src_nodes()) and no
+        # per-edge destination list (the structure is in sg.indptr)
+        sg._finish, sg._src, sg._dst, sg.pending_positions = None, ids, None, None
         return ids
 
     # ---- producer stage 2: feature loading --------------------------------------------------------------------
@@ -284,6 +287,7 @@ class MiniBatchPipeline:
                 item = self.sampled.get()
                 if item is _DONE:
                     break
+                t_load = time.perf_counter()
                 b = Batch()
                 b.step, b.input_nodes, b.output_nodes, b.subgraphs = item
                 if self.hops == "sampled":
@@ -321,6 +325,8 @@ class MiniBatchPipeline:
                     b.features = self._fetch_many(id_lists)
                     if self.labels is not None:
                         b.labels = self.labels[outp]
+                self.load_seconds += time.perf_counter() - t_load     # this thread's host time per batch (diagnostics)
+                self.load_batches += 1
                 self.queue.put(b)                                   # blocks while the queue is full
         except BaseException as exc:  # noqa: BLE001
             self._error = exc

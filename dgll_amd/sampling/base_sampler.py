@@ -59,7 +59,7 @@ class sugbraph():
         return self._src.shape[0]
 
     def num_dst_nodes(self):
-        return self._dst.shape[0]
+        return self._src.shape[0] if self._dst is None else self._dst.shape[0]
 
     def get_features(self, g, subgs):
         unique_nodes = torch.unique(torch.cat([subg.nodes() for subg in subgs]))

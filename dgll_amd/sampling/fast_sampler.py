@@ -101,6 +101,8 @@ class FastNeighborSampler(Base_sampler):
 
         sg = sugbraph(torch.from_numpy(src), torch.from_numpy(dst), torch.from_numpy(ptr), finish=finish)
         sg.max_degree = None if fanout is None else int(fanout)      # lets to_block() skip the long-row scan (host-only plan)
+        if finish is not None:        # what a device-side translation needs instead (MiniBatchPipeline(device_graph=...))
+            sg.pending_positions = (torch.from_numpy(seeds), torch.from_numpy(counts))
         return sg
 
     def sample_seeded(self, g, seed_nodes, seed, max_threads=1, last_hop_buffer=None):

@@ -51,7 +51,7 @@ def _dom(frag, ms=5.0, b_alg=65.6e9):
             "kernel_fragment": frag}
 
 
-def test_frac_has_one_definition_and_stale_traffic_is_refused(bench, tmp_path):
+def test_frac_is_unconditionally_the_algorithmic_fraction_and_stale_traffic_is_refused(bench, tmp_path):
     frag = "spmm_csr_kernel<unsigned short, unsigned short, 8, 32, true, 4, true, false>"
     sig = {"workload": "sage", "nodes": 1, "nnz": 2, "locality": 0.9, "permuted_ids": True, "reorder": "lpa", "hidden": 256, "dtype": "bf16"}
     entry = {"workload": dict(sig), "kernel_fragment": frag, "build_stamp": "stamp-A", "hbm_bytes_per_launch": 31.4e9, "round": "r03",
@@ -59,14 +59,15 @@ def test_frac_has_one_definition_and_stale_traffic_is_refused(bench, tmp_path):
     with open(tmp_path / "profiles" / "traffic.json", "w") as f:
         json.dump({"entries": [entry]}, f)
     rec = bench.roofline_record(_dom(frag), sig, "k", 3.5e9, world=1)
-    # counter traffic / live time / peak -- and the formula's value next to it
-    assert rec["traffic"] == 31.4e9 and abs(rec["frac"] - 31.4e9 / 5e-3 / 1e9 / 8000.0) < 1e-12
-    assert rec["frac"] == rec["frac_hbm_counters"] and "counter" in rec["frac_definition"]
-    assert abs(rec["frac_algorithmic"] - 65.6e9 / 5e-3 / 1e9 / 8000.0) < 1e-12 and rec["achieved"] == rec["frac_algorithmic"] * 8000.0
-    # another build of the library: the entry must not be used
+    # `frac` is achieved / peak with the section-8(d) algorithmic bytes -- UNCONDITIONALLY; the counter-based reading has its own name
+    assert abs(rec["frac"] - 65.6e9 / 5e-3 / 1e9 / 8000.0) < 1e-12 and rec["frac"] == rec["frac_algorithmic"] == rec["achieved"] / rec["peak"]
+    assert rec["traffic"] == 31.4e9 and abs(rec["frac_l2_miss_path"] - 31.4e9 / 5e-3 / 1e9 / 8000.0) < 1e-12
+    assert "algorithmic" in rec["frac_definition"] and "Infinity-Cache" in rec["frac_l2_miss_path_definition"]
+    # another build of the library: the entry must not be used -- and `frac` does not change its meaning
     bench.build_stamp = lambda: "stamp-B"
-    rec = bench.roofline_record(_dom(frag), sig, "k", 3.5e9, world=1)
-    assert rec["traffic"] is None and rec["frac"] == rec["frac_algorithmic"] and "formula" in rec["frac_definition"]
+    rec2 = bench.roofline_record(_dom(frag), sig, "k", 3.5e9, world=1)
+    assert rec2["traffic"] is None and rec2["frac_l2_miss_path"] is None
+    assert rec2["frac"] == rec["frac"] and rec2["frac_definition"] == rec["frac_definition"]
     bench.build_stamp = lambda: "stamp-A"
     # another workload / another kernel: no match either; multi-rank runs never take counter traffic
     assert bench.roofline_record(_dom(frag), dict(sig, nnz=3), "k", 0, world=1)["traffic"] is None
@@ -107,3 +108,19 @@ def test_pmc_parse_applies_the_ratios_calibrated_in_the_same_pass(tmp_path):
     assert "FETCH_SIZE reports 0.500 of the known read, WRITE_SIZE 1.000" in res.stdout
     # 100 KiB / 0.5 + 40 KiB / 1.0 = 240 KiB = 0.00 GB: check through the printed per-launch line
     assert "fetch 100 KiB write 40 KiB" in res.stdout
+
+
+def test_compact_record_keeps_the_contract_fields_of_a_child_run(bench):
+    full = {"metric": "m", "value": 2.5e10, "unit": "edges/s", "ms_per_step": 30.0, "steps": 10, "warmup": 3, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "config 4 ...", "nodes": 5, "nnz": 7, "heads": 8, "hidden": 256},
+            "roofline": {"bound": "hbm", "achieved": 11000.0, "peak": 8000.0, "unit": "GB/s", "frac": 1.375, "traffic": None,
+                         "frac_definition": "d", "frac_l2_miss_path": None, "kernel": "gat2", "kernel_fragment": "f", "avg_launch_ms": 6.3,
+                         "launches_timed": 10, "compulsory_bytes_per_launch": 1},
+            "cpu_baseline": {"value": 2e5, "unit": "edges/s", "cores": 256, "kind": "port", "sample": "s", "seconds_per_run": {}},
+            "gat_pass_over_spmm": {"fwd": 1.2}, "spmm_launch_table": {"gat fwd": {"avg_ms": 5.5, "count": 10}}, "dense_launch_table": {}}
+    c = bench.compact_record(full)
+    assert c["value"] == 2.5e10 and c["ms_per_step"] == 30.0 and c["workload"] == "config 4 ..."
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(c["roofline"]) and "launches_timed" not in c["roofline"]
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(c["cpu_baseline"]) and "seconds_per_run" not in c["cpu_baseline"]
+    assert c["gat_pass_over_spmm"] == {"fwd": 1.2} and c["gather_launch_ms"] == {"gat fwd": 5.5} and c["config"]["heads"] == 8
+    assert "dense_launch_table" not in c and "spmm_launch_table" not in c

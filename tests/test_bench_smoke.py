@@ -150,8 +150,11 @@ def test_bench_minibatch_and_rmat_workloads(fused):
     d = _last_json(res.stdout)
     assert d["config"]["workload_id"] == "minibatch" and d["steps"] == 64 and d["warmup"] == 8
     assert d["config"]["outermost_hop"].startswith("reduced" if fused else "fetched")
-    for key in ("gpu_side_ms_per_batch", "host_sampler_ms_per_batch", "cache_miss_rate", "batches_per_s", "roofline"):
+    for key in ("gpu_side_ms_per_batch", "gpu_side_ms_per_batch_p50", "gpu_side_ms_per_batch_p95", "host_sampler_ms_per_batch",
+                "host_sampler_threads", "sampler_mode", "consumer_host_ms_per_batch", "loader_host_ms_per_batch", "cache_miss_rate",
+                "batches_per_s", "roofline"):
         assert key in d, key
+    assert d["host_sampler_threads"] >= 1 and "per-batch seeds" in d["sampler_mode"]
     assert 0.0 < d["cache_miss_rate"] < 1.0 and d["loss"] == d["loss"]
     prev = getattr(test_bench_minibatch_and_rmat_workloads, "loss", None)
     if prev is not None:
@@ -163,3 +166,43 @@ def test_bench_minibatch_and_rmat_workloads(fused):
         assert res.returncode == 0, res.stderr[-3000:]
         r = _last_json(res.stdout)
         assert r["config"]["workload_id"] == "rmat27" and r["roofline"]["bound"] == "hbm" and r["value"] > 0
+
+
+def test_bench_minibatch_single_stream_mode_still_runs():
+    """--mb-sampler-threads 0: ONE sequential sampler stream on the interpreter's generator (the default-compatible mode of rounds
+    1-3), host-side translation of the outermost hop."""
+    shape = ["--workload", "minibatch", "--mb-nodes", "20000", "--mb-undirected-edges", "400000", "--mb-feats", "50", "--mb-classes", "7",
+             "--mb-batch", "64", "--mb-fanouts", "5,3,3", "--hidden", "64", "--no-cpu-baseline", "--mb-sampler-threads", "0", "--mb-host-translate"]
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + shape, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    d = _last_json(res.stdout)
+    assert d["host_sampler_threads"] == 0 and "sequential" in d["sampler_mode"] and d["outermost_hop_translation"] == "host"
+    assert d["loss"] == d["loss"] and d["steps"] == 64
+
+
+def test_default_line_carries_the_other_baseline_configs():
+    """`bench.py` (what the driver runs) appends `other_workloads` = compact records of configs 4, 2 and 5, each measured by a child
+    run; here at small shapes (DGLL_BENCH_OTHER_ARGS) with --other-workloads on."""
+    other = {
+        "gat": ["--nodes", "20000", "--undirected-edges", "200000", "--hidden", "64", "--heads", "8", "--classes", "10", "--in-feats", "40",
+                "--steps", "2", "--warmup", "1", "--cpu-sample-rows", "2000", "--no-extra-graphs"],
+        "minibatch": ["--mb-nodes", "20000", "--mb-undirected-edges", "400000", "--mb-feats", "50", "--mb-classes", "7", "--mb-batch", "64",
+                      "--mb-fanouts", "5,3,3", "--hidden", "64"],
+        "rmat27": ["--scale", "16", "--steps", "2", "--warmup", "1", "--cpu-sample-rows", "2000"],
+    }
+    env = dict(os.environ, DGLL_BENCH_OTHER_ARGS=json.dumps(other))
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--other-workloads", "on", "--no-extra-graphs"] + SHAPE,
+                         capture_output=True, text=True, timeout=1500, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    d = _last_json(res.stdout)
+    ow = d["other_workloads"]
+    assert set(ow) == {"gat", "minibatch", "rmat27"}
+    for name, rec in ow.items():
+        assert "error" not in rec, (name, rec)
+        assert rec["value"] > 0 and rec["ms_per_step"] > 0 and rec["wall_seconds"] > 0 and rec["command"].startswith("python bench.py --workload " + name)
+        assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(rec["roofline"]) and rec["roofline"]["frac"] == rec["roofline"]["achieved"] / rec["roofline"]["peak"]
+        assert set(("value", "unit", "cores", "kind", "sample")) <= set(rec["cpu_baseline"]) and rec["cpu_baseline"]["kind"] == "port"
+    assert "gat_pass_over_spmm" not in ow["gat"] and ow["minibatch"]["batches_per_s"] > 0       # --no-extra-graphs: no SpMM comparison leg
+    # the small-shape headline alone does not start them
+    assert "other_workloads" not in _last_json(subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-extra-graphs"] + SHAPE,
+                                                              capture_output=True, text=True, timeout=600).stdout)

@@ -194,6 +194,63 @@ def test_outermost_hop_reduced_out_of_the_cache_equals_fetch_then_reduce(reddit_
 
 
 @pytest.mark.gpu
+def test_per_batch_seeded_sampler_threads_with_device_translation_are_bit_equal_per_batch(reddit_batch):
+    """The multi-threaded mode at the Reddit shape: MiniBatchPipeline(sampler_threads=4, hops="sampled", device_graph=...) -- four
+    native sampler threads each draw whole batches under batch_seed(base, epoch, b); the outermost hop (2.5 M neighbours) leaves
+    the host as POSITIONS in pinned memory and becomes ids by a device gather.  Every batch, in order: ids bit-equal to
+    oracle/sampler.py (the reference loop) run right after random.seed(batch_seed(...)); fetched rows == features[ids]; the
+    outermost hop's mean out of the cache equals the reduction of the oracle's ids; the global generator is untouched."""
+    from dgll_amd.dataloader import DataLoader
+    from dgll_amd.pipeline import MiniBatchPipeline
+    from dgll_amd.sampling import FastNeighborSampler
+    from dgll_amd.sampling.fast_sampler import batch_seed
+    from oracle import cref, sampler as osampler
+
+    r = reddit_batch
+    dev, dg = r["dev"], r["dg"]
+    L = len(FANOUTS)
+    n_batches = 5
+    train = torch.randperm(N, generator=torch.Generator().manual_seed(9))[:n_batches * BATCH - 100]     # ragged last batch
+    indptr = torch.from_numpy(np.ascontiguousarray(dg.edges.indptr, dtype=np.int64)).to(dev)
+    indices = torch.from_numpy(np.ascontiguousarray(dg.edges.indices, dtype=np.int64)).to(dev)
+    loader = DataLoader(dg, train, FastNeighborSampler(FANOUTS, defer_last_hop=True), batch_size=BATCH)
+    pipe = MiniBatchPipeline(loader, cache=r["cache"], labels=r["labels"], queue_size=4, device=dev, hops="sampled",
+                             reduce_last_hop="mean", sampler_threads=4, base_seed=3, epoch=1, device_graph=(indptr, indices))
+    random.seed(77)
+    before = random.getstate()
+    seen = 0
+    for b in pipe:
+        i = b.step
+        assert i == seen
+        seeds = train[i * BATCH:(i + 1) * BATCH]
+        state = random.getstate()
+        random.seed(batch_seed(3, 1, i))
+        inp, outp, layers = osampler.sample(dg.edges, seeds.tolist(), FANOUTS)
+        random.setstate(state)
+        assert b.output_nodes.tolist() == outp
+        assert b.input_nodes.is_cuda and torch.equal(b.input_nodes.cpu(), torch.tensor(inp, dtype=torch.int64))   # translated on the device
+        for sg, (src, dst) in zip(b.subgraphs[1:], layers[1:]):                      # inner hops: host ids, both endpoints
+            assert torch.equal(sg.src_nodes(), torch.tensor(src, dtype=torch.int64))
+            assert torch.equal(sg.dst_nodes(), torch.tensor(dst, dtype=torch.int64))
+        assert int(b.subgraphs[0].indptr[-1]) == len(inp)
+        assert b.subgraphs[0].src_nodes() is b.input_nodes and b.subgraphs[0].num_src_nodes() == len(inp)
+        hop = [outp] + [layers[L - 1 - h][0] for h in range(L - 1)]
+        for ids, got in zip(hop, b.features[:-1]):
+            assert torch.equal(got.cpu(), r["feats"][torch.tensor(ids)])
+        assert b.features[-1] is None
+        if i in (0, n_batches - 1):
+            ptr = b.subgraphs[0].indptr.numpy()
+            rows = r["feats"][torch.tensor(inp)].float().numpy()
+            ref = torch.from_numpy(cref.spmm_csr(ptr, np.arange(len(inp), dtype=np.int32), None, rows, reduce="mean")).to(torch.bfloat16)
+            red = b.last_hop_reduced.cpu()
+            assert float((red == ref).float().mean()) >= 0.999
+        assert torch.equal(b.labels.cpu(), r["labels"][seeds])
+        seen += 1
+    assert seen == n_batches and random.getstate() == before
+    r["cache"].get_miss_rate()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("storage", ["bf16", "fp32"])
 def test_gradients_match_cpu_autograd_of_the_oracle(reddit_batch, storage):
     """Forward and backward (input-feature and parameter gradients) vs CPU autograd of oracle/torch_ref.sage_block, at the

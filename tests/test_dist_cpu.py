@@ -31,8 +31,8 @@ def _cpu_spmm(graph, x, val=None, reduce="sum"):
     return y
 
 
-def _worker(rank, world, port, weighted, feat):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+def _worker(rank, world, port, weighted, feat, form="p2p"):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), DGLL_EXCHANGE=form)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from dgll_amd import dist as ddist
@@ -55,7 +55,9 @@ def _worker(rank, world, port, weighted, feat):
         assert part.local.n_rows == part.halo.n_rows == part.n_own and part.local.nnz + part.halo.nnz == part.nnz
         assert sum(part.recv_counts) == part.n_halo and part.recv_counts[rank] == 0
         engine = ddist.DistGraph(part, "cpu", spmm_fn=_cpu_spmm)
-        engine.verify()
+        assert engine.exchange.form == form
+        engine.verify()                      # exchange lists + the start-up self-test through the chosen form, both directions
+        assert engine.exchange.calls == 0    # the self-test leaves the traffic counters at zero
         blk = slice(part.own_begin, part.own_end)
         h = engine.permute_to_local(x[blk]).clone().requires_grad_()
         out = engine.aggregate(h, reduce="mean")
@@ -121,6 +123,58 @@ def test_racom_async_queue_and_periodic_sync():
 @pytest.mark.parametrize("world,weighted,feat", [(2, False, 12), (2, True, 7), (3, False, 5), (8, False, 6)])
 def test_partitioned_aggregation_matches_single_process(world, weighted, feat):
     mp.spawn(_worker, args=(world, _free_port(), weighted, feat), nprocs=world, join=True)
+
+
+@pytest.mark.parametrize("world,feat", [(2, 9), (8, 6)])
+def test_alltoall_exchange_form_gives_the_same_results(world, feat):
+    """DGLL_EXCHANGE=alltoall: the same packed buffers through one all-to-all-v collective (the fallback for a grouped p2p form
+    that misbehaves on first contact with RCCL): self-test, forward, transposed exchange and static placement all pass unchanged."""
+    mp.spawn(_worker, args=(world, _free_port(), False, feat, "alltoall"), nprocs=world, join=True)
+
+
+def _bad_lists_worker(rank, world, port):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dgll_amd import dist as ddist
+        from dgll_amd import synth
+
+        full = synth.rmat_graph(7, 6, seed=2, device="cpu", symmetric=True, weighted=False)
+        part = ddist.partition_contiguous(full, world, rank)
+        engine = ddist.DistGraph(part, "cpu", spmm_fn=_cpu_spmm)
+        # a transport that delivers the right NUMBER of rows but the wrong rows (here: every rank rotates what it sends)
+        part.send_idx = torch.roll(part.send_idx, 1)
+        with pytest.raises(RuntimeError, match="self-test"):
+            engine.verify()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_start_up_self_test_catches_rows_that_arrive_in_the_wrong_place():
+    mp.spawn(_bad_lists_worker, args=(2, _free_port()), nprocs=2, join=True)
+
+
+def test_exchange_watchdog_reports_the_phase_of_an_exchange_that_never_completes():
+    """The watchdog's own logic, without killing the test process: a pending item that never completes triggers on_timeout with
+    its phase name; completed ones do not; DGLL_EXCHANGE rejects unknown forms."""
+    import time
+
+    from dgll_amd import dist as ddist
+
+    wd = ddist.ExchangeWatchdog(timeout=0.2, rank=5)
+    fired = []
+    wd.on_timeout = lambda phase, age: fired.append((phase, age))
+    with wd.guard("quick phase"):
+        pass
+    state = {"done": False}
+    wd._ensure_thread()
+    with wd._lock:
+        wd._pending.append(("layer-3 halo exchange", lambda: state["done"], time.monotonic()))
+    time.sleep(0.8)
+    assert [f[0] for f in fired] == ["layer-3 halo exchange"] and fired[0][1] > 0.2
+    part = ddist.Partition()
+    with pytest.raises(ValueError):
+        ddist._Exchange(part, form="ring")
 
 
 def test_partition_covers_every_edge_once():

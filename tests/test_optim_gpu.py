@@ -59,7 +59,7 @@ def test_full_graph_sage_step_through_flat_adam(cuda_device, monkeypatch):
     losses = {}
     for kind in ("torch", "flat"):
         torch.manual_seed(5)
-        model = dnn.GraphSage(40, [64, 64, 10], None).to(cuda_device)
+        model = dnn.GraphSage(40, [256, 256, 10], None).to(cuda_device)
         opt = torch.optim.Adam(model.parameters(), lr=1e-2) if kind == "torch" else FlatAdam(model.parameters(), lr=1e-2)
         packs = []
         real = dense._pack_now
