@@ -105,6 +105,9 @@ def parse_args(argv=None):
                     help="minibatch: K native sampler threads, each drawing whole batches under per-batch seeds (bit-equal to the reference "
                          "loop under random.seed(batch_seed(seed, epoch, b))); 0 = ONE sequential stream on the interpreter's generator "
                          "(rounds 1-3); -1 = min(8, host threads / 4)")
+    ap.add_argument("--mb-loader-blocks-per-cu", type=int, default=4,
+                    help="minibatch: cap of the feature-loading kernels' grids in workgroups per CU (0 = the kernels' own 16 / 32): they "
+                         "run on the loading stream next to the training kernels")
     ap.add_argument("--mb-host-translate", action="store_true",
                     help="minibatch: turn the outermost hop's positions into ids on the host (16 threads) instead of by a device gather")
     ap.add_argument("--scale", type=int, default=27, help="rmat27: RMAT scale (27 = config 5; smaller for a quick run)")
@@ -1020,6 +1023,9 @@ def run_minibatch(args, c):
     n_batches = args.warmup + args.steps
     train = torch.randperm(args.mb_nodes)[:n_batches * args.mb_batch]
 
+    from dgll_amd import _lib as _dl
+
+    _dl.check(_dl.lib.dgll_hip_debug_tune(12, int(args.mb_loader_blocks_per_cu)), "tune")
     k_threads = args.mb_sampler_threads if args.mb_sampler_threads >= 0 else max(1, min(8, (os.cpu_count() or 4) // 4))
     lock = __import__("threading").Lock()
 
@@ -1050,9 +1056,11 @@ def run_minibatch(args, c):
     fuse_last = not args.mb_no_fused_last_hop
     pipe = MiniBatchPipeline(loader, cache=cache, labels=labels, queue_size=4, device=c.dev, hops="sampled",
                              reduce_last_hop="mean" if fuse_last else None, sampler_threads=k_threads, base_seed=args.seed, epoch=0,
-                             device_graph=device_graph)
+                             device_graph=device_graph, build_blocks=True)
     model = dnn.GraphSage(args.mb_feats, [args.hidden] * (L - 1) + [args.mb_classes], fanouts).to(c.dev)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    from dgll_amd.optim import FlatAdam
+
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3) if args.torch_adam else FlatAdam(list(model.parameters()), lr=1e-3)
     random.seed(args.seed)
     timer_cm = ops.LaunchTimer()
     done = edges = 0
@@ -1067,7 +1075,14 @@ def run_minibatch(args, c):
     stream_ctx = torch.cuda.stream(compute)
     stream_ctx.__enter__()
     cpu_busy = 0.0
+    prof = None
+    if os.environ.get("DGLL_MB_PROFILE"):      # diagnostics: where the consumer thread's host time goes (cProfile, printed to stderr)
+        import cProfile
+
+        prof = cProfile.Profile()
     for b in pipe:
+        if prof is not None and done == args.warmup:
+            prof.enable()
         if done == args.warmup:
             torch.cuda.synchronize()
             timer_cm.__enter__()
@@ -1077,7 +1092,9 @@ def run_minibatch(args, c):
         t_body = time.perf_counter()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-        blocks = [b.subgraphs[L - 1 - h].to_block(c.dev) for h in range(L)]
+        blocks = b.blocks          # built by the loading stage on its own stream (the outermost one is None: reduced out of the cache)
+        if blocks[L - 1] is None and b.last_hop_reduced is None:
+            blocks[L - 1] = b.subgraphs[0].to_block(c.dev)
         out = model.forward_sampled(b.features, blocks, last_hop_reduced=b.last_hop_reduced)
         loss = ops.cross_entropy(out, b.labels)
         opt.zero_grad(set_to_none=True)
@@ -1093,6 +1110,11 @@ def run_minibatch(args, c):
         cpu_busy += time.perf_counter() - t_body
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if prof is not None:
+        import pstats
+
+        prof.disable()
+        pstats.Stats(prof, stream=sys.stderr).sort_stats("cumulative").print_stats(45)
     stream_ctx.__exit__(None, None, None)
     timer_cm.__exit__(None, None, None)
     sampler_s = TimedSampler.seconds - s0

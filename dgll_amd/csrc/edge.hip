@@ -393,6 +393,17 @@ __global__ __launch_bounds__(kBlock) void gat_long_finalize_kernel(const EdgeArg
             } else {
                 my_head = head; my_den = den; my_max = M;
             }
+        } else if (kind == 1 && a.exact_dd) {
+            // rows pass, exact dd: the chunks carry (sa, sb, sw); ds_i = sa + dd_i * sb with dd_i = -sw / den_i (gat_kernel.hpp)
+            if (!vec) {
+                float sa = 0.0f, sb = 0.0f, sw = 0.0f;
+                for (int c = cb; c < ce; ++c) {
+                    const float* w = a.ws + (int64_t)c * a.ws_ld + a.ws_vec;
+                    sa += w[head]; sb += w[a.heads + head]; sw += w[2 * a.heads + head];
+                }
+                const float dd = -sw / a.DEN[row * a.heads + head];
+                my_head = head; my_den = sa + dd * sb; my_max = dd;
+            }
         } else {
             float sacc = 0.0f;
             for (int c = cb; c < ce; ++c) sacc += a.ws[(int64_t)c * a.ws_ld + off];
@@ -407,7 +418,7 @@ __global__ __launch_bounds__(kBlock) void gat_long_finalize_kernel(const EdgeArg
                 }
             } else {
                 my_head = head;
-                my_den = ((kind == 1 && a.accumulate) ? a.out_a[row * a.heads + head] : 0.0f) + sacc;
+                my_den = ((kind == 1 && a.accumulate == 1) ? a.out_a[row * a.heads + head] : 0.0f) + sacc;
             }
         }
     }
@@ -415,6 +426,13 @@ __global__ __launch_bounds__(kBlock) void gat_long_finalize_kernel(const EdgeArg
     if (my_head >= 0) {
         a.out_a[row * a.heads + my_head] = my_den;
         if (kind == 0 && a.out_b) a.out_b[row * a.heads + my_head] = my_max;
+        if (kind == 1 && a.exact_dd) {
+            if (a.out_b) a.out_b[row * a.heads + my_head] = my_max;          // dd_i
+            if (a.sd_out) {
+                a.sd_out[row * a.sd_stride + my_head] = a.S[row * a.heads + my_head];
+                a.sd_out[row * a.sd_stride + a.heads + my_head] = my_max;
+            }
+        }
     }
 }
 
@@ -444,10 +462,18 @@ __global__ __launch_bounds__(kBlock) void gat_long_finalize_wave_kernel(const Ed
             }
             if (a.accumulate) den += a.out_a[row * a.heads + lane];
             h_max = M; h_den = den;
+        } else if (kind == 1 && a.exact_dd) {
+            float sa = 0.0f, sb = 0.0f, sw = 0.0f;
+            for (int c = cb; c < ce; ++c) {
+                const float* w = a.ws + (int64_t)c * a.ws_ld + a.ws_vec;
+                sa += w[lane]; sb += w[a.heads + lane]; sw += w[2 * a.heads + lane];
+            }
+            h_max = -sw / a.DEN[row * a.heads + lane];                         // dd_i
+            h_den = sa + h_max * sb;                                           // ds_i
         } else {
             float sacc = 0.0f;
             for (int c = cb; c < ce; ++c) sacc += a.ws[(int64_t)c * a.ws_ld + a.ws_vec + lane];
-            h_den = ((kind == 1 && a.accumulate) ? a.out_a[row * a.heads + lane] : 0.0f) + sacc;
+            h_den = ((kind == 1 && a.accumulate == 1) ? a.out_a[row * a.heads + lane] : 0.0f) + sacc;
         }
     }
     // ---- vector part: four columns per lane (fo is a multiple of 4, so they share a head)
@@ -491,6 +517,13 @@ __global__ __launch_bounds__(kBlock) void gat_long_finalize_wave_kernel(const Ed
     if (lane < a.heads) {
         a.out_a[row * a.heads + lane] = h_den;
         if (kind == 0 && a.out_b) a.out_b[row * a.heads + lane] = h_max;
+        if (kind == 1 && a.exact_dd) {
+            if (a.out_b) a.out_b[row * a.heads + lane] = h_max;              // dd_i
+            if (a.sd_out) {
+                a.sd_out[row * a.sd_stride + lane] = a.S[row * a.heads + lane];
+                a.sd_out[row * a.sd_stride + a.heads + lane] = h_max;
+            }
+        }
     }
 }
 
@@ -656,7 +689,7 @@ DGLL_API int dgll_hip_sddmm_csr(void* stream, const int64_t* rowptr, const int32
 }
 
 static int gat_ws_vec(int heads, int fo) { return (heads * fo + 7) & ~7; }
-static int gat_ws_ld(int heads, int fo) { return (gat_ws_vec(heads, fo) + 2 * heads + 7) & ~7; }
+static int gat_ws_ld(int heads, int fo) { return (gat_ws_vec(heads, fo) + 3 * heads + 7) & ~7; }   // three scalars per head (exact rows pass)
 
 DGLL_API size_t dgll_hip_gat_workspace_bytes(const dgll_csr_plan* plan, int heads, int fo) {
     if (!plan || plan->n_chunks == 0 || heads <= 0 || fo <= 0) return 0;
@@ -829,7 +862,9 @@ DGLL_API int dgll_hip_gat_fwd_strided(void* stream, const dgll_csr_plan* plan, c
                         fo, alpha, apply_elu, 0, workspace, workspace_bytes, 0, 0);
 }
 
-// Pass 1 of the backward (rows of A or of one column-half of A): DN, DD (written unless `accumulate`) and grad_S (+=).
+// Pass 1 of the backward (rows of A or of one column-half of A): DN, DD and grad_S.  accumulate: 0 = the only launch over
+// these rows (second-generation kernels: exact dd_i, gat_kernel.hpp); 2 = first of two launches over column halves of A (writes DN,
+// DD, grad_S); 1 = second of them (grad_S +=).
 static int gat_bwd_rows_impl(void* stream, const dgll_csr_plan* plan, const int64_t* rowptr, const int32_t* col,
                              const void* H, int64_t ldh, const float* S, const float* T, int t_stride, const float* edge_scale,
                              const void* out, int64_t ldo, const void* grad_out, int64_t ldg, int dtype,
@@ -856,11 +891,13 @@ static int gat_bwd_rows_impl(void* stream, const dgll_csr_plan* plan, const int6
     hipStream_t s = static_cast<hipStream_t>(stream);
     int lpr, nh, lph;
     if (gat2_pick(a, &lpr, &nh, &grid.y)) {
+        a.exact_dd = accumulate == 0 ? 1 : 0;      // the only launch over these rows: dd_i from the pass's own dot products
         if (!gat2_launch_1(dtype, lpr, nh, grid, s, a, gat2_inrow(a, lpr, nh, esz, a.T, nullptr))) { set_error("no second-generation GAT kernel for this head layout"); return DGLL_ERR_UNSUPPORTED; }
     } else {
         rc = gat1_pick(a, epv, &lph, &lpr, &grid.y);
         if (rc != DGLL_OK) return rc;
         DGLL_REQUIRE(dd, "the first-generation rows pass writes dd");
+        a.accumulate = accumulate == 1 ? 1 : 0;    // first-generation kernels: dd from the stored output row in every mode
 #define CALL(L)                                                                                                              \
     if (dtype == DGLL_F32) hipLaunchKernelGGL((gat_bwd_rows_kernel<float, 4, L, 2>), grid, dim3(kBlock), 0, s, a, lph);      \
     else hipLaunchKernelGGL((gat_bwd_rows_kernel<bf16_t, 8, L, 2>), grid, dim3(kBlock), 0, s, a, lph);

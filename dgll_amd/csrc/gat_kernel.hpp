@@ -70,7 +70,7 @@ __device__ __forceinline__ float head_sum_c(float v) {
 
 // KIND 0: forward.  KIND 1: backward over the rows of A (DN, DD, grad_S).  KIND 2: backward over the rows of A^T (grad_H, grad_T).
 // See edge.hip for the argument roles of each pass (they are unchanged).  Records (one per edge and head, wave-private LDS):
-//   KIND 0: w_ij            KIND 1: c_ij = w_ij * sign * lrelu'(z_ij)            KIND 2: { w_ij, c_ij } and dd_i * c_ij
+//   KIND 0: w_ij            KIND 1: { w_ij, c_ij = w_ij * sign * lrelu'(z_ij) }            KIND 2: { w_ij, c_ij } and dd_i * c_ij
 // INROW (one head, scores in the padding of the gathered rows themselves): the lane group's first idle lane reads the 16 bytes
 // behind the row's last column WITH the row -- t_j (or {s_i, dd_i} in the transposed pass) arrives with the gather, is broadcast
 // inside the lane group, and the record phase (a dependent load per batch, the LDS hand-over) disappears: for 8-lane rows the
@@ -78,7 +78,7 @@ __device__ __forceinline__ float head_sum_c(float v) {
 template <typename XT, typename YT, int EPV, int LPR, int NH, int U, int KIND, bool INROW = false>
 __global__ __launch_bounds__(kBlock) void gat2_kernel(const EdgeArgs a) {
     typedef VecIO<XT, EPV> IO;
-    typedef typename std::conditional<KIND == 2, float2, float>::type rec_t;   // KIND 2: {w_ij, c_ij}, plus dd_i * c_ij in rec1
+    typedef typename std::conditional<KIND != 0, float2, float>::type rec_t;   // backward passes: {w_ij, c_ij} (KIND 2 also dd_i * c_ij in rec1)
     constexpr int SLOTS = kWave / LPR;
     constexpr int LPH = LPR / NH;                                  // lanes per head
     constexpr bool BF = sizeof(XT) == 2;
@@ -141,6 +141,14 @@ __global__ __launch_bounds__(kBlock) void gat2_kernel(const EdgeArgs a) {
         float g[EPV], o[EPV];
         IO::unpack(col_ok ? IO::load_nt(static_cast<const XT*>(a.G) + row * a.ldg + c0) : IO::zero(), g);   // row-side operands: streamed
         IO::unpack(col_ok ? IO::load_nt(static_cast<const XT*>(a.O) + row * a.ldo + c0) : IO::zero(), o);
+        // dd_i = -DN_i . hp_i  (hp_i = the row's pre-activation output).  EXACT form (a.exact_dd, every single-launch use): hp_i is
+        // never reconstructed -- DN_i . hp_i = sum_j w_ij (DN_i . h_j) / den_i, and the dot products are formed below anyway: the
+        // lanes accumulate  sw = sum_j w_ij * partial_dot_ij  next to  sa = sum_j c_ij * partial_dot_ij  and dd_i falls out in the row
+        // epilogue (long rows: the chunk partials carry (sa, sb, sw) and the finalize kernel combines them -- ds_i is bilinear in
+        // them).  The same bf16 h_j enter dd_i and the transposed pass, so the cancellation in ds_i is exact to fp32 rounding.
+        // LEGACY form (split launches over two column halves of A, a.accumulate = 1 / 2): hp_i recovered from the stored output
+        // row (bf16: rounded to 8 bits; ELU inverted with a logarithm), dd_i known before the gathers.
+        const bool legacy = !a.exact_dd;
         float part = 0.0f;
 #pragma unroll
         for (int i = 0; i < EPV; ++i) {
@@ -149,19 +157,18 @@ __global__ __launch_bounds__(kBlock) void gat2_kernel(const EdgeArgs a) {
                 const float op1 = o[i] + 1.0f;    // saturated ELU (out == -1): gradient 0, and 0 * log(0) must stay 0
                 dhp = g[i] * op1;
                 // bf16 storage: the hardware logarithm (absolute error ~1e-7 on a value rounded to 8 bits anyway); fp32: log1pf
-                hp = op1 > 0.0f ? (BF ? __logf(op1) : log1pf(o[i])) : 0.0f;
+                if (legacy) hp = op1 > 0.0f ? (BF ? __logf(op1) : log1pf(o[i])) : 0.0f;
             }
             dn[i] = dhp * inv_den;
-            // bf16: the dot products below and the transposed pass see DN in storage precision; dd_i = -DN_i . hp_i must be formed
-            // from the SAME rounded values, or the cancellation in ds_i = sum_j c_ij (DN_i . h_j + dd_i) leaves the rounding of DN
-            // un-cancelled (measured: grad_s 8e-3 of float64 on the same operands, tools/gat_grad_precision.py)
+            // bf16: the dot products below and the transposed pass see DN in storage precision; whatever is formed from DN here must
+            // use the SAME rounded values, or the cancellation in ds_i = sum_j c_ij (DN_i . h_j + dd_i) leaves DN's rounding standing
             if constexpr (BF) dn[i] = bf16_to_f32(f32_to_bf16(dn[i]));
             part = fmaf(dn[i], hp, part);
         }
-        dd = -head_sum_c<LPH>(part);
-        if (slot == 0 && col_ok && it.first && !a.accumulate) {   // per-row outputs: written once (row itself / first chunk, first launch)
+        if (legacy) dd = -head_sum_c<LPH>(part);
+        if (slot == 0 && col_ok && it.first && a.accumulate != 1) {   // per-row outputs: written once (row itself / first chunk, first launch)
             VecIO<XT, EPV>::store_nt(static_cast<XT*>(a.Y) + row * a.ldy + c0, dn);
-            if (hs == 0) {
+            if (hs == 0 && legacy) {
                 if (a.out_b) a.out_b[row * a.heads + head] = dd;
                 if (a.sd_out) {   // {s_i, dd_i} side by side where the transposed pass gathers them with ONE line fill per edge
                     a.sd_out[row * a.sd_stride + head] = a.S[row * a.heads + head];
@@ -186,6 +193,7 @@ __global__ __launch_bounds__(kBlock) void gat2_kernel(const EdgeArgs a) {
 #pragma unroll
     for (int i = 0; i < EPV; ++i) acc[i] = 0.0f;
     float sa = 0.0f, sb = 0.0f;        // KIND 0: sb = denominator.  KIND 1/2: sa = sum c * partial dot, sb = sum c (or dd * c)
+    float sw = 0.0f;                   // KIND 1: sum w * partial dot (the exact dd_i)
 
     int col_cur = col_first;
     for (int64_t k0 = b; k0 < e; k0 += kWave) {
@@ -210,7 +218,7 @@ __global__ __launch_bounds__(kBlock) void gat2_kernel(const EdgeArgs a) {
                 w = (live && h0 + k < a.heads) ? w : 0.0f;
                 const float cc = w * a.sign * (z > 0.0f ? 1.0f : a.alpha);
                 if constexpr (KIND == 0) rec[k * kRecStride + lane] = w;
-                if constexpr (KIND == 1) rec[k * kRecStride + lane] = cc;
+                if constexpr (KIND == 1) rec[k * kRecStride + lane] = make_float2(w, cc);
                 if constexpr (KIND == 2) { rec[k * kRecStride + lane] = make_float2(w, cc); rec1[k * kRecStride + lane] = dv[k] * cc; }
             }
         }
@@ -243,7 +251,7 @@ __global__ __launch_bounds__(kBlock) void gat2_kernel(const EdgeArgs a) {
                     w = (j + u * SLOTS + slot < nb) ? w : 0.0f;
                     const float cc = w * a.sign * (z > 0.0f ? 1.0f : a.alpha);
                     if constexpr (KIND == 0) rr[u] = w;
-                    if constexpr (KIND == 1) rr[u] = cc;
+                    if constexpr (KIND == 1) rr[u] = make_float2(w, cc);
                     if constexpr (KIND == 2) {
                         rr[u] = make_float2(w, cc);
                         r1[u] = __shfl(__uint_as_float(v[u].y), tlane) * cc;    // dd_i sits next to s_i
@@ -274,8 +282,9 @@ __global__ __launch_bounds__(kBlock) void gat2_kernel(const EdgeArgs a) {
                             for (int i = 0; i < EPV; ++i) dot = fmaf(dn[i], f[i], dot);
                         }
                         if constexpr (INROW) dot = col_ok ? dot : 0.0f;   // the score lane holds score bits, not features: 0 x NaN
-                        sa = fmaf(dot, rr[u], sa);
-                        sb += rr[u];
+                        sa = fmaf(dot, rr[u].y, sa);
+                        sb += rr[u].y;
+                        sw = fmaf(dot, rr[u].x, sw);
                     } else {
                         float f[EPV];
                         IO::unpack(v[u], f);
@@ -339,10 +348,29 @@ __global__ __launch_bounds__(kBlock) void gat2_kernel(const EdgeArgs a) {
         }
     }
     if constexpr (KIND == 1) {
-        const float ds = head_sum_c<LPH>(slot_sum<LPR>(sa)) + dd * slot_sum<LPR>(sb);
-        if (slot == 0 && col_ok && hs == 0) {
-            if (it.chunk >= 0) a.ws[it.chunk * a.ws_ld + a.ws_vec + head] = ds;
-            else a.out_a[row * a.heads + head] = (a.accumulate ? a.out_a[row * a.heads + head] : 0.0f) + ds;
+        const float sa_t = head_sum_c<LPH>(slot_sum<LPR>(sa)), sb_t = slot_sum<LPR>(sb);
+        if (a.exact_dd) {
+            const float sw_t = head_sum_c<LPH>(slot_sum<LPR>(sw));
+            if (slot == 0 && col_ok && hs == 0) {
+                if (it.chunk >= 0) {          // bilinear in the partial sums: the finalize kernel combines (sa, sb, sw) of the chunks
+                    float* wsp = a.ws + it.chunk * a.ws_ld + a.ws_vec;
+                    wsp[head] = sa_t; wsp[a.heads + head] = sb_t; wsp[2 * a.heads + head] = sw_t;
+                } else {
+                    const float dd_x = -sw_t / a.DEN[row * a.heads + head];
+                    a.out_a[row * a.heads + head] = sa_t + dd_x * sb_t;
+                    if (a.out_b) a.out_b[row * a.heads + head] = dd_x;
+                    if (a.sd_out) {
+                        a.sd_out[row * a.sd_stride + head] = a.S[row * a.heads + head];
+                        a.sd_out[row * a.sd_stride + a.heads + head] = dd_x;
+                    }
+                }
+            }
+        } else {
+            const float ds = sa_t + dd * sb_t;
+            if (slot == 0 && col_ok && hs == 0) {
+                if (it.chunk >= 0) a.ws[it.chunk * a.ws_ld + a.ws_vec + head] = ds;
+                else a.out_a[row * a.heads + head] = (a.accumulate == 1 ? a.out_a[row * a.heads + head] : 0.0f) + ds;
+            }
         }
     }
     if constexpr (KIND == 2) {

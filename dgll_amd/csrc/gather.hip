@@ -161,6 +161,11 @@ static int gather_rows_impl(void* stream, const void* cache, int64_t ldc, const 
                             const int64_t* idx, const int64_t* slot, void* out, int64_t ldo, int64_t n, int feat,
                             int dtype, unsigned long long* miss_count, const int64_t* host_map);
 
+// dgll_hip_debug_tune(12, n): cap the grids of the feature-loading kernels below at n workgroups per CU (0 = their defaults, 16 and
+// 32).  They are grid-stride loops issued on a mini-batch pipeline's LOADING stream next to the training kernels: a smaller
+// grid leaves wavefront slots of every CU to the compute stream instead of filling the chip.
+int g_tune_loader_blocks_per_cu = 0;
+
 DGLL_API int dgll_hip_gather_rows(void* stream, const void* cache, int64_t ldc, const void* host, int64_t ldh,
                                   const int64_t* idx, const int64_t* slot, void* out, int64_t ldo, int64_t n, int feat,
                                   int dtype, unsigned long long* miss_count) {
@@ -188,7 +193,7 @@ static int gather_rows_impl(void* stream, const void* cache, int64_t ldc, const 
     auto ok16 = [&](const void* p, int64_t ld) { return !p || (aligned16(p) && (ld * esz) % 16 == 0); };
     const bool v16 = a.row_bytes % 16 == 0 && ok16(cache, ldc) && ok16(host, ldh) && ok16(out, ldo);
     const bool v4 = a.row_bytes % 4 == 0 && (ldh * esz) % 4 == 0 && (ldo * esz) % 4 == 0 && (!slot || (ldc * esz) % 4 == 0);
-    const int64_t blocks = std::min<int64_t>((n + kWavesPerBlock - 1) / kWavesPerBlock, 256 * 16);
+    const int64_t blocks = std::min<int64_t>((n + kWavesPerBlock - 1) / kWavesPerBlock, 256 * (g_tune_loader_blocks_per_cu > 0 ? g_tune_loader_blocks_per_cu : 16));
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (v16) hipLaunchKernelGGL(gather_rows_kernel<16>, dim3((uint32_t)blocks), dim3(kBlock), 0, s, a, esz);
     else if (v4) hipLaunchKernelGGL(gather_rows_kernel<4>, dim3((uint32_t)blocks), dim3(kBlock), 0, s, a, esz);
@@ -223,7 +228,7 @@ DGLL_API int dgll_hip_aggregate_rows_mapped(void* stream, const void* cache, int
     const bool v4 = a.row_bytes % 4 == 0 && ok(cache, ldc, 4) && ok(host, ldh, 4) && ok(out, ldo, 4);
     DGLL_REQUIRE(v16 || v4, "rows must be at least 4-byte granular (even bf16 width, 4-byte aligned pitches)");
     if (v16) a.row_bytes = ((a.row_bytes + 15) / 16) * 16;       // whole vectors: the padding columns are summed and written too
-    const int64_t blocks = std::min<int64_t>((n_rows + kWavesPerBlock - 1) / kWavesPerBlock, 256 * 32);
+    const int64_t blocks = std::min<int64_t>((n_rows + kWavesPerBlock - 1) / kWavesPerBlock, 256 * (g_tune_loader_blocks_per_cu > 0 ? g_tune_loader_blocks_per_cu : 32));
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (dtype == DGLL_BF16) {
         if (v16) hipLaunchKernelGGL((aggregate_rows_kernel<bf16_t, 16>), dim3((uint32_t)blocks), dim3(kBlock), 0, s, a);

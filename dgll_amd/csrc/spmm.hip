@@ -585,6 +585,7 @@ DGLL_API int dgll_hip_csr_plan_create(void* stream, const int64_t* rowptr, int64
 extern int g_tune_mfma_kperm;   // dense.hip
 extern int g_tune_gat_gen;      // edge.hip
 extern int g_tune_res_per_cu;
+extern int g_tune_loader_blocks_per_cu;   // gather.hip
 
 DGLL_API int dgll_hip_debug_tune(int key, int value) {
     switch (key) {
@@ -597,6 +598,7 @@ DGLL_API int dgll_hip_debug_tune(int key, int value) {
         case 7: break;                              // (retired: unroll depth of the first-generation GAT backward passes)
         case 9: g_tune_gat_gen = value; break;
         case 11: g_tune_res_per_cu = value; break;
+        case 12: g_tune_loader_blocks_per_cu = value; break;
         default: set_error("unknown tuning key"); return DGLL_ERR_INVALID;
     }
     return DGLL_OK;

@@ -432,11 +432,14 @@ class _SageTransform(torch.autograd.Function):
         else:
             out = mm2_nt(h, wsd.t(), agg, wnd.t(), relu=relu)
         ctx.relu = relu
+        ctx.wparams = (ws, wn)
         ctx.save_for_backward(h, agg, wsd, wnd, out if relu else None)
         return out
 
     @staticmethod
     def backward(ctx, g):
+        from .optim import grad_slot_of
+
         h, agg, wsd, wnd, out = ctx.saved_tensors
         if ctx.relu:
             g = torch.ops.aten.threshold_backward(g.contiguous(), out, 0)   # one vectorised pass: g where out > 0
@@ -447,10 +450,10 @@ class _SageTransform(torch.autograd.Function):
             gh = mm_nt(g, wsd) if ctx.needs_input_grad[0] else None
             gagg = mm_nt(g, wnd) if ctx.needs_input_grad[1] else None
         if ctx.needs_input_grad[2] and ctx.needs_input_grad[3]:
-            gws, gwn = grad_weight_pair(h, agg, g)
+            gws, gwn = grad_weight_pair(h, agg, g, out1=grad_slot_of(ctx.wparams[0]), out2=grad_slot_of(ctx.wparams[1]))
         else:
-            gws = grad_weight(h, g) if ctx.needs_input_grad[2] else None
-            gwn = grad_weight(agg, g) if ctx.needs_input_grad[3] else None
+            gws = grad_weight(h, g, out=grad_slot_of(ctx.wparams[0])) if ctx.needs_input_grad[2] else None
+            gwn = grad_weight(agg, g, out=grad_slot_of(ctx.wparams[1])) if ctx.needs_input_grad[3] else None
         return gh, gagg, gws, gwn, None
 
 

@@ -609,7 +609,10 @@ class DistGatAggregate(torch.autograd.Function):
         _, dn = engine.alloc_rows(p.n_own, feat, dtype)
         dd = torch.empty((p.n_own, heads), dtype=torch.float32, device=dev)
         grad_s = torch.empty((p.n_own, heads), dtype=torch.float32, device=dev)
-        oe.gat_bwd_rows_part(p.local, h_view, s_own, t_own, out, gv, rowsum, dn, dd, grad_s, heads, fo, alpha, apply_elu, False)
+        # two launches over the column halves of A when there is a halo (2 = first of two, 1 = second); alone, the local launch runs
+        # the exact form of dd_i (csrc/gat_kernel.hpp)
+        oe.gat_bwd_rows_part(p.local, h_view, s_own, t_own, out, gv, rowsum, dn, dd, grad_s, heads, fo, alpha, apply_elu,
+                             2 if p.n_halo else 0)
         if p.n_halo:
             oe.gat_bwd_rows_part(p.halo, halo_h, s_own, halo_t, out, gv, rowsum, dn, dd, grad_s, heads, fo, alpha, apply_elu, True)
         if ctx.halo_local:      # gradients of own and halo rows side by side; nothing travels

@@ -214,7 +214,9 @@ class GraphSage(F.nn.Module):
                     or layer.activation not in (None, F.relu)):
                 return False
         # every block is reduced BEFORE the transform (identity columns), or the layer does not narrow
-        return all(getattr(b, "identity_cols", False) for b in blocks[:self.num_layers])
+        L = self.num_layers      # (the outermost block may be None when its reduction arrives ready-made: it is never touched)
+        return all((b is None and i == L - 1 and last_hop_reduced is not None) or getattr(b, "identity_cols", False)
+                   for i, b in enumerate(blocks[:L]))
 
     @staticmethod
     def _stack_rows(parts):

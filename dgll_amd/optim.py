@@ -109,17 +109,22 @@ class FlatAdam:
         return (64 if n <= 64 else 128 if n <= 128 else 256), -(-k // 64) * 64
 
     def repack(self):
-        """(Re)build the packed bf16 forms of every 2-D parameter no larger than the MFMA transform takes (<= 256 x 256)."""
-        from . import dense
-
+        """(Re)build the packed bf16 forms of every 2-D parameter [K, N]: W^T (the forward product's [N rows, K padded], N <= 256)
+        and W itself (the input-gradient product's [K rows, N padded], K <= 256 -- a wider first layer has no such product)."""
         self._packed.clear()
         for i, p in enumerate(self.params):
-            if p.dim() != 2 or max(p.shape) > 256:
+            if p.dim() != 2 or p.shape[1] > 256:
                 continue
-            with torch.no_grad():
-                self._packed[i] = (dense._pack_now(p.detach()), dense._pack_now(p.detach().t()))
+            self._packed[i] = self._pack_pair(p)
             self._seen_version[i] = p._version
         self._table = None
+
+    @staticmethod
+    def _pack_pair(p):
+        from . import dense
+
+        with torch.no_grad():
+            return (dense._pack_now(p.detach()) if p.shape[0] <= 256 else None, dense._pack_now(p.detach().t()))
 
     def packed_for(self, wt):
         """The packed form of `wt` (a parameter of this optimizer or its transposed view) if it is registered and current."""
@@ -137,10 +142,7 @@ class FlatAdam:
         if wt.data_ptr() != p.data_ptr():
             return None
         if p._version != self._seen_version.get(i):       # somebody else wrote the parameter in place: refresh this one
-            from . import dense
-
-            with torch.no_grad():
-                pair = self._packed[i] = (dense._pack_now(p.detach()), dense._pack_now(p.detach().t()))
+            pair = self._packed[i] = self._pack_pair(p)
             self._seen_version[i] = p._version
             self._table = None
         if tuple(wt.shape) == tuple(p.shape) and wt.stride() == p.stride():
@@ -157,8 +159,8 @@ class FlatAdam:
             begin = i64(*[self.offsets[i] for i in idx])
             end = i64(*[self.offsets[i] + self.params[i].numel() for i in idx])
             cols = (C.c_int * max(n, 1))(*[self.params[i].shape[1] for i in idx])
-            pk = vp(*[self._packed[i][0].data_ptr() for i in idx])
-            ld = i64(*[self._packed[i][0].stride(0) for i in idx])
+            pk = vp(*[self._packed[i][0].data_ptr() if self._packed[i][0] is not None else None for i in idx])
+            ld = i64(*[self._packed[i][0].stride(0) if self._packed[i][0] is not None else 0 for i in idx])
             pkt = vp(*[self._packed[i][1].data_ptr() for i in idx])
             ldt = i64(*[self._packed[i][1].stride(0) for i in idx])
             self._table = (n, begin, end, cols, pk, ld, pkt, ldt)

@@ -154,17 +154,19 @@ class PinnedRing:
 
 
 class Batch:
-    __slots__ = ("input_nodes", "output_nodes", "subgraphs", "features", "labels", "ready", "step", "last_hop_reduced")
+    __slots__ = ("input_nodes", "output_nodes", "subgraphs", "features", "labels", "ready", "step", "last_hop_reduced", "blocks")
 
     def __init__(self):
         self.input_nodes = self.output_nodes = self.subgraphs = self.features = self.labels = self.ready = None
         self.last_hop_reduced = None
+        self.blocks = None          # build_blocks: [CSR block of hop 0, hop 1, ...] on the device (None where the hop needs none)
         self.step = 0
 
 
 class MiniBatchPipeline:
     def __init__(self, dataloader, cache=None, labels=None, queue_size=4, device="cuda", hops=None, memory_fraction=0.1,
-                 record_access=False, reduce_last_hop=None, sampler_threads=0, base_seed=0, epoch=0, device_graph=None):
+                 record_access=False, reduce_last_hop=None, sampler_threads=0, base_seed=0, epoch=0, device_graph=None,
+                 build_blocks=False):
         """dataloader: dgll_amd.dataloader.DataLoader; cache: GraphCacheServer (None: features come from
         dataloader.Dgraph.get_features on the host and are copied); hops: optional callable batch -> list of id tensors
         whose features are needed (default: the input nodes only, graphage.py:52).
@@ -188,6 +190,7 @@ class MiniBatchPipeline:
         if self.sampler_threads > 0 and not hasattr(dataloader.sampler, "sample_seeded"):
             raise ValueError("sampler_threads > 0 needs a sampler with sample_seeded (FastNeighborSampler)")
         self.device_graph = device_graph
+        self.build_blocks = bool(build_blocks)
         self._ring = None
         self._memory_bound_set = False
         self.hops = hops
@@ -311,6 +314,10 @@ class MiniBatchPipeline:
                             b.features = self._fetch_many(id_lists)
                         if self.labels is not None:
                             b.labels = self.labels[outp].to(self.device, non_blocking=True)
+                        if self.build_blocks:
+                            L = len(b.subgraphs)
+                            b.blocks = [None if (h == L - 1 and self.reduce_last_hop is not None) else b.subgraphs[L - 1 - h].to_block(self.device)
+                                        for h in range(L)]
                         b.ready = torch.cuda.Event()
                         b.ready.record(self.load_stream)
                         if self._ring is not None and getattr(self, "_late_release", None) is not None:
@@ -384,6 +391,10 @@ class MiniBatchPipeline:
                 for t in list(b.features or ()) + [b.last_hop_reduced]:
                     if t is not None:
                         t.record_stream(cur)
+                for blk in (b.blocks or ()):
+                    if blk is not None:
+                        blk.rowptr.record_stream(cur)
+                        blk.col.record_stream(cur)
                 if b.labels is not None and b.labels.is_cuda:
                     b.labels.record_stream(cur)
             yield b

@@ -151,7 +151,10 @@ int dgll_hip_gat_bwd(void* stream, const dgll_csr_plan* plan, const dgll_csr_pla
  * neighbours are split over an owned-columns CSR and a halo-columns CSR (mode 0 only):
  *   dgll_hip_gat_fwd_ex   raw != 0: leave the row un-normalised (numerator in `out`, denominator in rowsum);
  *                         accumulate != 0: add the numerator / denominator already there, then (unless raw) normalise + ELU;
- *   dgll_hip_gat_bwd_rows pass 1 over one half; accumulate != 0: add to grad_S and do not rewrite DN / DD;
+ *   dgll_hip_gat_bwd_rows pass 1; accumulate = 0: the ONLY launch over these rows (sparseGatConv form: dd_i = -DN_i . hp_i is then
+ *                         formed from the pass's own dot products, sum_j w_ij (DN_i . h_j) / den_i -- exact in the stored operands,
+ *                         no pre-activation row reconstructed from the rounded output); 2: first of two launches over column
+ *                         halves of A (writes DN, DD, grad_S; dd_i from the stored output row); 1: second of them (grad_S +=);
  *   dgll_hip_gat_bwd_cols pass 2 over one transposed structure: rows = source nodes (Hrow, T_row), columns = destination
  *                         rows (dn, S_col, dd_col, rowmax_col).                                                     */
 int dgll_hip_gat_fwd_ex(void* stream, const dgll_csr_plan* plan, const int64_t* rowptr, const int32_t* col,

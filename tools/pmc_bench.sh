@@ -13,11 +13,12 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-BENCH_ARGS="--steps 3 --warmup 2 --no-cpu-baseline --calibrate $*"
+# --other-workloads off: under rocprofv3 the program must not start child processes (the default line's other_workloads are children)
+BENCH_ARGS="--steps 3 --warmup 2 --no-cpu-baseline --calibrate --other-workloads off $*"
 rm -rf /tmp/kt_$TAG
 # the kernel-trace pass runs bench.py's default timed region only (no calibration launches, no extra graphs), so that the
 # AverageNs of each kernel instantiation is directly the figure bench.py's HIP events report for that launch kind
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$TAG -o p -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra-graphs $* > $OUT/bench_under_rocprof.json 2> $OUT/kernel_trace.log
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$TAG -o p -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra-graphs --other-workloads off $* > $OUT/bench_under_rocprof.json 2> $OUT/kernel_trace.log
 f=$(find /tmp/kt_$TAG -name '*kernel_stats.csv' | head -1)
 [ -n "$f" ] && cp $f $OUT/kernel_stats.csv
 for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do

@@ -9,6 +9,7 @@ import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from dgll_amd import nn as dnn, ops, synth  # noqa: E402
+from dgll_amd.optim import FlatAdam  # noqa: E402
 
 
 def main():
@@ -26,7 +27,7 @@ def main():
     x = ops.alloc_features(n, 100, torch.bfloat16, dev, pad_to=64)
     x.copy_(torch.randn(n, 100, device=dev).to(torch.bfloat16))
     labels = torch.randint(0, 47, (n,), device=dev)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    opt = FlatAdam(list(model.parameters()), lr=1e-3)          # as bench.py
 
     def step():
         opt.zero_grad(set_to_none=True)
@@ -51,8 +52,17 @@ def main():
         d = e.time_range.end - e.time_range.start
         tot += d
         if d >= 20:
-            print("%9.1f us  +%8.1f us  %s" % (e.time_range.start - t0, d, e.name[:110]))
-    print("kernel time %.3f ms, span %.3f ms" % (tot / 1e3, (evs[-1].time_range.end - t0) / 1e3))
+            print("%9.1f us  +%8.1f us  %s" % (e.time_range.start - t0, d, e.name[:110] if e.name.startswith("void dgll") or e.name.startswith("dgll") else e.name[:330]))
+    print("kernel time %.3f ms, span %.3f ms, %d kernels" % (tot / 1e3, (evs[-1].time_range.end - t0) / 1e3, len(evs)))
+    small = {}
+    for e in evs:
+        d = e.time_range.end - e.time_range.start
+        if d < 20:
+            k = small.setdefault(e.name[:150], [0, 0.0])
+            k[0] += 1; k[1] += d
+    print("kernels under 20 us: %d, %.3f ms" % (sum(v[0] for v in small.values()), sum(v[1] for v in small.values()) / 1e3))
+    for name, (cnt, us) in sorted(small.items(), key=lambda kv: -kv[1][1]):
+        print("  %3d x %7.1f us  %s" % (cnt, us, name))
 
 
 if __name__ == "__main__":
