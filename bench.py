@@ -695,7 +695,7 @@ def run_sage(args, c):
         else:
             out = engine.sage_forward(model, x_local, placed_input)
         # cross-entropy summed over this rank's nodes / global node count (x world: RaCoM averages over ranks)
-        loss = ops.cross_entropy(out, labels, reduction="sum") * (world / n)     # one kernel per direction
+        loss = ops.cross_entropy(out, labels, reduction="sum", fold_relu=True) * (world / n)     # one kernel per direction
         loss.backward()
         if opt_wrap is not None:
             opt_wrap.step()

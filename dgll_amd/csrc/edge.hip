@@ -862,9 +862,9 @@ DGLL_API int dgll_hip_gat_fwd_strided(void* stream, const dgll_csr_plan* plan, c
                         fo, alpha, apply_elu, 0, workspace, workspace_bytes, 0, 0);
 }
 
-// Pass 1 of the backward (rows of A or of one column-half of A): DN, DD and grad_S.  accumulate: 0 = the only launch over
-// these rows (second-generation kernels: exact dd_i, gat_kernel.hpp); 2 = first of two launches over column halves of A (writes DN,
-// DD, grad_S); 1 = second of them (grad_S +=).
+// Pass 1 of the backward (rows of A or of one column-half of A): DN, DD and grad_S.  accumulate: 0 = first (or only) launch:
+// writes DN, DD, grad_S, dd_i from the stored output row; 1 = a further launch over another column half (grad_S +=); 3 = DECLARED
+// the only launch over these rows (second-generation kernels: exact dd_i from the pass's own dot products, gat_kernel.hpp).
 static int gat_bwd_rows_impl(void* stream, const dgll_csr_plan* plan, const int64_t* rowptr, const int32_t* col,
                              const void* H, int64_t ldh, const float* S, const float* T, int t_stride, const float* edge_scale,
                              const void* out, int64_t ldo, const void* grad_out, int64_t ldg, int dtype,
@@ -891,7 +891,8 @@ static int gat_bwd_rows_impl(void* stream, const dgll_csr_plan* plan, const int6
     hipStream_t s = static_cast<hipStream_t>(stream);
     int lpr, nh, lph;
     if (gat2_pick(a, &lpr, &nh, &grid.y)) {
-        a.exact_dd = accumulate == 0 ? 1 : 0;      // the only launch over these rows: dd_i from the pass's own dot products
+        a.exact_dd = accumulate == 3 ? 1 : 0;      // declared the only launch over these rows: dd_i from the pass's own dot products
+        a.accumulate = accumulate == 1 ? 1 : 0;
         if (!gat2_launch_1(dtype, lpr, nh, grid, s, a, gat2_inrow(a, lpr, nh, esz, a.T, nullptr))) { set_error("no second-generation GAT kernel for this head layout"); return DGLL_ERR_UNSUPPORTED; }
     } else {
         rc = gat1_pick(a, epv, &lph, &lpr, &grid.y);
@@ -989,7 +990,7 @@ DGLL_API int dgll_hip_gat_bwd(void* stream, const dgll_csr_plan* plan, const dgl
                               void* workspace, size_t workspace_bytes) {
     DGLL_REQUIRE(t_rowptr && t_col, "NULL transposed CSR");
     int rc = dgll_hip_gat_bwd_rows(stream, plan, rowptr, col, H, ldh, S, T, edge_scale, out, ldo, grad_out, ldg, dtype, rowsum,
-                                   rowmax, dn_scratch, ldn, dd_scratch, grad_S, n_rows, heads, fo, alpha, apply_elu, mode, 0,
+                                   rowmax, dn_scratch, ldn, dd_scratch, grad_S, n_rows, heads, fo, alpha, apply_elu, mode, 3,
                                    workspace, workspace_bytes);
     if (rc != DGLL_OK) return rc;
     // the same scratch is reused: pass 2 is stream-ordered after pass 1
@@ -1013,7 +1014,7 @@ DGLL_API int dgll_hip_gat_bwd_rows_strided(void* stream, const dgll_csr_plan* pl
     DGLL_REQUIRE(sd_scratch && sd_stride >= 2 * heads && t_stride >= heads, "bad strided score arguments");
     return gat_bwd_rows_impl(stream, plan, rowptr, col, H, ldh, S, T, t_stride, nullptr, out, ldo, grad_out, ldg, dtype, rowsum,
                              nullptr, dn_scratch, ldn, nullptr, sd_scratch, sd_stride, grad_S, n_rows, heads, fo, alpha,
-                             apply_elu, 0, 0, workspace, workspace_bytes);
+                             apply_elu, 0, 3, workspace, workspace_bytes);      // the strided form is always the only launch over its rows
 }
 
 DGLL_API int dgll_hip_gat_bwd_cols_strided(void* stream, const dgll_csr_plan* t_plan, const int64_t* t_rowptr,

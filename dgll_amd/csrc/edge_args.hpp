@@ -30,7 +30,6 @@ struct EdgeArgs {
     float alpha, sign;          // leaky-relu slope; -1: exp(-lrelu) (sparseGatConv), +1: softmax(+lrelu) (gatConv)
     int apply_elu, use_max;
     int raw, accumulate;        // partitioned use: raw = leave the row un-normalised (num, den); accumulate = add what is already there
-                                // (rows pass of the GAT backward: 0 = the only launch, 2 = first of two column halves, 1 = second)
     int exact_dd;               // second-generation rows pass, single launch: dd_i from the pass's own dot products (gat_kernel.hpp)
     int32_t* arg_out;           // segment_max: int32 [n_rows, ld] source row of the maximum
     // long-row schedule (threshold == 0: none): chunk work items come first in the grid, partials go to `ws`

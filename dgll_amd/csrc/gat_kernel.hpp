@@ -146,7 +146,7 @@ __global__ __launch_bounds__(kBlock) void gat2_kernel(const EdgeArgs a) {
         // lanes accumulate  sw = sum_j w_ij * partial_dot_ij  next to  sa = sum_j c_ij * partial_dot_ij  and dd_i falls out in the row
         // epilogue (long rows: the chunk partials carry (sa, sb, sw) and the finalize kernel combines them -- ds_i is bilinear in
         // them).  The same bf16 h_j enter dd_i and the transposed pass, so the cancellation in ds_i is exact to fp32 rounding.
-        // LEGACY form (split launches over two column halves of A, a.accumulate = 1 / 2): hp_i recovered from the stored output
+        // LEGACY form (launches over column halves of A; the caller did not declare this launch the only one): hp_i from the stored output
         // row (bf16: rounded to 8 bits; ELU inverted with a logarithm), dd_i known before the gathers.
         const bool legacy = !a.exact_dd;
         float part = 0.0f;

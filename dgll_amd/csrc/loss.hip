@@ -24,6 +24,8 @@ struct XentArgs {
     const float* scale;     // device scalar (may be NULL: 1)
     int64_t n_rows;
     int n_classes;
+    int mask_nonpositive;   // gradient pass: zero the gradient where the logit is <= 0 (the logits are ReLU outputs and the loss
+                            // takes over that ReLU's backward: d loss / d pre-activation)
 };
 
 template <typename T> __device__ __forceinline__ float ld(const T* p);
@@ -41,10 +43,12 @@ __global__ __launch_bounds__(kBlock) void softmax_xent_kernel(const XentArgs a) 
     const T* z = static_cast<const T*>(a.z) + r * a.ldz;
     float v[PER], t[SOFT ? PER : 1];
     float m = -INFINITY, tsum = 0.0f, tz = 0.0f;
+    uint32_t keep = 0xffffffffu;          // bit j: class sub + j G keeps its gradient
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
         const int c = sub + j * G;
         v[j] = c < a.n_classes ? ld<T>(z + c) : -INFINITY;
+        if (a.mask_nonpositive && !(v[j] > 0.0f)) keep &= ~(1u << j);
         m = fmaxf(m, v[j]);
         if constexpr (SOFT) {
             t[j] = c < a.n_classes ? a.soft[r * a.lds + c] : 0.0f;
@@ -75,7 +79,7 @@ __global__ __launch_bounds__(kBlock) void softmax_xent_kernel(const XentArgs a) 
 #pragma unroll
             for (int j = 0; j < PER; ++j) {
                 const int c = sub + j * G;
-                if (c < a.n_classes) store_one<T>(g + c, scale * (v[j] * inv * tsum - t[j]));
+                if (c < a.n_classes) store_one<T>(g + c, ((keep >> j) & 1u) ? scale * (v[j] * inv * tsum - t[j]) : 0.0f);
             }
         }
     } else {
@@ -88,7 +92,7 @@ __global__ __launch_bounds__(kBlock) void softmax_xent_kernel(const XentArgs a) 
 #pragma unroll
             for (int j = 0; j < PER; ++j) {
                 const int c = sub + j * G;
-                if (c < a.n_classes) store_one<T>(g + c, scale * (v[j] * inv - (c == label ? 1.0f : 0.0f)));
+                if (c < a.n_classes) store_one<T>(g + c, ((keep >> j) & 1u) ? scale * (v[j] * inv - (c == label ? 1.0f : 0.0f)) : 0.0f);
             }
         }
     }
@@ -122,7 +126,7 @@ using namespace dgll;
 
 static int xent_impl(void* stream, const void* logits, int64_t ldz, int dtype, const int64_t* labels, const float* soft,
                      int64_t lds, float* row_loss, void* grad, int64_t ldg, const float* grad_scale, int64_t n_rows,
-                     int n_classes) {
+                     int n_classes, int flags = 0) {
     DGLL_REQUIRE(n_rows >= 0 && n_classes >= 0, "negative size");
     if (n_rows == 0 || n_classes == 0) return DGLL_OK;
     DGLL_REQUIRE(logits && (labels || soft), "NULL logits/targets");
@@ -136,7 +140,7 @@ static int xent_impl(void* stream, const void* logits, int64_t ldz, int dtype, c
     }
     XentArgs a{};
     a.z = logits; a.ldz = ldz; a.labels = labels; a.soft = soft; a.lds = lds; a.row_loss = row_loss; a.grad = grad; a.ldg = ldg;
-    a.scale = grad_scale; a.n_rows = n_rows; a.n_classes = n_classes;
+    a.scale = grad_scale; a.n_rows = n_rows; a.n_classes = n_classes; a.mask_nonpositive = flags & 1;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const hipError_t e = dtype == DGLL_F32 ? dispatch_xent<float>(a, s) : dispatch_xent<bf16_t>(a, s);
     if (e != hipSuccess) return hip_fail(e, "softmax_xent_kernel launch");
@@ -155,4 +159,13 @@ DGLL_API int dgll_hip_softmax_xent_soft(void* stream, const void* logits, int64_
                                         int64_t n_rows, int n_classes) {
     DGLL_REQUIRE(targets || n_rows == 0, "NULL targets");
     return xent_impl(stream, logits, ldz, dtype, nullptr, targets, ldt, row_loss, grad, ldg, grad_scale, n_rows, n_classes);
+}
+
+// flags bit 0: the logits are the output of a ReLU and the gradient returned is d loss / d PRE-activation -- zero wherever the
+// logit is <= 0 (aten::threshold_backward folded into this pass; the reference's GraphSage ends in a ReLU, sageconv.py:83).
+DGLL_API int dgll_hip_softmax_xent_ex(void* stream, const void* logits, int64_t ldz, int dtype, const int64_t* labels,
+                                      const float* targets, int64_t ldt, float* row_loss, void* grad, int64_t ldg,
+                                      const float* grad_scale, int64_t n_rows, int n_classes, int flags) {
+    DGLL_REQUIRE((labels != nullptr) != (targets != nullptr) || n_rows == 0, "pass class-index labels OR probability targets");
+    return xent_impl(stream, logits, ldz, dtype, labels, targets, ldt, row_loss, grad, ldg, grad_scale, n_rows, n_classes, flags);
 }

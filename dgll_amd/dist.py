@@ -439,8 +439,10 @@ class _DistSageLayer(torch.autograd.Function):
     applied it (`grad_is_gated`).  `placed`: the static input halo (first layer; no gradient to the raw features)."""
 
     @staticmethod
-    def forward(ctx, h, ws, wn, engine, reduce, relu, grad_is_gated, gate_input, placed):
+    def forward(ctx, h, ws, wn, engine, reduce, relu, grad_is_gated, gate_input, placed, token=None):
         from . import dense
+
+        ctx.token = token
 
         agg = engine.aggregate_static(placed, reduce) if placed is not None else _aggregate_forward(engine, h, reduce)
         wsd, wnd = dense.wcast(ws, h), dense.wcast(wn, h)
@@ -461,7 +463,7 @@ class _DistSageLayer(torch.autograd.Function):
         h, agg, wsd, wnd, out = ctx.saved_tensors
         engine = ctx.engine
         g = g.contiguous()
-        if ctx.relu and not ctx.grad_is_gated:
+        if ctx.relu and not ctx.grad_is_gated and not (ctx.token is not None and ctx.token.masked):
             g = torch.ops.aten.threshold_backward(g, out, 0)
         state = None
         if ctx.needs_input_grad[0]:   # the neighbour-path gradient first: its halo part has to travel
@@ -487,16 +489,17 @@ class _DistSageLayer(torch.autograd.Function):
             gh = _aggregate_backward_finish(engine, state, into=gh, gate=gate)
             if ctx.gate_input and gate is None:
                 gh = torch.ops.aten.threshold_backward(gh, h, 0)
-        return gh, gws, gwn, None, None, None, None, None, None
+        return gh, gws, gwn, None, None, None, None, None, None, None
 
 
 class _DistSageLayerTransformFirst(torch.autograd.Function):
     """act(h.Ws + reduce_A(h.Wn)) -- the narrowing layer: the NARROW product crosses the links and is aggregated."""
 
     @staticmethod
-    def forward(ctx, h, ws, wn, engine, reduce, relu, grad_is_gated, gate_input):
+    def forward(ctx, h, ws, wn, engine, reduce, relu, grad_is_gated, gate_input, token=None):
         from . import dense
 
+        ctx.token = token
         wsd, wnd = dense.wcast(ws, h), dense.wcast(wn, h)
         z = (dense.transform_bf16(h, wnd.t(), ld_align=64 if wn.shape[1] < 64 else None)
              if (h.is_cuda and dense._mfma_ok(h) and wn.shape[1] <= 256) else dense.mm_nt(h, wnd.t()))
@@ -517,7 +520,7 @@ class _DistSageLayerTransformFirst(torch.autograd.Function):
 
         h, wsd, wnd, out = ctx.saved_tensors
         engine = ctx.engine
-        masked = ctx.relu and not ctx.grad_is_gated
+        masked = ctx.relu and not ctx.grad_is_gated and not (ctx.token is not None and ctx.token.masked)
         if masked:                                                               # (masked) gradient in aligned rows
             _, gm = engine.alloc_rows(g.shape[0], g.shape[1], g.dtype)
             torch.ops.aten.threshold_backward.grad_input(g, out, 0, grad_input=gm)
@@ -548,7 +551,7 @@ class _DistSageLayerTransformFirst(torch.autograd.Function):
                 gh = dense.mm2_nt(gm, wsd, gz, wnd)
                 if ctx.gate_input:
                     gh = torch.ops.aten.threshold_backward(gh, h, 0)
-        return gh, gws, gwn, None, None, None, None, None
+        return gh, gws, gwn, None, None, None, None, None, None
 
 
 class DistGatAggregate(torch.autograd.Function):
@@ -609,10 +612,10 @@ class DistGatAggregate(torch.autograd.Function):
         _, dn = engine.alloc_rows(p.n_own, feat, dtype)
         dd = torch.empty((p.n_own, heads), dtype=torch.float32, device=dev)
         grad_s = torch.empty((p.n_own, heads), dtype=torch.float32, device=dev)
-        # two launches over the column halves of A when there is a halo (2 = first of two, 1 = second); alone, the local launch runs
-        # the exact form of dd_i (csrc/gat_kernel.hpp)
+        # two launches over the column halves of A when there is a halo (0 = first, 1 = second); alone, the local launch is declared
+        # the only one (3) and runs the exact form of dd_i (csrc/gat_kernel.hpp)
         oe.gat_bwd_rows_part(p.local, h_view, s_own, t_own, out, gv, rowsum, dn, dd, grad_s, heads, fo, alpha, apply_elu,
-                             2 if p.n_halo else 0)
+                             0 if p.n_halo else 3)
         if p.n_halo:
             oe.gat_bwd_rows_part(p.halo, halo_h, s_own, halo_t, out, gv, rowsum, dn, dd, grad_s, heads, fo, alpha, apply_elu, True)
         if ctx.halo_local:      # gradients of own and halo rows side by side; nothing travels
@@ -1060,12 +1063,15 @@ class DistGraph:
             if fusable[li]:
                 relu = layer.activation is not None
                 gated = bool(li + 1 < len(layers) and gates[li + 1] and relu)
+                token = ops.GateToken() if (relu and not gated) else None      # see fused_layers.sage_graph_layer
                 if layer.transform_first(h):
                     h = _DistSageLayerTransformFirst.apply(h, layer.weight, layer.neighborAgg.weight, self, reduce, relu,
-                                                           gated, gates[li])
+                                                           gated, gates[li], token)
                 else:
                     h = _DistSageLayer.apply(h, layer.weight, layer.neighborAgg.weight, self, reduce, relu, gated, gates[li],
-                                             placed_input if static else None)
+                                             placed_input if static else None, token)
+                if token is not None:
+                    h._dgll_gate_token = token
                 continue
             if static:
                 h = layer.transform_block(h, self.aggregate_static(placed_input, reduce=reduce))

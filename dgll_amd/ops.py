@@ -195,14 +195,28 @@ def spmm(graph, x, val=None, reduce="sum", bias=None, relu=False):
 
 
 # ------------------------------------------------------------------------------------------------ loss
-def _xent_launch(z, target, soft, row_loss, grad, scale):
+class GateToken:
+    """Handshake between a layer that ends in a ReLU and a consumer willing to take that ReLU's backward over (cross_entropy's
+    fold_relu): the layer tags its output with a token; a consumer that masks the gradient it returns sets `masked`, and the
+    layer's backward then skips its own masking pass.  No tag, or nobody sets it: the layer masks as always."""
+    __slots__ = ("masked",)
+
+    def __init__(self):
+        self.masked = False
+
+
+def _xent_launch(z, target, soft, row_loss, grad, scale, mask_nonpositive=False):
     n, c = z.shape
     with torch.cuda.device(z.device):
         stream = torch.cuda.current_stream(z.device).cuda_stream
         rl = row_loss.data_ptr() if row_loss is not None else None
         gp, gld = (grad.data_ptr(), grad.stride(0)) if grad is not None else (None, 0)
         sp = scale.data_ptr() if scale is not None else None
-        if soft:
+        if mask_nonpositive:
+            code = _lib.lib.dgll_hip_softmax_xent_ex(stream, z.data_ptr(), z.stride(0), _dtype_code(z), None if soft else target.data_ptr(),
+                                                     target.data_ptr() if soft else None, target.stride(0) if soft else 0, rl, gp, gld,
+                                                     sp, n, c, 1)
+        elif soft:
             code = _lib.lib.dgll_hip_softmax_xent_soft(stream, z.data_ptr(), z.stride(0), _dtype_code(z), target.data_ptr(),
                                                        target.stride(0), rl, gp, gld, sp, n, c)
         else:
@@ -218,7 +232,8 @@ class _CrossEntropy(torch.autograd.Function):
     (dgll_amd/graphs.py)."""
 
     @staticmethod
-    def forward(ctx, logits, target, reduction):
+    def forward(ctx, logits, target, reduction, token=None):
+        ctx.token = token
         _require_cuda(logits, target)
         if logits.dim() != 2:
             raise ValueError("cross_entropy expects logits [N, C]")
@@ -266,19 +281,28 @@ class _CrossEntropy(torch.autograd.Function):
         # it to the MFMA kernels as it is, without a re-layout pass over [N, C]
         line = 128 // z.element_size()
         grad = alloc_features(z.shape[0], z.shape[1], z.dtype, z.device, pad_to=line if z.shape[1] < line else 16 // z.element_size())
-        _xent_launch(z, target, ctx.soft, None, grad, scale)
+        # fold_relu: the logits are a ReLU's output and this pass returns the gradient of the PRE-activation (zero where z <= 0);
+        # the producing layer is told through its token and skips its own masking pass over [N, C]
+        _xent_launch(z, target, ctx.soft, None, grad, scale, mask_nonpositive=ctx.token is not None)
+        if ctx.token is not None:
+            ctx.token.masked = True
         if per_row:
             grad = grad * g.to(grad.dtype).unsqueeze(1)
-        return grad, None, None
+        return grad, None, None, None
 
 
-def cross_entropy(logits, labels, reduction="mean"):
+def cross_entropy(logits, labels, reduction="mean", fold_relu=False):
     """F.cross_entropy(logits, target) for GPU logits [N, C] (fp32 or bf16; math in fp32).  `target`: int64 class indices
     [N] (entries outside [0, C), e.g. -100, are ignored) or a float [N, C] matrix of probabilities / multi-hot labels --
-    the PPI loop's case (Evaluation/PPI/train_gcn.py:27,45 hands nn.CrossEntropyLoss the float label matrix)."""
+    the PPI loop's case (Evaluation/PPI/train_gcn.py:27,45 hands nn.CrossEntropyLoss the float label matrix).
+    fold_relu: the caller asserts that `logits` -- the output of a layer that ends in a ReLU, as the reference's GraphSage does
+    (sageconv.py:83) -- has NO other differentiable consumer.  When that layer tagged its output (GateToken), the gradient pass of
+    the loss also applies the ReLU's mask and the layer skips its own pass over [N, C]; same gradients (masking is idempotent), one
+    elementwise launch less.  Untagged logits: ignored."""
     if reduction not in ("mean", "sum", "none"):
         raise ValueError("reduction must be 'mean', 'sum' or 'none'")
-    return _CrossEntropy.apply(logits, labels, reduction)
+    token = getattr(logits, "_dgll_gate_token", None) if fold_relu else None
+    return _CrossEntropy.apply(logits, labels, reduction, token)
 
 
 from .ops_edge import gat_aggregate, gat_layer, head_width_padded, sddmm_raw, segment_max  # noqa: E402,F401

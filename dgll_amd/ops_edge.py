@@ -407,6 +407,8 @@ def gat_fwd_part(graph, h, s_rows, t_cols, out, rowsum, heads, fo, alpha, apply_
 
 
 def gat_bwd_rows_part(graph, h_cols, s_rows, t_cols, out, g, rowsum, dn, dd, grad_s, heads, fo, alpha, apply_elu, accumulate):
+    """Rows pass over one column half of A.  accumulate: False / 0 = first (or only) launch (writes DN, dd, grad_s; dd_i from the
+    stored output row), True / 1 = a further half (grad_s +=), 3 = DECLARED the only launch over these rows: exact dd_i."""
     dev = out.device
     ws, nbytes = _ws(graph.plan(), heads, fo, dev)
     with torch.cuda.device(dev):

@@ -151,10 +151,11 @@ int dgll_hip_gat_bwd(void* stream, const dgll_csr_plan* plan, const dgll_csr_pla
  * neighbours are split over an owned-columns CSR and a halo-columns CSR (mode 0 only):
  *   dgll_hip_gat_fwd_ex   raw != 0: leave the row un-normalised (numerator in `out`, denominator in rowsum);
  *                         accumulate != 0: add the numerator / denominator already there, then (unless raw) normalise + ELU;
- *   dgll_hip_gat_bwd_rows pass 1; accumulate = 0: the ONLY launch over these rows (sparseGatConv form: dd_i = -DN_i . hp_i is then
- *                         formed from the pass's own dot products, sum_j w_ij (DN_i . h_j) / den_i -- exact in the stored operands,
- *                         no pre-activation row reconstructed from the rounded output); 2: first of two launches over column
- *                         halves of A (writes DN, DD, grad_S; dd_i from the stored output row); 1: second of them (grad_S +=);
+ *   dgll_hip_gat_bwd_rows pass 1 over one half; accumulate = 0: first (or only) launch, writes DN / DD / grad_S, dd_i = -DN_i . hp_i with
+ *                         hp_i recovered from the stored output row; 1: a further launch over another column half (grad_S +=, DN / DD
+ *                         left alone); 3: DECLARED the only launch over these rows (sparseGatConv form): dd_i is formed from the
+ *                         pass's own dot products, sum_j w_ij (DN_i . h_j) / den_i -- exact in the stored operands (what
+ *                         dgll_hip_gat_bwd and the *_strided entry points do);
  *   dgll_hip_gat_bwd_cols pass 2 over one transposed structure: rows = source nodes (Hrow, T_row), columns = destination
  *                         rows (dn, S_col, dd_col, rowmax_col).                                                     */
 int dgll_hip_gat_fwd_ex(void* stream, const dgll_csr_plan* plan, const int64_t* rowptr, const int32_t* col,
@@ -409,6 +410,13 @@ int dgll_hip_softmax_xent(void* stream, const void* logits, int64_t ldz, int dty
 int dgll_hip_softmax_xent_soft(void* stream, const void* logits, int64_t ldz, int dtype, const float* targets,
                                int64_t ldt, float* row_loss, void* grad, int64_t ldg, const float* grad_scale,
                                int64_t n_rows, int n_classes);
+/* Both target kinds behind one entry (exactly one of labels / targets non-NULL) + flags.  bit 0: the logits are ReLU outputs and
+ * the gradient returned is d loss / d PRE-activation: zero wherever the logit is <= 0 (the last sageConv's ReLU backward,
+ * sageconv.py:83, folded into the loss's gradient pass instead of a separate pass over [n_rows, n_classes]).                  */
+int dgll_hip_softmax_xent_ex(void* stream, const void* logits, int64_t ldz, int dtype, const int64_t* labels, const float* targets,
+                             int64_t ldt, float* row_loss, void* grad, int64_t ldg, const float* grad_scale, int64_t n_rows,
+                             int n_classes, int flags);
+
 
 /* ---- a10: H = relu(A_csr . (X[:, :actual_F] . W[:actual_F, :])) --------------------------------------------
  * launch_gcn_fused_kernel is the reference's own symbol with its exact signature

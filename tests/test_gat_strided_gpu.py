@@ -93,9 +93,11 @@ def test_bf16_spgat_bench_configuration_against_the_storage_emulating_oracle(cud
     stores a tensor: x, W and a as bf16 operands, h = x.W stored, each layer's output stored.  The stored activations must
     agree to one bf16 step almost everywhere.  Gradients: the aggregation path is within bf16 rounding (grad_h 2e-3 per pass,
     tools/gat_grad_precision.py); the score gradients are differences of nearly equal sums, ds_i = sum_j c_ij (DN_i.h_j + dd_i),
-    formed from bf16-stored DN rows -- since dd_i is formed from the same ROUNDED DN_i (it was not: 8e-3 per pass, 1e-2 on every
-    W and 2.8e-2 on the output layer's a in this test) they are at 5e-3 per pass, and the parameter gradients here measure
-    3.1-5.5e-3 (W) and 5.5e-3-1e-2 (a).  Log-probabilities of a bf16 model are formed in fp32."""
+    formed from bf16-stored DN rows.  Round 3: dd_i = -DN_i.hp_i with hp_i recovered from the stored bf16 output row: 5e-3 per
+    pass, 3.1-5.5e-3 (W) and 5.5e-3-1e-2 (a) here.  Round 4: dd_i from the pass's own dot products, sum_j w_ij (DN_i.h_j) / den_i
+    (csrc/gat_kernel.hpp) -- the same stored h_j enter dd_i and every dot product, so the cancellation is exact to fp32 rounding:
+    1.7e-3 per pass (grad_s, grad_t: the level of grad_h), and here 3.7-4.3e-3 (W), 4.2-6.3e-3 (a): what is left is the bf16
+    rounding of the gradients handed from layer to layer.  Log-probabilities of a bf16 model are formed in fp32."""
     from dgll_amd import nn as dnn
     from dgll_amd import ops, synth
 
@@ -167,9 +169,9 @@ def test_bf16_spgat_bench_configuration_against_the_storage_emulating_oracle(cud
         assert rel <= tol, (name, rel)
 
     for k, att in enumerate(list(model.attentions) + [model.out_att]):
-        close("W of layer/head %d" % k, att.W.grad, ref_params[k][0].grad, 1e-2)
-        close("a of layer/head %d" % k, att.a.grad, ref_params[k][1].grad, 2e-2)
-    close("input features", xin.grad, cx.grad, 1e-2)
+        close("W of layer/head %d" % k, att.W.grad, ref_params[k][0].grad, 6e-3)
+        close("a of layer/head %d" % k, att.a.grad, ref_params[k][1].grad, 8e-3)
+    close("input features", xin.grad, cx.grad, 6e-3)
 
 
 @pytest.mark.parametrize("concat", [True, False])

@@ -65,3 +65,37 @@ def test_soft_target_cross_entropy_matches_torch(cuda_device, dtype, classes, n,
     (ref * w).sum().backward()
     tol = 2e-5 if dtype == torch.float32 else 1e-2
     torch.testing.assert_close(za.grad.float(), zr.grad, rtol=tol, atol=tol * float(zr.grad.abs().max()))
+
+
+def test_loss_that_folds_the_last_relu_gives_the_same_gradients(cuda_device):
+    """ops.cross_entropy(fold_relu=True) on the tagged output of a full-graph GraphSage (whose last sageConv ends in a ReLU, as the
+    reference's does, sageconv.py:83): the loss's gradient pass applies that ReLU's mask, the layer skips its own masking pass
+    (ops.GateToken) -- identical losses and parameter gradients; untagged logits ignore the flag; the ex entry point masks where the
+    logit is <= 0 and nowhere else."""
+    from dgll_amd import nn as dnn, ops, synth
+
+    dev = cuda_device
+    g = synth.products_like_graph(dev, seed=2, n=5000, n_undirected=40000, locality=0.9, n_blocks=4, exact=True)
+    x = ops.alloc_features(g.n_rows, 24, torch.bfloat16, dev, pad_to=64)
+    x.copy_(torch.randn(g.n_rows, 24, device=dev))
+    labels = torch.randint(0, 11, (g.n_rows,), device=dev)
+    grads = {}
+    for fold in (False, True):
+        torch.manual_seed(3)
+        model = dnn.GraphSage(24, [64, 64, 11], None).to(dev)
+        out = model.forward_graph(g, x)
+        token = getattr(out, "_dgll_gate_token", None)
+        assert token is not None and not token.masked
+        loss = ops.cross_entropy(out, labels, reduction="sum", fold_relu=fold) * (1.0 / g.n_rows)
+        loss.backward()
+        assert token.masked is fold
+        grads[fold] = (float(loss), [p.grad.clone() for p in model.parameters()])
+    assert grads[True][0] == grads[False][0]
+    for a, b in zip(grads[True][1], grads[False][1]):
+        assert torch.equal(a, b)
+    # untagged logits: the flag does nothing
+    z = torch.relu(torch.randn(300, 11, device=dev)).requires_grad_()
+    ops.cross_entropy(z, labels[:300], fold_relu=True).backward()
+    ref = z.detach().clone().requires_grad_()
+    torch.nn.functional.cross_entropy(ref, labels[:300]).backward()
+    torch.testing.assert_close(z.grad, ref.grad, rtol=1e-5, atol=1e-7)

@@ -588,3 +588,10 @@ def test_gat_split_launches_equal_the_fused_one(cuda_device, dtype):
     torch.testing.assert_close(gs, gs_ref, **gtol)
     torch.testing.assert_close(gt, gt_ref, **gtol)
     torch.testing.assert_close(gh, gh_ref.float(), **gtol)
+    # one launch over the whole adjacency, DECLARED the only one (accumulate = 3): dd_i from the pass's own dot products -- equal to
+    # the split launches' (dd_i from the stored output row) to rounding, and what the fused backward above ran
+    dn1, dd1, gs1 = _empty_padded(n, heads * fo, dtype, d), torch.empty(n, heads, device=d), torch.empty(n, heads, device=d)
+    gat_bwd_rows_part(full, hd, sd, td, out, go, rowsum, dn1, dd1, gs1, heads, fo, 0.2, True, accumulate=3)
+    torch.testing.assert_close(dn1.float(), dn.float(), rtol=0, atol=0)
+    torch.testing.assert_close(gs1, gs_ref, **gtol)
+    torch.testing.assert_close(dd1, dd, **(dict(rtol=2e-3, atol=2e-4) if dtype == torch.float32 else dict(rtol=5e-2, atol=5e-2)))

@@ -61,7 +61,7 @@ def main():
 
         def step():
             opt.zero_grad(set_to_none=True)
-            loss = ops.cross_entropy(model.forward_graph(full, x), lab, reduction="sum") * (1.0 / n)
+            loss = ops.cross_entropy(model.forward_graph(full, x), lab, reduction="sum", fold_relu=True) * (1.0 / n)
             loss.backward()
             opt.step()
 
@@ -97,7 +97,7 @@ def main():
         def step():
             opt.zero_grad(set_to_none=True)
             out = engine.sage_forward(model, x, placed)
-            loss = ops.cross_entropy(out, labels, reduction="sum") * (world / n)
+            loss = ops.cross_entropy(out, labels, reduction="sum", fold_relu=True) * (world / n)
             loss.backward()
             racom.all_reduce_and_wait()
             opt.step()

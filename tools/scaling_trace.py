@@ -35,7 +35,7 @@ placed = engine.place_input_halo(x)
 def step():
     opt.zero_grad(set_to_none=True)
     out = engine.sage_forward(model, x, placed)
-    loss = ops.cross_entropy(out, labels, reduction="sum") * (world / n)
+    loss = ops.cross_entropy(out, labels, reduction="sum", fold_relu=True) * (world / n)
     loss.backward()
     racom.all_reduce_and_wait()
     opt.step()

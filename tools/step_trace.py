@@ -32,7 +32,7 @@ def main():
     def step():
         opt.zero_grad(set_to_none=True)
         out = model.forward_graph(g, x)
-        loss = ops.cross_entropy(out, labels, reduction="sum") / n
+        loss = ops.cross_entropy(out, labels, reduction="sum", fold_relu=True) / n
         loss.backward()
         opt.step()
 
