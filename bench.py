@@ -1020,7 +1020,10 @@ def run_minibatch(args, c):
     # timed: at least 8 warm-up and 64 timed batches here, whatever --steps / --warmup say (the JSON line carries the counts used).
     args.warmup = max(args.warmup, 8)
     args.steps = max(args.steps, 64)
-    n_batches = args.warmup + args.steps
+    # ... + a TAIL of 16 batches outside the timed window: the per-launch HIP events behind the launch tables cost the consumer thread
+    # ~0.2 ms per batch (two event records per launch), so they are switched on for the tail only
+    tail = 16
+    n_batches = args.warmup + args.steps + tail
     train = torch.randperm(args.mb_nodes)[:n_batches * args.mb_batch]
 
     from dgll_amd import _lib as _dl
@@ -1085,10 +1088,17 @@ def run_minibatch(args, c):
             prof.enable()
         if done == args.warmup:
             torch.cuda.synchronize()
-            timer_cm.__enter__()
             t0 = time.perf_counter()
             s0 = TimedSampler.seconds
             l0, cpu_busy = pipe.load_seconds, 0.0
+        if done == args.warmup + args.steps:                  # the timed window ends here; the tail runs with per-launch events
+            torch.cuda.synchronize()
+            elapsed = time.perf_counter() - t0
+            sampler_s = TimedSampler.seconds - s0
+            loader_s, busy_s = pipe.load_seconds - l0, cpu_busy
+            if prof is not None:
+                prof.disable()
+            timer_cm.__enter__()
         t_body = time.perf_counter()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
@@ -1101,7 +1111,7 @@ def run_minibatch(args, c):
         loss.backward()
         opt.step()
         ev1.record()
-        if done >= args.warmup:
+        if args.warmup <= done < args.warmup + args.steps:
             events.append((ev0, ev1))
             # edges aggregated per batch: layer l runs over hops 0..L-l-1, each a gather over that hop's sampled edges (fwd + bwd)
             per_hop = [b.subgraphs[L - 1 - h].num_src_nodes() for h in range(L)]
@@ -1109,15 +1119,12 @@ def run_minibatch(args, c):
         done += 1
         cpu_busy += time.perf_counter() - t_body
     torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
     if prof is not None:
         import pstats
 
-        prof.disable()
         pstats.Stats(prof, stream=sys.stderr).sort_stats("cumulative").print_stats(45)
     stream_ctx.__exit__(None, None, None)
     timer_cm.__exit__(None, None, None)
-    sampler_s = TimedSampler.seconds - s0
     per_batch = sorted(a.elapsed_time(b_) for a, b_ in events)
     gpu_ms = sum(per_batch) / max(len(per_batch), 1)
     pct = lambda q: per_batch[min(len(per_batch) - 1, int(q * len(per_batch)))] if per_batch else None    # noqa: E731
@@ -1173,8 +1180,9 @@ def run_minibatch(args, c):
                    "host_sampler_threads": k_threads,
                    # where the batch period goes on the host: the consumer thread's own time per batch (issuing ~110 launches through
                    # Python), the loading thread's, and what is left of the period = the consumer waiting for a batch
-                   "consumer_host_ms_per_batch": cpu_busy / max(steps, 1) * 1e3,
-                   "loader_host_ms_per_batch": (pipe.load_seconds - l0) / max(steps, 1) * 1e3,
+                   "consumer_host_ms_per_batch": busy_s / max(steps, 1) * 1e3,
+                   "loader_host_ms_per_batch": loader_s / max(steps, 1) * 1e3,
+                   "launch_tables_from": "%d further batches after the timed window (per-launch HIP events on)" % tail,
                    "loaded_queue_starved_s": pipe.queue._starved,
                    "sampler_mode": ("per-batch seeds, %d native sampler threads (batch b under random.seed(batch_seed(%d, 0, b)))" % (
                        k_threads, args.seed)) if k_threads > 0 else "one sequential stream on the interpreter's generator",

@@ -88,19 +88,23 @@ class GraphCacheServer:
         vector is shared between the stream that records (the pipeline's loading stream) and the one that refreshes: every
         update is bracketed by events (`_access_event`), never by a host synchronisation."""
         stream = torch.cuda.current_stream(self.device) if stream is None else stream
-        with self._pending_lock:
-            if getattr(self, "_access", None) is None:
-                with torch.cuda.stream(stream):
-                    self._access = torch.zeros(self.node_num, dtype=torch.int64, device=self.device)
-            access, prev = self._access, getattr(self, "_access_event", None)
-        with torch.cuda.stream(stream):
-            if prev is not None:
-                stream.wait_event(prev)                    # a refresh on another stream may just have decayed the counts
+        # The whole enqueue -- wait for the other side's last event, the update, the new event -- happens under the lock, and so does
+        # refresh_from_access's: the two streams' accesses to the counter vector are then totally ordered by the events (a recorder that
+        # had snapshotted the previous event BEFORE a refresh published its own ran its index_add_ next to the refresh's top-k and
+        # decay: lost increments or a torn read -- ADVICE round 3).  Nothing here synchronises the host with the GPU.
+        with torch.cuda.stream(stream):                    # the id upload (it may block on a pageable source) stays outside the lock
             nids = nids.to(self.device, dtype=torch.int64, non_blocking=True)
-            access.index_add_(0, nids, torch.ones_like(nids))
-            ev = torch.cuda.Event()
-            ev.record(stream)
+            ones = torch.ones_like(nids)
         with self._pending_lock:
+            with torch.cuda.stream(stream):
+                if getattr(self, "_access", None) is None:
+                    self._access = torch.zeros(self.node_num, dtype=torch.int64, device=self.device)
+                prev = getattr(self, "_access_event", None)
+                if prev is not None:
+                    stream.wait_event(prev)
+                self._access.index_add_(0, nids, ones)
+                ev = torch.cuda.Event()
+                ev.record(stream)
             self._access_event = ev
 
     def refresh_from_access(self, decay=0.5):
@@ -109,17 +113,16 @@ class GraphCacheServer:
         if getattr(self, "_access", None) is None or self.capability >= self.node_num:
             return
         cur = torch.cuda.current_stream(self.device)
-        with self._pending_lock:
+        with self._pending_lock:                           # see record_access: reads and the decay are ordered against every recorder
             access, prev = self._access, getattr(self, "_access_event", None)
-        if prev is not None:
-            cur.wait_event(prev)                           # the loading stream's last index_add_
-        nids = torch.topk(access, self.capability).indices
-        self.cache_fix_data(nids, self.get_feat_from_server(nids), is_full=False)
-        access.copy_((access.to(torch.float64) * decay).to(torch.int64))
-        ev = torch.cuda.Event()
-        ev.record(cur)
-        with self._pending_lock:
+            if prev is not None:
+                cur.wait_event(prev)                       # the loading stream's last index_add_
+            nids = torch.topk(access, self.capability).indices
+            access.copy_((access.to(torch.float64) * decay).to(torch.int64))
+            ev = torch.cuda.Event()
+            ev.record(cur)
             self._access_event = ev
+        self.cache_fix_data(nids, self.get_feat_from_server(nids), is_full=False)
 
     def get_feat_from_server(self, nids, to_gpu=False):
         """Rows of the host feature store for local ids `nids` (storage.py:100-125)."""
@@ -150,8 +153,11 @@ class GraphCacheServer:
             self.full_cached = is_full
 
     # ---- the hot call ----------------------------------------------------------------------------------------
-    def fetch_data(self, nids, out=None, stream=None):
-        """[len(nids), D] device tensor of the nodes' features (ids in the local space).  ONE launch and no host
+    def fetch_data(self, nids, out=None, stream=None, contiguous=False):
+        """[len(nids), D] device tensor of the nodes' features (ids in the local space).  The rows sit on a 16-byte pitch (602 bf16
+        columns -> 608): when D is not a whole number of vectors the result is a VIEW [n, D] of that padded buffer whose padding
+        columns are uninitialised (the reference's fetch_data, storage.py:151-198, returns a dense tensor); contiguous=True returns a
+        dense copy instead, for callers that flatten, export or assert contiguity.  ONE launch and no host
         synchronisation whatever the cache state: with a partition (`nid_map`) the kernel resolves hit -> cache slot of
         the LOCAL id, miss -> host row nid_map[local id] itself (dgll_hip_gather_rows_mapped).  Everything -- the id
         upload, the allocation of `out`, the launch -- is issued on `stream` (default: the current stream), so `out`
@@ -197,6 +203,8 @@ class GraphCacheServer:
                     done.record(stream)           # the counter is final once THIS stream has passed the gather
                 with self._pending_lock:
                     self._pending.append((counter, n, done))
+            if contiguous and not out.is_contiguous():
+                out = out.contiguous()
         return out
 
     def aggregate_data(self, nids, rowptr, reduce="mean", stream=None):

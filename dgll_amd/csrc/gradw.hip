@@ -92,8 +92,16 @@ __global__ __launch_bounds__(512) void gradw_splitk_kernel(const GradWArgs a) {
     const char* lX = static_cast<const char*>(l_second ? a.X[1] : a.X[0]);
     const int l_kcol0 = (l_second ? lks - a.kslabs[0] : lks) * 64;
     // descriptors based at the slab's first row; records end with the slab's last row: the ragged last step reads zeros
-    const gw_rsrc_t rx = gw_rsrc(lX + r_begin * l_lda_b, l_has_x ? (uint64_t)(r_end - r_begin) * l_lda_b : 0);
-    const gw_rsrc_t rg = gw_rsrc(static_cast<const char*>(a.G) + r_begin * ldg_b, (uint64_t)(r_end - r_begin) * ldg_b);
+    // The records end inside the slab's LAST row at that row's own (16-byte rounded) valid columns, not a whole pitch later: an
+    // operand may be a column slice of a wider matrix (x[:, 512:602] of a 608-wide allocation), and a pitch counted from the slice
+    // pointer would reach k0 * 2 bytes past the allocation in the matrix's last row.  Rows before the last may still
+    // be read past their valid columns -- into their own padding / the next row: finite garbage that only feeds outputs nobody reads.
+    const uint32_t l_valid_b = (uint32_t)((((l_second ? a.K[1] : a.K[0]) * 2 + 15) / 16) * 16);
+    const uint32_t g_valid_b = (uint32_t)(((a.N * 2 + 15) / 16) * 16);
+    const gw_rsrc_t rx = gw_rsrc(lX + r_begin * l_lda_b,
+                                 l_has_x ? (uint64_t)(r_end - r_begin - 1) * l_lda_b + (l_valid_b < l_lda_b ? l_valid_b : l_lda_b) : 0);
+    const gw_rsrc_t rg = gw_rsrc(static_cast<const char*>(a.G) + r_begin * ldg_b,
+                                 (uint64_t)(r_end - r_begin - 1) * ldg_b + (g_valid_b < ldg_b ? g_valid_b : ldg_b));
     const int lx_row = 8 * (wave & 1) + (lane >> 3);
     uint32_t lx_off = (uint32_t)lx_row * l_lda_b + (uint32_t)(l_kcol0 * 2 + (lane & 7) * 16);
     const int lg_row = 2 * wave + half;

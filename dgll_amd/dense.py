@@ -316,8 +316,17 @@ def _grad_weight_hip(x1, x2, g, out1=None, out2=None):
     slabs = max(1, min(4096, n_cu // types, -(-m // _GW_MIN_ROWS)))   # at least _GW_MIN_ROWS rows per slab: short operands (sampled
                                                                        # blocks) would otherwise pay for summing hundreds of near-empty partials
     ld_max = max(x1.stride(0), x2.stride(0) if x2 is not None else 0, g.stride(0))
-    while slabs < 4096 and (-(-m // slabs) + 256) * ld_max * 2 >= (1 << 32) - (1 << 20):   # the kernel's uint32 byte offsets
+
+    def slab_fits(sl):      # the kernel's own check (gradw.hip): rows per slab rounded up to 64, + 256 rows of prefetch overshoot, in uint32 bytes
+        per = max(64, -(-(-(-m // sl)) // 64) * 64)
+        return (per + 256) * ld_max * 2 < (1 << 32)
+
+    while slabs < 4096 and not slab_fits(slabs):
         slabs *= 2
+    slabs = min(slabs, 4096)
+    if not slab_fits(slabs):
+        raise ValueError("grad_weight: rows of %d elements are too wide for the split-K kernel's 32-bit slab offsets even at 4096 slabs "
+                         "(%d rows): split the reduction over row blocks" % (ld_max, m))
     need = int(_lib.lib.dgll_hip_grad_weight_workspace(k1, k2, slabs))
     key = (g.device.index, torch.cuda.current_stream(g.device).cuda_stream)
     ws = _GW_WORKSPACE.get(key)
