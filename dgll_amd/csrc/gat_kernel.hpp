@@ -113,17 +113,11 @@ __global__ __launch_bounds__(kBlock) void gat2_kernel(const EdgeArgs a) {
             __syncthreads();
         }
     }
+    // (Round 4, measured and dropped: requesting the NEXT item's first score rows one item ahead, behind the current row's gathers --
+    // forward 5.58 -> 5.61 ms, rows pass 6.04 -> 6.15; in the transposed pass the held registers cost a wavefront of occupancy.)
     WorkItem it = resolve_item(a, wave, 0);
     int col_first = 0;                                             // the item's first index batch (lane = edge), prefetched
     if (it.valid && it.b + lane < it.e) col_first = __builtin_nontemporal_load(a.col + it.b + lane);
-    // The score rows of an item's FIRST index batch are requested one item ahead as well (round 4): a row's dependent chain was
-    // indices (prefetched) -> score rows -> exp -> LDS records -> gathers, and at 51 edges per row almost every row is a single batch,
-    // so the score-row latency stood in front of every row's gathers.  Now it flies behind the previous row's gathers.
-    // (Not in the transposed pass: holding {s_i, dd_i} -- or s_i alone -- across the item takes it from 95 to 115-124 VGPRs and
-    // from 5 to 4 wavefronts per SIMD; the forward and rows passes stay at 5 with 9-10 registers more.)
-    constexpr bool PF = !INROW && KIND != 2;
-    float tv_pf[PF ? NH : 1];
-    if constexpr (PF) load_heads<NH>(a.T, col_first, a.tstride, a.heads, h0, tv_pf);
   for (int r = 0; !it.done; ++r) {
     // the NEXT item's bounds and first index batch are requested before this item's gathers: a row's dependent chain
     // (row pointers -> indices -> score rows -> gathers) then starts at the score rows
@@ -217,13 +211,8 @@ __global__ __launch_bounds__(kBlock) void gat2_kernel(const EdgeArgs a) {
         // covers 32 edges with two adjacent lanes per 32-byte score row: forward unchanged, transposed pass 6.4 -> 7.8 ms.)
         if constexpr (!INROW) {
             float tv[NH], dv[NH];
+            load_heads<NH>(a.T, col_cur, a.tstride, a.heads, h0, tv);        // idle lanes hold column 0: a valid row
             if constexpr (KIND == 2) load_heads<NH>(a.DD, col_cur, a.tstride, a.heads, h0, dv);
-            if (PF && k0 == b) {                                             // first batch of the item: requested one item ago
-#pragma unroll
-                for (int k = 0; k < NH; ++k) tv[k] = tv_pf[PF ? k : 0];
-            } else {
-                load_heads<NH>(a.T, col_cur, a.tstride, a.heads, h0, tv);    // idle lanes hold column 0: a valid row
-            }
 #pragma unroll
             for (int k = 0; k < NH; ++k) {
                 const float z = su[k] + tv[k];
@@ -233,10 +222,6 @@ __global__ __launch_bounds__(kBlock) void gat2_kernel(const EdgeArgs a) {
                 if constexpr (KIND == 0) rec[k * kRecStride + lane] = w;
                 if constexpr (KIND == 1) rec[k * kRecStride + lane] = make_float2(w, cc);
                 if constexpr (KIND == 2) { rec[k * kRecStride + lane] = make_float2(w, cc); rec1[k * kRecStride + lane] = dv[k] * cc; }
-            }
-            if constexpr (PF) {
-                if (k0 == b && nx.valid)   // the NEXT item's first score rows: its column ids were requested at the top of this item
-                    load_heads<NH>(a.T, col_next_item, a.tstride, a.heads, h0, tv_pf);
             }
         }
         // idle lanes of the last batch repeat its last valid column (same cache lines as a live request; their records are zero)
@@ -412,8 +397,6 @@ __global__ __launch_bounds__(kBlock) void gat2_kernel(const EdgeArgs a) {
             }
         }
     }
-   } else if (nx.valid) {   // this item was skipped (a long row, handled as chunks elsewhere): nobody above requested the next item's
-        if constexpr (PF) load_heads<NH>(a.T, col_next_item, a.tstride, a.heads, h0, tv_pf);   // first score rows
    }
     it = nx;
     col_first = col_next_item;

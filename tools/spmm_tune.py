@@ -58,8 +58,11 @@ def run(g, x, weighted, reps=6):
     return ts[len(ts) // 2], ts[0]
 
 
+thresholds = [int(v) for v in os.environ.get("TUNE_THRESHOLDS", "128,256").split(",")]
+rpws = [int(v) for v in os.environ.get("TUNE_RPW", "0,2,8").split(",")]
+remaps = [int(v) for v in os.environ.get("TUNE_REMAP", "0,1").split(",")]
 configs = [("thr%d rpw%d remap%d" % (t, r, f), dict(unroll=4, rpw=r, flags=f, threshold=t))
-           for t in (128, 256) for r in (0, 2, 8) for f in (0, 1)]
+           for t in thresholds for r in rpws for f in remaps]
 for variant in variants:
     base = build(variant)
     x = torch.randn(base.n_cols, feat, device=dev).to(torch.bfloat16)
