@@ -67,6 +67,8 @@ SIGNATURES = {
                                    C.c_float, _i32, _vp, _sz, _i32, _i32]),
     "dgll_hip_gat_bwd_rows": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp,
                                      _i64, _vp, _vp, _i64, _i32, _i32, C.c_float, _i32, _i32, _i32, _vp, _sz]),
+    "dgll_hip_gat_bwd_rows_split": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _i64, _vp, _vp,
+                                           _i64, _i32, _i32, C.c_float, _i32, _i32, _vp, _vp, _sz]),
     "dgll_hip_gat_bwd_cols": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp,
                                      _i32, _i64, _i32, _i32, C.c_float, _i32, _vp, _sz]),
     "dgll_hip_gat_fwd_strided": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _vp, _i64, _i32, _vp, _i64, _i32, _i32,

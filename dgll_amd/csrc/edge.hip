@@ -401,8 +401,7 @@ __global__ __launch_bounds__(kBlock) void gat_long_finalize_kernel(const EdgeArg
                     const float* w = a.ws + (int64_t)c * a.ws_ld + a.ws_vec;
                     sa += w[head]; sb += w[a.heads + head]; sw += w[2 * a.heads + head];
                 }
-                const float dd = -sw / a.DEN[row * a.heads + head];
-                my_head = head; my_den = sa + dd * sb; my_max = dd;
+                gat_finish_scores(a, row, head, sa, sb, sw);      // finalises, or parks / adds the sums in part3 (split launches)
             }
         } else {
             float sacc = 0.0f;
@@ -423,16 +422,9 @@ __global__ __launch_bounds__(kBlock) void gat_long_finalize_kernel(const EdgeArg
         }
     }
     __syncthreads();
-    if (my_head >= 0) {
+    if (my_head >= 0 && !(kind == 1 && a.exact_dd)) {       // (the exact rows pass wrote its scalars above)
         a.out_a[row * a.heads + my_head] = my_den;
         if (kind == 0 && a.out_b) a.out_b[row * a.heads + my_head] = my_max;
-        if (kind == 1 && a.exact_dd) {
-            if (a.out_b) a.out_b[row * a.heads + my_head] = my_max;          // dd_i
-            if (a.sd_out) {
-                a.sd_out[row * a.sd_stride + my_head] = a.S[row * a.heads + my_head];
-                a.sd_out[row * a.sd_stride + a.heads + my_head] = my_max;
-            }
-        }
     }
 }
 
@@ -468,8 +460,7 @@ __global__ __launch_bounds__(kBlock) void gat_long_finalize_wave_kernel(const Ed
                 const float* w = a.ws + (int64_t)c * a.ws_ld + a.ws_vec;
                 sa += w[lane]; sb += w[a.heads + lane]; sw += w[2 * a.heads + lane];
             }
-            h_max = -sw / a.DEN[row * a.heads + lane];                         // dd_i
-            h_den = sa + h_max * sb;                                           // ds_i
+            gat_finish_scores(a, row, lane, sa, sb, sw);                       // finalises, or parks / adds the sums in part3
         } else {
             float sacc = 0.0f;
             for (int c = cb; c < ce; ++c) sacc += a.ws[(int64_t)c * a.ws_ld + a.ws_vec + lane];
@@ -514,16 +505,9 @@ __global__ __launch_bounds__(kBlock) void gat_long_finalize_wave_kernel(const Ed
     }
     // per-(row, head) scalars: written after every lane has read the previous launch's denominators
     __builtin_amdgcn_wave_barrier();
-    if (lane < a.heads) {
+    if (lane < a.heads && !(kind == 1 && a.exact_dd)) {       // (the exact rows pass wrote its scalars above)
         a.out_a[row * a.heads + lane] = h_den;
         if (kind == 0 && a.out_b) a.out_b[row * a.heads + lane] = h_max;
-        if (kind == 1 && a.exact_dd) {
-            if (a.out_b) a.out_b[row * a.heads + lane] = h_max;              // dd_i
-            if (a.sd_out) {
-                a.sd_out[row * a.sd_stride + lane] = a.S[row * a.heads + lane];
-                a.sd_out[row * a.sd_stride + a.heads + lane] = h_max;
-            }
-        }
     }
 }
 
@@ -870,7 +854,7 @@ static int gat_bwd_rows_impl(void* stream, const dgll_csr_plan* plan, const int6
                              const void* out, int64_t ldo, const void* grad_out, int64_t ldg, int dtype,
                              const float* rowsum, const float* rowmax, void* dn, int64_t ldn, float* dd, float* sd_out,
                              int sd_stride, float* grad_S, int64_t n_rows, int heads, int fo, float alpha, int apply_elu,
-                             int mode, int accumulate, void* workspace, size_t workspace_bytes) {
+                             int mode, int accumulate, void* workspace, size_t workspace_bytes, float* part3 = nullptr) {
     if (n_rows <= 0) return DGLL_OK;
     EdgeArgs a{};
     int rc = gat_common(a, rowptr, col, n_rows, heads, fo, dtype, alpha, mode, apply_elu);
@@ -891,14 +875,18 @@ static int gat_bwd_rows_impl(void* stream, const dgll_csr_plan* plan, const int6
     hipStream_t s = static_cast<hipStream_t>(stream);
     int lpr, nh, lph;
     if (gat2_pick(a, &lpr, &nh, &grid.y)) {
-        a.exact_dd = accumulate == 3 ? 1 : 0;      // declared the only launch over these rows: dd_i from the pass's own dot products
+        // 3: declared the only launch over these rows; 4 / 5 / 6: first / middle / last launch of a split exact pass (part3 carries
+        // the partial sums): dd_i from the pass's own dot products
+        a.exact_dd = accumulate == 3 ? 1 : (accumulate >= 4 && accumulate <= 6) ? accumulate - 2 : 0;
+        DGLL_REQUIRE(a.exact_dd < 2 || part3, "a split exact rows pass needs the [n_rows, 3 * heads] partial-sum buffer");
+        a.part3 = part3;
         a.accumulate = accumulate == 1 ? 1 : 0;
         if (!gat2_launch_1(dtype, lpr, nh, grid, s, a, gat2_inrow(a, lpr, nh, esz, a.T, nullptr))) { set_error("no second-generation GAT kernel for this head layout"); return DGLL_ERR_UNSUPPORTED; }
     } else {
         rc = gat1_pick(a, epv, &lph, &lpr, &grid.y);
         if (rc != DGLL_OK) return rc;
         DGLL_REQUIRE(dd, "the first-generation rows pass writes dd");
-        a.accumulate = accumulate == 1 ? 1 : 0;    // first-generation kernels: dd from the stored output row in every mode
+        a.accumulate = (accumulate == 1 || accumulate == 5 || accumulate == 6) ? 1 : 0;    // first-generation kernels: dd from the stored output row in every mode
 #define CALL(L)                                                                                                              \
     if (dtype == DGLL_F32) hipLaunchKernelGGL((gat_bwd_rows_kernel<float, 4, L, 2>), grid, dim3(kBlock), 0, s, a, lph);      \
     else hipLaunchKernelGGL((gat_bwd_rows_kernel<bf16_t, 8, L, 2>), grid, dim3(kBlock), 0, s, a, lph);
@@ -919,6 +907,20 @@ DGLL_API int dgll_hip_gat_bwd_rows(void* stream, const dgll_csr_plan* plan, cons
     return gat_bwd_rows_impl(stream, plan, rowptr, col, H, ldh, S, T, 0, edge_scale, out, ldo, grad_out, ldg, dtype, rowsum, rowmax,
                              dn, ldn, dd, nullptr, 0, grad_S, n_rows, heads, fo, alpha, apply_elu, mode, accumulate, workspace,
                              workspace_bytes);
+}
+
+// dgll_hip_gat_bwd_rows for a rows pass SPLIT over column halves of A (the partitioned path: owned-columns CSR, then halo-columns
+// CSR) with the exact dd_i: phase 4 = first launch (writes DN; partial sums -> partial3), 5 = a middle launch, 6 = the last
+// (adds partial3, writes dd and grad_S).  partial3: caller-owned fp32 [n_rows, 3 * heads], the same buffer for every phase.
+DGLL_API int dgll_hip_gat_bwd_rows_split(void* stream, const dgll_csr_plan* plan, const int64_t* rowptr, const int32_t* col,
+                                         const void* H, int64_t ldh, const float* S, const float* T, const void* out, int64_t ldo,
+                                         const void* grad_out, int64_t ldg, int dtype, const float* rowsum, void* dn, int64_t ldn,
+                                         float* dd, float* grad_S, int64_t n_rows, int heads, int fo, float alpha, int apply_elu,
+                                         int phase, float* partial3, void* workspace, size_t workspace_bytes) {
+    DGLL_REQUIRE(dd && partial3 && phase >= 4 && phase <= 6, "dgll_hip_gat_bwd_rows_split: phase 4 (first) / 5 (middle) / 6 (last), non-NULL dd and partial3");
+    return gat_bwd_rows_impl(stream, plan, rowptr, col, H, ldh, S, T, 0, nullptr, out, ldo, grad_out, ldg, dtype, rowsum, nullptr,
+                             dn, ldn, dd, nullptr, 0, grad_S, n_rows, heads, fo, alpha, apply_elu, 0, phase, workspace,
+                             workspace_bytes, partial3);
 }
 
 // Pass 2 of the backward over a transposed structure (rows = source nodes j, columns = destination rows i):

@@ -30,7 +30,10 @@ struct EdgeArgs {
     float alpha, sign;          // leaky-relu slope; -1: exp(-lrelu) (sparseGatConv), +1: softmax(+lrelu) (gatConv)
     int apply_elu, use_max;
     int raw, accumulate;        // partitioned use: raw = leave the row un-normalised (num, den); accumulate = add what is already there
-    int exact_dd;               // second-generation rows pass, single launch: dd_i from the pass's own dot products (gat_kernel.hpp)
+    int exact_dd;               // second-generation rows pass: dd_i from the pass's own dot products (gat_kernel.hpp).  1 = the only
+                                // launch over these rows; split over column halves of A: 2 = first launch (partial sums -> part3),
+                                // 3 = a middle one (part3 +=), 4 = the last (adds part3, then finalises ds_i, dd_i)
+    float* part3;               // fp32 [n_rows, 3 * heads]: (sa, sb, sw) per (row, head) between the launches of a split exact rows pass
     int32_t* arg_out;           // segment_max: int32 [n_rows, ld] source row of the maximum
     // long-row schedule (threshold == 0: none): chunk work items come first in the grid, partials go to `ws`
     int threshold;
@@ -53,6 +56,22 @@ struct EdgeArgs {
     const float* attn2;         // fp32 [heads * fo]
     const float* gs_rows;       // fp32 [n_rows of this pass, heads]: grad_S of the pass's rows (from the rows pass)
 };
+
+// Row epilogue of the exact rows pass for one (row, head): the launch's sums (sa, sb, sw) = (sum c.dot, sum c, sum w.dot) -- plus the
+// partial sums an earlier launch over another column half of A left in part3 -- either go (back) to part3 (more launches follow) or
+// are finalised: dd_i = -sw / den_i, ds_i = sa + dd_i sb (bilinear in the sums, so no launch can finalise its own share).
+__device__ __forceinline__ void gat_finish_scores(const EdgeArgs& a, int64_t row, int head, float sa, float sb, float sw) {
+    float* p3 = a.part3 ? a.part3 + (row * a.heads + head) * 3 : nullptr;
+    if (a.exact_dd >= 3) { sa += p3[0]; sb += p3[1]; sw += p3[2]; }
+    if (a.exact_dd == 2 || a.exact_dd == 3) { p3[0] = sa; p3[1] = sb; p3[2] = sw; return; }
+    const float dd = -sw / a.DEN[row * a.heads + head];
+    a.out_a[row * a.heads + head] = sa + dd * sb;
+    if (a.out_b) a.out_b[row * a.heads + head] = dd;
+    if (a.sd_out) {
+        a.sd_out[row * a.sd_stride + head] = a.S[row * a.heads + head];
+        a.sd_out[row * a.sd_stride + a.heads + head] = dd;
+    }
+}
 
 // Work item of this wavefront: a whole (short) row, or one chunk of a long row.
 struct WorkItem {

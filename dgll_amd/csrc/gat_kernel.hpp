@@ -168,7 +168,7 @@ __global__ __launch_bounds__(kBlock) void gat2_kernel(const EdgeArgs a) {
             part = fmaf(dn[i], hp, part);
         }
         if (legacy) dd = -head_sum_c<LPH>(part);
-        if (slot == 0 && col_ok && it.first && a.accumulate != 1) {   // per-row outputs: written once (row itself / first chunk, first launch)
+        if (slot == 0 && col_ok && it.first && a.accumulate != 1 && a.exact_dd < 3) {   // per-row outputs: written once (row itself / first chunk, first launch)
             VecIO<XT, EPV>::store_nt(static_cast<XT*>(a.Y) + row * a.ldy + c0, dn);
             if (hs == 0 && legacy) {
                 if (a.out_b) a.out_b[row * a.heads + head] = dd;
@@ -358,13 +358,7 @@ __global__ __launch_bounds__(kBlock) void gat2_kernel(const EdgeArgs a) {
                     float* wsp = a.ws + it.chunk * a.ws_ld + a.ws_vec;
                     wsp[head] = sa_t; wsp[a.heads + head] = sb_t; wsp[2 * a.heads + head] = sw_t;
                 } else {
-                    const float dd_x = -sw_t / a.DEN[row * a.heads + head];
-                    a.out_a[row * a.heads + head] = sa_t + dd_x * sb_t;
-                    if (a.out_b) a.out_b[row * a.heads + head] = dd_x;
-                    if (a.sd_out) {
-                        a.sd_out[row * a.sd_stride + head] = a.S[row * a.heads + head];
-                        a.sd_out[row * a.sd_stride + a.heads + head] = dd_x;
-                    }
+                    gat_finish_scores(a, row, head, sa_t, sb_t, sw_t);
                 }
             }
         } else {

@@ -289,6 +289,7 @@ class _Exchange:
         self.watchdog = watchdog if watchdog is not None else ExchangeWatchdog(rank=part.rank)
         self.bytes_sent = self.bytes_received = self.calls = 0
         self.phase = "exchange"
+        self.fault_p2p = False      # tests only: the p2p form delivers the right number of rows in the wrong order
 
     def _staged(self, t):
         return t.is_cuda and self.part.world > 1 and dist.is_initialized() and dist.get_backend(self.group) != "nccl"
@@ -312,6 +313,8 @@ class _Exchange:
                     works.append(dist.all_to_all_single(rb, sb.contiguous(), output_split_sizes=list(r_counts),
                                                         input_split_sizes=list(s_counts), group=self.group, async_op=True))
                 continue
+            if self.fault_p2p and sb.shape[0] > 1:
+                sb = torch.roll(sb, 1, 0)
             so = ro = 0
             for q in range(p.world):
                 if s_counts[q]:
@@ -612,12 +615,15 @@ class DistGatAggregate(torch.autograd.Function):
         _, dn = engine.alloc_rows(p.n_own, feat, dtype)
         dd = torch.empty((p.n_own, heads), dtype=torch.float32, device=dev)
         grad_s = torch.empty((p.n_own, heads), dtype=torch.float32, device=dev)
-        # two launches over the column halves of A when there is a halo (0 = first, 1 = second); alone, the local launch is declared
-        # the only one (3) and runs the exact form of dd_i (csrc/gat_kernel.hpp)
+        # two launches over the column halves of A when there is a halo: the exact dd_i is bilinear in the halves' sums, so the first
+        # launch parks its (sa, sb, sw) in `partial` and the second finalises (phases 4 / 6); alone, the local launch is declared the
+        # only one (3)  -- csrc/gat_kernel.hpp
+        partial = torch.empty((p.n_own, 3 * heads), dtype=torch.float32, device=dev) if p.n_halo else None
         oe.gat_bwd_rows_part(p.local, h_view, s_own, t_own, out, gv, rowsum, dn, dd, grad_s, heads, fo, alpha, apply_elu,
-                             0 if p.n_halo else 3)
+                             4 if p.n_halo else 3, partial=partial)
         if p.n_halo:
-            oe.gat_bwd_rows_part(p.halo, halo_h, s_own, halo_t, out, gv, rowsum, dn, dd, grad_s, heads, fo, alpha, apply_elu, True)
+            oe.gat_bwd_rows_part(p.halo, halo_h, s_own, halo_t, out, gv, rowsum, dn, dd, grad_s, heads, fo, alpha, apply_elu, 6,
+                                 partial=partial)
         if ctx.halo_local:      # gradients of own and halo rows side by side; nothing travels
             _, gh_all = engine.alloc_rows(p.n_own + p.n_halo, feat, dtype)
             gt_all = torch.empty((p.n_own + p.n_halo, heads), dtype=torch.float32, device=dev)
@@ -807,7 +813,32 @@ class DistGraph:
             if row[p.world + p.rank] != p.send_counts[q]:
                 raise RuntimeError("halo exchange lists disagree: rank %d sends %d rows to rank %d, which expects %d "
                                    "(the ranks did not build the same graph)" % (p.rank, p.send_counts[q], q, row[p.world + p.rank]))
-        self.self_test()
+        # every rank must reach the same verdict: a form that misdelivers on ONE rank is abandoned by all of them together
+        err = None
+        try:
+            self.self_test()
+        except RuntimeError as exc:
+            err = exc
+        bad = torch.tensor([0 if err is None else 1], dtype=torch.int32, device=comm_dev)
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=self.exchange.group)
+        if int(bad.item()) == 0:
+            return
+        if self.exchange.form == "p2p" and os.environ.get("DGLL_EXCHANGE_FALLBACK", "1") != "0":
+            if p.rank == 0:
+                print("dgll_amd.dist: the grouped point-to-point exchange failed its start-up self-test%s; switching every rank to "
+                      "DGLL_EXCHANGE=alltoall" % ("" if err is None else " (%s)" % err), file=sys.stderr, flush=True)
+            self.exchange.form = "alltoall"
+            err2 = None
+            try:
+                self.self_test()
+            except RuntimeError as exc:
+                err2 = exc
+            bad = torch.tensor([0 if err2 is None else 1], dtype=torch.int32, device=comm_dev)
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=self.exchange.group)
+            if int(bad.item()) == 0:
+                return
+            err = err2 or err
+        raise err if err is not None else RuntimeError("rank %d: another rank's exchange self-test failed" % p.rank)
 
     def self_test(self):
         p, ex = self.part, self.exchange

@@ -406,12 +406,25 @@ def gat_fwd_part(graph, h, s_rows, t_cols, out, rowsum, heads, fo, alpha, apply_
     _lib.check(code, "dgll_hip_gat_fwd_ex")
 
 
-def gat_bwd_rows_part(graph, h_cols, s_rows, t_cols, out, g, rowsum, dn, dd, grad_s, heads, fo, alpha, apply_elu, accumulate):
+def gat_bwd_rows_part(graph, h_cols, s_rows, t_cols, out, g, rowsum, dn, dd, grad_s, heads, fo, alpha, apply_elu, accumulate,
+                      partial=None):
     """Rows pass over one column half of A.  accumulate: False / 0 = first (or only) launch (writes DN, dd, grad_s; dd_i from the
-    stored output row), True / 1 = a further half (grad_s +=), 3 = DECLARED the only launch over these rows: exact dd_i."""
+    stored output row), True / 1 = a further half (grad_s +=), 3 = DECLARED the only launch over these rows: exact dd_i;
+    4 / 5 / 6 with `partial` (fp32 [n_rows, 3 * heads], the same buffer every time) = first / middle / last launch of a SPLIT
+    exact pass (dgll_hip_gat_bwd_rows_split)."""
     dev = out.device
     ws, nbytes = _ws(graph.plan(), heads, fo, dev)
     with torch.cuda.device(dev):
+        if int(accumulate) >= 4:
+            if partial is None or partial.dtype != torch.float32 or partial.numel() < graph.n_rows * 3 * heads or not partial.is_contiguous():
+                raise ValueError("a split exact rows pass needs a contiguous fp32 [n_rows, 3 * heads] `partial` buffer")
+            code = _lib.lib.dgll_hip_gat_bwd_rows_split(
+                _stream(dev), graph.plan(), graph.rowptr.data_ptr(), graph.col.data_ptr(), h_cols.data_ptr(), h_cols.stride(0),
+                s_rows.data_ptr(), t_cols.data_ptr(), out.data_ptr(), out.stride(0), g.data_ptr(), g.stride(0), _dtype_code(out),
+                rowsum.data_ptr(), dn.data_ptr(), dn.stride(0), dd.data_ptr(), grad_s.data_ptr(), graph.n_rows, heads, fo,
+                float(alpha), int(apply_elu), int(accumulate), partial.data_ptr(), ws.data_ptr() if ws is not None else None, nbytes)
+            _lib.check(code, "dgll_hip_gat_bwd_rows_split")
+            return
         code = _lib.lib.dgll_hip_gat_bwd_rows(
             _stream(dev), graph.plan(), graph.rowptr.data_ptr(), graph.col.data_ptr(), h_cols.data_ptr(), h_cols.stride(0),
             s_rows.data_ptr(), t_cols.data_ptr(), None, out.data_ptr(), out.stride(0), g.data_ptr(), g.stride(0),

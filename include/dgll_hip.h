@@ -158,6 +158,15 @@ int dgll_hip_gat_bwd(void* stream, const dgll_csr_plan* plan, const dgll_csr_pla
  *                         dgll_hip_gat_bwd and the *_strided entry points do);
  *   dgll_hip_gat_bwd_cols pass 2 over one transposed structure: rows = source nodes (Hrow, T_row), columns = destination
  *                         rows (dn, S_col, dd_col, rowmax_col).                                                     */
+/* dgll_hip_gat_bwd_rows_split: the rows pass over SEVERAL column halves of A with the exact dd_i (ds_i is bilinear in the sums
+ * (sum c.dot, sum c, sum w.dot), so no launch can finalise its own share): phase 4 = first launch (writes DN, parks the sums in
+ * partial3), 5 = a middle one, 6 = the last (adds partial3, writes dd and grad_S).  partial3: fp32 [n_rows, 3 * heads], caller-owned,
+ * the same buffer for every phase; mode 0 (sparseGatConv form) only.                                                           */
+int dgll_hip_gat_bwd_rows_split(void* stream, const dgll_csr_plan* plan, const int64_t* rowptr, const int32_t* col,
+                                const void* H, int64_t ldh, const float* S, const float* T, const void* out, int64_t ldo,
+                                const void* grad_out, int64_t ldg, int dtype, const float* rowsum, void* dn, int64_t ldn, float* dd,
+                                float* grad_S, int64_t n_rows, int heads, int fo, float alpha, int apply_elu, int phase,
+                                float* partial3, void* workspace, size_t workspace_bytes);
 int dgll_hip_gat_fwd_ex(void* stream, const dgll_csr_plan* plan, const int64_t* rowptr, const int32_t* col,
                         const void* H, int64_t ldh, const float* S, const float* T, const float* edge_scale,
                         void* out, int64_t ldo, int dtype, float* rowsum, int64_t n_rows, int heads, int fo, float alpha,

@@ -150,6 +150,33 @@ def _bad_lists_worker(rank, world, port):
         dist.destroy_process_group()
 
 
+def _fallback_worker(rank, world, port):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), DGLL_EXCHANGE="p2p")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dgll_amd import dist as ddist
+        from dgll_amd import synth
+
+        full = synth.rmat_graph(7, 6, seed=2, device="cpu", symmetric=True, weighted=False)
+        part = ddist.partition_contiguous(full, world, rank)
+        engine = ddist.DistGraph(part, "cpu", spmm_fn=_cpu_spmm)
+        if rank == 1:
+            engine.exchange.fault_p2p = True           # ONE rank's point-to-point form misdelivers
+        engine.verify()                                # ... every rank switches to the all-to-all form together and passes
+        assert engine.exchange.form == "alltoall"
+        torch.manual_seed(0)                            # the same features on every rank
+        x = torch.randn(full.n_rows, 4, dtype=torch.float64)
+        blk = slice(part.own_begin, part.own_end)
+        out = engine.aggregate(x[blk].clone(), reduce="mean")
+        np.testing.assert_allclose(out.numpy(), _cpu_spmm(full, x, reduce="mean")[blk].numpy(), rtol=1e-5, atol=1e-6)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_failed_p2p_self_test_moves_every_rank_to_the_alltoall_form():
+    mp.spawn(_fallback_worker, args=(3, _free_port()), nprocs=3, join=True)
+
+
 def test_start_up_self_test_catches_rows_that_arrive_in_the_wrong_place():
     mp.spawn(_bad_lists_worker, args=(2, _free_port()), nprocs=2, join=True)
 

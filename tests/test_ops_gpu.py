@@ -595,3 +595,14 @@ def test_gat_split_launches_equal_the_fused_one(cuda_device, dtype):
     torch.testing.assert_close(dn1.float(), dn.float(), rtol=0, atol=0)
     torch.testing.assert_close(gs1, gs_ref, **gtol)
     torch.testing.assert_close(dd1, dd, **(dict(rtol=2e-3, atol=2e-4) if dtype == torch.float32 else dict(rtol=5e-2, atol=5e-2)))
+    # the SPLIT exact pass (phases 4 / 6, partial sums parked between the launches): the same dd_i and grad_s as the single exact
+    # launch up to the order of the fp32 additions -- far inside what the stored-output form (above) differs by in bf16
+    dn2, dd2, gs2 = _empty_padded(n, heads * fo, dtype, d), torch.empty(n, heads, device=d), torch.empty(n, heads, device=d)
+    partial = torch.empty(n, 3 * heads, device=d)
+    gat_bwd_rows_part(halves[0], hd, sd, td, out, go, rowsum, dn2, dd2, gs2, heads, fo, 0.2, True, accumulate=4, partial=partial)
+    gat_bwd_rows_part(halves[1], hd, sd, td, out, go, rowsum, dn2, dd2, gs2, heads, fo, 0.2, True, accumulate=6, partial=partial)
+    torch.testing.assert_close(dn2.float(), dn1.float(), rtol=0, atol=0)
+    torch.testing.assert_close(dd2, dd1, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(gs2, gs1, rtol=1e-4, atol=2e-5)
+    with pytest.raises(ValueError):
+        gat_bwd_rows_part(halves[0], hd, sd, td, out, go, rowsum, dn2, dd2, gs2, heads, fo, 0.2, True, accumulate=4)
