@@ -13,4 +13,10 @@ for c in FETCH_SIZE WRITE_SIZE TCC_HIT_sum_TCC_MISS_sum; do
   cp gpurun_out/$SAGE/pmc_$c.csv profiles/${R}_pmc_$c.csv
   cp gpurun_out/$GAT/pmc_$c.csv profiles/${R}_gat_pmc_$c.csv
 done
+# the scaling tools' logs, the default line and the step trace of the same call (gpurun_out/<round>p/), when present
+E=gpurun_out/${R}p
+for f in scaling_model.log scaling_trace_n8.log partition_stats.log step_trace.log; do
+  [ -f $E/$f ] && grep -v "amdgpu.ids" $E/$f > profiles/${R}_$f
+done
+[ -f $E/bench_default.json ] && cp $E/bench_default.json profiles/${R}_bench_default.json
 grep -c Cijk profiles/${R}_bench_kernel_stats.csv profiles/${R}_gat_kernel_stats.csv || true
