@@ -1017,9 +1017,9 @@ def run_minibatch(args, c):
     cache.auto_cache(deg, capacity=int(args.mb_cache_frac * args.mb_nodes))
     # The producers run up to six batches ahead (queue of 4 loaded + 2 sampled): a short timed region would be served from that
     # backlog and report the consumer's speed, not the pipeline's.  Steady state needs the backlog to be a small share of the batches
-    # timed: at least 8 warm-up and 64 timed batches here, whatever --steps / --warmup say (the JSON line carries the counts used).
-    args.warmup = max(args.warmup, 8)
-    args.steps = max(args.steps, 64)
+    # timed: at least 16 warm-up and 192 timed batches here (a 64-batch window, 0.15 s, moved by +-30 % from run to run), whatever --steps / --warmup say (the JSON line carries the counts used).
+    args.warmup = max(args.warmup, 16)
+    args.steps = max(args.steps, 192)
     # ... + a TAIL of 16 batches outside the timed window: the per-launch HIP events behind the launch tables cost the consumer thread
     # ~0.2 ms per batch (two event records per launch), so they are switched on for the tail only
     tail = 16

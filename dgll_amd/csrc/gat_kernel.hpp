@@ -70,15 +70,19 @@ __device__ __forceinline__ float head_sum_c(float v) {
 
 // KIND 0: forward.  KIND 1: backward over the rows of A (DN, DD, grad_S).  KIND 2: backward over the rows of A^T (grad_H, grad_T).
 // See edge.hip for the argument roles of each pass (they are unchanged).  Records (one per edge and head, wave-private LDS):
-//   KIND 0: w_ij            KIND 1: { w_ij, c_ij = w_ij * sign * lrelu'(z_ij) }            KIND 2: { w_ij, c_ij } and dd_i * c_ij
+//   KIND 0: w_ij     KIND 1: w_ij carrying the sign of z_ij (c_ij = w_ij * sign * lrelu'(z_ij) needs only that bit)     KIND 2: { w_ij, c_ij } and dd_i * c_ij
 // INROW (one head, scores in the padding of the gathered rows themselves): the lane group's first idle lane reads the 16 bytes
 // behind the row's last column WITH the row -- t_j (or {s_i, dd_i} in the transposed pass) arrives with the gather, is broadcast
 // inside the lane group, and the record phase (a dependent load per batch, the LDS hand-over) disappears: for 8-lane rows the
 // passes are bound by exactly that per-row latency chain.
 template <typename XT, typename YT, int EPV, int LPR, int NH, int U, int KIND, bool INROW = false>
-__global__ __launch_bounds__(kBlock) void gat2_kernel(const EdgeArgs a) {
+// (the narrow in-row rows pass is held at 6 wavefronts per SIMD: the exact dd_i's extra sum took it from 79 to 86 VGPRs and from 6 to
+// 5 wavefronts, 2.56 -> 2.88 ms; bounded it fits 77 registers without scratch.  The 8-head form needs 12 bytes of scratch at that bound
+// and measured no faster: it runs at 83 registers / 5 wavefronts, 6.02 -> 6.17 ms for the exactness.)
+__global__ __launch_bounds__(kBlock, (KIND == 1 && INROW && sizeof(XT) == 2) ? 6 : 1) void gat2_kernel(const EdgeArgs a) {
     typedef VecIO<XT, EPV> IO;
-    typedef typename std::conditional<KIND != 0, float2, float>::type rec_t;   // backward passes: {w_ij, c_ij} (KIND 2 also dd_i * c_ij in rec1)
+    typedef typename std::conditional<KIND == 2, float2, float>::type rec_t;   // KIND 2: {w_ij, c_ij}, plus dd_i * c_ij in rec1;
+                                                                               // KIND 1: w_ij with the sign of z_ij (c_ij = w_ij * f, f = sign or sign * alpha)
     constexpr int SLOTS = kWave / LPR;
     constexpr int LPH = LPR / NH;                                  // lanes per head
     constexpr bool BF = sizeof(XT) == 2;
@@ -220,7 +224,7 @@ __global__ __launch_bounds__(kBlock) void gat2_kernel(const EdgeArgs a) {
                 w = (live && h0 + k < a.heads) ? w : 0.0f;
                 const float cc = w * a.sign * (z > 0.0f ? 1.0f : a.alpha);
                 if constexpr (KIND == 0) rec[k * kRecStride + lane] = w;
-                if constexpr (KIND == 1) rec[k * kRecStride + lane] = make_float2(w, cc);
+                if constexpr (KIND == 1) rec[k * kRecStride + lane] = z > 0.0f ? w : -w;
                 if constexpr (KIND == 2) { rec[k * kRecStride + lane] = make_float2(w, cc); rec1[k * kRecStride + lane] = dv[k] * cc; }
             }
         }
@@ -253,7 +257,7 @@ __global__ __launch_bounds__(kBlock) void gat2_kernel(const EdgeArgs a) {
                     w = (j + u * SLOTS + slot < nb) ? w : 0.0f;
                     const float cc = w * a.sign * (z > 0.0f ? 1.0f : a.alpha);
                     if constexpr (KIND == 0) rr[u] = w;
-                    if constexpr (KIND == 1) rr[u] = make_float2(w, cc);
+                    if constexpr (KIND == 1) rr[u] = z > 0.0f ? w : -w;
                     if constexpr (KIND == 2) {
                         rr[u] = make_float2(w, cc);
                         r1[u] = __shfl(__uint_as_float(v[u].y), tlane) * cc;    // dd_i sits next to s_i
@@ -284,9 +288,13 @@ __global__ __launch_bounds__(kBlock) void gat2_kernel(const EdgeArgs a) {
                             for (int i = 0; i < EPV; ++i) dot = fmaf(dn[i], f[i], dot);
                         }
                         if constexpr (INROW) dot = col_ok ? dot : 0.0f;   // the score lane holds score bits, not features: 0 x NaN
-                        sa = fmaf(dot, rr[u].y, sa);
-                        sb += rr[u].y;
-                        sw = fmaf(dot, rr[u].x, sw);
+                        // one record per (edge, head): |r| = w_ij, its sign = the sign of z_ij; c_ij = w_ij * f
+                        const float wv = fabsf(rr[u]);
+                        const float fz = rr[u] > 0.0f ? a.sign : a.sign * a.alpha;
+                        const float dw = dot * wv;
+                        sw += dw;
+                        sa = fmaf(fz, dw, sa);
+                        sb = fmaf(fz, wv, sb);
                     } else {
                         float f[EPV];
                         IO::unpack(v[u], f);

@@ -138,7 +138,7 @@ def test_bench_gat_workload_one_and_two_ranks():
 @pytest.mark.parametrize("fused", [True, False])
 def test_bench_minibatch_and_rmat_workloads(fused):
     """bench.py --workload minibatch (BASELINE config 2: sampler thread -> loader thread with the feature cache -> training) and
-    --workload rmat27 (config 5's shape at a small scale): the JSON contract, the steady-state window (at least 8 + 64 batches
+    --workload rmat27 (config 5's shape at a small scale): the JSON contract, the steady-state window (at least 16 + 192 batches
     whatever --steps says), the fields the judge reads, and that reducing the outermost hop straight out of the cache changes nothing
     but the speed."""
     shape = ["--workload", "minibatch", "--mb-nodes", "20000", "--mb-undirected-edges", "400000", "--mb-feats", "50", "--mb-classes", "7",
@@ -148,7 +148,7 @@ def test_bench_minibatch_and_rmat_workloads(fused):
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + shape, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-3000:]
     d = _last_json(res.stdout)
-    assert d["config"]["workload_id"] == "minibatch" and d["steps"] == 64 and d["warmup"] == 8
+    assert d["config"]["workload_id"] == "minibatch" and d["steps"] == 192 and d["warmup"] == 16
     assert d["config"]["outermost_hop"].startswith("reduced" if fused else "fetched")
     for key in ("gpu_side_ms_per_batch", "gpu_side_ms_per_batch_p50", "gpu_side_ms_per_batch_p95", "host_sampler_ms_per_batch",
                 "host_sampler_threads", "sampler_mode", "consumer_host_ms_per_batch", "loader_host_ms_per_batch", "cache_miss_rate",
@@ -177,7 +177,7 @@ def test_bench_minibatch_single_stream_mode_still_runs():
     assert res.returncode == 0, res.stderr[-3000:]
     d = _last_json(res.stdout)
     assert d["host_sampler_threads"] == 0 and "sequential" in d["sampler_mode"] and d["outermost_hop_translation"] == "host"
-    assert d["loss"] == d["loss"] and d["steps"] == 64
+    assert d["loss"] == d["loss"] and d["steps"] == 192
 
 
 def test_default_line_carries_the_other_baseline_configs():

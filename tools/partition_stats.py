@@ -40,6 +40,12 @@ for world in (2, 4, 8):
     rows = [bounds[r + 1] - bounds[r] for r in range(world)]
     edges = [int(g.rowptr[bounds[r + 1]] - g.rowptr[bounds[r]]) for r in range(world)]
     print("N=%d: rows per part %s, edges per part (max/mean %.3f)" % (world, rows, max(edges) / (sum(edges) / world)))
+    if world == 8:      # every rank's share: the step time of a real run is the slowest rank's
+        for r in range(world):
+            pr = ddist.partition_contiguous(g, world, r, bounds)
+            print("   rank %d: %7d own rows, %8d local + %7d halo edges (%.1f %% of its edges), %6d halo rows (%.2fx own)" % (
+                r, pr.n_own, pr.local.nnz, pr.halo.nnz, 100.0 * pr.halo.nnz / max(pr.nnz, 1), pr.n_halo, pr.n_halo / max(pr.n_own, 1)))
+            del pr
     p = ddist.partition_contiguous(g, world, 0, bounds)
     e0, e1 = int(g.rowptr[bounds[0]]), int(g.rowptr[bounds[1]])
     col = g.col[e0:e1].long()
