@@ -340,7 +340,7 @@ def spmm_kernel_fragment(feat, dtype_name, weighted, extra):
 
 
 def gat_kernel_fragment(heads, fo, dtype_name, kind, packed=False):
-    """gat2_kernel instantiation of a pass (kind 0 forward, 1 rows, 2 transposed rows) -- edge.hip's gat2_pick / gat2_inrow."""
+    """gat2_kernel instantiation of a pass (kind 0 forward, 3 rows in the exact-dd form -- 1: its stored-output form --, 2 transposed rows) -- edge.hip's gat2_pick / gat2_inrow."""
     bf = "bfloat16" in dtype_name
     epv = 8 if bf else 4
     vph = fo // epv
@@ -445,7 +445,7 @@ def launch_tables(launches, local_rows, heads_of=None):
             name = "gat %s %d heads x %d %s%s nnz=%d" % (kind, heads, fo, dt.replace("torch.", ""), (" " + packed) if packed else "", tag_nnz)
             table[name] = {"count": cnt, "avg_ms": avg_ms, "nnz": tag_nnz, "feat": heads * fo, "heads": heads, "pass": kind,
                            "scores_in_row_padding": bool(packed),
-                           "kernel_fragment": gat_kernel_fragment(heads, fo, dt, {"fwd": 0, "bwd_rows": 1, "bwd_cols": 2}[kind], bool(packed))}
+                           "kernel_fragment": gat_kernel_fragment(heads, fo, dt, {"fwd": 0, "bwd_rows": 3, "bwd_cols": 2}[kind], bool(packed))}
         elif tag[0] in ("transform", "transform_dual", "grad_weight"):
             kind, m, k1, k2, n_out, extra = tag
             b_alg = m * (k1 + k2 + n_out) * 2 + (m * n_out * 2 if ("gate" in extra or "addend" in extra) else 0)

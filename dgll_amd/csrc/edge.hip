@@ -881,7 +881,8 @@ static int gat_bwd_rows_impl(void* stream, const dgll_csr_plan* plan, const int6
         DGLL_REQUIRE(a.exact_dd < 2 || part3, "a split exact rows pass needs the [n_rows, 3 * heads] partial-sum buffer");
         a.part3 = part3;
         a.accumulate = accumulate == 1 ? 1 : 0;
-        if (!gat2_launch_1(dtype, lpr, nh, grid, s, a, gat2_inrow(a, lpr, nh, esz, a.T, nullptr))) { set_error("no second-generation GAT kernel for this head layout"); return DGLL_ERR_UNSUPPORTED; }
+        const bool inrow = gat2_inrow(a, lpr, nh, esz, a.T, nullptr);
+        if (!(a.exact_dd ? gat2_launch_3(dtype, lpr, nh, grid, s, a, inrow) : gat2_launch_1(dtype, lpr, nh, grid, s, a, inrow))) { set_error("no second-generation GAT kernel for this head layout"); return DGLL_ERR_UNSUPPORTED; }
     } else {
         rc = gat1_pick(a, epv, &lph, &lpr, &grid.y);
         if (rc != DGLL_OK) return rc;

@@ -79,11 +79,13 @@ template <typename XT, typename YT, int EPV, int LPR, int NH, int U, int KIND, b
 // (the narrow in-row rows pass is held at 6 wavefronts per SIMD: the exact dd_i's extra sum took it from 79 to 86 VGPRs and from 6 to
 // 5 wavefronts, 2.56 -> 2.88 ms; bounded it fits 77 registers without scratch.  The 8-head form needs 12 bytes of scratch at that bound
 // and measured no faster: it runs at 83 registers / 5 wavefronts, 6.02 -> 6.17 ms for the exactness.)
-__global__ __launch_bounds__(kBlock, (KIND == 1 && INROW && sizeof(XT) == 2) ? 6 : 1) void gat2_kernel(const EdgeArgs a) {
+__global__ __launch_bounds__(kBlock, ((KIND == 1 || KIND == 3) && INROW && sizeof(XT) == 2) ? 6 : 1) void gat2_kernel(const EdgeArgs a) {
     typedef VecIO<XT, EPV> IO;
     typedef typename std::conditional<KIND == 2, float2, float>::type rec_t;   // KIND 2: {w_ij, c_ij}, plus dd_i * c_ij in rec1;
                                                                                // KIND 1: w_ij with the sign of z_ij (c_ij = w_ij * f, f = sign or sign * alpha)
     constexpr int SLOTS = kWave / LPR;
+    constexpr bool ROWS = KIND == 1 || KIND == 3;                   // the rows pass: KIND 3 = its exact-dd form ALONE (no code of the
+    constexpr bool EXACT = KIND == 3;                               // stored-output form: 75 instead of 83 VGPRs, 6 wavefronts per SIMD)
     constexpr int LPH = LPR / NH;                                  // lanes per head
     constexpr bool BF = sizeof(XT) == 2;
     __shared__ rec_t rec_all[kWavesPerBlock][NH * kRecStride];
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(kBlock, (KIND == 1 && INROW && sizeof(XT) == 2) ? 6
     uint32_t rp[4] = {0u, 0u, 0u, 0u}; // bf16: DN_i (KIND 1) or h_j (KIND 2) as packed pairs for v_dot2
     float hj[EPV];                     // KIND 2 fp32: h_j
     float dd = 0.0f;
-    if constexpr (KIND == 1) {
+    if constexpr (ROWS) {
         const float inv_den = 1.0f / a.DEN[row * a.heads + head];
         float g[EPV], o[EPV];
         IO::unpack(col_ok ? IO::load_nt(static_cast<const XT*>(a.G) + row * a.ldg + c0) : IO::zero(), g);   // row-side operands: streamed
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(kBlock, (KIND == 1 && INROW && sizeof(XT) == 2) ? 6
         // them).  The same bf16 h_j enter dd_i and the transposed pass, so the cancellation in ds_i is exact to fp32 rounding.
         // LEGACY form (launches over column halves of A; the caller did not declare this launch the only one): hp_i from the stored output
         // row (bf16: rounded to 8 bits; ELU inverted with a logarithm), dd_i known before the gathers.
-        const bool legacy = !a.exact_dd;
+        constexpr bool legacy = !EXACT;
         float part = 0.0f;
 #pragma unroll
         for (int i = 0; i < EPV; ++i) {
@@ -224,7 +226,7 @@ __global__ __launch_bounds__(kBlock, (KIND == 1 && INROW && sizeof(XT) == 2) ? 6
                 w = (live && h0 + k < a.heads) ? w : 0.0f;
                 const float cc = w * a.sign * (z > 0.0f ? 1.0f : a.alpha);
                 if constexpr (KIND == 0) rec[k * kRecStride + lane] = w;
-                if constexpr (KIND == 1) rec[k * kRecStride + lane] = z > 0.0f ? w : -w;
+                if constexpr (ROWS) rec[k * kRecStride + lane] = z > 0.0f ? w : -w;
                 if constexpr (KIND == 2) { rec[k * kRecStride + lane] = make_float2(w, cc); rec1[k * kRecStride + lane] = dv[k] * cc; }
             }
         }
@@ -257,7 +259,7 @@ __global__ __launch_bounds__(kBlock, (KIND == 1 && INROW && sizeof(XT) == 2) ? 6
                     w = (j + u * SLOTS + slot < nb) ? w : 0.0f;
                     const float cc = w * a.sign * (z > 0.0f ? 1.0f : a.alpha);
                     if constexpr (KIND == 0) rr[u] = w;
-                    if constexpr (KIND == 1) rr[u] = z > 0.0f ? w : -w;
+                    if constexpr (ROWS) rr[u] = z > 0.0f ? w : -w;
                     if constexpr (KIND == 2) {
                         rr[u] = make_float2(w, cc);
                         r1[u] = __shfl(__uint_as_float(v[u].y), tlane) * cc;    // dd_i sits next to s_i
@@ -280,7 +282,7 @@ __global__ __launch_bounds__(kBlock, (KIND == 1 && INROW && sizeof(XT) == 2) ? 6
                         for (int q = 0; q < 4; ++q)
                             dot = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, rp[q]), __builtin_bit_cast(bf16x2_t, hv[q]), dot, false);
                     }
-                    if constexpr (KIND == 1) {
+                    if constexpr (ROWS) {
                         if constexpr (!BF) {
                             float f[EPV];
                             IO::unpack(v[u], f);
@@ -357,9 +359,9 @@ __global__ __launch_bounds__(kBlock, (KIND == 1 && INROW && sizeof(XT) == 2) ? 6
             }
         }
     }
-    if constexpr (KIND == 1) {
+    if constexpr (ROWS) {
         const float sa_t = head_sum_c<LPH>(slot_sum<LPR>(sa)), sb_t = slot_sum<LPR>(sb);
-        if (a.exact_dd) {
+        if constexpr (EXACT) {
             const float sw_t = head_sum_c<LPH>(slot_sum<LPR>(sw));
             if (slot == 0 && col_ok && hs == 0) {
                 if (it.chunk >= 0) {          // bilinear in the partial sums: the finalize kernel combines (sa, sb, sw) of the chunks
