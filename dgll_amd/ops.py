@@ -205,17 +205,17 @@ class GateToken:
         self.masked = False
 
 
-def _xent_launch(z, target, soft, row_loss, grad, scale, mask_nonpositive=False):
+def _xent_launch(z, target, soft, row_loss, grad, scale, mask_nonpositive=False, own_padding=False):
     n, c = z.shape
     with torch.cuda.device(z.device):
         stream = torch.cuda.current_stream(z.device).cuda_stream
         rl = row_loss.data_ptr() if row_loss is not None else None
         gp, gld = (grad.data_ptr(), grad.stride(0)) if grad is not None else (None, 0)
         sp = scale.data_ptr() if scale is not None else None
-        if mask_nonpositive:
+        if mask_nonpositive or own_padding:      # own_padding: `grad` is a fresh padded allocation whose padding may be written (zeros)
             code = _lib.lib.dgll_hip_softmax_xent_ex(stream, z.data_ptr(), z.stride(0), _dtype_code(z), None if soft else target.data_ptr(),
                                                      target.data_ptr() if soft else None, target.stride(0) if soft else 0, rl, gp, gld,
-                                                     sp, n, c, 1)
+                                                     sp, n, c, (1 if mask_nonpositive else 0) | (2 if own_padding else 0))
         elif soft:
             code = _lib.lib.dgll_hip_softmax_xent_soft(stream, z.data_ptr(), z.stride(0), _dtype_code(z), target.data_ptr(),
                                                        target.stride(0), rl, gp, gld, sp, n, c)
@@ -283,7 +283,7 @@ class _CrossEntropy(torch.autograd.Function):
         grad = alloc_features(z.shape[0], z.shape[1], z.dtype, z.device, pad_to=line if z.shape[1] < line else 16 // z.element_size())
         # fold_relu: the logits are a ReLU's output and this pass returns the gradient of the PRE-activation (zero where z <= 0);
         # the producing layer is told through its token and skips its own masking pass over [N, C]
-        _xent_launch(z, target, ctx.soft, None, grad, scale, mask_nonpositive=ctx.token is not None)
+        _xent_launch(z, target, ctx.soft, None, grad, scale, mask_nonpositive=ctx.token is not None, own_padding=True)
         if ctx.token is not None:
             ctx.token.masked = True
         if per_row:

@@ -421,7 +421,8 @@ int dgll_hip_softmax_xent_soft(void* stream, const void* logits, int64_t ldz, in
                                int64_t n_rows, int n_classes);
 /* Both target kinds behind one entry (exactly one of labels / targets non-NULL) + flags.  bit 0: the logits are ReLU outputs and
  * the gradient returned is d loss / d PRE-activation: zero wherever the logit is <= 0 (the last sageConv's ReLU backward,
- * sageconv.py:83, folded into the loss's gradient pass instead of a separate pass over [n_rows, n_classes]).                  */
+ * sageconv.py:83, folded into the loss's gradient pass instead of a separate pass over [n_rows, n_classes]).  bit 1: the padding
+ * [n_classes, ldg) of the gradient rows belongs to the output and may be written with zeros (whole 16-byte stores).            */
 int dgll_hip_softmax_xent_ex(void* stream, const void* logits, int64_t ldz, int dtype, const int64_t* labels, const float* targets,
                              int64_t ldt, float* row_loss, void* grad, int64_t ldg, const float* grad_scale, int64_t n_rows,
                              int n_classes, int flags);

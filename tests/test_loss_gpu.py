@@ -99,3 +99,41 @@ def test_loss_that_folds_the_last_relu_gives_the_same_gradients(cuda_device):
     ref = z.detach().clone().requires_grad_()
     torch.nn.functional.cross_entropy(ref, labels[:300]).backward()
     torch.testing.assert_close(z.grad, ref.grad, rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("classes", [2, 7, 8, 47, 64, 121, 300, 512])
+def test_cross_entropy_on_16_byte_aligned_bf16_rows(cuda_device, classes):
+    """bf16 logits whose rows start on 16-byte boundaries (what the layers hand the loss: a [N, C] view on a padded pitch) take the
+    kernel with eight consecutive classes per lane: loss and gradient as torch's on fp32 copies, NaN-filled row padding never read
+    into the result, ignored labels, the ReLU-folding mask."""
+    from dgll_amd import ops
+
+    torch.manual_seed(classes)
+    n = 2051
+    pitch = -(-classes // 64) * 64
+    store = torch.full((n, pitch), float("nan"), device=cuda_device, dtype=torch.bfloat16)
+    z = store[:, :classes]
+    z.copy_(torch.randn(n, classes, device=cuda_device) * 3)
+    labels = torch.randint(0, classes, (n,), device=cuda_device)
+    labels[::17] = -100
+    za = z.detach().requires_grad_()
+    zr = z.detach().float().clone().requires_grad_()
+    loss = ops.cross_entropy(za, labels, reduction="sum")
+    ref = F.cross_entropy(zr, labels, reduction="sum")
+    torch.testing.assert_close(loss, ref, rtol=2e-5, atol=1e-4)
+    loss.backward()
+    ref.backward()
+    torch.testing.assert_close(za.grad.float(), zr.grad, rtol=1e-2, atol=1e-2 * float(zr.grad.abs().max()))
+    assert bool((za.grad[::17] == 0).all()) and bool(torch.isfinite(za.grad).all())
+    # the gradient pass with the ReLU mask folded in (dgll_hip_softmax_xent_ex, flags bit 0) on the same kernel
+    from dgll_amd.ops import _xent_launch, alloc_features
+
+    zp = torch.relu(z.detach())
+    store2 = torch.zeros((n, pitch), device=cuda_device, dtype=torch.bfloat16)
+    zz = store2[:, :classes]
+    zz.copy_(zp)
+    g = alloc_features(n, classes, torch.bfloat16, cuda_device, pad_to=64)
+    _xent_launch(zz, labels, False, None, g, None, mask_nonpositive=True)
+    g0 = alloc_features(n, classes, torch.bfloat16, cuda_device, pad_to=64)
+    _xent_launch(zz, labels, False, None, g0, None)
+    assert torch.equal(g, torch.where(zz > 0, g0, torch.zeros_like(g0)))
