@@ -109,6 +109,8 @@ SIGNATURES = {
     "dgll_hip_grad_weight_workspace": (_i64, [_i32, _i32, _i32]),
     "dgll_hip_grad_weight_bf16": (_i32, [_vp, _vp, _i64, _i32, _vp, _i64, _i32, _vp, _i64, _i32, _i64, _vp, _i64, _i32, _vp, _i64,
                                          _vp, _i64]),
+    "dgll_hip_grad_weight_bf16_tr": (_i32, [_vp, _vp, _i64, _i32, _vp, _i64, _i32, _vp, _i64, _i32, _i64, _vp, _i64, _i32, _vp, _i64,
+                                            _vp, _i64]),
     "dgll_hip_softmax_xent": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _i64, _vp, _i64, _i32]),
     "dgll_hip_softmax_xent_soft": (_i32, [_vp, _vp, _i64, _i32, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i32]),
     "dgll_hip_softmax_xent_ex": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i32, _i32]),

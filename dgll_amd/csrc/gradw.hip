@@ -202,7 +202,7 @@ __global__ __launch_bounds__(512) void gradw_splitk_kernel(const GradWArgs a) {
 // [X1 | X2]^T . G; its four waves each add every fourth slab in slab order, then the four partial sums are added in wave order.
 __global__ __launch_bounds__(256) void gradw_reduce_kernel(const float* __restrict__ partial, int n_slabs, int kc_total, int kslabs0,
                                                            int K0, int K1, int N, float* __restrict__ dW0, int64_t ld0,
-                                                           float* __restrict__ dW1, int64_t ld1) {
+                                                           float* __restrict__ dW1, int64_t ld1, int transposed) {
     __shared__ float part[4][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int kc = blockIdx.x >> 2, n = (blockIdx.x & 3) * 64 + lane;
@@ -219,8 +219,10 @@ __global__ __launch_bounds__(256) void gradw_reduce_kernel(const float* __restri
     __syncthreads();
     if (w == 0 && n < N) {
         const float v = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
-        if (second) dW1[(int64_t)k * ld1 + n] = v;
-        else dW0[(int64_t)k * ld0 + n] = v;
+        // transposed: the caller wants G^T . X (its [N, K] destination) -- the products of one X with two G's (below)
+        float* d = second ? dW1 : dW0;
+        const int64_t ld = second ? ld1 : ld0;
+        d[transposed ? (int64_t)n * ld + k : (int64_t)k * ld + n] = v;
     }
 }
 
@@ -234,9 +236,9 @@ DGLL_API int64_t dgll_hip_grad_weight_workspace(int K1, int K2, int n_slabs) {
     return (int64_t)n_slabs * ks * 64 * 256 * (int64_t)sizeof(float);
 }
 
-DGLL_API int dgll_hip_grad_weight_bf16(void* stream, const void* X1, int64_t ldx1, int K1, const void* X2, int64_t ldx2, int K2,
-                                       const void* G, int64_t ldg, int N, int64_t M, void* workspace, int64_t workspace_bytes,
-                                       int n_slabs, float* dW1, int64_t lddw1, float* dW2, int64_t lddw2) {
+static int grad_weight_bf16_impl(void* stream, const void* X1, int64_t ldx1, int K1, const void* X2, int64_t ldx2, int K2,
+                                 const void* G, int64_t ldg, int N, int64_t M, void* workspace, int64_t workspace_bytes,
+                                 int n_slabs, float* dW1, int64_t lddw1, float* dW2, int64_t lddw2, bool transposed) {
     DGLL_REQUIRE(M >= 0 && N >= 0 && K1 >= 0 && K2 >= 0, "negative size");
     DGLL_REQUIRE(dW1 && K1 > 0 && N > 0 && (M == 0 || (X1 && G)), "NULL operand");    // an empty reduction may come with NULL inputs
     DGLL_REQUIRE(K1 <= 256 && K2 <= 256 && N <= 256, "dgll_hip_grad_weight_bf16 handles K1, K2, N <= 256");
@@ -245,15 +247,16 @@ DGLL_API int dgll_hip_grad_weight_bf16(void* stream, const void* X1, int64_t ldx
     DGLL_REQUIRE(workspace && workspace_bytes >= dgll_hip_grad_weight_workspace(K1, K2, n_slabs), "workspace too small");
     if (M == 0) {                                             // empty reduction: zeros
         hipStream_t s = static_cast<hipStream_t>(stream);
-        for (int k = 0; k < K1; ++k) DGLL_HIP_TRY(hipMemsetAsync(dW1 + (int64_t)k * lddw1, 0, (size_t)N * sizeof(float), s));
-        for (int k = 0; k < K2; ++k) DGLL_HIP_TRY(hipMemsetAsync(dW2 + (int64_t)k * lddw2, 0, (size_t)N * sizeof(float), s));
+        const int r1 = transposed ? N : K1, r2 = transposed ? (K2 ? N : 0) : K2;
+        for (int k = 0; k < r1; ++k) DGLL_HIP_TRY(hipMemsetAsync(dW1 + (int64_t)k * lddw1, 0, (size_t)(transposed ? K1 : N) * sizeof(float), s));
+        for (int k = 0; k < r2; ++k) DGLL_HIP_TRY(hipMemsetAsync(dW2 + (int64_t)k * lddw2, 0, (size_t)(transposed ? K2 : N) * sizeof(float), s));
         return DGLL_OK;
     }
     // 16-byte loads: rows start on 16-byte boundaries
     DGLL_REQUIRE(aligned16(X1) && (ldx1 & 7) == 0 && ldx1 >= K1, "X1: 16-byte aligned rows (leading dimension a multiple of 8)");
     DGLL_REQUIRE(!X2 || (aligned16(X2) && (ldx2 & 7) == 0 && ldx2 >= K2), "X2: 16-byte aligned rows (leading dimension a multiple of 8)");
     DGLL_REQUIRE(aligned16(G) && (ldg & 7) == 0 && ldg >= N, "G: 16-byte aligned rows (leading dimension a multiple of 8)");
-    DGLL_REQUIRE(lddw1 >= N && (!X2 || lddw2 >= N), "dW leading dimension");
+    DGLL_REQUIRE(transposed ? (lddw1 >= K1 && (!X2 || lddw2 >= K2)) : (lddw1 >= N && (!X2 || lddw2 >= N)), "dW leading dimension");
     hipStream_t s = static_cast<hipStream_t>(stream);
     GradWArgs a{};
     a.X[0] = X1; a.ldx[0] = ldx1; a.K[0] = K1;
@@ -287,8 +290,25 @@ DGLL_API int dgll_hip_grad_weight_bf16(void* stream, const void* X1, int64_t ldx
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "gradw_splitk_kernel launch");
     hipLaunchKernelGGL(gradw_reduce_kernel, dim3((uint32_t)(ks_total * 64 * 4)), dim3(256), 0, s, a.partial, used, ks_total * 64,
-                       a.kslabs[0], K1, K2, N, dW1, lddw1, dW2, lddw2);
+                       a.kslabs[0], K1, K2, N, dW1, lddw1, dW2, lddw2, transposed ? 1 : 0);
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "gradw_reduce_kernel launch");
     return DGLL_OK;
+}
+
+DGLL_API int dgll_hip_grad_weight_bf16(void* stream, const void* X1, int64_t ldx1, int K1, const void* X2, int64_t ldx2, int K2,
+                                       const void* G, int64_t ldg, int N, int64_t M, void* workspace, int64_t workspace_bytes,
+                                       int n_slabs, float* dW1, int64_t lddw1, float* dW2, int64_t lddw2) {
+    return grad_weight_bf16_impl(stream, X1, ldx1, K1, X2, ldx2, K2, G, ldg, N, M, workspace, workspace_bytes, n_slabs, dW1, lddw1,
+                                 dW2, lddw2, false);
+}
+
+// The same launch with the outputs stored transposed: dW1 [N, lddw1] = G^T . X1 and dW2 [N, lddw2] = G^T . X2.  This is the pair
+// "one X, two gradients" of the narrowing SAGE layer (out = h.Ws + A(h.Wn): dWs = h^T . g and dWn = h^T . (A^T g) share h): call it
+// with X1 = g, X2 = A^T g, G = h and the wide operand h is read once for both products instead of once per product.
+DGLL_API int dgll_hip_grad_weight_bf16_tr(void* stream, const void* X1, int64_t ldx1, int K1, const void* X2, int64_t ldx2, int K2,
+                                          const void* G, int64_t ldg, int N, int64_t M, void* workspace, int64_t workspace_bytes,
+                                          int n_slabs, float* dW1, int64_t lddw1, float* dW2, int64_t lddw2) {
+    return grad_weight_bf16_impl(stream, X1, ldx1, K1, X2, ldx2, K2, G, ldg, N, M, workspace, workspace_bytes, n_slabs, dW1, lddw1,
+                                 dW2, lddw2, true);
 }

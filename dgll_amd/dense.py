@@ -306,9 +306,10 @@ def _out_ok(out, k, n, device):
             and out.device == device)
 
 
-def _grad_weight_hip(x1, x2, g, out1=None, out2=None):
+def _grad_weight_hip(x1, x2, g, out1=None, out2=None, transposed=False):
     """(x1^T . g, x2^T . g) fp32 on the split-K MFMA kernel (csrc/gradw.hip): g is read once for both products.  out1 / out2:
-    fp32 [K, N] destinations (a parameter's slot of optim.FlatAdam's gradient buffer) written instead of fresh tensors."""
+    fp32 [K, N] destinations (a parameter's slot of optim.FlatAdam's gradient buffer) written instead of fresh tensors.
+    transposed: the results are stored as (g^T . x1, g^T . x2), [N, K] each (dgll_hip_grad_weight_bf16_tr)."""
     m, n = g.shape
     k1, k2 = x1.shape[1], (x2.shape[1] if x2 is not None else 0)
     types = (-(-k1 // 64) + -(-k2 // 64) + 3) // 4
@@ -332,18 +333,20 @@ def _grad_weight_hip(x1, x2, g, out1=None, out2=None):
     ws = _GW_WORKSPACE.get(key)
     if ws is None or ws.numel() * 4 < need:
         ws = _GW_WORKSPACE[key] = torch.empty(need // 4, dtype=torch.float32, device=g.device)
-    d1 = out1 if _out_ok(out1, k1, n, g.device) else torch.empty((k1, n), dtype=torch.float32, device=g.device)
-    d2 = (out2 if _out_ok(out2, k2, n, g.device) else torch.empty((k2, n), dtype=torch.float32, device=g.device)) if x2 is not None else None
+    s1, s2 = ((n, k1), (n, k2)) if transposed else ((k1, n), (k2, n))
+    d1 = out1 if _out_ok(out1, s1[0], s1[1], g.device) else torch.empty(s1, dtype=torch.float32, device=g.device)
+    d2 = (out2 if _out_ok(out2, s2[0], s2[1], g.device) else torch.empty(s2, dtype=torch.float32, device=g.device)) if x2 is not None else None
+    entry = "dgll_hip_grad_weight_bf16_tr" if transposed else "dgll_hip_grad_weight_bf16"
     with torch.cuda.device(g.device):       # the launch (and its event bracket) belong to g's device, whatever is current
-        end = _timed(("grad_weight", m, k1, k2, n, ""), g.device)
-        code = _lib.lib.dgll_hip_grad_weight_bf16(
+        end = _timed(("grad_weight", m, k1, k2, n, "tr" if transposed else ""), g.device)
+        code = getattr(_lib.lib, entry)(
             torch.cuda.current_stream(g.device).cuda_stream, x1.data_ptr(), x1.stride(0), k1,
             x2.data_ptr() if x2 is not None else None, x2.stride(0) if x2 is not None else 0, k2, g.data_ptr(), g.stride(0), n, m,
             ws.data_ptr(), ws.numel() * 4, slabs, d1.data_ptr(), d1.stride(0), d2.data_ptr() if d2 is not None else None,
             d2.stride(0) if d2 is not None else 0)
         if end is not None:
             end.record(torch.cuda.current_stream(g.device))
-    _lib.check(code, "dgll_hip_grad_weight_bf16")
+    _lib.check(code, entry)
     return d1, d2
 
 
@@ -355,6 +358,8 @@ def _grad_weight_f32(x, g):
     g = g if g.stride(1) == 1 else g.contiguous()
     m, k = x.shape
     n = g.shape[1]
+    if m == 0:                                   # an empty reduction (an empty tensor has no storage to point the kernel at)
+        return torch.zeros((k, n), dtype=torch.float32, device=x.device)
     slabs = max(1, min(256, -(-m // 256)))
     need = int(_lib.lib.dgll_hip_grad_weight_f32_workspace(k, n, slabs))
     ws = torch.empty(need // 4, dtype=torch.float32, device=x.device)
@@ -410,6 +415,15 @@ def grad_weight_pair(x1, x2, g, out1=None, out2=None):
     if _gradw_ok(x1, x2, g):
         return _grad_weight_hip(x1, x2, g, out1=out1, out2=out2)
     return grad_weight(x1, g, out=out1), grad_weight(x2, g, out=out2)
+
+
+def grad_weight_shared_x(x, g1, g2, out1=None, out2=None):
+    """(x^T . g1, x^T . g2): the two weight gradients of the narrowing SAGE layer share the WIDE operand x (fused_layers.
+    _SageGraphLayerTransformFirst: g1 the output gradient, g2 its transposed aggregation).  One launch with the roles swapped and
+    the results stored transposed reads x once: two launches each read it whole (2 x 1.25 GB of the headline step)."""
+    if _gradw_ok(g1, g2, x) and g1.shape[1] <= 256 and g2.shape[1] <= 256 and x.shape[1] <= 256:
+        return _grad_weight_hip(g1, g2, x, out1=out1, out2=out2, transposed=True)
+    return grad_weight(x, g1, out=out1), grad_weight(x, g2, out=out2)
 
 
 def column_sum(g, slabs=2048):

@@ -139,8 +139,12 @@ class _SageGraphLayerTransformFirst(torch.autograd.Function):
             gz = ops.spmm_raw(gt, gp, val=gt.val, reduce="sum")
         else:
             gz = ops.spmm_raw(gt, gm, val=graph.mean_scale_transposed() if ctx.reduce == "mean" else gt.val, reduce="sum")
-        gws = dense.grad_weight(h, gm, out=grad_slot_of(ctx.wparams[0])) if ctx.needs_input_grad[1] else None
-        gwn = dense.grad_weight(h, gz, out=grad_slot_of(ctx.wparams[1])) if ctx.needs_input_grad[2] else None
+        if ctx.needs_input_grad[1] and ctx.needs_input_grad[2]:
+            # h^T . g and h^T . (A^T g): one launch that reads the wide operand h once (dense.grad_weight_shared_x)
+            gws, gwn = dense.grad_weight_shared_x(h, gm, gz, out1=grad_slot_of(ctx.wparams[0]), out2=grad_slot_of(ctx.wparams[1]))
+        else:
+            gws = dense.grad_weight(h, gm, out=grad_slot_of(ctx.wparams[0])) if ctx.needs_input_grad[1] else None
+            gwn = dense.grad_weight(h, gz, out=grad_slot_of(ctx.wparams[1])) if ctx.needs_input_grad[2] else None
         gh = None
         if ctx.needs_input_grad[0]:
             if dense._mfma_ok(gm, gz) and wsd.shape[0] <= 256 and (not ctx.gate_input or h.stride(1) == 1):

@@ -403,6 +403,12 @@ int64_t dgll_hip_grad_weight_workspace(int K1, int K2, int n_slabs);
 int dgll_hip_grad_weight_bf16(void* stream, const void* X1, int64_t ldx1, int K1, const void* X2, int64_t ldx2, int K2,
                               const void* G, int64_t ldg, int N, int64_t M, void* workspace, int64_t workspace_bytes,
                               int n_slabs, float* dW1, int64_t lddw1, float* dW2, int64_t lddw2);
+/* The same launch with both results stored transposed: dW1 [N, lddw1 >= K1] = G^T . X1, dW2 [N, lddw2 >= K2] = G^T . X2.  Called with
+ * X1 = g, X2 = A^T g, G = h it yields dWs = h^T . g and dWn = h^T . (A^T g) of the narrowing SAGE layer (sageconv.py:72-82 with the
+ * narrow product aggregated) with the wide operand h read once for both.                                                          */
+int dgll_hip_grad_weight_bf16_tr(void* stream, const void* X1, int64_t ldx1, int K1, const void* X2, int64_t ldx2, int K2,
+                                 const void* G, int64_t ldg, int N, int64_t M, void* workspace, int64_t workspace_bytes,
+                                 int n_slabs, float* dW1, int64_t lddw1, float* dW2, int64_t lddw2);
 
 /* ---- the loss at the end of the path: softmax cross-entropy with class-index targets ---------------------------
  * nn.CrossEntropyLoss on the last layer's output (Evaluation/PPI/train_gcn.py:27,45), one pass per direction:

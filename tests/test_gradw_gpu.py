@@ -131,3 +131,36 @@ def test_transform_dual_argument_checks():
         dense.transform_bf16_dual(a, torch.randn(32, 64, device=dev), torch.randn(48, 64, device=dev))
     o1, o2 = dense.transform_bf16_dual(a, torch.randn(40, 64, device=dev), torch.randn(40, 64, device=dev))
     assert o1.shape == (128, 40) and o2.shape == (128, 40)
+
+
+@pytest.mark.parametrize("m,k,n1,n2", [(40000, 256, 47, 47), (16391, 100, 64, 7), (0, 256, 47, 47), (33, 130, 2, 256)])
+def test_grad_weight_shared_x_is_the_two_products(m, k, n1, n2):
+    """dgll_hip_grad_weight_bf16_tr: x^T . g1 and x^T . g2 from one launch (the narrowing SAGE layer's pair: the wide operand read
+    once) -- bit-identical to the transposes of the untransposed launch with the roles swapped, close to the fp64 products,
+    written straight into caller-provided [K, N] destinations, NaN row padding never read into a kept output."""
+    from dgll_amd import dense, ops
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(m + k + n1)
+
+    def feats(rows, cols):
+        t = ops.alloc_features(rows, cols, torch.bfloat16, dev, pad_to=64)
+        t.as_strided((rows, t.stride(0)), (t.stride(0), 1)).fill_(float("nan"))
+        t.copy_(torch.randn(rows, cols, device=dev))
+        return t
+
+    x, g1, g2 = feats(m, k), feats(m, n1), feats(m, n2)
+    o1 = torch.full((k, n1), float("nan"), device=dev)
+    o2 = torch.full((k, n2), float("nan"), device=dev)
+    d1, d2 = dense.grad_weight_shared_x(x, g1, g2, out1=o1, out2=o2)
+    assert d1 is o1 and d2 is o2
+    t1, t2 = dense._grad_weight_hip(g1, g2, x)                       # [n, k] each
+    assert torch.equal(d1, t1.t()) and torch.equal(d2, t2.t())
+    for got, g in ((d1, g1), (d2, g2)):
+        ref = _ref(x, g)
+        assert float((got.double().cpu() - ref).abs().max()) <= 2e-3 * float(ref.abs().max() if m else 0.0) + 1e-3
+    # fp32 operands (no MFMA form): the same public call falls back to two products
+    a, b = dense.grad_weight_shared_x(x.float(), g1.float(), g2.float())
+    if m:
+        assert float((a.double().cpu() - _ref(x, g1)).abs().max()) <= 1e-3 * float(_ref(x, g1).abs().max()) + 1e-3
+    assert a.shape == (k, n1) and b.shape == (k, n2)
