@@ -13,6 +13,7 @@ from HBM, misses over PCIe from pinned memory), records an event and fills the s
 on the event from its compute stream.  Sampling of batch i+2, loading of batch i+1 and training on batch i overlap.  The end of the epoch is signalled with a sentinel
 (buffer_queues.py:43-46 sets a flag under the Condition).
 """
+import os
 import threading
 import time
 
@@ -285,6 +286,23 @@ class MiniBatchPipeline:
 
     # ---- producer stage 2: feature loading --------------------------------------------------------------------
     def _load(self):
+        prof = None
+        if os.environ.get("DGLL_MB_PROFILE_LOADER"):      # diagnostics: where this thread's host time goes (printed to stderr at its end)
+            import cProfile
+
+            prof = cProfile.Profile()
+            prof.enable()
+        try:
+            self._load_loop()
+        finally:
+            if prof is not None:
+                import pstats
+                import sys
+
+                prof.disable()
+                pstats.Stats(prof, stream=sys.stderr).sort_stats("cumulative").print_stats(40)
+
+    def _load_loop(self):
         try:
             while True:
                 item = self.sampled.get()

@@ -368,3 +368,40 @@ def test_ordered_handoff_returns_batches_in_order_and_bounds_the_run_ahead():
         t.join()
     h.close(20)
     assert got == [i * i for i in range(20)] and h.get() is None
+
+
+@pytest.mark.gpu
+def test_consumed_batches_are_never_overwritten_under_a_slow_consumer(cuda_device):
+    """A batch's tensors are allocated on the loading stream and read on the consumer's: with a consumer whose kernels lag far behind
+    its host thread (a long spin kernel queued per batch) the loader must not write the next gathers into memory those queued kernels
+    still read (the pipeline registers them with the caching allocator, record_stream).  Every batch's rows, read on the consumer's
+    stream AFTER the lag, must still equal the host's."""
+    from dgll_amd.cache import GraphCacheServer
+    from dgll_amd.data import DGraph
+    from dgll_amd.dataloader import DataLoader
+    from dgll_amd.pipeline import MiniBatchPipeline
+    from dgll_amd.sampling import FastNeighborSampler
+
+    rng = torch.Generator().manual_seed(3)
+    n, deg = 3000, 12
+    idx = torch.randint(0, n, (n * deg,), generator=rng)
+    ptr = torch.arange(0, n * deg + 1, deg)
+    feats = torch.randn(n, 64, generator=rng)
+    labels = torch.arange(n) % 5
+    dg = DGraph.from_csr(ptr.numpy(), idx.numpy(), labels=labels, features=feats)
+    srv = GraphCacheServer(feats, gpuid=0)
+    srv.auto_cache(torch.full((n,), deg), capacity=n // 2)
+    loader = DataLoader(dg, torch.randperm(n, generator=rng)[:2560], FastNeighborSampler([3, 3]), batch_size=64)
+    pipe = MiniBatchPipeline(loader, cache=srv, labels=labels, queue_size=2, device=cuda_device)
+    random.seed(1)
+    compute = torch.cuda.Stream(cuda_device)
+    checks = []
+    with torch.cuda.stream(compute):
+        for b in pipe:
+            torch.cuda._sleep(2_000_000)                       # ~1 ms of queued work ahead of this batch's reads
+            got = b.features[0].float().sum(1)                 # reads the loader's buffer on the consumer's stream, late
+            checks.append((got, feats[b.input_nodes].sum(1)))
+    torch.cuda.synchronize()
+    assert len(checks) == 40
+    for got, ref in checks:
+        torch.testing.assert_close(got.cpu(), ref, rtol=1e-5, atol=1e-5)
