@@ -186,6 +186,11 @@ def test_dense_backward_products_at_full_size(cuda_device):
     h = m // 2 + 7
     top, bot = dense.grad_weight(x[:h], g[:h]), dense.grad_weight(x[h:], g[h:])
     assert torch.equal(top + bot, d1)
+    # the shared-operand form of the narrowing layer (x^T.g1, x^T.g2 from one launch, stored transposed): on integers exactly the
+    # column blocks of the full product
+    n1 = 47
+    a, b = dense.grad_weight_shared_x(x, g[:, :n1], g[:, 64:64 + n1])
+    assert torch.equal(a, d1[:, :n1]) and torch.equal(b, d1[:, 64:64 + n1])
     # column sums through a ones operand, against an integer reduction
     ones = torch.ones(m, 64, device=dev, dtype=torch.bfloat16)
     s = dense.grad_weight(ones, g)
