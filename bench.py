@@ -108,6 +108,8 @@ def parse_args(argv=None):
     ap.add_argument("--mb-loader-blocks-per-cu", type=int, default=4,
                     help="minibatch: cap of the feature-loading kernels' grids in workgroups per CU (0 = the kernels' own 16 / 32): they "
                          "run on the loading stream next to the training kernels")
+    ap.add_argument("--gat-unfused-loss", action="store_true",
+                    help="gat: F.nll_loss on the model's log_softmax output (torch kernels) instead of dgll_amd.ops.cross_entropy on its activations")
     ap.add_argument("--mb-host-translate", action="store_true",
                     help="minibatch: turn the outermost hop's positions into ids on the host (16 threads) instead of by a device gather")
     ap.add_argument("--scale", type=int, default=27, help="rmat27: RMAT scale (27 = config 5; smaller for a quick run)")
@@ -835,9 +837,16 @@ def run_gat(args, c):
 
     def step():
         opt.zero_grad(set_to_none=True)
-        out = model(x_local, full) if engine is None else engine.spgat_forward(model, x_local, placed_input)     # log_softmax
-        # F.nll_loss of the reference's training loops, as its definition (torch's nll_loss kernels take 10 ms at this size)
-        loss = -out.gather(1, labels.unsqueeze(1)).float().sum() * (world / n)
+        if args.gat_unfused_loss:
+            out = model(x_local, full) if engine is None else engine.spgat_forward(model, x_local, placed_input)     # log_softmax
+            # F.nll_loss of the reference's training loops, as its definition (torch's nll_loss kernels take 10 ms at this size)
+            loss = -out.gather(1, labels.unsqueeze(1)).float().sum() * (world / n)
+        else:
+            # the same loss, nll_loss(log_softmax(a)) = cross_entropy(a), on the model's activations before its log_softmax: one
+            # kernel per direction instead of log_softmax + gather (+ their backward passes) over an fp32 copy of [N, 47]
+            act = model.forward_activations(x_local, full) if engine is None else engine.spgat_forward(model, x_local, placed_input,
+                                                                                                       activations=True)
+            loss = ops.cross_entropy(act, labels, reduction="sum") * (world / n)
         loss.backward()
         if racom is not None:
             racom.all_reduce_and_wait()

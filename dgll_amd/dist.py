@@ -1049,10 +1049,11 @@ class DistGraph:
         out = DistGatAggregate.apply(hp, st[:, :heads], st[:, heads:], self, heads, fo_pad, alpha, concat, halo_local)
         return out if fo_pad == fo else out.view(-1, heads, fo_pad)[:, :, :fo].reshape(-1, heads * fo)
 
-    def spgat_forward(self, model, x_local, placed_input=None):
+    def spgat_forward(self, model, x_local, placed_input=None, activations=False):
         """SpGAT.forward (gatconv.py:194-199) on this rank's rows; input/attention dropout must be inactive.  placed_input
         (place_input_halo): the first layer's transform x.W is evaluated on the halo rows too instead of exchanging its
-        heads * nhid-wide result every step (dist._DistSageInputLayerAll has the argument; here it needs no placed aggregate)."""
+        heads * nhid-wide result every step (dist._DistSageInputLayerAll has the argument; here it needs no placed aggregate).
+        activations: return elu(out head) without the final log_softmax (SpGAT.forward_activations: for a fused cross-entropy)."""
         if model.training and model.dropout > 0:
             raise NotImplementedError("the partitioned GAT path runs with dropout inactive (eval mode or p = 0)")
         halves = [att._split_a() for att in model.attentions]
@@ -1061,6 +1062,8 @@ class DistGraph:
                            [h[1] for h in halves], model.attentions[0].alpha, True, halo_local=local)
         a1, a2 = model.out_att._split_a()
         x = torch.nn.functional.elu(self.gat_layer(x, [model.out_att.W], [a1], [a2], model.out_att.alpha, False))
+        if activations:
+            return x
         return torch.log_softmax(x, dim=1, dtype=torch.float32 if x.dtype == torch.bfloat16 else None)
 
     def sage_forward(self, model, x_local, placed_input=None):

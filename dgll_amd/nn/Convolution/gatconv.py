@@ -257,6 +257,16 @@ class _MultiHead(F.nn.Module):
         self.out_att = self.layer_cls(nhid * nheads, nclass, dropout=dropout, alpha=alpha, concat=False)
 
     def forward(self, x, adj):
+        # bf16 activations: the log-probabilities (and the softmax of their backward) are formed in fp32 -- a bf16 log-probability
+        # of -4.6 carries 1.5e-2 of absolute error, i.e. 1.5 % on the probability its backward exponentiates
+        x = self.forward_activations(x, adj)
+        return F.log_softmax(x, dim=1, dtype=F.float32 if x.dtype == F.bfloat16 else None)
+
+    def forward_activations(self, x, adj):
+        """forward() up to, not including, its log_softmax: elu(out head) [N, nclass].  A training loop that applies
+        F.nll_loss to forward()'s output (the reference's loops) computes cross_entropy of THIS tensor; dgll_amd.ops.cross_entropy
+        on it is that loss from one kernel per direction instead of log_softmax + gather and their backward passes over an fp32
+        copy of the [N, nclass] output (1.4 ms of the products-sized step)."""
         x = F.dropout(x, self.dropout, training=self.training)
         first = self.attentions[0]      # every head in one launch
         halves = [att._split_a() for att in self.attentions]
@@ -270,9 +280,7 @@ class _MultiHead(F.nn.Module):
                        out.dropout if isinstance(out.dropout, float) else out.dropout.p, self.training)
         else:
             x = F.elu(self.out_att(x, adj))
-        # bf16 activations: the log-probabilities (and the softmax of their backward) are formed in fp32 -- a bf16 log-probability
-        # of -4.6 carries 1.5e-2 of absolute error, i.e. 1.5 % on the probability its backward exponentiates
-        return F.log_softmax(x, dim=1, dtype=F.float32 if x.dtype == F.bfloat16 else None)
+        return x
 
 
 class GAT(_MultiHead):

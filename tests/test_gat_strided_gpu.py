@@ -215,3 +215,35 @@ def test_gatconv_on_the_gpu_treats_an_edgeless_row_like_the_reference(cuda_devic
     sp = sparseGatConv(9, 8, dropout=0.0, alpha=0.2).eval().to(cuda_device)
     with pytest.raises(AssertionError):
         sp(x.to(cuda_device), adj.to(cuda_device))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_cross_entropy_of_the_activations_is_the_nll_of_the_models_log_softmax(cuda_device, dtype):
+    """SpGAT.forward ends in log_softmax (gatconv.py:199) and the reference's loops apply F.nll_loss to it.  forward_activations()
+    stops before the log_softmax; ops.cross_entropy on it is the same loss with the same parameter gradients (bench.py's gat step
+    takes that route: one kernel per direction instead of log_softmax + gather and their backward passes)."""
+    from dgll_amd import nn as dnn
+    from dgll_amd import ops, synth
+
+    dev = cuda_device
+    g = synth.rmat_graph(11, 10, seed=2, device=dev, symmetric=True, weighted=False, self_loops=True)
+    n = g.n_rows
+    x = ops.alloc_features(n, 40, dtype, dev)
+    x.copy_(torch.randn(n, 40, device=dev))
+    labels = torch.randint(0, 47, (n,), device=dev)
+    res = {}
+    for fused in (False, True):
+        torch.manual_seed(4)
+        model = dnn.SpGAT(40, 16, 47, 0.0, 0.2, 4).to(dev)
+        if fused:
+            loss = ops.cross_entropy(model.forward_activations(x, g), labels, reduction="sum") * (1.0 / n)
+        else:
+            out = model(x, g)
+            assert out.dtype == torch.float32
+            loss = torch.nn.functional.nll_loss(out, labels, reduction="sum") * (1.0 / n)
+        loss.backward()
+        res[fused] = (float(loss), [p.grad.float().clone() for p in model.parameters()])
+    tol = 1e-5 if dtype == torch.float32 else 2e-3
+    assert res[True][0] == pytest.approx(res[False][0], rel=tol)
+    for a, b in zip(res[True][1], res[False][1]):
+        assert float((a - b).abs().max()) <= (1e-4 if dtype == torch.float32 else 2e-2) * float(b.abs().max()) + 1e-7
