@@ -37,8 +37,8 @@ def _pack_now(wt, rows=None):
     if wt.is_cuda and wt.dtype in (torch.float32, torch.bfloat16):
         wt = wt.detach()
         out = torch.empty((rows, ld), dtype=torch.bfloat16, device=wt.device)
-        with torch.cuda.device(wt.device):
-            code = _lib.lib.dgll_hip_pack_weight_bf16(torch.cuda.current_stream(wt.device).cuda_stream, wt.data_ptr(),
+        with _lib.on_device(wt.device):
+            code = _lib.lib.dgll_hip_pack_weight_bf16(_lib.raw_stream(wt.device), wt.data_ptr(),
                                                       _lib.F32 if wt.dtype == torch.float32 else _lib.BF16, wt.stride(0), wt.stride(1),
                                                       n, k, out.data_ptr(), ld, rows)
         _lib.check(code, "dgll_hip_pack_weight_bf16")
@@ -89,7 +89,7 @@ def transform_bf16(a1, wt1, a2=None, wt2=None, relu=False, out_dtype=torch.bfloa
         raise ValueError("transform_bf16: `out` must be a [M, N] device tensor of the output dtype with contiguous rows")
     if bias is not None:
         bias = bias.detach().float().contiguous()
-    with torch.cuda.device(a1.device):
+    with _lib.on_device(a1.device):
         if row_scale is not None and (row_scale.dtype != torch.float32 or row_scale.shape != (m,) or not row_scale.is_contiguous()):
             raise ValueError("row_scale must be a contiguous fp32 vector with one entry per row")
         if out_gate is not None and (out_gate.dtype != torch.bfloat16 or out_gate.shape != (m, n) or out_gate.stride(1) != 1):
@@ -100,7 +100,7 @@ def transform_bf16(a1, wt1, a2=None, wt2=None, relu=False, out_dtype=torch.bfloa
                       "+".join(t for t, on in (("gate", out_gate is not None), ("addend", addend is not None),
                                                ("row_scale", row_scale is not None), ("mask", mask is not None)) if on)), a1.device)
         code = _lib.lib.dgll_hip_transform_bf16_add(
-            torch.cuda.current_stream(a1.device).cuda_stream, a1.data_ptr(), a1.stride(0), a1.shape[1], p1.data_ptr(),
+            _lib.raw_stream(a1.device), a1.data_ptr(), a1.stride(0), a1.shape[1], p1.data_ptr(),
             p1.stride(0), a2.data_ptr() if a2 is not None else None, a2.stride(0) if a2 is not None else 0,
             a2.shape[1] if a2 is not None else 0, p2.data_ptr() if p2 is not None else None,
             p2.stride(0) if p2 is not None else 0, p1.shape[0], mask.data_ptr() if mask is not None else None,
@@ -181,10 +181,10 @@ def transform_bf16_dual(a, wt1, wt2):
     ld = -(-n // 8) * 8
     outs = [torch.empty((m, ld), dtype=torch.bfloat16, device=a.device) for _ in range(2)]
     o1, o2 = (o[:, :n] if ld != n else o for o in outs)
-    with torch.cuda.device(a.device):
+    with _lib.on_device(a.device):
         end = _timed(("transform_dual", m, a.shape[1], 0, 2 * n, ""), a.device)
         code = _lib.lib.dgll_hip_transform_bf16_dual(
-            torch.cuda.current_stream(a.device).cuda_stream, a.data_ptr(), a.stride(0), a.shape[1], p1.data_ptr(), p2.data_ptr(),
+            _lib.raw_stream(a.device), a.data_ptr(), a.stride(0), a.shape[1], p1.data_ptr(), p2.data_ptr(),
             p1.stride(0), p1.shape[0], o1.data_ptr(), o1.stride(0), o2.data_ptr(), o2.stride(0), m, n)
         if end is not None:
             end.record(torch.cuda.current_stream(a.device))
@@ -216,8 +216,8 @@ def _mm_f32(a, wt, relu, bias, addend):
         addend = addend if addend.stride(1) == 1 else addend.contiguous()
     if bias is not None:
         bias = bias.detach().to(torch.float32).contiguous()
-    with torch.cuda.device(a.device):
-        stream = torch.cuda.current_stream(a.device).cuda_stream
+    with _lib.on_device(a.device):
+        stream = _lib.raw_stream(a.device)
         for n0 in range(0, n, 256):
             nn = min(256, n - n0)
             code = _lib.lib.dgll_hip_mm_f32(
@@ -329,7 +329,7 @@ def _grad_weight_hip(x1, x2, g, out1=None, out2=None, transposed=False):
         raise ValueError("grad_weight: rows of %d elements are too wide for the split-K kernel's 32-bit slab offsets even at 4096 slabs "
                          "(%d rows): split the reduction over row blocks" % (ld_max, m))
     need = int(_lib.lib.dgll_hip_grad_weight_workspace(k1, k2, slabs))
-    key = (g.device.index, torch.cuda.current_stream(g.device).cuda_stream)
+    key = (g.device.index, _lib.raw_stream(g.device))
     ws = _GW_WORKSPACE.get(key)
     if ws is None or ws.numel() * 4 < need:
         ws = _GW_WORKSPACE[key] = torch.empty(need // 4, dtype=torch.float32, device=g.device)
@@ -337,10 +337,10 @@ def _grad_weight_hip(x1, x2, g, out1=None, out2=None, transposed=False):
     d1 = out1 if _out_ok(out1, s1[0], s1[1], g.device) else torch.empty(s1, dtype=torch.float32, device=g.device)
     d2 = (out2 if _out_ok(out2, s2[0], s2[1], g.device) else torch.empty(s2, dtype=torch.float32, device=g.device)) if x2 is not None else None
     entry = "dgll_hip_grad_weight_bf16_tr" if transposed else "dgll_hip_grad_weight_bf16"
-    with torch.cuda.device(g.device):       # the launch (and its event bracket) belong to g's device, whatever is current
+    with _lib.on_device(g.device):       # the launch (and its event bracket) belong to g's device, whatever is current
         end = _timed(("grad_weight", m, k1, k2, n, "tr" if transposed else ""), g.device)
         code = getattr(_lib.lib, entry)(
-            torch.cuda.current_stream(g.device).cuda_stream, x1.data_ptr(), x1.stride(0), k1,
+            _lib.raw_stream(g.device), x1.data_ptr(), x1.stride(0), k1,
             x2.data_ptr() if x2 is not None else None, x2.stride(0) if x2 is not None else 0, k2, g.data_ptr(), g.stride(0), n, m,
             ws.data_ptr(), ws.numel() * 4, slabs, d1.data_ptr(), d1.stride(0), d2.data_ptr() if d2 is not None else None,
             d2.stride(0) if d2 is not None else 0)

@@ -105,8 +105,8 @@ def spmm_raw(graph, x, val=None, reduce="sum", bias=None, relu=False, out_dtype=
         end = timer.start(("spmm", feat, str(x.dtype), val is not None, graph.nnz, extra), x.device)
     else:
         end = None
-    with torch.cuda.device(x.device):
-        stream = torch.cuda.current_stream(x.device).cuda_stream
+    with _lib.on_device(x.device):
+        stream = _lib.raw_stream(x.device)
         if gate is not None and (gate.dtype != out.dtype or gate.shape != out.shape or gate.stride(1) != 1):
             raise ValueError("gate must match the output's shape and dtype, rows contiguous")
         code = _lib.lib.dgll_hip_spmm_csr_gated(
@@ -207,8 +207,8 @@ class GateToken:
 
 def _xent_launch(z, target, soft, row_loss, grad, scale, mask_nonpositive=False, own_padding=False):
     n, c = z.shape
-    with torch.cuda.device(z.device):
-        stream = torch.cuda.current_stream(z.device).cuda_stream
+    with _lib.on_device(z.device):
+        stream = _lib.raw_stream(z.device)
         rl = row_loss.data_ptr() if row_loss is not None else None
         gp, gld = (grad.data_ptr(), grad.stride(0)) if grad is not None else (None, 0)
         sp = scale.data_ptr() if scale is not None else None

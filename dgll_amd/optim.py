@@ -174,9 +174,9 @@ class FlatAdam:
         if self.device.type != "cuda":
             return self._step_host()
         n, begin, end, cols, pk, ld, pkt, ldt = self._segments() if self.pack_weights else (0, None, None, None, None, None, None, None)
-        with torch.cuda.device(self.device):
+        with _lib.on_device(self.device):
             code = _lib.lib.dgll_hip_adam_flat(
-                torch.cuda.current_stream(self.device).cuda_stream, self.flat.data_ptr(), self.grad.data_ptr(),
+                _lib.raw_stream(self.device), self.flat.data_ptr(), self.grad.data_ptr(),
                 self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.total, self.lr, self.betas[0], self.betas[1], self.eps,
                 self.weight_decay, self.steps, float(self.grad_scale), n, begin, end, cols, pk, ld, pkt, ldt)
         _lib.check(code, "dgll_hip_adam_flat")
