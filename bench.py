@@ -110,6 +110,9 @@ def parse_args(argv=None):
                          "run on the loading stream next to the training kernels")
     ap.add_argument("--gat-unfused-loss", action="store_true",
                     help="gat: F.nll_loss on the model's log_softmax output (torch kernels) instead of dgll_amd.ops.cross_entropy on its activations")
+    ap.add_argument("--mb-hip-graph", choices=["auto", "on", "off"], default="auto",
+                    help="minibatch: the consumer's forward + loss + backward as ONE HIP graph on padded static block shapes "
+                         "(dgll_amd.graphs.GraphedSampledStep), replayed per batch")
     ap.add_argument("--mb-host-translate", action="store_true",
                     help="minibatch: turn the outermost hop's positions into ids on the host (16 threads) instead of by a device gather")
     ap.add_argument("--scale", type=int, default=27, help="rmat27: RMAT scale (27 = config 5; smaller for a quick run)")
@@ -1073,6 +1076,18 @@ def run_minibatch(args, c):
     from dgll_amd.optim import FlatAdam
 
     opt = torch.optim.Adam(model.parameters(), lr=1e-3) if args.torch_adam else FlatAdam(list(model.parameters()), lr=1e-3)
+    graphed = None
+    if args.mb_hip_graph == "on" or (args.mb_hip_graph == "auto" and fuse_last and not args.torch_adam):
+        from dgll_amd.graphs import GraphedSampledStep
+
+        try:
+            graphed = GraphedSampledStep(model, opt, args.mb_batch, fanouts, args.mb_feats, args.mb_classes, dtype=c.dtype, device=c.dev)
+        except Exception as exc:  # noqa: BLE001  (auto: a stack that cannot capture the step runs it launch by launch, and says so)
+            if args.mb_hip_graph == "on":
+                raise
+            print("bench.py: HIP-graph capture of the sampled step failed (%s: %s); running launch by launch" % (type(exc).__name__, exc),
+                  file=sys.stderr, flush=True)
+            opt.zero_grad(set_to_none=True)
     random.seed(args.seed)
     timer_cm = ops.LaunchTimer()
     done = edges = 0
@@ -1114,11 +1129,14 @@ def run_minibatch(args, c):
         blocks = b.blocks          # built by the loading stage on its own stream (the outermost one is None: reduced out of the cache)
         if blocks[L - 1] is None and b.last_hop_reduced is None:
             blocks[L - 1] = b.subgraphs[0].to_block(c.dev)
-        out = model.forward_sampled(b.features, blocks, last_hop_reduced=b.last_hop_reduced)
-        loss = ops.cross_entropy(out, b.labels)
-        opt.zero_grad(set_to_none=True)
-        loss.backward()
-        opt.step()
+        if graphed is not None and done < args.warmup + args.steps:
+            loss = graphed(b)                 # copies into the static inputs, one graph replay, the optimizer's launch
+        else:                                 # (the tail after the timed window runs launch by launch: it feeds the launch tables)
+            out = model.forward_sampled(b.features, blocks, last_hop_reduced=b.last_hop_reduced)
+            loss = ops.cross_entropy(out, b.labels)
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
         ev1.record()
         if args.warmup <= done < args.warmup + args.steps:
             events.append((ev0, ev1))
@@ -1196,6 +1214,8 @@ def run_minibatch(args, c):
                    "sampler_mode": ("per-batch seeds, %d native sampler threads (batch b under random.seed(batch_seed(%d, 0, b)))" % (
                        k_threads, args.seed)) if k_threads > 0 else "one sequential stream on the interpreter's generator",
                    "outermost_hop_translation": "host" if device_graph is None else "device gather from pinned positions",
+                   "consumer_step": "one HIP graph on padded static block shapes + the optimizer's launch" if graphed is not None
+                   else "launch by launch",
                    "cache_miss_rate": cache.get_miss_rate(),
                    "epoch_time_s_153431_train_nodes": elapsed / steps * (153_431 / args.mb_batch),
                    "roofline": roofline, "spmm_launch_table": table, "dense_launch_table": dense_table})

@@ -75,3 +75,138 @@ class GraphedTrainStep:
         if self.sync_after_replay:
             torch.cuda.current_stream().synchronize()
         return self.loss
+
+
+class PaddedBlock:
+    """Factory of the CSR block of one hop of a sampled batch on STATIC shapes: `rows` destination rows over `cols` source rows
+    (cols = rows x fan-out, the hop's upper bound), the row pointers in a buffer that is refilled per batch (pad(): the rows a
+    batch does not use are empty, the source rows it does not use belong to no edge).  Everything derived from the row pointers
+    is recomputed on every call -- inside a captured step that means on every replay."""
+
+    @staticmethod
+    def make(rows, fanout, device):
+        from .graph import CSRGraph
+
+        class _Block(CSRGraph):
+            identity_cols = True
+
+            def degrees(self):                       # never cached: the row pointers change under the captured step
+                return self.rowptr[1:] - self.rowptr[:-1]
+
+            def row_index(self):
+                """Destination row of every source row; source rows past the batch's edges (no destination) are clamped to the
+                last row and masked out by edge_mask()."""
+                r = torch.searchsorted(self.rowptr[1:], self._edge_ids, right=True)
+                return r.clamp_(max=self.n_rows - 1)
+
+            def edge_mask(self):
+                return self._edge_ids < self.rowptr[-1]
+
+        cols = rows * fanout
+        rowptr = torch.arange(0, cols + 1, fanout, dtype=torch.int64, device=device)
+        g = _Block(rowptr, torch.arange(cols, dtype=torch.int32, device=device), None, rows, cols, check=False)
+        g.max_degree = fanout
+        g._edge_ids = torch.arange(cols, dtype=torch.int64, device=device)
+        return g
+
+    @staticmethod
+    def pad(block, rowptr, n_edges):
+        """Load a batch's row pointers ([n + 1] entries, the last one = n_edges) into the block's static buffer."""
+        n = int(rowptr.numel()) - 1
+        if n > block.n_rows or n_edges > block.n_cols:
+            raise ValueError("a batch larger than the static block (%d rows / %d edges against %d / %d)" % (n, n_edges, block.n_rows,
+                                                                                                         block.n_cols))
+        block.rowptr[:n + 1].copy_(rowptr, non_blocking=True)
+        if n < block.n_rows:
+            block.rowptr[n + 1:].fill_(n_edges)
+
+
+class GraphedSampledStep:
+    """forward_sampled -> cross-entropy -> backward of a sampled GraphSAGE batch as ONE HIP graph, the optimizer step behind it.
+
+    A sampled step on the Reddit shape is ~80 launches of a few microseconds each: issued one by one through Python the consumer
+    thread needs 2.1 ms per batch for 1.4 ms of kernels, and it shares the interpreter with the loading thread.  The blocks of a
+    batch differ in size from batch to batch but are bounded by batch x prod(fan-outs): the step is captured ONCE on those bounds
+    (PaddedBlock) and replayed on every batch after a handful of copies into its static inputs.  Rows a batch does not fill are
+    empty rows / rows no edge points at: they receive zero gradient (their labels are ignored, no edge carries gradient to
+    them) and hold finite stale values, so they add exact zeros to the weight gradients.  The optimizer's step stays outside the
+    graph (its bias corrections are host scalars of the launch): one more launch.
+
+    model: GraphSage on the GPU (standard layers: hops of a layer batched, forward_sampled's fast path); optimizer: FlatAdam (the
+    weight-gradient kernels write its gradient slots in place -- the replay refills them) or any torch optimizer.
+    fanouts: the sampler's, in the model's order; the outermost hop arrives reduced (Batch.last_hop_reduced)."""
+
+    def __init__(self, model, optimizer, batch_size, fanouts, in_feats, n_classes, dtype=torch.bfloat16, device="cuda", warmup=2):
+        from . import ops
+
+        if not torch.cuda.is_available():
+            raise RuntimeError("GraphedSampledStep captures a HIP graph: a GPU is required")
+        self.model, self.optimizer = model, optimizer
+        dev = self.device = torch.device(device)
+        order = [int(f) for f in reversed(fanouts)]                  # hop h -> h + 1 was sampled with order[h] (base_sampler.py:30-58)
+        L = self.L = len(order)
+        self.rows = [int(batch_size)]
+        for f in order[:-1]:
+            self.rows.append(self.rows[-1] * f)                      # rows of hops 0 .. L-1 (upper bounds)
+        total = sum(self.rows)
+        store = ops.alloc_features(total, in_feats, dtype, dev)
+        store.zero_()
+        self.feat_all = store
+        offs = [0]
+        for r in self.rows:
+            offs.append(offs[-1] + r)
+        self.features = [store[offs[h]:offs[h + 1]] for h in range(L)]             # consecutive row slices: stacked without a copy
+        self.reduced = ops.alloc_features(self.rows[L - 1], in_feats, dtype, dev)   # the outermost hop's reduction, per hop L-1 row
+        self.reduced.zero_()
+        self.blocks = [PaddedBlock.make(self.rows[h], order[h], dev) for h in range(L - 1)] + [None]
+        self.labels = torch.full((self.rows[0],), -100, dtype=torch.int64, device=dev)
+        # synthetic full-size contents for the warm-up and the capture (finite features, every label valid)
+        store.normal_()
+        self.reduced.normal_()
+        self.labels.random_(0, int(n_classes))
+        self._ops = ops
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):                                 # same stream for warm-up and capture (see GraphedTrainStep)
+            for _ in range(max(1, warmup)):
+                self._zero_grad()
+                self._forward_backward()
+            self._zero_grad()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, stream=side, capture_error_mode="thread_local"):
+            self.loss = self._forward_backward()
+        torch.cuda.synchronize(dev)
+
+    def _zero_grad(self):
+        self.optimizer.zero_grad(set_to_none=True)
+
+    def _forward_backward(self):
+        out = self.model.forward_sampled(self.features, self.blocks, last_hop_reduced=self.reduced)
+        loss = self._ops.cross_entropy(out, self.labels)
+        loss.backward()
+        return loss.detach()
+
+    def load(self, batch):
+        """Copy one pipeline batch (features of hops 0 .. L-1, the reduced outermost hop, CSR blocks, labels) into the static inputs,
+        on the current stream."""
+        L = self.L
+        n = [int(batch.features[h].shape[0]) for h in range(L)]
+        for h in range(L):
+            if n[h] > self.rows[h]:
+                raise ValueError("hop %d of the batch has %d rows, the captured step holds %d" % (h, n[h], self.rows[h]))
+            self.features[h][:n[h]].copy_(batch.features[h], non_blocking=True)
+        self.reduced[:n[L - 1]].copy_(batch.last_hop_reduced, non_blocking=True)
+        for h in range(L - 1):
+            PaddedBlock.pad(self.blocks[h], batch.blocks[h].rowptr, n[h + 1])
+        if n[0] < self.rows[0]:
+            self.labels.fill_(-100)
+        self.labels[:n[0]].copy_(batch.labels, non_blocking=True)
+
+    def __call__(self, batch):
+        """One training step on `batch`; returns the (static) loss tensor: read it before the next call."""
+        self.load(batch)
+        self.graph.replay()
+        self.optimizer.step()
+        return self.loss

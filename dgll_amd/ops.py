@@ -154,6 +154,9 @@ class _Spmm(torch.autograd.Function):
             if ctx.reduce == "mean":
                 gs = g * (1.0 / graph.degrees().clamp(min=1).to(torch.float32)).unsqueeze(1).to(g.dtype)
             grad_x = gs.index_select(0, graph.row_index())
+            mask = getattr(graph, "edge_mask", None)       # a block on static shapes (graphs.PaddedBlock): source rows past the
+            if mask is not None:                           # batch's edges belong to no destination and receive exact zeros
+                grad_x = grad_x * mask().unsqueeze(1).to(grad_x.dtype)
             w = graph.val if val is None else val.detach()
             if w is not None:
                 grad_x = grad_x * w.unsqueeze(1).to(grad_x.dtype)

@@ -193,6 +193,8 @@ class MiniBatchPipeline:
         self.device_graph = device_graph
         self.build_blocks = bool(build_blocks)
         self._ring = None
+        self._staging = None           # pinned ring for the batches' small arrays (sample_seeded(staging=)): one upload per batch
+        self._labels_dev = None
         self._memory_bound_set = False
         self.hops = hops
         self.load_stream = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None   # d_stream
@@ -219,8 +221,9 @@ class MiniBatchPipeline:
             for i in range(t, n_batches, self.sampler_threads):
                 seeds = dl.train_nodes[i * dl.batch_size:(i + 1) * dl.batch_size]
                 buf = self._ring.acquire if self._ring is not None else None
+                stg = self._staging.acquire if self._staging is not None else None
                 inp, outp, subgs = dl.sampler.sample_seeded(dl.Dgraph, seeds, batch_seed(self.base_seed, self.epoch, i), max_threads=1,
-                                                            last_hop_buffer=buf)
+                                                            last_hop_buffer=buf, staging=stg)
                 handoff.put(i, (i, inp, outp, subgs))
         except BaseException as exc:  # noqa: BLE001
             self._error = exc
@@ -264,10 +267,10 @@ class MiniBatchPipeline:
             self._late_release = getattr(last, "buffer_token", None)    # a pinned buffer still to be uploaded: freed with b.ready
         return ids
 
-    def _translate_on_device(self, sg):
+    def _translate_on_device(self, sg, device_inputs=None):
         """positions -> neighbour ids on the loading stream: ids[k] = indices[indptr[seed(k)] + position[k]]."""
         indptr, indices = self.device_graph
-        hop_seeds, counts = sg.pending_positions
+        hop_seeds, counts = sg.pending_positions if device_inputs is None else device_inputs
         pos = sg._src
         with torch.cuda.stream(self.load_stream):
             seeds_d = hop_seeds.to(self.device, non_blocking=True)
@@ -311,6 +314,13 @@ class MiniBatchPipeline:
                 t_load = time.perf_counter()
                 b = Batch()
                 b.step, b.input_nodes, b.output_nodes, b.subgraphs = item
+                staged = getattr(b.subgraphs[0], "staged", None) if self.load_stream is not None else None
+                if staged is not None:
+                    self._load_staged(b, staged)
+                    self.load_seconds += time.perf_counter() - t_load
+                    self.load_batches += 1
+                    self.queue.put(b)
+                    continue
                 if self.hops == "sampled":
                     id_lists = self._hop_ids(b)
                     b.input_nodes = id_lists[-1]
@@ -360,6 +370,63 @@ class MiniBatchPipeline:
         finally:
             self.queue.put(_DONE)
 
+    def _load_staged(self, b, staged):
+        """The loading stage for a batch whose small arrays arrive packed in one pinned buffer (FastNeighborSampler.sample_seeded(
+        staging=)): ONE upload, everything else is views of it on the device -- the seeds and the hops' source ids (fetched with one
+        gather), the row pointers (CSR blocks, the outermost hop's fused reduction), the outermost hop's seeds and counts (device-side
+        translation of its positions).  The host arrays of the sugbraphs are replaced by these device views: the pinned buffer goes
+        back to its ring as soon as the upload has run."""
+        L = len(b.subgraphs)
+        off, n = staged.offsets, staged.rows                       # n[h]: rows of hop h; rows of hop h + 1 = edges of hop h
+        with torch.cuda.stream(self.load_stream):
+            dev = staged.tensor().to(self.device, non_blocking=True)
+            uploaded = torch.cuda.Event()
+            uploaded.record(self.load_stream)
+            ids = [dev[off["seeds"]:off["seeds"] + n[0]]]
+            for h in range(L - 1):
+                sg = b.subgraphs[L - 1 - h]
+                n_src = int(sg._src.shape[0])
+                ids.append(dev[off["src"][h]:off["src"][h] + n_src])
+                sg._src = ids[-1]                                      # the host copy lived in the pinned buffer
+            ptrs = [dev[off["ptr"][h]:off["ptr"][h] + n[h] + 1] for h in range(L)]
+            for h in range(L):
+                b.subgraphs[L - 1 - h].indptr = ptrs[h]
+                b.subgraphs[L - 1 - h].staged = None
+            last = b.subgraphs[0]
+            if self.device_graph is not None and getattr(last, "pending_positions", None) is not None and getattr(last, "_finish", None) is not None:
+                ids.append(self._translate_on_device(last, device_inputs=(ids[L - 1], ptrs[L - 1][1:] - ptrs[L - 1][:-1])))
+            else:
+                ids.append(last.src_nodes())
+                self._late_release = getattr(last, "buffer_token", None)
+            b.input_nodes = ids[-1]
+            self._staging.release(staged.token, uploaded)      # (after the host-side translation above, which reads the hop's seeds)
+            if self.reduce_last_hop is not None:
+                rows = self._fetch(torch.cat(ids[:-1]))
+                b.features = list(rows.split([int(t.numel()) for t in ids[:-1]])) + [None]
+                if self.record_access:
+                    self.cache.record_access(ids[-1], stream=self.load_stream)
+                b.last_hop_reduced = self.cache.aggregate_data(ids[-1], ptrs[L - 1], reduce=self.reduce_last_hop, stream=self.load_stream)
+            else:
+                dev_ids = [torch.as_tensor(t).reshape(-1).to(self.device, dtype=torch.int64, non_blocking=True) for t in ids]
+                rows = self._fetch(torch.cat(dev_ids))
+                b.features = list(rows.split([int(t.numel()) for t in dev_ids]))
+            if self._labels_dev is not None:
+                b.labels = self._labels_dev[ids[0]]
+            elif self.labels is not None:
+                b.labels = self.labels[b.output_nodes].to(self.device, non_blocking=True)
+            b.blocks = [None if (h == L - 1 and self.reduce_last_hop is not None) else b.subgraphs[L - 1 - h].to_block(self.device)
+                        for h in range(L)]
+            b.ready = torch.cuda.Event()
+            b.ready.record(self.load_stream)
+            if self._ring is not None and getattr(self, "_late_release", None) is not None:
+                self._ring.release(self._late_release, b.ready)
+                self._late_release = None
+        if not self._memory_bound_set:
+            self._memory_bound_set = True
+            nbytes = sum(t.numel() * t.element_size() for t in list(b.features) + [b.last_hop_reduced] if t is not None)
+            free, _total = torch.cuda.mem_get_info(self.device)
+            self.queue.set_memory_bound(nbytes, self.memory_fraction * free)
+
     def _fetch_many(self, id_lists):
         """Features of several id lists with ONE gather: the lists' rows are consecutive slices of one buffer (one id upload, one
         launch; GraphSage.forward_sampled stacks the hops of a layer without copying them)."""
@@ -391,6 +458,11 @@ class MiniBatchPipeline:
             for f in self.dataloader.sampler.fanouts:
                 cap *= int(f)
             self._ring = PinnedRing(3 * self.sampler_threads + 4, cap)       # more buffers than batches can be in flight before the upload
+            if self.hops == "sampled" and self.cache is not None and self.build_blocks and hasattr(self.dataloader.sampler, "staging_entries"):
+                self._staging = PinnedRing(3 * self.sampler_threads + 4,
+                                           self.dataloader.sampler.staging_entries(self.dataloader.batch_size, self.dataloader.sampler.fanouts))
+                if self.labels is not None and self._labels_dev is None:
+                    self._labels_dev = self.labels.to(self.device)
         self._thread = threading.Thread(target=self._sample_threaded if self.sampler_threads > 0 else self._sample,
                                         name="dgll-sample-producer", daemon=True)
         self._loader = threading.Thread(target=self._load, name="dgll-feature-loader", daemon=True)

@@ -42,6 +42,18 @@ def _seed_key(seed):
     return np.array(words or [0], dtype=np.uint32)
 
 
+class StagedBatch:
+    """What sample_seeded(staging=) packed into one buffer: `buffer` (int64 numpy view of the pinned memory), `offsets`
+    {"seeds": 0, "src": [offset of hop h's source ids, h < L-1], "ptr": [offset of hop h's row pointers]}, `rows` [rows of hop h]
+    (rows of hop h + 1 = edges of hop h), `token` for the ring the buffer came from."""
+
+    def __init__(self, token, buffer, offsets):
+        self.token, self.buffer, self.offsets, self.rows = token, buffer, offsets, []
+
+    def tensor(self):
+        return torch.from_numpy(self.buffer)
+
+
 class _LazyInput:
     """Stands for `subgs[0].src_nodes()` (the input nodes of the batch) without forcing the deferred translation."""
 
@@ -105,13 +117,28 @@ class FastNeighborSampler(Base_sampler):
             sg.pending_positions = (torch.from_numpy(seeds), torch.from_numpy(counts))
         return sg
 
-    def sample_seeded(self, g, seed_nodes, seed, max_threads=1, last_hop_buffer=None):
+    @staticmethod
+    def staging_entries(batch_size, fanouts):
+        """int64 entries of the staging buffer of one batch (sample_seeded(staging=)): seeds, the source ids of every hop but the
+        outermost, the row pointers of every hop."""
+        order = [int(f) for f in reversed(fanouts)]
+        rows = [int(batch_size)]
+        for f in order[:-1]:
+            rows.append(rows[-1] * f)
+        return rows[0] + sum(rows[1:]) + sum(r + 1 for r in rows)
+
+    def sample_seeded(self, g, seed_nodes, seed, max_threads=1, last_hop_buffer=None, staging=None):
         """The whole batch under ITS OWN generator, seeded as random.seed(seed) seeds the interpreter's: the ids the reference loop
         draws right after that call.  Touches neither the global `random` state nor any shared scratch, and the native call runs
         without the GIL: several threads may each draw whole batches at the same time (MiniBatchPipeline(sampler_threads=K)).
         Returns what `sample` returns.  last_hop_buffer: optional callable(capacity) -> (int64 numpy array of that many entries,
         token) supplying the outermost hop's id/position array (the pipeline hands out pinned host memory so that the upload is
-        an asynchronous DMA); the token is attached to the outermost sugbraph as `.buffer_token`."""
+        an asynchronous DMA); the token is attached to the outermost sugbraph as `.buffer_token`.
+        staging: optional callable(entries) -> (int64 numpy array, token): ONE (pinned) buffer that receives everything else of the
+        batch a device consumer needs -- [seeds | source ids of hop 0 | ... of hop L-2 | row pointers of hop 0 | ... of hop L-1],
+        each block at its upper-bound offset -- so that the loading stage uploads it with one copy instead of one per array
+        (ten pageable copies of ~0.1 ms each were half of that thread's time per batch).  Every sugbraph of the batch then carries
+        `.staged` = StagedBatch(token, buffer as a tensor, offsets, rows per hop)."""
         if any(f is None for f in self.fanouts):
             raise ValueError("sample_seeded needs integer fan-outs")
         indptr, indices = self._csr(g)
@@ -126,6 +153,23 @@ class FastNeighborSampler(Base_sampler):
             n_prev = n_prev * f
         cap = np.array(caps, dtype=np.int64)
         src = [np.empty(c, dtype=np.int64) for c in caps]
+        staged = None
+        if staging is not None:
+            rows_cap = [len(seeds)] + caps[:-1]                                # rows of hop h: upper bounds
+            entries = rows_cap[0] + sum(rows_cap[1:]) + sum(r + 1 for r in rows_cap)
+            got = staging(entries)
+            if got is not None:
+                buf, stoken = got
+                off, o = {"seeds": 0, "src": [], "ptr": []}, rows_cap[0]
+                buf[:rows_cap[0]] = seeds
+                for h in range(L - 1):
+                    off["src"].append(o)
+                    src[h] = buf[o:o + caps[h]]
+                    o += caps[h]
+                for h in range(L):
+                    off["ptr"].append(o)
+                    o += rows_cap[h] + 1
+                staged = StagedBatch(stoken, buf, off)
         token = None
         if last_hop_buffer is not None:
             got = last_hop_buffer(caps[-1])
@@ -146,7 +190,12 @@ class FastNeighborSampler(Base_sampler):
         for h in range(L):
             n_h = int(n_out[h])
             cnt = counts[h][:len(hop_seeds)]
-            ptr = np.zeros(len(hop_seeds) + 1, dtype=np.int64)
+            if staged is not None:
+                o = staged.offsets["ptr"][h]
+                ptr = staged.buffer[o:o + len(hop_seeds) + 1]
+                ptr[0] = 0
+            else:
+                ptr = np.zeros(len(hop_seeds) + 1, dtype=np.int64)
             np.cumsum(cnt, out=ptr[1:])
             s_h, d_h = src[h][:n_h], dst[h][:n_h]
             finish = None
@@ -158,6 +207,9 @@ class FastNeighborSampler(Base_sampler):
                 sg.pending_positions = (torch.from_numpy(hop_seeds), torch.from_numpy(cnt))
             if h == L - 1:
                 sg.buffer_token = token
+            if staged is not None:
+                staged.rows.append(len(hop_seeds))
+                sg.staged = staged
             subgs.insert(0, sg)
             hop_seeds = s_h
         return _LazyInput(subgs[0]) if defer else subgs[0].src_nodes(), seed_nodes, subgs

@@ -1,0 +1,107 @@
+"""dgll_amd.graphs.GraphedSampledStep: a sampled GraphSAGE step (graphage.py:47-63's loop body on sageconv.py:103-114's hop pyramid)
+captured once on padded static block shapes and replayed per batch -- against the launch-by-launch step on the same batches."""
+import types
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _batch(dev, rng, batch, order, feats, classes, fill):
+    """A pipeline-shaped batch with variable fan-out: hop h + 1 holds one row per sampled edge of hop h (duplicates kept, as the
+    reference's sampler hands them on); `fill` in (0, 1]: share of the seed slots used."""
+    from dgll_amd.graph import CSRGraph
+    from dgll_amd import ops
+
+    n = [max(1, int(batch * fill))]
+    blocks = []
+    for f in order:
+        deg = torch.randint(0, f + 1, (n[-1],), generator=rng)
+        deg[0] = f
+        rowptr = torch.zeros(n[-1] + 1, dtype=torch.int64)
+        torch.cumsum(deg, 0, out=rowptr[1:])
+        n.append(int(rowptr[-1]))
+        g = CSRGraph(rowptr.to(dev), torch.arange(n[-1], dtype=torch.int32, device=dev), None, n[-2], n[-1], check=False)
+        g.identity_cols, g.max_degree = True, f
+        blocks.append(g)
+    L = len(order)
+    store = ops.alloc_features(sum(n[:L]), feats, torch.bfloat16, dev)
+    store.copy_(torch.randn(sum(n[:L]), feats, generator=rng).to(dev))
+    offs = [0]
+    for r in n[:L]:
+        offs.append(offs[-1] + r)
+    features = [store[offs[h]:offs[h + 1]] for h in range(L)] + [None]
+    # the outermost hop arrives reduced: one row per hop L-1 node
+    reduced = ops.alloc_features(n[L - 1], feats, torch.bfloat16, dev)
+    reduced.copy_(torch.randn(n[L - 1], feats, generator=rng).to(dev))
+    labels = torch.randint(0, classes, (n[0],), generator=rng).to(dev)
+    return types.SimpleNamespace(features=features, last_hop_reduced=reduced, blocks=blocks[:L - 1] + [None], labels=labels)
+
+
+def _eager(model, opt, b, ops):
+    opt.zero_grad(set_to_none=True)
+    loss = ops.cross_entropy(model.forward_sampled(b.features, b.blocks, last_hop_reduced=b.last_hop_reduced), b.labels)
+    loss.backward()
+    return float(loss), [p.grad.detach().clone() for p in model.parameters()]
+
+
+def test_replayed_step_equals_the_eager_step_batch_by_batch(cuda_device):
+    from dgll_amd import nn as dnn, ops
+    from dgll_amd.graphs import GraphedSampledStep
+    from dgll_amd.optim import FlatAdam
+
+    dev = cuda_device
+    fanouts, batch, feats, classes = [5, 4, 3], 64, 40, 7
+    order = list(reversed(fanouts))
+    rng = torch.Generator().manual_seed(0)
+    batches = [_batch(dev, rng, batch, order, feats, classes, fill) for fill in (1.0, 1.0, 0.4, 1.0)]
+    torch.manual_seed(1)
+    model = dnn.GraphSage(feats, [32, 32, classes], fanouts).to(dev)
+    opt = FlatAdam(list(model.parameters()), lr=0.0)                  # lr 0: the parameters stay put, every batch is comparable
+    step = GraphedSampledStep(model, opt, batch, fanouts, feats, classes, device=dev)
+    ref = [_eager(model, opt, b, ops) for b in batches]
+    got = []
+    for b in batches + [batches[0]]:                                   # ... and the first batch again, after a smaller one
+        loss = step(b)
+        got.append((float(loss), [p.grad.detach().clone() for p in model.parameters()]))
+    for (lr_, gr), (lg, gg) in zip(ref + [ref[0]], got):
+        assert lg == pytest.approx(lr_, rel=1e-5)
+        for a, b_ in zip(gg, gr):
+            assert float((a - b_).abs().max()) <= 2e-3 * float(b_.abs().max()) + 1e-7
+    # rows a batch does not fill contribute exact zeros: the same batch gives the same bits whatever was loaded before it
+    assert got[0][0] == got[-1][0]
+    for a, b_ in zip(got[0][1], got[-1][1]):
+        assert torch.equal(a, b_)
+    with pytest.raises(ValueError):
+        step.load(_batch(dev, rng, 2 * batch, order, feats, classes, 1.0))
+
+
+def test_replayed_training_follows_the_eager_loop(cuda_device):
+    """Several optimizer steps: the captured forward / backward + FlatAdam's launch against the eager loop from the same start."""
+    from dgll_amd import nn as dnn, ops
+    from dgll_amd.graphs import GraphedSampledStep
+    from dgll_amd.optim import FlatAdam
+
+    dev = cuda_device
+    fanouts, batch, feats, classes = [4, 3], 128, 24, 5
+    order = list(reversed(fanouts))
+    rng = torch.Generator().manual_seed(3)
+    batches = [_batch(dev, rng, batch, order, feats, classes, fill) for fill in (1.0, 0.7, 1.0, 0.9, 1.0, 1.0)]
+    losses = {}
+    for mode in ("eager", "graph"):
+        torch.manual_seed(2)
+        model = dnn.GraphSage(feats, [64, classes], fanouts).to(dev)
+        opt = FlatAdam(list(model.parameters()), lr=1e-2)
+        step = GraphedSampledStep(model, opt, batch, fanouts, feats, classes, device=dev) if mode == "graph" else None
+        trace = []
+        for b in batches:
+            if step is not None:
+                trace.append(float(step(b)))
+            else:
+                loss, _ = _eager(model, opt, b, ops)
+                opt.step()
+                trace.append(loss)
+        losses[mode] = trace
+    assert losses["graph"] == pytest.approx(losses["eager"], rel=5e-3)
+    assert losses["graph"][-1] < losses["graph"][0] or losses["eager"][-1] >= losses["eager"][0]
