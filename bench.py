@@ -1077,17 +1077,26 @@ def run_minibatch(args, c):
 
     opt = torch.optim.Adam(model.parameters(), lr=1e-3) if args.torch_adam else FlatAdam(list(model.parameters()), lr=1e-3)
     graphed = None
-    if args.mb_hip_graph == "on" or (args.mb_hip_graph == "auto" and fuse_last and not args.torch_adam):
+    want_graph = args.mb_hip_graph == "on" or (args.mb_hip_graph == "auto" and fuse_last and not args.torch_adam)
+    seen_rows = [0] * L          # the warm-up batches run launch by launch and show how far the hops fill their upper bounds
+    graph_misses = 0
+
+    def capture():
+        # bounds of the captured step: what the warm-up batches reached + 10 % (a multiple of 64 rows), at most batch x prod(fan-outs);
+        # a batch beyond them runs launch by launch (counted in the record).  Captured while the pipeline's threads keep working
+        # (capture_error_mode = thread_local).
         from dgll_amd.graphs import GraphedSampledStep
 
+        rows = [args.mb_batch] + [-(-int(r * 1.1) // 64) * 64 for r in seen_rows[1:]]
         try:
-            graphed = GraphedSampledStep(model, opt, args.mb_batch, fanouts, args.mb_feats, args.mb_classes, dtype=c.dtype, device=c.dev)
+            return GraphedSampledStep(model, opt, args.mb_batch, fanouts, args.mb_feats, args.mb_classes, dtype=c.dtype, device=c.dev, rows=rows)
         except Exception as exc:  # noqa: BLE001  (auto: a stack that cannot capture the step runs it launch by launch, and says so)
             if args.mb_hip_graph == "on":
                 raise
             print("bench.py: HIP-graph capture of the sampled step failed (%s: %s); running launch by launch" % (type(exc).__name__, exc),
                   file=sys.stderr, flush=True)
             opt.zero_grad(set_to_none=True)
+            return None
     random.seed(args.seed)
     timer_cm = ops.LaunchTimer()
     done = edges = 0
@@ -1111,6 +1120,8 @@ def run_minibatch(args, c):
         if prof is not None and done == args.warmup:
             prof.enable()
         if done == args.warmup:
+            if want_graph:
+                graphed = capture()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             s0 = TimedSampler.seconds
@@ -1129,9 +1140,17 @@ def run_minibatch(args, c):
         blocks = b.blocks          # built by the loading stage on its own stream (the outermost one is None: reduced out of the cache)
         if blocks[L - 1] is None and b.last_hop_reduced is None:
             blocks[L - 1] = b.subgraphs[0].to_block(c.dev)
-        if graphed is not None and done < args.warmup + args.steps:
-            loss = graphed(b)                 # copies into the static inputs, one graph replay, the optimizer's launch
-        else:                                 # (the tail after the timed window runs launch by launch: it feeds the launch tables)
+        use_graph = graphed is not None and done < args.warmup + args.steps
+        if use_graph:
+            try:
+                loss = graphed(b)             # copies into the static inputs, one graph replay, the optimizer's launch
+            except ValueError:                # a batch beyond the captured bounds
+                use_graph = False
+                graph_misses += 1
+        if done < args.warmup:
+            for h in range(L):
+                seen_rows[h] = max(seen_rows[h], int(b.features[h].shape[0]) if b.features[h] is not None else 0)
+        if not use_graph:                     # (also the tail after the timed window: launch by launch, it feeds the launch tables)
             out = model.forward_sampled(b.features, blocks, last_hop_reduced=b.last_hop_reduced)
             loss = ops.cross_entropy(out, b.labels)
             opt.zero_grad(set_to_none=True)
@@ -1214,7 +1233,8 @@ def run_minibatch(args, c):
                    "sampler_mode": ("per-batch seeds, %d native sampler threads (batch b under random.seed(batch_seed(%d, 0, b)))" % (
                        k_threads, args.seed)) if k_threads > 0 else "one sequential stream on the interpreter's generator",
                    "outermost_hop_translation": "host" if device_graph is None else "device gather from pinned positions",
-                   "consumer_step": "one HIP graph on padded static block shapes + the optimizer's launch" if graphed is not None
+                   "consumer_step": ("one HIP graph on padded static block shapes (rows per hop %s, %d of %d timed batches beyond them ran "
+                                     "launch by launch) + the optimizer's launch" % (graphed.rows, graph_misses, steps)) if graphed is not None
                    else "launch by launch",
                    "cache_miss_rate": cache.get_miss_rate(),
                    "epoch_time_s_153431_train_nodes": elapsed / steps * (153_431 / args.mb_batch),

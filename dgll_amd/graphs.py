@@ -84,26 +84,24 @@ class PaddedBlock:
     is recomputed on every call -- inside a captured step that means on every replay."""
 
     @staticmethod
-    def make(rows, fanout, device):
+    def make(rows, fanout, device, cols=None):
+        """cols: bound on the block's edges (= rows of the next hop); default rows x fanout, the hop's upper bound."""
         from .graph import CSRGraph
 
         class _Block(CSRGraph):
             identity_cols = True
+            padded = True
 
             def degrees(self):                       # never cached: the row pointers change under the captured step
                 return self.rowptr[1:] - self.rowptr[:-1]
 
             def row_index(self):
-                """Destination row of every source row; source rows past the batch's edges (no destination) are clamped to the
-                last row and masked out by edge_mask()."""
-                r = torch.searchsorted(self.rowptr[1:], self._edge_ids, right=True)
-                return r.clamp_(max=self.n_rows - 1)
+                """Destination row of every source row; n_rows for the source rows past the batch's edges (they have none: the block's
+                backward reads an appended all-zero gradient row for them, ops._Spmm.backward)."""
+                return torch.searchsorted(self.rowptr[1:], self._edge_ids, right=True)
 
-            def edge_mask(self):
-                return self._edge_ids < self.rowptr[-1]
-
-        cols = rows * fanout
-        rowptr = torch.arange(0, cols + 1, fanout, dtype=torch.int64, device=device)
+        cols = rows * fanout if cols is None else int(cols)
+        rowptr = torch.clamp(torch.arange(0, rows * fanout + 1, fanout, dtype=torch.int64, device=device), max=cols)
         g = _Block(rowptr, torch.arange(cols, dtype=torch.int32, device=device), None, rows, cols, check=False)
         g.max_degree = fanout
         g._edge_ids = torch.arange(cols, dtype=torch.int64, device=device)
@@ -129,14 +127,15 @@ class GraphedSampledStep:
     batch differ in size from batch to batch but are bounded by batch x prod(fan-outs): the step is captured ONCE on those bounds
     (PaddedBlock) and replayed on every batch after a handful of copies into its static inputs.  Rows a batch does not fill are
     empty rows / rows no edge points at: they receive zero gradient (their labels are ignored, no edge carries gradient to
-    them) and hold finite stale values, so they add exact zeros to the weight gradients.  The optimizer's step stays outside the
+    them: the block's backward reads an all-zero row for them) and hold finite stale values, so they add exact zeros to the weight gradients.  The optimizer's step stays outside the
     graph (its bias corrections are host scalars of the launch): one more launch.
 
     model: GraphSage on the GPU (standard layers: hops of a layer batched, forward_sampled's fast path); optimizer: FlatAdam (the
     weight-gradient kernels write its gradient slots in place -- the replay refills them) or any torch optimizer.
     fanouts: the sampler's, in the model's order; the outermost hop arrives reduced (Batch.last_hop_reduced)."""
 
-    def __init__(self, model, optimizer, batch_size, fanouts, in_feats, n_classes, dtype=torch.bfloat16, device="cuda", warmup=2):
+    def __init__(self, model, optimizer, batch_size, fanouts, in_feats, n_classes, dtype=torch.bfloat16, device="cuda", warmup=2,
+                 rows=None):
         from . import ops
 
         if not torch.cuda.is_available():
@@ -148,6 +147,13 @@ class GraphedSampledStep:
         self.rows = [int(batch_size)]
         for f in order[:-1]:
             self.rows.append(self.rows[-1] * f)                      # rows of hops 0 .. L-1 (upper bounds)
+        if rows is not None:
+            # tighter bounds chosen by the caller (what its batches actually reach, with a margin): the padding is GPU work -- on a
+            # graph with many low-degree nodes the hops fill 70 % of batch x prod(fan-outs) and the upper bounds cost 40 % more
+            # kernel time than the batches need.  A batch that exceeds them is refused by load(): run it launch by launch.
+            if len(rows) != L or any(int(r) < 1 for r in rows):
+                raise ValueError("rows: one bound per hop 0 .. L-1")
+            self.rows = [min(int(r), cap) for r, cap in zip(rows, self.rows)]
         total = sum(self.rows)
         store = ops.alloc_features(total, in_feats, dtype, dev)
         store.zero_()
@@ -158,7 +164,7 @@ class GraphedSampledStep:
         self.features = [store[offs[h]:offs[h + 1]] for h in range(L)]             # consecutive row slices: stacked without a copy
         self.reduced = ops.alloc_features(self.rows[L - 1], in_feats, dtype, dev)   # the outermost hop's reduction, per hop L-1 row
         self.reduced.zero_()
-        self.blocks = [PaddedBlock.make(self.rows[h], order[h], dev) for h in range(L - 1)] + [None]
+        self.blocks = [PaddedBlock.make(self.rows[h], order[h], dev, cols=self.rows[h + 1]) for h in range(L - 1)] + [None]
         self.labels = torch.full((self.rows[0],), -100, dtype=torch.int64, device=dev)
         # synthetic full-size contents for the warm-up and the capture (finite features, every label valid)
         store.normal_()

@@ -150,13 +150,19 @@ class _Spmm(torch.autograd.Function):
         if ctx.needs_input_grad[0] and graph.identity_cols and graph.n_cols == graph.nnz:
             # sampled block (col == arange): source row e receives exactly g[row(e)] (times its weight) -- one gather,
             # no transposed CSR to sort together and no launch plan for it, both of which would be rebuilt every batch
-            gs = g
-            if ctx.reduce == "mean":
-                gs = g * (1.0 / graph.degrees().clamp(min=1).to(torch.float32)).unsqueeze(1).to(g.dtype)
+            scale = (1.0 / graph.degrees().clamp(min=1).to(torch.float32)).unsqueeze(1).to(g.dtype) if ctx.reduce == "mean" else None
+            if getattr(graph, "padded", False):
+                # a block on static shapes (graphs.PaddedBlock): source rows past the batch's edges belong to no destination -- its
+                # row_index() sends them to row n_rows, an extra all-zero row appended to the (scaled) gradient: exact zeros, no mask pass
+                gs = torch.empty((g.shape[0] + 1, g.shape[1]), dtype=g.dtype, device=g.device)
+                gs[g.shape[0]:].zero_()
+                if scale is not None:
+                    torch.mul(g, scale, out=gs[:g.shape[0]])
+                else:
+                    gs[:g.shape[0]].copy_(g)
+            else:
+                gs = g if scale is None else g * scale
             grad_x = gs.index_select(0, graph.row_index())
-            mask = getattr(graph, "edge_mask", None)       # a block on static shapes (graphs.PaddedBlock): source rows past the
-            if mask is not None:                           # batch's edges belong to no destination and receive exact zeros
-                grad_x = grad_x * mask().unsqueeze(1).to(grad_x.dtype)
             w = graph.val if val is None else val.detach()
             if w is not None:
                 grad_x = grad_x * w.unsqueeze(1).to(grad_x.dtype)

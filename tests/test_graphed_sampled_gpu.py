@@ -75,6 +75,18 @@ def test_replayed_step_equals_the_eager_step_batch_by_batch(cuda_device):
         assert torch.equal(a, b_)
     with pytest.raises(ValueError):
         step.load(_batch(dev, rng, 2 * batch, order, feats, classes, 1.0))
+    # tighter bounds than batch x prod(fan-outs) (what a caller's batches reach, plus a margin): same results for the batches that
+    # fit, a refusal for one that does not
+    need = [max(int(b.features[h].shape[0]) for b in batches) for h in range(3)]
+    tight = GraphedSampledStep(model, opt, batch, fanouts, feats, classes, device=dev, rows=[batch, need[1] + 3, need[2] + 5])
+    assert tight.rows[1] < step.rows[1] and tight.rows[2] < step.rows[2]
+    for b, (lr_, gr) in zip(batches, ref):
+        assert float(tight(b)) == pytest.approx(lr_, rel=1e-5)
+        for a, b_ in zip([p.grad for p in model.parameters()], gr):
+            assert float((a - b_).abs().max()) <= 2e-3 * float(b_.abs().max()) + 1e-7
+    small = GraphedSampledStep(model, opt, batch, fanouts, feats, classes, device=dev, rows=[batch, need[1], max(need[2] // 2, 1)])
+    with pytest.raises(ValueError):
+        small.load(batches[0])
 
 
 def test_replayed_training_follows_the_eager_loop(cuda_device):

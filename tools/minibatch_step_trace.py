@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Where a mini-batch's period goes on the GPU (config 2 shape, the bench's own pipeline): kernel time per batch on the consumer's
 stream and on the loading stream (torch profiler over 8 steady-state batches), next to the host time of both threads.
-    python tools/minibatch_step_trace.py"""
+    python tools/minibatch_step_trace.py [--graph]"""
 import os
 import sys
 import time
@@ -42,6 +42,11 @@ def main():
                              sampler_threads=8, base_seed=0, epoch=0, device_graph=device_graph, build_blocks=True)
     model = dnn.GraphSage(f, [256, 256, classes], fanouts).to(dev)
     opt = FlatAdam(list(model.parameters()), lr=1e-3)
+    graphed = None
+    if "--graph" in sys.argv:                 # the consumer's step as one HIP graph (dgll_amd.graphs.GraphedSampledStep)
+        from dgll_amd.graphs import GraphedSampledStep
+
+        graphed = GraphedSampledStep(model, opt, batch, fanouts, f, classes, device=dev)
     compute = torch.cuda.Stream(dev, priority=-1)
     compute.wait_stream(torch.cuda.current_stream(dev))
     prof = profile(activities=[ProfilerActivity.CUDA])
@@ -56,11 +61,14 @@ def main():
                 torch.cuda.synchronize()
                 wall = time.perf_counter() - t0
                 prof.__exit__(None, None, None)
-            out = model.forward_sampled(b.features, b.blocks, last_hop_reduced=b.last_hop_reduced)
-            loss = ops.cross_entropy(out, b.labels)
-            opt.zero_grad(set_to_none=True)
-            loss.backward()
-            opt.step()
+            if graphed is not None:
+                graphed(b)
+            else:
+                out = model.forward_sampled(b.features, b.blocks, last_hop_reduced=b.last_hop_reduced)
+                loss = ops.cross_entropy(out, b.labels)
+                opt.zero_grad(set_to_none=True)
+                loss.backward()
+                opt.step()
             done += 1
     torch.cuda.synchronize()
     evs = [e for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA]
@@ -75,7 +83,7 @@ def main():
         for e in es:
             cnt[e.name[:90]] += 1
             tim[e.name[:90]] += e.time_range.end - e.time_range.start
-        for name, t in tim.most_common(14):
+        for name, t in tim.most_common(22):
             print("    %5.1f x %7.1f us  %s" % (cnt[name] / 8, t / cnt[name], name))
 
 
