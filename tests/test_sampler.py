@@ -228,3 +228,49 @@ def test_per_batch_seeded_sampler_is_bit_exact_under_random_seed_and_thread_safe
     assert batch_seed(7, 3, 11) == (7 << 40) | (3 << 20) | 11
     with pytest.raises(ValueError):
         batch_seed(0, 0, 1 << 20)
+
+
+def test_staged_batch_holds_the_same_ids_in_one_buffer():
+    """sample_seeded(staging=): the seeds, the source ids of every hop but the outermost and every hop's row pointers are written
+    into ONE caller-provided buffer (the pipeline's pinned staging memory: one upload per batch) -- same ids as without it, found at
+    the recorded offsets; staging_entries() is the size of the buffer for a full batch."""
+    from dgll_amd.sampling import FastNeighborSampler
+    from dgll_amd.sampling.fast_sampler import batch_seed
+
+    rng = np.random.default_rng(4)
+    n = 1500
+    edges = [rng.choice(n, size=int(min(n - 1, rng.zipf(1.3))) if v % 11 else 0, replace=False).tolist() for v in range(n)]
+    dg = DGraph(nodes=torch.arange(n), edges=edges, labels=torch.zeros(n), features=torch.zeros(n, 1))
+    fanouts = [6, 4, 3]
+    sampler = FastNeighborSampler(fanouts, defer_last_hop=True)
+    handed = []
+
+    def staging(entries):
+        buf = np.full(entries + 7, -7, dtype=np.int64)
+        handed.append((entries, buf))
+        return buf[:entries], "token"
+
+    for batch in (96, 17):
+        seeds = torch.from_numpy(rng.integers(0, n, size=batch))
+        s = batch_seed(1, 2, batch)
+        plain = sampler.sample_seeded(dg, seeds, s)
+        got = sampler.sample_seeded(dg, seeds, s, staging=staging)
+        entries, buf = handed[-1]
+        assert entries == FastNeighborSampler.staging_entries(batch, fanouts)
+        assert (buf[entries:] == -7).all()                                    # nothing written past the requested entries
+        L = len(fanouts)
+        st = got[2][0].staged
+        assert st is not None and st.token == "token" and all(sg.staged is st for sg in got[2])
+        assert st.rows[0] == batch and len(st.rows) == L
+        assert buf[:batch].tolist() == seeds.tolist()
+        for h in range(L):
+            sg_p, sg_s = plain[2][L - 1 - h], got[2][L - 1 - h]
+            assert sg_s.indptr.tolist() == sg_p.indptr.tolist()
+            o = st.offsets["ptr"][h]
+            assert buf[o:o + st.rows[h] + 1].tolist() == sg_p.indptr.tolist()
+            if h < L - 1:
+                assert sg_s.src_nodes().tolist() == sg_p.src_nodes().tolist()
+                o = st.offsets["src"][h]
+                assert buf[o:o + len(sg_p.src_nodes())].tolist() == sg_p.src_nodes().tolist()
+                assert st.rows[h + 1] == len(sg_p.src_nodes())
+        assert got[0].resolve().tolist() == plain[0].resolve().tolist()
