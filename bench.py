@@ -113,6 +113,10 @@ def parse_args(argv=None):
     ap.add_argument("--mb-hip-graph", choices=["auto", "on", "off"], default="auto",
                     help="minibatch: the consumer's forward + loss + backward as ONE HIP graph on padded static block shapes "
                          "(dgll_amd.graphs.GraphedSampledStep), replayed per batch")
+    ap.add_argument("--mb-dense-kernel", choices=["auto", "4wave"], default="4wave",
+                    help="minibatch: 4wave = every bf16 transform on the 4-wavefront MFMA kernel (dgll_hip_debug_tune(4, 1)) instead of the "
+                         "persistent resident-weights one, whose workgroups need a whole CU's registers and LDS and wait for the loading "
+                         "stream's wavefronts to drain")
     ap.add_argument("--mb-host-translate", action="store_true",
                     help="minibatch: turn the outermost hop's positions into ids on the host (16 threads) instead of by a device gather")
     ap.add_argument("--scale", type=int, default=27, help="rmat27: RMAT scale (27 = config 5; smaller for a quick run)")
@@ -1041,6 +1045,8 @@ def run_minibatch(args, c):
     from dgll_amd import _lib as _dl
 
     _dl.check(_dl.lib.dgll_hip_debug_tune(12, int(args.mb_loader_blocks_per_cu)), "tune")
+    if args.mb_dense_kernel == "4wave":
+        _dl.check(_dl.lib.dgll_hip_debug_tune(4, 1), "tune")
     k_threads = args.mb_sampler_threads if args.mb_sampler_threads >= 0 else max(1, min(8, (os.cpu_count() or 4) // 4))
     lock = __import__("threading").Lock()
 
