@@ -4,6 +4,7 @@ There is no fallback: if the library is missing and cannot be built, importing d
 in-tree location (dgll_amd/lib/libdgll_hip.so) is deliberate -- the driver records which in-tree .so
 files the test processes mapped.
 """
+import contextlib
 import ctypes as C
 import os
 
@@ -134,25 +135,21 @@ for _name, (_res, _args) in SIGNATURES.items():
 # current.  torch.cuda.current_stream() builds a Stream object (2-4 us) and `with torch.cuda.device(d)` a context object (3-4 us):
 # of the ~25 us a launch costs through Python that is a third, and the consumer thread of the mini-batch pipeline issues ~80 launches
 # per 2 ms batch.  Both are replaced by their cheap cores.
-import contextlib as _contextlib
-
-import torch as _torch
-
-_NULL_CTX = _contextlib.nullcontext()
+_NULL_CTX = contextlib.nullcontext()
 
 
 def raw_stream(device):
     """hipStream_t (an int) of torch's current stream on `device`."""
     idx = device.index
-    return _torch._C._cuda_getCurrentRawStream(_torch.cuda.current_device() if idx is None else idx)
+    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device() if idx is None else idx)
 
 
 def on_device(device):
     """Context that makes `device` current for the launch: a shared no-op object when it already is."""
     idx = device.index
-    if idx is None or idx == _torch.cuda.current_device():
+    if idx is None or idx == torch.cuda.current_device():
         return _NULL_CTX
-    return _torch.cuda.device(idx)
+    return torch.cuda.device(idx)
 
 
 def last_error():
