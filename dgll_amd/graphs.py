@@ -162,8 +162,12 @@ class GraphedSampledStep:
         for r in self.rows:
             offs.append(offs[-1] + r)
         self.features = [store[offs[h]:offs[h + 1]] for h in range(L)]             # consecutive row slices: stacked without a copy
-        self.reduced = ops.alloc_features(self.rows[L - 1], in_feats, dtype, dev)   # the outermost hop's reduction, per hop L-1 row
-        self.reduced.zero_()
+        # the first layer's neighbour reductions of all hops in one buffer: the outermost hop's (it arrives ready-made, per hop L-1
+        # row) is its tail, the model writes the others in front of it (GraphSage._forward_sampled_batched) -- no concatenation
+        self.agg_all = ops.alloc_features(total, in_feats, dtype, dev)
+        self.agg_all.zero_()
+        self.reduced = self.agg_all[offs[L - 1]:offs[L]]
+        self.reduced._dgll_stack = self.agg_all
         self.blocks = [PaddedBlock.make(self.rows[h], order[h], dev, cols=self.rows[h + 1]) for h in range(L - 1)] + [None]
         self.labels = torch.full((self.rows[0],), -100, dtype=torch.int64, device=dev)
         # synthetic full-size contents for the warm-up and the capture (finite features, every label valid)

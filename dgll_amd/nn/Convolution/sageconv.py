@@ -69,11 +69,14 @@ class NeighborAggregator(F.nn.Module):
             return ops.segment_max(graph, flat)
         return ops.spmm(graph, flat, reduce=self.aggr_method)
 
-    def reduce_block(self, block, x_src):
-        """Same reduction driven by a CSR block (rows = destination nodes, columns index x_src)."""
+    def reduce_block(self, block, x_src, out=None):
+        """Same reduction driven by a CSR block (rows = destination nodes, columns index x_src).  out: rows of a caller's buffer to
+        write (mean / sum on the GPU)."""
         _check_method(self.aggr_method, ("mean", "sum", "max"), "aggr_method")
         if self.aggr_method == "max":
             return ops.segment_max(block, x_src)
+        if out is not None and x_src.is_cuda:
+            return ops.spmm(block, x_src, reduce=self.aggr_method, out=out)
         return ops.spmm(block, x_src, reduce=self.aggr_method)
 
     def transform(self, reduced):
@@ -247,12 +250,22 @@ class GraphSage(F.nn.Module):
             for hop in range(n_h + (1 if l > 0 else 0)):
                 offs.append(offs[-1] + sizes[hop])
             src = (lambda hop: hidden[hop]) if l == 0 else (lambda hop: parent[offs[hop]:offs[hop + 1]])
+            # the first layer's reductions in ONE buffer when the ready-made outermost one already sits at its tail (the tensor
+            # carries `_dgll_stack`, graphs.GraphedSampledStep): the hops' reductions are written in front of it and the stacked
+            # operand of the transform needs no concatenation (a 130 MB copy per batch at the Reddit shape)
+            stack = None
+            if l == 0 and last_hop_reduced is not None and layer.aggr_neighbor_method in ("mean", "sum"):
+                stack = getattr(last_hop_reduced, "_dgll_stack", None)
+                if stack is not None and not (stack.shape[0] == offs[n_h] and stack.dtype == last_hop_reduced.dtype
+                                              and stack[offs[L - 1]:].data_ptr() == last_hop_reduced.data_ptr()):
+                    stack = None
             aggs = []
             for hop in range(n_h):
                 if l == 0 and hop == L - 1 and last_hop_reduced is not None:
                     aggs.append(last_hop_reduced)
                 else:
-                    aggs.append(layer.neighborAgg.reduce_block(blocks[hop], src(hop + 1)))
+                    aggs.append(layer.neighborAgg.reduce_block(blocks[hop], src(hop + 1),
+                                                               out=stack[offs[hop]:offs[hop + 1]] if stack is not None else None))
             x_dst = self._stack_rows([hidden[hop] for hop in range(n_h)]) if l == 0 else parent[:offs[n_h]]
             parent = layer.transform_block(x_dst, self._stack_rows(aggs))     # hops 0 .. n_h - 1 of the next layer's input
         return parent

@@ -128,8 +128,10 @@ class _Spmm(torch.autograd.Function):
     (gatconv.py:76-78), grad_bias = column sums."""
 
     @staticmethod
-    def forward(ctx, x, val, bias, graph, reduce, relu):
-        y = spmm_raw(graph, x, val=val, reduce=reduce, bias=bias, relu=relu)
+    def forward(ctx, x, val, bias, graph, reduce, relu, out_ref=None):
+        # out_ref: a one-element list holding the destination (rows of a caller's buffer): a list, so that autograd does not take
+        # the buffer for an input of the node
+        y = spmm_raw(graph, x, val=val, reduce=reduce, bias=bias, relu=relu, out=out_ref[0] if out_ref else None)
         ctx.graph, ctx.reduce, ctx.relu = graph, reduce, relu
         ctx.has_bias = bias is not None
         ctx.save_for_backward(x if (val is not None and val.requires_grad) else None, val, y if relu else None)
@@ -190,17 +192,18 @@ class _Spmm(torch.autograd.Function):
             grad_val = sddmm_raw(graph, g, x)
             if ctx.reduce == "mean":
                 grad_val = grad_val / graph.degrees().clamp(min=1).to(torch.float32)[graph.row_index()]
-        return grad_x, grad_val, grad_bias, None, None, None
+        return grad_x, grad_val, grad_bias, None, None, None, None
 
 
-def spmm(graph, x, val=None, reduce="sum", bias=None, relu=False):
+def spmm(graph, x, val=None, reduce="sum", bias=None, relu=False, out=None):
     """Differentiable CSR SpMM on the GPU.  `graph` is a CSRGraph; `val` optional per-edge fp32 weights
-    (defaults to graph.val); `reduce` 'sum' or 'mean'; optional fused bias / ReLU epilogue."""
+    (defaults to graph.val); `reduce` 'sum' or 'mean'; optional fused bias / ReLU epilogue.  out: [n_rows, feat] rows of a
+    caller's buffer to write (several reductions stacked in one buffer feed the next transform without a concatenation)."""
     if not isinstance(graph, CSRGraph):
         raise TypeError("spmm expects a CSRGraph (use dgll_amd.graph.as_csr_graph for torch sparse tensors)")
     if val is None and graph.val is not None and graph.val.requires_grad:
         val = graph.val
-    return _Spmm.apply(x, val, bias, graph, reduce, relu)
+    return _Spmm.apply(x, val, bias, graph, reduce, relu, [out] if out is not None else None)
 
 
 # ------------------------------------------------------------------------------------------------ loss
