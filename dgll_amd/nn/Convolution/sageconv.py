@@ -249,7 +249,16 @@ class GraphSage(F.nn.Module):
             offs = [0]
             for hop in range(n_h + (1 if l > 0 else 0)):
                 offs.append(offs[-1] + sizes[hop])
-            src = (lambda hop: hidden[hop]) if l == 0 else (lambda hop: parent[offs[hop]:offs[hop + 1]])
+            if l == 0:
+                src = lambda hop: hidden[hop]                                                    # noqa: E731
+            else:
+                # the row ranges of the layer's input this layer reads: [0, offs[n_h]) as the transform's self operand and one range per
+                # block's sources -- taken through ONE autograd node (ops.row_slices) whose backward assembles their gradients in a
+                # single buffer; as plain slices every range came back as a full-size zero-filled tensor, summed pairwise
+                bounds = [(0, offs[n_h])] + [(offs[hop + 1], offs[hop + 2]) for hop in range(n_h)]
+                views = ops.row_slices(parent, bounds)
+                x_dst_view, hop_rows = views[0], views[1:]                                       # hop_rows[k]: the rows of hop k + 1
+                src = lambda hop, hop_rows=hop_rows: hop_rows[hop - 1]                           # noqa: E731
             # the first layer's reductions in ONE buffer when the ready-made outermost one already sits at its tail (the tensor
             # carries `_dgll_stack`, graphs.GraphedSampledStep): the hops' reductions are written in front of it and the stacked
             # operand of the transform needs no concatenation (a 130 MB copy per batch at the Reddit shape)
@@ -266,7 +275,7 @@ class GraphSage(F.nn.Module):
                 else:
                     aggs.append(layer.neighborAgg.reduce_block(blocks[hop], src(hop + 1),
                                                                out=stack[offs[hop]:offs[hop + 1]] if stack is not None else None))
-            x_dst = self._stack_rows([hidden[hop] for hop in range(n_h)]) if l == 0 else parent[:offs[n_h]]
+            x_dst = self._stack_rows([hidden[hop] for hop in range(n_h)]) if l == 0 else x_dst_view
             parent = layer.transform_block(x_dst, self._stack_rows(aggs))     # hops 0 .. n_h - 1 of the next layer's input
         return parent
     def forward_graph(self, graph, x):

@@ -206,6 +206,62 @@ def spmm(graph, x, val=None, reduce="sum", bias=None, relu=False, out=None):
     return _Spmm.apply(x, val, bias, graph, reduce, relu, [out] if out is not None else None)
 
 
+class _RowSlices(torch.autograd.Function):
+    """Several row ranges [a, b) of one matrix, possibly overlapping, as one autograd node."""
+
+    @staticmethod
+    def forward(ctx, x, bounds):
+        ctx.bounds, ctx.shape = bounds, x.shape
+        return tuple(x[a:b] for a, b in bounds)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        # one buffer for the matrix's gradient: a range's gradient is COPIED where nothing has been written yet and ADDED where an
+        # earlier range overlaps; rows no range covers are zero-filled.  (Plain slices: a zero-filled full-size tensor per range plus
+        # pairwise full-size additions -- for the three ranges of a 113 k x 256 layer input that is 0.17 ms against 0.07.)
+        ref = next(g for g in grads if g is not None)
+        out = torch.empty(ctx.shape, dtype=ref.dtype, device=ref.device)
+        covered = []                                   # disjoint, sorted [a, b) ranges already written
+        for (a, b), g in zip(ctx.bounds, grads):
+            if g is None or b <= a:
+                continue
+            pos = a
+            for ca, cb in list(covered):
+                if cb <= pos or ca >= b:
+                    continue
+                if ca > pos:                           # a gap before this covered piece: first write
+                    out[pos:ca].copy_(g[pos - a:ca - a])
+                lo, hi = max(ca, pos), min(cb, b)
+                out[lo:hi].add_(g[lo - a:hi - a])
+                pos = hi
+            if pos < b:
+                out[pos:b].copy_(g[pos - a:b - a])
+            covered.append((a, b))
+            covered.sort()
+            merged = [covered[0]]
+            for ca, cb in covered[1:]:
+                if ca <= merged[-1][1]:
+                    merged[-1] = (merged[-1][0], max(merged[-1][1], cb))
+                else:
+                    merged.append((ca, cb))
+            covered = merged
+        pos = 0
+        for ca, cb in covered + [(ctx.shape[0], ctx.shape[0])]:
+            if ca > pos:
+                out[pos:ca].zero_()
+            pos = max(pos, cb)
+        return out, None
+
+
+def row_slices(x, bounds):
+    """[x[a:b] for (a, b) in bounds] through one autograd node (GraphSage._forward_sampled_batched: the stacked hops of a layer's
+    input are read as overlapping row ranges)."""
+    bounds = [(int(a), int(b)) for a, b in bounds]
+    if not x.requires_grad:
+        return [x[a:b] for a, b in bounds]
+    return list(_RowSlices.apply(x, bounds))
+
+
 # ------------------------------------------------------------------------------------------------ loss
 class GateToken:
     """Handshake between a layer that ends in a ReLU and a consumer willing to take that ReLU's backward over (cross_entropy's

@@ -21,6 +21,9 @@ from dgll_amd.pipeline import MiniBatchPipeline  # noqa: E402
 from dgll_amd.sampling import FastNeighborSampler  # noqa: E402
 
 
+NAMEW = 220 if "--wide" in sys.argv else 90          # characters of a kernel's name kept
+
+
 def main():
     dev = torch.device("cuda:0")
     n, f, classes, batch, fanouts = 232965, 602, 41, 1024, [25, 10, 10]
@@ -81,8 +84,8 @@ def main():
         print("stream %s: %d kernels / copies, %.3f ms busy per batch, %.1f launches per batch" % (sid, len(es), tot / 8e3, len(es) / 8))
         cnt, tim = Counter(), Counter()
         for e in es:
-            cnt[e.name[:90]] += 1
-            tim[e.name[:90]] += e.time_range.end - e.time_range.start
+            cnt[e.name[:NAMEW]] += 1
+            tim[e.name[:NAMEW]] += e.time_range.end - e.time_range.start
         for name, t in tim.most_common(22):
             print("    %5.1f x %7.1f us  %s" % (cnt[name] / 8, t / cnt[name], name))
 
