@@ -411,9 +411,24 @@ def grad_weight(x, g, out=None):
 
 
 def grad_weight_pair(x1, x2, g, out1=None, out2=None):
-    """(x1^T . g, x2^T . g): the two weight gradients of a SAGE layer share g -- one launch reads it once."""
+    """(x1^T . g, x2^T . g): the two weight gradients of a SAGE layer share g -- one launch reads it once.  Operands wider than 256
+    columns (the 602-column first layer of the Reddit shape) are cut into 256-column blocks and the blocks of BOTH operands are
+    paired two per launch: 3 launches for 2 x 602 columns where one operand after the other took 4."""
     if _gradw_ok(x1, x2, g):
         return _grad_weight_hip(x1, x2, g, out1=out1, out2=out2)
+    wide = (x1.is_cuda and x1.dtype == x2.dtype == g.dtype == torch.bfloat16 and g.shape[1] <= 256 and _gradw_ok(g)
+            and max(x1.shape[1], x2.shape[1]) > 256)
+    if wide:
+        x1, x2 = _as_rows16(x1), _as_rows16(x2)
+        n = g.shape[1]
+        outs = [o if _out_ok(o, x.shape[1], n, g.device) and o.is_contiguous() else torch.empty((x.shape[1], n), dtype=torch.float32, device=g.device)
+                for o, x in ((out1, x1), (out2, x2))]
+        blocks = [(x[:, k0:k0 + 256], o[k0:k0 + 256]) for x, o in zip((x1, x2), outs) for k0 in range(0, x.shape[1], 256)]
+        if all(_gradw_ok(b) for b, _ in blocks):
+            for i in range(0, len(blocks), 2):
+                (xa, oa), (xb, ob) = blocks[i], (blocks[i + 1] if i + 1 < len(blocks) else (None, None))
+                _grad_weight_hip(xa, xb, g, out1=oa, out2=ob)
+            return outs[0], outs[1]
     return grad_weight(x1, g, out=out1), grad_weight(x2, g, out=out2)
 
 

@@ -164,3 +164,26 @@ def test_grad_weight_shared_x_is_the_two_products(m, k, n1, n2):
     if m:
         assert float((a.double().cpu() - _ref(x, g1)).abs().max()) <= 1e-3 * float(_ref(x, g1).abs().max()) + 1e-3
     assert a.shape == (k, n1) and b.shape == (k, n2)
+
+
+def test_wide_operands_pair_their_column_blocks():
+    """grad_weight_pair with 602-column operands (the first layer at the Reddit shape): the 256-column blocks of both operands are
+    paired two per launch and written straight into the [K, N] destinations -- same results as one operand after the other."""
+    from dgll_amd import dense, ops
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(9)
+    m, k, n = 30000, 602, 256
+    x1 = ops.alloc_features(m, k, torch.bfloat16, dev); x1.copy_(torch.randn(m, k, device=dev))
+    x2 = ops.alloc_features(m, k, torch.bfloat16, dev); x2.copy_(torch.randn(m, k, device=dev))
+    g = torch.randn(m, n, device=dev).to(torch.bfloat16)
+    o1 = torch.full((k, n), float("nan"), device=dev)
+    o2 = torch.full((k, n), float("nan"), device=dev)
+    d1, d2 = dense.grad_weight_pair(x1, x2, g, out1=o1, out2=o2)
+    assert d1 is o1 and d2 is o2
+    for got, x in ((d1, x1), (d2, x2)):
+        ref = _ref(x, g)
+        assert float((got.double().cpu() - ref).abs().max()) <= 2e-3 * float(ref.abs().max())
+        assert torch.equal(got, dense.grad_weight(x, g))              # block by block the same launches' arithmetic
+    a, b = dense.grad_weight_pair(x1, x2[:, :100], g)                   # unequal widths, fresh outputs
+    assert torch.equal(a, d1) and torch.equal(b, d2[:100])
