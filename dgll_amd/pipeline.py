@@ -17,6 +17,7 @@ import os
 import threading
 import time
 
+import numpy as np
 import torch
 
 _DONE = object()
@@ -132,11 +133,11 @@ class PinnedRing:
     sampler and uploaded from it by an asynchronous DMA (a pageable source is staged by the runtime: the loading thread sat in that
     copy for 2-3 ms per batch).  A buffer returns with the event that marks its upload complete and is reused after it."""
 
-    def __init__(self, n_buffers, capacity):
+    def __init__(self, n_buffers, capacity, dtype=torch.int64):
         import queue
 
         self._free = queue.Queue()
-        self.buffers = [torch.empty(int(capacity), dtype=torch.int64, pin_memory=True) for _ in range(int(n_buffers))]
+        self.buffers = [torch.empty(int(capacity), dtype=dtype, pin_memory=True) for _ in range(int(n_buffers))]
         for i in range(len(self.buffers)):
             self._free.put((i, None))
         self.capacity = int(capacity)
@@ -194,6 +195,7 @@ class MiniBatchPipeline:
         self.build_blocks = bool(build_blocks)
         self._ring = None
         self._staging = None           # pinned ring for the batches' small arrays (sample_seeded(staging=)): one upload per batch
+        self._pos_ring = None          # pinned ring of 16- / 32-bit buffers for the outermost hop's positions
         self._labels_dev = None
         self._memory_bound_set = False
         self.hops = hops
@@ -220,10 +222,21 @@ class MiniBatchPipeline:
         try:
             for i in range(t, n_batches, self.sampler_threads):
                 seeds = dl.train_nodes[i * dl.batch_size:(i + 1) * dl.batch_size]
-                buf = self._ring.acquire if self._ring is not None else None
+                buf = self._ring.acquire if (self._ring is not None and self._pos_ring is None) else None
                 stg = self._staging.acquire if self._staging is not None else None
                 inp, outp, subgs = dl.sampler.sample_seeded(dl.Dgraph, seeds, batch_seed(self.base_seed, self.epoch, i), max_threads=1,
                                                             last_hop_buffer=buf, staging=stg)
+                last = subgs[0]
+                if self._pos_ring is not None and getattr(last, "pending_positions", None) is not None and getattr(last, "_finish", None) is not None:
+                    # the outermost hop's neighbour POSITIONS (< the maximum degree) leave the host as 16- or 32-bit integers: they are the
+                    # largest upload of a batch (2.2 M entries at the Reddit shape: 17.6 MB as int64 next to 40 MB of cache misses on a
+                    # link that is the pipeline's bound at a 50 % cache); narrowed here, on the sampling thread, into pinned memory
+                    n_pos = int(last._src.shape[0])
+                    got = self._pos_ring.acquire(n_pos)
+                    if got is not None:
+                        small, tok = got
+                        np.copyto(small, last._src.numpy(), casting="unsafe")
+                        last.positions_compact = (torch.from_numpy(small), tok)
                 handoff.put(i, (i, inp, outp, subgs))
         except BaseException as exc:  # noqa: BLE001
             self._error = exc
@@ -264,23 +277,37 @@ class MiniBatchPipeline:
             ids.append(self._translate_on_device(last))
         else:
             ids.append(last.src_nodes())
+            self._drop_compact(last)
             self._late_release = getattr(last, "buffer_token", None)    # a pinned buffer still to be uploaded: freed with b.ready
         return ids
+
+    def _drop_compact(self, sg):
+        c = getattr(sg, "positions_compact", None)
+        if c is not None:                                   # narrowed positions that no upload will use: back to the ring
+            self._pos_ring.release(c[1], None)
+            sg.positions_compact = None
 
     def _translate_on_device(self, sg, device_inputs=None):
         """positions -> neighbour ids on the loading stream: ids[k] = indices[indptr[seed(k)] + position[k]]."""
         indptr, indices = self.device_graph
         hop_seeds, counts = sg.pending_positions if device_inputs is None else device_inputs
         pos = sg._src
+        compact = getattr(sg, "positions_compact", None)
         with torch.cuda.stream(self.load_stream):
             seeds_d = hop_seeds.to(self.device, non_blocking=True)
             cnt_d = counts.to(self.device, non_blocking=True)
-            pos_d = pos.to(self.device, non_blocking=True)
+            if compact is not None:
+                pos_d = compact[0].to(self.device, non_blocking=True).to(torch.int64)
+            else:
+                pos_d = pos.to(self.device, non_blocking=True)
             start = indptr[seeds_d]
             ids = indices[torch.repeat_interleave(start, cnt_d, output_size=int(pos.numel())) + pos_d]
             done = torch.cuda.Event()
             done.record(self.load_stream)
-        if self._ring is not None:
+        if compact is not None:
+            self._pos_ring.release(compact[1], done)
+            sg.positions_compact = None
+        elif self._ring is not None:
             self._ring.release(getattr(sg, "buffer_token", None), done)
         # the pinned buffer goes back to the ring: from here on the subgraph holds its source ids ON THE DEVICE (src_nodes()) and no
         # per-edge destination list (the structure is in sg.indptr)
@@ -397,6 +424,7 @@ class MiniBatchPipeline:
                 ids.append(self._translate_on_device(last, device_inputs=(ids[L - 1], ptrs[L - 1][1:] - ptrs[L - 1][:-1])))
             else:
                 ids.append(last.src_nodes())
+                self._drop_compact(last)
                 self._late_release = getattr(last, "buffer_token", None)
             b.input_nodes = ids[-1]
             self._staging.release(staged.token, uploaded)      # (after the host-side translation above, which reads the hop's seeds)
@@ -453,11 +481,17 @@ class MiniBatchPipeline:
     def __iter__(self):
         self._error = None
         if self.sampler_threads > 0 and self.device_graph is not None and self.load_stream is not None and self._ring is None \
+                and self._pos_ring is None \
                 and getattr(self.dataloader.sampler, "defer_last_hop", False):
             cap = self.dataloader.batch_size
             for f in self.dataloader.sampler.fanouts:
                 cap *= int(f)
-            self._ring = PinnedRing(3 * self.sampler_threads + 4, cap)       # more buffers than batches can be in flight before the upload
+            n_buf = 3 * self.sampler_threads + 4                              # more buffers than batches can be in flight before the upload
+            max_deg = int((self.device_graph[0][1:] - self.device_graph[0][:-1]).max())
+            if max_deg < (1 << 31):
+                self._pos_ring = PinnedRing(n_buf, cap, dtype=torch.int16 if max_deg < (1 << 15) else torch.int32)
+            else:
+                self._ring = PinnedRing(n_buf, cap)
             if self.hops == "sampled" and self.cache is not None and self.build_blocks and hasattr(self.dataloader.sampler, "staging_entries"):
                 self._staging = PinnedRing(3 * self.sampler_threads + 4,
                                            self.dataloader.sampler.staging_entries(self.dataloader.batch_size, self.dataloader.sampler.fanouts))
