@@ -537,12 +537,35 @@ def timed_steps(args, c, step):
                 print("warm-up loss %.6f" % float(g), file=sys.stderr)
     barrier(c)
     loss = None
-    with ops.LaunchTimer() as timer:
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            loss = step()
-        barrier(c)
-        elapsed = time.perf_counter() - t0
+    marks = []                                      # one event per step boundary: the timed steps' own GPU durations (diagnostics)
+
+    def mark():
+        if c.dev.type == "cuda":
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            marks.append(e)
+
+    # The interpreter's cyclic garbage collector is switched off for the timed steps (as timeit does): right after the barrier the host
+    # is not yet ahead of the GPU, and a full collection that falls into the first steps -- 8 ... 76 ms, measured as one 97 ms step among
+    # 21 ms ones -- is idle GPU time in the measurement of a loop that is otherwise GPU-bound.
+    import gc
+
+    gc.collect()
+    gc_was_on = gc.isenabled()
+    gc.disable()
+    try:
+        with ops.LaunchTimer() as timer:
+            t0 = time.perf_counter()
+            mark()
+            for _ in range(args.steps):
+                loss = step()
+                mark()
+            barrier(c)
+            elapsed = time.perf_counter() - t0
+    finally:
+        if gc_was_on:
+            gc.enable()
+    timer.per_step_gpu_ms = [round(a.elapsed_time(b), 3) for a, b in zip(marks[:-1], marks[1:])]
     if c.world > 1:
         t = torch.tensor([elapsed], device=c.dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -753,6 +776,9 @@ def run_sage(args, c):
     result.update({"loss": float(global_loss), "roofline": roofline, "spmm_launch_table": table,
                    # bytes = 2 (K1 + K2 + N) per row (+ 2 N for a gate / addend operand); the 5.5 TB/s "streaming ceiling" is what
                    "dense_launch_table": dense_table})      # a trivial 2R:1W kernel reaches (tools/probes/rw_mix.hip)
+    # this rank's GPU time of every timed step (events at the step boundaries): the first step after the barrier runs ~1.5 ms longer
+    # (the GPU idled through it), the rest sit at the steady state -- what a longer K converges to
+    result["per_step_gpu_ms"] = getattr(timer, "per_step_gpu_ms", None)
     if trace:
         result["warmup_loss_trace"] = trace
     if per_rank is not None:
@@ -888,7 +914,8 @@ def run_gat(args, c):
         {"nodes": n, "nnz": nnz, "hidden": args.hidden, "heads": heads, "locality": args.locality, "permuted_ids": not args.no_permute,
          "reorder": args.reorder, "reorder_seconds_one_off": reorder_s, "parallelism": "1-D row partition x%d" % c.world,
          "gather_passes_per_step": passes})
-    result.update({"loss": float(global_loss), "roofline": roofline, "spmm_launch_table": table, "dense_launch_table": dense_table})
+    result.update({"loss": float(global_loss), "roofline": roofline, "spmm_launch_table": table, "dense_launch_table": dense_table,
+                   "per_step_gpu_ms": getattr(timer, "per_step_gpu_ms", None)})
     if trace:
         result["warmup_loss_trace"] = trace
     if c.world == 1 and not args.no_extra:
