@@ -1030,6 +1030,7 @@ def run_minibatch(args, c):
       GPU : one-launch hit/miss gather from the HBM hot-node cache + pinned host memory (storage.py:151-198), CSR blocks,
             hop-pyramid forward / backward / Adam.
     A step = one batch; W warm-up batches, K timed batches."""
+    import gc
     import random
 
     import numpy as np
@@ -1156,12 +1157,15 @@ def run_minibatch(args, c):
             if want_graph:
                 graphed = capture()
             torch.cuda.synchronize()
+            gc.collect()
+            gc.disable()                       # as in timed_steps: no full collection inside the timed window
             t0 = time.perf_counter()
             s0 = TimedSampler.seconds
             l0, cpu_busy = pipe.load_seconds, 0.0
         if done == args.warmup + args.steps:                  # the timed window ends here; the tail runs with per-launch events
             torch.cuda.synchronize()
             elapsed = time.perf_counter() - t0
+            gc.enable()
             sampler_s = TimedSampler.seconds - s0
             loader_s, busy_s = pipe.load_seconds - l0, cpu_busy
             if prof is not None:
