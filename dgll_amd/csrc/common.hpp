@@ -1,12 +1,8 @@
 // common.hpp -- shared device/host helpers of libdgll_hip.so (gfx950 only, wave64).
 #pragma once
 #include <hip/hip_runtime.h>
-#include <stdint.h>
-#include <string>
 
-#include "../../include/dgll_hip.h"
-
-#define DGLL_API extern "C" __attribute__((visibility("default")))
+#include "host_common.hpp"
 
 // Load-balancing schedule of one CSR structure (opaque to callers; include/dgll_hip.h).  Rows longer than `threshold`
 // nonzeros are cut into chunks that run as independent work items and are reduced in a fixed order afterwards.
@@ -33,19 +29,13 @@ typedef uint16_t bf16_t;            // raw bfloat16 bits
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 
-// ---- error plumbing (thread-local text, negative return codes; never exit()) -----------------------
-void set_error(const std::string& msg);
+// ---- error plumbing (set_error / DGLL_REQUIRE: host_common.hpp) ---------------------------------------
 int hip_fail(hipError_t e, const char* what);
 
 #define DGLL_HIP_TRY(expr)                                          \
     do {                                                            \
         hipError_t _e = (expr);                                     \
         if (_e != hipSuccess) return ::dgll::hip_fail(_e, #expr);   \
-    } while (0)
-
-#define DGLL_REQUIRE(cond, msg)                                     \
-    do {                                                            \
-        if (!(cond)) { ::dgll::set_error(std::string(msg) + " [" #cond "]"); return DGLL_ERR_INVALID; } \
     } while (0)
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

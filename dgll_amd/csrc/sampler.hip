@@ -21,7 +21,7 @@
 #include <thread>
 #include <vector>
 
-#include "common.hpp"
+#include "host_common.hpp"   // host code only: this file also builds with g++ -fsanitize=thread (tests/c_abi/Makefile)
 
 namespace {
 

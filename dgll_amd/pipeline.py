@@ -105,11 +105,19 @@ class OrderedHandoff:
         self._cv = threading.Condition()
 
     def put(self, index, item):
+        """False once the hand-over was closed (the consumer is gone or another producer failed): the caller stops producing."""
         with self._cv:
             while index >= self._next + self.capacity and self._total is None:
                 self._cv.wait()
+            if self._total is not None and index >= self._total:
+                return False
             self._slots[index] = item
             self._cv.notify_all()
+            return True
+
+    @property
+    def closed(self):
+        return self._total is not None
 
     def close(self, total):
         with self._cv:
@@ -128,14 +136,22 @@ class OrderedHandoff:
             return item
 
 
+class PipelineStopped(Exception):
+    """Raised inside a producer thread that waited for a buffer while the pipeline was being stopped (never reaches the user)."""
+
+
 class PinnedRing:
     """A few page-locked int64 host buffers handed round: the outermost hop's positions / ids are written into one by the native
     sampler and uploaded from it by an asynchronous DMA (a pageable source is staged by the runtime: the loading thread sat in that
-    copy for 2-3 ms per batch).  A buffer returns with the event that marks its upload complete and is reused after it."""
+    copy for 2-3 ms per batch).  A buffer returns with the event that marks its upload complete and is reused after it.
+    `stop` (threading.Event, set by the pipeline when a stage failed or the consumer left): a thread waiting for a free buffer
+    gives up with PipelineStopped instead of waiting for a release that will never come."""
 
-    def __init__(self, n_buffers, capacity, dtype=torch.int64):
+    def __init__(self, n_buffers, capacity, dtype=torch.int64, stop=None):
         import queue
 
+        self._empty = queue.Empty
+        self.stop = stop
         self._free = queue.Queue()
         self.buffers = [torch.empty(int(capacity), dtype=dtype, pin_memory=True) for _ in range(int(n_buffers))]
         for i in range(len(self.buffers)):
@@ -145,7 +161,13 @@ class PinnedRing:
     def acquire(self, n):
         if n > self.capacity:
             return None
-        i, event = self._free.get()
+        while True:
+            try:
+                i, event = self._free.get(timeout=0.05)
+                break
+            except self._empty:
+                if self.stop is not None and self.stop.is_set():
+                    raise PipelineStopped() from None
         if event is not None:
             event.synchronize()
         return self.buffers[i].numpy()[:n], i
@@ -202,25 +224,39 @@ class MiniBatchPipeline:
         self.load_stream = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None   # d_stream
         self._thread = None
         self._error = None
+        self._stop = threading.Event()          # set when a stage failed or the consumer left: every producer winds down
         self.load_seconds, self.load_batches = 0.0, 0
 
     # ---- producer stage 1: sampling (buffer_queues.py:22-46) ---------------------------------------------------
     def _sample(self):
         try:
             for step, (inp, outp, subgs) in enumerate(self.dataloader):
+                if self._stop.is_set():
+                    break
                 self.sampled.put((step, inp, outp, subgs))            # blocks while the queue is full
         except BaseException as exc:  # noqa: BLE001  (surface producer failures in the consumer)
-            self._error = exc
+            self._fail(exc)
         finally:
             self.sampled.put(_DONE)
 
+    def _fail(self, exc):
+        """First failure wins; every stage sees the stop flag at its next step."""
+        if not isinstance(exc, PipelineStopped) and self._error is None:
+            self._error = exc
+        self._stop.set()
+
     def _sample_seeded_worker(self, t, handoff, n_batches):
-        """Thread t of K draws batches t, t + K, ... whole, each under its own seed; nothing is shared between the threads."""
+        """Thread t of K draws batches t, t + K, ... whole, each under its own seed.  Shared between the threads: the sampler's CSR
+        copy of the adjacency (read-only; built before the threads start, FastNeighborSampler.prepare), the pinned rings (queues)
+        and the stop flag -- a worker that fails sets it, the others leave at their next batch or buffer wait."""
         from .sampling.fast_sampler import batch_seed
 
         dl = self.dataloader
         try:
             for i in range(t, n_batches, self.sampler_threads):
+                if self._stop.is_set() or handoff.closed:
+                    handoff.close(0)             # the thread waiting in get() for this worker's next batch must not wait for ever
+                    break
                 seeds = dl.train_nodes[i * dl.batch_size:(i + 1) * dl.batch_size]
                 buf = self._ring.acquire if (self._ring is not None and self._pos_ring is None) else None
                 stg = self._staging.acquire if self._staging is not None else None
@@ -237,14 +273,17 @@ class MiniBatchPipeline:
                         small, tok = got
                         np.copyto(small, last._src.numpy(), casting="unsafe")
                         last.positions_compact = (torch.from_numpy(small), tok)
-                handoff.put(i, (i, inp, outp, subgs))
+                if not handoff.put(i, (i, inp, outp, subgs)):
+                    break
         except BaseException as exc:  # noqa: BLE001
-            self._error = exc
+            self._fail(exc)
             handoff.close(0)
 
     def _sample_threaded(self):
         """Producer stage 1 in the per-batch-seeded mode: K workers -> OrderedHandoff -> the hand-over queue of the loader."""
         n_batches = len(self.dataloader)
+        if hasattr(self.dataloader.sampler, "prepare"):            # the CSR copy of a list-of-lists DGraph: once, before any worker
+            self.dataloader.sampler.prepare(self.dataloader.Dgraph)
         handoff = OrderedHandoff(capacity=2 * self.sampler_threads)
         workers = [threading.Thread(target=self._sample_seeded_worker, args=(t, handoff, n_batches), name="dgll-sampler-%d" % t,
                                     daemon=True) for t in range(self.sampler_threads)]
@@ -252,19 +291,21 @@ class MiniBatchPipeline:
             w.start()
         try:
             taken = 0
-            while taken < n_batches:
+            while taken < n_batches and not self._stop.is_set():
                 item = handoff.get()
                 if item is None:
                     break
                 self.sampled.put(item)
                 taken += 1
         except BaseException as exc:  # noqa: BLE001
-            self._error = exc
+            self._fail(exc)
         finally:
-            handoff.close(0)
+            handoff.close(0)                 # put() stops blocking and reports the closure; buffer waits end on the stop flag
+            if taken < n_batches:
+                self._stop.set()
+            self.sampled.put(_DONE)          # before the joins: the loader must not wait for workers that are winding down
             for w in workers:
                 w.join()
-            self.sampled.put(_DONE)
 
     def _hop_ids(self, b):
         """hops = "sampled": [seeds, sources around hop 0, ..., outermost sources]; the outermost list comes from the device-side
@@ -338,6 +379,9 @@ class MiniBatchPipeline:
                 item = self.sampled.get()
                 if item is _DONE:
                     break
+                if self._stop.is_set():          # a stage failed or the consumer left: drain without loading
+                    self._release_unloaded(item)
+                    continue
                 t_load = time.perf_counter()
                 b = Batch()
                 b.step, b.input_nodes, b.output_nodes, b.subgraphs = item
@@ -391,11 +435,27 @@ class MiniBatchPipeline:
                 self.load_batches += 1
                 self.queue.put(b)                                   # blocks while the queue is full
         except BaseException as exc:  # noqa: BLE001
-            self._error = exc
-            while self.sampled.get() is not _DONE:                  # let the sampling thread run to its end
+            self._fail(exc)
+            while self.sampled.get() is not _DONE:                  # let the sampling thread run to its end (it stops at the flag)
                 pass
         finally:
             self.queue.put(_DONE)
+
+    def _release_unloaded(self, item):
+        """Pinned buffers of a sampled batch that will not be loaded go back to their rings."""
+        try:
+            subgs = item[3]
+            last = subgs[0]
+            staged = getattr(last, "staged", None)
+            if staged is not None and self._staging is not None:
+                self._staging.release(staged.token, None)
+            c = getattr(last, "positions_compact", None)
+            if c is not None and self._pos_ring is not None:
+                self._pos_ring.release(c[1], None)
+            if self._ring is not None:
+                self._ring.release(getattr(last, "buffer_token", None), None)
+        except Exception:  # noqa: BLE001  (best effort while shutting down)
+            pass
 
     def _load_staged(self, b, staged):
         """The loading stage for a batch whose small arrays arrive packed in one pinned buffer (FastNeighborSampler.sample_seeded(
@@ -480,6 +540,7 @@ class MiniBatchPipeline:
     # ---- consumer side -----------------------------------------------------------------------------------------
     def __iter__(self):
         self._error = None
+        self._stop.clear()
         if self.sampler_threads > 0 and self.device_graph is not None and self.load_stream is not None and self._ring is None \
                 and self._pos_ring is None \
                 and getattr(self.dataloader.sampler, "defer_last_hop", False):
@@ -489,12 +550,13 @@ class MiniBatchPipeline:
             n_buf = 3 * self.sampler_threads + 4                              # more buffers than batches can be in flight before the upload
             max_deg = int((self.device_graph[0][1:] - self.device_graph[0][:-1]).max())
             if max_deg < (1 << 31):
-                self._pos_ring = PinnedRing(n_buf, cap, dtype=torch.int16 if max_deg < (1 << 15) else torch.int32)
+                self._pos_ring = PinnedRing(n_buf, cap, dtype=torch.int16 if max_deg < (1 << 15) else torch.int32, stop=self._stop)
             else:
-                self._ring = PinnedRing(n_buf, cap)
+                self._ring = PinnedRing(n_buf, cap, stop=self._stop)
             if self.hops == "sampled" and self.cache is not None and self.build_blocks and hasattr(self.dataloader.sampler, "staging_entries"):
                 self._staging = PinnedRing(3 * self.sampler_threads + 4,
-                                           self.dataloader.sampler.staging_entries(self.dataloader.batch_size, self.dataloader.sampler.fanouts))
+                                           self.dataloader.sampler.staging_entries(self.dataloader.batch_size, self.dataloader.sampler.fanouts),
+                                           stop=self._stop)
                 if self.labels is not None and self._labels_dev is None:
                     self._labels_dev = self.labels.to(self.device)
         self._thread = threading.Thread(target=self._sample_threaded if self.sampler_threads > 0 else self._sample,
@@ -502,6 +564,21 @@ class MiniBatchPipeline:
         self._loader = threading.Thread(target=self._load, name="dgll-feature-loader", daemon=True)
         self._thread.start()
         self._loader.start()
+        finished = False
+        try:
+            yield from self._consume()
+            finished = True
+        finally:
+            if not finished:                 # the consumer left early (break / exception in its loop): wind the producers down
+                self._stop.set()
+                while self.queue.get() is not _DONE:
+                    pass
+            self._thread.join()
+            self._loader.join()
+        if self._error is not None:
+            raise self._error
+
+    def _consume(self):
         while True:
             b = self.queue.get()
             if b is _DONE:
@@ -522,7 +599,3 @@ class MiniBatchPipeline:
                 if b.labels is not None and b.labels.is_cuda:
                     b.labels.record_stream(cur)
             yield b
-        self._thread.join()
-        self._loader.join()
-        if self._error is not None:
-            raise self._error

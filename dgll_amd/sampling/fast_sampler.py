@@ -7,6 +7,7 @@ stores the advanced state back, so it can be freely interleaved with other users
 import ctypes as C
 import math
 import random
+import threading
 
 import numpy as np
 import torch
@@ -69,19 +70,35 @@ class FastNeighborSampler(Base_sampler):
         super().__init__()
         self.fanouts = fanouts
         self.defer_last_hop = defer_last_hop
-        self._csr_of = None
-        self._indptr = self._indices = None
+        self._csr_lock = threading.Lock()
+        self._csr_cache = None          # (edges object, indptr, indices): published as ONE reference, never filled in place
 
     def _csr(self, g):
+        """The CSR arrays of g.edges.  Safe to call from several threads at once (MiniBatchPipeline(sampler_threads=K) does): the
+        copy of a list-of-lists adjacency (dgraph.py:18-47) is built into locals under a lock and becomes visible only as a whole
+        -- a reader either finds the finished tuple for this adjacency or builds it itself; it never sees arrays that are still
+        being filled (round 4 published a zero-filled indptr first: a thread reading it then sampled a graph without edges)."""
         if hasattr(g.edges, "indptr"):           # CSRAdjacency: use the arrays directly
             return (np.ascontiguousarray(g.edges.indptr, dtype=np.int64), np.ascontiguousarray(g.edges.indices, dtype=np.int64))
-        if self._csr_of is not g.edges:
-            deg = np.fromiter((len(e) for e in g.edges), dtype=np.int64, count=len(g.edges))
-            self._indptr = np.zeros(len(g.edges) + 1, dtype=np.int64)
-            np.cumsum(deg, out=self._indptr[1:])
-            self._indices = np.fromiter((u for e in g.edges for u in e), dtype=np.int64, count=int(self._indptr[-1]))
-            self._csr_of = g.edges
-        return self._indptr, self._indices
+        cached = self._csr_cache
+        if cached is not None and cached[0] is g.edges:
+            return cached[1], cached[2]
+        with self._csr_lock:
+            cached = self._csr_cache
+            if cached is not None and cached[0] is g.edges:
+                return cached[1], cached[2]
+            edges = g.edges
+            deg = np.fromiter((len(e) for e in edges), dtype=np.int64, count=len(edges))
+            indptr = np.zeros(len(edges) + 1, dtype=np.int64)
+            np.cumsum(deg, out=indptr[1:])
+            indices = np.fromiter((u for e in edges for u in e), dtype=np.int64, count=int(indptr[-1]))
+            self._csr_cache = (edges, indptr, indices)
+            return indptr, indices
+
+    def prepare(self, g):
+        """Build the CSR copy of g.edges now (the pipeline calls this before it starts its sampler threads)."""
+        self._csr(g)
+        return self
 
     def sample_neighbours(self, g, nodes, fanout=None, defer_translation=False):
         indptr, indices = self._csr(g)

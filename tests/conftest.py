@@ -16,8 +16,27 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def _gpu_present():
+    try:
+        import torch
+
+        return torch.cuda.device_count() > 0          # counting devices does not initialise the GPU
+    except Exception:  # noqa: BLE001
+        return False
+
+
+@pytest.hookimpl(tryfirst=True)
 def pytest_collection_modifyitems(config, items):
-    """GPU tests are selected with -m gpu; when selected on a box without a GPU they fail loudly rather than skip."""
+    """GPU tests are selected with -m gpu; when selected on a box without a GPU they fail loudly rather than skip.
+
+    On a box WITH a GPU every host test (sampler threads, queues, partitioner, gloo world-size 2-8 runs, RaCoM, ABI, oracle vs
+    goldens: none of them reads /root/reference) also carries the gpu marker, so the round-end `pytest -m gpu` run covers the
+    threaded host code as well (round 4: a 12-35 % flaky sampler race sat in the 134 tests that run never saw a second machine).
+    DGLL_TEST_HOST_ON_GPU_BOX=0 restores the split."""
+    if os.environ.get("DGLL_TEST_HOST_ON_GPU_BOX", "1") != "0" and _gpu_present():
+        for item in items:
+            if item.get_closest_marker("gpu") is None:
+                item.add_marker(pytest.mark.gpu)
 
 
 class Golden:

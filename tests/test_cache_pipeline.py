@@ -1,5 +1,6 @@
 """f2: hot-node feature cache (one-launch hit/miss gather) and the bounded mini-batch queues."""
 import random
+import sys
 import threading
 import time
 
@@ -343,6 +344,227 @@ def test_per_batch_seeded_pipeline_with_sampler_threads_matches_the_reference_lo
             random.seed(1234)          # whatever the consumer does with the global generator, the batches do not depend on it
         assert steps == list(range(len(loader)))
     random.setstate(before)
+
+
+def test_200_fresh_threaded_pipelines_on_a_list_of_lists_dgraph_are_bit_equal_to_the_reference_loop():
+    """Regression for the round-4 race: FastNeighborSampler._csr used to publish a zero-filled indptr before filling it, and K
+    sampler threads calling it at once on the reference's own DGraph format (list-of-lists, dgraph.py:18-47) could sample a graph
+    without edges (input_nodes == []).  200 FRESH samplers (each one builds its CSR copy under contention) x 4 threads; every
+    batch equals oracle/sampler.py (base_sampler.py:45-58, dgllsampler.py:10-21) under that batch's seed."""
+    from dgll_amd.data import DGraph
+    from dgll_amd.dataloader import DataLoader
+    from dgll_amd.pipeline import MiniBatchPipeline
+    from dgll_amd.sampling import FastNeighborSampler
+    from dgll_amd.sampling.fast_sampler import batch_seed
+    from oracle import sampler as osampler
+
+    n = 1500
+    edges = _zipf_graph(n, 3)
+    feats = torch.arange(n * 2, dtype=torch.float32).view(n, 2)
+    dg = DGraph(nodes=torch.arange(n), edges=edges, labels=torch.arange(n) % 5, features=feats)
+    fanouts = [5, 3]
+    train = torch.randperm(n, generator=torch.Generator().manual_seed(0))[:512]
+    before = random.getstate()
+    expected = []
+    for i in range(8):
+        random.seed(batch_seed(11, 2, i))
+        expected.append(osampler.sample(edges, train[i * 64:(i + 1) * 64].tolist(), fanouts))
+    random.setstate(before)
+    wrong = 0
+    interval = sys.getswitchinterval()
+    sys.setswitchinterval(1e-5)             # interpreter threads change hands every few bytecodes: the old race showed in most runs
+    try:
+        wrong = _run_fresh_pipelines(200, dg, train, fanouts, expected)
+    finally:
+        sys.setswitchinterval(interval)
+    assert wrong == 0
+
+
+def _run_fresh_pipelines(runs, dg, train, fanouts, expected):
+    from dgll_amd.dataloader import DataLoader
+    from dgll_amd.pipeline import MiniBatchPipeline
+    from dgll_amd.sampling import FastNeighborSampler
+
+    wrong = 0
+    for run in range(runs):
+        loader = DataLoader(dg, train, FastNeighborSampler(fanouts, defer_last_hop=bool(run & 1)), batch_size=64)
+        pipe = MiniBatchPipeline(loader, labels=dg.labels, queue_size=3, device="cpu", hops="sampled", sampler_threads=4,
+                                 base_seed=11, epoch=2)
+        for b in pipe:
+            inp, outp, layers = expected[b.step]
+            ok = b.output_nodes.tolist() == outp and torch.as_tensor(b.input_nodes).tolist() == inp
+            for sg, (src, dst) in zip(b.subgraphs, layers):
+                ok = ok and sg.src_nodes().tolist() == src and sg.dst_nodes().tolist() == dst
+            wrong += not ok
+    return wrong
+
+
+def test_sampler_csr_copy_is_safe_for_direct_callers_from_many_threads():
+    """_csr without the pipeline's prepare(): 8 threads call sample_seeded on one fresh sampler at the same moment."""
+    from dgll_amd.data import DGraph
+    from dgll_amd.sampling import FastNeighborSampler
+    from oracle import sampler as osampler
+
+    n = 4000
+    edges = _zipf_graph(n, 5)
+    dg = DGraph(nodes=torch.arange(n), edges=edges, labels=torch.zeros(n, dtype=torch.long), features=torch.zeros(n, 1))
+    seeds = torch.arange(0, 256)
+    before = random.getstate()
+    random.seed(99)
+    want = osampler.sample(edges, seeds.tolist(), [4, 4])
+    random.setstate(before)
+    interval = sys.getswitchinterval()
+    sys.setswitchinterval(1e-5)
+    try:
+        _hammer_one_sampler(dg, seeds, want)
+    finally:
+        sys.setswitchinterval(interval)
+
+
+def _hammer_one_sampler(dg, seeds, want):
+    from dgll_amd.sampling import FastNeighborSampler
+
+    for _ in range(25):
+        smp = FastNeighborSampler([4, 4])
+        start = threading.Barrier(8)
+        out = [None] * 8
+
+        def work(t):
+            start.wait()
+            inp, outp, subgs = smp.sample_seeded(dg, seeds, 99)
+            out[t] = (torch.as_tensor(inp).tolist(), [(sg.src_nodes().tolist(), sg.dst_nodes().tolist()) for sg in subgs])
+
+        ts = [threading.Thread(target=work, args=(t,)) for t in range(8)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        for got in out:
+            assert got[0] == want[0] and got[1] == [(list(s), list(d)) for s, d in want[2]]
+
+
+@pytest.mark.gpu
+def test_threaded_pipeline_on_a_list_of_lists_dgraph_with_device_translation_is_bit_equal_per_batch(cuda_device):
+    """The GPU twin of the regression above: the reference's own DGraph format (python list of lists), sampler_threads=4,
+    device_graph= built from the SAME lists, cache + pinned rings + device-side translation of the outermost hop; 40 fresh
+    samplers/pipelines; every batch: ids bit-equal to oracle/sampler.py, fetched rows == features[ids]."""
+    from dgll_amd.cache import GraphCacheServer
+    from dgll_amd.data import DGraph
+    from dgll_amd.dataloader import DataLoader
+    from dgll_amd.pipeline import MiniBatchPipeline
+    from dgll_amd.sampling import FastNeighborSampler
+    from dgll_amd.sampling.fast_sampler import batch_seed
+    from oracle import sampler as osampler
+
+    n = 1500
+    edges = _zipf_graph(n, 3)
+    feats = torch.randn(n, 8, generator=torch.Generator().manual_seed(1))
+    dg = DGraph(nodes=torch.arange(n), edges=edges, labels=torch.arange(n) % 5, features=feats)
+    deg = np.array([len(e) for e in edges], dtype=np.int64)
+    indptr = torch.from_numpy(np.concatenate([[0], np.cumsum(deg)])).to(cuda_device)
+    indices = torch.tensor([u for e in edges for u in e], dtype=torch.int64, device=cuda_device)
+    fanouts = [5, 3]
+    train = torch.randperm(n, generator=torch.Generator().manual_seed(0))[:512]
+    before = random.getstate()
+    expected = []
+    for i in range(8):
+        random.seed(batch_seed(11, 2, i))
+        expected.append(osampler.sample(edges, train[i * 64:(i + 1) * 64].tolist(), fanouts))
+    random.setstate(before)
+    srv = GraphCacheServer(feats, n)
+    srv.auto_cache(torch.from_numpy(deg), capacity=n // 2)
+    interval = sys.getswitchinterval()
+    sys.setswitchinterval(1e-5)
+    try:
+        for run in range(40):
+            loader = DataLoader(dg, train, FastNeighborSampler(fanouts, defer_last_hop=True), batch_size=64)
+            pipe = MiniBatchPipeline(loader, cache=srv, labels=dg.labels, queue_size=3, device=cuda_device, hops="sampled",
+                                     sampler_threads=4, base_seed=11, epoch=2, device_graph=(indptr, indices), build_blocks=bool(run & 1))
+            steps = []
+            for b in pipe:
+                inp, outp, layers = expected[b.step]
+                torch.cuda.current_stream().synchronize()
+                assert torch.as_tensor(b.output_nodes).cpu().tolist() == outp
+                assert b.input_nodes.is_cuda and b.input_nodes.cpu().tolist() == inp
+                assert torch.equal(b.features[-1].cpu().float(), feats[torch.tensor(inp, dtype=torch.int64)].reshape(len(inp), -1))
+                assert torch.as_tensor(b.subgraphs[1].src_nodes()).cpu().tolist() == layers[1][0]
+                steps.append(b.step)
+            assert steps == list(range(8))
+    finally:
+        sys.setswitchinterval(interval)
+
+
+class _FailingSampler:
+    """FastNeighborSampler whose sample_seeded raises on one batch (by seed)."""
+
+    def __init__(self, inner, bad_seed):
+        self._inner, self._bad = inner, bad_seed
+        self.fanouts = inner.fanouts
+        self.defer_last_hop = inner.defer_last_hop
+
+    def prepare(self, g):
+        self._inner.prepare(g)
+
+    def sample_seeded(self, g, seeds, seed, **kw):
+        if seed == self._bad:
+            raise RuntimeError("sampler failed on purpose")
+        return self._inner.sample_seeded(g, seeds, seed, **kw)
+
+
+@pytest.mark.parametrize("threads", [1, 4])
+def test_a_failing_sampler_worker_surfaces_its_exception_instead_of_hanging_the_epoch(threads):
+    """after a worker failed, the surviving workers kept sampling batches nobody consumed and the joins never
+    returned.  A long epoch (200 batches >> queue + hand-over capacity), batch 7 raises: the consumer gets the batches before it,
+    then the exception, within seconds; no pipeline thread stays behind."""
+    from dgll_amd.data import DGraph
+    from dgll_amd.dataloader import DataLoader
+    from dgll_amd.pipeline import MiniBatchPipeline
+    from dgll_amd.sampling import FastNeighborSampler
+    from dgll_amd.sampling.fast_sampler import batch_seed
+
+    n = 1500
+    dg = DGraph(nodes=torch.arange(n), edges=_zipf_graph(n, 3), labels=torch.arange(n) % 5, features=torch.zeros(n, 2))
+    train = torch.arange(n).repeat(3)[:200 * 16]
+    loader = DataLoader(dg, train, _FailingSampler(FastNeighborSampler([3, 2]), batch_seed(0, 0, 7)), batch_size=16)
+    pipe = MiniBatchPipeline(loader, labels=dg.labels, queue_size=2, device="cpu", hops="sampled", sampler_threads=threads)
+    seen, result = [], {}
+
+    def consume():
+        try:
+            for b in pipe:
+                seen.append(b.step)
+            result["error"] = None
+        except RuntimeError as exc:
+            result["error"] = str(exc)
+
+    t = threading.Thread(target=consume, daemon=True)
+    t.start()
+    t.join(30)
+    assert not t.is_alive(), "the pipeline hung after a sampler worker failed"
+    assert result["error"] == "sampler failed on purpose"
+    assert seen == list(range(len(seen))) and len(seen) <= 7
+    time.sleep(0.2)
+    assert not [th.name for th in threading.enumerate() if th.name.startswith("dgll-")]
+
+
+def test_a_consumer_that_leaves_early_winds_the_producers_down():
+    from dgll_amd.data import DGraph
+    from dgll_amd.dataloader import DataLoader
+    from dgll_amd.pipeline import MiniBatchPipeline
+    from dgll_amd.sampling import FastNeighborSampler
+
+    n = 1500
+    dg = DGraph(nodes=torch.arange(n), edges=_zipf_graph(n, 3), labels=torch.arange(n) % 5, features=torch.zeros(n, 2))
+    train = torch.arange(n).repeat(3)[:200 * 16]
+    for threads in (0, 4):
+        loader = DataLoader(dg, train, FastNeighborSampler([3, 2]), batch_size=16)
+        pipe = MiniBatchPipeline(loader, labels=dg.labels, queue_size=2, device="cpu", hops="sampled", sampler_threads=threads)
+        it = iter(pipe)
+        assert next(it).step == 0 and next(it).step == 1
+        it.close()
+        time.sleep(0.2)
+        assert not [th.name for th in threading.enumerate() if th.name.startswith("dgll-")]
+        assert [b.step for b in pipe][:3] == [0, 1, 2]          # and the pipeline can be iterated again
 
 
 def test_ordered_handoff_returns_batches_in_order_and_bounds_the_run_ahead():
