@@ -17,6 +17,8 @@ def test_threaded_host_sampler_is_clean_under_the_sanitizer(target, tmp_path):
     proc = subprocess.run(["make", "-C", os.path.join(HERE, "c_abi"), target, "OUT=" + str(tmp_path)], capture_output=True, text=True,
                           timeout=600)
     out = proc.stdout + proc.stderr
+    if "unexpected memory mapping" in out:      # the TSAN runtime could not lay out its shadow even with randomisation off
+        pytest.skip("ThreadSanitizer's runtime refuses this host's address-space layout (not a finding about the code)")
     assert proc.returncode == 0, out[-4000:]
     assert "ThreadSanitizer" not in out and "AddressSanitizer" not in out and "runtime error" not in out, out[-4000:]
     assert "equal the sequential draw" in out
