@@ -20,8 +20,9 @@ accumulation.
     minibatch  config 2: Reddit-shaped graph, sampled 3-layer GraphSAGE (fan-out 25-10-10, batch 1024, hidden 256 bf16)
                through the bit-exact host sampler, the hot-node feature cache (PARTIAL: pinned-host leg carries traffic) and
                the mini-batch queue.  A step = one batch.
-    rmat27     config 5 on ONE GPU: RMAT-27 (134 M nodes, > 2^31 nonzeros), F = 128 bf16: a step = one mean-SpMM pass + the
-               dense X.W of the same layer (gcnconv.py:30-31).  --scale N for a smaller RMAT.
+    rmat27     config 5: RMAT-27 (134 M nodes, > 2^31 nonzeros), F = 128 bf16: a step = one mean-SpMM pass + the dense X.W of
+               the same layer (gcnconv.py:30-31); --gpus N: cost-balanced contiguous row blocks, X replicated, no exchange in
+               the step (dgll_amd.dist.RowBlockShard).  --scale S for a smaller RMAT.
 
 Workload (sage / gat): exactly ogbn-products' size (2 449 029 nodes, 61 859 140 undirected = 123 718 280 directed edges), 64
 planted communities holding 90 % of the edges, node ids RANDOMLY PERMUTED (what a raw dataset looks like).  The engine's own
@@ -120,6 +121,9 @@ def parse_args(argv=None):
     ap.add_argument("--mb-host-translate", action="store_true",
                     help="minibatch: turn the outermost hop's positions into ids on the host (16 threads) instead of by a device gather")
     ap.add_argument("--scale", type=int, default=27, help="rmat27: RMAT scale (27 = config 5; smaller for a quick run)")
+    ap.add_argument("--rmat-order", choices=["auto", "transform-first", "aggregate-first"], default="auto",
+                    help="rmat27: the layer as A.(X.W) (the reference's order; N = 1 default) or as (A.X).W (N > 1: own rows only)")
+    ap.add_argument("--rmat-no-allgather", action="store_true", help="rmat27, N > 1: skip the separately timed all-gather of the outputs")
     return ap.parse_args(argv)
 
 
@@ -941,13 +945,19 @@ def run_gat(args, c):
 
 # ---------------------------------------------------------------------------------------------------- workload: rmat27
 def run_rmat27(args, c):
-    """BASELINE config 5 on one GPU: Y = A . (X . W) of a GCN layer (gcnconv.py:30-31) at RMAT-27 size, F = 128 bf16, mean
-    weights: a step = the MFMA transform X.W + the SpMM over > 2^31 nonzeros (int64 row pointers)."""
-    from dgll_amd import dense, ops, synth
+    """BASELINE config 5: one GCN layer Y = A . X . W (gcnconv.py:30-31) at RMAT-27 size, F = 128 bf16, mean weights, > 2^31
+    nonzeros (int64 row pointers).
 
-    if c.world > 1:
-        raise SystemExit("bench.py --workload rmat27 measures one GPU (replicas only: the SpMM of config 5 shards by row block, "
-                         "every rank would run this same pass on its block)")
+    N = 1: a step = the MFMA transform S = X.W, then the SpMM Y = A.S -- the reference's order.
+    N > 1 (process shape MQGCN.py:161-163): A is cut into N contiguous COST-balanced row blocks (cut
+    points on the prefix sum of bytes per row, dgll_amd.dist.cost_balanced_bounds: on the hubs-first order equal-row blocks are
+    not equal-nnz blocks), X is REPLICATED on every rank (34 GB of 288 at bf16), and every rank runs the same two kernels on its
+    block in the order (A.X).W: the SpMM over its rows against the full X, then the transform of its own rows -- 1/N of both, no
+    exchange inside the step (A.(X.W) would need S = X.W for ALL rows on every rank: N times the transform, or an all-gather of
+    34 GB per step).  value = sum of the ranks' nonzeros / the slowest rank's time; `per_rank` carries every rank's rows, nonzeros,
+    launch times and roofline; the all-gather of the outputs a FOLLOWING layer would need is timed separately (`output_allgather`)."""
+    from dgll_amd import dense, dist as ddist, ops, synth
+
     feat = 128
     t0 = time.time()
     g = synth.rmat_graph(args.scale, 16, seed=args.seed, device=c.dev, symmetric=False, weighted=False, self_loops=True)
@@ -960,42 +970,129 @@ def run_rmat27(args, c):
     torch.cuda.synchronize()
     reorder_s = time.time() - t0
     torch.cuda.empty_cache()
-    g.plan()
-    n, nnz = g.n_rows, g.nnz
-    x = torch.randn(n, feat, device=c.dev).to(c.dtype)
-    w = (torch.randn(feat, feat, device=c.dev) / feat ** 0.5).to(c.dtype)
-    y = ops.alloc_features(n, feat, c.dtype, c.dev)
+    n, nnz_total = g.n_rows, g.nnz
+    order = args.rmat_order
+    if order == "auto":
+        order = "transform-first" if c.world == 1 else "aggregate-first"
+    if c.world > 1 and order != "aggregate-first":
+        raise SystemExit("bench.py --workload rmat27 --gpus N > 1 runs the layer as (A.X).W on replicated X (--rmat-order aggregate-first)")
+    # bytes per edge / per row of one rank's step: the gathered row + its column id; the SpMM's output row + row pointer + the
+    # transform's read and write of that row
+    edge_cost, row_cost = feat * c.esz + 4, feat * c.esz + 8 + 2 * feat * c.esz
+    shard = ddist.RowBlockShard(g, c.world, c.rank, edge_cost, row_cost)
+    bounds, block_nnz = shard.bounds, shard.block_nnz
+    if c.world > 1:
+        shard.own_copy()
+        del g
+        torch.cuda.empty_cache()
+        blk = shard.block
+    else:
+        blk = g
+    blk.plan()
+    rows, nnz = blk.n_rows, blk.nnz
+    gen = torch.Generator(device=c.dev)
+    gen.manual_seed(args.seed + 1)                       # the same X and W on every rank: X is replicated, not exchanged
+    x = ops.alloc_features(n, feat, c.dtype, c.dev)
+    chunk = 1 << 24
+    for lo in range(0, n, chunk):                        # (a one-shot randn of [2^27, 128] fp32 is 69 GB of scratch)
+        hi = min(n, lo + chunk)
+        x[lo:hi] = torch.randn(hi - lo, feat, device=c.dev, generator=gen).to(c.dtype)
+    w = (torch.randn(feat, feat, device=c.dev, generator=gen) / feat ** 0.5).to(c.dtype)
+    y = ops.alloc_features(rows, feat, c.dtype, c.dev)
 
-    def step():
-        s = dense.transform_bf16(x, w.t()) if c.dtype == torch.bfloat16 else x @ w       # S = X.W      gcnconv.py:30
-        ops.spmm_raw(g, s, reduce="mean", out=y)                                           # Y = A.S      gcnconv.py:31
+    def transform(a):
+        return dense.transform_bf16(a, w.t()) if c.dtype == torch.bfloat16 else a @ w
+
+    def step_transform_first():
+        ops.spmm_raw(blk, transform(x), reduce="mean", out=y)                # S = X.W (gcnconv.py:30), Y = A.S (:31)
         return y
 
-    for _ in range(args.warmup):
-        step()
-    barrier(c)
-    with ops.LaunchTimer() as timer:
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
+    def step_aggregate_first():
+        return transform(ops.spmm_raw(blk, x, reduce="mean", out=y))         # the same layer as (A.X).W: own rows only
+
+    step = step_transform_first if order == "transform-first" else step_aggregate_first
+
+    def timed(fn, steps):
+        for _ in range(args.warmup):
+            fn()
         barrier(c)
-        elapsed = time.perf_counter() - t0
-    table, dense_table = launch_tables(timer.summary(), n)
+        with ops.LaunchTimer() as timer:
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                fn()
+            torch.cuda.synchronize()
+            own = time.perf_counter() - t0
+            barrier(c)
+            elapsed = time.perf_counter() - t0
+        return own, elapsed, timer
+
+    own_s, elapsed, timer = timed(step, args.steps)
+    if c.world > 1:
+        t = torch.tensor([elapsed], device=c.dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    table, dense_table = launch_tables(timer.summary(), rows)
     dom = table[max(table, key=lambda k: table[k]["avg_ms"])]
-    compulsory = nnz * 4 + n * feat * c.esz * 2 + n * 8
-    roofline = roofline_record(dom, workload_signature(args, nnz, nodes=n, hidden=feat, scale=args.scale),
-                               "spmm_csr_kernel %s unweighted mean, F=%d, int64 row pointers" % (args.dtype, feat), compulsory, 1)
+    n_src = n
+    compulsory = nnz * 4 + (n_src + rows) * feat * c.esz + rows * 8
+    mine = {"rank": c.rank, "rows": rows, "nnz": nnz, "row_range": [shard.own_begin, shard.own_end],
+            "own_ms_per_step": own_s / args.steps * 1e3, "spmm_avg_ms": dom["avg_ms"], "spmm_algorithmic_GBps": dom["algorithmic_GBps"],
+            "spmm_frac_algorithmic": dom["frac_algorithmic"], "spmm_G_edges_per_s": dom["G_edges_per_s"],
+            "dense_ms": {k: v["avg_ms"] for k, v in dense_table.items()}}
+    per_rank = [mine]
+    if c.world > 1:
+        per_rank = [None] * c.world
+        torch.distributed.all_gather_object(per_rank, mine)
+    allgather = None
+    if c.world > 1 and not args.rmat_no_allgather:
+        # what a FOLLOWING layer would need (its source rows = this layer's outputs of all ranks): N broadcasts into the slices of
+        # one [n, F] buffer (blocks differ in rows: no padding, no staging copy); NOT part of the timed step
+        try:
+            y_all = torch.empty(n, feat, dtype=c.dtype, device=c.dev)
+            out_rows = step()
+            times = []
+            for _ in range(3):
+                barrier(c)
+                t0 = time.perf_counter()
+                shard.gather_output(out_rows, out=y_all)
+                barrier(c)
+                times.append(time.perf_counter() - t0)
+            ms = sorted(times)[1] * 1e3
+            nbytes = n * feat * c.esz
+            allgather = {"ms": ms, "bytes_received_per_rank": nbytes - rows * feat * c.esz,
+                         "GBps_ingress_per_rank": (nbytes - rows * feat * c.esz) / (ms * 1e-3) / 1e9,
+                         "form": "dist.RowBlockShard.gather_output: N broadcasts into the row slices of one [n, F] buffer", "backend": c.backend}
+            del y_all
+        except Exception as exc:  # noqa: BLE001  (a diagnostic: the timed step does not depend on it)
+            allgather = {"ms": None, "error": "%s: %s" % (type(exc).__name__, exc)}
+    slow = max(per_rank, key=lambda r: r["own_ms_per_step"])
+    sig = workload_signature(args, nnz_total, nodes=n, hidden=feat, scale=args.scale)
+    roofline = roofline_record(dom, sig, "spmm_csr_kernel %s unweighted mean, F=%d, int64 row pointers%s" % (
+        args.dtype, feat, "" if c.world == 1 else " (rank 0's row block; per_rank lists every rank)"), compulsory, c.world)
     result = base_result(
-        args, c, nnz * args.steps / elapsed, elapsed,
-        "BASELINE config 5 on one GPU: GCN layer Y = A.(X.W) (gcnconv.py:30-31) on RMAT-%d (%d nodes, nnz %d%s, self-loops), F = %d, "
-        "engine reorder: %s" % (args.scale, n, nnz, " > 2^31" if nnz > 2 ** 31 else "", feat, reorder if args.reorder != "none" else "none"),
-        {"nodes": n, "nnz": nnz, "hidden": feat, "scale": args.scale, "reorder": reorder if args.reorder != "none" else "none",
-         "graph_build_seconds": build_s, "reorder_seconds_one_off": reorder_s, "parallelism": "single GPU",
+        args, c, nnz_total * args.steps / elapsed, elapsed,
+        "BASELINE config 5%s: GCN layer Y = A.X.W (gcnconv.py:30-31) on RMAT-%d (%d nodes, nnz %d%s, self-loops), F = %d, "
+        "engine reorder: %s; %s" % (
+            " on one GPU" if c.world == 1 else " on %d ranks: cost-balanced contiguous row blocks, X replicated, no exchange in the step" % c.world,
+            args.scale, n, nnz_total, " > 2^31" if nnz_total > 2 ** 31 else "", feat, reorder if args.reorder != "none" else "none",
+            "step = X.W then A.(.)" if order == "transform-first" else "step = A.X on own rows then (.).W on own rows"),
+        {"nodes": n, "nnz": nnz_total, "hidden": feat, "scale": args.scale, "reorder": reorder if args.reorder != "none" else "none",
+         "graph_build_seconds": build_s, "reorder_seconds_one_off": reorder_s,
+         "parallelism": "single GPU" if c.world == 1 else "row blocks x%d, X replicated" % c.world, "layer_order": order,
+         "row_bounds": bounds, "block_nnz": block_nnz, "edge_cost_bytes": edge_cost, "row_cost_bytes": row_cost,
          "peak_memory_GB": torch.cuda.max_memory_allocated() / 1e9})
-    result.update({"roofline": roofline, "spmm_launch_table": table, "dense_launch_table": dense_table})
-    if not args.no_cpu_baseline:
+    result.update({"roofline": roofline, "spmm_launch_table": table, "dense_launch_table": dense_table, "per_rank": per_rank,
+                   "slowest_rank": slow["rank"],
+                   "imbalance_max_over_mean": slow["own_ms_per_step"] / (sum(r["own_ms_per_step"] for r in per_rank) / len(per_rank)),
+                   "output_allgather": allgather})
+    if c.world == 1 and order == "transform-first":
+        # the N > 1 ranks run the layer as (A.X).W: the same launch kinds in the other order, measured here so that a scaling
+        # ratio can be formed between equal steps
+        _o, el2, _t = timed(step_aggregate_first, max(2, args.steps // 2))
+        result["aggregate_first_ms_per_step"] = el2 / max(2, args.steps // 2) * 1e3
+    if not args.no_cpu_baseline and c.rank == 0 and c.world == 1:
         del x, y
-        result["cpu_baseline"] = cpu_baseline_rows_only(g, feat, min(args.cpu_sample_rows, 1_000_000), args.seed)
+        result["cpu_baseline"] = cpu_baseline_rows_only(blk, feat, min(args.cpu_sample_rows, 1_000_000), args.seed)
     return result
 
 

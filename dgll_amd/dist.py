@@ -777,6 +777,96 @@ class _DistSageLayerOnAll(torch.autograd.Function):
         return gh_all, gws, gwn, None, None, None, None, None
 
 
+def cost_balanced_bounds(rowptr, n_parts, edge_cost=1, row_cost=0):
+    """Contiguous row blocks of about equal COST, cost(block) = edge_cost . nnz + row_cost . rows: cut points on the prefix sum
+    edge_cost . rowptr[i] + row_cost . i (monotone), not at n_rows / n_parts -- on a hubs-first RMAT order equal-row blocks are far
+    from equal-nnz blocks, and equal-nnz blocks are far from equal-row ones (the last block of RMAT-27 / 8 holds half the rows).
+    The costs are bytes: per edge one gathered row + the column id, per row the output row + the row pointer (+ what the
+    dense transform moves per row)."""
+    n = int(rowptr.numel() - 1)
+    c = rowptr.to(torch.int64) * int(edge_cost)
+    if row_cost:
+        c = c + torch.arange(n + 1, device=rowptr.device, dtype=torch.int64) * int(row_cost)
+    total = int(c[-1])
+    targets = (torch.arange(1, n_parts, device=rowptr.device, dtype=torch.float64) * (total / n_parts)).to(torch.int64)
+    cuts = torch.searchsorted(c, targets).clamp_(0, n).tolist()
+    bounds = [0] + cuts + [n]
+    for i in range(1, len(bounds)):                      # monotone even when one row outweighs a whole share
+        bounds[i] = max(bounds[i], bounds[i - 1])
+    return bounds
+
+
+def row_block(graph, lo, hi):
+    """Rows [lo, hi) of a CSR adjacency as their own CSRGraph over ALL source columns (views of the col / val arrays, a rebased
+    copy of the row pointers)."""
+    lo, hi = int(lo), int(hi)
+    e0, e1 = int(graph.rowptr[lo]), int(graph.rowptr[hi])
+    return CSRGraph(graph.rowptr[lo:hi + 1] - e0, graph.col[e0:e1], None if graph.val is None else graph.val[e0:e1], hi - lo,
+                    graph.n_cols, check=False)
+
+
+class RowBlockShard:
+    """BASELINE config 5's sharding: A is cut into contiguous, cost-balanced row blocks, one per rank
+    (process shape: one process per GPU as the reference's mp.spawn, MQGCN.py:161-163); the SOURCE rows X are replicated on every
+    rank (RMAT-27, F = 128 bf16: 34 GB of 288 GB), so a layer's aggregation needs no exchange at all -- every rank runs the same
+    SpMM kernel over its block against the full X and owns the output rows [own_begin, own_end).  A following layer would need
+    the outputs of all ranks: gather_output() (one all-gather of the padded blocks), timed separately by the bench.
+
+    spmm_fn (graph, x, reduce) -> rows: injected by the CPU tests (the product kernels are GPU-only)."""
+
+    def __init__(self, full_graph, world, rank, edge_cost=1, row_cost=0, bounds=None, group=None, spmm_fn=None):
+        self.world, self.rank, self.group = int(world), int(rank), group
+        self.bounds = list(bounds) if bounds is not None else cost_balanced_bounds(full_graph.rowptr, world, edge_cost, row_cost)
+        if len(self.bounds) != self.world + 1 or self.bounds[0] != 0 or self.bounds[-1] != full_graph.n_rows:
+            raise ValueError("bounds must run from 0 to n_rows in world + 1 steps")
+        self.n_rows_total, self.n_cols = full_graph.n_rows, full_graph.n_cols
+        self.own_begin, self.own_end = self.bounds[self.rank], self.bounds[self.rank + 1]
+        self.block = row_block(full_graph, self.own_begin, self.own_end)
+        at = full_graph.rowptr[torch.tensor(self.bounds, device=full_graph.rowptr.device)].tolist()
+        self.block_nnz = [int(at[r + 1] - at[r]) for r in range(self.world)]
+        self._spmm_fn = spmm_fn
+
+    @property
+    def n_own(self):
+        return self.own_end - self.own_begin
+
+    def own_copy(self):
+        """Own the block's arrays (copies), so that the full graph can be freed; builds the kernel's row schedule."""
+        b = self.block
+        self.block = CSRGraph(b.rowptr.clone(), b.col.clone(), None if b.val is None else b.val.clone(), b.n_rows, b.n_cols, check=False)
+        if self.block.is_cuda and self._spmm_fn is None:
+            self.block.plan()
+        return self
+
+    def aggregate(self, x_full, reduce="mean", out=None):
+        """Rows [own_begin, own_end) of reduce(A) . X from the replicated X; no communication."""
+        if x_full.shape[0] != self.n_cols:
+            raise ValueError("the replicated source matrix has %d rows, the adjacency gathers from %d" % (x_full.shape[0], self.n_cols))
+        if self._spmm_fn is not None:
+            y = self._spmm_fn(self.block, x_full, reduce)
+            if out is not None:
+                out.copy_(y)
+                return out
+            return y
+        return ops.spmm_raw(self.block, x_full, reduce=reduce, out=out)
+
+    def gather_output(self, y_own, out=None):
+        """[n_rows_total, F]: every rank's output rows in one buffer -- what a following layer would gather from.  One broadcast
+        per rank straight into that rank's row slice of `out` (the blocks differ in rows: an all-gather would pad every block to
+        the largest one, which on a hubs-first order holds half the rows), all in flight together."""
+        if out is None:
+            out = y_own.new_empty((self.n_rows_total, y_own.shape[1]))
+        out[self.own_begin:self.own_end].copy_(y_own)
+        if self.world == 1:
+            return out
+        handles = [dist.broadcast(out[self.bounds[r]:self.bounds[r + 1]], src=dist.get_global_rank(self.group, r) if self.group is not None else r,
+                                  group=self.group, async_op=True)
+                   for r in range(self.world) if self.bounds[r + 1] > self.bounds[r]]
+        for h in handles:
+            h.wait()
+        return out
+
+
 class DistGraph:
     """Per-rank engine: owns the Partition, the communication stream and the kernels' scratch."""
 

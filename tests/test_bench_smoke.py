@@ -168,6 +168,35 @@ def test_bench_minibatch_and_rmat_workloads(fused):
         assert r["config"]["workload_id"] == "rmat27" and r["roofline"]["bound"] == "hbm" and r["value"] > 0
 
 
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_rmat27_row_blocks_on_several_ranks(world):
+    """BASELINE config 5 at N > 1 (`bench.py --workload rmat27 --gpus N`; here scale 16, the ranks share the one GPU over gloo: a
+    functional run, never a reported number): cost-balanced contiguous row blocks, X replicated, value = sum of the ranks'
+    nonzeros / slowest rank, per-rank roofline, the separately timed output all-gather."""
+    env = dict(os.environ, DGLL_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    one = _last_json(subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "rmat27", "--scale", "16", "--steps", "2",
+                                     "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600).stdout)
+    assert one["config"]["layer_order"] == "transform-first" and one["aggregate_first_ms_per_step"] > 0 and len(one["per_rank"]) == 1
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "rmat27", "--scale", "16", "--steps", "2",
+                          "--warmup", "1", "--gpus", str(world)], capture_output=True, text=True, timeout=1200, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    d = _last_json(res.stdout)
+    assert d["n_gpus"] == world and d["scaling"] == "strong" and d["config"]["layer_order"] == "aggregate-first"
+    assert d["config"]["nnz"] == one["config"]["nnz"] and d["config"]["nodes"] == one["config"]["nodes"]
+    ranks = d["per_rank"]
+    assert [r["rank"] for r in ranks] == list(range(world))
+    assert sum(r["nnz"] for r in ranks) == d["config"]["nnz"] and sum(r["rows"] for r in ranks) == d["config"]["nodes"]
+    assert [r["row_range"][0] for r in ranks] == d["config"]["row_bounds"][:-1]
+    cost = [d["config"]["edge_cost_bytes"] * r["nnz"] + d["config"]["row_cost_bytes"] * r["rows"] for r in ranks]
+    assert max(cost) < 1.25 * (sum(cost) / world)                                   # (one hub row is ~1 % of a share at this scale)
+    assert all(r["spmm_avg_ms"] > 0 and r["spmm_frac_algorithmic"] > 0 for r in ranks)
+    assert abs(d["value"] - d["config"]["nnz"] * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) < 1e-6 * d["value"]
+    assert d["output_allgather"]["ms"] > 0 and "cpu_baseline" not in d
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
+
+
 def test_bench_minibatch_single_stream_mode_still_runs():
     """--mb-sampler-threads 0: ONE sequential sampler stream on the interpreter's generator (the default-compatible mode of rounds
     1-3), host-side translation of the outermost hop."""

@@ -387,3 +387,64 @@ def test_first_layer_recomputed_on_halo_rows_equals_the_exchange(world):
     the merged adjacency, so layers 0 and 1 exchange nothing per step (dist._DistSageInputLayerAll).  Outputs and the all-reduced
     parameter gradients equal the single-process model and the exchanging path; the per-step exchanges left are the third layer's."""
     mp.spawn(_sage_model_worker, args=(world, _free_port()), nprocs=world, join=True)
+
+
+# ---------------------------------------------------------------------------------------------------------------- config 5
+def _rowblock_worker(rank, world, port, scale):
+    """BASELINE config 5's sharding over gloo (process shape MQGCN.py:161-163): cost-balanced contiguous
+    row blocks, X replicated, no exchange inside the aggregation; results == the single-process pass."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dgll_amd import dist as ddist
+        from dgll_amd import synth
+
+        full = synth.rmat_graph(scale, 16, seed=3, device="cpu", symmetric=False, weighted=False, self_loops=True)
+        full, _perm = full.reorder(method="degree", seed=0)            # hubs first, as bench.py orders RMAT-27
+        n, feat = full.n_rows, 24
+        x = torch.randn(n, feat, generator=torch.Generator().manual_seed(7))          # replicated: the same on every rank
+        ref = _cpu_spmm(full, x, reduce="mean")
+
+        def spmm(graph, xx, reduce):
+            return _cpu_spmm(graph, xx, reduce=reduce)
+
+        edge_cost, row_cost = feat * 4 + 4, feat * 4 + 8 + 2 * feat * 4
+        shard = ddist.RowBlockShard(full, world, rank, edge_cost, row_cost, spmm_fn=spmm)
+        # every rank derives the same cut points; blocks tile the rows; costs are balanced to within one (heaviest) row
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (shard.bounds, shard.block.nnz, shard.n_own))
+        assert all(b == shard.bounds for b, _, _ in gathered)
+        assert sum(nz for _, nz, _ in gathered) == full.nnz and sum(r for _, _, r in gathered) == n
+        assert shard.block_nnz == [nz for _, nz, _ in gathered]
+        costs = [edge_cost * nz + row_cost * r for _, nz, r in gathered]
+        heaviest_row = edge_cost * int(full.degrees().max()) + row_cost
+        assert max(costs) - min(costs) <= 2 * heaviest_row, (costs, heaviest_row)
+        equal_rows_nnz = [int(full.rowptr[(r + 1) * n // world] - full.rowptr[r * n // world]) for r in range(world)]
+        assert max(equal_rows_nnz) > 1.5 * max(shard.block_nnz)          # what 2^scale / world blocks would have done on this order
+        shard.own_copy()
+        out = shard.aggregate(x, reduce="mean")
+        assert out.shape == (shard.n_own, feat)
+        assert torch.equal(out, ref[shard.own_begin:shard.own_end])      # the same rows, the same per-row order of additions
+        everything = shard.gather_output(out)
+        assert torch.equal(everything, ref)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,scale", [(2, 13), (8, 12)])
+def test_config5_row_blocks_with_replicated_sources_equal_the_single_process_pass(world, scale):
+    mp.spawn(_rowblock_worker, args=(world, _free_port(), scale), nprocs=world, join=True)
+
+
+def test_cost_balanced_bounds_edge_cases():
+    from dgll_amd import dist as ddist
+
+    rp = torch.tensor([0, 0, 0, 10, 10, 11, 11, 11, 30], dtype=torch.int64)
+    b = ddist.cost_balanced_bounds(rp, 3, edge_cost=1, row_cost=0)
+    assert b[0] == 0 and b[-1] == 8 and b == sorted(b)
+    assert ddist.cost_balanced_bounds(rp, 1) == [0, 8]
+    # more parts than rows with edges: empty blocks are allowed, the cuts stay monotone
+    b = ddist.cost_balanced_bounds(torch.tensor([0, 100], dtype=torch.int64), 4, 1, 0)
+    assert b[0] == 0 and b[-1] == 1 and b == sorted(b)
+    # rows only (no edges): equal row counts
+    assert ddist.cost_balanced_bounds(torch.zeros(9, dtype=torch.int64), 4, 1, 1) == [0, 2, 4, 6, 8]

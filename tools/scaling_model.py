@@ -40,7 +40,92 @@ class NullExchange:
 RANK = int(os.environ.get("MODEL_RANK", "0"))      # which rank's share is run (0 holds the hub communities: the heaviest)
 
 
+def rmat27_model(scale, feat=128, dtype=torch.bfloat16, reps=5):
+    """Config 5 at N = 1, 2, 4, 8 on ONE GPU: the step has no exchange (row blocks, X replicated: dist.RowBlockShard), so a rank's
+    step time on its own GPU is its block's time here.  EVERY block of every N is run through the real kernels (the bench's
+    aggregate-first step: SpMM over the block against the full X, transform of the block's rows); predicted step = the slowest
+    block.  Then the per-edge / per-row costs are FITTED to the measured block times (least squares over all blocks of all N) and
+    the cut points recomputed with them: what the byte-count guess leaves on the table."""
+    from dgll_amd import dense
+
+    dev = torch.device("cuda:0")
+    g = synth.rmat_graph(scale, 16, seed=0, device=dev, symmetric=False, weighted=False, self_loops=True)
+    g, _ = g.reorder(method="degree" if g.nnz >= (1 << 30) else "lpa", seed=0)
+    torch.cuda.empty_cache()
+    n, esz = g.n_rows, 2 if dtype == torch.bfloat16 else 4
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1)
+    x = ops.alloc_features(n, feat, dtype, dev)
+    for lo in range(0, n, 1 << 24):
+        hi = min(n, lo + (1 << 24))
+        x[lo:hi] = torch.randn(hi - lo, feat, device=dev, generator=gen).to(dtype)
+    w = (torch.randn(feat, feat, device=dev, generator=gen) / feat ** 0.5).to(dtype)
+    print("RMAT-%d: %d nodes, %d nonzeros, max degree %d, F = %d %s" % (scale, n, g.nnz, int(g.degrees().max()), feat, dtype))
+
+    def run_block(blk):
+        y = ops.alloc_features(blk.n_rows, feat, dtype, dev)
+
+        def step():
+            return dense.transform_bf16(ops.spmm_raw(blk, x, reduce="mean", out=y), w.t()) if dtype == torch.bfloat16 \
+                else ops.spmm_raw(blk, x, reduce="mean", out=y) @ w
+
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        with ops.LaunchTimer() as timer:
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                step()
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / reps * 1e3
+        kinds = {k[0]: v[1] for k, v in timer.summary().items()}
+        return ms, kinds.get("spmm", 0.0), kinds.get("transform", 0.0)
+
+    def sweep(edge_cost, row_cost, label):
+        samples, single = [], None
+        for world in (1, 2, 4, 8):
+            bounds = ddist.cost_balanced_bounds(g.rowptr, world, edge_cost, row_cost)
+            rows_out = []
+            for r in range(world):
+                shard = ddist.RowBlockShard(g, world, r, bounds=bounds)
+                if world > 1:
+                    shard.own_copy()
+                else:
+                    shard.block = g
+                    g.plan()
+                ms, spmm_ms, dense_ms = run_block(shard.block)
+                rows_out.append((r, shard.n_own, shard.block.nnz, ms, spmm_ms, dense_ms))
+                samples.append((shard.block.nnz, shard.n_own, ms))
+                del shard
+                torch.cuda.empty_cache()
+            slow = max(rows_out, key=lambda t: t[3])
+            mean = sum(t[3] for t in rows_out) / world
+            if world == 1:
+                single = slow[3]
+            print("[%s] N=%d: predicted step %.2f ms (slowest block: rank %d), mean %.2f, max/mean %.3f, speed-up vs N=1 %.2fx" % (
+                label, world, slow[3], slow[0], mean, slow[3] / mean, single / slow[3]))
+            for r, rows, nnz, ms, sp, de in rows_out:
+                print("      rank %d: %11d rows %12d nnz | step %.2f ms = spmm %.2f + transform %.2f | %.1f G edges/s, spmm %.2f TB/s algorithmic" % (
+                    r, rows, nnz, ms, sp, de, nnz / (ms * 1e-3) / 1e9,
+                    (nnz * (feat * esz + 4) + rows * (feat * esz + 8)) / max(sp, 1e-9) / 1e9))
+        return samples
+
+    edge_cost, row_cost = feat * esz + 4, feat * esz + 8 + 2 * feat * esz
+    samples = sweep(edge_cost, row_cost, "byte costs: %d B/edge, %d B/row" % (edge_cost, row_cost))
+    a = torch.tensor([[s[0], s[1]] for s in samples], dtype=torch.float64)
+    b = torch.tensor([s[2] for s in samples], dtype=torch.float64).unsqueeze(1)
+    sol = torch.linalg.lstsq(a, b).solution.flatten()
+    per_edge_ns, per_row_ns = float(sol[0]) * 1e6, float(sol[1]) * 1e6
+    print("fitted: %.4f ns per edge, %.4f ns per row (ratio row/edge %.2f; the byte costs assume %.2f)" % (
+        per_edge_ns, per_row_ns, per_row_ns / per_edge_ns, row_cost / edge_cost))
+    if per_edge_ns > 0 and per_row_ns > 0:
+        sweep(max(1, int(round(per_edge_ns * 1000))), max(1, int(round(per_row_ns * 1000))), "fitted costs")
+
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "rmat27":
+        return rmat27_model(int(sys.argv[2]) if len(sys.argv) > 2 else 27)
     dev = torch.device("cuda:0")
     raw = synth.products_like_graph(dev, seed=0, locality=0.9, exact=True, permute_ids=True)     # bench.py's default graph
     n, nnz = raw.n_rows, raw.nnz
