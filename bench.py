@@ -29,10 +29,13 @@ planted communities holding 90 % of the edges, node ids RANDOMLY PERMUTED (what 
 one-off locality pass (CSRGraph.reorder, --reorder) relabels the nodes before training, as the METIS relabelling of BASELINE
 config 3 does; --reorder none measures the raw order, --no-permute the generator's community-sorted order.
 
-Rank 0 prints ONE JSON line; DESIGN.md section 6 explains every field.  `roofline.frac` has ONE definition, named in
-`roofline.frac_definition`: HBM-side counter traffic of that very launch (profiles/traffic.json -- rocprofv3 FETCH_SIZE /
-WRITE_SIZE over this program, corrected by the ratios calibrated in the same pass, and only when the entry was collected
-with THIS build of libdgll_hip.so) / the live launch time / peak; without a matching entry, the section-8(d) formula.
+Rank 0 prints ONE JSON line; DESIGN.md section 7 explains every field.  `roofline.achieved` is the section-8(d) algorithmic rate
+(every edge charged one full feature row) of the dominant launch, timed live with HIP events on the launch stream.
+`roofline.frac` is a fraction (<= 1) of the 8 TB/s peak, defined in `roofline.frac_definition`: counter traffic of that very
+launch kind (profiles/traffic.json -- rocprofv3 FETCH_SIZE / WRITE_SIZE over this program, corrected by the ratios calibrated in
+the same pass, used only when the entry was collected with THIS build of libdgll_hip.so; Infinity-Cache hits included: an upper
+bound on HBM utilisation) / the live launch time / peak; without a matching entry min(1, frac_algorithmic).  `frac_algorithmic`
+(may exceed 1: caches serve re-reads), `traffic_over_compulsory` and `frac_conservative` sit next to it.
 """
 import argparse
 import json
@@ -99,7 +102,9 @@ def parse_args(argv=None):
     ap.add_argument("--mb-classes", type=int, default=41)
     ap.add_argument("--mb-batch", type=int, default=1024)
     ap.add_argument("--mb-fanouts", default="25,10,10")
-    ap.add_argument("--mb-cache-frac", type=float, default=0.5, help="fraction of the nodes whose features sit in the HBM cache")
+    ap.add_argument("--mb-cache-frac", type=float, default=0.5,
+                    help="fraction of the nodes whose features sit in the HBM cache; -1 = the reference's capacity rule (storage.py:64-98: "
+                         "every row that fits in free device memory)")
     ap.add_argument("--mb-no-fused-last-hop", action="store_true",
                     help="minibatch: fetch the outermost hop's rows and reduce them in the model instead of reducing them straight out of the cache")
     ap.add_argument("--mb-sampler-threads", type=int, default=-1,
@@ -401,16 +406,21 @@ def roofline_record(dom, sig, kernel_desc, compulsory, world, extra=None):
            "avg_launch_ms": dom["avg_ms"], "algorithmic_bytes_per_launch": dom["algorithmic_bytes"],
            "compulsory_bytes_per_launch": compulsory, "edges_per_s_this_kernel": dom["nnz"] / (dom["avg_ms"] * 1e-3),
            "build_stamp": build_stamp()}
-    # `frac` is ALWAYS achieved / peak with `achieved` = the section-8(d) algorithmic bytes / the live launch time -- the contract's
-    # definition; it exceeds 1 when caches serve re-reads (every edge is charged a full feature row).  Next to it, always present:
-    #   frac_l2_miss_path  bytes the L2s requested from the fabric for this launch kind (rocprofv3 FETCH_SIZE / WRITE_SIZE, corrected by
-    #                      the ratios calibrated in the same pass; Infinity-Cache hits are INCLUDED: an upper bound on DRAM traffic)
-    #                      / live launch time / peak; null unless profiles/traffic.json holds an entry for this workload, kernel
-    #                      instantiation and build;
-    #   frac_conservative  (sage headline only, filled in by the caller) structure-free graph in raw id order, formula.
-    rec["frac"] = rec["frac_algorithmic"]
-    rec["frac_definition"] = "algorithmic bytes (SURVEY 8(d): every edge one full feature row) / live launch time / peak; > 1 = cache-served re-reads"
+    # `frac` is a FRACTION (<= 1) of the HBM peak:
+    #   * when profiles/traffic.json holds counter traffic for this workload, kernel instantiation AND this build of libdgll_hip.so:
+    #     frac = counter bytes per launch / live launch time / peak  (= frac_l2_miss_path).  The bytes are what the L2s requested from
+    #     the fabric (rocprofv3 FETCH_SIZE / WRITE_SIZE, corrected by the ratios calibrated in the same pass); Infinity-Cache hits are
+    #     INCLUDED (this box's rocprofv3 exposes no DRAM-side counter: profiles/r05_rocprofv3_counter_names.txt), so it is an UPPER
+    #     BOUND on HBM utilisation;
+    #   * otherwise frac = min(1, frac_algorithmic) and frac_definition says that no counter entry matched.
+    # Always next to it: frac_algorithmic (section 8(d): every edge charged one full feature row / time / peak; > 1 = cache-served
+    # re-reads), traffic_over_compulsory (counter bytes / compulsory bytes: the remaining headroom is THIS ratio), and for the sage
+    # headline frac_conservative (structure-free graph in raw id order, formula; filled in by the caller).
+    rec["frac"] = min(1.0, rec["frac_algorithmic"])
+    rec["frac_definition"] = ("no counter entry in profiles/traffic.json for this workload / kernel instantiation / build: min(1, "
+                              "frac_algorithmic) -- algorithmic bytes (SURVEY 8(d)) / live launch time / peak, capped at 1 (caches serve re-reads)")
     rec["frac_l2_miss_path"] = None
+    rec["traffic_over_compulsory"] = None
     entry = load_traffic(sig, dom["kernel_fragment"]) if world == 1 else None
     if entry is not None:
         rec["traffic"] = entry["hbm_bytes_per_launch"]
@@ -419,8 +429,14 @@ def roofline_record(dom, sig, kernel_desc, compulsory, world, extra=None):
         hbm = entry["hbm_bytes_per_launch"] / (dom["avg_ms"] * 1e-3) / 1e9
         rec["achieved_l2_miss_path"] = hbm
         rec["frac_l2_miss_path"] = hbm / HBM_PEAK_GBPS
-        rec["frac_l2_miss_path_definition"] = ("counter bytes per launch (profiles/traffic.json: FETCH_SIZE / ratio_read + WRITE_SIZE / "
-                                               "ratio_write, same build; includes Infinity-Cache hits) / live launch time / peak")
+        rec["frac"] = min(1.0, hbm / HBM_PEAK_GBPS)
+        rec["frac_definition"] = ("counter bytes per launch (profiles/traffic.json, same build: FETCH_SIZE / ratio_read + WRITE_SIZE / "
+                                  "ratio_write = what the L2s requested from the fabric; Infinity-Cache hits included, so an UPPER BOUND on "
+                                  "HBM utilisation) / live launch time / peak.  `achieved` stays the section-8(d) algorithmic rate "
+                                  "(frac_algorithmic = achieved / peak, > 1 when caches serve re-reads)")
+        rec["frac_l2_miss_path_definition"] = rec["frac_definition"]
+        if compulsory:
+            rec["traffic_over_compulsory"] = entry["hbm_bytes_per_launch"] / compulsory
     if extra:
         rec.update(extra)
     return rec
@@ -1155,7 +1171,14 @@ def run_minibatch(args, c):
     dg = DGraph.from_csr(indptr, indices, labels=labels, features=feats)
     cache = GraphCacheServer(feats, gpuid=c.dev.index or 0)
     cache.log = True
-    cache.auto_cache(deg, capacity=int(args.mb_cache_frac * args.mb_nodes))
+    if args.mb_cache_frac < 0:        # the reference's rule, storage.py:64-98: as many rows as fit in the free device memory (minus a reserve)
+        cache.auto_cache(deg)
+        cache_rule = "storage.py:64-98 capacity rule (free device memory / row bytes): %d of %d rows cached" % (
+            min(cache.capability, args.mb_nodes), args.mb_nodes)
+        args.mb_cache_frac = min(cache.capability, args.mb_nodes) / args.mb_nodes
+    else:
+        cache.auto_cache(deg, capacity=int(args.mb_cache_frac * args.mb_nodes))
+        cache_rule = "fixed fraction %.2f of the nodes (hottest by out-degree)" % args.mb_cache_frac
     # The producers run up to six batches ahead (queue of 4 loaded + 2 sampled): a short timed region would be served from that
     # backlog and report the consumer's speed, not the pipeline's.  Steady state needs the backlog to be a small share of the batches
     # timed: at least 16 warm-up and 192 timed batches here (a 64-batch window, 0.15 s, moved by +-30 % from run to run), whatever --steps / --warmup say (the JSON line carries the counts used).
@@ -1370,7 +1393,8 @@ def run_minibatch(args, c):
                    "consumer_step": ("one HIP graph on padded static block shapes (rows per hop %s, %d of %d timed batches beyond them ran "
                                      "launch by launch) + the optimizer's launch" % (graphed.rows, graph_misses, steps)) if graphed is not None
                    else "launch by launch",
-                   "cache_miss_rate": cache.get_miss_rate(),
+                   "cache_miss_rate": cache.get_miss_rate(), "cache_rule": cache_rule,
+                   "cache_rows": int(min(cache.capability, args.mb_nodes)),
                    "epoch_time_s_153431_train_nodes": elapsed / steps * (153_431 / args.mb_batch),
                    "roofline": roofline, "spmm_launch_table": table, "dense_launch_table": dense_table})
     if not args.no_cpu_baseline:
@@ -1448,10 +1472,16 @@ def per_rank_diagnostics(c, engine, step, racom=None, opt_wrap=None):
     return everyone
 
 
-OTHER_WORKLOADS = {        # child command line tails and wall-clock bounds (seconds); the driver allows the whole run 30 minutes
-    "gat": (["--steps", "10", "--warmup", "3", "--no-extra-graphs"], 420),
-    "minibatch": ([], 420),
-    "rmat27": (["--steps", "5", "--warmup", "2"], 600),
+OTHER_WORKLOADS = {        # record name -> (--workload, child command line tail, wall-clock bound in seconds)
+    "gat": ("gat", ["--steps", "10", "--warmup", "3", "--no-extra-graphs"], 420),
+    "minibatch": ("minibatch", [], 420),
+    "rmat27": ("rmat27", ["--steps", "5", "--warmup", "2"], 600),
+    # the headline step in the reference's own arithmetic (fp32 storage, dgll/__init__.py:1, gcnconv.py:30-31): BASELINE.md section 3
+    # quotes a 4.65 G edges/s fp32-weighted target next to the bf16 one
+    "sage_f32": ("sage", ["--dtype", "f32", "--steps", "10", "--warmup", "3", "--no-extra-graphs", "--no-cpu-baseline", "--other-workloads", "off"], 300),
+    # config 2 with the reference's own capacity rule for the feature cache (storage.py:64-98: everything that fits in free device
+    # memory -- all of a Reddit-sized matrix in 288 GB) next to the 50 % cache the `minibatch` record keeps from the earlier rounds
+    "minibatch_capacity_rule_cache": ("minibatch", ["--mb-cache-frac", "-1", "--no-cpu-baseline"], 420),
 }
 
 
@@ -1461,18 +1491,19 @@ def compact_record(d):
     keep = {k: d.get(k) for k in ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "data", "epoch_time_s", "loss")}
     keep["workload"] = d.get("config", {}).get("workload")
     r = d.get("roofline") or {}
-    keep["roofline"] = {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "frac_definition", "frac_l2_miss_path",
-                                              "kernel", "kernel_fragment", "avg_launch_ms", "algorithmic_bytes_per_launch", "build_stamp")} if r else None
+    keep["roofline"] = {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "frac_definition", "frac_algorithmic",
+                                              "frac_l2_miss_path", "traffic_over_compulsory", "kernel", "kernel_fragment", "avg_launch_ms", "algorithmic_bytes_per_launch", "build_stamp")} if r else None
     cb = d.get("cpu_baseline") or {}
     keep["cpu_baseline"] = {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "sample", "oracle_c_openmp_csr_edges_per_s",
                                                    "oracle_c_openmp_edges_per_s", "cpu_model")} if cb else None
     for k in ("gat_pass_over_spmm", "spmm_same_width_same_graph_ms", "batches_per_s", "gpu_side_ms_per_batch", "gpu_side_ms_per_batch_p50",
               "gpu_side_ms_per_batch_p95", "host_sampler_ms_per_batch", "host_sampler_threads", "sampler_mode", "consumer_host_ms_per_batch",
-              "loader_host_ms_per_batch", "cache_miss_rate", "epoch_time_s_153431_train_nodes"):
+              "loader_host_ms_per_batch", "cache_miss_rate", "epoch_time_s_153431_train_nodes", "cache_rows", "cache_rule",
+              "aggregate_first_ms_per_step"):
         if k in d:
             keep[k] = d[k]
     cfg = d.get("config", {})
-    for k in ("nodes", "nnz", "hidden", "heads", "batch", "fanouts", "scale", "peak_memory_GB"):
+    for k in ("nodes", "nnz", "hidden", "heads", "batch", "fanouts", "scale", "peak_memory_GB", "cache_fraction"):
         if k in cfg:
             keep.setdefault("config", {})[k] = cfg[k]
     launches = {name: round(v["avg_ms"], 4) for name, v in (d.get("spmm_launch_table") or {}).items()}
@@ -1488,11 +1519,11 @@ def run_other_workloads(args):
     torch.cuda.empty_cache()
     overrides = json.loads(os.environ.get("DGLL_BENCH_OTHER_ARGS", "{}"))      # tests: small shapes
     out = {}
-    for name, (tail, limit) in OTHER_WORKLOADS.items():
-        extra = overrides.get(name, tail)
+    for name, (workload, tail, limit) in OTHER_WORKLOADS.items():
+        extra = overrides.get(name, tail if not overrides else None)      # tests name the records they want (small shapes)
         if extra is None:
             continue
-        cmd = [sys.executable, os.path.abspath(__file__), "--workload", name, "--seed", str(args.seed)] + list(extra)
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", workload, "--seed", str(args.seed)] + list(extra)
         t0 = time.perf_counter()
         try:
             res = subprocess.run(cmd, capture_output=True, text=True, timeout=limit)
@@ -1504,7 +1535,7 @@ def run_other_workloads(args):
         except subprocess.TimeoutExpired:
             out[name] = {"error": "no result within %d s" % limit}
         out[name]["wall_seconds"] = time.perf_counter() - t0
-        out[name]["command"] = "python bench.py --workload %s %s" % (name, " ".join(extra))
+        out[name]["command"] = "python bench.py --workload %s %s" % (workload, " ".join(extra))
     return out
 
 

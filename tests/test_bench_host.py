@@ -51,7 +51,7 @@ def _dom(frag, ms=5.0, b_alg=65.6e9):
             "kernel_fragment": frag}
 
 
-def test_frac_is_unconditionally_the_algorithmic_fraction_and_stale_traffic_is_refused(bench, tmp_path):
+def test_frac_is_a_fraction_counter_based_when_the_build_matches_and_stale_traffic_is_refused(bench, tmp_path):
     frag = "spmm_csr_kernel<unsigned short, unsigned short, 8, 32, true, 4, true, false>"
     sig = {"workload": "sage", "nodes": 1, "nnz": 2, "locality": 0.9, "permuted_ids": True, "reorder": "lpa", "hidden": 256, "dtype": "bf16"}
     entry = {"workload": dict(sig), "kernel_fragment": frag, "build_stamp": "stamp-A", "hbm_bytes_per_launch": 31.4e9, "round": "r03",
@@ -59,15 +59,20 @@ def test_frac_is_unconditionally_the_algorithmic_fraction_and_stale_traffic_is_r
     with open(tmp_path / "profiles" / "traffic.json", "w") as f:
         json.dump({"entries": [entry]}, f)
     rec = bench.roofline_record(_dom(frag), sig, "k", 3.5e9, world=1)
-    # `frac` is achieved / peak with the section-8(d) algorithmic bytes -- UNCONDITIONALLY; the counter-based reading has its own name
-    assert abs(rec["frac"] - 65.6e9 / 5e-3 / 1e9 / 8000.0) < 1e-12 and rec["frac"] == rec["frac_algorithmic"] == rec["achieved"] / rec["peak"]
+    # `achieved` is the section-8(d) algorithmic rate (here above the peak: caches serve re-reads); `frac` is a FRACTION: the counter
+    # traffic of this launch kind / live time / peak, because the entry was collected with this build
+    assert abs(rec["frac_algorithmic"] - 65.6e9 / 5e-3 / 1e9 / 8000.0) < 1e-12 and rec["frac_algorithmic"] == rec["achieved"] / rec["peak"] > 1
     assert rec["traffic"] == 31.4e9 and abs(rec["frac_l2_miss_path"] - 31.4e9 / 5e-3 / 1e9 / 8000.0) < 1e-12
-    assert "algorithmic" in rec["frac_definition"] and "Infinity-Cache" in rec["frac_l2_miss_path_definition"]
-    # another build of the library: the entry must not be used -- and `frac` does not change its meaning
+    assert rec["frac"] == rec["frac_l2_miss_path"] <= 1.0
+    assert abs(rec["traffic_over_compulsory"] - 31.4 / 3.5) < 1e-9
+    assert "counter bytes" in rec["frac_definition"] and "Infinity-Cache" in rec["frac_definition"] and "UPPER BOUND" in rec["frac_definition"]
+    # another build of the library: the entry must not be used; `frac` falls back to min(1, algorithmic) and says so
     bench.build_stamp = lambda: "stamp-B"
     rec2 = bench.roofline_record(_dom(frag), sig, "k", 3.5e9, world=1)
-    assert rec2["traffic"] is None and rec2["frac_l2_miss_path"] is None
-    assert rec2["frac"] == rec["frac"] and rec2["frac_definition"] == rec["frac_definition"]
+    assert rec2["traffic"] is None and rec2["frac_l2_miss_path"] is None and rec2["traffic_over_compulsory"] is None
+    assert rec2["frac"] == 1.0 and rec2["frac_algorithmic"] == rec["frac_algorithmic"] and "no counter entry" in rec2["frac_definition"]
+    rec3 = bench.roofline_record(_dom(frag, ms=20.0), sig, "k", 3.5e9, world=1)
+    assert rec3["frac"] == rec3["frac_algorithmic"] < 1.0
     bench.build_stamp = lambda: "stamp-A"
     # another workload / another kernel: no match either; multi-rank runs never take counter traffic
     assert bench.roofline_record(_dom(frag), dict(sig, nnz=3), "k", 0, world=1)["traffic"] is None

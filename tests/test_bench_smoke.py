@@ -40,7 +40,7 @@ def test_bench_single_rank_contract():
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["unit"] == "edges/s" and d["vs_baseline"] is None
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
     assert d["roofline"]["bound"] == "hbm" and d["roofline"]["traffic"] is None       # counters exist for the default shape only
-    assert d["roofline"]["frac"] is None or d["roofline"]["frac"] <= 1.0 or d["roofline"]["frac_algorithmic"] == d["roofline"]["frac"]
+    assert 0.0 < d["roofline"]["frac"] <= 1.0 and d["roofline"]["frac"] == min(1.0, d["roofline"]["frac_algorithmic"])      # no counter entry for this shape
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(d["cpu_baseline"]) and d["cpu_baseline"]["kind"] == "port"
     # the reference's COO op AND the CSR variant, warm-up + median of 3, torch version and cores stated
     assert set(("torch_sparse_mm_csr_edges_per_s", "oracle_c_openmp_csr_edges_per_s", "torch_version", "threads")) <= set(d["cpu_baseline"])
@@ -229,7 +229,7 @@ def test_default_line_carries_the_other_baseline_configs():
     for name, rec in ow.items():
         assert "error" not in rec, (name, rec)
         assert rec["value"] > 0 and rec["ms_per_step"] > 0 and rec["wall_seconds"] > 0 and rec["command"].startswith("python bench.py --workload " + name)
-        assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(rec["roofline"]) and rec["roofline"]["frac"] == rec["roofline"]["achieved"] / rec["roofline"]["peak"]
+        assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(rec["roofline"]) and 0.0 < rec["roofline"]["frac"] <= 1.0 and rec["roofline"]["frac_algorithmic"] == rec["roofline"]["achieved"] / rec["roofline"]["peak"]
         assert set(("value", "unit", "cores", "kind", "sample")) <= set(rec["cpu_baseline"]) and rec["cpu_baseline"]["kind"] == "port"
     assert "gat_pass_over_spmm" not in ow["gat"] and ow["minibatch"]["batches_per_s"] > 0       # --no-extra-graphs: no SpMM comparison leg
     # the small-shape headline alone does not start them
