@@ -128,6 +128,8 @@ def parse_args(argv=None):
     ap.add_argument("--scale", type=int, default=27, help="rmat27: RMAT scale (27 = config 5; smaller for a quick run)")
     ap.add_argument("--rmat-order", choices=["auto", "transform-first", "aggregate-first"], default="auto",
                     help="rmat27: the layer as A.(X.W) (the reference's order; N = 1 default) or as (A.X).W (N > 1: own rows only)")
+    ap.add_argument("--rmat-no-rebalance", action="store_true",
+                    help="rmat27, N > 1: keep the built-in cost ratio instead of re-fitting it on the live ranks and re-cutting once")
     ap.add_argument("--rmat-no-allgather", action="store_true", help="rmat27, N > 1: skip the separately timed all-gather of the outputs")
     return ap.parse_args(argv)
 
@@ -992,20 +994,13 @@ def run_rmat27(args, c):
         order = "transform-first" if c.world == 1 else "aggregate-first"
     if c.world > 1 and order != "aggregate-first":
         raise SystemExit("bench.py --workload rmat27 --gpus N > 1 runs the layer as (A.X).W on replicated X (--rmat-order aggregate-first)")
-    # bytes per edge / per row of one rank's step: the gathered row + its column id; the SpMM's output row + row pointer + the
-    # transform's read and write of that row
-    edge_cost, row_cost = feat * c.esz + 4, feat * c.esz + 8 + 2 * feat * c.esz
+    # cost of one rank's step per edge and per row, in picoseconds on one MI355X (tools/scaling_model.py rmat27, least squares over
+    # the 15 blocks of N = 1, 2, 4, 8 at scale 27: 0.035 ns per edge, 0.183 ns per row -- profiles/r05_rmat27_scaling_model.log).  The
+    # byte counts (260 B per edge, 776 B per row: ratio 3.0) under-charge the rows: a block of degree-1 rows is bound by rows per
+    # second, not bytes (predicted 8-GPU speed-up 5.3x with the byte ratio, 7.4x with the fitted one).  --rmat-rebalance (default)
+    # re-fits both on the live ranks after a first measurement and re-cuts once.
+    edge_cost, row_cost = 35, 183
     shard = ddist.RowBlockShard(g, c.world, c.rank, edge_cost, row_cost)
-    bounds, block_nnz = shard.bounds, shard.block_nnz
-    if c.world > 1:
-        shard.own_copy()
-        del g
-        torch.cuda.empty_cache()
-        blk = shard.block
-    else:
-        blk = g
-    blk.plan()
-    rows, nnz = blk.n_rows, blk.nnz
     gen = torch.Generator(device=c.dev)
     gen.manual_seed(args.seed + 1)                       # the same X and W on every rank: X is replicated, not exchanged
     x = ops.alloc_features(n, feat, c.dtype, c.dev)
@@ -1014,6 +1009,53 @@ def run_rmat27(args, c):
         hi = min(n, lo + chunk)
         x[lo:hi] = torch.randn(hi - lo, feat, device=c.dev, generator=gen).to(c.dtype)
     w = (torch.randn(feat, feat, device=c.dev, generator=gen) / feat ** 0.5).to(c.dtype)
+    rebalance = None
+    if c.world > 1:
+        shard.own_copy()
+        if not args.rmat_no_rebalance:
+            # one measured pass per rank -> (nnz, rows, ms) of every rank -> least-squares cost per edge and per row -> new cut points
+            # (every rank computes the same ones from the same gathered numbers); kept when the model predicts a step >= 2 % shorter
+            yb = ops.alloc_features(shard.n_own, feat, c.dtype, c.dev)
+
+            def probe():
+                out = ops.spmm_raw(shard.block, x, reduce="mean", out=yb)
+                return dense.transform_bf16(out, w.t()) if c.dtype == torch.bfloat16 else out @ w
+
+            for _ in range(2):
+                probe()
+            barrier(c)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                probe()
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / 3 * 1e3
+            del yb
+            got = [None] * c.world
+            torch.distributed.all_gather_object(got, (shard.block.nnz, shard.n_own, ms))
+            a_ = torch.tensor([[t[0], t[1]] for t in got], dtype=torch.float64)
+            sol = torch.linalg.lstsq(a_, torch.tensor([[t[2]] for t in got], dtype=torch.float64)).solution.flatten()
+            per_edge, per_row = float(sol[0]), float(sol[1])
+            rebalance = {"measured_ms": [t[2] for t in got], "fitted_ns_per_edge": per_edge * 1e6, "fitted_ns_per_row": per_row * 1e6,
+                         "applied": False}
+            if per_edge > 0 and per_row > 0:
+                e2, r2 = max(1, int(round(per_edge * 1e9))), max(1, int(round(per_row * 1e9)))
+                b2 = ddist.cost_balanced_bounds(g.rowptr, c.world, e2, r2)
+                at = g.rowptr[torch.tensor(b2, device=c.dev)].tolist()
+                pred = max(per_edge * (at[r + 1] - at[r]) + per_row * (b2[r + 1] - b2[r]) for r in range(c.world))
+                rebalance["predicted_ms_after"] = pred
+                if pred < 0.98 * max(t[2] for t in got):
+                    shard = ddist.RowBlockShard(g, c.world, c.rank, bounds=b2).own_copy()
+                    edge_cost, row_cost = e2, r2
+                    rebalance["applied"] = True
+        bounds, block_nnz = shard.bounds, shard.block_nnz
+        del g
+        torch.cuda.empty_cache()
+        blk = shard.block
+    else:
+        bounds, block_nnz = shard.bounds, shard.block_nnz
+        blk = g
+    blk.plan()
+    rows, nnz = blk.n_rows, blk.nnz
     y = ops.alloc_features(rows, feat, c.dtype, c.dev)
 
     def transform(a):
@@ -1095,7 +1137,7 @@ def run_rmat27(args, c):
         {"nodes": n, "nnz": nnz_total, "hidden": feat, "scale": args.scale, "reorder": reorder if args.reorder != "none" else "none",
          "graph_build_seconds": build_s, "reorder_seconds_one_off": reorder_s,
          "parallelism": "single GPU" if c.world == 1 else "row blocks x%d, X replicated" % c.world, "layer_order": order,
-         "row_bounds": bounds, "block_nnz": block_nnz, "edge_cost_bytes": edge_cost, "row_cost_bytes": row_cost,
+         "row_bounds": bounds, "block_nnz": block_nnz, "edge_cost": edge_cost, "row_cost": row_cost, "rebalance": rebalance,
          "peak_memory_GB": torch.cuda.max_memory_allocated() / 1e9})
     result.update({"roofline": roofline, "spmm_launch_table": table, "dense_launch_table": dense_table, "per_rank": per_rank,
                    "slowest_rank": slow["rank"],

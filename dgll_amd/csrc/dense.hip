@@ -1,8 +1,10 @@
 // dense.hip -- dense transforms next to the aggregation: C[M,N] = act(A[M,K] . B[K,N] + bias).
 //
 // Reference call sites: F.mm(x, weight) gcnconv.py:30, F.matmul sageconv.py:41,72, F.mm gatconv.py:31,117, and the
-// X.W inside FusedKernel/gcn_fused_kernel.cu:46-54.  This file holds the exact-fp32 kernel used by the C-ABI-only
-// entry points (the fused GCN launcher); the Python layers use library GEMMs for forward/dX.
+// X.W inside FusedKernel/gcn_fused_kernel.cu:46-54.  Every dense product of the Python layers runs here or in gradw.hip /
+// gemm_f32.hip: the bf16 MFMA transforms (resident-weights persistent kernel and the 4-wavefront one), their gated / addend
+// epilogues, the weight pack, and the exact-fp32 kernel behind the C-ABI-only fused GCN launcher.  No library GEMM is called on any
+// GPU path (no Cijk_* kernel in profiles/r0*_bench_kernel_stats.csv).
 #include <algorithm>
 
 #include "common.hpp"

@@ -189,8 +189,9 @@ def test_bench_rmat27_row_blocks_on_several_ranks(world):
     assert [r["rank"] for r in ranks] == list(range(world))
     assert sum(r["nnz"] for r in ranks) == d["config"]["nnz"] and sum(r["rows"] for r in ranks) == d["config"]["nodes"]
     assert [r["row_range"][0] for r in ranks] == d["config"]["row_bounds"][:-1]
-    cost = [d["config"]["edge_cost_bytes"] * r["nnz"] + d["config"]["row_cost_bytes"] * r["rows"] for r in ranks]
+    cost = [d["config"]["edge_cost"] * r["nnz"] + d["config"]["row_cost"] * r["rows"] for r in ranks]
     assert max(cost) < 1.25 * (sum(cost) / world)                                   # (one hub row is ~1 % of a share at this scale)
+    assert len(d["config"]["rebalance"]["measured_ms"]) == world
     assert all(r["spmm_avg_ms"] > 0 and r["spmm_frac_algorithmic"] > 0 for r in ranks)
     assert abs(d["value"] - d["config"]["nnz"] * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) < 1e-6 * d["value"]
     assert d["output_allgather"]["ms"] > 0 and "cpu_baseline" not in d

@@ -242,9 +242,12 @@ def test_partitioned_training_steps_track_the_single_process_run(tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("world", [2, 8])
-def test_config5_row_blocks_on_the_gpu_are_bit_equal_to_the_single_pass(cuda_device, world):
+def test_config5_row_blocks_on_the_gpu_equal_the_single_pass(cuda_device, world):
     """dist.RowBlockShard through the real kernels: every rank's block (cost-balanced contiguous rows of a hubs-first RMAT, long
-    rows included) against the replicated X gives exactly the rows of the one-GPU pass -- bf16 and fp32, and the C oracle agrees."""
+    rows included) against the replicated X gives the rows of the one-GPU pass -- to fp32 / bf16 rounding, not bit for bit: a
+    block of short rows is handed to the row-per-slot kernel (spmm.hip: average row length decides), which adds a row's terms in
+    another order than the wave-per-row kernel the full graph gets.  (The gloo test on CPU, one summation order, is bit-equal.)
+    The C oracle agrees with both."""
     import numpy as np
 
     from dgll_amd import dist as ddist, ops, synth
@@ -264,7 +267,12 @@ def test_config5_row_blocks_on_the_gpu_are_bit_equal_to_the_single_pass(cuda_dev
             out = shard.aggregate(x, reduce="mean")
             assert out.shape[0] == shard.n_own
             parts.append(out)
-        assert torch.equal(torch.cat(parts), full)
+        got = torch.cat(parts)
+        assert got.shape == full.shape
+        if x.dtype == torch.float32:
+            assert torch.allclose(got, full, rtol=1e-5, atol=1e-6)
+        else:                                   # one bf16 rounding step of the fp32 sums
+            assert float((got.float() - full.float()).abs().max()) <= 2.0 ** -7 * float(full.float().abs().max())
     gc = g.to("cpu")
     ref = cref.spmm_csr(gc.rowptr.numpy(), gc.col.numpy(), None, x32.cpu().numpy(), reduce="mean")
     np.testing.assert_allclose(ops.spmm_raw(g, x32, reduce="mean").cpu().numpy(), ref, rtol=1e-4, atol=1e-4)
