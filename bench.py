@@ -761,6 +761,10 @@ def run_sage(args, c):
 
     if args.calibrate and c.world == 1:
         calibrate_launches(args, c, n)
+    halo_mode = None
+    if engine is not None:        # DGLL_HALO_MODE=auto: both forms of the first two layers timed on the live ranks, the faster kept
+        halo_mode = {"mode": engine.resolve_halo_mode(step), "requested": os.environ.get("DGLL_HALO_MODE", "recompute"),
+                     "timings_ms": engine.halo_mode_timings}
     elapsed, loss, timer, trace = timed_steps(args, c, step)
     if opt_wrap is not None:
         opt_wrap.flush()
@@ -806,6 +810,7 @@ def run_sage(args, c):
     if per_rank is not None:
         result["per_rank"] = per_rank
         result["config"]["exchange_form"] = engine.exchange.form
+        result["config"]["halo_mode"] = halo_mode
     if c.world == 1 and not args.no_extra and not args.dataset:
         del model, opt
         result["roofline_no_locality"] = extra_roofline(args, c, locality=0.0, permute=False, reorder=args.reorder,

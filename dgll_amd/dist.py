@@ -877,13 +877,50 @@ class DistGraph:
         self._spmm_fn = spmm_fn
         self.comm_stream = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
         self.wait_events = None          # set to [] to have join_comm() time the compute stream's stall behind every exchange
-        self.halo_recompute = True       # sage_forward: first layer recomputed on halo rows instead of exchanged (set False to compare)
+        # DGLL_HALO_MODE = recompute | exchange | auto (default recompute).  What happens to the WIDE rows of a remote neighbour in
+        # the first two layers: `recompute` evaluates the first layer on own + halo rows (its inputs are static) and exchanges
+        # nothing for layers 0 and 1 -- compute proportional to the halo rows; `exchange` sends / receives the hidden-width rows
+        # every step and direction.  Which one wins depends on the fabric (xGMI bandwidth RCCL reaches for grouped send/recv), which
+        # no model measures: `auto` = resolve_halo_mode() times both for a few warm-up steps on the live ranks and keeps the faster.
+        self.halo_mode = os.environ.get("DGLL_HALO_MODE", "recompute")
+        if self.halo_mode not in ("recompute", "exchange", "auto"):
+            raise ValueError("DGLL_HALO_MODE must be recompute, exchange or auto")
+        self.halo_recompute = self.halo_mode != "exchange"       # sage_forward / spgat_forward read this
+        self.halo_mode_timings = None
         if self.device.type == "cuda":   # build the schedules up front, not inside the first timed step
             for g in (part.local, part.halo):
                 g.plan()
                 self.transposed(g).plan()
             if part.send_reduce is not None:
                 part.send_reduce.plan()
+
+    def resolve_halo_mode(self, step, reps=3):
+        """DGLL_HALO_MODE=auto: run `step` (one whole training step of the caller; these are ordinary warm-up steps) `reps` times in
+        either mode after one untimed step each, take the MAX over ranks of the mean step time (the step is the slowest rank's),
+        keep the faster mode on every rank.  Returns the chosen mode; `halo_mode_timings` keeps both figures (ms)."""
+        if self.halo_mode != "auto":
+            return "recompute" if self.halo_recompute else "exchange"
+        timings = {}
+        for mode in ("recompute", "exchange"):
+            self.halo_recompute = mode == "recompute"
+            step()
+            if self.device.type == "cuda":
+                torch.cuda.synchronize(self.device)
+            if dist.is_initialized():
+                dist.barrier(self.exchange.group)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                step()
+            if self.device.type == "cuda":
+                torch.cuda.synchronize(self.device)
+            t = torch.tensor([(time.perf_counter() - t0) / reps * 1e3], dtype=torch.float64, device=self.device)
+            if dist.is_initialized():
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.exchange.group)
+            timings[mode] = float(t.item())
+        self.halo_mode_timings = timings
+        self.halo_recompute = timings["recompute"] <= timings["exchange"]
+        self.halo_mode = "recompute" if self.halo_recompute else "exchange"
+        return self.halo_mode
 
     def verify(self):
         """Before anything is timed: (1) cross-check the locally derived exchange lists across ranks (a mismatch would otherwise

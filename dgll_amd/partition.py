@@ -85,11 +85,83 @@ def relabel_by_parts(part_of_node, n_parts=None):
     return perm, bounds
 
 
-def partition_and_order(graph, n_parts, seed=0, sweeps=8, refine=True, imbalance=1.05, stats=None):
+# What one rank's step costs, per unit, on one MI355X (tools/scaling_model.py: every rank of N = 2, 4, 8 of the bench graph run
+# through its real kernels, least squares; profiles/r05_scaling_model.log): nanoseconds per own edge (the five SpMM-type passes),
+# per HALO ROW (first layer recomputed on it, the transposed pass into it, its share of the weight gradient, the narrow exchange's
+# gathers) and per own row (dense transforms, loss).  Equal-EDGE parts leave the rank with the hub communities 25-35 % more halo rows.
+STEP_COST_NS = {"edge": 0.125, "halo_row": 1.56, "row": 2.3}
+
+
+def part_costs(graph, part, n_parts):
+    """Per part: own edges, own rows, HALO rows (distinct remote source nodes its rows gather from), as int64 tensors [n_parts]."""
+    deg = graph.degrees()
+    dev = deg.device
+    edges = torch.zeros(n_parts, dtype=torch.int64, device=dev).index_add_(0, part, deg)
+    rows = torch.bincount(part, minlength=n_parts)
+    row_part = torch.repeat_interleave(part, deg)
+    col = graph.col.long()
+    cut = row_part != part[col]
+    keys = torch.unique(row_part[cut] * graph.n_cols + col[cut])
+    halo = torch.bincount(keys // graph.n_cols, minlength=n_parts)
+    return edges, rows, halo
+
+
+def rebalance_parts(graph, part, n_parts, cost=None, tol=0.02, max_iters=40, log=None):
+    """Move boundary nodes from the most expensive part to the cheapest one until every part's MODELLED step cost
+    (cost['edge'] . own edges + cost['halo_row'] . halo rows + cost['row'] . own rows) is within `tol` of the mean.  The nodes moved
+    from p to q are those of p with the most neighbours already in q relative to p (least damage to the cut), lightest first among
+    equals; a move's effect on the halo counts is not predictable node by node, so every iteration moves a damped share of the
+    difference and the costs are recounted.  Deterministic.  Returns the new node -> part vector."""
+    cost = dict(STEP_COST_NS if cost is None else cost)
+    part = part.clone()
+    if n_parts < 2 or graph.nnz == 0:
+        return part
+    deg = graph.degrees()
+    dev = deg.device
+    row = graph.row_index()
+    col = graph.col.long()
+    n = graph.n_rows
+    best, best_spread = part.clone(), None
+    for it in range(max_iters):
+        edges, rows, halo = part_costs(graph, part, n_parts)
+        c = cost["edge"] * edges.double() + cost["halo_row"] * halo.double() + cost["row"] * rows.double()
+        mean = float(c.mean())
+        spread = float(c.max()) / mean
+        if log is not None:
+            log.append({"iter": it, "max_over_mean": spread, "min_over_mean": float(c.min()) / mean, "halo_rows": halo.tolist(),
+                        "edges": edges.tolist(), "rows": rows.tolist()})
+        if best_spread is None or spread < best_spread:
+            best, best_spread = part.clone(), spread
+        if spread <= 1.0 + tol and float(c.min()) / mean >= 1.0 - tol:
+            break
+        p, q = int(torch.argmax(c)), int(torch.argmin(c))
+        transfer = 0.6 * min(float(c[p]) - mean, mean - float(c[q]))
+        if transfer <= 0:
+            transfer = 0.3 * (float(c[p]) - float(c[q]))
+        in_p = part == p
+        pc = part[col]
+        rp = in_p[row]
+        to_q = torch.zeros(n, dtype=torch.int64, device=dev).index_add_(0, row[rp], (pc[rp] == q).long())
+        to_p = torch.zeros(n, dtype=torch.int64, device=dev).index_add_(0, row[rp], (pc[rp] == p).long())
+        cand = torch.nonzero(in_p).flatten()
+        gain = (to_q - to_p)[cand]
+        move_cost = cost["edge"] * deg[cand].double() + cost["row"]
+        gmin = int(gain.min())
+        order = torch.argsort((gain - gmin) * (int(deg.max()) + 2) + (int(deg.max()) + 1 - deg[cand]), descending=True, stable=True)
+        cum = torch.cumsum(move_cost[order], 0)
+        k = int(torch.searchsorted(cum, torch.tensor(transfer, dtype=cum.dtype, device=dev)))
+        if k == 0:
+            break
+        part[cand[order[:k]]] = q
+    return best
+
+
+def partition_and_order(graph, n_parts, seed=0, sweeps=8, refine=True, imbalance=1.05, stats=None, balance_cost=True):
     """(perm, bounds) for the multi-GPU engine in one pass: parts from `community_parts`, boundary-refined by `refine_parts`
-    (refine=False: the packed communities as they come), and inside every part the locality order of dgll_amd/reorder.py
-    (communities contiguous, largest first; hubs first inside a community).  New node i is old node perm[i]; part p owns
-    [bounds[p], bounds[p+1]).  `stats`: a dict that receives cut / balance before and after the refinement."""
+    (refine=False: the packed communities as they come), then balanced on the modelled step cost (`rebalance_parts`: own edges +
+    halo rows + own rows, STEP_COST_NS; balance_cost=False keeps the equal-edge parts of round 4), and inside every part the
+    locality order of dgll_amd/reorder.py (communities contiguous, largest first; hubs first inside a community).  New node i is
+    old node perm[i]; part p owns [bounds[p], bounds[p+1]).  `stats`: a dict that receives cut / balance before and after."""
     part, dense = community_parts(graph, n_parts, seed=seed, sweeps=sweeps, return_communities=True)
     if stats is not None:
         stats["before"] = partition_quality(graph, part, n_parts)
@@ -97,6 +169,10 @@ def partition_and_order(graph, n_parts, seed=0, sweeps=8, refine=True, imbalance
         part = refine_parts(graph, part, n_parts, imbalance=imbalance, seed=seed, log=None if stats is None else stats.setdefault("passes", []))
         if stats is not None:
             stats["after"] = partition_quality(graph, part, n_parts)
+    if balance_cost and n_parts > 1:
+        part = rebalance_parts(graph, part, n_parts, log=None if stats is None else stats.setdefault("rebalance", []))
+        if stats is not None:
+            stats["balanced"] = partition_quality(graph, part, n_parts)
     n = graph.n_rows
     deg = graph.degrees()
     dmax = int(deg.max()) + 1 if n else 1

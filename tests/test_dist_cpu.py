@@ -377,6 +377,34 @@ def _sage_model_worker(rank, world, port):
             (out * gout[blk]).sum().backward()
             per_step[recompute] = len(calls)
         assert per_step == {True: 2, False: 4}, per_step
+        engine.exchange.start = start
+        # DGLL_HALO_MODE=auto: both forms timed on the live ranks (max over ranks), every rank keeps the same, faster one
+        os.environ["DGLL_HALO_MODE"] = "auto"
+        try:
+            eng2 = ddist.DistGraph(part, "cpu", spmm_fn=_cpu_spmm)
+        finally:
+            del os.environ["DGLL_HALO_MODE"]
+        assert eng2.halo_mode == "auto" and eng2.halo_mode_timings is None
+        placed2 = eng2.place_input_halo(x[blk].clone())
+
+        def one_step():
+            model.zero_grad()
+            o = eng2.sage_forward(model, x[blk].clone(), placed2)
+            (o * gout[blk]).sum().backward()
+
+        chosen = eng2.resolve_halo_mode(one_step, reps=2)
+        assert chosen in ("recompute", "exchange") and set(eng2.halo_mode_timings) == {"recompute", "exchange"}
+        assert eng2.halo_recompute == (chosen == "recompute") and eng2.halo_mode == chosen
+        votes = [None] * world
+        dist.all_gather_object(votes, (chosen, eng2.halo_mode_timings))
+        assert all(v == votes[0] for v in votes)                                     # one decision, the same numbers, on every rank
+        assert (eng2.halo_mode_timings["recompute"] <= eng2.halo_mode_timings["exchange"]) == (chosen == "recompute")
+        os.environ["DGLL_HALO_MODE"] = "sometimes"
+        try:
+            with pytest.raises(ValueError):
+                ddist.DistGraph(part, "cpu", spmm_fn=_cpu_spmm)
+        finally:
+            del os.environ["DGLL_HALO_MODE"]
     finally:
         dist.destroy_process_group()
 

@@ -112,3 +112,36 @@ def test_boundary_refinement_lowers_the_cut_under_the_balance_cap_and_is_determi
     g2 = synth.products_like_graph("cpu", seed=2, n=n, n_undirected=90000, locality=0.9, n_blocks=blocks, exact=True, permute_ids=True)
     perm, bounds = partition.partition_and_order(g2, world, seed=0, stats=st)
     assert st["after"]["cut"] <= st["before"]["cut"] and sorted(perm.tolist()) == list(range(n)) and bounds[-1] == n
+
+
+def test_cost_model_rebalancing_evens_out_the_modelled_step_cost_of_the_parts():
+    """equal-EDGE parts leave the rank that holds the hub communities with a third more halo rows, and the step
+    is the slowest rank's.  rebalance_parts moves boundary nodes until edge + halo-row + row cost (partition.STEP_COST_NS) is
+    within 2 % of the mean on every part; the result is a valid partition, deterministic, and its cut does not explode."""
+    from dgll_amd import partition as P, synth
+
+    g = synth.products_like_graph("cpu", seed=0, n=40000, n_undirected=900000, locality=0.9, exact=True, permute_ids=True)
+    for n_parts in (4, 8):
+        part = P.refine_parts(g, P.community_parts(g, n_parts, seed=0), n_parts, seed=0)
+        log = []
+        new = P.rebalance_parts(g, part, n_parts, log=log)
+        assert new.shape == part.shape and int(new.min()) >= 0 and int(new.max()) < n_parts
+        assert torch.equal(new, P.rebalance_parts(g, part, n_parts))
+
+        def spread(p):
+            e, r, h = P.part_costs(g, p, n_parts)
+            c = P.STEP_COST_NS["edge"] * e.double() + P.STEP_COST_NS["halo_row"] * h.double() + P.STEP_COST_NS["row"] * r.double()
+            return float(c.max() / c.mean()), float(c.min() / c.mean())
+
+        before, after = spread(part), spread(new)
+        assert after[0] <= 1.03 and after[1] >= 0.97 and after[0] <= before[0]
+        assert P.partition_quality(g, new, n_parts)["cut"] <= P.partition_quality(g, part, n_parts)["cut"] + 0.03
+        # halo rows counted by part_costs = distinct remote sources, checked the slow way for one part
+        e, r, h = P.part_costs(g, new, n_parts)
+        rows0 = torch.nonzero(new == 0).flatten()
+        cols = torch.cat([g.col[g.rowptr[v]:g.rowptr[v + 1]] for v in rows0[:3000].tolist()]).long()
+        assert int(e.sum()) == g.nnz and int(r.sum()) == g.n_rows
+        remote = torch.unique(cols[new[cols] != 0])
+        assert remote.numel() <= int(h[0])
+    perm, bounds = P.partition_and_order(g, 8, seed=0)
+    assert sorted(perm.tolist()) == list(range(g.n_rows)) and bounds[0] == 0 and bounds[-1] == g.n_rows

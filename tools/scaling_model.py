@@ -162,51 +162,87 @@ def main():
     single_ms = float(os.environ["SINGLE_MS"]) if "SINGLE_MS" in os.environ else single_gpu_step_ms()
     torch.cuda.empty_cache()
     print("single-GPU step (same model and graph, measured in this run): %.2f ms" % single_ms)
+    samples = []
+    balance = os.environ.get("MODEL_BALANCE", "cost")            # cost: partition.rebalance_parts (default); edges: round 4's equal-edge parts
+    halo_modes = os.environ.get("MODEL_HALO_MODES", "recompute").split(",")
+    summary = []
     for world in (2, 4, 8):
-        torch.manual_seed(0)
-        model = dnn.GraphSage(100, [256, 256, 47], None).to(dev)
-        params = list(model.parameters())
-        opt = FlatAdam(params, lr=1e-3)
-        racom = ddist.RaCoM(params, dev, flat=opt)       # as bench.py; no process group here: the all-reduce itself is skipped
-        perm, bounds = dpart.partition_and_order(raw, world, seed=0)        # as bench.py: communities packed into parts
+        stats = {}
+        perm, bounds = dpart.partition_and_order(raw, world, seed=0, stats=stats, balance_cost=(balance == "cost"))   # as bench.py
         full = dreorder.relabel(raw, perm)
-        part = ddist.partition_contiguous(full, world, RANK % world, bounds)
+        q = stats.get("balanced", stats["after"])
+        print("N=%d partition (%s-balanced): cut %.2f %% (after refinement %.2f %%), edges max/mean %.3f%s" % (
+            world, balance, 100 * q["cut"], 100 * stats["after"]["cut"], q["balance"],
+            (", %d rebalancing passes: modelled cost max/mean %.3f -> %.3f" % (
+                len(stats["rebalance"]), stats["rebalance"][0]["max_over_mean"], stats["rebalance"][-1]["max_over_mean"])) if "rebalance" in stats else ""))
+        ranks = list(range(world)) if "MODEL_RANK" not in os.environ else [RANK % world]
+        feats_p, labels_p = feats[perm], labels_all[perm]
+        for mode in halo_modes:
+            per_rank = []
+            for rank in ranks:
+                torch.manual_seed(0)
+                model = dnn.GraphSage(100, [256, 256, 47], None).to(dev)
+                params = list(model.parameters())
+                opt = FlatAdam(params, lr=1e-3)
+                racom = ddist.RaCoM(params, dev, flat=opt)       # as bench.py; no process group here: the all-reduce itself is skipped
+                part = ddist.partition_contiguous(full, world, rank, bounds)
+                engine = ddist.DistGraph(part, dev)
+                engine.halo_recompute = mode == "recompute"
+                engine.exchange = NullExchange(part)
+                x = ops.alloc_features(part.n_own, 100, torch.bfloat16, dev, pad_to=64)
+                x.copy_(feats_p[part.own_begin:part.own_end])
+                labels = labels_p[part.own_begin:part.own_end]
+                placed = engine.place_input_halo(x)
+
+                def step():
+                    opt.zero_grad(set_to_none=True)
+                    out = engine.sage_forward(model, x, placed)
+                    loss = ops.cross_entropy(out, labels, reduction="sum", fold_relu=True) * (world / n)
+                    loss.backward()
+                    racom.all_reduce_and_wait()
+                    opt.step()
+
+                for _ in range(3):
+                    step()
+                torch.cuda.synchronize()
+                engine.exchange.sent = engine.exchange.received = 0
+                t0 = time.perf_counter()
+                reps = 10
+                for _ in range(reps):
+                    step()
+                torch.cuda.synchronize()
+                ms = (time.perf_counter() - t0) / reps * 1e3
+                rx, tx = engine.exchange.received / reps, engine.exchange.sent / reps
+                per_rank.append((rank, ms, rx, tx, part.n_own, part.local.nnz + part.halo.nnz, part.n_halo))
+                if mode == "recompute":
+                    samples.append((part.local.nnz + part.halo.nnz, part.n_halo, part.n_own, ms))
+                print("   N=%d [%s] rank %d: %7d rows, %9d + %8d (halo) edges, %7d halo rows | compute %.2f ms/step | receives %.0f MB, sends %.0f MB per step" % (
+                    world, mode, rank, part.n_own, part.local.nnz, part.halo.nnz, part.n_halo, ms, rx / 1e6, tx / 1e6))
+                del engine, part, model, opt, racom, placed, x
+                torch.cuda.empty_cache()
+            slow = max(per_rank, key=lambda t: t[1])
+            mean = sum(t[1] for t in per_rank) / len(per_rank)
+            rx, tx = max(t[2] for t in per_rank), max(t[3] for t in per_rank)
+            print("N=%d [%s]: slowest rank %d %.2f ms, mean %.2f ms, spread %+.1f %% / %+.1f %% of the mean" % (
+                world, mode, slow[0], slow[1], mean, 100 * (slow[1] / mean - 1), 100 * (min(t[1] for t in per_rank) / mean - 1)))
+            for bw in (150e9, 300e9, 450e9):
+                wire = max(rx, tx) / bw * 1e3
+                print("      at %3.0f GB/s per direction: wire %.2f ms -> step %.2f (hidden) .. %.2f ms (exposed): speed-up %.2fx .. %.2fx" % (
+                    bw / 1e9, wire, max(slow[1], wire), slow[1] + wire, single_ms / max(slow[1], wire), single_ms / (slow[1] + wire)))
+            summary.append((world, mode, slow[1], mean, single_ms / slow[1]))
         del full
-        engine = ddist.DistGraph(part, dev)
-        engine.exchange = NullExchange(part)
-        x = ops.alloc_features(part.n_own, 100, torch.bfloat16, dev, pad_to=64)
-        x.copy_(feats[part.own_begin:part.own_end])
-        labels = labels_all[part.own_begin:part.own_end]
-        placed = engine.place_input_halo(x)
-
-        def step():
-            opt.zero_grad(set_to_none=True)
-            out = engine.sage_forward(model, x, placed)
-            loss = ops.cross_entropy(out, labels, reduction="sum", fold_relu=True) * (world / n)
-            loss.backward()
-            racom.all_reduce_and_wait()
-            opt.step()
-
-        for _ in range(3):
-            step()
-        torch.cuda.synchronize()
-        engine.exchange.sent = engine.exchange.received = 0
-        t0 = time.perf_counter()
-        reps = 10
-        for _ in range(reps):
-            step()
-        torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / reps * 1e3
-        rx, tx = engine.exchange.received / reps, engine.exchange.sent / reps
-        line = "N=%d rank %d: %d rows, %d + %d (halo) edges, %d halo rows | compute %.2f ms/step | receives %.0f MB, sends %.0f MB per step" % (
-            world, RANK % world, part.n_own, part.local.nnz, part.halo.nnz, part.n_halo, ms, rx / 1e6, tx / 1e6)
-        print(line)
-        for bw in (150e9, 300e9, 450e9):
-            wire = max(rx, tx) / bw * 1e3
-            print("      at %3.0f GB/s per direction: wire %.2f ms -> step %.2f (hidden) .. %.2f ms (exposed): speed-up %.1fx .. %.1fx" % (
-                bw / 1e9, wire, max(ms, wire), ms + wire, single_ms / max(ms, wire), single_ms / (ms + wire)))
-        del engine, part, model, opt
         torch.cuda.empty_cache()
+    if len(samples) >= 4:
+        a_ = torch.tensor([[s_[0], s_[1], s_[2], 1.0] for s_ in samples], dtype=torch.float64)
+        b_ = torch.tensor([[s_[3]] for s_ in samples], dtype=torch.float64)
+        sol = torch.linalg.lstsq(a_, b_).solution.flatten()
+        resid = (a_ @ sol.unsqueeze(1) - b_).abs().max()
+        print("cost fit over %d ranks (recompute mode): %.4f ns per own edge, %.3f ns per halo row, %.3f ns per own row, %.3f ms constant; "
+              "largest residual %.3f ms   [partition.STEP_COST_NS = %s]" % (
+                  len(samples), sol[0] * 1e6, sol[1] * 1e6, sol[2] * 1e6, sol[3], resid, dpart.STEP_COST_NS))
+    print("summary (single-GPU step %.2f ms):" % single_ms)
+    for world, mode, slow, mean, sp in summary:
+        print("   N=%d %-9s slowest rank %.2f ms (mean %.2f): %.2fx with the exchange hidden" % (world, mode, slow, mean, sp))
 
 
 if __name__ == "__main__":
