@@ -89,7 +89,10 @@ def relabel_by_parts(part_of_node, n_parts=None):
 # through its real kernels, least squares; profiles/r05_scaling_model.log): nanoseconds per own edge (the five SpMM-type passes),
 # per HALO ROW (first layer recomputed on it, the transposed pass into it, its share of the weight gradient, the narrow exchange's
 # gathers) and per own row (dense transforms, loss).  Equal-EDGE parts leave the rank with the hub communities 25-35 % more halo rows.
-STEP_COST_NS = {"edge": 0.125, "halo_row": 1.56, "row": 2.3}
+# Fit of round 5 over the 14 ranks of N = 2, 4, 8 (two runs: 0.096-0.110 / 1.00-1.03 / 3.5-4.3 ns, constant 0.67 ms per step, largest
+# residual 0.08-0.28 ms).  A first guess from round 4's floor analysis (0.125 / 1.56 / 2.3) over-charged the halo rows and moved
+# too much off the hub rank (3.56 ms against 4.06-4.16 on the others).
+STEP_COST_NS = {"edge": 0.103, "halo_row": 1.0, "row": 3.9}
 
 
 def part_costs(graph, part, n_parts):
