@@ -44,6 +44,21 @@ __global__ void find_long_rows_kernel(const int64_t* __restrict__ rowptr, int64_
     }
 }
 
+// flattened schedule: first row of wave w's share = the first row whose first edge is at or after w * edges_per_wave
+__global__ void flat_row0_kernel(const int64_t* __restrict__ rowptr, int64_t n_rows, int64_t edges_per_wave, int64_t n_flat,
+                                 int64_t* __restrict__ row0) {
+    for (int64_t w = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; w <= n_flat; w += (int64_t)gridDim.x * blockDim.x) {
+        if (w == n_flat) { row0[w] = n_rows; continue; }
+        const int64_t target = w * edges_per_wave;
+        int64_t lo = 0, hi = n_rows;               // lower bound over rowptr[0 .. n_rows)
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (rowptr[mid] < target) lo = mid + 1; else hi = mid;
+        }
+        row0[w] = lo;
+    }
+}
+
 struct SpmmArgs {
     const int64_t* rowptr;
     const int32_t* col;
@@ -67,6 +82,8 @@ struct SpmmArgs {
     int accumulate;           // 1: Y = epi(scale * (A.X + Y));  2: Y += gate(scale * A.X), rows without edges untouched
     const void* gate;         // optional [n_rows, ldg] of Y's type: outputs are zeroed where gate <= 0 (fused ReLU backward)
     int64_t ldg;
+    const int64_t* flat_row0; // flattened kernel: first row of every wave's share (plan->d_flat_row0), n_flat + 1 entries
+    int64_t n_flat;
 };
 
 template <typename T> __device__ __forceinline__ float load_one(const T* p);
@@ -266,6 +283,198 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_kernel(const SpmmArgs a) {
     }
 }
 
+// ---- flattened variant: a wavefront walks the EDGE STREAM of its rows, not one row after the other ---------------------------
+// The wave-per-row kernel drains its gather pipeline at every row end (reduce, epilogue, next row pointers, next index batch):
+// rows of 64+ edges run at 0.032-0.036 ns per edge, rows of 16-64 edges at 0.054-0.059, rows under 16 at 0.06-0.09
+// (tools/rowlen_probe.py, products-sized bench graph, F = 256 bf16) -- and a fifth of the edges sit in rows under 64.  The same
+// edge stream cut into rows of exactly 128 edges takes 3.61 ms where the real rows take 4.37.
+// Here wave w owns the rows whose first edge falls into [w E, (w + 1) E) of the column array (plan->d_flat_row0, E = 512): whole rows,
+// edge-balanced.  It reads the column ids of its share in coalesced batches of 64 regardless of row boundaries and keeps U gathers
+// per lane in flight across them; a group of SLOTS x U edges that lies inside the current row is accumulated as in the kernel
+// above; a group that contains row ends is consumed step by step: the slots' values are added up to the row end, the row is reduced
+// across the slots and written (same epilogue code), the accumulators restart, the rest of the step goes to the next row.  All
+// of that control flow is wave-uniform (row bounds live in scalar registers).  Rows above the plan's threshold are skipped (their
+// chunk items run in the same launch); rows without edges get their epilogue of an empty sum.  The order in which a row's terms
+// are added is the kernel's own (fixed: bit-reproducible run to run); it differs from the wave-per-row kernel's in the last bits.
+template <typename XT, typename YT, int EPV, int LPR, bool HAS_VAL, int U, bool EXTRA>
+__global__ __launch_bounds__(kBlock) void spmm_csr_flat_kernel(const SpmmArgs a) {
+    typedef VecIO<XT, EPV> IO;
+    constexpr int SLOTS = kWave / LPR, G = SLOTS * U;
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int sub = lane % LPR, slot = lane / LPR;
+    const int c0 = ((int)blockIdx.y * LPR + sub) * EPV;
+    const bool col_ok = c0 < a.feat;
+    const XT* xcol = static_cast<const XT*>(a.X) + (col_ok ? c0 : 0);
+    uint32_t bid = blockIdx.x;
+
+    if (bid < a.chunk_blocks) {  // ---- a chunk of a long row: identical to spmm_csr_kernel's chunk items
+        const int64_t chunk = __builtin_amdgcn_readfirstlane((int)(bid * kWavesPerBlock + wave));
+        if (chunk >= a.n_chunks) return;
+        float acc[EPV];
+#pragma unroll
+        for (int i = 0; i < EPV; ++i) acc[i] = 0.0f;
+        gather_edges<XT, EPV, LPR, HAS_VAL, U>(a.col, a.val, xcol, a.ldx, uniform64(a.chunk_begin[chunk]),
+                                               uniform64(a.chunk_end[chunk]), lane, acc);
+        if (lane < LPR && col_ok) {
+            float* w = a.ws + chunk * a.ws_ld + c0;
+#pragma unroll
+            for (int i = 0; i < EPV; ++i) w[i] = acc[i];
+        }
+        return;
+    }
+    bid -= a.chunk_blocks;
+    const int64_t w = (int64_t)bid * kWavesPerBlock + wave;
+    if (w >= a.n_flat) return;
+    int64_t r = uniform64(a.flat_row0[w]);
+    const int64_t r_end = uniform64(a.flat_row0[w + 1]);
+    if (r >= r_end) return;
+    int64_t rb = uniform64(a.rowptr[r]), re = uniform64(a.rowptr[r + 1]);       // the current row's edges [rb, re)
+    const int64_t p_end = uniform64(a.rowptr[r_end]);
+    int64_t p = rb;                       // next edge to consume; invariant: acc = sum over the current row's edges [rb, p)
+    const bool writer = lane < LPR && col_ok;
+    const bool full = c0 + EPV <= a.feat;
+    const uint32_t ld32 = (uint32_t)a.ldx;
+    const int thr = a.threshold;
+    float acc[EPV];
+#pragma unroll
+    for (int i = 0; i < EPV; ++i) acc[i] = 0.0f;
+    bool stop = false;                    // the current row must not be gathered here (long row) or the share is done
+
+    // the current row is complete in acc (per slot): reduce across the slots, epilogue, store; move on to the next row
+    auto flush = [&]() {
+#pragma unroll
+        for (int off = LPR; off < kWave; off <<= 1) {
+#pragma unroll
+            for (int i = 0; i < EPV; ++i) acc[i] += __shfl_xor(acc[i], off);
+        }
+        bool emit = writer;
+        if constexpr (EXTRA) {
+            if (a.accumulate == 2 && re == rb) emit = false;       // increment form: nothing to add to a row without edges
+        }
+        if (emit) {
+            YT* yrow = static_cast<YT*>(a.Y) + r * a.ldy;
+            RowVec<YT, EPV> prev, gatev;
+            const YT* grow = nullptr;
+            if constexpr (EXTRA) {
+                grow = a.gate ? static_cast<const YT*>(a.gate) + r * a.ldg : nullptr;
+                if (full) {
+                    if (a.accumulate) prev.load(yrow + c0);
+                    if (grow) gatev.load(grow + c0);
+                }
+            }
+            const float scale = a.row_scale ? a.row_scale[r]
+                                            : ((a.reduce == DGLL_REDUCE_MEAN && re > rb) ? 1.0f / (float)(re - rb) : 1.0f);
+            finish_row<YT, EPV, EXTRA>(yrow, c0, a.feat, scale, a.epilogue, a.bias, acc, a.accumulate, grow, full, prev, gatev);
+        }
+#pragma unroll
+        for (int i = 0; i < EPV; ++i) acc[i] = 0.0f;
+        ++r;
+        rb = re;
+        if (r < r_end) {
+            re = uniform64(a.rowptr[r + 1]);
+            stop = thr > 0 && re - rb > thr;
+        } else {
+            stop = true;
+        }
+    };
+
+    stop = thr > 0 && re - rb > thr;
+    while (r < r_end) {
+        if (stop) {                       // a long row: its chunk items do the work; nothing of it was consumed here
+            if (r >= r_end) break;
+            p = re;
+            ++r;
+            rb = re;
+            stop = false;
+            if (r < r_end) {
+                re = uniform64(a.rowptr[r + 1]);
+                stop = thr > 0 && re - rb > thr;
+            }
+            continue;
+        }
+        if (p >= p_end || re == rb) {     // rows without edges (also the trailing ones of the share)
+            flush();
+            continue;
+        }
+        const int64_t left = p_end - p;
+        const int nb = left < kWave ? (int)left : kWave;
+        int my_col = 0;
+        float my_val = 0.0f;
+        if (lane < nb) {
+            my_col = __builtin_nontemporal_load(a.col + p + lane);
+            if (HAS_VAL) my_val = __builtin_nontemporal_load(a.val + p + lane);
+        }
+        int j = 0;
+        while (j < nb && !stop) {
+            const int64_t q0 = p + j;
+            if (j + G <= nb && q0 + G <= re) {        // the whole group belongs to the current row
+                int c[U];
+                float wv[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int src = j + u * SLOTS + slot;
+                    c[u] = __shfl(my_col, src);
+                    wv[u] = HAS_VAL ? __shfl(my_val, src) : 1.0f;
+                }
+                typename IO::raw_t v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) v[u] = IO::load(xcol + (uint64_t)(uint32_t)c[u] * ld32);
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    float f[EPV];
+                    IO::unpack(v[u], f);
+#pragma unroll
+                    for (int i = 0; i < EPV; ++i) acc[i] = HAS_VAL ? fmaf(wv[u], f[i], acc[i]) : acc[i] + f[i];
+                }
+                j += G;
+                if (q0 + G == re) flush();
+                continue;
+            }
+            // a group with row ends (or the batch's ragged end) inside: all U gathers are issued back to back, then consumed step by step
+            int c[U];
+            float wv[U];
+            bool ok[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = j + u * SLOTS + slot;
+                ok[u] = idx < nb;
+                const int src = ok[u] ? idx : nb - 1;
+                c[u] = __shfl(my_col, src);
+                wv[u] = HAS_VAL ? __shfl(my_val, src) : 1.0f;
+            }
+            typename IO::raw_t v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = IO::load(xcol + (uint64_t)(uint32_t)c[u] * ld32);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t qa = q0 + u * SLOTS;                 // first edge of this step (uniform); the slots hold qa + slot
+                if (stop || qa >= p + nb) continue;
+                float f[EPV];
+                IO::unpack(v[u], f);
+                const int64_t pos = qa + slot;
+                int64_t lo = qa;
+                while (true) {
+                    const int64_t hi = re < qa + SLOTS ? re : qa + SLOTS;
+                    const bool take = ok[u] && pos >= lo && pos < hi;
+#pragma unroll
+                    for (int i = 0; i < EPV; ++i) {
+                        const float t = take ? f[i] : 0.0f;
+                        acc[i] = HAS_VAL ? fmaf(wv[u], t, acc[i]) : acc[i] + t;
+                    }
+                    if (re > qa + SLOTS || re > p + nb) break;     // the row goes on beyond this step (or beyond the batch)
+                    flush();                                       // the row ended inside this step
+                    lo = hi;
+                    if (stop || lo >= qa + SLOTS) break;
+                }
+            }
+            j += G;
+        }
+        // what the batch consumed: everything, unless a long row (or the end of the share) stopped it -- then the current row starts at rb
+        p = stop ? rb : p + nb;
+    }
+}
+
 // ---- short-row / narrow-row variant: one output row per SLOT, 64 / LPR rows per wavefront at a time ---------------------
 // The wave-per-row kernel above pays a fixed price per row -- row pointers, one index batch, a cross-slot shuffle tree
 // (log2(SLOTS) x EPV shuffles), the epilogue -- and runs those prices one row after the other.  That is noise for a 256-wide
@@ -424,6 +633,8 @@ static int g_tune_rows_per_wave = 0; // 0 = automatic
 static int g_tune_flags = 0;         // bit 0: XCD-contiguous row mapping (off: measured slower when degree correlates with row id)
 static int g_tune_threshold = 0;     // 0 = plan default (256)
 static int g_tune_rowslot = 0;       // 0 = automatic choice of the row-per-slot kernel, 1 = never, 2 = whenever it applies
+static int g_tune_flat = 0;          // flattened kernel (spmm_csr_flat_kernel): 0 = automatic, 1 = never, 2 = whenever the plan has its schedule
+static int g_tune_flat_edges = 512;  // edges per wave of the flattened schedule (read when a plan is created)
 
 template <typename XT, typename YT, int EPV, int LPR, int U>
 static hipError_t launch_u(const SpmmArgs& a, dim3 grid, hipStream_t s) {
@@ -480,6 +691,25 @@ static hipError_t launch_rowslot_lpr(const SpmmArgs& a, int lpr, dim3 grid, hipS
         case 16: return launch_rowslot<XT, YT, EPV, 16>(a, grid, s);
         default: return launch_rowslot<XT, YT, EPV, 32>(a, grid, s);
     }
+}
+
+template <typename XT, typename YT, int EPV, int LPR>
+static hipError_t launch_flat(const SpmmArgs& a, dim3 grid, hipStream_t s) {
+    const bool extra = a.accumulate || a.gate;
+    if (a.val) {
+        if (extra) hipLaunchKernelGGL((spmm_csr_flat_kernel<XT, YT, EPV, LPR, true, 4, true>), grid, dim3(kBlock), 0, s, a);
+        else hipLaunchKernelGGL((spmm_csr_flat_kernel<XT, YT, EPV, LPR, true, 4, false>), grid, dim3(kBlock), 0, s, a);
+    } else {
+        if (extra) hipLaunchKernelGGL((spmm_csr_flat_kernel<XT, YT, EPV, LPR, false, 4, true>), grid, dim3(kBlock), 0, s, a);
+        else hipLaunchKernelGGL((spmm_csr_flat_kernel<XT, YT, EPV, LPR, false, 4, false>), grid, dim3(kBlock), 0, s, a);
+    }
+    return hipGetLastError();
+}
+
+template <typename XT, typename YT, int EPV>
+static hipError_t launch_flat_lpr(const SpmmArgs& a, int lpr, dim3 grid, hipStream_t s) {
+    if (lpr == 16) return launch_flat<XT, YT, EPV, 16>(a, grid, s);
+    return launch_flat<XT, YT, EPV, 32>(a, grid, s);
 }
 
 template <typename XT, typename YT, int EPV>
@@ -576,6 +806,17 @@ DGLL_API int dgll_hip_csr_plan_create(void* stream, const int64_t* rowptr, int64
         PLAN_TRY(hipMemcpyAsync(p->d_chunk_end, chunk_end.data(), sizeof(int64_t) * chunk_end.size(), hipMemcpyHostToDevice, s));
         PLAN_TRY(hipStreamSynchronize(s));
     }
+    // the flattened kernel's wave schedule (one binary search per wave, once per graph)
+    if (nnz > 0 && n_rows > 0 && g_tune_flat_edges > 0) {
+        p->flat_edges = g_tune_flat_edges;
+        p->n_flat = (nnz + p->flat_edges - 1) / p->flat_edges;
+        PLAN_TRY(hipMalloc(&p->d_flat_row0, sizeof(int64_t) * (size_t)(p->n_flat + 1)));
+        const int blocks = (int)std::min<int64_t>((p->n_flat + 1 + kBlock - 1) / kBlock, 4096);
+        hipLaunchKernelGGL(flat_row0_kernel, dim3(blocks), dim3(kBlock), 0, s, rowptr, n_rows, (int64_t)p->flat_edges, p->n_flat,
+                           p->d_flat_row0);
+        PLAN_TRY(hipGetLastError());
+        PLAN_TRY(hipStreamSynchronize(s));
+    }
 #undef PLAN_TRY
     cleanup();
     *out_plan = p;
@@ -595,6 +836,8 @@ DGLL_API int dgll_hip_debug_tune(int key, int value) {
         case 3: g_tune_threshold = value; break;
         case 4: g_tune_mfma_kperm = value; break;
         case 5: g_tune_rowslot = value; break;
+        case 13: g_tune_flat = value; break;
+        case 14: g_tune_flat_edges = value; break;
         case 7: break;                              // (retired: unroll depth of the first-generation GAT backward passes)
         case 9: g_tune_gat_gen = value; break;
         case 11: g_tune_res_per_cu = value; break;
@@ -611,6 +854,7 @@ DGLL_API void dgll_hip_csr_plan_destroy(dgll_csr_plan* p) {
     if (p->d_chunk_begin) (void)hipFree(p->d_chunk_begin);
     if (p->d_chunk_end) (void)hipFree(p->d_chunk_end);
     if (p->d_chunk_row) (void)hipFree(p->d_chunk_row);
+    if (p->d_flat_row0) (void)hipFree(p->d_flat_row0);
     delete p;
 }
 
@@ -755,6 +999,21 @@ int dgll_spmm_csr_impl(void* stream, const dgll_csr_plan* plan, const int64_t* r
         if (x_dtype == DGLL_F32) err = launch_rowslot_lpr<float, float, 4>(a, lpr, grid, s);
         else if (y_dtype == DGLL_BF16) err = launch_rowslot_lpr<bf16_t, bf16_t, 8>(a, lpr, grid, s);
         else err = launch_rowslot_lpr<bf16_t, float, 8>(a, lpr, grid, s);
+    } else if (fast && !only_long && plan && plan->d_flat_row0 && g_tune_flat != 1 && g_tune_unroll == 4 && !(a.flags & 1) &&
+               [&]() { const int v = (feat + epv - 1) / epv; return v > 8 && v <= 32; }() &&
+               (g_tune_flat == 2 || (double)plan->nnz / (double)std::max<int64_t>(n_rows, 1) >= 8.0)) {
+        // wide rows (16 or 32 lanes per row), not very short on average: the flattened edge-stream kernel
+        const int vecs = (feat + epv - 1) / epv;
+        const int lpr = vecs <= 16 ? 16 : 32;
+        a.flat_row0 = plan->d_flat_row0;
+        a.n_flat = plan->n_flat;
+        const int64_t flat_blocks = (plan->n_flat + kWavesPerBlock - 1) / kWavesPerBlock;
+        DGLL_REQUIRE(flat_blocks + chunk_blocks < (int64_t)0x7fffffff, "grid too large");
+        a.row_blocks = (uint32_t)flat_blocks;
+        dim3 grid((uint32_t)(flat_blocks + chunk_blocks), (uint32_t)((vecs + lpr - 1) / lpr));
+        if (x_dtype == DGLL_F32) err = launch_flat_lpr<float, float, 4>(a, lpr, grid, s);
+        else if (y_dtype == DGLL_BF16) err = launch_flat_lpr<bf16_t, bf16_t, 8>(a, lpr, grid, s);
+        else err = launch_flat_lpr<bf16_t, float, 8>(a, lpr, grid, s);
     } else if (fast) {
         const int vecs = (feat + epv - 1) / epv;
         int lpr = 4;

@@ -31,6 +31,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows-per-group", default="64")
     ap.add_argument("--locality", type=float, default=0.9)
+    ap.add_argument("--edges-per-group", default="", help="comma list: groups of a fixed number of EDGES instead of rows (perfect balance)")
     args = ap.parse_args()
     lib = build()
     dev = torch.device("cuda:0")
@@ -85,6 +86,21 @@ def main():
                 run(sorted_col, ptr, n_groups, rpg, remap, u, "group's edges by ascending source")
         # (3) the same with duplicates of a source inside a group gathered once (what an LDS-accumulating kernel could NOT do:
         #     every edge has its own destination row; listed only as the bound of 'one fetch per distinct source per group')
+        del sorted_col
+        torch.cuda.empty_cache()
+    # groups of equal EDGE counts (cut anywhere, also inside a row: the long-row chunking of the shipped kernel taken to its limit):
+    # the row-group form above is dominated by the hub groups' tails, this one isolates what the source order does to the gather
+    for epg in [int(v) for v in args.edges_per_group.split(",") if v]:
+        n_groups = (nnz + epg - 1) // epg
+        ptr = torch.arange(0, n_groups + 1, device=dev, dtype=torch.int64).mul_(epg).clamp_(max=nnz)
+        rpg = max(1, epg // 50)
+        for remap in (0, 1):
+            run(g.col, ptr, n_groups, rpg, remap, 4, "E=%d per group, CSR order" % epg)
+        key = (torch.arange(nnz, device=dev) // epg) * n + g.col.long()
+        sorted_col = g.col[torch.argsort(key)].contiguous()
+        del key
+        for remap in (0, 1):
+            run(sorted_col, ptr, n_groups, rpg, remap, 4, "E=%d per group, ascending source" % epg)
         del sorted_col
         torch.cuda.empty_cache()
 
