@@ -16,8 +16,8 @@ struct dgll_csr_plan {
     int64_t* d_chunk_begin = nullptr; // [n_chunks]    first edge of the chunk
     int64_t* d_chunk_end = nullptr;   // [n_chunks]    one past its last edge
     int64_t* d_chunk_row = nullptr;   // [n_chunks]    row the chunk belongs to
-    // edge-balanced wave schedule of the flattened kernel (spmm_csr_flat_kernel): wave w owns the rows whose FIRST edge lies in
-    // [w * flat_edges, (w + 1) * flat_edges) = rows [d_flat_row0[w], d_flat_row0[w + 1]); nullptr: no such schedule (host-only plan)
+    // cost-balanced wave schedule of the flattened kernel (spmm_csr_flat_kernel): wave w owns rows [d_flat_row0[w], d_flat_row0[w + 1]),
+    // about flat_edges edges (a row is charged like 4 edges); nullptr: no such schedule (host-only plan)
     int flat_edges = 0;
     int64_t n_flat = 0;
     int64_t* d_flat_row0 = nullptr;   // [n_flat + 1]

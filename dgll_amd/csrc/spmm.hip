@@ -44,16 +44,19 @@ __global__ void find_long_rows_kernel(const int64_t* __restrict__ rowptr, int64_
     }
 }
 
-// flattened schedule: first row of wave w's share = the first row whose first edge is at or after w * edges_per_wave
-__global__ void flat_row0_kernel(const int64_t* __restrict__ rowptr, int64_t n_rows, int64_t edges_per_wave, int64_t n_flat,
+// flattened schedule: wave w owns the rows whose KEY rowptr[row] + kFlatRowCost * row lies in [w C, (w + 1) C): balanced on edges
+// plus a per-row charge (a row end costs a cross-slot reduction, an epilogue and a store whatever its length -- and a graph's
+// rows WITHOUT edges, which a locality order puts side by side by the hundred thousand, would otherwise all fall to one wave).
+constexpr int64_t kFlatRowCost = 4;
+__global__ void flat_row0_kernel(const int64_t* __restrict__ rowptr, int64_t n_rows, int64_t cost_per_wave, int64_t n_flat,
                                  int64_t* __restrict__ row0) {
     for (int64_t w = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; w <= n_flat; w += (int64_t)gridDim.x * blockDim.x) {
         if (w == n_flat) { row0[w] = n_rows; continue; }
-        const int64_t target = w * edges_per_wave;
-        int64_t lo = 0, hi = n_rows;               // lower bound over rowptr[0 .. n_rows)
+        const int64_t target = w * cost_per_wave;
+        int64_t lo = 0, hi = n_rows;               // lower bound of the (strictly increasing) key over rows [0, n_rows)
         while (lo < hi) {
             const int64_t mid = (lo + hi) >> 1;
-            if (rowptr[mid] < target) lo = mid + 1; else hi = mid;
+            if (rowptr[mid] + kFlatRowCost * mid < target) lo = mid + 1; else hi = mid;
         }
         row0[w] = lo;
     }
@@ -288,14 +291,14 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_kernel(const SpmmArgs a) {
 // rows of 64+ edges run at 0.032-0.036 ns per edge, rows of 16-64 edges at 0.054-0.059, rows under 16 at 0.06-0.09
 // (tools/rowlen_probe.py, products-sized bench graph, F = 256 bf16) -- and a fifth of the edges sit in rows under 64.  The same
 // edge stream cut into rows of exactly 128 edges takes 3.61 ms where the real rows take 4.37.
-// Here wave w owns the rows whose first edge falls into [w E, (w + 1) E) of the column array (plan->d_flat_row0, E = 512): whole rows,
-// edge-balanced.  It reads the column ids of its share in coalesced batches of 64 regardless of row boundaries and keeps U gathers
-// per lane in flight across them; a group of SLOTS x U edges that lies inside the current row is accumulated as in the kernel
-// above; a group that contains row ends is consumed step by step: the slots' values are added up to the row end, the row is reduced
-// across the slots and written (same epilogue code), the accumulators restart, the rest of the step goes to the next row.  All
-// of that control flow is wave-uniform (row bounds live in scalar registers).  Rows above the plan's threshold are skipped (their
-// chunk items run in the same launch); rows without edges get their epilogue of an empty sum.  The order in which a row's terms
-// are added is the kernel's own (fixed: bit-reproducible run to run); it differs from the wave-per-row kernel's in the last bits.
+// Here wave w owns a run of whole rows of about E edges (plan->d_flat_row0: balanced on edges + 4 per row).  It reads the column
+// ids of its share in coalesced batches of 64 REGARDLESS of row boundaries (the next batch requested while the current one is
+// consumed), so a row end costs no row-pointer -> index-batch -> gather chain: the row bounds live in scalar registers and a
+// group of up to SLOTS x U gathers is cut at the current row's end; after the group that completes a row the slots are reduced,
+// the epilogue runs (same code as above) and the accumulators restart.  All of that control flow is wave-uniform.  Rows above the
+// plan's threshold are skipped (their chunk items run in the same launch); rows without edges get the epilogue of an empty sum.
+// The order in which a row's terms are added is fixed (bit-reproducible run to run) and equals the wave-per-row kernel's for rows
+// that lie inside one index batch; other rows differ from it in the last bits.
 template <typename XT, typename YT, int EPV, int LPR, bool HAS_VAL, int U, bool EXTRA>
 __global__ __launch_bounds__(kBlock) void spmm_csr_flat_kernel(const SpmmArgs a) {
     typedef VecIO<XT, EPV> IO;
@@ -380,9 +383,12 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_flat_kernel(const SpmmArgs a)
     };
 
     stop = thr > 0 && re - rb > thr;
+    // index batches: 64 consecutive column ids of the share, the next batch requested while the current one is consumed
+    int my_col = 0, nx_col = 0;
+    float my_val = 0.0f, nx_val = 0.0f;
+    int64_t nx_p = -1;                    // position the prefetched batch starts at (-1: none)
     while (r < r_end) {
         if (stop) {                       // a long row: its chunk items do the work; nothing of it was consumed here
-            if (r >= r_end) break;
             p = re;
             ++r;
             rb = re;
@@ -393,22 +399,38 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_flat_kernel(const SpmmArgs a)
             }
             continue;
         }
-        if (p >= p_end || re == rb) {     // rows without edges (also the trailing ones of the share)
+        if (re == rb) {                   // a row without edges: its epilogue of an empty sum
             flush();
             continue;
         }
         const int64_t left = p_end - p;
         const int nb = left < kWave ? (int)left : kWave;
-        int my_col = 0;
-        float my_val = 0.0f;
-        if (lane < nb) {
-            my_col = __builtin_nontemporal_load(a.col + p + lane);
-            if (HAS_VAL) my_val = __builtin_nontemporal_load(a.val + p + lane);
+        if (nx_p == p) {
+            my_col = nx_col;
+            my_val = nx_val;
+        } else {
+            my_col = 0;
+            my_val = 0.0f;
+            if (lane < nb) {
+                my_col = __builtin_nontemporal_load(a.col + p + lane);
+                if (HAS_VAL) my_val = __builtin_nontemporal_load(a.val + p + lane);
+            }
+        }
+        nx_p = p + kWave;
+        nx_col = 0;
+        nx_val = 0.0f;
+        if (nx_p + lane < p_end) {
+            nx_col = __builtin_nontemporal_load(a.col + nx_p + lane);
+            if (HAS_VAL) nx_val = __builtin_nontemporal_load(a.val + nx_p + lane);
         }
         int j = 0;
         while (j < nb && !stop) {
+            // one group = up to SLOTS x U edges of the CURRENT row: a group never crosses a row end, so one flush site serves all
             const int64_t q0 = p + j;
-            if (j + G <= nb && q0 + G <= re) {        // the whole group belongs to the current row
+            const int64_t in_row = re - q0;                        // >= 1: the current row has edges left (invariant)
+            int cnt = nb - j < G ? nb - j : G;
+            if (in_row < cnt) cnt = (int)in_row;
+            if (cnt == G) {
                 int c[U];
                 float wv[U];
 #pragma unroll
@@ -427,51 +449,38 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_flat_kernel(const SpmmArgs a)
 #pragma unroll
                     for (int i = 0; i < EPV; ++i) acc[i] = HAS_VAL ? fmaf(wv[u], f[i], acc[i]) : acc[i] + f[i];
                 }
-                j += G;
-                if (q0 + G == re) flush();
-                continue;
-            }
-            // a group with row ends (or the batch's ragged end) inside: all U gathers are issued back to back, then consumed step by step
-            int c[U];
-            float wv[U];
-            bool ok[U];
+            } else {
+                // the U gathers are still issued back to back: an idle slot re-reads the group's last live edge and is zeroed after the load
+                int c[U];
+                float wv[U];
+                bool ok[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int idx = j + u * SLOTS + slot;
-                ok[u] = idx < nb;
-                const int src = ok[u] ? idx : nb - 1;
-                c[u] = __shfl(my_col, src);
-                wv[u] = HAS_VAL ? __shfl(my_val, src) : 1.0f;
-            }
-            typename IO::raw_t v[U];
+                for (int u = 0; u < U; ++u) {
+                    const int idx = u * SLOTS + slot;
+                    ok[u] = idx < cnt;
+                    const int src = j + (ok[u] ? idx : cnt - 1);
+                    c[u] = __shfl(my_col, src);
+                    wv[u] = HAS_VAL ? __shfl(my_val, src) : 1.0f;
+                }
+                typename IO::raw_t v[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) v[u] = IO::load(xcol + (uint64_t)(uint32_t)c[u] * ld32);
+                for (int u = 0; u < U; ++u) v[u] = IO::load(xcol + (uint64_t)(uint32_t)c[u] * ld32);
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int64_t qa = q0 + u * SLOTS;                 // first edge of this step (uniform); the slots hold qa + slot
-                if (stop || qa >= p + nb) continue;
-                float f[EPV];
-                IO::unpack(v[u], f);
-                const int64_t pos = qa + slot;
-                int64_t lo = qa;
-                while (true) {
-                    const int64_t hi = re < qa + SLOTS ? re : qa + SLOTS;
-                    const bool take = ok[u] && pos >= lo && pos < hi;
+                for (int u = 0; u < U; ++u) {
+                    float f[EPV];
+                    IO::unpack(ok[u] ? v[u] : IO::zero(), f);
 #pragma unroll
-                    for (int i = 0; i < EPV; ++i) {
-                        const float t = take ? f[i] : 0.0f;
-                        acc[i] = HAS_VAL ? fmaf(wv[u], t, acc[i]) : acc[i] + t;
-                    }
-                    if (re > qa + SLOTS || re > p + nb) break;     // the row goes on beyond this step (or beyond the batch)
-                    flush();                                       // the row ended inside this step
-                    lo = hi;
-                    if (stop || lo >= qa + SLOTS) break;
+                    for (int i = 0; i < EPV; ++i) acc[i] = HAS_VAL ? fmaf(wv[u], f[i], acc[i]) : acc[i] + f[i];
                 }
             }
-            j += G;
+            j += cnt;
+            if (q0 + cnt == re) {                                   // the row is complete
+                flush();
+                while (!stop && re == rb) flush();                  // rows without edges that follow it
+            }
         }
-        // what the batch consumed: everything, unless a long row (or the end of the share) stopped it -- then the current row starts at rb
-        p = stop ? rb : p + nb;
+        // what the batch consumed: j edges, unless a long row (or the end of the share) stopped it -- then the current row starts at rb
+        p = stop ? rb : p + j;
     }
 }
 
@@ -634,7 +643,7 @@ static int g_tune_flags = 0;         // bit 0: XCD-contiguous row mapping (off: 
 static int g_tune_threshold = 0;     // 0 = plan default (256)
 static int g_tune_rowslot = 0;       // 0 = automatic choice of the row-per-slot kernel, 1 = never, 2 = whenever it applies
 static int g_tune_flat = 0;          // flattened kernel (spmm_csr_flat_kernel): 0 = automatic, 1 = never, 2 = whenever the plan has its schedule
-static int g_tune_flat_edges = 512;  // edges per wave of the flattened schedule (read when a plan is created)
+static int g_tune_flat_edges = 256;  // edges per wave of the flattened schedule (read when a plan is created)
 
 template <typename XT, typename YT, int EPV, int LPR, int U>
 static hipError_t launch_u(const SpmmArgs& a, dim3 grid, hipStream_t s) {
@@ -807,9 +816,9 @@ DGLL_API int dgll_hip_csr_plan_create(void* stream, const int64_t* rowptr, int64
         PLAN_TRY(hipStreamSynchronize(s));
     }
     // the flattened kernel's wave schedule (one binary search per wave, once per graph)
-    if (nnz > 0 && n_rows > 0 && g_tune_flat_edges > 0) {
+    if (n_rows > 0 && g_tune_flat_edges > 0) {
         p->flat_edges = g_tune_flat_edges;
-        p->n_flat = (nnz + p->flat_edges - 1) / p->flat_edges;
+        p->n_flat = (nnz + kFlatRowCost * n_rows + p->flat_edges - 1) / p->flat_edges;
         PLAN_TRY(hipMalloc(&p->d_flat_row0, sizeof(int64_t) * (size_t)(p->n_flat + 1)));
         const int blocks = (int)std::min<int64_t>((p->n_flat + 1 + kBlock - 1) / kBlock, 4096);
         hipLaunchKernelGGL(flat_row0_kernel, dim3(blocks), dim3(kBlock), 0, s, rowptr, n_rows, (int64_t)p->flat_edges, p->n_flat,
@@ -1001,8 +1010,11 @@ int dgll_spmm_csr_impl(void* stream, const dgll_csr_plan* plan, const int64_t* r
         else err = launch_rowslot_lpr<bf16_t, float, 8>(a, lpr, grid, s);
     } else if (fast && !only_long && plan && plan->d_flat_row0 && g_tune_flat != 1 && g_tune_unroll == 4 && !(a.flags & 1) &&
                [&]() { const int v = (feat + epv - 1) / epv; return v > 8 && v <= 32; }() &&
-               (g_tune_flat == 2 || (double)plan->nnz / (double)std::max<int64_t>(n_rows, 1) >= 8.0)) {
-        // wide rows (16 or 32 lanes per row), not very short on average: the flattened edge-stream kernel
+               (g_tune_flat == 2 || (x_dtype == DGLL_F32 && (double)plan->nnz / (double)std::max<int64_t>(n_rows, 1) >= 8.0))) {
+        // The flattened edge-stream kernel.  Measured on the products-sized bench graph (tools/flat_ab.py, E = 256, interleaved):
+        // fp32 F = 100 forward 4.23 -> 3.93 ms (-7 %): chosen for fp32 rows of 16 / 32 lanes; bf16 F = 256 forward 4.35 -> 4.26-4.35,
+        // F = 100 / 128 bf16 +3-4 % slower, the weighted + gated + accumulating transposed pass 5.49 -> 5.85 (73-87 registers: 5-6
+        // wavefronts per SIMD against 8): not chosen for bf16 (dgll_hip_debug_tune(13, 2) forces it, (13, 1) disables it).
         const int vecs = (feat + epv - 1) / epv;
         const int lpr = vecs <= 16 ? 16 : 32;
         a.flat_row0 = plan->d_flat_row0;
