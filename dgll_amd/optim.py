@@ -24,18 +24,35 @@ import torch
 from . import _lib
 
 
-class FlatAdam:
+class FlatAdam(torch.optim.Optimizer):
+    """torch.optim.Adam over flat buffers.  A torch Optimizer (param_groups with lr / betas / eps / weight_decay, read on EVERY step:
+    learning-rate schedulers work; `params` may be a list of parameters or of parameter-group dicts), with torch.optim.Adam's
+    behaviour for a parameter WITHOUT a gradient at step(): it is skipped entirely -- value, both moments and its own step count
+    untouched, no weight decay (round 4 zero-filled its slot: stale momentum kept moving it).  The common case -- every parameter
+    has a gradient -- is one launch; parameters that were skipped at some point (their step counts, hence bias corrections, differ)
+    or groups with different hyper-parameters are updated by one launch per run of consecutive parameters.
+    Not capturable: step() computes the bias corrections on the host per call and refuses to run under stream capture."""
+
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, pack_weights=True):
-        self.params = [p for p in params if p.requires_grad]
+        params = list(params)
+        super().__init__(params, dict(lr=float(lr), betas=(float(betas[0]), float(betas[1])), eps=float(eps), weight_decay=float(weight_decay)))
+        self.params, self._group_of = [], []
+        for gi, group in enumerate(self.param_groups):
+            for p in group["params"]:
+                if p.requires_grad:
+                    self.params.append(p)
+                    self._group_of.append(gi)
         if not self.params:
             raise ValueError("FlatAdam got no parameter that requires grad")
         dev = self.params[0].device
         if any(p.device != dev or p.dtype != torch.float32 for p in self.params):
             raise ValueError("FlatAdam takes fp32 parameters on one device")
         self.device = dev
-        self.lr, self.betas, self.eps, self.weight_decay = float(lr), (float(betas[0]), float(betas[1])), float(eps), float(weight_decay)
-        self.steps = 0
-        self.grad_scale = 1.0          # RaCoM sets 1 / world_size (the reference's average, MQGCN.py:64) instead of a div_ launch
+        self.steps = 0                 # step() calls so far; param_steps: updates every parameter has received (torch's state['step'])
+        self.param_steps = [0] * len(self.params)
+        self.grad_scale = 1.0          # ONE-SHOT factor on the gradients of the next step(): RaCoM sets 1 / world_size (the reference's
+                                       # average, MQGCN.py:64) instead of a div_ launch; clip_grad_norm_ folds its coefficient in.  step()
+                                       # consumes it and resets it to 1.0
         self.offsets, off = [], 0
         for p in self.params:
             self.offsets.append(off)
@@ -59,6 +76,12 @@ class FlatAdam:
         if self.pack_weights:
             self.repack()
 
+    # hyper-parameters of the first group under their old attribute names (read-only convenience; the groups are what step() reads)
+    lr = property(lambda self: self.param_groups[0]["lr"])
+    betas = property(lambda self: self.param_groups[0]["betas"])
+    eps = property(lambda self: self.param_groups[0]["eps"])
+    weight_decay = property(lambda self: self.param_groups[0]["weight_decay"])
+
     # ---- gradient slots --------------------------------------------------------------------------------------------
     def grad_slot(self, p):
         """A FRESH [shape of p] view of p's slice of the gradient buffer: hand it to a kernel as its output and return it from an
@@ -80,12 +103,16 @@ class FlatAdam:
     def _slot_ptr(self, i):
         return self.grad.data_ptr() + 4 * self.offsets[i]
 
-    def gather_grads(self):
+    def gather_grads(self, zero_missing=True):
         """Make the gradient buffer hold every parameter's gradient: slots written in place are left alone, a gradient that autograd
-        produced elsewhere is copied in, a parameter without gradient gets zeros.  Afterwards every .grad IS its slot."""
+        produced elsewhere is copied in.  zero_missing (what a gradient all-reduce over the whole buffer needs, dist.RaCoM: another
+        rank may hold a gradient for it): a parameter without gradient gets a zero slot as its .grad; False (step()): it is left
+        without one and the update skips it."""
         for i, p in enumerate(self.params):
             g = p.grad
             if g is not None and g.data_ptr() == self._slot_ptr(i) and g.is_contiguous():
+                continue
+            if g is None and not zero_missing:
                 continue
             slot = self.grad_slot(p)
             if g is None:
@@ -93,6 +120,26 @@ class FlatAdam:
             else:
                 slot.copy_(g)
             p.grad = slot
+
+    def grad_norm(self):
+        """2-norm of the gradients as the next step() will apply them (grad_scale included: after an in-place RaCoM reduction .grad
+        holds the SUM over ranks and grad_scale the 1 / world of the average)."""
+        self.gather_grads(zero_missing=False)
+        sq = None
+        for i, p in enumerate(self.params):
+            if p.grad is not None:
+                t = self.grad_slot(p).double().square().sum()
+                sq = t if sq is None else sq + t
+        return (sq.sqrt() * abs(self.grad_scale)).float() if sq is not None else torch.zeros((), device=self.device)
+
+    def clip_grad_norm_(self, max_norm):
+        """torch.nn.utils.clip_grad_norm_ for this optimizer: the clip coefficient goes into the one-shot grad_scale (no launch over the
+        gradients; .grad itself is not rescaled).  Returns the norm before clipping."""
+        norm = self.grad_norm()
+        coef = float(max_norm) / (float(norm) + 1e-6)
+        if coef < 1.0:
+            self.grad_scale *= coef
+        return norm
 
     def zero_grad(self, set_to_none=True):
         """set_to_none (default): drop the .grad references -- the next backward writes the slots afresh; no launch."""
@@ -167,41 +214,100 @@ class FlatAdam:
         return self._table
 
     # ---- the step --------------------------------------------------------------------------------------------------
-    def step(self):
-        self.gather_grads()
+    def _runs(self, has):
+        """Runs of consecutive parameters updated by one launch: same group, same (new) step count, all with a gradient."""
+        runs, cur = [], None
+        for i, ok in enumerate(has):
+            key = (self._group_of[i], self.param_steps[i] + 1) if ok else None
+            if key is None:
+                cur = None
+                continue
+            if cur is not None and cur[0] == key:
+                cur[2] = i
+            else:
+                cur = [key, i, i]
+                runs.append(cur)
+        return [(key[0], key[1], i0, i1) for key, i0, i1 in runs]
+
+    def step(self, closure=None):
+        if closure is not None:
+            raise NotImplementedError("FlatAdam.step takes no closure")
+        if self.device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("FlatAdam.step() cannot be captured into a HIP graph: its bias corrections are host scalars of the launch "
+                               "(call it after graph.replay(), as graphs.GraphedSampledStep does)")
+        has = [p.grad is not None for p in self.params]
+        self.gather_grads(zero_missing=False)
         self.steps += 1
         self._handed_out = [True] * len(self.params)        # until the next zero_grad(): .grad still holds this step's gradient
+        scale, self.grad_scale = float(self.grad_scale), 1.0    # one-shot
+        for gi, step_no, i0, i1 in self._runs(has):
+            group = self.param_groups[gi]
+            begin, end = self.offsets[i0], (self.offsets[i1 + 1] if i1 + 1 < len(self.params) else self.total)
+            self._update(begin, end, float(group["lr"]), (float(group["betas"][0]), float(group["betas"][1])), float(group["eps"]),
+                         float(group["weight_decay"]), step_no, scale)
+            for i in range(i0, i1 + 1):
+                self.param_steps[i] = step_no
+
+    def _update(self, begin, end, lr, betas, eps, weight_decay, step_no, scale):
         if self.device.type != "cuda":
-            return self._step_host()
-        n, begin, end, cols, pk, ld, pkt, ldt = self._segments() if self.pack_weights else (0, None, None, None, None, None, None, None)
+            return self._update_host(begin, end, lr, betas, eps, weight_decay, step_no, scale)
+        whole = begin == 0 and end == self.total
+        if self.pack_weights:
+            n, sb, se, cols, pk, ld, pkt, ldt = self._segments() if whole else self._segments_in(begin, end)
+        else:
+            n, sb, se, cols, pk, ld, pkt, ldt = (0, None, None, None, None, None, None, None)
         with _lib.on_device(self.device):
             code = _lib.lib.dgll_hip_adam_flat(
-                _lib.raw_stream(self.device), self.flat.data_ptr(), self.grad.data_ptr(),
-                self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.total, self.lr, self.betas[0], self.betas[1], self.eps,
-                self.weight_decay, self.steps, float(self.grad_scale), n, begin, end, cols, pk, ld, pkt, ldt)
+                _lib.raw_stream(self.device), self.flat.data_ptr() + 4 * begin, self.grad.data_ptr() + 4 * begin,
+                self.exp_avg.data_ptr() + 4 * begin, self.exp_avg_sq.data_ptr() + 4 * begin, end - begin, lr, betas[0], betas[1], eps,
+                weight_decay, step_no, scale, n, sb, se, cols, pk, ld, pkt, ldt)
         _lib.check(code, "dgll_hip_adam_flat")
 
-    def _step_host(self):
+    def _segments_in(self, begin, end):
+        """The packed-weight table of the parameters inside [begin, end), offsets relative to `begin` (a partial update)."""
+        idx = [i for i in sorted(self._packed) if begin <= self.offsets[i] and self.offsets[i] + self.params[i].numel() <= end]
+        n = len(idx)
+        i64, vp = C.c_int64 * max(n, 1), C.c_void_p * max(n, 1)
+        return (n, i64(*[self.offsets[i] - begin for i in idx]), i64(*[self.offsets[i] + self.params[i].numel() - begin for i in idx]),
+                (C.c_int * max(n, 1))(*[self.params[i].shape[1] for i in idx]),
+                vp(*[self._packed[i][0].data_ptr() if self._packed[i][0] is not None else None for i in idx]),
+                i64(*[self._packed[i][0].stride(0) if self._packed[i][0] is not None else 0 for i in idx]),
+                vp(*[self._packed[i][1].data_ptr() for i in idx]), i64(*[self._packed[i][1].stride(0) for i in idx]))
+
+    def _update_host(self, begin, end, lr, betas, eps, weight_decay, step_no, scale):
         """Host tensors (the gloo tests): the same arithmetic with torch ops."""
-        b1, b2 = self.betas
+        b1, b2 = betas
+        sl = slice(begin, end)
         with torch.no_grad():
-            g = self.grad * self.grad_scale
-            if self.weight_decay:
-                g = g + self.weight_decay * self.flat
-            self.exp_avg.lerp_(g, 1 - b1)
-            self.exp_avg_sq.mul_(b2).addcmul_(g, g, value=1 - b2)
-            bc1, bc2 = 1 - b1 ** self.steps, 1 - b2 ** self.steps
-            denom = (self.exp_avg_sq.sqrt() / (bc2 ** 0.5)).add_(self.eps)
-            self.flat.addcdiv_(self.exp_avg, denom, value=-self.lr / bc1)
+            g = self.grad[sl] * scale
+            if weight_decay:
+                g = g + weight_decay * self.flat[sl]
+            self.exp_avg[sl].lerp_(g, 1 - b1)
+            self.exp_avg_sq[sl].mul_(b2).addcmul_(g, g, value=1 - b2)
+            bc1, bc2 = 1 - b1 ** step_no, 1 - b2 ** step_no
+            denom = (self.exp_avg_sq[sl].sqrt() / (bc2 ** 0.5)).add_(eps)
+            self.flat[sl].addcdiv_(self.exp_avg[sl], denom, value=-lr / bc1)
 
     def state_dict(self):
-        return {"steps": self.steps, "exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(),
+        return {"steps": self.steps, "param_steps": list(self.param_steps), "exp_avg": self.exp_avg.clone(),
+                "exp_avg_sq": self.exp_avg_sq.clone(),
+                "groups": [{k: g[k] for k in ("lr", "betas", "eps", "weight_decay")} for g in self.param_groups],
                 "lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay}
 
     def load_state_dict(self, sd):
+        """Moments, step counts AND hyper-parameters (a checkpoint taken at a decayed learning rate resumes at it)."""
         self.steps = int(sd["steps"])
+        self.param_steps = [int(v) for v in sd.get("param_steps", [self.steps] * len(self.params))]
+        if len(self.param_steps) != len(self.params):
+            raise ValueError("state_dict holds %d parameters, this optimizer %d" % (len(self.param_steps), len(self.params)))
         self.exp_avg.copy_(sd["exp_avg"])
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        groups = sd.get("groups") or [{k: sd[k] for k in ("lr", "betas", "eps", "weight_decay") if k in sd}]
+        if len(groups) != len(self.param_groups):
+            raise ValueError("state_dict holds %d parameter groups, this optimizer %d" % (len(groups), len(self.param_groups)))
+        for g, saved in zip(self.param_groups, groups):
+            for k, v in saved.items():
+                g[k] = tuple(v) if k == "betas" else v
 
 
 def grad_slot_of(param):

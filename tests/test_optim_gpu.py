@@ -81,3 +81,38 @@ def test_full_graph_sage_step_through_flat_adam(cuda_device, monkeypatch):
         else:
             assert packs
     assert losses["flat"] == pytest.approx(losses["torch"], rel=2e-3)
+
+
+def test_skipped_parameters_partial_launches_and_no_capture(cuda_device):
+    """ADVICE round 4 on the GPU: a parameter without gradient is skipped like torch.optim.Adam skips it (value, moments, its step
+    count); the others are updated by launches over their runs of the flat buffer, the packed bf16 forms of exactly those follow;
+    step() refuses to be captured into a HIP graph."""
+    torch.manual_seed(2)
+    shapes = [(100, 256), (256, 256), (256, 47), (47,)]
+    a = [torch.nn.Parameter(torch.randn(*s, device=cuda_device)) for s in shapes]
+    b = [torch.nn.Parameter(p.detach().clone()) for p in a]
+    ref = torch.optim.Adam(a, lr=3e-3, weight_decay=0.02)
+    opt = FlatAdam(b, lr=3e-3, weight_decay=0.02)
+    for step in range(6):
+        for i, (p, q) in enumerate(zip(a, b)):
+            g = torch.randn_like(p)
+            if i == 1 and step in (1, 2, 4):
+                p.grad = q.grad = None
+            else:
+                p.grad, q.grad = g.clone(), g.clone()
+        ref.step()
+        opt.step()
+    for p, q in zip(a, b):
+        torch.testing.assert_close(q, p, rtol=2e-6, atol=2e-7)
+    assert opt.param_steps == [6, 3, 6, 6]
+    for q in b[:3]:
+        assert torch.equal(dense._pad_wt(q.detach().t()), dense._pack_now(q.detach().t()))
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    for q in b:
+        q.grad = torch.zeros_like(q)
+    with pytest.raises(RuntimeError, match="cannot be captured"):
+        with torch.cuda.graph(g, stream=side):
+            opt.step()
+    torch.cuda.synchronize()
