@@ -204,22 +204,47 @@ def nnz_balanced_bounds(graph, world):
 # ----------------------------------------------------------------------------------------------------------------
 class ExchangeWatchdog:
     """First contact with a transport can hang (a grouped send/recv whose peers disagree, an IPC set-up that never completes): the
-    host then sits in a synchronize() for ever and the job dies without a word.  Every exchange registers an event recorded behind
-    it; a daemon thread polls the pending events and, when one is still incomplete `timeout` seconds after it was queued, prints
-    the phase name and EXITS THE PROCESS with code 3 (never re-executes anything).  DGLL_EXCHANGE_TIMEOUT_S (default 120, 0 =
-    off).  Host-tensor exchanges (gloo on CPU) block in wait() and are bracketed by `guard()` instead."""
+    host then sits in a synchronize() for ever and the job dies without a word.  An exchange registers an event recorded behind it;
+    a daemon thread polls the pending events and, when one is still incomplete `timeout` seconds after it was queued, prints the
+    phase name AND the Python stack of every thread (faulthandler), then EXITS THE PROCESS with code 3 (never re-executes anything).
 
-    def __init__(self, timeout=None, rank=0):
+    What is watched (DGLL_EXCHANGE_WATCHDOG): "startup" (default) = the start-up self-test and the first `arm_first` (16) exchanges
+    -- the hangs this exists for happen at first contact; a steady-state job is not watched, so a process stopped under a debugger
+    (SIGSTOP), a serialised `rocprofv3 --pmc` run or a first-step module load cannot get a healthy job killed without a traceback
+    (the clock starts when an exchange is QUEUED, not when it runs); "always" = every exchange; "off".
+    DGLL_EXCHANGE_TIMEOUT_S (default 120, 0 = off).  Host-tensor exchanges (gloo on CPU) block in wait() and are bracketed by
+    `guard()` instead.  Events come from a small pool (no allocation in the steady state when watching is on)."""
+
+    def __init__(self, timeout=None, rank=0, mode=None, arm_first=16):
         self.timeout = float(os.environ.get("DGLL_EXCHANGE_TIMEOUT_S", "120")) if timeout is None else float(timeout)
+        self.mode = (mode or os.environ.get("DGLL_EXCHANGE_WATCHDOG", "startup")).lower()
+        if self.mode not in ("startup", "always", "off"):
+            raise ValueError("DGLL_EXCHANGE_WATCHDOG must be startup, always or off")
+        if self.mode == "off":
+            self.timeout = 0.0
+        self.arm_first = int(arm_first)
+        self.watched = 0
         self.rank = rank
         self._pending = []
         self._lock = threading.Lock()
         self._thread = None
+        self._event_pool = []
         self.on_timeout = self._die            # tests replace it
 
+    def armed(self):
+        """Whether the next exchange is watched."""
+        return self.timeout > 0 and (self.mode == "always" or self.watched < self.arm_first)
+
     def _die(self, phase, age):
-        print("dgll_amd.dist: rank %d: exchange phase '%s' did not complete within %.0f s -- exiting (code 3)" % (self.rank, phase, age),
-              file=sys.stderr, flush=True)
+        print("dgll_amd.dist: rank %d: exchange phase '%s' did not complete within %.0f s -- exiting (code 3); Python stacks follow" % (
+            self.rank, phase, age), file=sys.stderr, flush=True)
+        try:
+            import faulthandler
+
+            faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+            sys.stderr.flush()
+        except Exception:  # noqa: BLE001
+            pass
         os._exit(3)
 
     def _run(self):
@@ -228,13 +253,15 @@ class ExchangeWatchdog:
             now = time.monotonic()
             with self._lock:
                 keep = []
-                for phase, probe, t0 in self._pending:
+                for phase, probe, t0, event in self._pending:
                     if probe():
+                        if event is not None and len(self._event_pool) < 8:
+                            self._event_pool.append(event)
                         continue
                     if now - t0 > self.timeout:
                         self.on_timeout(phase, now - t0)
                         continue
-                    keep.append((phase, probe, t0))
+                    keep.append((phase, probe, t0, event))
                 self._pending = keep
 
     def _ensure_thread(self):
@@ -242,25 +269,39 @@ class ExchangeWatchdog:
             self._thread = threading.Thread(target=self._run, name="dgll-exchange-watchdog", daemon=True)
             self._thread.start()
 
-    def watch_event(self, phase, event):
+    def watch_stream(self, phase, stream):
+        """Record an event behind the exchange on `stream` and watch it -- when this exchange is to be watched at all (armed())."""
+        if not self.armed():
+            return
+        self.watched += 1
+        with self._lock:
+            event = self._event_pool.pop() if self._event_pool else None
+        if event is None:
+            event = torch.cuda.Event()
+        event.record(stream)
+        self.watch_event(phase, event, _pooled=True)
+
+    def watch_event(self, phase, event, _pooled=False):
         """event: a torch.cuda.Event recorded behind the exchange on its stream."""
         if self.timeout <= 0:
             return
         self._ensure_thread()
         with self._lock:
-            self._pending.append((phase, event.query, time.monotonic()))
+            self._pending.append((phase, event.query, time.monotonic(), event if _pooled else None))
 
-    def guard(self, phase):
-        """Context manager around a host-blocking wait."""
+    def guard(self, phase, force=False):
+        """Context manager around a host-blocking wait (force: watched whatever the mode -- the start-up self-test)."""
         wd = self
+        on = wd.timeout > 0 and (force or wd.armed())
 
         class _G:
             def __enter__(self_g):
                 self_g.done = False
-                if wd.timeout > 0:
+                if on:
+                    wd.watched += 1
                     wd._ensure_thread()
                     with wd._lock:
-                        wd._pending.append((phase, lambda: self_g.done, time.monotonic()))
+                        wd._pending.append((phase, lambda: self_g.done, time.monotonic(), None))
 
             def __exit__(self_g, *exc):
                 self_g.done = True
@@ -332,9 +373,7 @@ class _Exchange:
         if device_side:
             for r in reqs:
                 r.wait()                                     # stream-ordered: returns at once; a hang shows up behind it
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream())
-            self.watchdog.watch_event(self.phase, ev)
+            self.watchdog.watch_stream(self.phase, torch.cuda.current_stream())
         else:
             with self.watchdog.guard(self.phase):
                 for r in reqs:
@@ -989,7 +1028,7 @@ class DistGraph:
             self.join_comm()
             want_back = torch.stack([sent_ids, dest], dim=1)
             if dev.type == "cuda":
-                with ex.watchdog.guard(ex.phase + ": synchronize"):
+                with ex.watchdog.guard(ex.phase + ": synchronize", force=True):
                     torch.cuda.current_stream(dev).synchronize()
             bad = int((recv != want).any(dim=1).sum()), int((back != want_back).any(dim=1).sum())
         finally:

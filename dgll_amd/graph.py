@@ -232,8 +232,11 @@ class CSRGraph:
             handle = C.c_void_p()
             with torch.cuda.device(self.device):
                 stream = torch.cuda.current_stream(self.device).cuda_stream
-                # max_degree (set by the block constructors) <= 128: no row can be "long" -> host-only plan, no sync
-                threshold = -1 if (self.max_degree is not None and self.max_degree <= 128) else 0
+                # max_degree (set by the block constructors) <= 128: no row can be "long" -> host-only plan, no sync.  A PADDED
+                # block (graphs.PaddedBlock) rewrites its row pointers under a captured step: a chunk schedule derived from the
+                # capture-time pointers would be stale on every replay, so it gets the host-only plan whatever its fan-out
+                # (every row gathered inline; correct for any row length)
+                threshold = -1 if ((self.max_degree is not None and self.max_degree <= 128) or getattr(self, "padded", False)) else 0
                 _lib.check(_lib.lib.dgll_hip_csr_plan_create(stream, self.rowptr.data_ptr(), self.n_rows, self.nnz, threshold,
                                                              C.byref(handle)), "dgll_hip_csr_plan_create")
             self._plan = handle.value

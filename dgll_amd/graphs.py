@@ -81,7 +81,9 @@ class PaddedBlock:
     """Factory of the CSR block of one hop of a sampled batch on STATIC shapes: `rows` destination rows over `cols` source rows
     (cols = rows x fan-out, the hop's upper bound), the row pointers in a buffer that is refilled per batch (pad(): the rows a
     batch does not use are empty, the source rows it does not use belong to no edge).  Everything derived from the row pointers
-    is recomputed on every call -- inside a captured step that means on every replay."""
+    is recomputed on every call -- inside a captured step that means on every replay.  The kernels' launch plan of a padded block is
+    the host-only one whatever the fan-out (graph.CSRGraph.plan: no long-row chunk schedule, which would describe the capture-time
+    row pointers and go stale on the first replay; rows of any length are gathered inline)."""
 
     @staticmethod
     def make(rows, fanout, device, cols=None):

@@ -196,9 +196,24 @@ def test_exchange_watchdog_reports_the_phase_of_an_exchange_that_never_completes
     state = {"done": False}
     wd._ensure_thread()
     with wd._lock:
-        wd._pending.append(("layer-3 halo exchange", lambda: state["done"], time.monotonic()))
+        wd._pending.append(("layer-3 halo exchange", lambda: state["done"], time.monotonic(), None))
     time.sleep(0.8)
     assert [f[0] for f in fired] == ["layer-3 halo exchange"] and fired[0][1] > 0.2
+    # default mode "startup": the first `arm_first` exchanges are watched, a steady-state job is not (a process paused under a
+    # debugger or a serialised counter run must not get a healthy job killed); "always" and "off" are the other two
+    wd2 = ddist.ExchangeWatchdog(timeout=5.0, arm_first=3)
+    assert wd2.mode == "startup"
+    for k in range(5):
+        assert wd2.armed() == (k < 3)
+        with wd2.guard("exchange %d" % k):
+            pass
+    assert wd2.watched == 3
+    with wd2.guard("self-test", force=True):             # the start-up self-test is watched whatever was counted before
+        assert any(ph == "self-test" for ph, _p, _t, _e in wd2._pending)
+    assert ddist.ExchangeWatchdog(timeout=5.0, mode="always", arm_first=0).armed()
+    assert not ddist.ExchangeWatchdog(timeout=5.0, mode="off").armed()
+    with pytest.raises(ValueError):
+        ddist.ExchangeWatchdog(mode="sometimes")
     part = ddist.Partition()
     with pytest.raises(ValueError):
         ddist._Exchange(part, form="ring")

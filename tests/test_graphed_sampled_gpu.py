@@ -117,3 +117,31 @@ def test_replayed_training_follows_the_eager_loop(cuda_device):
         losses[mode] = trace
     assert losses["graph"] == pytest.approx(losses["eager"], rel=5e-3)
     assert losses["graph"][-1] < losses["graph"][0] or losses["eager"][-1] >= losses["eager"][0]
+
+
+def test_replay_equals_eager_at_a_fan_out_above_128(cuda_device):
+    """PaddedBlock rewrites its row pointers under the captured step, but a launch plan with a long-row chunk
+    schedule (fan-out > 128: graph.CSRGraph.plan scanned the capture-time pointers) would have described the synthetic full block
+    on every replay -- wrong aggregates, silently.  Padded blocks now take the host-only plan whatever the fan-out; here a hop with
+    fan-out 300 (rows of up to 300 edges, most batches far from full) replayed against the eager step."""
+    from dgll_amd import nn as dnn, ops
+    from dgll_amd.graphs import GraphedSampledStep
+    from dgll_amd.optim import FlatAdam
+
+    dev = cuda_device
+    fanouts, batch, feats, classes = [3, 300], 24, 40, 5           # the model's order: hop 0 -> 1 was sampled with 300
+    order = list(reversed(fanouts))
+    rng = torch.Generator().manual_seed(5)
+    batches = [_batch(dev, rng, batch, order, feats, classes, fill) for fill in (1.0, 0.5, 1.0)]
+    assert max(int(b.blocks[0].degrees().max()) for b in batches) == 300
+    torch.manual_seed(1)
+    model = dnn.GraphSage(feats, [32, classes], fanouts).to(dev)
+    opt = FlatAdam(list(model.parameters()), lr=0.0)
+    step = GraphedSampledStep(model, opt, batch, fanouts, feats, classes, device=dev)
+    assert step.blocks[0].max_degree == 300 and step.blocks[0].num_long_rows() == 0          # host-only plan: no chunk schedule
+    for b in batches:
+        want, grads = _eager(model, opt, b, ops)
+        got = float(step(b))
+        assert got == pytest.approx(want, rel=1e-5)
+        for a, b_ in zip([p.grad for p in model.parameters()], grads):
+            assert float((a - b_).abs().max()) <= 2e-3 * float(b_.abs().max()) + 1e-7
