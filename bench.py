@@ -1196,7 +1196,7 @@ def run_minibatch(args, c):
     import numpy as np
 
     from dgll_amd import nn as dnn
-    from dgll_amd import ops, synth
+    from dgll_amd import ops, ranges, synth
     from dgll_amd.cache import GraphCacheServer
     from dgll_amd.data import DGraph
     from dgll_amd.dataloader import DataLoader
@@ -1355,11 +1355,12 @@ def run_minibatch(args, c):
             for h in range(L):
                 seen_rows[h] = max(seen_rows[h], int(b.features[h].shape[0]) if b.features[h] is not None else 0)
         if not use_graph:                     # (also the tail after the timed window: launch by launch, it feeds the launch tables)
-            out = model.forward_sampled(b.features, blocks, last_hop_reduced=b.last_hop_reduced)
-            loss = ops.cross_entropy(out, b.labels)
-            opt.zero_grad(set_to_none=True)
-            loss.backward()
-            opt.step()
+            with ranges.rng("consume"):       # (DGLL_PROFILE_RANGES=1: the reference's 'gpu-compute' range, FeatureCache/gs.py:93)
+                out = model.forward_sampled(b.features, blocks, last_hop_reduced=b.last_hop_reduced)
+                loss = ops.cross_entropy(out, b.labels)
+                opt.zero_grad(set_to_none=True)
+                loss.backward()
+                opt.step()
         ev1.record()
         if args.warmup <= done < args.warmup + args.steps:
             events.append((ev0, ev1))

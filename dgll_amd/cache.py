@@ -15,6 +15,7 @@ import threading
 import torch
 
 from . import _lib
+from .ranges import rng
 from .ops import _dtype_code
 
 
@@ -126,9 +127,10 @@ class GraphCacheServer:
 
     def get_feat_from_server(self, nids, to_gpu=False):
         """Rows of the host feature store for local ids `nids` (storage.py:100-125)."""
-        full = nids if self.nid_map is None else self.nid_map[nids]
-        rows = self.features[full.cpu()]
-        return rows.to(self.device, non_blocking=True) if to_gpu else rows
+        with rng("cache-cpu"):
+            full = nids if self.nid_map is None else self.nid_map[nids]
+            rows = self.features[full.cpu()]
+            return rows.to(self.device, non_blocking=True) if to_gpu else rows
 
     def cache_fix_data(self, nids, data, is_full=False):
         """storage.py:127-148.  Safe DURING iteration (the pipeline's loading thread fetches on its own stream while the
@@ -164,7 +166,7 @@ class GraphCacheServer:
         belongs to that stream; a consumer on another stream must wait for it and `record_stream` the tensor.  The miss
         count of a logged fetch is read back lazily (get_miss_rate), not here."""
         stream = torch.cuda.current_stream(self.device) if stream is None else stream
-        with torch.cuda.stream(stream):
+        with torch.cuda.stream(stream), rng("cache-index"):
             nids = nids.to(self.device, dtype=torch.int64, non_blocking=True)
             n = int(nids.numel())
             if out is None:
@@ -185,7 +187,7 @@ class GraphCacheServer:
             counter = None
             if self.log and use_map:
                 counter = torch.zeros(1, dtype=torch.int64, device=self.device)
-            with torch.cuda.device(self.device):
+            with torch.cuda.device(self.device), rng("cache-gpu"):
                 code = _lib.lib.dgll_hip_gather_rows_mapped(
                     stream.cuda_stream, cache.data_ptr() if use_map else None, cache.stride(0) if use_map else 0,
                     self.features.data_ptr(), self.features.stride(0), nids.data_ptr(),
@@ -216,7 +218,7 @@ class GraphCacheServer:
         if reduce not in ("mean", "sum"):
             raise ValueError("aggregate_data reduces with 'mean' or 'sum'")
         stream = torch.cuda.current_stream(self.device) if stream is None else stream
-        with torch.cuda.stream(stream):
+        with torch.cuda.stream(stream), rng("cache-index"):
             nids = nids.to(self.device, dtype=torch.int64, non_blocking=True)
             rowptr = rowptr.to(self.device, dtype=torch.int64, non_blocking=True)
             n_rows = int(rowptr.numel()) - 1
@@ -239,7 +241,7 @@ class GraphCacheServer:
             counter = None
             if self.log and use_map:
                 counter = torch.zeros(1, dtype=torch.int64, device=self.device)
-            with torch.cuda.device(self.device):
+            with torch.cuda.device(self.device), rng("cache-gpu"):
                 code = _lib.lib.dgll_hip_aggregate_rows_mapped(
                     stream.cuda_stream, cache.data_ptr() if use_map else None, cache.stride(0) if use_map else 0,
                     self.features.data_ptr(), self.features.stride(0), nids.data_ptr(),

@@ -30,6 +30,7 @@ import torch.distributed as dist
 from . import ops
 from .graph import CSRGraph
 from .optim import grad_slot_of
+from .ranges import rng
 
 
 class Partition:
@@ -338,6 +339,10 @@ class _Exchange:
     def start(self, send_buf, recv_buf, reverse=False, more=()):
         """One exchange moving `send_buf` rows to their peers and filling `recv_buf`; `more` = further
         (send, recv) pairs with the same row layout (e.g. the fp32 score rows next to the feature rows)."""
+        with rng("exchange"):
+            return self._start(send_buf, recv_buf, reverse, more)
+
+    def _start(self, send_buf, recv_buf, reverse, more):
         p = self.part
         s_counts, r_counts = (p.recv_counts, p.send_counts) if reverse else (p.send_counts, p.recv_counts)
         opsl, works, copy_back = [], [], []
@@ -368,6 +373,10 @@ class _Exchange:
         return (reqs, copy_back)
 
     def wait(self, handle):
+        with rng("exchange"):
+            return self._wait(handle)
+
+    def _wait(self, handle):
         reqs, copy_back = handle
         device_side = bool(reqs) and torch.cuda.is_available() and dist.is_initialized() and dist.get_backend(self.group) == "nccl"
         if device_side:
@@ -1320,6 +1329,10 @@ class RaCoM:
         self.bytes_reduced = 0
 
     def launch(self):
+        with rng("racom-allreduce"):
+            return self._launch()
+
+    def _launch(self):
         if self.flat is not None:
             self.flat.gather_grads()                           # no launch when every gradient was written into its slot
             if not self.in_place:
@@ -1346,6 +1359,10 @@ class RaCoM:
                 self._work = dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def wait(self):
+        with rng("racom-allreduce"):
+            return self._wait()
+
+    def _wait(self):
         if self._work is not None:
             self._work.wait()
             self._work = None

@@ -218,7 +218,10 @@ class GraphedSampledStep:
 
     def __call__(self, batch):
         """One training step on `batch`; returns the (static) loss tensor: read it before the next call."""
-        self.load(batch)
-        self.graph.replay()
-        self.optimizer.step()
+        from .ranges import rng
+
+        with rng("consume"):
+            self.load(batch)
+            self.graph.replay()
+            self.optimizer.step()
         return self.loss

@@ -20,6 +20,8 @@ import time
 import numpy as np
 import torch
 
+from .ranges import rng
+
 _DONE = object()
 
 
@@ -230,10 +232,15 @@ class MiniBatchPipeline:
     # ---- producer stage 1: sampling (buffer_queues.py:22-46) ---------------------------------------------------
     def _sample(self):
         try:
-            for step, (inp, outp, subgs) in enumerate(self.dataloader):
-                if self._stop.is_set():
+            it, step = iter(self.dataloader), 0
+            while not self._stop.is_set():
+                with rng("sample"):
+                    item = next(it, None)
+                if item is None:
                     break
+                inp, outp, subgs = item
                 self.sampled.put((step, inp, outp, subgs))            # blocks while the queue is full
+                step += 1
         except BaseException as exc:  # noqa: BLE001  (surface producer failures in the consumer)
             self._fail(exc)
         finally:
@@ -260,8 +267,9 @@ class MiniBatchPipeline:
                 seeds = dl.train_nodes[i * dl.batch_size:(i + 1) * dl.batch_size]
                 buf = self._ring.acquire if (self._ring is not None and self._pos_ring is None) else None
                 stg = self._staging.acquire if self._staging is not None else None
-                inp, outp, subgs = dl.sampler.sample_seeded(dl.Dgraph, seeds, batch_seed(self.base_seed, self.epoch, i), max_threads=1,
-                                                            last_hop_buffer=buf, staging=stg)
+                with rng("sample"):
+                    inp, outp, subgs = dl.sampler.sample_seeded(dl.Dgraph, seeds, batch_seed(self.base_seed, self.epoch, i), max_threads=1,
+                                                                last_hop_buffer=buf, staging=stg)
                 last = subgs[0]
                 if self._pos_ring is not None and getattr(last, "pending_positions", None) is not None and getattr(last, "_finish", None) is not None:
                     # the outermost hop's neighbour POSITIONS (< the maximum degree) leave the host as 16- or 32-bit integers: they are the
@@ -387,50 +395,13 @@ class MiniBatchPipeline:
                 b.step, b.input_nodes, b.output_nodes, b.subgraphs = item
                 staged = getattr(b.subgraphs[0], "staged", None) if self.load_stream is not None else None
                 if staged is not None:
-                    self._load_staged(b, staged)
+                    with rng("gpu-load"):
+                        self._load_staged(b, staged)
                     self.load_seconds += time.perf_counter() - t_load
                     self.load_batches += 1
                     self.queue.put(b)
                     continue
-                if self.hops == "sampled":
-                    id_lists = self._hop_ids(b)
-                    b.input_nodes = id_lists[-1]
-                else:
-                    if hasattr(b.input_nodes, "resolve"):      # FastNeighborSampler(defer_last_hop=True): the outermost hop's
-                        b.input_nodes = b.input_nodes.resolve()    # positions become ids here, off the sampling thread
-                    id_lists = self.hops(b) if self.hops is not None else [b.input_nodes]
-                inp, outp = b.input_nodes, b.output_nodes
-                if self.load_stream is not None:
-                    with torch.cuda.stream(self.load_stream):
-                        if self.reduce_last_hop is not None:
-                            # outermost hop (subgraphs are outermost first): reduced straight out of the cache, never fetched
-                            b.features = self._fetch_many(id_lists[:-1]) + [None]
-                            if self.record_access:
-                                self.cache.record_access(id_lists[-1], stream=self.load_stream)
-                            b.last_hop_reduced = self.cache.aggregate_data(id_lists[-1], b.subgraphs[0].indptr,
-                                                                           reduce=self.reduce_last_hop, stream=self.load_stream)
-                        else:
-                            b.features = self._fetch_many(id_lists)
-                        if self.labels is not None:
-                            b.labels = self.labels[outp].to(self.device, non_blocking=True)
-                        if self.build_blocks:
-                            L = len(b.subgraphs)
-                            b.blocks = [None if (h == L - 1 and self.reduce_last_hop is not None) else b.subgraphs[L - 1 - h].to_block(self.device)
-                                        for h in range(L)]
-                        b.ready = torch.cuda.Event()
-                        b.ready.record(self.load_stream)
-                        if self._ring is not None and getattr(self, "_late_release", None) is not None:
-                            self._ring.release(self._late_release, b.ready)
-                            self._late_release = None
-                    if not self._memory_bound_set:          # first loaded batch: how many of these fit in the memory budget
-                        self._memory_bound_set = True
-                        nbytes = sum(t.numel() * t.element_size() for t in list(b.features) + [b.last_hop_reduced] if t is not None)
-                        free, _total = torch.cuda.mem_get_info(self.device)
-                        self.queue.set_memory_bound(nbytes, self.memory_fraction * free)
-                else:
-                    b.features = self._fetch_many(id_lists)
-                    if self.labels is not None:
-                        b.labels = self.labels[outp]
+                self._load_generic(b)
                 self.load_seconds += time.perf_counter() - t_load     # this thread's host time per batch (diagnostics)
                 self.load_batches += 1
                 self.queue.put(b)                                   # blocks while the queue is full
@@ -440,6 +411,49 @@ class MiniBatchPipeline:
                 pass
         finally:
             self.queue.put(_DONE)
+
+    def _load_generic(self, b):
+        """The loading stage for a batch whose arrays arrive as host tensors (no staging buffer)."""
+        with rng("gpu-load"):
+            if self.hops == "sampled":
+                id_lists = self._hop_ids(b)
+                b.input_nodes = id_lists[-1]
+            else:
+                if hasattr(b.input_nodes, "resolve"):      # FastNeighborSampler(defer_last_hop=True): the outermost hop's
+                    b.input_nodes = b.input_nodes.resolve()    # positions become ids here, off the sampling thread
+                id_lists = self.hops(b) if self.hops is not None else [b.input_nodes]
+            inp, outp = b.input_nodes, b.output_nodes
+            if self.load_stream is not None:
+                with torch.cuda.stream(self.load_stream):
+                    if self.reduce_last_hop is not None:
+                        # outermost hop (subgraphs are outermost first): reduced straight out of the cache, never fetched
+                        b.features = self._fetch_many(id_lists[:-1]) + [None]
+                        if self.record_access:
+                            self.cache.record_access(id_lists[-1], stream=self.load_stream)
+                        b.last_hop_reduced = self.cache.aggregate_data(id_lists[-1], b.subgraphs[0].indptr,
+                                                                       reduce=self.reduce_last_hop, stream=self.load_stream)
+                    else:
+                        b.features = self._fetch_many(id_lists)
+                    if self.labels is not None:
+                        b.labels = self.labels[outp].to(self.device, non_blocking=True)
+                    if self.build_blocks:
+                        L = len(b.subgraphs)
+                        b.blocks = [None if (h == L - 1 and self.reduce_last_hop is not None) else b.subgraphs[L - 1 - h].to_block(self.device)
+                                    for h in range(L)]
+                    b.ready = torch.cuda.Event()
+                    b.ready.record(self.load_stream)
+                    if self._ring is not None and getattr(self, "_late_release", None) is not None:
+                        self._ring.release(self._late_release, b.ready)
+                        self._late_release = None
+                if not self._memory_bound_set:          # first loaded batch: how many of these fit in the memory budget
+                    self._memory_bound_set = True
+                    nbytes = sum(t.numel() * t.element_size() for t in list(b.features) + [b.last_hop_reduced] if t is not None)
+                    free, _total = torch.cuda.mem_get_info(self.device)
+                    self.queue.set_memory_bound(nbytes, self.memory_fraction * free)
+            else:
+                b.features = self._fetch_many(id_lists)
+                if self.labels is not None:
+                    b.labels = self.labels[outp]
 
     def _release_unloaded(self, item):
         """Pinned buffers of a sampled batch that will not be loaded go back to their rings."""
