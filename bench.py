@@ -119,6 +119,9 @@ def parse_args(argv=None):
     ap.add_argument("--mb-hip-graph", choices=["auto", "on", "off"], default="auto",
                     help="minibatch: the consumer's forward + loss + backward as ONE HIP graph on padded static block shapes "
                          "(dgll_amd.graphs.GraphedSampledStep), replayed per batch")
+    ap.add_argument("--mb-copy-inputs", action="store_true",
+                    help="minibatch: the captured step copies every batch into ONE static input set (round 4) instead of the loading stage "
+                         "writing batches in place into one of six sets")
     ap.add_argument("--mb-dense-kernel", choices=["auto", "4wave"], default="4wave",
                     help="minibatch: 4wave = every bf16 transform on the 4-wavefront MFMA kernel (dgll_hip_debug_tune(4, 1)) instead of the "
                          "persistent resident-weights one, whose workgroups need a whole CU's registers and LDS and wait for the loading "
@@ -1280,7 +1283,7 @@ def run_minibatch(args, c):
     graphed = None
     want_graph = args.mb_hip_graph == "on" or (args.mb_hip_graph == "auto" and fuse_last and not args.torch_adam)
     seen_rows = [0] * L          # the warm-up batches run launch by launch and show how far the hops fill their upper bounds
-    graph_misses = 0
+    graph_misses = in_place = 0
 
     def capture():
         # bounds of the captured step: what the warm-up batches reached + 10 % (a multiple of 64 rows), at most batch x prod(fan-outs);
@@ -1290,7 +1293,13 @@ def run_minibatch(args, c):
 
         rows = [args.mb_batch] + [-(-int(r * 1.1) // 64) * 64 for r in seen_rows[1:]]
         try:
-            return GraphedSampledStep(model, opt, args.mb_batch, fanouts, args.mb_feats, args.mb_classes, dtype=c.dtype, device=c.dev, rows=rows)
+            # queue of 4 loaded batches + the one being consumed + the one being loaded = 6 in-place input sets (+ set 0, the copy path's)
+            n_sets = 1 if args.mb_copy_inputs else 7
+            step_ = GraphedSampledStep(model, opt, args.mb_batch, fanouts, args.mb_feats, args.mb_classes, dtype=c.dtype, device=c.dev, rows=rows,
+                                       n_sets=n_sets)
+            if n_sets > 1:
+                pipe.use_static_sets(step_)       # batches loaded from now on land in a set; the ones already queued take the copy path
+            return step_
         except Exception as exc:  # noqa: BLE001  (auto: a stack that cannot capture the step runs it launch by launch, and says so)
             if args.mb_hip_graph == "on":
                 raise
@@ -1344,6 +1353,7 @@ def run_minibatch(args, c):
         blocks = b.blocks          # built by the loading stage on its own stream (the outermost one is None: reduced out of the cache)
         if blocks[L - 1] is None and b.last_hop_reduced is None:
             blocks[L - 1] = b.subgraphs[0].to_block(c.dev)
+        in_place += b.static_set is not None and args.warmup <= done < args.warmup + args.steps
         use_graph = graphed is not None and done < args.warmup + args.steps
         if use_graph:
             try:
@@ -1356,11 +1366,14 @@ def run_minibatch(args, c):
                 seen_rows[h] = max(seen_rows[h], int(b.features[h].shape[0]) if b.features[h] is not None else 0)
         if not use_graph:                     # (also the tail after the timed window: launch by launch, it feeds the launch tables)
             with ranges.rng("consume"):       # (DGLL_PROFILE_RANGES=1: the reference's 'gpu-compute' range, FeatureCache/gs.py:93)
-                out = model.forward_sampled(b.features, blocks, last_hop_reduced=b.last_hop_reduced)
-                loss = ops.cross_entropy(out, b.labels)
-                opt.zero_grad(set_to_none=True)
-                loss.backward()
-                opt.step()
+                if graphed is not None and b.static_set is not None:
+                    loss = graphed.eager(b)   # a batch that was loaded in place: the same step on its static set, launch by launch
+                else:
+                    out = model.forward_sampled(b.features, blocks, last_hop_reduced=b.last_hop_reduced)
+                    loss = ops.cross_entropy(out, b.labels)
+                    opt.zero_grad(set_to_none=True)
+                    loss.backward()
+                    opt.step()
         ev1.record()
         if args.warmup <= done < args.warmup + args.steps:
             events.append((ev0, ev1))
@@ -1439,8 +1452,11 @@ def run_minibatch(args, c):
                        k_threads, args.seed)) if k_threads > 0 else "one sequential stream on the interpreter's generator",
                    "outermost_hop_translation": "host" if device_graph is None else "device gather from pinned positions",
                    "consumer_step": ("one HIP graph on padded static block shapes (rows per hop %s, %d of %d timed batches beyond them ran "
-                                     "launch by launch) + the optimizer's launch" % (graphed.rows, graph_misses, steps)) if graphed is not None
+                                     "launch by launch) + the optimizer's launch; %d of the timed batches were written IN PLACE into one of %d "
+                                     "static input sets by the loading stage (no copy into the graph's inputs)" % (
+                                         graphed.rows, graph_misses, steps, in_place, len(graphed.sets) - 1)) if graphed is not None
                    else "launch by launch",
+                   "batches_loaded_in_place": in_place,
                    "cache_miss_rate": cache.get_miss_rate(), "cache_rule": cache_rule,
                    "cache_rows": int(min(cache.capability, args.mb_nodes)),
                    "epoch_time_s_153431_train_nodes": elapsed / steps * (153_431 / args.mb_batch),

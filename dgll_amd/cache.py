@@ -209,7 +209,7 @@ class GraphCacheServer:
                 out = out.contiguous()
         return out
 
-    def aggregate_data(self, nids, rowptr, reduce="mean", stream=None):
+    def aggregate_data(self, nids, rowptr, reduce="mean", stream=None, out=None):
         """[len(rowptr) - 1, D] rows: row i = mean (or sum) of the features of nids[rowptr[i]:rowptr[i+1]] -- fetch_data fused with
         the neighbour reduction of the layer that consumes the rows (sageconv.py:33-36).  For the OUTERMOST hop of a sampled batch,
         whose features enter the model through that reduction only: its fan-out x batch rows are read from the HBM cache / the pinned
@@ -225,9 +225,12 @@ class GraphCacheServer:
             esz = self.features.element_size()
             epv = 16 // esz
             ld = -(-self.total_dim // epv) * epv
-            store = torch.zeros((n_rows, ld), dtype=self.features.dtype, device=self.device) if ld != self.total_dim else \
-                torch.empty((n_rows, ld), dtype=self.features.dtype, device=self.device)
-            out = store[:, :self.total_dim] if ld != self.total_dim else store
+            if out is None:
+                store = torch.zeros((n_rows, ld), dtype=self.features.dtype, device=self.device) if ld != self.total_dim else \
+                    torch.empty((n_rows, ld), dtype=self.features.dtype, device=self.device)
+                out = store[:, :self.total_dim] if ld != self.total_dim else store
+            elif out.shape[0] != n_rows or out.shape[1] != self.total_dim or out.stride(1) != 1:
+                raise ValueError("aggregate_data(out=): [len(rowptr) - 1, D] rows, unit column stride")
             if n_rows <= 0:
                 return out
             if (self.total_dim * esz) % 4 != 0 or (self.features.stride(0) * esz) % 4 != 0:

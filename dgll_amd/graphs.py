@@ -137,7 +137,12 @@ class GraphedSampledStep:
     fanouts: the sampler's, in the model's order; the outermost hop arrives reduced (Batch.last_hop_reduced)."""
 
     def __init__(self, model, optimizer, batch_size, fanouts, in_feats, n_classes, dtype=torch.bfloat16, device="cuda", warmup=2,
-                 rows=None):
+                 rows=None, n_sets=1):
+        """n_sets > 1: that many independent sets of static inputs, each with its own captured graph.  Set 0 is the one `load()` copies
+        into; sets 1 .. n_sets-1 are written IN PLACE by the pipeline's loading stage (MiniBatchPipeline.use_static_sets: the cache
+        gather, the outermost hop's reduction, the row pointers and the labels of a batch land directly in a set; the consumer
+        replays that set's graph without copying anything -- at the Reddit shape the copies were 260 MB per batch) and handed
+        round: a set is rewritten only after the replay that read it has passed (`free` event)."""
         from . import ops
 
         if not torch.cuda.is_available():
@@ -156,53 +161,66 @@ class GraphedSampledStep:
             if len(rows) != L or any(int(r) < 1 for r in rows):
                 raise ValueError("rows: one bound per hop 0 .. L-1")
             self.rows = [min(int(r), cap) for r, cap in zip(rows, self.rows)]
+        self._ops = ops
+        self.sets = [self._make_set(order, in_feats, n_classes, dtype, warmup) for _ in range(max(1, int(n_sets)))]
+        first = self.sets[0]                                          # the copy path's set under the names earlier rounds used
+        self.feat_all, self.features, self.agg_all, self.reduced = first.feat_all, first.features, first.agg_all, first.reduced
+        self.blocks, self.labels, self.graph, self.loss = first.blocks, first.labels, first.graph, first.loss
+
+    def _make_set(self, order, in_feats, n_classes, dtype, warmup):
+        import types
+
+        ops, dev, L = self._ops, self.device, self.L
+        st = types.SimpleNamespace()
         total = sum(self.rows)
         store = ops.alloc_features(total, in_feats, dtype, dev)
         store.zero_()
-        self.feat_all = store
+        st.feat_all = store
         offs = [0]
         for r in self.rows:
             offs.append(offs[-1] + r)
-        self.features = [store[offs[h]:offs[h + 1]] for h in range(L)]             # consecutive row slices: stacked without a copy
+        st.features = [store[offs[h]:offs[h + 1]] for h in range(L)]               # consecutive row slices: stacked without a copy
         # the first layer's neighbour reductions of all hops in one buffer: the outermost hop's (it arrives ready-made, per hop L-1
         # row) is its tail, the model writes the others in front of it (GraphSage._forward_sampled_batched) -- no concatenation
-        self.agg_all = ops.alloc_features(total, in_feats, dtype, dev)
-        self.agg_all.zero_()
-        self.reduced = self.agg_all[offs[L - 1]:offs[L]]
-        self.reduced._dgll_stack = self.agg_all
-        self.blocks = [PaddedBlock.make(self.rows[h], order[h], dev, cols=self.rows[h + 1]) for h in range(L - 1)] + [None]
-        self.labels = torch.full((self.rows[0],), -100, dtype=torch.int64, device=dev)
+        st.agg_all = ops.alloc_features(total, in_feats, dtype, dev)
+        st.agg_all.zero_()
+        st.reduced = st.agg_all[offs[L - 1]:offs[L]]
+        st.reduced._dgll_stack = st.agg_all
+        st.blocks = [PaddedBlock.make(self.rows[h], order[h], dev, cols=self.rows[h + 1]) for h in range(L - 1)] + [None]
+        st.labels = torch.full((self.rows[0],), -100, dtype=torch.int64, device=dev)
+        st.free = None                 # event behind the last replay that read this set (the loading stage waits for it)
         # synthetic full-size contents for the warm-up and the capture (finite features, every label valid)
         store.normal_()
-        self.reduced.normal_()
-        self.labels.random_(0, int(n_classes))
-        self._ops = ops
+        st.reduced.normal_()
+        st.labels.random_(0, int(n_classes))
         side = torch.cuda.Stream(dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):                                 # same stream for warm-up and capture (see GraphedTrainStep)
             for _ in range(max(1, warmup)):
                 self._zero_grad()
-                self._forward_backward()
+                self._forward_backward(st)
             self._zero_grad()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, stream=side, capture_error_mode="thread_local"):
-            self.loss = self._forward_backward()
+        st.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(st.graph, stream=side, capture_error_mode="thread_local"):
+            st.loss = self._forward_backward(st)
         torch.cuda.synchronize(dev)
+        return st
 
     def _zero_grad(self):
         self.optimizer.zero_grad(set_to_none=True)
 
-    def _forward_backward(self):
-        out = self.model.forward_sampled(self.features, self.blocks, last_hop_reduced=self.reduced)
-        loss = self._ops.cross_entropy(out, self.labels)
+    def _forward_backward(self, st=None):
+        st = self.sets[0] if st is None else st
+        out = self.model.forward_sampled(st.features, st.blocks, last_hop_reduced=st.reduced)
+        loss = self._ops.cross_entropy(out, st.labels)
         loss.backward()
         return loss.detach()
 
     def load(self, batch):
-        """Copy one pipeline batch (features of hops 0 .. L-1, the reduced outermost hop, CSR blocks, labels) into the static inputs,
-        on the current stream."""
+        """Copy one pipeline batch (features of hops 0 .. L-1, the reduced outermost hop, CSR blocks, labels) into the static inputs
+        of set 0, on the current stream."""
         L = self.L
         n = [int(batch.features[h].shape[0]) for h in range(L)]
         for h in range(L):
@@ -216,12 +234,42 @@ class GraphedSampledStep:
             self.labels.fill_(-100)
         self.labels[:n[0]].copy_(batch.labels, non_blocking=True)
 
+    def eager(self, batch):
+        """The same step launch by launch (diagnostics: per-launch events) on the batch's own tensors -- or, for a batch that was
+        loaded in place, on its static set (padded shapes)."""
+        k = getattr(batch, "static_set", None)
+        if k is None:
+            out = self.model.forward_sampled(batch.features, batch.blocks, last_hop_reduced=batch.last_hop_reduced)
+            loss = self._ops.cross_entropy(out, batch.labels)
+        else:
+            st = self.sets[k]
+            out = self.model.forward_sampled(st.features, st.blocks, last_hop_reduced=st.reduced)
+            loss = self._ops.cross_entropy(out, st.labels)
+        self.optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        self._mark_free(k)
+        self.optimizer.step()
+        return loss.detach()
+
+    def _mark_free(self, k):
+        if k is not None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            self.sets[k].free = ev
+
     def __call__(self, batch):
-        """One training step on `batch`; returns the (static) loss tensor: read it before the next call."""
+        """One training step on `batch`; returns the (static) loss tensor: read it before the next call.  A batch the loading stage
+        wrote in place (batch.static_set = k) replays set k's graph as it is; any other batch is copied into set 0 first."""
         from .ranges import rng
 
+        k = getattr(batch, "static_set", None)
         with rng("consume"):
-            self.load(batch)
-            self.graph.replay()
+            if k is None:
+                self.load(batch)
+                st = self.sets[0]
+            else:
+                st = self.sets[k]
+            st.graph.replay()
+            self._mark_free(k)
             self.optimizer.step()
-        return self.loss
+        return st.loss

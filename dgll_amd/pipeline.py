@@ -180,11 +180,13 @@ class PinnedRing:
 
 
 class Batch:
-    __slots__ = ("input_nodes", "output_nodes", "subgraphs", "features", "labels", "ready", "step", "last_hop_reduced", "blocks")
+    __slots__ = ("input_nodes", "output_nodes", "subgraphs", "features", "labels", "ready", "step", "last_hop_reduced", "blocks",
+                 "static_set")
 
     def __init__(self):
         self.input_nodes = self.output_nodes = self.subgraphs = self.features = self.labels = self.ready = None
         self.last_hop_reduced = None
+        self.static_set = None      # use_static_sets: index of the GraphedSampledStep input set this batch was written into
         self.blocks = None          # build_blocks: [CSR block of hop 0, hop 1, ...] on the device (None where the hop needs none)
         self.step = 0
 
@@ -227,6 +229,8 @@ class MiniBatchPipeline:
         self._thread = None
         self._error = None
         self._stop = threading.Event()          # set when a stage failed or the consumer left: every producer winds down
+        self._static_step = None                # use_static_sets(): batches are written into a captured step's input sets in place
+        self._next_set = 1
         self.load_seconds, self.load_batches = 0.0, 0
 
     # ---- producer stage 1: sampling (buffer_queues.py:22-46) ---------------------------------------------------
@@ -478,6 +482,9 @@ class MiniBatchPipeline:
         translation of its positions).  The host arrays of the sugbraphs are replaced by these device views: the pinned buffer goes
         back to its ring as soon as the upload has run."""
         L = len(b.subgraphs)
+        step = self._static_step
+        if step is not None and self._load_into_set(b, staged, step):
+            return
         off, n = staged.offsets, staged.rows                       # n[h]: rows of hop h; rows of hop h + 1 = edges of hop h
         with torch.cuda.stream(self.load_stream):
             dev = staged.tensor().to(self.device, non_blocking=True)
@@ -528,6 +535,82 @@ class MiniBatchPipeline:
             nbytes = sum(t.numel() * t.element_size() for t in list(b.features) + [b.last_hop_reduced] if t is not None)
             free, _total = torch.cuda.mem_get_info(self.device)
             self.queue.set_memory_bound(nbytes, self.memory_fraction * free)
+
+    def use_static_sets(self, step):
+        """From the next loaded batch on, write every batch that fits IN PLACE into one of `step`'s (graphs.GraphedSampledStep, n_sets
+        >= 2) input sets 1 .. n_sets-1, round robin: the hop features by one cache gather per hop straight into the set's rows, the
+        outermost hop's reduction into its tail, row pointers and labels into its buffers.  The consumer then replays that set's graph
+        without copying a byte (Batch.static_set); a set is rewritten only behind the `free` event of the replay that read it.  Needs
+        the staged loading path (sampler_threads > 0, hops="sampled", a cache, build_blocks, reduce_last_hop).  None switches it off."""
+        if step is not None:
+            if len(step.sets) < 2:
+                raise ValueError("use_static_sets needs a GraphedSampledStep with n_sets >= 2 (set 0 stays the copy path's)")
+            # a set must not come round again before its batch was consumed: the loader runs at most (queue bound + 1) batches ahead
+            # of the batch the consumer holds
+            bound = self.queue.max_size if self.queue.adaptive else self.queue.size
+            if len(step.sets) - 1 < bound + 2:
+                raise ValueError("use_static_sets: %d in-place sets for a loaded-batch queue of up to %d: need at least %d (n_sets = %d)" % (
+                    len(step.sets) - 1, bound, bound + 2, bound + 3))
+        self._next_set = 1
+        self._static_step = step
+
+    def _load_into_set(self, b, staged, step):
+        """_load_staged's work with the outputs landing in a static input set of the captured step.  False: the batch does not fit."""
+        L = len(b.subgraphs)
+        off, n = staged.offsets, staged.rows
+        n_src = [int(b.subgraphs[L - 1 - h]._src.shape[0]) for h in range(L)]          # edges of hop h = rows of hop h + 1
+        if L != step.L or any(n[h] > step.rows[h] for h in range(L)) or any(n_src[h] > step.rows[h + 1] for h in range(L - 1)):
+            return False
+        last = b.subgraphs[0]
+        if self.reduce_last_hop is None or self.device_graph is None or getattr(last, "pending_positions", None) is None \
+                or getattr(last, "_finish", None) is None:
+            return False
+        k = self._next_set
+        self._next_set = k + 1 if k + 1 < len(step.sets) else 1
+        st = step.sets[k]
+        from .graphs import PaddedBlock
+
+        with torch.cuda.stream(self.load_stream):
+            if st.free is not None:
+                self.load_stream.wait_event(st.free)            # the replay that read this set's previous batch
+            dev = staged.tensor().to(self.device, non_blocking=True)
+            uploaded = torch.cuda.Event()
+            uploaded.record(self.load_stream)
+            ids = [dev[off["seeds"]:off["seeds"] + n[0]]]
+            for h in range(L - 1):
+                sg = b.subgraphs[L - 1 - h]
+                ids.append(dev[off["src"][h]:off["src"][h] + n_src[h]])
+                sg._src = ids[-1]
+            ptrs = [dev[off["ptr"][h]:off["ptr"][h] + n[h] + 1] for h in range(L)]
+            for h in range(L):
+                b.subgraphs[L - 1 - h].indptr = ptrs[h]
+                b.subgraphs[L - 1 - h].staged = None
+            ids.append(self._translate_on_device(last, device_inputs=(ids[L - 1], ptrs[L - 1][1:] - ptrs[L - 1][:-1])))
+            b.input_nodes = ids[-1]
+            self._staging.release(staged.token, uploaded)
+            for h in range(L):                                   # one gather per hop, straight into the set's rows of that hop
+                if self.record_access:
+                    self.cache.record_access(ids[h], stream=self.load_stream)
+                self.cache.fetch_data(ids[h], out=st.features[h][:n[h]], stream=self.load_stream)
+            if self.record_access:
+                self.cache.record_access(ids[-1], stream=self.load_stream)
+            self.cache.aggregate_data(ids[-1], ptrs[L - 1], reduce=self.reduce_last_hop, stream=self.load_stream, out=st.reduced[:n[L - 1]])
+            for h in range(L - 1):
+                PaddedBlock.pad(st.blocks[h], ptrs[h], n[h + 1])
+            if n[0] < step.rows[0]:
+                st.labels.fill_(-100)
+            if self._labels_dev is not None:
+                torch.index_select(self._labels_dev, 0, ids[0], out=st.labels[:n[0]])
+            elif self.labels is not None:
+                st.labels[:n[0]].copy_(self.labels[b.output_nodes].to(self.device, non_blocking=True))
+            b.static_set = k
+            b.features = [st.features[h][:n[h]] for h in range(L)] + [None]
+            b.last_hop_reduced = st.reduced[:n[L - 1]]
+            b.labels = st.labels[:n[0]]
+            b.blocks = list(st.blocks)
+            b.ready = torch.cuda.Event()
+            b.ready.record(self.load_stream)
+        return True
 
     def _fetch_many(self, id_lists):
         """Features of several id lists with ONE gather: the lists' rows are consecutive slices of one buffer (one id upload, one
@@ -603,13 +686,14 @@ class MiniBatchPipeline:
                 # The tensors were allocated on the load stream and are consumed on `cur`: tell the caching allocator, or
                 # the block returns to the load stream's pool when the consumer drops the batch -- while forward/backward
                 # kernels reading it may still be queued -- and the loader's next gather could be written into it.
-                for t in list(b.features or ()) + [b.last_hop_reduced]:
-                    if t is not None:
-                        t.record_stream(cur)
-                for blk in (b.blocks or ()):
-                    if blk is not None:
-                        blk.rowptr.record_stream(cur)
-                        blk.col.record_stream(cur)
-                if b.labels is not None and b.labels.is_cuda:
-                    b.labels.record_stream(cur)
+                if b.static_set is None:                     # (a static input set is long-lived: nothing to tell the allocator)
+                    for t in list(b.features or ()) + [b.last_hop_reduced]:
+                        if t is not None:
+                            t.record_stream(cur)
+                    for blk in (b.blocks or ()):
+                        if blk is not None:
+                            blk.rowptr.record_stream(cur)
+                            blk.col.record_stream(cur)
+                    if b.labels is not None and b.labels.is_cuda:
+                        b.labels.record_stream(cur)
             yield b

@@ -145,3 +145,59 @@ def test_replay_equals_eager_at_a_fan_out_above_128(cuda_device):
         assert got == pytest.approx(want, rel=1e-5)
         for a, b_ in zip([p.grad for p in model.parameters()], grads):
             assert float((a - b_).abs().max()) <= 2e-3 * float(b_.abs().max()) + 1e-7
+
+
+def test_batches_written_in_place_by_the_loading_stage_replay_to_the_same_losses(cuda_device):
+    """MiniBatchPipeline.use_static_sets: the loading stage writes a batch's hop features (one cache gather per hop), the outermost
+    hop's reduction, the row pointers and the labels straight into one of the captured step's input sets; the consumer replays that
+    set's graph without a copy.  Same batches (per-batch seeds), parameters frozen: every in-place replay gives the loss the copy
+    path gives for that batch, sets are handed round, and the launch-by-launch form on a static set agrees too."""
+    import numpy as np
+
+    from dgll_amd import nn as dnn, ops, synth
+    from dgll_amd.cache import GraphCacheServer
+    from dgll_amd.data import DGraph
+    from dgll_amd.dataloader import DataLoader
+    from dgll_amd.graphs import GraphedSampledStep
+    from dgll_amd.optim import FlatAdam
+    from dgll_amd.pipeline import MiniBatchPipeline
+    from dgll_amd.sampling import FastNeighborSampler
+
+    dev = cuda_device
+    nodes, feats, classes, batch, fanouts = 20000, 50, 7, 64, [5, 3, 3]
+    g = synth.products_like_graph(dev, seed=1, n=nodes, n_undirected=nodes * 12, locality=0.0, exact=True)
+    indptr, indices = g.rowptr.cpu().numpy(), g.col.cpu().numpy().astype(np.int64)
+    x = torch.randn(nodes, feats, generator=torch.Generator().manual_seed(0)).to(torch.bfloat16)
+    labels = torch.randint(0, classes, (nodes,), generator=torch.Generator().manual_seed(1))
+    dg = DGraph.from_csr(indptr, indices, labels=labels, features=x)
+    cache = GraphCacheServer(x, gpuid=dev.index or 0)
+    cache.auto_cache(g.degrees().cpu(), capacity=nodes // 2)
+    n_batches = 14
+    train = torch.randperm(nodes, generator=torch.Generator().manual_seed(2))[:n_batches * batch - 20]     # ragged last batch
+    torch.manual_seed(3)
+    model = dnn.GraphSage(feats, [32, 32, classes], fanouts).to(dev)
+    opt = FlatAdam(list(model.parameters()), lr=0.0)
+    dgraph = (torch.from_numpy(indptr).to(dev), torch.from_numpy(indices).to(dev))
+
+    def pipeline():
+        loader = DataLoader(dg, train, FastNeighborSampler(fanouts, defer_last_hop=True), batch_size=batch)
+        return MiniBatchPipeline(loader, cache=cache, labels=labels, queue_size=2, device=dev, hops="sampled", reduce_last_hop="mean",
+                                 sampler_threads=2, base_seed=5, epoch=0, device_graph=dgraph, build_blocks=True)
+
+    step = GraphedSampledStep(model, opt, batch, fanouts, feats, classes, device=dev, n_sets=5)
+    want = []
+    for b in pipeline():                                    # the copy path (set 0)
+        assert b.static_set is None
+        want.append(float(step(b)))
+    with pytest.raises(ValueError):
+        pipeline().use_static_sets(GraphedSampledStep(model, opt, batch, fanouts, feats, classes, device=dev, n_sets=3))   # too few for the queue
+    pipe = pipeline()
+    pipe.use_static_sets(step)
+    got, used = [], []
+    for i, b in enumerate(pipe):
+        assert b.static_set is not None and 1 <= b.static_set <= 4
+        used.append(b.static_set)
+        got.append(float(step(b)) if i % 3 else float(step.eager(b)))      # every third batch launch by launch on its static set
+    assert got == pytest.approx(want, rel=2e-3) and len(got) == n_batches
+    assert used[:8] == [1, 2, 3, 4, 1, 2, 3, 4]
+    torch.cuda.synchronize()
