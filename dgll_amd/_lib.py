@@ -89,6 +89,7 @@ SIGNATURES = {
     "dgll_hip_pack_weight_bf16": (_i32, [_vp, _vp, _i32, _i64, _i64, _i32, _i32, _vp, _i64, _i32]),
     "dgll_hip_gather_rows_mapped": (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp]),
     "dgll_hip_aggregate_rows_mapped": (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp]),
+    "dgll_hip_translate_positions": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i32, _vp]),
     "dgll_host_sample_neighbors": (_i32, [_vp, C.POINTER(_i32), _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _i64,
                                           C.POINTER(_i64)]),
     "dgll_host_translate_neighbors": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _vp]),

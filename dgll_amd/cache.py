@@ -209,6 +209,49 @@ class GraphCacheServer:
                 out = out.contiguous()
         return out
 
+    def fetch_data_into(self, nids_list, outs, stream=None):
+        """fetch_data for several id vectors at once, each into its own caller-owned [len(ids), D] row block (`outs`, e.g. row slices
+        of a captured step's static inputs): ONE snapshot of the cache state, one miss counter and one event for the lot, one launch
+        per block -- the bookkeeping of a fetch (lock, counter tensor, event, record_stream) costs more host time than its launch,
+        and the loading stage of the mini-batch pipeline is host-bound.  ids: int64 device tensors (local id space)."""
+        stream = torch.cuda.current_stream(self.device) if stream is None else stream
+        with torch.cuda.stream(stream):
+            with rng("cache-index"):
+                with self._pending_lock:
+                    slot_map, cache, ready = getattr(self, "_state", (None, None, None))
+                use_map = cache is not None
+                if ready is not None:
+                    stream.wait_event(ready)
+                host_map = self.nid_map
+                counter = torch.zeros(1, dtype=torch.int64, device=self.device) if (self.log and use_map) else None
+            total = 0
+            with torch.cuda.device(self.device), rng("cache-gpu"):
+                for nids, out in zip(nids_list, outs):
+                    n = int(nids.numel())
+                    if n == 0:
+                        continue
+                    if out.shape[0] != n or out.shape[1] != self.total_dim or out.stride(1) != 1 or out.dtype != self.features.dtype:
+                        raise ValueError("fetch_data_into: every output block is [len(ids), D] of the feature dtype, unit column stride")
+                    total += n
+                    code = _lib.lib.dgll_hip_gather_rows_mapped(
+                        stream.cuda_stream, cache.data_ptr() if use_map else None, cache.stride(0) if use_map else 0,
+                        self.features.data_ptr(), self.features.stride(0), nids.data_ptr(),
+                        slot_map.data_ptr() if use_map else None, host_map.data_ptr() if host_map is not None else None,
+                        out.data_ptr(), out.stride(0), n, self.total_dim, _dtype_code(out),
+                        counter.data_ptr() if counter is not None else None)
+                    _lib.check(code, "dgll_hip_gather_rows_mapped")
+            if use_map:
+                slot_map.record_stream(stream)
+                cache.record_stream(stream)
+            if self.log and total:
+                done = None
+                if counter is not None:
+                    done = torch.cuda.Event()
+                    done.record(stream)
+                with self._pending_lock:
+                    self._pending.append((counter, total, done))
+        return outs
+
     def aggregate_data(self, nids, rowptr, reduce="mean", stream=None, out=None):
         """[len(rowptr) - 1, D] rows: row i = mean (or sum) of the features of nids[rowptr[i]:rowptr[i+1]] -- fetch_data fused with
         the neighbour reduction of the layer that consumes the rows (sageconv.py:33-36).  For the OUTERMOST hop of a sampled batch,

@@ -166,6 +166,45 @@ static int gather_rows_impl(void* stream, const void* cache, int64_t ldc, const 
 // grid leaves wavefront slots of every CU to the compute stream instead of filling the chip.
 int g_tune_loader_blocks_per_cu = 0;
 
+namespace dgll {
+// positions -> neighbour ids of one sampled hop: one wavefront per seed row, lanes over its kept neighbours
+template <typename PT>
+__global__ __launch_bounds__(kBlock) void translate_positions_kernel(const int64_t* __restrict__ indptr, const int64_t* __restrict__ indices,
+                                                                     const int64_t* __restrict__ seeds, const int64_t* __restrict__ rowptr,
+                                                                     int64_t n_rows, const PT* __restrict__ pos, int64_t* __restrict__ out) {
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    for (int64_t r = (int64_t)blockIdx.x * kWavesPerBlock + wave; r < n_rows; r += (int64_t)gridDim.x * kWavesPerBlock) {
+        const int64_t b = rowptr[r], e = rowptr[r + 1];
+        if (e <= b) continue;
+        const int64_t* nb = indices + indptr[seeds[r]];
+        for (int64_t k = b + lane; k < e; k += kWave) out[k] = nb[(int64_t)pos[k]];
+    }
+}
+}  // namespace dgll
+
+DGLL_API int dgll_hip_translate_positions(void* stream, const int64_t* indptr, const int64_t* indices, const int64_t* seeds,
+                                          const int64_t* rowptr, int64_t n_rows, const void* positions, int pos_bytes, int64_t* out_ids) {
+    DGLL_REQUIRE(n_rows >= 0, "negative row count");
+    if (n_rows == 0) return DGLL_OK;
+    DGLL_REQUIRE(indptr && indices && seeds && rowptr && positions && out_ids, "NULL argument");
+    DGLL_REQUIRE(pos_bytes == 2 || pos_bytes == 4 || pos_bytes == 8, "positions are int16, int32 or int64");
+    const dim3 grid((uint32_t)std::min<int64_t>((n_rows + kWavesPerBlock - 1) / kWavesPerBlock, 65536));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (pos_bytes == 2)
+        hipLaunchKernelGGL(translate_positions_kernel<int16_t>, grid, dim3(kBlock), 0, s, indptr, indices, seeds, rowptr, n_rows,
+                           static_cast<const int16_t*>(positions), out_ids);
+    else if (pos_bytes == 4)
+        hipLaunchKernelGGL(translate_positions_kernel<int32_t>, grid, dim3(kBlock), 0, s, indptr, indices, seeds, rowptr, n_rows,
+                           static_cast<const int32_t*>(positions), out_ids);
+    else
+        hipLaunchKernelGGL(translate_positions_kernel<int64_t>, grid, dim3(kBlock), 0, s, indptr, indices, seeds, rowptr, n_rows,
+                           static_cast<const int64_t*>(positions), out_ids);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "translate_positions_kernel launch");
+    return DGLL_OK;
+}
+
 DGLL_API int dgll_hip_gather_rows(void* stream, const void* cache, int64_t ldc, const void* host, int64_t ldh,
                                   const int64_t* idx, const int64_t* slot, void* out, int64_t ldo, int64_t n, int feat,
                                   int dtype, unsigned long long* miss_count) {

@@ -343,18 +343,32 @@ class MiniBatchPipeline:
     def _translate_on_device(self, sg, device_inputs=None):
         """positions -> neighbour ids on the loading stream: ids[k] = indices[indptr[seed(k)] + position[k]]."""
         indptr, indices = self.device_graph
-        hop_seeds, counts = sg.pending_positions if device_inputs is None else device_inputs
         pos = sg._src
         compact = getattr(sg, "positions_compact", None)
         with torch.cuda.stream(self.load_stream):
-            seeds_d = hop_seeds.to(self.device, non_blocking=True)
-            cnt_d = counts.to(self.device, non_blocking=True)
-            if compact is not None:
-                pos_d = compact[0].to(self.device, non_blocking=True).to(torch.int64)
+            if device_inputs is not None and len(device_inputs) == 3:
+                # the hop's seeds and ROW POINTERS are on the device already (views of the staged upload): ONE launch
+                # (dgll_hip_translate_positions) instead of five torch ones; positions leave the host as 16- / 32-bit integers
+                seeds_d, ptr_d, n_rows = device_inputs
+                src = compact[0] if compact is not None else pos
+                pos_d = src.to(self.device, non_blocking=True)
+                ids = torch.empty(int(pos.numel()), dtype=torch.int64, device=self.device)
+                from . import _lib
+
+                with torch.cuda.device(self.device):
+                    _lib.check(_lib.lib.dgll_hip_translate_positions(self.load_stream.cuda_stream, indptr.data_ptr(), indices.data_ptr(),
+                                                                     seeds_d.data_ptr(), ptr_d.data_ptr(), int(n_rows), pos_d.data_ptr(),
+                                                                     pos_d.element_size(), ids.data_ptr()), "dgll_hip_translate_positions")
             else:
-                pos_d = pos.to(self.device, non_blocking=True)
-            start = indptr[seeds_d]
-            ids = indices[torch.repeat_interleave(start, cnt_d, output_size=int(pos.numel())) + pos_d]
+                hop_seeds, counts = sg.pending_positions if device_inputs is None else device_inputs
+                seeds_d = hop_seeds.to(self.device, non_blocking=True)
+                cnt_d = counts.to(self.device, non_blocking=True)
+                if compact is not None:
+                    pos_d = compact[0].to(self.device, non_blocking=True).to(torch.int64)
+                else:
+                    pos_d = pos.to(self.device, non_blocking=True)
+                start = indptr[seeds_d]
+                ids = indices[torch.repeat_interleave(start, cnt_d, output_size=int(pos.numel())) + pos_d]
             done = torch.cuda.Event()
             done.record(self.load_stream)
         if compact is not None:
@@ -502,7 +516,7 @@ class MiniBatchPipeline:
                 b.subgraphs[L - 1 - h].staged = None
             last = b.subgraphs[0]
             if self.device_graph is not None and getattr(last, "pending_positions", None) is not None and getattr(last, "_finish", None) is not None:
-                ids.append(self._translate_on_device(last, device_inputs=(ids[L - 1], ptrs[L - 1][1:] - ptrs[L - 1][:-1])))
+                ids.append(self._translate_on_device(last, device_inputs=(ids[L - 1], ptrs[L - 1], n[L - 1])))
             else:
                 ids.append(last.src_nodes())
                 self._drop_compact(last)
@@ -585,18 +599,22 @@ class MiniBatchPipeline:
             for h in range(L):
                 b.subgraphs[L - 1 - h].indptr = ptrs[h]
                 b.subgraphs[L - 1 - h].staged = None
-            ids.append(self._translate_on_device(last, device_inputs=(ids[L - 1], ptrs[L - 1][1:] - ptrs[L - 1][:-1])))
+            ids.append(self._translate_on_device(last, device_inputs=(ids[L - 1], ptrs[L - 1], n[L - 1])))
             b.input_nodes = ids[-1]
             self._staging.release(staged.token, uploaded)
-            for h in range(L):                                   # one gather per hop, straight into the set's rows of that hop
-                if self.record_access:
-                    self.cache.record_access(ids[h], stream=self.load_stream)
-                self.cache.fetch_data(ids[h], out=st.features[h][:n[h]], stream=self.load_stream)
             if self.record_access:
-                self.cache.record_access(ids[-1], stream=self.load_stream)
+                for t in ids:
+                    self.cache.record_access(t, stream=self.load_stream)
+            # one launch per hop straight into the set's rows of that hop (one bookkeeping pass for the three)
+            self.cache.fetch_data_into(ids[:L], [st.features[h][:n[h]] for h in range(L)], stream=self.load_stream)
             self.cache.aggregate_data(ids[-1], ptrs[L - 1], reduce=self.reduce_last_hop, stream=self.load_stream, out=st.reduced[:n[L - 1]])
             for h in range(L - 1):
-                PaddedBlock.pad(st.blocks[h], ptrs[h], n[h + 1])
+                # the set's row pointers in ONE launch: the batch's n[h] + 1 entries, then the edge count for the rows it does not use
+                # (the staged block holds rows_cap + 1 >= cap + 1 entries; what lies behind the batch's own is never selected)
+                cap = step.rows[h]
+                blk = st.blocks[h]
+                src = dev[off["ptr"][h]:off["ptr"][h] + cap + 1]
+                torch.where(self._arange(cap + 1) <= n[h], src, src[n[h]:n[h] + 1], out=blk.rowptr)
             if n[0] < step.rows[0]:
                 st.labels.fill_(-100)
             if self._labels_dev is not None:
@@ -611,6 +629,12 @@ class MiniBatchPipeline:
             b.ready = torch.cuda.Event()
             b.ready.record(self.load_stream)
         return True
+
+    def _arange(self, m):
+        ar = getattr(self, "_ar_cache", None)
+        if ar is None or ar.numel() < m:
+            ar = self._ar_cache = torch.arange(max(m, 1 << 17), dtype=torch.int64, device=self.device)
+        return ar[:m]
 
     def _fetch_many(self, id_lists):
         """Features of several id lists with ONE gather: the lists' rows are consecutive slices of one buffer (one id upload, one

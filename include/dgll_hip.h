@@ -287,6 +287,16 @@ int dgll_hip_aggregate_rows_mapped(void* stream, const void* cache, int64_t ldc,
                                    void* out, int64_t ldo, int64_t n_rows, int feat, int dtype, int reduce,
                                    unsigned long long* miss_count);
 
+/* The outermost hop of a natively sampled batch leaves the host as neighbour POSITIONS inside each seed's adjacency list
+ * (dgll_host_sample_batch_seeded with defer_last; reference loop: base_sampler.py:45-58 keeps `neighbors[j]`, the lookup
+ * `g.get_neighbors` is dgll/data/dgraph.py:49-62).  One launch turns them into node ids on the device:
+ *     out_ids[k] = indices[ indptr[ seeds[r] ] + positions[k] ]      for k in [rowptr[r], rowptr[r + 1])
+ * indptr / indices: the graph's CSR arrays in device memory (int64); seeds [n_rows] int64; rowptr [n_rows + 1] int64 (the hop's
+ * row pointers: rowptr[r + 1] - rowptr[r] kept neighbours of seed r); positions: int16 / int32 / int64 entries (pos_bytes = 2, 4,
+ * 8), rowptr[n_rows] of them.  Replaces five torch launches (gather of the starts, repeat_interleave, widening, add, gather). */
+int dgll_hip_translate_positions(void* stream, const int64_t* indptr, const int64_t* indices, const int64_t* seeds,
+                                 const int64_t* rowptr, int64_t n_rows, const void* positions, int pos_bytes, int64_t* out_ids);
+
 /* ---- f1 (host code): one hop of the reference's neighbour sampler, bit-exact with CPython 3.10's random.sample -------
  * For every seed in order: all neighbours if deg <= fanout (or fanout < 0), else random.sample(neighbors, fanout)
  * (/root/reference/dgll/sampling/base_sampler.py:45-58), drawn from the MT19937 state passed in (`random.getstate()`:
