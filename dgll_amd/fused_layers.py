@@ -24,6 +24,15 @@ from .optim import grad_slot_of
 FUSE_AGGREGATE_TRANSFORM = False
 
 
+# Backward of the aggregate-first layer, input gradient  g.Ws^T + A^T(scale . (g.Wn^T)).  Two orders (the mean is linear):
+#   "transform-first"  [gh | gagg] = g.[Ws^T | Wn^T] (one dual MFMA launch), then the transposed SpMM of gagg ACCUMULATES onto gh and
+#                      applies the ReLU mask of the layer below in its epilogue (rounds 2-4);
+#   "aggregate-first"  gt = A^T(scale . g) (plain weighted SpMM: no read-modify-write of the output, no gate operand, the 8-wavefront
+#                      instantiation), then ONE two-operand MFMA launch  gate(g.Ws^T + gt.Wn^T)  -- when g is no wider than the layer's input.
+# dgll_amd.fused_layers.BACKWARD_ORDER = "auto" picks aggregate-first whenever it applies; measured in bench.py's step (CHANGELOG).
+BACKWARD_ORDER = __import__("os").environ.get("DGLL_BACKWARD_ORDER", "auto")      # auto | transform-first
+
+
 def _aligned(t):
     return (t.stride(0) * t.element_size()) % 16 == 0 and t.data_ptr() % 16 == 0 and t.stride(1) == 1
 
@@ -64,7 +73,17 @@ class _SageGraphLayer(torch.autograd.Function):
             gws = dense.grad_weight(h, g, out=grad_slot_of(ctx.wparams[0])) if ctx.needs_input_grad[1] else None
             gwn = dense.grad_weight(agg, g, out=grad_slot_of(ctx.wparams[1])) if ctx.needs_input_grad[2] else None
         gh = None
-        if ctx.needs_input_grad[0]:
+        agg_first = (BACKWARD_ORDER != "transform-first" and ctx.needs_input_grad[0] and wsd.shape[1] <= wsd.shape[0]
+                     and dense._mfma_ok(g) and wsd.shape[0] <= 256 and _aligned(g) and (not ctx.gate_input or h.stride(1) == 1))
+        if agg_first:
+            gt, _ = graph.transpose()
+            tval = gt.val
+            if ctx.reduce == "mean":
+                scale = graph.mean_scale_transposed()
+                tval = scale if tval is None else tval * scale
+            gtg = ops.spmm_raw(gt, g, val=tval, reduce="sum")                       # A^T (scale . g): plain weighted gather
+            gh = dense.transform_bf16(g, wsd, gtg, wnd, out_gate=h if ctx.gate_input else None)
+        elif ctx.needs_input_grad[0]:
             gh, gagg = dense.input_grads(g, wsd, wnd)      # self path, neighbour path: one MFMA launch, g read once
             gt, _ = graph.transpose()
             tval = gt.val
