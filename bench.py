@@ -412,7 +412,7 @@ def roofline_record(dom, sig, kernel_desc, compulsory, world, extra=None):
            "kernel": kernel_desc, "kernel_fragment": dom["kernel_fragment"], "launches_timed": dom["count"],
            "avg_launch_ms": dom["avg_ms"], "algorithmic_bytes_per_launch": dom["algorithmic_bytes"],
            "compulsory_bytes_per_launch": compulsory, "edges_per_s_this_kernel": dom["nnz"] / (dom["avg_ms"] * 1e-3),
-           "build_stamp": build_stamp()}
+           "build_stamp": build_stamp(), "traffic_signature": sig}
     # `frac` is a FRACTION (<= 1) of the HBM peak:
     #   * when profiles/traffic.json holds counter traffic for this workload, kernel instantiation AND this build of libdgll_hip.so:
     #     frac = counter bytes per launch / live launch time / peak  (= frac_l2_miss_path).  The bytes are what the L2s requested from
@@ -1075,6 +1075,15 @@ def run_rmat27(args, c):
         ops.spmm_raw(blk, transform(x), reduce="mean", out=y)                # S = X.W (gcnconv.py:30), Y = A.S (:31)
         return y
 
+    calibrate_rows = None
+    if args.calibrate and c.world == 1:       # the PMC passes' known-byte launches, in this workload's kernel instantiation (F = 128)
+        import copy
+
+        a2 = copy.copy(args)
+        a2.hidden = feat
+        calibrate_rows = min(n, 1 << 22)
+        calibrate_launches(a2, c, calibrate_rows)
+
     def step_aggregate_first():
         return transform(ops.spmm_raw(blk, x, reduce="mean", out=y))         # the same layer as (A.X).W: own rows only
 
@@ -1148,6 +1157,7 @@ def run_rmat27(args, c):
          "graph_build_seconds": build_s, "reorder_seconds_one_off": reorder_s,
          "parallelism": "single GPU" if c.world == 1 else "row blocks x%d, X replicated" % c.world, "layer_order": order,
          "row_bounds": bounds, "block_nnz": block_nnz, "edge_cost": edge_cost, "row_cost": row_cost, "rebalance": rebalance,
+         "calibrate_rows": calibrate_rows,
          "peak_memory_GB": torch.cuda.max_memory_allocated() / 1e9})
     result.update({"roofline": roofline, "spmm_launch_table": table, "dense_launch_table": dense_table, "per_rank": per_rank,
                    "slowest_rank": slow["rank"],

@@ -72,12 +72,17 @@ def main():
     # calibration: the first three launches of the unweighted F = hidden SpMM kernel read n*hidden*esz + n*12 bytes (rows,
     # rowptr, col) and write n*hidden*esz
     t = "unsigned short" if esz == 2 else "float"
-    calib_frag = "spmm_csr_kernel<%s, %s, %d, 32, false, 4, false, false>" % (t, t, 16 // esz)
+    vecs = -(-hidden // (16 // esz))
+    lpr = 4
+    while lpr < 64 and lpr < vecs:
+        lpr <<= 1
+    calib_frag = "spmm_csr_kernel<%s, %s, %d, %d, false, 4, false, false>" % (t, t, 16 // esz, lpr)
+    n_cal = cfg.get("calibrate_rows") or n           # rmat27 calibrates on a slice of the rows
     calib_kernel = next((k for k in fetch if calib_frag in k), None)
     ratio_r, ratio_w, calib = 0.5, 1.0, None
     if calib_kernel and len(fetch[calib_kernel]) >= 3:
-        known_r = n * hidden * esz + n * 12
-        known_w = n * hidden * esz
+        known_r = n_cal * hidden * esz + n_cal * 12
+        known_w = n_cal * hidden * esz
         fr = sum(v for _, v, _ in fetch[calib_kernel][:3]) / 3 * 1024
         wr = sum(v for _, v, _ in write[calib_kernel][:3]) / 3 * 1024
         ratio_r, ratio_w = fr / known_r, wr / known_w
@@ -88,10 +93,12 @@ def main():
             raise SystemExit("implausible calibration (%.3f / %.3f): the first three launches of %s are not the known-byte launches" % (ratio_r, ratio_w, calib_kernel))
     else:
         print("NO calibration launches found: falling back to ratio_read 0.5 / ratio_write 1.0")
-    sig = {"workload": cfg.get("workload_id", "sage"), "nodes": n, "nnz": cfg["nnz"], "locality": cfg["locality"],
-           "permuted_ids": cfg["permuted_ids"], "reorder": cfg["reorder"], "hidden": hidden, "dtype": bench["dtype"]}
-    if "heads" in cfg:
-        sig["heads"] = cfg["heads"]
+    sig = (bench.get("roofline") or {}).get("traffic_signature")      # what bench.py matches an entry against (round 5 on)
+    if sig is None:
+        sig = {"workload": cfg.get("workload_id", "sage"), "nodes": n, "nnz": cfg["nnz"], "locality": cfg["locality"],
+               "permuted_ids": cfg["permuted_ids"], "reorder": cfg["reorder"], "hidden": hidden, "dtype": bench["dtype"]}
+        if "heads" in cfg:
+            sig["heads"] = cfg["heads"]
     entries = []
     for name, v in bench["spmm_launch_table"].items():
         frag = v.get("kernel_fragment")
