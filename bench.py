@@ -352,8 +352,10 @@ def build_stamp():
         return None
 
 
-def spmm_kernel_fragment(feat, dtype_name, weighted, extra):
-    """Name fragment of the spmm_csr_kernel instantiation a launch of this kind runs (wave-per-row variant, 16-byte rows)."""
+def spmm_kernel_fragment(feat, dtype_name, weighted, extra, avg_len=None):
+    """Name fragment of the kernel instantiation a launch of this kind runs (16-byte rows): the wave-per-row kernel, the
+    row-per-slot kernel for short rows (spmm.hip's rule: <= 24 edges per row on average at up to 16 lanes per row, <= 4.5 at 32 --
+    RMAT-27's 16.8 edges per row at F = 128), the flattened kernel for fp32 rows of 16 / 32 lanes (>= 8 edges per row)."""
     bf = "bfloat16" in dtype_name
     epv = 8 if bf else 4
     vecs = -(-feat // epv)
@@ -361,7 +363,12 @@ def spmm_kernel_fragment(feat, dtype_name, weighted, extra):
     while lpr < 64 and lpr < vecs:
         lpr <<= 1
     t = "unsigned short" if bf else "float"
-    return "spmm_csr_kernel<%s, %s, %d, %d, %s, 4, %s, false>" % (t, t, epv, lpr, "true" if weighted else "false", "true" if extra else "false")
+    w, e = "true" if weighted else "false", "true" if extra else "false"
+    if avg_len is not None and ((lpr <= 16 and avg_len <= 24.0) or (lpr == 32 and avg_len <= 4.5)):
+        return "spmm_rowslot_kernel<%s, %s, %d, %d, %s, %s>" % (t, t, epv, lpr, w, e)
+    if avg_len is not None and not bf and 8 < vecs <= 32 and avg_len >= 8.0:
+        return "spmm_csr_flat_kernel<%s, %s, %d, %d, %s, 4, %s>" % (t, t, epv, 16 if vecs <= 16 else 32, w, e)
+    return "spmm_csr_kernel<%s, %s, %d, %d, %s, 4, %s, false>" % (t, t, epv, lpr, w, e)
 
 
 def gat_kernel_fragment(heads, fo, dtype_name, kind, packed=False):
@@ -461,7 +468,8 @@ def launch_tables(launches, local_rows, heads_of=None):
             name = "spmm F=%d %s %s%s nnz=%d" % (feat, dt.replace("torch.", ""), "weighted" if weighted else "unweighted",
                                                  (" " + extra) if extra else "", tag_nnz)
             table[name] = {"count": cnt, "avg_ms": avg_ms, "nnz": tag_nnz, "feat": feat, "weighted": bool(weighted),
-                           "epilogue": extra, "kernel_fragment": spmm_kernel_fragment(feat, dt, weighted, bool(extra))}
+                           "epilogue": extra,
+                           "kernel_fragment": spmm_kernel_fragment(feat, dt, weighted, bool(extra), tag_nnz / max(local_rows, 1))}
         elif tag[0] == "fused_sage":
             # aggregate -> transform in one launch: the SpMM's section-8(d) bytes (every edge one feature row; the aggregated row is
             # still written for the backward pass) plus the transform's own operands (self rows read, output rows written)

@@ -39,6 +39,13 @@ def test_kernel_fragments_name_the_instantiations(bench):
     assert bench.spmm_kernel_fragment(47, "torch.bfloat16", False, False) == \
         "spmm_csr_kernel<unsigned short, unsigned short, 8, 8, false, 4, false, false>"
     assert bench.spmm_kernel_fragment(100, "torch.float32", False, False) == "spmm_csr_kernel<float, float, 4, 32, false, 4, false, false>"
+    # the launch's average row length picks the kernel as spmm.hip does: RMAT-27 (16.8 edges per row, F = 128) runs the row-per-slot
+    # kernel, fp32 rows of 16 / 32 lanes the flattened one, the products-sized graph (50.5 per row, bf16) the wave-per-row kernel
+    assert bench.spmm_kernel_fragment(128, "torch.bfloat16", False, False, 16.8) == "spmm_rowslot_kernel<unsigned short, unsigned short, 8, 16, false, false>"
+    assert bench.spmm_kernel_fragment(256, "torch.bfloat16", True, False, 3.2) == "spmm_rowslot_kernel<unsigned short, unsigned short, 8, 32, true, false>"
+    assert bench.spmm_kernel_fragment(100, "torch.float32", False, False, 50.5) == "spmm_csr_flat_kernel<float, float, 4, 32, false, 4, false>"
+    assert bench.spmm_kernel_fragment(256, "torch.float32", False, False, 50.5) == "spmm_csr_kernel<float, float, 4, 64, false, 4, false, false>"
+    assert bench.spmm_kernel_fragment(256, "torch.bfloat16", True, False, 50.5) == "spmm_csr_kernel<unsigned short, unsigned short, 8, 32, true, 4, false, false>"
     # 8 heads x 32 bf16: 4 lanes per head, 8 heads per wavefront; 1 head x 48 with scores in the row padding: the in-row form
     assert bench.gat_kernel_fragment(8, 32, "torch.bfloat16", 2) == "gat2_kernel<unsigned short, unsigned short, 8, 32, 8, 4, 2, false>"
     assert bench.gat_kernel_fragment(1, 48, "torch.bfloat16", 0, packed=True) == "gat2_kernel<unsigned short, unsigned short, 8, 8, 1, 4, 0, true>"

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Copy the summaries of tools/pmc_bench.sh runs into profiles/ (tracked) and rebuild profiles/traffic.json.
-#   usage: bash tools/collect_profiles.sh <sage-tag> <gat-tag> [round]       e.g.  r03t_sage r03t_gat r03
+#   usage: bash tools/collect_profiles.sh <sage-tag> <gat-tag> [round] [rmat27-tag]       e.g.  r05p_sage r05p_gat r05 r05p_rmat
 set -eu
-SAGE=$1; GAT=$2; R=${3:-r03}
+SAGE=$1; GAT=$2; R=${3:-r03}; RMAT=${4:-}
 python tools/pmc_parse.py gpurun_out/$GAT --round $R --write | tail -8
 python tools/pmc_parse.py gpurun_out/$SAGE --round $R --write | tail -6
 cp gpurun_out/$SAGE/kernel_stats.csv profiles/${R}_bench_kernel_stats.csv
@@ -15,7 +15,13 @@ for c in FETCH_SIZE WRITE_SIZE TCC_HIT_sum_TCC_MISS_sum; do
 done
 # the scaling tools' logs, the default line and the step trace of the same call (gpurun_out/<round>p/), when present
 E=gpurun_out/${R}p
-for f in scaling_model.log scaling_trace_n8.log partition_stats.log step_trace.log; do
+if [ -n "$RMAT" ]; then
+  python tools/pmc_parse.py gpurun_out/$RMAT --round $R --write | tail -4
+  cp gpurun_out/$RMAT/kernel_stats.csv profiles/${R}_rmat27_kernel_stats.csv
+  cp gpurun_out/$RMAT/bench_under_rocprof.json profiles/${R}_rmat27_bench_under_rocprof.json
+  for c in FETCH_SIZE WRITE_SIZE TCC_HIT_sum_TCC_MISS_sum; do cp gpurun_out/$RMAT/pmc_$c.csv profiles/${R}_rmat27_pmc_$c.csv; done
+fi
+for f in scaling_model.log rmat27_scaling_model.log scaling_trace_n8.log partition_stats.log step_trace.log; do
   [ -f $E/$f ] && grep -v "amdgpu.ids" $E/$f > profiles/${R}_$f
 done
 [ -f $E/bench_default.json ] && cp $E/bench_default.json profiles/${R}_bench_default.json
