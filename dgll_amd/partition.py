@@ -109,9 +109,9 @@ def part_costs(graph, part, n_parts):
     return edges, rows, halo
 
 
-def rebalance_parts(graph, part, n_parts, cost=None, tol=0.02, max_iters=40, log=None):
+def rebalance_parts(graph, part, n_parts, cost=None, tol=0.01, max_iters=40, log=None):
     """Move boundary nodes from the most expensive part to the cheapest one until every part's MODELLED step cost
-    (cost['edge'] . own edges + cost['halo_row'] . halo rows + cost['row'] . own rows) is within `tol` of the mean.  The nodes moved
+    (cost['edge'] . own edges + cost['halo_row'] . halo rows + cost['row'] . own rows) is within `tol` (1 %) of the mean.  The nodes moved
     from p to q are those of p with the most neighbours already in q relative to p (least damage to the cut), lightest first among
     equals; a move's effect on the halo counts is not predictable node by node, so every iteration moves a damped share of the
     difference and the costs are recounted.  Deterministic.  Returns the new node -> part vector."""
