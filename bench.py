@@ -674,6 +674,9 @@ def make_engine(args, c, full, feats_all, labels_all, bounds):
     torch.cuda.empty_cache()
     part = ddist.partition_rows(own_rowptr, own_col, None, bounds, c.rank)
     del own_rowptr, own_col
+    # which form of the first two layers (recompute on halo rows / exchange hidden-width rows) wins depends on the fabric: unless the
+    # caller fixed it, let the live ranks decide during warm-up (DistGraph.resolve_halo_mode, called by the workload)
+    os.environ.setdefault("DGLL_HALO_MODE", "auto")
     engine = ddist.DistGraph(part, c.dev)
     engine.verify()          # exchange lists agree across ranks + the start-up self-test of the chosen exchange form (DGLL_EXCHANGE)
     x_local = ops.alloc_features(part.n_own, args.in_feats, c.dtype, c.dev, pad_to=args.feat_align)
@@ -928,6 +931,8 @@ def run_gat(args, c):
 
     if args.calibrate and c.world == 1:
         calibrate_launches(args, c, n)
+    if engine is not None:
+        engine.resolve_halo_mode(step)          # DGLL_HALO_MODE=auto: recompute / exchange of the first layer timed on the live ranks
     elapsed, loss, timer, trace = timed_steps(args, c, step)
     global_loss = loss.detach().double() / c.world
     if c.world > 1:
