@@ -66,7 +66,7 @@ def _check_two_ranks(res):
 
 
 def test_bench_two_ranks_on_one_gpu_agree_with_one_rank():
-    env = dict(os.environ, DGLL_BENCH_BACKEND="gloo")
+    env = dict(os.environ, DGLL_BENCH_BACKEND="gloo", DGLL_HALO_MODE="recompute")   # (auto adds warm-up steps: the loss is compared across rank counts)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SHAPE
     _check_two_ranks(subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env))
@@ -75,7 +75,7 @@ def test_bench_two_ranks_on_one_gpu_agree_with_one_rank():
 def test_bench_gpus_flag_starts_the_ranks_itself():
     """`python bench.py --gpus 2` with no torchrun around it (the shape of the driver's N = 1 command): the parent spawns the
     two ranks, relays rank 0's line and exits with their status (MQGCN.py:161-163 `mp.spawn(run, nprocs=num_gpus)`)."""
-    env = dict(os.environ, DGLL_BENCH_BACKEND="gloo")
+    env = dict(os.environ, DGLL_BENCH_BACKEND="gloo", DGLL_HALO_MODE="recompute")   # (auto adds warm-up steps: the loss is compared across rank counts)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SHAPE, capture_output=True, text=True,
@@ -89,6 +89,20 @@ def test_bench_gpus_flag_starts_the_ranks_itself():
     assert d["n_gpus"] == 2 and "async" in d["config"]["gradient_sharing"] and d["loss"] == d["loss"]
 
 
+def test_bench_lets_the_live_ranks_choose_the_halo_mode():
+    """bench.py at N > 1 defaults to DGLL_HALO_MODE=auto: the first two layers' two forms (recompute on halo rows / exchange of
+    hidden-width rows) are both timed during warm-up, max over ranks, and the faster one runs the timed steps; the line says which."""
+    env = dict(os.environ, DGLL_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "DGLL_HALO_MODE"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SHAPE, capture_output=True, text=True,
+                         timeout=900, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    hm = _last_json(res.stdout)["config"]["halo_mode"]
+    assert hm["requested"] == "auto" and hm["mode"] in ("recompute", "exchange") and set(hm["timings_ms"]) == {"recompute", "exchange"}
+    assert (hm["timings_ms"]["recompute"] <= hm["timings_ms"]["exchange"]) == (hm["mode"] == "recompute")
+
+
 def test_bench_refuses_a_world_size_that_contradicts_gpus():
     env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SHAPE, capture_output=True, text=True,
@@ -99,7 +113,7 @@ def test_bench_refuses_a_world_size_that_contradicts_gpus():
 def test_bench_eight_ranks_on_one_gpu():
     """The world-size-8 shape of BASELINE config 3 end to end (8 ranks share the one GPU over gloo: a functional run of the
     partitioner, the halo exchange with seven peers, RaCoM and the JSON contract -- never a reported number)."""
-    env = dict(os.environ, DGLL_BENCH_BACKEND="gloo")
+    env = dict(os.environ, DGLL_BENCH_BACKEND="gloo", DGLL_HALO_MODE="recompute")   # (auto adds warm-up steps: the loss is compared across rank counts)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"] + SHAPE, capture_output=True, text=True,
@@ -125,7 +139,7 @@ def test_bench_gat_workload_one_and_two_ranks():
     assert passes == {"fwd", "bwd_rows", "bwd_cols"}
     assert "gat2_kernel" in d["roofline"]["kernel_fragment"] and d["roofline"]["frac_definition"]
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0 and "gat_pass_over_spmm" in d
-    env = dict(os.environ, DGLL_BENCH_BACKEND="gloo")
+    env = dict(os.environ, DGLL_BENCH_BACKEND="gloo", DGLL_HALO_MODE="recompute")   # (auto adds warm-up steps: the loss is compared across rank counts)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
     res2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + shape, capture_output=True, text=True,
