@@ -22,6 +22,21 @@ REDUCE_SUM, REDUCE_MEAN = 0, 1
 EPI_NONE, EPI_BIAS, EPI_RELU = 0, 1, 2
 
 
+class BatchLoad(C.Structure):
+    """include/dgll_hip.h: struct dgll_batch_load (dgll_hip_load_sampled_batch)."""
+    _fields_ = [("staged_host", C.c_void_p), ("staged_entries", C.c_int64), ("staged_dev", C.c_void_p),
+                ("pos_host", C.c_void_p), ("n_outer", C.c_int64), ("pos_bytes", C.c_int), ("pos_dev", C.c_void_p),
+                ("indptr", C.c_void_p), ("indices", C.c_void_p),
+                ("n_hops", C.c_int), ("rows", C.c_int64 * 8), ("seeds_off", C.c_int64), ("src_off", C.c_int64 * 8), ("ptr_off", C.c_int64 * 8),
+                ("cache", C.c_void_p), ("ldc", C.c_int64), ("host", C.c_void_p), ("ldh", C.c_int64), ("slot", C.c_void_p),
+                ("host_map", C.c_void_p), ("feat", C.c_int), ("dtype", C.c_int), ("miss_count", C.c_void_p),
+                ("feat_out", C.c_void_p * 8), ("ld_feat", C.c_int64),
+                ("reduced_out", C.c_void_p), ("ld_reduced", C.c_int64), ("reduce", C.c_int),
+                ("ids_out", C.c_void_p),
+                ("rowptr_out", C.c_void_p * 8), ("rowptr_cap", C.c_int64 * 8),
+                ("labels", C.c_void_p), ("labels_out", C.c_void_p), ("labels_cap", C.c_int64), ("label_fill", C.c_int64)]
+
+
 class DgllHipError(RuntimeError):
     pass
 
@@ -90,6 +105,7 @@ SIGNATURES = {
     "dgll_hip_gather_rows_mapped": (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp]),
     "dgll_hip_aggregate_rows_mapped": (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp]),
     "dgll_hip_translate_positions": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i32, _vp]),
+    "dgll_hip_load_sampled_batch": (_i32, [_vp, _vp]),
     "dgll_host_sample_neighbors": (_i32, [_vp, C.POINTER(_i32), _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _i64,
                                           C.POINTER(_i64)]),
     "dgll_host_translate_neighbors": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _vp]),

@@ -252,6 +252,32 @@ class GraphCacheServer:
                     self._pending.append((counter, total, done))
         return outs
 
+    def native_load_begin(self, stream):
+        """What a native loading call (dgll_hip_load_sampled_batch) needs of the server, with fetch_data's bookkeeping done once:
+        (cache ptr, ldc, host ptr, ldh, slot ptr, host_map ptr, miss-counter tensor or None, keep-alive tuple).  `stream` is made to
+        wait for the current (slot map, cache block) pair; call native_load_end afterwards."""
+        with self._pending_lock:
+            slot_map, cache, ready = getattr(self, "_state", (None, None, None))
+        use_map = cache is not None
+        if ready is not None:
+            stream.wait_event(ready)
+        counter = torch.zeros(1, dtype=torch.int64, device=self.device) if (self.log and use_map) else None
+        return (cache.data_ptr() if use_map else None, cache.stride(0) if use_map else 0, self.features.data_ptr(), self.features.stride(0),
+                slot_map.data_ptr() if use_map else None, self.nid_map.data_ptr() if self.nid_map is not None else None, counter,
+                (slot_map, cache))
+
+    def native_load_end(self, stream, counter, keep, tries, done=None):
+        slot_map, cache = keep
+        if cache is not None:
+            slot_map.record_stream(stream)
+            cache.record_stream(stream)
+        if self.log and tries:
+            if counter is not None and done is None:
+                done = torch.cuda.Event()
+                done.record(stream)
+            with self._pending_lock:
+                self._pending.append((counter, int(tries), done if counter is not None else None))
+
     def aggregate_data(self, nids, rowptr, reduce="mean", stream=None, out=None):
         """[len(rowptr) - 1, D] rows: row i = mean (or sum) of the features of nids[rowptr[i]:rowptr[i+1]] -- fetch_data fused with
         the neighbour reduction of the layer that consumes the rows (sageconv.py:33-36).  For the OUTERMOST hop of a sampled batch,

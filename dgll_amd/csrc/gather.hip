@@ -205,6 +205,67 @@ DGLL_API int dgll_hip_translate_positions(void* stream, const int64_t* indptr, c
     return DGLL_OK;
 }
 
+namespace dgll {
+// dst[i] = src[i] for i <= n, src[n] (the edge count) for n < i <= cap: a batch's row pointers on a static block's shape
+__global__ __launch_bounds__(kBlock) void pad_rowptr_kernel(const int64_t* __restrict__ src, int64_t n, int64_t* __restrict__ dst, int64_t cap) {
+    const int64_t last = src[n];
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i <= cap; i += (int64_t)gridDim.x * kBlock) dst[i] = i <= n ? src[i] : last;
+}
+// dst[i] = labels[ids[i]] for i < n, fill for n <= i < cap
+__global__ __launch_bounds__(kBlock) void gather_labels_kernel(const int64_t* __restrict__ labels, const int64_t* __restrict__ ids, int64_t n,
+                                                               int64_t* __restrict__ dst, int64_t cap, int64_t fill) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < cap; i += (int64_t)gridDim.x * kBlock) dst[i] = i < n ? labels[ids[i]] : fill;
+}
+}  // namespace dgll
+
+DGLL_API int dgll_hip_load_sampled_batch(void* stream, const dgll_batch_load* b) {
+    DGLL_REQUIRE(b != nullptr, "NULL batch");
+    const int L = b->n_hops;
+    DGLL_REQUIRE(L >= 1 && L <= 8, "1 .. 8 hops");
+    DGLL_REQUIRE(b->staged_host && b->staged_dev && b->staged_entries > 0, "staging buffer");
+    DGLL_REQUIRE(b->n_outer == 0 || (b->pos_host && b->pos_dev && b->ids_out && b->indptr && b->indices), "outermost hop arguments");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    DGLL_HIP_TRY(hipMemcpyAsync(b->staged_dev, b->staged_host, (size_t)b->staged_entries * 8, hipMemcpyHostToDevice, s));
+    if (b->n_outer > 0)
+        DGLL_HIP_TRY(hipMemcpyAsync(b->pos_dev, b->pos_host, (size_t)b->n_outer * (size_t)b->pos_bytes, hipMemcpyHostToDevice, s));
+    const int64_t* st = b->staged_dev;
+    const int64_t* ids_of[8];
+    ids_of[0] = st + b->seeds_off;
+    for (int h = 1; h < L; ++h) ids_of[h] = st + b->src_off[h - 1];           // rows of hop h = the sources around hop h - 1
+    int code = DGLL_OK;
+    if (b->n_outer > 0) {
+        code = dgll_hip_translate_positions(stream, b->indptr, b->indices, ids_of[L - 1], st + b->ptr_off[L - 1], b->rows[L - 1], b->pos_dev,
+                                            b->pos_bytes, b->ids_out);
+        if (code != DGLL_OK) return code;
+    }
+    for (int h = 0; h < L; ++h) {
+        if (b->rows[h] <= 0 || !b->feat_out[h]) continue;
+        code = dgll_hip_gather_rows_mapped(stream, b->cache, b->ldc, b->host, b->ldh, ids_of[h], b->slot, b->host_map, b->feat_out[h], b->ld_feat,
+                                           b->rows[h], b->feat, b->dtype, b->miss_count);
+        if (code != DGLL_OK) return code;
+    }
+    if (b->reduced_out && b->rows[L - 1] > 0) {
+        code = dgll_hip_aggregate_rows_mapped(stream, b->cache, b->ldc, b->host, b->ldh, b->ids_out, b->slot, b->host_map, st + b->ptr_off[L - 1],
+                                              b->reduced_out, b->ld_reduced, b->rows[L - 1], b->feat, b->dtype, b->reduce, b->miss_count);
+        if (code != DGLL_OK) return code;
+    }
+    for (int h = 0; h + 1 < L; ++h) {
+        if (!b->rowptr_out[h]) continue;
+        DGLL_REQUIRE(b->rows[h] <= b->rowptr_cap[h], "a hop with more rows than the static block holds");
+        const int blocks = (int)std::min<int64_t>((b->rowptr_cap[h] + kBlock) / kBlock, 1024);
+        hipLaunchKernelGGL(pad_rowptr_kernel, dim3(blocks), dim3(kBlock), 0, s, st + b->ptr_off[h], b->rows[h], b->rowptr_out[h], b->rowptr_cap[h]);
+    }
+    if (b->labels && b->labels_out && b->labels_cap > 0) {
+        DGLL_REQUIRE(b->rows[0] <= b->labels_cap, "more seeds than the label buffer holds");
+        const int blocks = (int)std::min<int64_t>((b->labels_cap + kBlock - 1) / kBlock, 1024);
+        hipLaunchKernelGGL(gather_labels_kernel, dim3(blocks), dim3(kBlock), 0, s, b->labels, ids_of[0], b->rows[0], b->labels_out, b->labels_cap,
+                           b->label_fill);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "dgll_hip_load_sampled_batch launches");
+    return DGLL_OK;
+}
+
 DGLL_API int dgll_hip_gather_rows(void* stream, const void* cache, int64_t ldc, const void* host, int64_t ldh,
                                   const int64_t* idx, const int64_t* slot, void* out, int64_t ldo, int64_t n, int feat,
                                   int dtype, unsigned long long* miss_count) {

@@ -231,6 +231,7 @@ class MiniBatchPipeline:
         self._stop = threading.Event()          # set when a stage failed or the consumer left: every producer winds down
         self._static_step = None                # use_static_sets(): batches are written into a captured step's input sets in place
         self._next_set = 1
+        self._native_loader = os.environ.get("DGLL_NATIVE_LOADER", "1") != "0"    # in-place loading through ONE native call per batch
         self.load_seconds, self.load_batches = 0.0, 0
 
     # ---- producer stage 1: sampling (buffer_queues.py:22-46) ---------------------------------------------------
@@ -582,6 +583,9 @@ class MiniBatchPipeline:
         k = self._next_set
         self._next_set = k + 1 if k + 1 < len(step.sets) else 1
         st = step.sets[k]
+        if self._native_loader and self._labels_dev is not None and not self.record_access:
+            self._load_into_set_native(b, staged, step, st, k, n, n_src, off)
+            return True
         from .graphs import PaddedBlock
 
         with torch.cuda.stream(self.load_stream):
@@ -629,6 +633,86 @@ class MiniBatchPipeline:
             b.ready = torch.cuda.Event()
             b.ready.record(self.load_stream)
         return True
+
+    def _load_into_set_native(self, b, staged, step, st, k, n, n_src, off):
+        """_load_into_set as ONE native call (dgll_hip_load_sampled_batch): both uploads, the positions -> ids translation, the
+        hop gathers, the outermost hop's reduction, the padded row pointers and the labels are enqueued on the loading stream from
+        C++; what stays in Python is the bookkeeping (rings, events, the views a consumer may look at)."""
+        import ctypes as C
+
+        from . import _lib
+        from .cache import _dtype_code
+
+        L = len(b.subgraphs)
+        last = b.subgraphs[0]
+        compact = getattr(last, "positions_compact", None)
+        pos_host = compact[0] if compact is not None else last._src
+        n_outer = int(last._src.shape[0])
+        scratch = getattr(st, "_native", None)
+        if scratch is None:                      # per-set device scratch, sized once at the upper bounds
+            cap_outer = self.dataloader.batch_size
+            for f in self.dataloader.sampler.fanouts:
+                cap_outer *= int(f)
+            with torch.cuda.stream(self.load_stream):
+                scratch = st._native = (torch.empty(int(staged.buffer.shape[0]), dtype=torch.int64, device=self.device),
+                                        torch.empty(cap_outer * 8, dtype=torch.uint8, device=self.device),
+                                        torch.empty(cap_outer, dtype=torch.int64, device=self.device), _lib.BatchLoad())
+        staged_dev, pos_dev, ids_dev, d = scratch
+        if int(staged.buffer.shape[0]) > staged_dev.numel() or n_outer > ids_dev.numel():
+            raise RuntimeError("a batch larger than the loading stage's scratch (the sampler's fan-outs changed?)")
+        stream = self.load_stream
+        if st.free is not None:
+            stream.wait_event(st.free)                 # the replay that read this set's previous batch
+        cptr, ldc, hptr, ldh, sptr, mptr, counter, keep = self.cache.native_load_begin(stream)
+        d.staged_host, d.staged_entries, d.staged_dev = staged.buffer.ctypes.data, int(staged.buffer.shape[0]), staged_dev.data_ptr()
+        d.pos_host, d.n_outer, d.pos_bytes, d.pos_dev = pos_host.data_ptr(), n_outer, pos_host.element_size(), pos_dev.data_ptr()
+        d.indptr, d.indices = self.device_graph[0].data_ptr(), self.device_graph[1].data_ptr()
+        d.n_hops, d.seeds_off = L, off["seeds"]
+        for h in range(L):
+            d.rows[h] = n[h]
+            d.ptr_off[h] = off["ptr"][h]
+            d.feat_out[h] = st.features[h].data_ptr()
+            if h < L - 1:
+                d.src_off[h] = off["src"][h]
+                d.rowptr_out[h] = st.blocks[h].rowptr.data_ptr()
+                d.rowptr_cap[h] = step.rows[h]
+        d.cache, d.ldc, d.host, d.ldh, d.slot, d.host_map = cptr, ldc, hptr, ldh, sptr, mptr
+        d.feat, d.dtype = self.cache.total_dim, _dtype_code(st.feat_all)
+        d.miss_count = counter.data_ptr() if counter is not None else None
+        d.ld_feat = st.feat_all.stride(0)
+        d.reduced_out, d.ld_reduced = st.reduced.data_ptr(), st.reduced.stride(0)
+        d.reduce = _lib.REDUCE_MEAN if self.reduce_last_hop == "mean" else _lib.REDUCE_SUM
+        d.ids_out = ids_dev.data_ptr()
+        d.labels, d.labels_out, d.labels_cap, d.label_fill = self._labels_dev.data_ptr(), st.labels.data_ptr(), step.rows[0], -100
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib.dgll_hip_load_sampled_batch(stream.cuda_stream, C.byref(d)), "dgll_hip_load_sampled_batch")
+        done = torch.cuda.Event()
+        done.record(stream)
+        self.cache.native_load_end(stream, counter, keep, sum(n[:L]) + n_outer, done)
+        self._staging.release(staged.token, done)
+        if compact is not None:
+            self._pos_ring.release(compact[1], done)
+            last.positions_compact = None
+        elif self._ring is not None:
+            self._ring.release(getattr(last, "buffer_token", None), done)
+        # the views a consumer (or a test) may look at: ids and row pointers on the device, as the Python path leaves them
+        ids = [staged_dev[off["seeds"]:off["seeds"] + n[0]]]
+        for h in range(L - 1):
+            ids.append(staged_dev[off["src"][h]:off["src"][h] + n_src[h]])
+            b.subgraphs[L - 1 - h]._src = ids[-1]
+        for h in range(L):
+            sg = b.subgraphs[L - 1 - h]
+            sg.indptr = staged_dev[off["ptr"][h]:off["ptr"][h] + n[h] + 1]
+            sg.staged = None
+        outer = ids_dev[:n_outer]
+        last._finish, last._src, last._dst, last.pending_positions = None, outer, None, None
+        b.input_nodes = outer
+        b.static_set = k
+        b.features = [st.features[h][:n[h]] for h in range(L)] + [None]
+        b.last_hop_reduced = st.reduced[:n[L - 1]]
+        b.labels = st.labels[:n[0]]
+        b.blocks = list(st.blocks)
+        b.ready = done
 
     def _arange(self, m):
         ar = getattr(self, "_ar_cache", None)

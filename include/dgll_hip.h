@@ -297,6 +297,34 @@ int dgll_hip_aggregate_rows_mapped(void* stream, const void* cache, int64_t ldc,
 int dgll_hip_translate_positions(void* stream, const int64_t* indptr, const int64_t* indices, const int64_t* seeds,
                                  const int64_t* rowptr, int64_t n_rows, const void* positions, int pos_bytes, int64_t* out_ids);
 
+/* The LOADING STAGE of one sampled mini-batch as ONE call (buffer_queues.py:22-46's `sample_generator` body: stage the batch on
+ * the side stream; storage.py:151-198's fetch per hop; graphage.py:52-53's labels): everything the stage enqueues for a batch --
+ *   1. the upload of the batch's staging buffer (seeds | source ids per hop | row pointers per hop: dgll_host_sample_batch_seeded's
+ *      arrays at their upper-bound offsets) and of the outermost hop's neighbour positions, from pinned host memory,
+ *   2. positions -> node ids of the outermost hop (dgll_hip_translate_positions),
+ *   3. one cache gather per hop 0 .. n_hops-1 straight into that hop's rows of the consumer's input (dgll_hip_gather_rows_mapped),
+ *   4. the outermost hop's reduction straight out of the cache (dgll_hip_aggregate_rows_mapped),
+ *   5. the row pointers of hops 0 .. n_hops-2 padded to the consumer's static block shapes (entries past the batch's rows = its
+ *      edge count: empty rows), and the seeds' labels (entries past the batch = label_fill) --
+ * is issued on `stream` from native code: through Python the same work is ~15 launches and 1.0-1.8 ms of interpreter time per
+ * batch on the loading thread, which bounds a pipeline whose GPU side takes 1.6 ms.  All pointers in device memory unless named
+ * *_host (pinned).  Offsets are in int64 entries of the staging buffer.  rows[h] = rows of hop h (rows[h + 1] = edges of hop h);
+ * n_outer = edges of the outermost hop.  miss_count: optional device counter (hit / miss accounting, storage.py:213-220).      */
+typedef struct dgll_batch_load {
+    const void* staged_host; int64_t staged_entries; int64_t* staged_dev;
+    const void* pos_host; int64_t n_outer; int pos_bytes; void* pos_dev;
+    const int64_t* indptr; const int64_t* indices;
+    int n_hops; int64_t rows[8]; int64_t seeds_off; int64_t src_off[8]; int64_t ptr_off[8];
+    const void* cache; int64_t ldc; const void* host; int64_t ldh; const int64_t* slot; const int64_t* host_map;
+    int feat; int dtype; unsigned long long* miss_count;
+    void* feat_out[8]; int64_t ld_feat;
+    void* reduced_out; int64_t ld_reduced; int reduce;
+    int64_t* ids_out;
+    int64_t* rowptr_out[8]; int64_t rowptr_cap[8];
+    const int64_t* labels; int64_t* labels_out; int64_t labels_cap; int64_t label_fill;
+} dgll_batch_load;
+int dgll_hip_load_sampled_batch(void* stream, const dgll_batch_load* batch);
+
 /* ---- f1 (host code): one hop of the reference's neighbour sampler, bit-exact with CPython 3.10's random.sample -------
  * For every seed in order: all neighbours if deg <= fanout (or fanout < 0), else random.sample(neighbors, fanout)
  * (/root/reference/dgll/sampling/base_sampler.py:45-58), drawn from the MT19937 state passed in (`random.getstate()`:

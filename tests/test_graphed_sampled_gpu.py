@@ -147,7 +147,8 @@ def test_replay_equals_eager_at_a_fan_out_above_128(cuda_device):
             assert float((a - b_).abs().max()) <= 2e-3 * float(b_.abs().max()) + 1e-7
 
 
-def test_batches_written_in_place_by_the_loading_stage_replay_to_the_same_losses(cuda_device):
+@pytest.mark.parametrize("native", [True, False])
+def test_batches_written_in_place_by_the_loading_stage_replay_to_the_same_losses(cuda_device, native):
     """MiniBatchPipeline.use_static_sets: the loading stage writes a batch's hop features (one cache gather per hop), the outermost
     hop's reduction, the row pointers and the labels straight into one of the captured step's input sets; the consumer replays that
     set's graph without a copy.  Same batches (per-batch seeds), parameters frozen: every in-place replay gives the loss the copy
@@ -192,11 +193,24 @@ def test_batches_written_in_place_by_the_loading_stage_replay_to_the_same_losses
     with pytest.raises(ValueError):
         pipeline().use_static_sets(GraphedSampledStep(model, opt, batch, fanouts, feats, classes, device=dev, n_sets=3))   # too few for the queue
     pipe = pipeline()
+    pipe._native_loader = native            # True: ONE native call per batch (dgll_hip_load_sampled_batch); False: the torch-op path
     pipe.use_static_sets(step)
     got, used = [], []
     for i, b in enumerate(pipe):
         assert b.static_set is not None and 1 <= b.static_set <= 4
         used.append(b.static_set)
+        if i in (0, n_batches - 1):             # the loaded arrays themselves, against a plain lookup (first and the ragged last batch)
+            torch.cuda.current_stream().wait_event(b.ready)
+            seeds = train[i * batch:(i + 1) * batch]
+            assert torch.equal(b.features[0].float().cpu(), x[seeds].float()) and torch.equal(b.labels.cpu(), labels[seeds])
+            assert torch.equal(b.features[1].float().cpu(), x[b.subgraphs[2].src_nodes().cpu()].float())
+            ptr = b.subgraphs[0].indptr.cpu()
+            ids = b.input_nodes.cpu()
+            want = torch.stack([x[ids[ptr[r]:ptr[r + 1]]].float().mean(0) if ptr[r + 1] > ptr[r] else torch.zeros(feats) for r in range(64)])
+            assert float((b.last_hop_reduced[:64].float().cpu() - want).abs().max()) < 2e-2
+            blk = step.sets[b.static_set].blocks[0]
+            n0 = int(b.features[0].shape[0])
+            assert torch.equal(blk.rowptr[:n0 + 1].cpu(), b.subgraphs[2].indptr.cpu()) and bool((blk.rowptr[n0:] == blk.rowptr[n0]).all())
         got.append(float(step(b)) if i % 3 else float(step.eager(b)))      # every third batch launch by launch on its static set
     assert got == pytest.approx(want, rel=2e-3) and len(got) == n_batches
     assert used[:8] == [1, 2, 3, 4, 1, 2, 3, 4]

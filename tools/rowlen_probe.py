@@ -47,3 +47,26 @@ for lo, hi in ((0, 1), (1, 8), (8, 16), (16, 32), (32, 64), (64, 128), (128, 257
     tot += ms
     print("   degree [%d,%d): %8d rows %10d edges: %.3f ms = %.3f ns/edge, %.1f ns/row" % (lo, hi, rows.numel(), e, ms, ms * 1e6 / max(e, 1), ms * 1e6 / max(rows.numel(), 1)))
 print("   sum of the classes: %.3f ms" % tot)
+
+# Are the long rows' chunks better processed IN PLACE (at their row's position in the launch) than all at the front of the grid
+# (the plan's "chunks first" schedule)?  Emulation without touching the kernel: every row above the threshold is replaced by
+# ceil(deg / 256) consecutive pseudo-rows of at most 256 edges (the outputs of the pseudo-rows are partial sums nobody adds up:
+# timing only).  The kernel then has no chunk items at all and meets those edges where the row sits.
+cuts = []
+deg_c = deg.clone()
+rp = g.rowptr
+long_rows = torch.nonzero(deg > 256).flatten()
+pieces = (deg + 255) // 256
+pieces = torch.where(deg > 256, pieces, torch.ones_like(pieces))
+new_rows = int(pieces.sum())
+owner = torch.repeat_interleave(torch.arange(n, device=dev), pieces)                     # real row of every pseudo-row
+first = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+torch.cumsum(pieces, 0, out=first[1:])
+k = torch.arange(new_rows, device=dev) - first[owner]                                    # piece index inside its row
+start = rp[owner] + k * 256
+end = torch.minimum(start + 256, rp[owner + 1])
+rp2 = torch.cat([start, end[-1:]])
+assert bool((rp2[1:] >= rp2[:-1]).all()) and int(rp2[-1]) == nnz
+g3 = dgll_amd.CSRGraph(rp2.contiguous(), g.col, None, new_rows, n, check=False)
+t(g3, "long rows cut IN PLACE into pseudo-rows of <= 256 edges (%d rows, no chunk items)" % new_rows)
+t(g, "bench graph, real rows (chunks of long rows scheduled first)")
