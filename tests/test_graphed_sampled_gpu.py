@@ -206,8 +206,8 @@ def test_batches_written_in_place_by_the_loading_stage_replay_to_the_same_losses
             assert torch.equal(b.features[1].float().cpu(), x[b.subgraphs[2].src_nodes().cpu()].float())
             ptr = b.subgraphs[0].indptr.cpu()
             ids = b.input_nodes.cpu()
-            want = torch.stack([x[ids[ptr[r]:ptr[r + 1]]].float().mean(0) if ptr[r + 1] > ptr[r] else torch.zeros(feats) for r in range(64)])
-            assert float((b.last_hop_reduced[:64].float().cpu() - want).abs().max()) < 2e-2
+            mean = torch.stack([x[ids[ptr[r]:ptr[r + 1]]].float().mean(0) if ptr[r + 1] > ptr[r] else torch.zeros(feats) for r in range(64)])
+            assert float((b.last_hop_reduced[:64].float().cpu() - mean).abs().max()) < 2e-2
             blk = step.sets[b.static_set].blocks[0]
             n0 = int(b.features[0].shape[0])
             assert torch.equal(blk.rowptr[:n0 + 1].cpu(), b.subgraphs[2].indptr.cpu()) and bool((blk.rowptr[n0:] == blk.rowptr[n0]).all())
