@@ -206,6 +206,84 @@ DGLL_API int dgll_hip_translate_positions(void* stream, const int64_t* indptr, c
 }
 
 namespace dgll {
+// out[k, :] = scale_r * g[r, :] for k in [rowptr[r], rowptr[r + 1]); the rows behind rowptr[n_rows] are zeroed.  One wavefront per
+// destination row (then per tail row); VEC = 16: 16-byte lanes over rows on 16-byte pitches, else element by element.
+template <typename T, int VEC>
+__global__ __launch_bounds__(kBlock) void expand_rows_kernel(const int64_t* __restrict__ rowptr, int64_t n_rows, const T* __restrict__ g,
+                                                             int64_t ldg, T* __restrict__ out, int64_t ldo, int64_t n_out_rows, int feat,
+                                                             int mean) {
+    constexpr int EL = VEC / (int)sizeof(T);
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t used = rowptr[n_rows];
+    const int64_t items = n_rows + (n_out_rows > used ? n_out_rows - used : 0);
+    const int vecs = (feat + EL - 1) / EL;
+    for (int64_t it = (int64_t)blockIdx.x * kWavesPerBlock + wave; it < items; it += (int64_t)gridDim.x * kWavesPerBlock) {
+        if (it >= n_rows) {                                   // a row of the unused tail: zeros
+            T* dst = out + (used + (it - n_rows)) * ldo;
+            for (int v = lane; v < vecs; v += kWave) {
+                if (VEC == 16) *reinterpret_cast<uint4*>(dst + v * EL) = make_uint4(0, 0, 0, 0);
+                else dst[v] = (T)0;
+            }
+            continue;
+        }
+        const int64_t b = rowptr[it], e = rowptr[it + 1];
+        if (e <= b) continue;
+        const float sc = mean ? 1.0f / (float)(e - b) : 1.0f;
+        const T* src = g + it * ldg;
+        for (int v = lane; v < vecs; v += kWave) {
+            if constexpr (VEC == 16 && sizeof(T) == 2) {
+                const uint4 r = *reinterpret_cast<const uint4*>(src + v * EL);
+                const uint4 o = make_uint4(pack_bf16x2(bf16_lo(r.x) * sc, bf16_hi(r.x) * sc), pack_bf16x2(bf16_lo(r.y) * sc, bf16_hi(r.y) * sc),
+                                           pack_bf16x2(bf16_lo(r.z) * sc, bf16_hi(r.z) * sc), pack_bf16x2(bf16_lo(r.w) * sc, bf16_hi(r.w) * sc));
+                for (int64_t k = b; k < e; ++k) *reinterpret_cast<uint4*>(out + k * ldo + v * EL) = o;
+            } else if constexpr (VEC == 16) {
+                float4 r = *reinterpret_cast<const float4*>(src + v * EL);
+                r.x *= sc; r.y *= sc; r.z *= sc; r.w *= sc;
+                for (int64_t k = b; k < e; ++k) *reinterpret_cast<float4*>(out + k * ldo + v * EL) = r;
+            } else if constexpr (sizeof(T) == 2) {
+                const bf16_t o = f32_to_bf16(bf16_to_f32(src[v]) * sc);
+                for (int64_t k = b; k < e; ++k) out[k * ldo + v] = o;
+            } else {
+                const float o = src[v] * sc;
+                for (int64_t k = b; k < e; ++k) out[k * ldo + v] = o;
+            }
+        }
+    }
+}
+}  // namespace dgll
+
+DGLL_API int dgll_hip_expand_rows(void* stream, const int64_t* rowptr, int64_t n_rows, const void* g, int64_t ldg, void* out, int64_t ldo,
+                                  int64_t n_out_rows, int feat, int dtype, int mean) {
+    DGLL_REQUIRE(n_rows >= 0 && n_out_rows >= 0 && feat >= 0, "negative size");
+    if (n_out_rows == 0 || feat == 0) return DGLL_OK;
+    DGLL_REQUIRE(rowptr && out && (g || n_rows == 0), "NULL argument");
+    DGLL_REQUIRE(dtype == DGLL_F32 || dtype == DGLL_BF16, "dtype");
+    DGLL_REQUIRE(ldg >= feat && ldo >= feat, "leading dimension smaller than feat");
+    const int esz = dtype == DGLL_BF16 ? 2 : 4;
+    const int el = 16 / esz;
+    const int64_t padded = (int64_t)(feat + el - 1) / el * el;
+    const bool vec = aligned16(g) && aligned16(out) && (ldg * esz) % 16 == 0 && (ldo * esz) % 16 == 0 && ldg >= padded && ldo >= padded;
+    const int64_t items = n_rows + n_out_rows;          // an upper bound of the work items (the kernel reads the real count)
+    const dim3 grid((uint32_t)std::min<int64_t>((items + kWavesPerBlock - 1) / kWavesPerBlock, 16384));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == DGLL_BF16) {
+        if (vec) hipLaunchKernelGGL((expand_rows_kernel<bf16_t, 16>), grid, dim3(kBlock), 0, s, rowptr, n_rows, static_cast<const bf16_t*>(g), ldg,
+                                    static_cast<bf16_t*>(out), ldo, n_out_rows, feat, mean);
+        else hipLaunchKernelGGL((expand_rows_kernel<bf16_t, 2>), grid, dim3(kBlock), 0, s, rowptr, n_rows, static_cast<const bf16_t*>(g), ldg,
+                                static_cast<bf16_t*>(out), ldo, n_out_rows, feat, mean);
+    } else {
+        if (vec) hipLaunchKernelGGL((expand_rows_kernel<float, 16>), grid, dim3(kBlock), 0, s, rowptr, n_rows, static_cast<const float*>(g), ldg,
+                                    static_cast<float*>(out), ldo, n_out_rows, feat, mean);
+        else hipLaunchKernelGGL((expand_rows_kernel<float, 4>), grid, dim3(kBlock), 0, s, rowptr, n_rows, static_cast<const float*>(g), ldg,
+                                static_cast<float*>(out), ldo, n_out_rows, feat, mean);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "expand_rows_kernel launch");
+    return DGLL_OK;
+}
+
+namespace dgll {
 // dst[i] = src[i] for i <= n, src[n] (the edge count) for n < i <= cap: a batch's row pointers on a static block's shape
 __global__ __launch_bounds__(kBlock) void pad_rowptr_kernel(const int64_t* __restrict__ src, int64_t n, int64_t* __restrict__ dst, int64_t cap) {
     const int64_t last = src[n];

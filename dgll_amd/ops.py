@@ -149,8 +149,18 @@ class _Spmm(torch.autograd.Function):
             from .dense import column_sum
 
             grad_bias = column_sum(g)
-        if ctx.needs_input_grad[0] and graph.identity_cols and graph.n_cols == graph.nnz:
-            # sampled block (col == arange): source row e receives exactly g[row(e)] (times its weight) -- one gather,
+        if ctx.needs_input_grad[0] and graph.identity_cols and graph.n_cols == graph.nnz and g.is_cuda and val is None \
+                and graph.val is None and g.dtype in (torch.float32, torch.bfloat16):
+            # sampled block (col == arange), unweighted: source row e receives exactly scale . g[row(e)] -- ONE launch
+            # (dgll_hip_expand_rows: the degree / reciprocal / scale / searchsorted / gather chain of tensor ops was nine launches per
+            # block and batch, ~0.3 ms of a 1.7 ms sampled step); the unused tail of a block on static shapes comes out as zeros
+            grad_x = alloc_features(graph.n_cols, g.shape[1], g.dtype, g.device, pad_to=16 // g.element_size())
+            with _lib.on_device(g.device):
+                _lib.check(_lib.lib.dgll_hip_expand_rows(_lib.raw_stream(g.device), graph.rowptr.data_ptr(), graph.n_rows, g.data_ptr(), g.stride(0),
+                                                         grad_x.data_ptr(), grad_x.stride(0), graph.n_cols, g.shape[1], _dtype_code(g),
+                                                         1 if ctx.reduce == "mean" else 0), "dgll_hip_expand_rows")
+        elif ctx.needs_input_grad[0] and graph.identity_cols and graph.n_cols == graph.nnz:
+            # the same through tensor ops (host tensors, weighted blocks): one gather,
             # no transposed CSR to sort together and no launch plan for it, both of which would be rebuilt every batch
             scale = (1.0 / graph.degrees().clamp(min=1).to(torch.float32)).unsqueeze(1).to(g.dtype) if ctx.reduce == "mean" else None
             if getattr(graph, "padded", False):

@@ -297,6 +297,15 @@ int dgll_hip_aggregate_rows_mapped(void* stream, const void* cache, int64_t ldc,
 int dgll_hip_translate_positions(void* stream, const int64_t* indptr, const int64_t* indices, const int64_t* seeds,
                                  const int64_t* rowptr, int64_t n_rows, const void* positions, int pos_bytes, int64_t* out_ids);
 
+/* Backward of the K-axis reduction over a SAMPLED block (sageconv.py:33-36 on a block whose source rows each belong to exactly one
+ * destination row: col == arange(nnz), base_sampler.py:30-43 keeps duplicates): source row k of destination row r receives
+ *     out[k, :] = scale_r * g[r, :]        scale_r = 1 / deg(r) for the mean (mean != 0), 1 for the sum,
+ * k in [rowptr[r], rowptr[r + 1]); rows rowptr[n_rows] .. n_out_rows-1 of `out` (the unused tail of a block on static shapes) are
+ * zeroed.  One launch instead of the degree / reciprocal / scale / searchsorted / gather chain of tensor ops (nine launches per
+ * block and batch).  dtype: DGLL_F32 or DGLL_BF16 for both matrices (fp32 arithmetic); leading dimensions in elements.        */
+int dgll_hip_expand_rows(void* stream, const int64_t* rowptr, int64_t n_rows, const void* g, int64_t ldg, void* out, int64_t ldo,
+                         int64_t n_out_rows, int feat, int dtype, int mean);
+
 /* The LOADING STAGE of one sampled mini-batch as ONE call (buffer_queues.py:22-46's `sample_generator` body: stage the batch on
  * the side stream; storage.py:151-198's fetch per hop; graphage.py:52-53's labels): everything the stage enqueues for a batch --
  *   1. the upload of the batch's staging buffer (seeds | source ids per hop | row pointers per hop: dgll_host_sample_batch_seeded's

@@ -606,3 +606,52 @@ def test_gat_split_launches_equal_the_fused_one(cuda_device, dtype):
     torch.testing.assert_close(gs2, gs1, rtol=1e-4, atol=2e-5)
     with pytest.raises(ValueError):
         gat_bwd_rows_part(halves[0], hd, sd, td, out, go, rowsum, dn2, dd2, gs2, heads, fo, 0.2, True, accumulate=4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,feat", [(torch.bfloat16, 256), (torch.bfloat16, 602), (torch.float32, 100), (torch.bfloat16, 47), (torch.float32, 7)])
+@pytest.mark.parametrize("reduce", ["mean", "sum"])
+def test_sampled_block_backward_is_one_expand_launch(cuda_device, dtype, feat, reduce):
+    """Backward of the K-axis reduction over a sampled block (col == arange: every source row belongs to one destination row,
+    base_sampler.py:30-43; sageconv.py:33-36): dgll_hip_expand_rows against the definition out[k] = g[row(k)] (/ deg for the mean),
+    on an ordinary block and on a block padded to static shapes (unused rows empty, the unused tail of the sources zero)."""
+    from dgll_amd import ops
+    from dgll_amd.graph import CSRGraph
+    from dgll_amd.graphs import PaddedBlock
+
+    dev = cuda_device
+    gen = torch.Generator().manual_seed(5)
+    n_rows, fan = 300, 7
+    deg = torch.randint(0, fan + 1, (n_rows,), generator=gen)
+    deg[3] = 0
+    rowptr = torch.zeros(n_rows + 1, dtype=torch.int64)
+    torch.cumsum(deg, 0, out=rowptr[1:])
+    nnz = int(rowptr[-1])
+    blk = CSRGraph(rowptr.to(dev), torch.arange(nnz, dtype=torch.int32, device=dev), None, n_rows, nnz, check=False)
+    blk.identity_cols, blk.max_degree = True, fan
+    x = ops.alloc_features(nnz, feat, dtype, dev)
+    x.copy_(torch.randn(nnz, feat, generator=gen).to(dev))
+    x.requires_grad_()
+    y = ops.spmm(blk, x, reduce=reduce)
+    g = torch.randn(n_rows, feat, generator=gen).to(dev).to(dtype)
+    y.backward(g)
+    row = torch.repeat_interleave(torch.arange(n_rows), deg).to(dev)
+    want = g.float()[row]
+    if reduce == "mean":
+        want = want / deg.clamp(min=1).float().to(dev)[row].unsqueeze(1)
+    tol = 2 ** -7 if dtype == torch.bfloat16 else 1e-6
+    assert x.grad.shape == (nnz, feat) and float((x.grad.float() - want).abs().max()) <= tol * max(float(want.abs().max()), 1.0)
+    # the same batch on a static block with room for more rows and edges
+    pb = PaddedBlock.make(n_rows + 20, fan, dev, cols=nnz + 50)
+    PaddedBlock.pad(pb, rowptr.to(dev), nnz)
+    xp = ops.alloc_features(nnz + 50, feat, dtype, dev)
+    xp.zero_()
+    xp[:nnz].copy_(x.detach())
+    xp.requires_grad_()
+    yp = ops.spmm(pb, xp, reduce=reduce)
+    assert torch.equal(yp[:n_rows].detach(), y.detach())
+    gp = torch.zeros(n_rows + 20, feat, dtype=dtype, device=dev)
+    gp[:n_rows] = g
+    gp[n_rows:] = 7.0                                   # gradient of rows the batch does not use: reaches nobody
+    yp.backward(gp)
+    assert torch.equal(xp.grad[:nnz], x.grad) and float(xp.grad[nnz:].abs().max()) == 0.0
