@@ -106,7 +106,7 @@ SIGNATURES = {
     "dgll_hip_aggregate_rows_mapped": (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp]),
     "dgll_hip_translate_positions": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i32, _vp]),
     "dgll_hip_load_sampled_batch": (_i32, [_vp, _vp]),
-    "dgll_hip_expand_rows": (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32]),
+    "dgll_hip_expand_rows": (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _i32]),
     "dgll_host_sample_neighbors": (_i32, [_vp, C.POINTER(_i32), _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _i64,
                                           C.POINTER(_i64)]),
     "dgll_host_translate_neighbors": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _vp]),

@@ -211,12 +211,12 @@ namespace dgll {
 template <typename T, int VEC>
 __global__ __launch_bounds__(kBlock) void expand_rows_kernel(const int64_t* __restrict__ rowptr, int64_t n_rows, const T* __restrict__ g,
                                                              int64_t ldg, T* __restrict__ out, int64_t ldo, int64_t n_out_rows, int feat,
-                                                             int mean) {
+                                                             int mean, int accumulate) {
     constexpr int EL = VEC / (int)sizeof(T);
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t used = rowptr[n_rows];
-    const int64_t items = n_rows + (n_out_rows > used ? n_out_rows - used : 0);
+    const int64_t items = n_rows + ((!accumulate && n_out_rows > used) ? n_out_rows - used : 0);
     const int vecs = (feat + EL - 1) / EL;
     for (int64_t it = (int64_t)blockIdx.x * kWavesPerBlock + wave; it < items; it += (int64_t)gridDim.x * kWavesPerBlock) {
         if (it >= n_rows) {                                   // a row of the unused tail: zeros
@@ -236,17 +236,31 @@ __global__ __launch_bounds__(kBlock) void expand_rows_kernel(const int64_t* __re
                 const uint4 r = *reinterpret_cast<const uint4*>(src + v * EL);
                 const uint4 o = make_uint4(pack_bf16x2(bf16_lo(r.x) * sc, bf16_hi(r.x) * sc), pack_bf16x2(bf16_lo(r.y) * sc, bf16_hi(r.y) * sc),
                                            pack_bf16x2(bf16_lo(r.z) * sc, bf16_hi(r.z) * sc), pack_bf16x2(bf16_lo(r.w) * sc, bf16_hi(r.w) * sc));
-                for (int64_t k = b; k < e; ++k) *reinterpret_cast<uint4*>(out + k * ldo + v * EL) = o;
+                if (!accumulate) {
+                    for (int64_t k = b; k < e; ++k) *reinterpret_cast<uint4*>(out + k * ldo + v * EL) = o;
+                } else {
+                    const float a8[8] = {bf16_lo(o.x), bf16_hi(o.x), bf16_lo(o.y), bf16_hi(o.y), bf16_lo(o.z), bf16_hi(o.z), bf16_lo(o.w), bf16_hi(o.w)};
+                    for (int64_t k = b; k < e; ++k) {
+                        uint4* d = reinterpret_cast<uint4*>(out + k * ldo + v * EL);
+                        const uint4 p = *d;
+                        *d = make_uint4(pack_bf16x2(bf16_lo(p.x) + a8[0], bf16_hi(p.x) + a8[1]), pack_bf16x2(bf16_lo(p.y) + a8[2], bf16_hi(p.y) + a8[3]),
+                                        pack_bf16x2(bf16_lo(p.z) + a8[4], bf16_hi(p.z) + a8[5]), pack_bf16x2(bf16_lo(p.w) + a8[6], bf16_hi(p.w) + a8[7]));
+                    }
+                }
             } else if constexpr (VEC == 16) {
                 float4 r = *reinterpret_cast<const float4*>(src + v * EL);
                 r.x *= sc; r.y *= sc; r.z *= sc; r.w *= sc;
-                for (int64_t k = b; k < e; ++k) *reinterpret_cast<float4*>(out + k * ldo + v * EL) = r;
+                for (int64_t k = b; k < e; ++k) {
+                    float4* d = reinterpret_cast<float4*>(out + k * ldo + v * EL);
+                    if (accumulate) { const float4 p = *d; *d = make_float4(p.x + r.x, p.y + r.y, p.z + r.z, p.w + r.w); }
+                    else *d = r;
+                }
             } else if constexpr (sizeof(T) == 2) {
                 const bf16_t o = f32_to_bf16(bf16_to_f32(src[v]) * sc);
-                for (int64_t k = b; k < e; ++k) out[k * ldo + v] = o;
+                for (int64_t k = b; k < e; ++k) out[k * ldo + v] = accumulate ? f32_to_bf16(bf16_to_f32(out[k * ldo + v]) + bf16_to_f32(o)) : o;
             } else {
                 const float o = src[v] * sc;
-                for (int64_t k = b; k < e; ++k) out[k * ldo + v] = o;
+                for (int64_t k = b; k < e; ++k) out[k * ldo + v] = accumulate ? out[k * ldo + v] + o : o;
             }
         }
     }
@@ -254,7 +268,7 @@ __global__ __launch_bounds__(kBlock) void expand_rows_kernel(const int64_t* __re
 }  // namespace dgll
 
 DGLL_API int dgll_hip_expand_rows(void* stream, const int64_t* rowptr, int64_t n_rows, const void* g, int64_t ldg, void* out, int64_t ldo,
-                                  int64_t n_out_rows, int feat, int dtype, int mean) {
+                                  int64_t n_out_rows, int feat, int dtype, int mean, int accumulate) {
     DGLL_REQUIRE(n_rows >= 0 && n_out_rows >= 0 && feat >= 0, "negative size");
     if (n_out_rows == 0 || feat == 0) return DGLL_OK;
     DGLL_REQUIRE(rowptr && out && (g || n_rows == 0), "NULL argument");
@@ -269,14 +283,14 @@ DGLL_API int dgll_hip_expand_rows(void* stream, const int64_t* rowptr, int64_t n
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (dtype == DGLL_BF16) {
         if (vec) hipLaunchKernelGGL((expand_rows_kernel<bf16_t, 16>), grid, dim3(kBlock), 0, s, rowptr, n_rows, static_cast<const bf16_t*>(g), ldg,
-                                    static_cast<bf16_t*>(out), ldo, n_out_rows, feat, mean);
+                                    static_cast<bf16_t*>(out), ldo, n_out_rows, feat, mean, accumulate);
         else hipLaunchKernelGGL((expand_rows_kernel<bf16_t, 2>), grid, dim3(kBlock), 0, s, rowptr, n_rows, static_cast<const bf16_t*>(g), ldg,
-                                static_cast<bf16_t*>(out), ldo, n_out_rows, feat, mean);
+                                static_cast<bf16_t*>(out), ldo, n_out_rows, feat, mean, accumulate);
     } else {
         if (vec) hipLaunchKernelGGL((expand_rows_kernel<float, 16>), grid, dim3(kBlock), 0, s, rowptr, n_rows, static_cast<const float*>(g), ldg,
-                                    static_cast<float*>(out), ldo, n_out_rows, feat, mean);
+                                    static_cast<float*>(out), ldo, n_out_rows, feat, mean, accumulate);
         else hipLaunchKernelGGL((expand_rows_kernel<float, 4>), grid, dim3(kBlock), 0, s, rowptr, n_rows, static_cast<const float*>(g), ldg,
-                                static_cast<float*>(out), ldo, n_out_rows, feat, mean);
+                                static_cast<float*>(out), ldo, n_out_rows, feat, mean, accumulate);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "expand_rows_kernel launch");

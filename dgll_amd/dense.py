@@ -171,7 +171,7 @@ def sage_fused_forward(graph, x, reduce, h_self, wt_self, wt_nbr, relu, bias=Non
     return out, (agg if keep_agg else None)
 
 
-def transform_bf16_dual(a, wt1, wt2):
+def transform_bf16_dual(a, wt1, wt2, out1=None):
     """(a . wt1^T, a . wt2^T) in one MFMA launch that reads `a` once: the two input gradients g.Ws^T, g.Wn^T of a SAGE
     layer.  wt1, wt2: [N, K] with N, K <= 256; a: bf16 [M, K], 16-byte aligned rows."""
     n, m = wt1.shape[0], a.shape[0]
@@ -181,6 +181,10 @@ def transform_bf16_dual(a, wt1, wt2):
     ld = -(-n // 8) * 8
     outs = [torch.empty((m, ld), dtype=torch.bfloat16, device=a.device) for _ in range(2)]
     o1, o2 = (o[:, :n] if ld != n else o for o in outs)
+    if out1 is not None:       # the first product into a caller's rows (a range of a row_slices gradient buffer): bf16, 16-byte pitch
+        if out1.shape != (m, n) or out1.dtype != torch.bfloat16 or out1.stride(1) != 1 or out1.stride(0) % 8 or out1.data_ptr() % 16:
+            raise ValueError("transform_bf16_dual(out1=): [M, N] bf16 rows on a 16-byte pitch")
+        o1 = out1
     with _lib.on_device(a.device):
         end = _timed(("transform_dual", m, a.shape[1], 0, 2 * n, ""), a.device)
         code = _lib.lib.dgll_hip_transform_bf16_dual(
@@ -268,10 +272,13 @@ def mm2_nt(a1, wt1, a2, wt2, relu=False):
     return parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
 
 
-def input_grads(g, wsd, wnd):
-    """(g . Ws^T, g . Wn^T) for weights stored [in, out]: one MFMA launch that reads g once for tall bf16 gradients, else two."""
+def input_grads(g, wsd, wnd, out1=None):
+    """(g . Ws^T, g . Wn^T) for weights stored [in, out]: one MFMA launch that reads g once for tall bf16 gradients, else two.
+    out1: optional destination rows of the first product (transform_bf16_dual / mm_nt's `out`)."""
     if g.shape[0] >= 64 * _SLABS and _mfma_ok(g) and wsd.shape == wnd.shape and max(wsd.shape) <= 256:
-        return transform_bf16_dual(g, wsd, wnd)
+        if out1 is not None and (out1.dtype != torch.bfloat16 or out1.stride(0) % 8 or out1.data_ptr() % 16):
+            out1 = None
+        return transform_bf16_dual(g, wsd, wnd, out1=out1)
     return mm_nt(g, wsd), mm_nt(g, wnd)
 
 
@@ -471,11 +478,13 @@ class _SageTransform(torch.autograd.Function):
             out = mm2_nt(h, wsd.t(), agg, wnd.t(), relu=relu)
         ctx.relu = relu
         ctx.wparams = (ws, wn)
+        ctx.h_dest = getattr(h, "_dgll_grad_dest", None)      # h is a row range of a stacked layer input (ops.row_slices)
         ctx.save_for_backward(h, agg, wsd, wnd, out if relu else None)
         return out
 
     @staticmethod
     def backward(ctx, g):
+        from .ops import grad_dest
         from .optim import grad_slot_of
 
         h, agg, wsd, wnd, out = ctx.saved_tensors
@@ -483,7 +492,12 @@ class _SageTransform(torch.autograd.Function):
             g = torch.ops.aten.threshold_backward(g.contiguous(), out, 0)   # one vectorised pass: g where out > 0
         g = g.contiguous()
         if ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
-            gh, gagg = input_grads(g, wsd, wnd)
+            # the self path's product straight into its rows of the stacked input's gradient buffer (no copy pass afterwards)
+            got = grad_dest(ctx.h_dest, h.shape, g.dtype, g.device, allow_accumulate=False) if (ctx.mfma and g.is_cuda) else None
+            gh, gagg = input_grads(g, wsd, wnd, out1=got[0] if got is not None else None)
+            if got is not None and gh.data_ptr() != got[0].data_ptr():
+                got[0].copy_(gh)                      # (the product took another path: honour the claim)
+                gh = got[0]
         else:
             gh = mm_nt(g, wsd) if ctx.needs_input_grad[0] else None
             gagg = mm_nt(g, wnd) if ctx.needs_input_grad[1] else None

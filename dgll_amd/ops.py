@@ -133,6 +133,7 @@ class _Spmm(torch.autograd.Function):
         # the buffer for an input of the node
         y = spmm_raw(graph, x, val=val, reduce=reduce, bias=bias, relu=relu, out=out_ref[0] if out_ref else None)
         ctx.graph, ctx.reduce, ctx.relu = graph, reduce, relu
+        ctx.x_dest = getattr(x, "_dgll_grad_dest", None)
         ctx.has_bias = bias is not None
         ctx.save_for_backward(x if (val is not None and val.requires_grad) else None, val, y if relu else None)
         return y
@@ -154,11 +155,17 @@ class _Spmm(torch.autograd.Function):
             # sampled block (col == arange), unweighted: source row e receives exactly scale . g[row(e)] -- ONE launch
             # (dgll_hip_expand_rows: the degree / reciprocal / scale / searchsorted / gather chain of tensor ops was nine launches per
             # block and batch, ~0.3 ms of a 1.7 ms sampled step); the unused tail of a block on static shapes comes out as zeros
-            grad_x = alloc_features(graph.n_cols, g.shape[1], g.dtype, g.device, pad_to=16 // g.element_size())
+            # written (or added) straight into the rows of the layer input's gradient buffer when the input is a row range of one
+            # (ops.row_slices): no copy / add pass afterwards
+            got = grad_dest(ctx.x_dest, (graph.n_cols, g.shape[1]), g.dtype, g.device)
+            if got is not None:
+                grad_x, acc = got
+            else:
+                grad_x, acc = alloc_features(graph.n_cols, g.shape[1], g.dtype, g.device, pad_to=16 // g.element_size()), False
             with _lib.on_device(g.device):
                 _lib.check(_lib.lib.dgll_hip_expand_rows(_lib.raw_stream(g.device), graph.rowptr.data_ptr(), graph.n_rows, g.data_ptr(), g.stride(0),
                                                          grad_x.data_ptr(), grad_x.stride(0), graph.n_cols, g.shape[1], _dtype_code(g),
-                                                         1 if ctx.reduce == "mean" else 0), "dgll_hip_expand_rows")
+                                                         1 if ctx.reduce == "mean" else 0, 1 if acc else 0), "dgll_hip_expand_rows")
         elif ctx.needs_input_grad[0] and graph.identity_cols and graph.n_cols == graph.nnz:
             # the same through tensor ops (host tensors, weighted blocks): one gather,
             # no transposed CSR to sort together and no launch plan for it, both of which would be rebuilt every batch
@@ -216,25 +223,89 @@ def spmm(graph, x, val=None, reduce="sum", bias=None, relu=False, out=None):
     return _Spmm.apply(x, val, bias, graph, reduce, relu, [out] if out is not None else None)
 
 
+class _GradArena:
+    """The gradient buffer of a matrix whose row ranges feed several consumers (row_slices): the consumers' backward passes may
+    write their result straight into their range of it instead of returning a tensor that is copied / added in afterwards
+    (five strided copies and an add per sampled step).  claim(k) -> (rows [a, b) of the buffer, accumulate) or None:
+    accumulate = False when nothing has been written to the range yet (the producer WRITES), True when all of it has been
+    written (the producer ADDS); a range that is partly written is not handed out (the node's backward merges that gradient)."""
+
+    def __init__(self, shape, bounds):
+        self.shape, self.bounds = tuple(shape), list(bounds)
+        self.out = None
+        self.written = []                  # disjoint, sorted [a, b)
+        self.claimed = [False] * len(self.bounds)
+
+    def _covered(self, a, b):
+        pos, any_overlap = a, False
+        for ca, cb in self.written:
+            if cb <= a or ca >= b:
+                continue
+            any_overlap = True
+            if ca > pos:
+                return "partial"
+            pos = max(pos, cb)
+        if not any_overlap:
+            return "none"
+        return "all" if pos >= b else "partial"
+
+    def _mark(self, a, b):
+        self.written.append((a, b))
+        self.written.sort()
+        merged = [self.written[0]]
+        for ca, cb in self.written[1:]:
+            if ca <= merged[-1][1]:
+                merged[-1] = (merged[-1][0], max(merged[-1][1], cb))
+            else:
+                merged.append((ca, cb))
+        self.written = merged
+
+    def claim(self, k, dtype, device, allow_accumulate=True):
+        a, b = self.bounds[k]
+        if b <= a or self.claimed[k]:
+            return None
+        state = self._covered(a, b)
+        if state == "partial" or (state == "all" and not allow_accumulate):
+            return None
+        if self.out is None:
+            self.out = alloc_features(self.shape[0], self.shape[1], dtype, device, pad_to=16 // torch.empty((), dtype=dtype).element_size())
+        elif self.out.dtype != dtype:
+            return None
+        self.claimed[k] = True
+        if state == "none":
+            self._mark(a, b)
+        return self.out[a:b], state == "all"
+
+
 class _RowSlices(torch.autograd.Function):
     """Several row ranges [a, b) of one matrix, possibly overlapping, as one autograd node."""
 
     @staticmethod
-    def forward(ctx, x, bounds):
+    def forward(ctx, x, bounds, arena):
         ctx.bounds, ctx.shape = bounds, x.shape
+        ctx.arena = arena
         return tuple(x[a:b] for a, b in bounds)
 
     @staticmethod
     def backward(ctx, *grads):
-        # one buffer for the matrix's gradient: a range's gradient is COPIED where nothing has been written yet and ADDED where an
-        # earlier range overlaps; rows no range covers are zero-filled.  (Plain slices: a zero-filled full-size tensor per range plus
-        # pairwise full-size additions -- for the three ranges of a 113 k x 256 layer input that is 0.17 ms against 0.07.)
+        # one buffer for the matrix's gradient.  A range whose producer CLAIMED its rows of the buffer (ctx.arena: the block's
+        # expand launch, the transform's input-gradient product) is in place already; any other range's gradient is COPIED where
+        # nothing has been written yet and ADDED where an earlier range overlaps; rows no range covers are zero-filled.  (Plain
+        # slices: a zero-filled full-size tensor per range plus pairwise full-size additions.)
+        arena = ctx.arena
         ref = next(g for g in grads if g is not None)
-        out = torch.empty(ctx.shape, dtype=ref.dtype, device=ref.device)
-        covered = []                                   # disjoint, sorted [a, b) ranges already written
-        for (a, b), g in zip(ctx.bounds, grads):
+        out = arena.out if arena.out is not None else torch.empty(ctx.shape, dtype=ref.dtype, device=ref.device)
+        covered = list(arena.written)                  # disjoint, sorted [a, b) ranges already written
+        for k, ((a, b), g) in enumerate(zip(ctx.bounds, grads)):
             if g is None or b <= a:
                 continue
+            if arena.claimed[k]:
+                if g.data_ptr() != out[a:b].data_ptr():
+                    # (the view has a second consumer and autograd summed two gradients into a new tensor: the rows written in
+                    # place hold only a part of it and cannot be told apart any more)
+                    raise RuntimeError("row_slices: a range whose gradient was written in place arrived as another tensor "
+                                       "(a view returned by row_slices must feed exactly one differentiable consumer)")
+                continue                               # written (or added) in place by its producer
             pos = a
             for ca, cb in list(covered):
                 if cb <= pos or ca >= b:
@@ -260,7 +331,8 @@ class _RowSlices(torch.autograd.Function):
             if ca > pos:
                 out[pos:ca].zero_()
             pos = max(pos, cb)
-        return out, None
+        ctx.arena = None
+        return out, None, None
 
 
 def row_slices(x, bounds):
@@ -269,7 +341,23 @@ def row_slices(x, bounds):
     bounds = [(int(a), int(b)) for a, b in bounds]
     if not x.requires_grad:
         return [x[a:b] for a, b in bounds]
-    return list(_RowSlices.apply(x, bounds))
+    arena = _GradArena(x.shape, bounds)
+    outs = list(_RowSlices.apply(x, bounds, arena))
+    if x.is_cuda:
+        for k, o in enumerate(outs):           # a consumer whose backward can write its gradient in place looks for this (grad_dest)
+            o._dgll_grad_dest = (arena, k)
+    return outs
+
+
+def grad_dest(dest, shape, dtype, device, allow_accumulate=True):
+    """(rows of a row_slices gradient buffer to write this gradient into, accumulate) for a producer's backward pass, or None."""
+    if dest is None:
+        return None
+    arena, k = dest
+    a, b = arena.bounds[k]
+    if (b - a, arena.shape[1]) != tuple(shape):
+        return None
+    return arena.claim(k, dtype, device, allow_accumulate=allow_accumulate)
 
 
 # ------------------------------------------------------------------------------------------------ loss

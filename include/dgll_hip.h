@@ -302,9 +302,11 @@ int dgll_hip_translate_positions(void* stream, const int64_t* indptr, const int6
  *     out[k, :] = scale_r * g[r, :]        scale_r = 1 / deg(r) for the mean (mean != 0), 1 for the sum,
  * k in [rowptr[r], rowptr[r + 1]); rows rowptr[n_rows] .. n_out_rows-1 of `out` (the unused tail of a block on static shapes) are
  * zeroed.  One launch instead of the degree / reciprocal / scale / searchsorted / gather chain of tensor ops (nine launches per
- * block and batch).  dtype: DGLL_F32 or DGLL_BF16 for both matrices (fp32 arithmetic); leading dimensions in elements.        */
+ * block and batch).  dtype: DGLL_F32 or DGLL_BF16 for both matrices (fp32 arithmetic); leading dimensions in elements.
+ * accumulate != 0: out[k, :] += scale_r * g[r, :] instead (rows behind rowptr[n_rows] untouched): the rows already hold another
+ * contribution to the same gradient (the layer's self path), written by an earlier launch.                                      */
 int dgll_hip_expand_rows(void* stream, const int64_t* rowptr, int64_t n_rows, const void* g, int64_t ldg, void* out, int64_t ldo,
-                         int64_t n_out_rows, int feat, int dtype, int mean);
+                         int64_t n_out_rows, int feat, int dtype, int mean, int accumulate);
 
 /* The LOADING STAGE of one sampled mini-batch as ONE call (buffer_queues.py:22-46's `sample_generator` body: stage the batch on
  * the side stream; storage.py:151-198's fetch per hop; graphage.py:52-53's labels): everything the stage enqueues for a batch --

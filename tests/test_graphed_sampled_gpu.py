@@ -215,3 +215,32 @@ def test_batches_written_in_place_by_the_loading_stage_replay_to_the_same_losses
     assert got == pytest.approx(want, rel=2e-3) and len(got) == n_batches
     assert used[:8] == [1, 2, 3, 4, 1, 2, 3, 4]
     torch.cuda.synchronize()
+
+
+def test_sampled_step_gradients_written_in_place_equal_the_merged_ones(cuda_device):
+    """ops.row_slices hands its consumers rows of ONE gradient buffer (the block's expand launch adds / writes there, the
+    transform's self-path product writes there): the sampled step's parameter gradients equal the ones of the same step with that
+    plumbing off (every range's gradient returned as its own tensor and merged by copies / adds), bit for bit in bf16."""
+    from dgll_amd import nn as dnn, ops
+    from dgll_amd.optim import FlatAdam
+
+    dev = cuda_device
+    fanouts, batch, feats, classes = [5, 4, 3], 96, 40, 7
+    order = list(reversed(fanouts))
+    rng = torch.Generator().manual_seed(11)
+    b = _batch(dev, rng, batch, order, feats, classes, 1.0)
+    torch.manual_seed(4)
+    model = dnn.GraphSage(feats, [64, 64, classes], fanouts).to(dev)
+    opt = FlatAdam(list(model.parameters()), lr=0.0)
+    loss_a, grads_a = _eager(model, opt, b, ops)
+    real = ops.grad_dest
+    calls = []
+    ops.grad_dest = lambda *a, **k: (calls.append(1), None)[1]        # plumbing off: producers return their own tensors
+    import dgll_amd.dense as dense_mod
+    try:
+        loss_b, grads_b = _eager(model, opt, b, ops)
+    finally:
+        ops.grad_dest = real
+    assert loss_a == loss_b and len(calls) >= 3
+    for ga, gb in zip(grads_a, grads_b):
+        assert float((ga - gb).abs().max()) <= 1e-6 * max(float(gb.abs().max()), 1.0)
