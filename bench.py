@@ -119,11 +119,11 @@ def parse_args(argv=None):
     ap.add_argument("--mb-hip-graph", choices=["auto", "on", "off"], default="auto",
                     help="minibatch: the consumer's forward + loss + backward as ONE HIP graph on padded static block shapes "
                          "(dgll_amd.graphs.GraphedSampledStep), replayed per batch")
-    ap.add_argument("--mb-in-place", action="store_true",
-                    help="minibatch: the loading stage writes batches IN PLACE into one of six static input sets of the captured step "
-                         "(MiniBatchPipeline.use_static_sets) instead of the step copying every batch (260 MB) into ONE set.  Measured "
-                         "(round 5, three runs each): GPU side 1.78 -> 1.57-1.77 ms per batch, end to end 528-592 against 552-573 batches/s "
-                         "-- the copies it saves come back as loader launches; not the default")
+    ap.add_argument("--mb-copy-inputs", action="store_true",
+                    help="minibatch: the captured step copies every batch (260 MB) into ONE static input set (rounds 3-4) instead of the "
+                         "loading stage writing batches IN PLACE into one of six sets through one native call per batch "
+                         "(MiniBatchPipeline.use_static_sets, dgll_hip_load_sampled_batch).  Interleaved A/B on one box (round 5, "
+                         "tools/minibatch_inplace_ab.sh): in place 649-655 batches/s, GPU side 1.42-1.46 ms; copies 615-620, 1.58 ms")
     ap.add_argument("--mb-dense-kernel", choices=["auto", "4wave"], default="4wave",
                     help="minibatch: 4wave = every bf16 transform on the 4-wavefront MFMA kernel (dgll_hip_debug_tune(4, 1)) instead of the "
                          "persistent resident-weights one, whose workgroups need a whole CU's registers and LDS and wait for the loading "
@@ -1319,7 +1319,7 @@ def run_minibatch(args, c):
         rows = [args.mb_batch] + [-(-int(r * 1.1) // 64) * 64 for r in seen_rows[1:]]
         try:
             # queue of 4 loaded batches + the one being consumed + the one being loaded = 6 in-place input sets (+ set 0, the copy path's)
-            n_sets = 7 if args.mb_in_place else 1
+            n_sets = 1 if args.mb_copy_inputs else 7
             step_ = GraphedSampledStep(model, opt, args.mb_batch, fanouts, args.mb_feats, args.mb_classes, dtype=c.dtype, device=c.dev, rows=rows,
                                        n_sets=n_sets)
             if n_sets > 1:
