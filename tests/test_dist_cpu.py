@@ -19,6 +19,12 @@ def _free_port():
     return port
 
 
+def _few_threads(world):
+    """A worker process keeps to a few intra-op threads: on a 256-thread host eight ranks with the default thread count each spend
+    their time in the thread pool (the GPU box: 91 s for a test that takes 5 s on 8 cores)."""
+    torch.set_num_threads(max(1, min(4, (os.cpu_count() or 4) // max(int(world), 1))))
+
+
 def _cpu_spmm(graph, x, val=None, reduce="sum"):
     v = val if val is not None else (graph.val if graph.val is not None else torch.ones(graph.nnz))
     v = v.to(x.dtype)
@@ -33,6 +39,7 @@ def _cpu_spmm(graph, x, val=None, reduce="sum"):
 
 def _worker(rank, world, port, weighted, feat, form="p2p"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), DGLL_EXCHANGE=form)
+    _few_threads(world)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from dgll_amd import dist as ddist
@@ -83,6 +90,7 @@ def _worker(rank, world, port, weighted, feat, form="p2p"):
 
 def _racom_worker(rank, world, port):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    _few_threads(world)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from dgll_amd import dist as ddist
@@ -134,6 +142,7 @@ def test_alltoall_exchange_form_gives_the_same_results(world, feat):
 
 def _bad_lists_worker(rank, world, port):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    _few_threads(world)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from dgll_amd import dist as ddist
@@ -152,6 +161,7 @@ def _bad_lists_worker(rank, world, port):
 
 def _fallback_worker(rank, world, port):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), DGLL_EXCHANGE="p2p")
+    _few_threads(world)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from dgll_amd import dist as ddist
@@ -239,6 +249,7 @@ def test_partition_covers_every_edge_once():
 def _rows_worker(rank, world, port):
     """partition_rows: every rank holds ONLY its own row block; the send lists come from one exchange of halo ids."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    _few_threads(world)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from dgll_amd import dist as ddist
@@ -286,6 +297,7 @@ def _ddp_worker(rank, world, port):
     """RaCoM with staleness 0 (sync period 1) must equal DistributedDataParallel bit for bit (SURVEY 8 f3;
     reference semantics avg = sum of grads / world_size, MQGCN.py:55-79)."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    _few_threads(world)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from torch.nn.parallel import DistributedDataParallel as DDP
@@ -338,6 +350,7 @@ def test_racom_sync_form_equals_ddp_bit_for_bit(world):
 
 def _sage_model_worker(rank, world, port):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    _few_threads(world)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from dgll_amd import dist as ddist
@@ -437,6 +450,7 @@ def _rowblock_worker(rank, world, port, scale):
     """BASELINE config 5's sharding over gloo (process shape MQGCN.py:161-163): cost-balanced contiguous
     row blocks, X replicated, no exchange inside the aggregation; results == the single-process pass."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    _few_threads(world)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from dgll_amd import dist as ddist
