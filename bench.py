@@ -1633,6 +1633,10 @@ WORKLOADS = {"sage": run_sage, "gat": run_gat, "rmat27": run_rmat27, "minibatch"
 
 def main():
     args = parse_args()
+    if os.environ.get("DGLL_BENCH_DUMP_AFTER"):       # diagnostics: every thread's Python stack after that many seconds (a rank that hangs)
+        import faulthandler
+
+        faulthandler.dump_traceback_later(int(os.environ["DGLL_BENCH_DUMP_AFTER"]), exit=False)
     c = setup(args)
     import dgll_amd  # noqa: F401  (loads libdgll_hip.so; raises if it cannot be built)
 
