@@ -124,6 +124,8 @@ SIGNATURES = {
                                              _vp, _i64, _i32, _i64, _i32, _i32, _vp, _vp, _i64, _vp]),
     "dgll_hip_transform_bf16_add": (_i32, [_vp, _vp, _i64, _i32, _vp, _i64, _vp, _i64, _i32, _vp, _i64, _i32, _vp, _i64,
                                            _vp, _i64, _i32, _i64, _i32, _i32, _vp, _vp, _i64, _vp, _vp, _i64]),
+    "dgll_hip_transform_bf16_bits": (_i32, [_vp, _vp, _i64, _i32, _vp, _i64, _vp, _i64, _i32, _vp, _i64, _i32, _vp, _i64, _i64, _i32,
+                                            _i32, _vp, _vp, _i64, _vp, _i64, _vp, _i64]),
     "dgll_hip_transform_bf16_dual": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _i64, _i32, _vp, _i64, _vp, _i64, _i64, _i32]),
     "dgll_hip_grad_weight_workspace": (_i64, [_i32, _i32, _i32]),
     "dgll_hip_grad_weight_bf16": (_i32, [_vp, _vp, _i64, _i32, _vp, _i64, _i32, _vp, _i64, _i32, _i64, _vp, _i64, _i32, _vp, _i64,

@@ -138,6 +138,13 @@ struct MfmaGemmArgs {
     int64_t ldadd;
     void* out2;             // dual form (resident-weights kernel, COLSPLIT = 2): out = A[0].Wt[0]^T and out2 = A[0].Wt[1]^T, A[0] read once
     int64_t ldo2;
+    // One bit per output element instead of a bf16 gate matrix (32 bytes per 256-column row against 512): word w of row i, bit b
+    // = column 32 w + b is positive.  bits_out: written by the epilogue from the values it stores (the producer of an activation);
+    // gate_bits: read INSTEAD of out_gate by the resident-weights kernel (the consumer's ReLU backward).
+    const uint32_t* gate_bits;
+    int64_t ld_gate_bits;   // words per row, a multiple of 4 (16-byte rows)
+    uint32_t* bits_out;
+    int64_t ld_bits_out;
 #ifdef DGLL_RES_TRACE
     unsigned long long* trace;   // probe builds only (tools/probes/res_trace.hip): [wg < 16][wave 8][block < 4][16 events]
 #endif
@@ -166,6 +173,46 @@ __device__ __forceinline__ uint4 relu_mask(uint4 v, uint4 m) {  // zero bf16 lan
         a[d] &= (lo_pos | hi_pos);
     }
     return make_uint4(a[0], a[1], a[2], a[3]);
+}
+
+// the keep-condition of relu_mask as one bit per element: bit e (of the low byte) = element e of v is positive -- sign clear and
+// magnitude non-zero, i.e. (int16) v > 0: packed max with 0 then packed min with 1 leaves the flag at bits 0 and 16 of a dword.
+// (Inline asm: written with builtins, hipcc turns both helpers back into compare + select per element -- 3-4x the instructions,
+// with wait states between the v_cmp and the v_cndmask; tools/probes/res_epi.hip counts the epilogue's cycles.)
+__device__ __forceinline__ uint32_t pos_bits8(uint4 v) {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    const uint32_t ones = 0x00010001u;                           // (a packed inline constant is not replicated into the high half)
+    uint32_t f4 = 0;                                             // low elements' flags at bits 0 2 4 6, high elements' at 16 18 20 22
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        uint32_t t, f;
+        asm("v_pk_max_i16 %0, %1, 0" : "=v"(t) : "v"(w[d]));
+        asm("v_pk_min_u16 %0, %1, %2" : "=v"(f) : "v"(t), "s"(ones));
+        f4 |= f << (2 * d);
+    }
+    return (f4 & 0x55u) | ((f4 >> 15) & 0xaau);                  // bit 16 + 2 d -> 2 d + 1
+}
+
+// zero element e of v where bit e of `bits` is clear (higher bits ignored): relu_mask with the gate as bits.  A signed one-bit field
+// extract gives 0 / ~0; v_bfi merges the two halves' masks
+__device__ __forceinline__ uint4 keep_bits8(uint4 v, uint32_t bits) {
+    uint32_t a[4] = {v.x, v.y, v.z, v.w};
+    const uint32_t low_half = 0x0000ffffu;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        uint32_t lo, hi, m;
+        asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(lo) : "v"(bits), "n"(2 * d));
+        asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(hi) : "v"(bits), "n"(2 * d + 1));
+        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(m) : "s"(low_half), "v"(lo), "v"(hi));
+        a[d] &= m;
+    }
+    return make_uint4(a[0], a[1], a[2], a[3]);
+}
+
+__device__ __forceinline__ uint32_t quad_or(uint32_t v) {   // OR over the four lanes 4 q .. 4 q + 3 (two DPP quad permutations, no LDS)
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);    // quad_perm [1, 0, 3, 2]
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false);    // quad_perm [2, 3, 0, 1]
+    return v;
 }
 
 // Global loads of chunk c: the weight slab (NT vectors per thread) and this lane's four activation vectors.
@@ -532,7 +579,7 @@ __device__ __forceinline__ void res_mfmas(const char* base, const int (&slot_off
 // (Measured and dropped: software-pipelining the halves -- second half transposed before the first half's MFMAs, the next
 // chunk's first half before the second half's -- was 5-7 % SLOWER; the two extra scheduling fences cost more than the LDS
 // round trips they hide, which the other waves of the SIMD already cover.)
-template <int NTW, int RG, int NC, int D, int ROWS, int P>
+template <int NTW, int RG, int NC, int D, int ROWS, int P, bool WAIT = true>
 __device__ __forceinline__ void res_phase(const MfmaGemmArgs& a, const ResCtx& x, int64_t blk0, const ResLane& L, const char* wlane,
                                           int chunk_bytes, f32x16_t (&acc)[RG][NTW], u32x4_t (&A)[D][4 * RG], const int (&slot_off)[4],
                                           int t_blk, int wave) {
@@ -547,8 +594,10 @@ __device__ __forceinline__ void res_phase(const MfmaGemmArgs& a, const ResCtx& x
     res_mfmas<NTW, RG, 0>(base, slot_off, f, acc);
     res_transpose<RG, 1>(L, A[S], nxt, f);
     res_mfmas<NTW, RG, 1>(base, slot_off, f, acc);
-    res_wait<4 * RG * (D - 1), 4 * RG>(A[(P + 1) % D]);   // the next phase's chunk has landed; D - 1 younger sets may still fly
-    RES_TRACE(2 + P % NC);
+    if constexpr (WAIT) {
+        res_wait<4 * RG * (D - 1), 4 * RG>(A[(P + 1) % D]);   // the next phase's chunk has landed; D - 1 younger sets may still fly
+        RES_TRACE(2 + P % NC);
+    }
     (void)t_blk; (void)wave; (void)a;
 }
 
@@ -569,9 +618,15 @@ __device__ __forceinline__ void res_phases(const MfmaGemmArgs& a, const ResCtx& 
 // of the inline-asm prefetch of the next block queued ahead of that load -- so it emits vmcnt(0) and the whole prefetch is
 // drained before the epilogue starts (measured with cycle stamps, tools/probes/res_trace.hip: 19 k of a block's 34 k cycles
 // sat in that wait).  The bias therefore comes from LDS (staged once), never from global memory.
-template <int NTW, bool PLAIN>
+// EPI: 0 = the general epilogue, 1 = PLAIN, 2 = PLAIN + an output gate given as BITS (`gb`: per `it`, the four words of this wave's
+// tiles for row (it * 64 + lane) / 4 of the row group -- fetched by the caller BEFORE the block's last phase, so nothing is waited
+// for here).  Any of them also writes the sign bits of what it stores when a.bits_out is set (stores only).
+template <int NTW, int EPI>
 __device__ __forceinline__ void res_epilogue(const MfmaGemmArgs& a, char* scratch, const float* bias_w, f32x16_t (&acc)[NTW],
-                                             int64_t m0, int64_t row, int64_t row_ld, int n0, int lane, int half, int l32) {
+                                             int64_t m0, int64_t row, int64_t row_ld, int n0, int lane, int half, int l32,
+                                             const uint4 (&gb)[2]) {
+    constexpr bool PLAIN = EPI != 0;
+    uint32_t my_word[2] = {0u, 0u};                             // bits_out: lane l keeps the word of tile l % 4 for its row
     float rs = 1.0f;
     if constexpr (!PLAIN) rs = a.row_scale ? a.row_scale[row_ld] : 1.0f;
     constexpr int kPitch = 80;                                  // 64 bytes of bf16 + 16: conflict-free 8-byte writes
@@ -672,6 +727,7 @@ __device__ __forceinline__ void res_epilogue(const MfmaGemmArgs& a, char* scratc
         }
         __builtin_amdgcn_wave_barrier();                       // compiler fence only: one wave's LDS operations execute in order,
                                                                // so the reads below see the whole tile without a wait
+        if constexpr (EPI == 0) {
 #pragma unroll
         for (int it = 0; it < 2; ++it) {                       // 32 rows x 4 vectors of 16 bytes = 128 vectors, two per lane
             const int idx = it * kWave + lane;
@@ -703,13 +759,62 @@ __device__ __forceinline__ void res_epilogue(const MfmaGemmArgs& a, char* scratc
                 }
             }
         }
+        } else {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {                       // 32 rows x 4 vectors of 16 bytes = 128 vectors, two per lane
+            const int idx = it * kWave + lane;
+            const int r = idx >> 2, nl = (idx & 3) * 8;
+            const int n = nt0 + nl;
+            const int64_t grow = m0 + r;
+            const bool live = grow < a.M && n < n_store;
+            if (!a.bits_out && !live) continue;                 // (with bits_out all 64 lanes stay: the quad OR below needs them)
+            uint4 d = *reinterpret_cast<const uint4*>(scratch + r * kPitch + nl * 2);     // (any lane: the address is inside the tile)
+            const bool pad_vec = a.pad_store && n + 8 > a.N && n + 8 <= a.ldo;    // a vector that reaches into the row padding
+            if (pad_vec) d = mask_tail(d, a.N > n ? a.N - n : 0);
+            if constexpr (EPI == 2) {
+                const uint32_t gw = t == 0 ? gb[it].x : t == 1 ? gb[it].y : t == 2 ? gb[it].z : gb[it].w;
+                d = keep_bits8(d, gw >> ((idx & 3) * 8));
+            }
+            if (a.bits_out) {                                   // wave-uniform
+                const int valid = a.N - n;                      // elements of this vector inside the matrix
+                uint32_t bits = pos_bits8(d) & (valid >= 8 ? 0xffu : valid > 0 ? (1u << valid) - 1u : 0u);
+                if (!live) bits = 0;
+                const uint32_t word = quad_or(bits << ((idx & 3) * 8));
+                if ((lane & 3) == t) my_word[it] = word;
+                if (!live) continue;
+            }
+            bf16_t* o = static_cast<bf16_t*>(a.out) + grow * a.ldo + n;
+#if defined(DGLL_RES_ABL) && (DGLL_RES_ABL & 1)
+            if (d.x != 0x12345678u) continue;                          // probe: no stores
+#endif
+            if ((n + 8 <= a.N || pad_vec) && vec_rows) {
+                *reinterpret_cast<uint4*>(o) = d;
+            } else if (n < a.N) {
+                const uint32_t w[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    if (n + e >= a.N) continue;
+                    o[e] = (bf16_t)((w[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+                }
+            }
+        }
+        }
         __builtin_amdgcn_wave_barrier();                       // (same: the next tile's writes queue behind these reads)
     }
+    }
+    if (EPI != 0 && a.bits_out) {                               // 64 lanes x 4 bytes: 16 rows x the 16 contiguous bytes of this wave's tiles
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int idx = it * kWave + lane;
+            const int64_t grow = m0 + (idx >> 2);
+            const int wcol = (n0 >> 5) + (lane & 3);
+            if (grow < a.M && wcol < a.ld_bits_out) a.bits_out[grow * a.ld_bits_out + wcol] = my_word[it];
+        }
     }
 }
 
 // blocks QI .. Q-1 of a super-iteration; true = the last row block of this workgroup has been written
-template <int NTW, int RG, int NC, int D, int ROWS, int Q, bool PLAIN, int QI>
+template <int NTW, int RG, int NC, int D, int ROWS, int Q, int EPI, int QI>
 __device__ __forceinline__ bool res_blocks(const MfmaGemmArgs& a, const ResCtx& x, int64_t blk0, const ResLane& L, const char* wlane,
                                            int chunk_bytes, u32x4_t (&A)[D][4 * RG], const int (&slot_off)[4], int& t_blk, int wave) {
     if constexpr (QI < Q) {
@@ -722,8 +827,49 @@ __device__ __forceinline__ bool res_blocks(const MfmaGemmArgs& a, const ResCtx& 
             for (int t = 0; t < NTW; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[g][t][r] = 0.0f;
-        res_phases<NTW, RG, NC, D, ROWS, QI * NC, QI * NC + NC>(a, x, blk0, L, wlane, chunk_bytes, acc, A, slot_off, t_blk, wave);
         const int64_t blk = blk0 + QI * x.stride;
+        // EPI 2: the gate words of the whole block (two 16-byte loads per row group and lane).  Every phase ends in a wait for ALL
+        // loads but the youngest ones, so a load has to land within the phase that issues it -- and these miss to HBM while the
+        // activation chunks mostly hit the L2 (the partner fetched them): issued at the start of the last phase they stretched it
+        // by 2-3 k cycles.  They are issued at the END of the second-to-last phase instead, as the youngest loads, and that phase's
+        // wait lets them fly: a whole phase to land, and the last phase's own wait covers them.
+        uint4 gb[RG][2];
+#pragma unroll
+        for (int g = 0; g < RG; ++g) gb[g][0] = gb[g][1] = make_uint4(0u, 0u, 0u, 0u);
+        auto fetch_gate_words = [&]() {
+            int b_lane = L.lane, b_n0 = L.n_col0;
+            asm volatile("" : "+v"(b_lane), "+s"(b_n0));        // (opaque: keeps the addresses out of the persistent loop's live set)
+#pragma unroll
+            for (int g = 0; g < RG; ++g)
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const int64_t grow = blk * ROWS + (L.rgroup * RG + g) * 32 + ((it * kWave + b_lane) >> 2);
+                    gb[g][it] = *reinterpret_cast<const uint4*>(a.gate_bits + (grow < a.M ? grow : a.M - 1) * a.ld_gate_bits + (b_n0 >> 5));
+                }
+        };
+        if constexpr (EPI == 2 && NC >= 2) {
+            res_phases<NTW, RG, NC, D, ROWS, QI * NC, QI * NC + NC - 2>(a, x, blk0, L, wlane, chunk_bytes, acc, A, slot_off, t_blk, wave);
+            constexpr int P2 = QI * NC + NC - 2;
+            res_phase<NTW, RG, NC, D, ROWS, P2, false>(a, x, blk0, L, wlane, chunk_bytes, acc, A, slot_off, t_blk, wave);
+            fetch_gate_words();
+            res_wait<4 * RG * (D - 1) + 2 * RG, 4 * RG>(A[(P2 + 1) % D]);
+            RES_TRACE(2 + P2 % NC);
+        } else {
+            res_phases<NTW, RG, NC, D, ROWS, QI * NC, QI * NC + NC - 1>(a, x, blk0, L, wlane, chunk_bytes, acc, A, slot_off, t_blk, wave);
+            if constexpr (EPI == 2) fetch_gate_words();
+        }
+        res_phases<NTW, RG, NC, D, ROWS, QI * NC + NC - 1, QI * NC + NC>(a, x, blk0, L, wlane, chunk_bytes, acc, A, slot_off, t_blk, wave);
+        if constexpr (EPI == 2) {
+            // The words have landed (the phase's own vmcnt(0)), but hipcc does not know: it would wait for each of the four loads at
+            // its first use INSIDE the epilogue with the count of memory operations issued since -- and on gfx9 stores share that
+            // counter, so every such wait also drains the epilogue's own stores (seen as vmcnt(2) / vmcnt(3) in front of the mask
+            // arithmetic).  Touching the registers here makes it place those waits now, where they cost nothing.
+#pragma unroll
+            for (int g = 0; g < RG; ++g)
+#pragma unroll
+                for (int it = 0; it < 2; ++it)
+                    asm volatile("" : "+v"(gb[g][it].x), "+v"(gb[g][it].y), "+v"(gb[g][it].z), "+v"(gb[g][it].w));
+        }
         RES_TRACE(11);
 #pragma unroll
         for (int g = 0; g < RG; ++g) {
@@ -734,12 +880,12 @@ __device__ __forceinline__ bool res_blocks(const MfmaGemmArgs& a, const ResCtx& 
             // row / column pairs) would otherwise be hoisted out of the persistent loop and stay live through the main loop
             int e_lane = L.lane, e_half = L.half, e_l32 = L.l32, e_n0 = L.n_col0;
             asm volatile("" : "+v"(e_lane), "+v"(e_half), "+v"(e_l32), "+s"(e_n0));
-            res_epilogue<NTW, PLAIN>(a, L.scratch, L.bias_w, acc[g], m0, row, row_ld, e_n0, e_lane, e_half, e_l32);
+            res_epilogue<NTW, EPI>(a, L.scratch, L.bias_w, acc[g], m0, row, row_ld, e_n0, e_lane, e_half, e_l32, gb[g]);
         }
         RES_TRACE(12);
         ++t_blk;
         if (blk + x.stride >= x.n_blocks) return true;
-        return res_blocks<NTW, RG, NC, D, ROWS, Q, PLAIN, QI + 1>(a, x, blk0, L, wlane, chunk_bytes, A, slot_off, t_blk, wave);
+        return res_blocks<NTW, RG, NC, D, ROWS, Q, EPI, QI + 1>(a, x, blk0, L, wlane, chunk_bytes, A, slot_off, t_blk, wave);
     } else {
         return false;
     }
@@ -759,7 +905,7 @@ __device__ __forceinline__ void res_prologue(const ResCtx& x, int64_t blk0, u32x
     }
 }
 
-template <int NTW, int RG, int NC, int CS, int COLSPLIT, int D, bool PLAIN, int NW, bool DUAL>
+template <int NTW, int RG, int NC, int CS, int COLSPLIT, int D, int EPI, int NW, bool DUAL>
 __global__ __launch_bounds__(NW * 64) void gemm_bf16_res_kernel(const MfmaGemmArgs a_in) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     static_assert(!DUAL || COLSPLIT == 2, "the dual form hands the second weight matrix to the second column share");
@@ -841,22 +987,33 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_res_kernel(const MfmaGemmAr
     res_wait<4 * RG * (D - 1), 4 * RG>(A[0]);
     int t_blk = 0;
     for (;;) {
-        if (res_blocks<NTW, RG, NC, D, kRows, Q, PLAIN, 0>(a, x, blk, L, wlane, kChunkBytes, A, slot_off, t_blk, wave)) break;
+        if (res_blocks<NTW, RG, NC, D, kRows, Q, EPI, 0>(a, x, blk, L, wlane, kChunkBytes, A, slot_off, t_blk, wave)) break;
         blk += Q * x.stride;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the loads issued past the last block (zero-byte descriptors)
 }
 
-template <int NTW, int NC, int CS, int COLSPLIT, bool PLAIN, bool DUAL = false>
+template <int NTW, int NC, int CS, int COLSPLIT, int EPI, bool DUAL = false>
 static hipError_t launch_mfma_res_p(const MfmaGemmArgs& a, hipStream_t s);
+
+// which epilogue: 1 (plain) loads nothing; 2 = plain + the output gate as bits (fetched a phase ahead); 0 = everything else
+static int res_epilogue_kind(const MfmaGemmArgs& a) {
+    const bool simple = !a.out_f32 && !a.row_scale && !a.addend;
+    if (simple && !a.out_gate && !a.gate_bits) return 1;
+    if (simple && a.gate_bits && (a.ldo & 7) == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15u) == 0) return 2;
+    return 0;
+}
 
 template <int NTW, int NC, int CS, int COLSPLIT>
 static hipError_t launch_mfma_res(const MfmaGemmArgs& a, hipStream_t s) {
-    const bool plain = !a.out_f32 && !a.row_scale && !a.addend && !a.out_gate;
-    return plain ? launch_mfma_res_p<NTW, NC, CS, COLSPLIT, true>(a, s) : launch_mfma_res_p<NTW, NC, CS, COLSPLIT, false>(a, s);
+    switch (res_epilogue_kind(a)) {
+        case 1: return launch_mfma_res_p<NTW, NC, CS, COLSPLIT, 1>(a, s);
+        case 2: return launch_mfma_res_p<NTW, NC, CS, COLSPLIT, 2>(a, s);
+        default: return launch_mfma_res_p<NTW, NC, CS, COLSPLIT, 0>(a, s);
+    }
 }
 
-template <int NTW, int NC, int CS, int COLSPLIT, bool PLAIN, bool DUAL>
+template <int NTW, int NC, int CS, int COLSPLIT, int EPI, bool DUAL>
 static hipError_t launch_mfma_res_p(const MfmaGemmArgs& a, hipStream_t s) {
     // ring depth: D | NC or NC | D (slot arithmetic)
 #ifdef DGLL_RES_D
@@ -877,7 +1034,7 @@ static hipError_t launch_mfma_res_p(const MfmaGemmArgs& a, hipStream_t s) {
 #endif
     constexpr int NWG_T = NTW * CS;
     const size_t lds = (size_t)NC * NWG_T * 32 * 128 + NW * 32 * 80 + NWG_T * 32 * 4;
-    auto kern = &gemm_bf16_res_kernel<NTW, RG, NC, CS, COLSPLIT, D, PLAIN, NW, DUAL>;
+    auto kern = &gemm_bf16_res_kernel<NTW, RG, NC, CS, COLSPLIT, D, EPI, NW, DUAL>;
     // both the LDS attribute and the CU count are per device (single-process multi-device use): cached per device id
     static bool raised_on[64] = {};
     static int n_cu_of[64] = {};
@@ -915,6 +1072,10 @@ static bool res_applies(int nt, int n_chunks) {
 }
 
 static hipError_t launch_mfma_res_dispatch(const MfmaGemmArgs& a, int nt, int n_chunks, hipStream_t s) {
+#ifdef DGLL_RES_PROBE          // probe builds instantiate the few kernels they launch themselves (3 minutes of compile time otherwise)
+    (void)a; (void)nt; (void)n_chunks; (void)s;
+    return hipErrorNotSupported;
+#else
 #define RES_NC(NTW, CS, COLSPLIT)                                                      \
     switch (n_chunks) {                                                                \
         case 1: return launch_mfma_res<NTW, 1, CS, COLSPLIT>(a, s);                    \
@@ -931,6 +1092,7 @@ static hipError_t launch_mfma_res_dispatch(const MfmaGemmArgs& a, int nt, int n_
     if (n_chunks <= 4) { RES_NC(4, 2, 1) }                  // N <= 256, K <= 256: two waves per row group
     RES_NC(4, 1, 2)                                         // N <= 256, K <= 512: two workgroups per row block
 #undef RES_NC
+#endif
 }
 
 }  // namespace dgll
@@ -940,6 +1102,21 @@ int g_tune_mfma_kperm = 0;   // dgll_hip_debug_tune(4, v): 0 = per-shape choice 
 // ---- weight packing: [n, k] fp32 / bf16 with arbitrary element strides (a parameter or its transposed view) -> the zero-padded
 // bf16 [rows, ld] block the transform kernels stage.  ONE launch where the wrappers used to cast, zero-fill and copy (three).
 namespace dgll {
+// word w of row i <- the sign bits (positive = 1) of out[i, 32 w .. 32 w + 31], zeros past N and in the padding words
+__global__ __launch_bounds__(kBlock) void sign_bits_kernel(const bf16_t* __restrict__ out, int64_t ldo, int64_t M, int N,
+                                                           uint32_t* __restrict__ bits, int64_t ldb) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= M * ldb) return;
+    const int64_t r = i / ldb;
+    const int n0 = (int)(i % ldb) * 32;
+    uint32_t w = 0;
+    for (int e = 0; e < 32 && n0 + e < N; ++e) {
+        const uint32_t v = out[r * ldo + n0 + e];
+        if ((v & 0x8000u) == 0u && (v & 0x7fffu) != 0u) w |= 1u << e;
+    }
+    bits[i] = w;
+}
+
 template <typename T>
 __global__ __launch_bounds__(kBlock) void pack_weight_kernel(const T* __restrict__ src, int64_t sr, int64_t sc, int n, int k,
                                                              bf16_t* __restrict__ dst, int64_t ld, int rows) {
@@ -979,7 +1156,8 @@ static int transform_bf16_impl(void* stream, const void* A1, int64_t lda1, int K
                                const void* A2, int64_t lda2, int K2, const void* Wt2, int64_t ldw2, int wt_rows,
                                const void* relu_mask, int64_t ldm, void* out, int64_t ldo, int out_dtype, int64_t M,
                                int N, int relu, const float* bias, const void* out_gate, int64_t ldgate,
-                               const float* row_scale, const void* addend, int64_t ldadd);
+                               const float* row_scale, const void* addend, int64_t ldadd, const uint32_t* gate_bits = nullptr,
+                               int64_t ld_gate_bits = 0, uint32_t* bits_out = nullptr, int64_t ld_bits_out = 0);
 
 DGLL_API int dgll_hip_transform_bf16(void* stream, const void* A1, int64_t lda1, int K1, const void* Wt1, int64_t ldw1,
                                      const void* A2, int64_t lda2, int K2, const void* Wt2, int64_t ldw2, int wt_rows,
@@ -1007,6 +1185,15 @@ DGLL_API int dgll_hip_transform_bf16_add(void* stream, const void* A1, int64_t l
                                out_dtype, M, N, relu, bias, out_gate, ldgate, row_scale, addend, ldadd);
 }
 
+DGLL_API int dgll_hip_transform_bf16_bits(void* stream, const void* A1, int64_t lda1, int K1, const void* Wt1, int64_t ldw1,
+                                          const void* A2, int64_t lda2, int K2, const void* Wt2, int64_t ldw2, int wt_rows,
+                                          void* out, int64_t ldo, int64_t M, int N, int relu, const float* bias,
+                                          const void* out_gate, int64_t ldgate, const uint32_t* gate_bits, int64_t ld_gate_bits,
+                                          uint32_t* bits_out, int64_t ld_bits_out) {
+    return transform_bf16_impl(stream, A1, lda1, K1, Wt1, ldw1, A2, lda2, K2, Wt2, ldw2, wt_rows, nullptr, 0, out, ldo, DGLL_BF16,
+                               M, N, relu, bias, out_gate, ldgate, nullptr, nullptr, 0, gate_bits, ld_gate_bits, bits_out, ld_bits_out);
+}
+
 DGLL_API int dgll_hip_transform_bf16_dual(void* stream, const void* A, int64_t lda, int K, const void* Wt1, const void* Wt2,
                                           int64_t ldw, int wt_rows, void* out1, int64_t ldo1, void* out2, int64_t ldo2, int64_t M,
                                           int N) {
@@ -1026,13 +1213,15 @@ DGLL_API int dgll_hip_transform_bf16_dual(void* stream, const void* A, int64_t l
     a.pairs = 1;
     a.out = out1; a.ldo = ldo1; a.out2 = out2; a.ldo2 = ldo2; a.M = M; a.N = N;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipError_t e;
+    hipError_t e = hipErrorNotSupported;
+#ifndef DGLL_RES_PROBE
     switch ((K + kChunkK - 1) / kChunkK) {             // 256 columns per workgroup (two waves per row group), two workgroups per row block
-        case 1: e = launch_mfma_res_p<4, 1, 2, 2, true, true>(a, s); break;
-        case 2: e = launch_mfma_res_p<4, 2, 2, 2, true, true>(a, s); break;
-        case 3: e = launch_mfma_res_p<4, 3, 2, 2, true, true>(a, s); break;
-        default: e = launch_mfma_res_p<4, 4, 2, 2, true, true>(a, s); break;
+        case 1: e = launch_mfma_res_p<4, 1, 2, 2, 1, true>(a, s); break;
+        case 2: e = launch_mfma_res_p<4, 2, 2, 2, 1, true>(a, s); break;
+        case 3: e = launch_mfma_res_p<4, 3, 2, 2, 1, true>(a, s); break;
+        default: e = launch_mfma_res_p<4, 4, 2, 2, 1, true>(a, s); break;
     }
+#endif
     if (e != hipSuccess) return hip_fail(e, "gemm_bf16_res_kernel (dual) launch");
     return DGLL_OK;
 }
@@ -1041,7 +1230,8 @@ static int transform_bf16_impl(void* stream, const void* A1, int64_t lda1, int K
                                const void* A2, int64_t lda2, int K2, const void* Wt2, int64_t ldw2, int wt_rows,
                                const void* relu_mask, int64_t ldm, void* out, int64_t ldo, int out_dtype, int64_t M,
                                int N, int relu, const float* bias, const void* out_gate, int64_t ldgate,
-                               const float* row_scale, const void* addend, int64_t ldadd) {
+                               const float* row_scale, const void* addend, int64_t ldadd, const uint32_t* gate_bits,
+                               int64_t ld_gate_bits, uint32_t* bits_out, int64_t ld_bits_out) {
     DGLL_REQUIRE(M >= 0 && N >= 0 && K1 >= 0 && K2 >= 0, "negative size");
     if (M == 0 || N == 0) return DGLL_OK;
     DGLL_REQUIRE(A1 && Wt1 && out && K1 > 0, "NULL operand");
@@ -1074,6 +1264,12 @@ static int transform_bf16_impl(void* stream, const void* A1, int64_t lda1, int K
     a.row_scale = row_scale;
     DGLL_REQUIRE(!addend || ldadd >= N, "addend: bf16 [M, ldadd >= N]");
     a.addend = static_cast<const bf16_t*>(addend); a.ldadd = ldadd;
+    const int n_words = -(-((N + 31) / 32) / 4) * 4;      // gate bits: 32 columns per word, rows padded to whole 16-byte vectors
+    DGLL_REQUIRE(!gate_bits || (ld_gate_bits >= n_words && ld_gate_bits % 4 == 0 && aligned16(gate_bits)),
+                 "gate_bits: uint32 [M, ld >= 4 * ceil(N / 128)], ld a multiple of 4, 16-byte aligned");
+    DGLL_REQUIRE(!bits_out || (ld_bits_out >= n_words && ld_bits_out % 4 == 0 && aligned16(bits_out) && out_dtype == DGLL_BF16),
+                 "bits_out: uint32 [M, ld >= 4 * ceil(N / 128)], ld a multiple of 4, 16-byte aligned; bf16 output only");
+    a.gate_bits = gate_bits; a.ld_gate_bits = ld_gate_bits; a.bits_out = bits_out; a.ld_bits_out = ld_bits_out;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int nt = (N + 31) / 32;
     hipError_t e;
@@ -1083,14 +1279,28 @@ static int transform_bf16_impl(void* stream, const void* A1, int64_t lda1, int K
     // whole reduction fit LDS (K1 + K2 <= 512) -- fused 256+256 -> 256: 0.90 ms against 1.2-1.4 for the 4-wave kernel, single
     // 256 -> 256: 0.59 against 0.82, 256 -> 47: 0.37 against 0.40.  The 4-wave kernel keeps the input-mask form and longer
     // reductions (weights staged per chunk).
-    if (g_tune_mfma_kperm != 1 && !a.mask && res_applies(nt, n_chunks) && a.ldw[0] == (a.pairs > 1 ? a.ldw[1] : a.ldw[0])) {
+    const bool res = g_tune_mfma_kperm != 1 && !a.mask && res_applies(nt, n_chunks) && a.ldw[0] == (a.pairs > 1 ? a.ldw[1] : a.ldw[0]);
+    // the bits are an ALTERNATIVE reading of the gate: only the resident-weights kernel's bit epilogue takes them; every other path
+    // reads out_gate, which must then be there too
+    DGLL_REQUIRE(!gate_bits || out_gate || (res && res_epilogue_kind(a) == 2),
+                 "gate_bits alone: this shape / operand set runs a kernel that reads the gate as bf16 -- pass out_gate as well");
+    const bool epilogue_bits = res && res_epilogue_kind(a) != 0;      // the plain / bit-gated epilogues write the sign bits themselves
+    if (!epilogue_bits) a.bits_out = nullptr;
+    if (res) {
         e = launch_mfma_res_dispatch(a, nt, n_chunks, s);
         if (e != hipSuccess) return hip_fail(e, "gemm_bf16_res_kernel launch");
-        return DGLL_OK;
+    } else {
+        if (nt <= 2) e = launch_mfma<2>(a, s);
+        else if (nt <= 4) e = launch_mfma<4>(a, s);
+        else e = launch_mfma<8>(a, s);
+        if (e != hipSuccess) return hip_fail(e, "gemm_bf16_nt_kernel launch");
     }
-    if (nt <= 2) e = launch_mfma<2>(a, s);
-    else if (nt <= 4) e = launch_mfma<4>(a, s);
-    else e = launch_mfma<8>(a, s);
-    if (e != hipSuccess) return hip_fail(e, "gemm_bf16_nt_kernel launch");
+    if (bits_out && !epilogue_bits) {                    // the general epilogue and the 4-wave kernel: one pass over what they wrote
+        const int64_t n_items = M * ld_bits_out;
+        hipLaunchKernelGGL(sign_bits_kernel, dim3((uint32_t)((n_items + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
+                           static_cast<const bf16_t*>(out), ldo, M, N, bits_out, ld_bits_out);
+        e = hipGetLastError();
+        if (e != hipSuccess) return hip_fail(e, "sign_bits_kernel launch");
+    }
     return DGLL_OK;
 }

@@ -69,14 +69,33 @@ def _mfma_ok(*mats):
                              and m.stride(0) % 8 == 0 and m.data_ptr() % 16 == 0) for m in mats)
 
 
+def bit_words(n):
+    """Words per row of a sign-bit matrix over n columns: 32 columns per word, rows padded to whole 16-byte vectors."""
+    return -(-(-(-n // 32)) // 4) * 4
+
+
 def transform_bf16(a1, wt1, a2=None, wt2=None, relu=False, out_dtype=torch.bfloat16, n_out=None, mask=None, bias=None,
-                   ld_align=None, out_gate=None, row_scale=None, addend=None, out=None):
+                   ld_align=None, out_gate=None, row_scale=None, addend=None, out=None, gate_bits=None, bits_out=False):
     """out[M, N] = act(a1 . wt1^T (+ a2 . wt2^T)) on the MFMA kernel.  wt*: [N, K] weights (transposed), any float
     dtype; padded here.  a*: bf16 [M, K], 16-byte aligned rows.  out_gate: bf16 [M, N]; out is zeroed where it is <= 0.
     row_scale: fp32 [M] factor on the product (before bias / activation).  addend: bf16 [M, N] added before the
-    activation.  out: write into this [M, N] tensor instead of allocating."""
+    activation.  out: write into this [M, N] tensor instead of allocating.
+    bits_out: also return the sign bits of the result, (out, bits) with bits int32 [M, bit_words(N)] (bit b of word w: column
+    32 w + b is positive) -- written by the epilogue from the values it stores.  gate_bits: such a matrix for out_gate's values;
+    the kernel reads 32 bytes of a 256-column row instead of 512 (dgll_hip_transform_bf16_bits).  Both only without mask /
+    row_scale / addend and with bf16 output; gate_bits is ignored otherwise when out_gate is there too."""
     n = wt1.shape[0] if n_out is None else n_out
     m = a1.shape[0]
+    bits_form = mask is None and row_scale is None and addend is None and out_dtype == torch.bfloat16
+    if bits_out and not bits_form:
+        raise ValueError("transform_bf16(bits_out=True): bf16 output without mask / row_scale / addend")
+    if gate_bits is not None:
+        if not bits_form:
+            if out_gate is None:
+                raise ValueError("transform_bf16(gate_bits=) without out_gate: bf16 output without mask / row_scale / addend only")
+            gate_bits = None
+        elif gate_bits.dtype != torch.int32 or gate_bits.shape != (m, bit_words(n)) or not gate_bits.is_contiguous():
+            raise ValueError("gate_bits must be a contiguous int32 [M, bit_words(N)] matrix")
     p1 = _pad_wt(wt1)
     p2 = _pad_wt(wt2) if a2 is not None else None
     own_store = out is None       # `out`: a caller's [M, N] buffer (rows of a larger matrix, say); its padding is not ours to write
@@ -99,6 +118,21 @@ def transform_bf16(a1, wt1, a2=None, wt2=None, relu=False, out_dtype=torch.bfloa
         end = _timed(("transform", m, a1.shape[1], a2.shape[1] if a2 is not None else 0, n,
                       "+".join(t for t, on in (("gate", out_gate is not None), ("addend", addend is not None),
                                                ("row_scale", row_scale is not None), ("mask", mask is not None)) if on)), a1.device)
+        bits = torch.empty((m, bit_words(n)), dtype=torch.int32, device=a1.device) if bits_out else None
+        if bits is not None or gate_bits is not None:
+            code = _lib.lib.dgll_hip_transform_bf16_bits(
+                _lib.raw_stream(a1.device), a1.data_ptr(), a1.stride(0), a1.shape[1], p1.data_ptr(),
+                p1.stride(0), a2.data_ptr() if a2 is not None else None, a2.stride(0) if a2 is not None else 0,
+                a2.shape[1] if a2 is not None else 0, p2.data_ptr() if p2 is not None else None,
+                p2.stride(0) if p2 is not None else 0, p1.shape[0], out.data_ptr(), out.stride(0), m, n,
+                int(relu) | (2 if own_store else 0), bias.data_ptr() if bias is not None else None,
+                out_gate.data_ptr() if out_gate is not None else None, out_gate.stride(0) if out_gate is not None else 0,
+                gate_bits.data_ptr() if gate_bits is not None else None, gate_bits.stride(0) if gate_bits is not None else 0,
+                bits.data_ptr() if bits is not None else None, bits.stride(0) if bits is not None else 0)
+            if end is not None:
+                end.record(torch.cuda.current_stream(a1.device))
+            _lib.check(code, "dgll_hip_transform_bf16_bits")
+            return (out, bits) if bits_out else out
         code = _lib.lib.dgll_hip_transform_bf16_add(
             _lib.raw_stream(a1.device), a1.data_ptr(), a1.stride(0), a1.shape[1], p1.data_ptr(),
             p1.stride(0), a2.data_ptr() if a2 is not None else None, a2.stride(0) if a2 is not None else 0,

@@ -490,15 +490,19 @@ class _DistSageLayer(torch.autograd.Function):
     applied it (`grad_is_gated`).  `placed`: the static input halo (first layer; no gradient to the raw features)."""
 
     @staticmethod
-    def forward(ctx, h, ws, wn, engine, reduce, relu, grad_is_gated, gate_input, placed, token=None):
-        from . import dense
+    def forward(ctx, h, ws, wn, engine, reduce, relu, grad_is_gated, gate_input, placed, token=None, bits_box=None):
+        from . import dense, fused_layers
 
         ctx.token = token
 
         agg = engine.aggregate_static(placed, reduce) if placed is not None else _aggregate_forward(engine, h, reduce)
         wsd, wnd = dense.wcast(ws, h), dense.wcast(wn, h)
         if h.is_cuda and dense._mfma_ok(h, agg) and ws.shape[1] <= 256:
-            out = dense.transform_bf16(h, wsd.t(), agg, wnd.t(), relu=relu)
+            if relu and bits_box is not None and fused_layers.GATE_BITS:      # sign bits of the activation: fused_layers._tag_bits
+                out, bits = dense.transform_bf16(h, wsd.t(), agg, wnd.t(), relu=relu, bits_out=True)
+                bits_box.append(bits)
+            else:
+                out = dense.transform_bf16(h, wsd.t(), agg, wnd.t(), relu=relu)
         else:
             out = dense.mm2_nt(h, wsd.t(), agg, wnd.t(), relu=relu)
         ctx.engine, ctx.reduce, ctx.relu = engine, reduce, relu
@@ -540,7 +544,7 @@ class _DistSageLayer(torch.autograd.Function):
             gh = _aggregate_backward_finish(engine, state, into=gh, gate=gate)
             if ctx.gate_input and gate is None:
                 gh = torch.ops.aten.threshold_backward(gh, h, 0)
-        return gh, gws, gwn, None, None, None, None, None, None, None
+        return gh, gws, gwn, None, None, None, None, None, None, None, None
 
 
 class _DistSageLayerTransformFirst(torch.autograd.Function):
@@ -548,9 +552,10 @@ class _DistSageLayerTransformFirst(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, h, ws, wn, engine, reduce, relu, grad_is_gated, gate_input, token=None):
-        from . import dense
+        from . import dense, fused_layers
 
         ctx.token = token
+        ctx.h_bits = fused_layers._bits_of(h) if gate_input else None
         wsd, wnd = dense.wcast(ws, h), dense.wcast(wn, h)
         z = (dense.transform_bf16(h, wnd.t(), ld_align=64 if wn.shape[1] < 64 else None)
              if (h.is_cuda and dense._mfma_ok(h) and wn.shape[1] <= 256) else dense.mm_nt(h, wnd.t()))
@@ -597,7 +602,7 @@ class _DistSageLayerTransformFirst(torch.autograd.Function):
         gh = None
         if ctx.needs_input_grad[0]:
             if g.is_cuda and dense._mfma_ok(gm, gz) and wsd.shape[0] <= 256 and (not ctx.gate_input or h.stride(1) == 1):
-                gh = dense.transform_bf16(gm, wsd, gz, wnd, out_gate=h if ctx.gate_input else None)
+                gh = dense.transform_bf16(gm, wsd, gz, wnd, out_gate=h if ctx.gate_input else None, gate_bits=ctx.h_bits)
             else:
                 gh = dense.mm2_nt(gm, wsd, gz, wnd)
                 if ctx.gate_input:
@@ -768,8 +773,8 @@ class _DistSageLayerOnAll(torch.autograd.Function):
     gradient it returns covers all n_own + n_halo rows (the self path only the own ones)."""
 
     @staticmethod
-    def forward(ctx, h_all, ws, wn, engine, reduce, relu, grad_is_gated, gate_input):
-        from . import dense
+    def forward(ctx, h_all, ws, wn, engine, reduce, relu, grad_is_gated, gate_input, bits_box=None):
+        from . import dense, fused_layers
 
         p = engine.part
         scale = p.inv_deg if reduce == "mean" else None
@@ -778,7 +783,11 @@ class _DistSageLayerOnAll(torch.autograd.Function):
         h = h_all[:p.n_own]
         wsd, wnd = dense.wcast(ws, h), dense.wcast(wn, h)
         if h.is_cuda and dense._mfma_ok(h, agg) and ws.shape[1] <= 256:
-            out = dense.transform_bf16(h, wsd.t(), agg, wnd.t(), relu=relu)
+            if relu and bits_box is not None and fused_layers.GATE_BITS:      # sign bits of the activation: fused_layers._tag_bits
+                out, bits = dense.transform_bf16(h, wsd.t(), agg, wnd.t(), relu=relu, bits_out=True)
+                bits_box.append(bits)
+            else:
+                out = dense.transform_bf16(h, wsd.t(), agg, wnd.t(), relu=relu)
         else:
             out = dense.mm2_nt(h, wsd.t(), agg, wnd.t(), relu=relu)
         ctx.engine, ctx.reduce, ctx.relu = engine, reduce, relu
@@ -822,7 +831,7 @@ class _DistSageLayerOnAll(torch.autograd.Function):
         else:
             gws = dense.grad_weight(h, g, out=grad_slot_of(ctx.wparams[0])) if ctx.needs_input_grad[1] else None
             gwn = dense.grad_weight(agg, g, out=grad_slot_of(ctx.wparams[1])) if ctx.needs_input_grad[2] else None
-        return gh_all, gws, gwn, None, None, None, None, None
+        return gh_all, gws, gwn, None, None, None, None, None, None
 
 
 def cost_balanced_bounds(rowptr, n_parts, edge_cost=1, row_cost=0):
@@ -1261,8 +1270,11 @@ class DistGraph:
             h_all = _DistSageInputLayerAll.apply(layers[0].weight, layers[0].neighborAgg.weight, self, layers[0].aggr_neighbor_method,
                                                  relu0, relu0, placed_input)          # layer 1 returns its gradient masked
             gated1 = bool(len(layers) > 2 and gates[2] and relu1)
+            box = [] if relu1 else None
             h = _DistSageLayerOnAll.apply(h_all, layers[1].weight, layers[1].neighborAgg.weight, self,
-                                          layers[1].aggr_neighbor_method, relu1, gated1, relu0)
+                                          layers[1].aggr_neighbor_method, relu1, gated1, relu0, box)
+            if box:
+                fused_layers._tag_bits(h, box[0])
             first = 2
         for li, layer in enumerate(layers):
             if li < first:
@@ -1277,8 +1289,11 @@ class DistGraph:
                     h = _DistSageLayerTransformFirst.apply(h, layer.weight, layer.neighborAgg.weight, self, reduce, relu,
                                                            gated, gates[li], token)
                 else:
+                    box = [] if relu else None
                     h = _DistSageLayer.apply(h, layer.weight, layer.neighborAgg.weight, self, reduce, relu, gated, gates[li],
-                                             placed_input if static else None, token)
+                                             placed_input if static else None, token, box)
+                    if box:
+                        fused_layers._tag_bits(h, box[0])
                 if token is not None:
                     h._dgll_gate_token = token
                 continue

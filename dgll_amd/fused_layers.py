@@ -8,6 +8,8 @@ layers are seen by nobody else, so the pair (producer, consumer) may agree that 
 ALREADY masked by (h > 0) -- written by the epilogue of the kernel that produces it (`gate_input`: SpMM gate /
 MFMA output gate) -- and the producer skips its own masking pass (`grad_is_gated`).  Masking is linear and idempotent, so
 the parameter gradients and the model-input gradient are exactly those of the unfused graph."""
+import os
+
 import torch
 
 from . import dense, ops
@@ -33,6 +35,25 @@ FUSE_AGGREGATE_TRANSFORM = False
 BACKWARD_ORDER = __import__("os").environ.get("DGLL_BACKWARD_ORDER", "auto")      # auto | transform-first
 
 
+GATE_BITS = os.environ.get("DGLL_GATE_BITS", "1") != "0"      # 0: the ReLU gates are read back as bf16 activations (A/B, tests)
+
+
+def _tag_bits(out, bits):
+    """The sign bits of an activation travel with the tensor that holds it: (bits, data_ptr, version) -- a consumer uses them only
+    for the very storage and version they were written for (an in-place edit in between bumps the version)."""
+    out._dgll_gate_bits = (bits, out.data_ptr(), out._version)
+
+
+def _bits_of(h):
+    tag = getattr(h, "_dgll_gate_bits", None)
+    if tag is None or not GATE_BITS:
+        return None
+    bits, ptr, version = tag
+    if ptr != h.data_ptr() or version != h._version or bits.shape != (h.shape[0], dense.bit_words(h.shape[1])):
+        return None
+    return bits
+
+
 def _aligned(t):
     return (t.stride(0) * t.element_size()) % 16 == 0 and t.data_ptr() % 16 == 0 and t.stride(1) == 1
 
@@ -41,9 +62,10 @@ class _SageGraphLayer(torch.autograd.Function):
     """out = act(h.Ws + reduce_A(h).Wn)  -- aggregate-then-transform (sageconv.py:33-41,72-75)."""
 
     @staticmethod
-    def forward(ctx, h, ws, wn, graph, reduce, relu, grad_is_gated=False, gate_input=False, token=None):
+    def forward(ctx, h, ws, wn, graph, reduce, relu, grad_is_gated=False, gate_input=False, token=None, bits_box=None):
         wsd, wnd = dense.wcast(ws, h), dense.wcast(wn, h)
         ctx.grad_is_gated, ctx.gate_input, ctx.token = grad_is_gated, gate_input, token
+        ctx.h_bits = _bits_of(h) if gate_input else None
         if FUSE_AGGREGATE_TRANSFORM and dense.fused_ok(graph, h, ws.shape[1], h):
             # ONE launch: a workgroup aggregates a 32-row tile into LDS and feeds it to the MFMAs; the aggregated rows are
             # written (the weight gradient needs them) but never read back (csrc/fused_sage.hip)
@@ -51,7 +73,11 @@ class _SageGraphLayer(torch.autograd.Function):
         else:
             agg = ops.spmm_raw(graph, h, reduce=reduce)
             if dense._mfma_ok(h, agg) and ws.shape[1] <= 256:
-                out = dense.transform_bf16(h, wsd.t(), agg, wnd.t(), relu=relu)
+                if relu and bits_box is not None and GATE_BITS:     # the sign bits ride out with the activation (stores only)
+                    out, bits = dense.transform_bf16(h, wsd.t(), agg, wnd.t(), relu=relu, bits_out=True)
+                    bits_box.append(bits)
+                else:
+                    out = dense.transform_bf16(h, wsd.t(), agg, wnd.t(), relu=relu)
             else:
                 out = dense.mm2_nt(h, wsd.t(), agg, wnd.t(), relu=relu)
         ctx.graph, ctx.reduce, ctx.relu = graph, reduce, relu
@@ -82,7 +108,7 @@ class _SageGraphLayer(torch.autograd.Function):
                 scale = graph.mean_scale_transposed()
                 tval = scale if tval is None else tval * scale
             gtg = ops.spmm_raw(gt, g, val=tval, reduce="sum")                       # A^T (scale . g): plain weighted gather
-            gh = dense.transform_bf16(g, wsd, gtg, wnd, out_gate=h if ctx.gate_input else None)
+            gh = dense.transform_bf16(g, wsd, gtg, wnd, out_gate=h if ctx.gate_input else None, gate_bits=ctx.h_bits)
         elif ctx.needs_input_grad[0]:
             gh, gagg = dense.input_grads(g, wsd, wnd)      # self path, neighbour path: one MFMA launch, g read once
             gt, _ = graph.transpose()
@@ -101,16 +127,17 @@ class _SageGraphLayer(torch.autograd.Function):
                 gh = gh + ops.spmm_raw(gt, gagg, val=tval, reduce="sum")
                 if ctx.gate_input:
                     gh = torch.ops.aten.threshold_backward(gh, h, 0)
-        return gh, gws, gwn, None, None, None, None, None, None
+        return gh, gws, gwn, None, None, None, None, None, None, None
 
 
 class _SageGraphLayerTransformFirst(torch.autograd.Function):
     """out = act(h.Ws + reduce_A(h.Wn))  -- the narrowing layer: the NARROW product is aggregated (mean/sum are linear)."""
 
     @staticmethod
-    def forward(ctx, h, ws, wn, graph, reduce, relu, grad_is_gated=False, gate_input=False, token=None):
+    def forward(ctx, h, ws, wn, graph, reduce, relu, grad_is_gated=False, gate_input=False, token=None, bits_box=None):
         wsd, wnd = dense.wcast(ws, h), dense.wcast(wn, h)
         ctx.grad_is_gated, ctx.gate_input, ctx.token = grad_is_gated, gate_input, token
+        ctx.h_bits = _bits_of(h) if gate_input else None
         # the narrow product is gathered next: one 128-byte line per row (ld_align) instead of rows straddling two lines
         z = (dense.transform_bf16(h, wnd.t(), ld_align=64 if wn.shape[1] < 64 else None)
              if (dense._mfma_ok(h) and wn.shape[1] <= 256) else dense.mm_nt(h, wnd.t()))
@@ -168,12 +195,12 @@ class _SageGraphLayerTransformFirst(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if dense._mfma_ok(gm, gz) and wsd.shape[0] <= 256 and (not ctx.gate_input or h.stride(1) == 1):
                 # g.Ws^T + gz.Wn^T and the ReLU mask of the layer below: one MFMA launch, every operand read once
-                gh = dense.transform_bf16(gm, wsd, gz, wnd, out_gate=h if ctx.gate_input else None)
+                gh = dense.transform_bf16(gm, wsd, gz, wnd, out_gate=h if ctx.gate_input else None, gate_bits=ctx.h_bits)
             else:
                 gh = dense.mm2_nt(gm, wsd, gz, wnd)
                 if ctx.gate_input:
                     gh = torch.ops.aten.threshold_backward(gh, h, 0)
-        return gh, gws, gwn, None, None, None, None, None, None
+        return gh, gws, gwn, None, None, None, None, None, None, None
 
 
 def can_fuse(layer, on_gpu):
@@ -195,8 +222,11 @@ def sage_graph_layer(layer, graph, h, grad_is_gated=False, gate_input=False):
     # a layer that will mask its incoming gradient itself tags its output: a consumer that takes the ReLU's backward over
     # (ops.cross_entropy(fold_relu=True)) says so through the token and the masking pass is skipped (ops.GateToken)
     token = ops.GateToken() if (relu and not grad_is_gated) else None
+    box = [] if relu else None
     out = node.apply(h, layer.weight, layer.neighborAgg.weight, graph, layer.aggr_neighbor_method, relu,
-                     bool(grad_is_gated and relu), bool(gate_input), token)
+                     bool(grad_is_gated and relu), bool(gate_input), token, box)
     if token is not None:
         out._dgll_gate_token = token
+    if box:
+        _tag_bits(out, box[0])
     return out

@@ -434,6 +434,21 @@ int dgll_hip_transform_bf16_add(void* stream, const void* A1, int64_t lda1, int 
                                 int N, int relu, const float* bias, const void* out_gate, int64_t ldgate,
                                 const float* row_scale, const void* addend, int64_t ldadd);
 
+/* The transform with the ReLU gate carried as ONE BIT PER ELEMENT instead of a bf16 matrix (bf16 output; no input mask, row
+ * scale or addend).  The reference keeps the activation itself for autograd's ReLU backward (models/sage.py applies F.relu between
+ * sageConv layers; sageconv.py:72-82 the in-layer activation): 512 bytes of a 256-column row are read back only to learn 256 signs.
+ *   bits_out (may be NULL): uint32 [M, ld_bits_out]; word w of row i, bit b <- out[i, 32 w + b] > 0, from the values the epilogue
+ *     stores (stores only: the producing transform is no slower); words up to 4 * ceil(N / 128) are written, zero past N;
+ *   gate_bits (may be NULL): such a matrix, read INSTEAD of out_gate: out[i, n] is written as 0 where its bit is clear.  The
+ *     resident-weights kernel fetches a block's words one reduction phase ahead of its epilogue; shapes that run the 4-wave
+ *     kernel read out_gate (pass both; gate_bits alone is an error there).  Both describe the same gate: out_gate[i, n] > 0.
+ * ld_*: words per row, multiples of 4, >= 4 * ceil(N / 128); 16-byte aligned bases.  Other arguments as dgll_hip_transform_bf16. */
+int dgll_hip_transform_bf16_bits(void* stream, const void* A1, int64_t lda1, int K1, const void* Wt1, int64_t ldw1,
+                                 const void* A2, int64_t lda2, int K2, const void* Wt2, int64_t ldw2, int wt_rows,
+                                 void* out, int64_t ldo, int64_t M, int N, int relu, const float* bias,
+                                 const void* out_gate, int64_t ldgate, const uint32_t* gate_bits, int64_t ld_gate_bits,
+                                 uint32_t* bits_out, int64_t ld_bits_out);
+
 /* Two products of ONE activation matrix: out1 = A.Wt1^T and out2 = A.Wt2^T, A read once -- the two input gradients
  * g.Ws^T and g.Wn^T of a SAGE layer (what autograd derives for sageconv.py:72-75's `src @ W` pair).  bf16 A [M, lda],
  * Wt1 / Wt2 [wt_rows >= 256, ldw] zero-padded as dgll_hip_transform_bf16 wants them, bf16 out1 / out2 [M, ldo >= N];

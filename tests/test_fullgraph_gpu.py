@@ -394,3 +394,139 @@ def test_weight_packing_is_cast_pad_and_layout_in_one_launch(cuda_device, n, k, 
     act = torch.empty(1, dtype=torch.bfloat16, device=cuda_device)
     assert dense.wcast(base, act) is base                      # fp32: packed (and cast) later; bf16: nothing to do
     assert dense.wcast(base, act.float()).dtype == torch.float32
+
+
+def _sign_bits(t):
+    """Reference packing of (t > 0): int32 [M, bit_words(N)], bit b of word w = column 32 w + b."""
+    from dgll_amd import dense
+
+    m, n = t.shape
+    words = dense.bit_words(n)
+    pos = torch.zeros(m, words * 32, dtype=torch.int64, device=t.device)
+    pos[:, :n] = (t.float() > 0).to(torch.int64)
+    w = (pos.view(m, words, 32) << torch.arange(32, device=t.device)).sum(-1)           # < 2^32
+    return torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32)
+
+
+@pytest.mark.parametrize("M,K1,K2,N", [(1000, 256, 256, 256), (777, 100, 100, 256), (513, 256, 0, 47), (130, 64, 0, 128),
+                                       (4097, 40, 24, 33), (2049, 256, 256, 200), (77, 8, 0, 1), (600, 320, 320, 256)])
+def test_mfma_transform_sign_bits_of_the_output(cuda_device, M, K1, K2, N):
+    """dgll_hip_transform_bf16_bits, producer side: the bits are those of the bf16 values the same launch stored, the values
+    themselves are bit-equal to the launch without bits; padding words / bits past N are zero.  (600, 320+320) runs the 4-wave
+    kernel: the bits come from its one-pass fallback there."""
+    from dgll_amd import dense, ops
+
+    a1 = ops.alloc_features(M, K1, torch.bfloat16, cuda_device)
+    a1.copy_(torch.randn(M, K1, device=cuda_device))
+    a2 = w2 = None
+    if K2:
+        a2 = ops.alloc_features(M, K2, torch.bfloat16, cuda_device)
+        a2.copy_(torch.randn(M, K2, device=cuda_device))
+        w2 = torch.randn(N, K2, device=cuda_device).to(torch.bfloat16)
+    w1 = torch.randn(N, K1, device=cuda_device).to(torch.bfloat16)
+    for relu in (True, False):
+        want = dense.transform_bf16(a1, w1, a2, w2, relu=relu)
+        out, bits = dense.transform_bf16(a1, w1, a2, w2, relu=relu, bits_out=True)
+        assert torch.equal(out, want)
+        assert bits.dtype == torch.int32 and bits.shape == (M, dense.bit_words(N))
+        assert torch.equal(bits, _sign_bits(out))
+
+
+@pytest.mark.parametrize("M,K1,K2,N", [(1111, 47, 47, 256), (1000, 256, 256, 256), (513, 64, 0, 128), (4097, 40, 24, 33),
+                                       (300, 128, 0, 64), (2049, 256, 256, 200), (600, 320, 320, 256)])
+def test_mfma_transform_gate_given_as_bits(cuda_device, M, K1, K2, N):
+    """Consumer side: the gate as bits gives bit-for-bit what the gate as a bf16 matrix gives -- with and without out_gate passed
+    along, into an own allocation (padding written) and into a caller's buffer."""
+    from dgll_amd import dense, ops
+
+    a1 = ops.alloc_features(M, K1, torch.bfloat16, cuda_device, pad_to=64)
+    a1.copy_(torch.randn(M, K1, device=cuda_device))
+    a2 = w2 = None
+    if K2:
+        a2 = ops.alloc_features(M, K2, torch.bfloat16, cuda_device)
+        a2.copy_(torch.randn(M, K2, device=cuda_device))
+        w2 = torch.randn(N, K2, device=cuda_device).to(torch.bfloat16)
+    w1 = torch.randn(N, K1, device=cuda_device).to(torch.bfloat16)
+    gate = ops.alloc_features(M, N, torch.bfloat16, cuda_device)                      # rows on a 16-byte pitch, as every activation
+    gate.copy_(torch.relu(torch.randn(M, N, device=cuda_device)))                     # what a ReLU leaves: zeros and positives
+    gate[5] = 0
+    gate[7] = 1
+    bits = _sign_bits(gate)
+    want = dense.transform_bf16(a1, w1, a2, w2, out_gate=gate)
+    got = dense.transform_bf16(a1, w1, a2, w2, out_gate=gate, gate_bits=bits)
+    assert torch.equal(got, want)
+    assert bool((got[5] == 0).all()) and bool(((got == 0) | (gate > 0)).all())
+    if K1 + K2 <= 512:                                         # the resident-weights kernel: the bits alone are enough
+        assert torch.equal(dense.transform_bf16(a1, w1, a2, w2, gate_bits=bits), want)
+    else:
+        with pytest.raises(RuntimeError, match="out_gate"):
+            dense.transform_bf16(a1, w1, a2, w2, gate_bits=bits)
+    buf = torch.full((M, N + 8), 7.0, dtype=torch.bfloat16, device=cuda_device)
+    if (N + 8) % 8 == 0:
+        dense.transform_bf16(a1, w1, a2, w2, out_gate=gate, gate_bits=bits, out=buf[:, :N])
+        assert torch.equal(buf[:, :N], want) and bool((buf[:, N:] == 7).all())
+    # both at once: gated output and its own sign bits
+    out2, bits2 = dense.transform_bf16(a1, w1, a2, w2, out_gate=gate, gate_bits=bits, bits_out=True)
+    assert torch.equal(out2, want) and torch.equal(bits2, _sign_bits(want))
+
+
+def test_gate_bits_argument_checks(cuda_device):
+    from dgll_amd import dense, ops
+
+    a = ops.alloc_features(64, 64, torch.bfloat16, cuda_device)
+    a.zero_()
+    w = torch.zeros(64, 64, device=cuda_device, dtype=torch.bfloat16)
+    with pytest.raises(ValueError, match="bits_out"):
+        dense.transform_bf16(a, w, out_dtype=torch.float32, bits_out=True)
+    with pytest.raises(ValueError, match="gate_bits"):
+        dense.transform_bf16(a, w, gate_bits=torch.zeros(64, 3, dtype=torch.int32, device=cuda_device))
+    with pytest.raises(ValueError, match="without out_gate"):
+        dense.transform_bf16(a, w, gate_bits=torch.zeros(64, 4, dtype=torch.int32, device=cuda_device),
+                             row_scale=torch.ones(64, device=cuda_device))
+
+
+def test_forward_graph_hands_the_relu_gates_on_as_bits(cuda_device, monkeypatch):
+    """forward_graph with the sign bits riding along its activations (the default) against DGLL_GATE_BITS=0 (gates read back as
+    bf16 activations): every output, input gradient and parameter gradient bit-equal -- the two forms of the gate are the same
+    mask.  An activation edited in place between the layers loses its bits (version check) and the bf16 form is read."""
+    from dgll_amd import fused_layers, ops
+
+    g_cpu, model, x = _setup(cuda_device, fin=100, hidden=(256, 256, 47))
+    g = g_cpu.to(cuda_device)
+    m = model.to(cuda_device)
+    xb = ops.alloc_features(g.n_rows, 100, torch.bfloat16, cuda_device)
+    xb.copy_(x.to(cuda_device))
+    gout = torch.randn(g.n_rows, 47, device=cuda_device).to(torch.bfloat16)
+    seen = []
+    real = fused_layers.dense.transform_bf16
+
+    def spy(*a, **kw):
+        seen.append(kw.get("gate_bits") is not None)
+        return real(*a, **kw)
+
+    def run(bits):
+        monkeypatch.setattr(fused_layers, "GATE_BITS", bits)
+        m.zero_grad()
+        store = ops.alloc_features(g.n_rows, 100, torch.bfloat16, cuda_device)
+        store.copy_(xb)
+        xin = store.requires_grad_()
+        out = m.forward_graph(g, xin)
+        (out.float() * gout.float()).sum().backward()
+        return out.detach(), xin.grad.detach().clone(), [p.grad.detach().clone() for p in m.parameters()]
+
+    monkeypatch.setattr(fused_layers.dense, "transform_bf16", spy)
+    a = run(True)
+    assert any(seen)                                            # the gated input-gradient launches did take the bits
+    seen.clear()
+    b = run(False)
+    assert not any(seen)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    for p, q in zip(a[2], b[2]):
+        assert torch.equal(p, q)
+    # a stale tag is not used
+    h = torch.relu(torch.randn(64, 256, device=cuda_device)).to(torch.bfloat16)
+    fused_layers._tag_bits(h, _sign_bits(h))
+    monkeypatch.setattr(fused_layers, "GATE_BITS", True)
+    assert fused_layers._bits_of(h) is not None
+    h.mul_(2)
+    assert fused_layers._bits_of(h) is None
