@@ -492,7 +492,10 @@ def launch_tables(launches, local_rows, heads_of=None):
                            "kernel_fragment": gat_kernel_fragment(heads, fo, dt, {"fwd": 0, "bwd_rows": 3, "bwd_cols": 2}[kind], bool(packed))}
         elif tag[0] in ("transform", "transform_dual", "grad_weight"):
             kind, m, k1, k2, n_out, extra = tag
-            b_alg = m * (k1 + k2 + n_out) * 2 + (m * n_out * 2 if ("gate" in extra or "addend" in extra) else 0)
+            parts = extra.split("+") if extra else []
+            b_alg = m * (k1 + k2 + n_out) * 2 + (m * n_out * 2 if ("gate" in parts or "addend" in parts) else 0)
+            # a gate read / sign bits written as one bit per element: 4 bytes per 32 columns, rows padded to 16 bytes
+            b_alg += m * 16 * -(-n_out // 128) * (("gatebits" in parts) + ("signbits" in parts))
             name = "%s M=%d K=%d%s N=%d%s" % (kind, m, k1, ("+%d" % k2) if k2 else "", n_out, (" " + extra) if extra else "")
             dense_table[name] = {"count": cnt, "avg_ms": avg_ms, "algorithmic_bytes": b_alg,
                                  "algorithmic_GBps": b_alg / (avg_ms * 1e-3) / 1e9,
@@ -816,7 +819,8 @@ def run_sage(args, c):
          "spmm_launches_per_step": passes,
          "gradient_sharing": None if c.world == 1 else ("RaCoM async (staleness 1)" if opt_wrap is not None else "RaCoM sync")})
     result.update({"loss": float(global_loss), "roofline": roofline, "spmm_launch_table": table,
-                   # bytes = 2 (K1 + K2 + N) per row (+ 2 N for a gate / addend operand); the 5.5 TB/s "streaming ceiling" is what
+                   # bytes = 2 (K1 + K2 + N) per row (+ 2 N for a bf16 gate / addend operand, + 16 ceil(N / 128) for a gate read or sign
+                   # bits written as bits); the 5.5 TB/s "streaming ceiling" is what
                    "dense_launch_table": dense_table})      # a trivial 2R:1W kernel reaches (tools/probes/rw_mix.hip)
     # this rank's GPU time of every timed step (events at the step boundaries): the first step after the barrier runs ~1.5 ms longer
     # (the GPU idled through it), the rest sit at the steady state -- what a longer K converges to

@@ -116,7 +116,8 @@ def transform_bf16(a1, wt1, a2=None, wt2=None, relu=False, out_dtype=torch.bfloa
         if addend is not None and (addend.dtype != torch.bfloat16 or addend.shape != (m, n) or addend.stride(1) != 1):
             raise ValueError("addend must be bf16 [M, N] with contiguous rows")
         end = _timed(("transform", m, a1.shape[1], a2.shape[1] if a2 is not None else 0, n,
-                      "+".join(t for t, on in (("gate", out_gate is not None), ("addend", addend is not None),
+                      "+".join(t for t, on in (("gate", out_gate is not None and gate_bits is None), ("gatebits", gate_bits is not None),
+                                               ("signbits", bits_out), ("addend", addend is not None),
                                                ("row_scale", row_scale is not None), ("mask", mask is not None)) if on)), a1.device)
         bits = torch.empty((m, bit_words(n)), dtype=torch.int32, device=a1.device) if bits_out else None
         if bits is not None or gate_bits is not None:
