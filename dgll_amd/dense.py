@@ -152,6 +152,37 @@ def transform_bf16(a1, wt1, a2=None, wt2=None, relu=False, out_dtype=torch.bfloa
     return out
 
 
+def transform_bf16_cat(a, wt_first, wt_second):
+    """[a . wt_first^T | a . wt_second^T] from ONE pass over `a`: (first, second), two [M, n] views of one bf16 buffer whose rows
+    hold `first` in columns [0, n) and `second` from column hp (64 for n <= 64, else 128) on: every row of either product starts on
+    a 128-byte line.  The narrowing SAGE layer's h.Wn (gathered next) and h.Ws (the aggregate lands on top of it) -- h read once
+    instead of once per product (sageconv.py:72-75 computes them as two matmuls over the same `src`).  wt_*: [n <= 128, K <= 256],
+    any float dtype / strides; a: bf16 [M, K], 16-byte aligned rows."""
+    n, k = wt_first.shape
+    if wt_second.shape != (n, k) or n > 128 or k > 256:
+        raise ValueError("transform_bf16_cat: two [n <= 128, K <= 256] weight matrices of one shape")
+    m = a.shape[0]
+    hp = 64 if n <= 64 else 128
+    rows, ld = 2 * hp, -(-k // 64) * 64
+    packed = torch.empty((rows, ld), dtype=torch.bfloat16, device=a.device)
+    store = torch.empty((m, rows), dtype=torch.bfloat16, device=a.device)
+    with _lib.on_device(a.device):
+        stream = _lib.raw_stream(a.device)
+        for i, wt in enumerate((wt_first, wt_second)):           # cast, zero padding and layout of each half: one small launch
+            w = wt.detach()
+            code = _lib.lib.dgll_hip_pack_weight_bf16(stream, w.data_ptr(), _lib.F32 if w.dtype == torch.float32 else _lib.BF16,
+                                                      w.stride(0), w.stride(1), n, k, packed.data_ptr() + i * hp * ld * 2, ld, hp)
+            _lib.check(code, "dgll_hip_pack_weight_bf16")
+        end = _timed(("transform", m, k, 0, hp + n, "two products"), a.device)
+        code = _lib.lib.dgll_hip_transform_bf16(
+            stream, a.data_ptr(), a.stride(0), k, packed.data_ptr(), ld, None, 0, 0, None, 0, rows, None, 0,
+            store.data_ptr(), rows, _lib.BF16, m, hp + n, 2, None)          # relu bit 1: the row padding is ours (zeros)
+        if end is not None:
+            end.record(torch.cuda.current_stream(a.device))
+    _lib.check(code, "dgll_hip_transform_bf16")
+    return store[:, :n], store[:, hp:hp + n]
+
+
 def fused_ok(graph, x, n_out, h_self=None):
     """Shapes / layouts the fused aggregate -> transform kernel (csrc/fused_sage.hip) takes."""
     return (_mfma_ok(x, h_self) and x.shape[1] <= 256 and n_out <= 256 and getattr(graph, "is_cuda", False)

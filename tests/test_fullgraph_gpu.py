@@ -530,3 +530,18 @@ def test_forward_graph_hands_the_relu_gates_on_as_bits(cuda_device, monkeypatch)
     assert fused_layers._bits_of(h) is not None
     h.mul_(2)
     assert fused_layers._bits_of(h) is None
+
+
+@pytest.mark.parametrize("M,K,n", [(1000, 256, 47), (777, 100, 64), (513, 256, 100), (130, 64, 128), (77, 8, 1)])
+def test_transform_cat_equals_two_transforms(cuda_device, M, K, n):
+    """dense.transform_bf16_cat: both products of one activation matrix from one pass, each starting on a 128-byte line of a shared
+    row -- bit-equal to the two single transforms (same kernel, same reduction order per column)."""
+    from dgll_amd import dense, ops
+
+    a = ops.alloc_features(M, K, torch.bfloat16, cuda_device)
+    a.copy_(torch.randn(M, K, device=cuda_device))
+    w1, w2 = torch.randn(n, K, device=cuda_device), torch.randn(n, K, device=cuda_device)
+    first, second = dense.transform_bf16_cat(a, w1, w2.t().contiguous().t())           # (any strides)
+    assert first.shape == second.shape == (M, n) and first.stride(0) == second.stride(0) == (128 if n <= 64 else 256)
+    assert second.data_ptr() - first.data_ptr() == (128 if n <= 64 else 256)
+    assert torch.equal(first, dense.transform_bf16(a, w1)) and torch.equal(second, dense.transform_bf16(a, w2))
