@@ -535,7 +535,8 @@ def test_forward_graph_hands_the_relu_gates_on_as_bits(cuda_device, monkeypatch)
 @pytest.mark.parametrize("M,K,n", [(1000, 256, 47), (777, 100, 64), (513, 256, 100), (130, 64, 128), (77, 8, 1)])
 def test_transform_cat_equals_two_transforms(cuda_device, M, K, n):
     """dense.transform_bf16_cat: both products of one activation matrix from one pass, each starting on a 128-byte line of a shared
-    row -- bit-equal to the two single transforms (same kernel, same reduction order per column)."""
+    row -- bit-equal to the two single transforms while both run the kernel shape with 512-row blocks (n <= 64); the 256-column
+    shape walks the reduction of a row from another chunk (256-row blocks), so there the results agree to bf16 rounding."""
     from dgll_amd import dense, ops
 
     a = ops.alloc_features(M, K, torch.bfloat16, cuda_device)
@@ -544,4 +545,9 @@ def test_transform_cat_equals_two_transforms(cuda_device, M, K, n):
     first, second = dense.transform_bf16_cat(a, w1, w2.t().contiguous().t())           # (any strides)
     assert first.shape == second.shape == (M, n) and first.stride(0) == second.stride(0) == (128 if n <= 64 else 256)
     assert second.data_ptr() - first.data_ptr() == (128 if n <= 64 else 256)
-    assert torch.equal(first, dense.transform_bf16(a, w1)) and torch.equal(second, dense.transform_bf16(a, w2))
+    want1, want2 = dense.transform_bf16(a, w1), dense.transform_bf16(a, w2)
+    if n <= 64:
+        assert torch.equal(first, want1) and torch.equal(second, want2)
+    else:
+        torch.testing.assert_close(first.float(), want1.float(), rtol=1e-2, atol=1e-2 * float(want1.float().abs().max()))
+        torch.testing.assert_close(second.float(), want2.float(), rtol=1e-2, atol=1e-2 * float(want2.float().abs().max()))
