@@ -205,3 +205,37 @@ def test_dense_backward_products_at_full_size(cuda_device):
     lhs = float((gx.double() ** 2).sum())                                        # <round(g.W^T), gx>
     rhs = float((dense.grad_weight(gx, gr).double() * w.double()).sum())         # <gx^T.g, W> = <g.W^T, gx>
     assert abs(lhs - rhs) <= 1e-3 * abs(rhs), (lhs, rhs)
+
+
+def test_gate_bits_at_full_size(cuda_device):
+    """The bit form of the ReLU gate at the bench shape (M = 2 449 029 rows -- not a multiple of the kernels' 256 / 512-row
+    blocks --, 256 columns): the sign bits a forward transform writes are exactly the signs of what it stored (every word, popcount
+    as a checksum), and the gated transform gives bit for bit the same matrix whether it reads those bits or the activation."""
+    from dgll_amd import dense, ops
+
+    M = 2_449_029
+    torch.manual_seed(0)
+    h = ops.alloc_features(M, 256, torch.bfloat16, cuda_device)
+    h.copy_(torch.randn(M, 256, device=cuda_device))
+    w = (torch.randn(256, 256, device=cuda_device) * 0.06).to(torch.bfloat16)
+    out, bits = dense.transform_bf16(h, w, relu=True, bits_out=True)
+    assert bits.shape == (M, 8)
+    pos = out > 0
+    # word by word on a sample of rows spread over the matrix (first / last block included), popcount over all of it
+    rows = torch.cat([torch.arange(0, 600, device=cuda_device), torch.arange(M - 600, M, device=cuda_device),
+                      torch.randint(0, M, (20_000,), device=cuda_device)])
+    weights = (1 << torch.arange(32, device=cuda_device, dtype=torch.int64))
+    words = (pos[rows].view(-1, 8, 32).to(torch.int64) * weights).sum(-1)
+    got = bits[rows].to(torch.int64) & 0xFFFFFFFF
+    assert torch.equal(got, words)
+    lut = torch.tensor([bin(i).count("1") for i in range(256)], device=cuda_device, dtype=torch.int64)
+    by = bits.view(torch.uint8).to(torch.int64)
+    assert int(lut[by].sum()) == int(pos.sum())
+    del by, words, got
+    g = ops.alloc_features(M, 64, torch.bfloat16, cuda_device)
+    g.copy_(torch.randn(M, 64, device=cuda_device))
+    wg = (torch.randn(256, 64, device=cuda_device) * 0.1).to(torch.bfloat16)
+    a = dense.transform_bf16(g, wg, out_gate=out)
+    b = dense.transform_bf16(g, wg, out_gate=out, gate_bits=bits)
+    assert torch.equal(a, b)
+    assert bool((b[~pos] == 0).all())
