@@ -3,6 +3,7 @@
 // block, after the first wait, after each of the 8 chunk phases, after the next block's loads are issued, around the epilogue.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude tools/probes/res_trace.hip -o tools/probes/res_trace.bin
 #define DGLL_RES_TRACE 1
+#define DGLL_RES_PROBE 1
 #include "../../dgll_amd/csrc/dense.hip"
 #include <cstdio>
 #include <vector>
@@ -44,15 +45,14 @@ static void run(const char* name, int pairs, int K) {
         const unsigned long long* e = &t[((wg * 8 + w) * 4 + b) * 16];
         if (!e[0] || !e[12]) continue;
         ++n;
-        d[0] += (double)(e[1] - e[0]);                                   // first wait
-        for (int c = 0; c < NC; ++c) d[1 + c] += (double)(e[2 + c] - (c ? e[1 + c] : e[1]));
+        for (int c = 0; c < NC; ++c) d[1 + c] += (double)(e[2 + c] - (c ? e[1 + c] : e[0]));   // (phase 0 from the block's start)
         d[9] += (double)(e[11] - e[2 + NC - 1]);                         // issue next block's loads
         d[10] += (double)(e[12] - e[11]);                                // epilogue
         d[11] += (double)(e[12] - e[0]);                                 // whole block
     }
     if (!n) { printf("  no samples\n"); return; }
-    printf("  wait for chunk 0: %.0f", d[0] / n);
-    for (int c = 0; c < NC; ++c) printf("  | phase %d: %.0f", c, d[1 + c] / n);
+    printf(" ");
+    for (int c = 0; c < NC; ++c) printf(" %sphase %d: %.0f", c ? "| " : "", c, d[1 + c] / n);
     printf("  | issue next: %.0f  | epilogue: %.0f  | block: %.0f  (%d samples)\n", d[9] / n, d[10] / n, d[11] / n, n);
     // one wave's raw timeline
     const unsigned long long* e = &t[((3 * 8 + 2) * 4 + 1) * 16];
