@@ -52,6 +52,8 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+LINE_LIMIT = 6000        # characters of the stdout line (the driver keeps an 8 000-character tail and parses the last line)
+FULL_RECORD = os.path.join(ROOT, "bench_full.json")
 METRIC = "aggregated edges/sec + epoch time, 3-layer GraphSAGE ogbn-products, 1/2/4/8 GPU"
 
 
@@ -89,6 +91,10 @@ def parse_args(argv=None):
                     help="append compact records of the other BASELINE configs (gat = config 4, minibatch = config 2, rmat27 = config 5 on "
                          "one GPU) to the default line as `other_workloads`, each measured by a child `bench.py --workload X` run after the "
                          "headline; auto = on for the default single-GPU products-sized sage run")
+    ap.add_argument("--full-line", action="store_true",
+                    help="print the FULL record (definitions, launch tables, per-rank diagnostics, the complete child records) as the stdout "
+                         "line, as rounds 1-5 did; default: a compact line of at most %d characters -- the full record goes to "
+                         "bench_full.json next to bench.py and to stderr" % LINE_LIMIT)
     ap.add_argument("--calibrate", action="store_true",
                     help="launch the known-byte identity gather 3 times before the timed steps (PMC calibration rows)")
     ap.add_argument("--cpu-sample-rows", type=int, default=400_000)
@@ -1616,7 +1622,7 @@ def run_other_workloads(args):
         extra = overrides.get(name, tail if not overrides else None)      # tests name the records they want (small shapes)
         if extra is None:
             continue
-        cmd = [sys.executable, os.path.abspath(__file__), "--workload", workload, "--seed", str(args.seed)] + list(extra)
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", workload, "--seed", str(args.seed), "--full-line"] + list(extra)
         t0 = time.perf_counter()
         try:
             res = subprocess.run(cmd, capture_output=True, text=True, timeout=limit)
@@ -1635,6 +1641,127 @@ def run_other_workloads(args):
 WORKLOADS = {"sage": run_sage, "gat": run_gat, "rmat27": run_rmat27, "minibatch": run_minibatch}
 
 
+def _sig(x, digits=6):
+    """Numbers of the compact line carry `digits` significant figures (the full record keeps every digit)."""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    if isinstance(x, float):
+        return float("%.*g" % (digits, x)) if x == x and abs(x) != float("inf") else None
+    return x
+
+
+def _short(text, limit):
+    text = " ".join(str(text).split())
+    return text if len(text) <= limit else text[:limit - 3] + "..."
+
+
+def compact_roofline(r):
+    """`roofline` of the compact line: numbers + two short strings.  frac_kind = "counter" when `frac` comes from the counter traffic
+    of profiles/traffic.json (same build), "algorithmic_capped" when no entry matched and frac = min(1, frac_algorithmic)."""
+    if not r:
+        return None
+    out = {k: _sig(r.get(k)) for k in ("bound", "achieved", "peak", "unit", "frac", "frac_algorithmic", "traffic", "traffic_over_compulsory",
+                                       "avg_launch_ms", "algorithmic_bytes_per_launch")}
+    out["kernel_fragment"] = _short(r.get("kernel_fragment"), 96)
+    out["build_stamp"] = (r.get("build_stamp") or "")[:16] or None
+    out["frac_kind"] = "counter" if r.get("traffic") is not None and r.get("frac_l2_miss_path") is not None else "algorithmic_capped"
+    if r.get("frac_conservative") is not None:
+        out["frac_conservative"] = _sig(r["frac_conservative"])
+    return out
+
+
+def compact_cpu_baseline(cb):
+    if not cb:
+        return None
+    out = {k: _sig(cb.get(k)) for k in ("value", "unit", "cores", "threads", "kind")}
+    out["cpu_model"] = _short(cb.get("cpu_model"), 48)
+    out["sample"] = _short(cb.get("sample"), 110)
+    for k in ("torch_sparse_mm_csr_edges_per_s", "oracle_c_openmp_csr_edges_per_s", "oracle_c_openmp_edges_per_s"):
+        if cb.get(k) is not None:
+            out[k] = _sig(cb[k])
+    return out
+
+
+def compact_other(rec):
+    """At most ten numeric keys of a child record (the full child record is in bench_full.json)."""
+    if "error" in rec:
+        return {"error": _short(rec["error"], 80), "wall_seconds": _sig(rec.get("wall_seconds"), 4)}
+    r = rec.get("roofline") or {}
+    cb = rec.get("cpu_baseline") or {}
+    out = {"ms_per_step": rec.get("ms_per_step"), "value": rec.get("value"), "roofline_frac": r.get("frac"),
+           "roofline_frac_algorithmic": r.get("frac_algorithmic"), "cpu_baseline_value": cb.get("value")}
+    if "batches_per_s" in rec:
+        out.update({k: rec.get(k) for k in ("batches_per_s", "gpu_side_ms_per_batch", "gpu_side_ms_per_batch_p95",
+                                            "loader_host_ms_per_batch", "cache_miss_rate")})
+    passes = {}
+    for name, ms in (rec.get("gather_launch_ms") or {}).items():       # the three GAT passes of the hidden (8-head) layer
+        for kind in ("fwd", "bwd_rows", "bwd_cols"):
+            if name.startswith("gat %s " % kind) and "packed" not in name and kind not in passes:
+                passes[kind] = ms
+    for kind, ms in passes.items():
+        out["gat_%s_ms" % kind] = ms
+    if "aggregate_first_ms_per_step" in rec:
+        out["aggregate_first_ms_per_step"] = rec["aggregate_first_ms_per_step"]
+    out["wall_seconds"] = rec.get("wall_seconds")
+    return {k: _sig(v, 5) for k, v in list(out.items())[:10] if v is not None}
+
+
+def compact_line(result, full_path=None):
+    """The ONE stdout line: the contract fields, `roofline` and `cpu_baseline` as numbers + short strings, `other_workloads` as at most
+    ten numbers per config -- at most LINE_LIMIT characters.  Definitions, `sample` prose, launch tables, per-step times, the extra-graph
+    rooflines, per-rank diagnostics and the child commands stay in the full record (bench_full.json / stderr / --full-line)."""
+    cfg = result.get("config", {})
+    line = {k: _sig(result.get(k), 10) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                                 "scaling", "vs_baseline", "dtype", "data")}
+    keep_cfg = {"workload": _short(cfg.get("workload"), 260)}
+    for k in ("workload_id", "nodes", "nnz", "hidden", "heads", "scale", "batch", "fanouts", "locality", "permuted_ids", "reorder",
+              "parallelism", "spmm_launches_per_step", "gradient_sharing", "ranks", "backend", "exchange_form"):
+        if cfg.get(k) is not None:
+            keep_cfg[k] = _sig(cfg[k])
+    if isinstance(cfg.get("halo_mode"), dict):
+        keep_cfg["halo_mode"] = cfg["halo_mode"].get("mode")
+    line["config"] = keep_cfg
+    for k in ("epoch_time_s", "loss", "batches_per_s", "gpu_side_ms_per_batch", "gpu_side_ms_per_batch_p95", "loader_host_ms_per_batch",
+              "cache_miss_rate", "aggregate_first_ms_per_step", "allgather_ms"):
+        if result.get(k) is not None:
+            line[k] = _sig(result[k])
+    line["roofline"] = compact_roofline(result.get("roofline"))
+    if "cpu_baseline" in result:
+        line["cpu_baseline"] = compact_cpu_baseline(result["cpu_baseline"])
+    gather = {_short(name, 60): _sig(v.get("avg_ms"), 4) for name, v in (result.get("spmm_launch_table") or {}).items()}
+    dense = {_short(name, 60): [_sig(v.get("avg_ms"), 4), _sig(v.get("frac_of_hbm_peak"), 3)]
+             for name, v in (result.get("dense_launch_table") or {}).items()}
+    if gather:
+        line["gather_launch_ms"] = gather
+    if dense:
+        line["dense_launch_ms_and_frac_of_hbm_peak"] = dense
+    if result.get("other_workloads"):
+        line["other_workloads"] = {name: compact_other(rec) for name, rec in result["other_workloads"].items()}
+    line["full_record"] = os.path.basename(full_path) if full_path else None
+    text = json.dumps(line, separators=(",", ":"))
+    for drop in ("dense_launch_ms_and_frac_of_hbm_peak", "gather_launch_ms"):      # never over the limit: the optional tables go first
+        if len(text) > LINE_LIMIT and drop in line:
+            del line[drop]
+            text = json.dumps(line, separators=(",", ":"))
+    if len(text) > LINE_LIMIT:
+        line["config"]["workload"] = _short(line["config"]["workload"], 80)
+        line.pop("other_workloads", None)
+        text = json.dumps(line, separators=(",", ":"))
+    return text
+
+
+def write_full_record(result):
+    """The full record next to bench.py (bench_full.json; DGLL_BENCH_FULL_RECORD overrides the path); None when the directory is read-only."""
+    path = os.environ.get("DGLL_BENCH_FULL_RECORD", FULL_RECORD)
+    try:
+        with open(path + ".tmp", "w") as f:
+            json.dump(result, f, indent=1)
+        os.replace(path + ".tmp", path)
+        return path
+    except OSError:
+        return None
+
+
 def main():
     args = parse_args()
     if os.environ.get("DGLL_BENCH_DUMP_AFTER"):       # diagnostics: every thread's Python stack after that many seconds (a rank that hangs)
@@ -1650,7 +1777,13 @@ def main():
                          and args.undirected_edges == 61_859_140 and args.dtype == "bf16")
         if args.other_workloads == "on" or (args.other_workloads == "auto" and default_shape):
             result["other_workloads"] = run_other_workloads(args)
-        print(json.dumps(result))
+        if args.full_line:
+            print(json.dumps(result), flush=True)
+            return
+        full_path = write_full_record(result)
+        sys.stderr.write("bench.py full record%s:\n%s\n" % ((" (also in %s)" % full_path) if full_path else "", json.dumps(result)))
+        sys.stderr.flush()
+        print(compact_line(result, full_path), flush=True)
 
 
 if __name__ == "__main__":

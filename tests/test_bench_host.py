@@ -136,3 +136,38 @@ def test_compact_record_keeps_the_contract_fields_of_a_child_run(bench):
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(c["cpu_baseline"]) and "seconds_per_run" not in c["cpu_baseline"]
     assert c["gat_pass_over_spmm"] == {"fwd": 1.2} and c["gather_launch_ms"] == {"gat fwd": 5.5} and c["config"]["heads"] == 8
     assert "dense_launch_table" not in c and "spmm_launch_table" not in c
+
+
+def test_compact_line_of_a_full_default_record_fits_the_drivers_reader(bench):
+    """The round-5 default record (25 KB, profiles/r05_bench_default.json: headline + five child records) through compact_line: under
+    LINE_LIMIT characters, valid JSON, contract fields kept, roofline / cpu_baseline numeric, <= 10 numbers per other workload."""
+    with open(os.path.join(ROOT, "profiles", "r05_bench_default.json")) as f:
+        full = json.load(f)
+    assert len(json.dumps(full)) > 20000
+    text = bench.compact_line(full, "/somewhere/bench_full.json")
+    assert len(text) <= bench.LINE_LIMIT == 6000 and "\n" not in text
+    d = json.loads(text)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline", "cpu_baseline", "other_workloads"):
+        assert key in d, key
+    assert d["metric"] == full["metric"] and d["value"] == pytest.approx(full["value"], rel=1e-9) and d["ms_per_step"] == pytest.approx(full["ms_per_step"], rel=1e-9)
+    r = d["roofline"]
+    assert r["frac"] == pytest.approx(full["roofline"]["frac"], rel=1e-5) and r["frac"] <= 1 and r["frac_kind"] == "counter" and r["traffic"] == full["roofline"]["traffic"]
+    assert r["frac_conservative"] == pytest.approx(full["roofline"]["frac_conservative"], rel=1e-5) and r["build_stamp"] == full["roofline"]["build_stamp"][:16]
+    assert set(r) <= {"bound", "achieved", "peak", "unit", "frac", "frac_algorithmic", "traffic", "traffic_over_compulsory", "kernel_fragment",
+                      "avg_launch_ms", "algorithmic_bytes_per_launch", "build_stamp", "frac_kind", "frac_conservative"}
+    cb = d["cpu_baseline"]
+    assert cb["value"] > 0 and cb["cores"] == 256 and cb["kind"] == "port" and cb["oracle_c_openmp_csr_edges_per_s"] > 0 and len(cb["sample"]) <= 110
+    assert set(d["other_workloads"]) == set(full["other_workloads"])
+    for name, rec in d["other_workloads"].items():
+        assert len(rec) <= 10 and all(isinstance(v, (int, float)) for v in rec.values()), name
+        assert rec["ms_per_step"] == pytest.approx(full["other_workloads"][name]["ms_per_step"], rel=1e-4)
+    assert d["other_workloads"]["gat"]["gat_fwd_ms"] == pytest.approx(5.7051) and d["other_workloads"]["minibatch"]["batches_per_s"] > 600
+    assert d["other_workloads"]["sage_f32"]["roofline_frac"] <= 1.0 and d["full_record"] == "bench_full.json"
+    # a record that would still be too long loses its optional tables first, never the contract fields
+    fat = dict(full, spmm_launch_table={("launch kind %04d " % i) + "x" * 40: {"avg_ms": 1.0} for i in range(200)})
+    slim = json.loads(bench.compact_line(fat, None))
+    assert len(bench.compact_line(fat, None)) <= bench.LINE_LIMIT and "gather_launch_ms" not in slim and "roofline" in slim and "cpu_baseline" in slim
+    # a failed child leaves a short error record
+    bad = dict(full, other_workloads={"gat": {"error": "exit code 1", "stderr_tail": "x" * 600, "wall_seconds": 3.0, "command": "c"}})
+    assert json.loads(bench.compact_line(bad, None))["other_workloads"]["gat"] == {"error": "exit code 1", "wall_seconds": 3.0}

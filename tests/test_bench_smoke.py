@@ -31,7 +31,7 @@ def _last_json(text):
 
 
 def test_bench_single_rank_contract():
-    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SHAPE, capture_output=True, text=True, timeout=600)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--full-line"] + SHAPE, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-3000:]
     d = _last_json(res.stdout)
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
@@ -54,6 +54,41 @@ def test_bench_single_rank_contract():
     test_bench_single_rank_contract.loss = d["loss"]
 
 
+def test_bench_default_line_is_compact_and_parses(tmp_path):
+    """What the driver reads: the LAST stdout line, without --full-line -- at most 6000 characters (round 5's 25 KB line was not parsed),
+    valid JSON, the contract fields, numeric `roofline` / `cpu_baseline`, `other_workloads` as <= 10 numbers per config; the full record
+    goes to bench_full.json (here: DGLL_BENCH_FULL_RECORD) and to stderr."""
+    other = {"rmat27": ["--scale", "16", "--steps", "2", "--warmup", "1", "--cpu-sample-rows", "2000"]}
+    full_path = str(tmp_path / "full.json")
+    env = dict(os.environ, DGLL_BENCH_OTHER_ARGS=json.dumps(other), DGLL_BENCH_FULL_RECORD=full_path)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--other-workloads", "on"] + SHAPE, capture_output=True, text=True,
+                         timeout=900, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    line = lines[-1]
+    assert len(line) < 6000 and sum(ln.startswith("{") for ln in lines) == 1
+    d = json.loads(line)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["dtype"] == "bf16" and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"] and d["config"]["nnz"] == 400000
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and 0.0 < r["frac"] <= 1.0 and r["achieved"] > 0
+    assert r["frac_kind"] in ("counter", "algorithmic_capped") and (r["traffic"] is None) == (r["frac_kind"] == "algorithmic_capped")
+    assert all(not isinstance(v, str) or len(v) <= 100 for v in r.values()) and "frac_definition" not in r
+    cb = d["cpu_baseline"]
+    assert cb["value"] > 0 and cb["kind"] == "port" and cb["cores"] >= 1 and cb["unit"] == "edges/s" and len(cb["sample"]) <= 110
+    # value and ms_per_step agree with each other: 5 SpMM-type launches of nnz edges per step
+    assert abs(d["value"] - 5 * d["config"]["nnz"] / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    ow = d["other_workloads"]["rmat27"]
+    assert len(ow) <= 10 and all(isinstance(v, (int, float)) for v in ow.values()) and ow["ms_per_step"] > 0 and 0 < ow["roofline_frac"] <= 1
+    full = json.load(open(full_path))
+    assert d["full_record"] == "full.json" and "spmm_launch_table" in full and "frac_definition" in full["roofline"]
+    assert full["ms_per_step"] == pytest.approx(d["ms_per_step"], rel=1e-8) and "command" in full["other_workloads"]["rmat27"]
+    assert "bench.py full record" in res.stderr
+
+
 def _check_two_ranks(res):
     assert res.returncode == 0, res.stderr[-3000:]
     d = _last_json(res.stdout)
@@ -68,7 +103,7 @@ def _check_two_ranks(res):
 def test_bench_two_ranks_on_one_gpu_agree_with_one_rank():
     env = dict(os.environ, DGLL_BENCH_BACKEND="gloo", DGLL_HALO_MODE="recompute")   # (auto adds warm-up steps: the loss is compared across rank counts)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SHAPE
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--full-line", "--gpus", "2"] + SHAPE
     _check_two_ranks(subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env))
 
 
@@ -78,11 +113,11 @@ def test_bench_gpus_flag_starts_the_ranks_itself():
     env = dict(os.environ, DGLL_BENCH_BACKEND="gloo", DGLL_HALO_MODE="recompute")   # (auto adds warm-up steps: the loss is compared across rank counts)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
-    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SHAPE, capture_output=True, text=True,
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--full-line", "--gpus", "2"] + SHAPE, capture_output=True, text=True,
                          timeout=900, env=env)
     _check_two_ranks(res)
     # asynchronous RaCoM (gradients applied one step late, drained every sync period): same contract, finite loss
-    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--racom-async"] + SHAPE,
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--full-line", "--gpus", "2", "--racom-async"] + SHAPE,
                          capture_output=True, text=True, timeout=900, env=env)
     assert res.returncode == 0, res.stderr[-3000:]
     d = _last_json(res.stdout)
@@ -95,7 +130,7 @@ def test_bench_lets_the_live_ranks_choose_the_halo_mode():
     env = dict(os.environ, DGLL_BENCH_BACKEND="gloo")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "DGLL_HALO_MODE"):
         env.pop(k, None)
-    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SHAPE, capture_output=True, text=True,
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--full-line", "--gpus", "2"] + SHAPE, capture_output=True, text=True,
                          timeout=900, env=env)
     assert res.returncode == 0, res.stderr[-3000:]
     hm = _last_json(res.stdout)["config"]["halo_mode"]
@@ -105,7 +140,7 @@ def test_bench_lets_the_live_ranks_choose_the_halo_mode():
 
 def test_bench_refuses_a_world_size_that_contradicts_gpus():
     env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
-    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SHAPE, capture_output=True, text=True,
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--full-line", "--gpus", "2"] + SHAPE, capture_output=True, text=True,
                          timeout=300, env=env)
     assert res.returncode == 2 and "WORLD_SIZE" in res.stderr
 
@@ -116,7 +151,7 @@ def test_bench_eight_ranks_on_one_gpu():
     env = dict(os.environ, DGLL_BENCH_BACKEND="gloo", DGLL_HALO_MODE="recompute")   # (auto adds warm-up steps: the loss is compared across rank counts)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
-    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"] + SHAPE, capture_output=True, text=True,
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--full-line", "--gpus", "8"] + SHAPE, capture_output=True, text=True,
                          timeout=1500, env=env)
     assert res.returncode == 0, res.stderr[-3000:]
     d = _last_json(res.stdout)
@@ -131,7 +166,7 @@ def test_bench_gat_workload_one_and_two_ranks():
     the GAT cpu_baseline; two ranks (gloo, one GPU) reach the same loss through the partitioned edge-softmax."""
     shape = ["--workload", "gat", "--nodes", "20000", "--undirected-edges", "200000", "--hidden", "64", "--heads", "8", "--classes", "10",
              "--in-feats", "40", "--steps", "2", "--warmup", "1", "--cpu-sample-rows", "2000"]
-    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + shape, capture_output=True, text=True, timeout=600)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--full-line"] + shape, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-3000:]
     d = _last_json(res.stdout)
     assert d["config"]["workload_id"] == "gat" and d["config"]["gather_passes_per_step"] == 6 and d["roofline"]["bound"] == "hbm"
@@ -142,7 +177,7 @@ def test_bench_gat_workload_one_and_two_ranks():
     env = dict(os.environ, DGLL_BENCH_BACKEND="gloo", DGLL_HALO_MODE="recompute")   # (auto adds warm-up steps: the loss is compared across rank counts)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
-    res2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + shape, capture_output=True, text=True,
+    res2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--full-line", "--gpus", "2"] + shape, capture_output=True, text=True,
                           timeout=900, env=env)
     assert res2.returncode == 0, res2.stderr[-3000:]
     d2 = _last_json(res2.stdout)
@@ -159,7 +194,7 @@ def test_bench_minibatch_and_rmat_workloads(fused):
              "--mb-batch", "64", "--mb-fanouts", "5,3,3", "--hidden", "64", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
     if not fused:
         shape.append("--mb-no-fused-last-hop")
-    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + shape, capture_output=True, text=True, timeout=600)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--full-line"] + shape, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-3000:]
     d = _last_json(res.stdout)
     assert d["config"]["workload_id"] == "minibatch" and d["steps"] == 192 and d["warmup"] == 16
@@ -175,7 +210,7 @@ def test_bench_minibatch_and_rmat_workloads(fused):
         assert abs(prev - d["loss"]) < 2e-2 * abs(prev)                 # same batches (seeded sampler), same model
     test_bench_minibatch_and_rmat_workloads.loss = d["loss"]
     if fused:
-        res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "rmat27", "--scale", "16", "--steps", "2",
+        res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--full-line", "--workload", "rmat27", "--scale", "16", "--steps", "2",
                               "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
         assert res.returncode == 0, res.stderr[-3000:]
         r = _last_json(res.stdout)
@@ -190,10 +225,10 @@ def test_bench_rmat27_row_blocks_on_several_ranks(world):
     env = dict(os.environ, DGLL_BENCH_BACKEND="gloo")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
-    one = _last_json(subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "rmat27", "--scale", "16", "--steps", "2",
+    one = _last_json(subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--full-line", "--workload", "rmat27", "--scale", "16", "--steps", "2",
                                      "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600).stdout)
     assert one["config"]["layer_order"] == "transform-first" and one["aggregate_first_ms_per_step"] > 0 and len(one["per_rank"]) == 1
-    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "rmat27", "--scale", "16", "--steps", "2",
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--full-line", "--workload", "rmat27", "--scale", "16", "--steps", "2",
                           "--warmup", "1", "--gpus", str(world)], capture_output=True, text=True, timeout=1200, env=env)
     assert res.returncode == 0, res.stderr[-3000:]
     d = _last_json(res.stdout)
@@ -217,7 +252,7 @@ def test_bench_minibatch_single_stream_mode_still_runs():
     1-3), host-side translation of the outermost hop."""
     shape = ["--workload", "minibatch", "--mb-nodes", "20000", "--mb-undirected-edges", "400000", "--mb-feats", "50", "--mb-classes", "7",
              "--mb-batch", "64", "--mb-fanouts", "5,3,3", "--hidden", "64", "--no-cpu-baseline", "--mb-sampler-threads", "0", "--mb-host-translate"]
-    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + shape, capture_output=True, text=True, timeout=600)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--full-line"] + shape, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-3000:]
     d = _last_json(res.stdout)
     assert d["host_sampler_threads"] == 0 and "sequential" in d["sampler_mode"] and d["outermost_hop_translation"] == "host"
@@ -235,7 +270,7 @@ def test_default_line_carries_the_other_baseline_configs():
         "rmat27": ["--scale", "16", "--steps", "2", "--warmup", "1", "--cpu-sample-rows", "2000"],
     }
     env = dict(os.environ, DGLL_BENCH_OTHER_ARGS=json.dumps(other))
-    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--other-workloads", "on", "--no-extra-graphs"] + SHAPE,
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--full-line", "--other-workloads", "on", "--no-extra-graphs"] + SHAPE,
                          capture_output=True, text=True, timeout=1500, env=env)
     assert res.returncode == 0, res.stderr[-3000:]
     d = _last_json(res.stdout)
@@ -248,7 +283,7 @@ def test_default_line_carries_the_other_baseline_configs():
         assert set(("value", "unit", "cores", "kind", "sample")) <= set(rec["cpu_baseline"]) and rec["cpu_baseline"]["kind"] == "port"
     assert "gat_pass_over_spmm" not in ow["gat"] and ow["minibatch"]["batches_per_s"] > 0       # --no-extra-graphs: no SpMM comparison leg
     # the small-shape headline alone does not start them
-    assert "other_workloads" not in _last_json(subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-extra-graphs"] + SHAPE,
+    assert "other_workloads" not in _last_json(subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--full-line", "--no-extra-graphs"] + SHAPE,
                                                               capture_output=True, text=True, timeout=600).stdout)
 
 
@@ -267,7 +302,7 @@ def test_bench_runs_a_dataset_directory_in_the_ogb_raw_layout(tmp_path):
     np.savetxt(raw / "edge.csv", np.stack([src[keep], dst[keep]], 1), fmt="%d", delimiter=",")
     np.savetxt(raw / "node-feat.csv", rng.standard_normal((n, f)).astype(np.float32), fmt="%.5f", delimiter=",")
     np.savetxt(raw / "node-label.csv", rng.integers(0, c, (n, 1)), fmt="%d", delimiter=",")
-    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dataset", str(tmp_path / "products"), "--hidden", "64",
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--full-line", "--dataset", str(tmp_path / "products"), "--hidden", "64",
                           "--steps", "2", "--warmup", "1", "--cpu-sample-rows", "500", "--no-extra-graphs"],
                          capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-3000:]
