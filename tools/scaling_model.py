@@ -123,9 +123,127 @@ def rmat27_model(scale, feat=128, dtype=torch.bfloat16, reps=5):
 
 
 
+def gat_model(worlds=(2, 4), heads=8, fo=32, classes=47, in_feats=100):
+    """Config 4 ("2-layer GAT (8 heads) on ogbn-products, 1 -> 4 GPUs"): EVERY rank of N = 2, 4 of bench.py's `--workload gat` step
+    through its real kernels on one GPU with the stand-in transport -- the partitioned SpGAT (DistGraph.spgat_forward: first layer's
+    transform and scores evaluated on the placed halo rows, nothing exchanged for it; the out head exchanges its 47-wide rows and
+    scores), the fused cross-entropy, RaCoM's flat buffer, Adam.  MODEL_HALO_MODES=recompute,exchange runs both forms."""
+    dev = torch.device("cuda:0")
+    raw = synth.products_like_graph(dev, seed=0, locality=0.9, exact=True, permute_ids=True, self_loops=True)     # bench.py --workload gat
+    n, nnz = raw.n_rows, raw.nnz
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1)
+    feats = torch.randn(n, in_feats, generator=gen, device=dev)
+    labels_all = torch.randint(0, classes, (n,), generator=gen, device=dev)
+
+    def timed(step, reps=10, warm=3):
+        for _ in range(warm):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            step()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    def single_gpu_step_ms():
+        torch.manual_seed(0)
+        model = dnn.SpGAT(in_feats, fo, classes, dropout=0.0, alpha=0.2, nheads=heads).to(dev)
+        opt = FlatAdam(list(model.parameters()), lr=1e-3)
+        full, perm = raw.reorder(seed=0)
+        full.plan(); full.transpose()[0].plan()
+        x = ops.alloc_features(n, in_feats, torch.bfloat16, dev, pad_to=64)
+        x.copy_(feats[perm])
+        lab = labels_all[perm]
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            loss = ops.cross_entropy(model.forward_activations(x, full), lab, reduction="sum") * (1.0 / n)
+            loss.backward()
+            opt.step()
+
+        return timed(step)
+
+    single_ms = float(os.environ["SINGLE_MS"]) if "SINGLE_MS" in os.environ else single_gpu_step_ms()
+    torch.cuda.empty_cache()
+    print("config 4, single-GPU SpGAT step (%d heads x %d -> %d; %d nodes, nnz %d with self-loops; measured in this run): %.2f ms" % (
+        heads, fo, classes, n, nnz, single_ms))
+    halo_modes = os.environ.get("MODEL_HALO_MODES", "recompute").split(",")
+    summary = []
+    for world in worlds:
+        stats = {}
+        perm, bounds = dpart.partition_and_order(raw, world, seed=0, stats=stats)
+        full = dreorder.relabel(raw, perm)
+        q = stats.get("balanced", stats["after"])
+        print("N=%d partition: cut %.2f %%, edges max/mean %.3f" % (world, 100 * q["cut"], q["balance"]))
+        feats_p, labels_p = feats[perm], labels_all[perm]
+        ranks = list(range(world)) if "MODEL_RANK" not in os.environ else [RANK % world]
+        for mode in halo_modes:
+            per_rank = []
+            for rank in ranks:
+                torch.manual_seed(0)
+                model = dnn.SpGAT(in_feats, fo, classes, dropout=0.0, alpha=0.2, nheads=heads).to(dev)
+                params = list(model.parameters())
+                opt = FlatAdam(params, lr=1e-3)
+                racom = ddist.RaCoM(params, dev, flat=opt)
+                part = ddist.partition_contiguous(full, world, rank, bounds)
+                engine = ddist.DistGraph(part, dev)
+                engine.halo_recompute = mode == "recompute"
+                engine.exchange = NullExchange(part)
+                x = ops.alloc_features(part.n_own, in_feats, torch.bfloat16, dev, pad_to=64)
+                x.copy_(feats_p[part.own_begin:part.own_end])
+                labels = labels_p[part.own_begin:part.own_end]
+                placed = engine.place_input_halo(x)
+
+                def step():
+                    opt.zero_grad(set_to_none=True)
+                    act = engine.spgat_forward(model, x, placed, activations=True)
+                    loss = ops.cross_entropy(act, labels, reduction="sum") * (world / n)
+                    loss.backward()
+                    racom.all_reduce_and_wait()
+                    opt.step()
+
+                for _ in range(3):
+                    step()
+                torch.cuda.synchronize()
+                engine.exchange.sent = engine.exchange.received = 0
+                reps = 10
+                with ops.LaunchTimer() as timer:
+                    t0 = time.perf_counter()
+                    for _ in range(reps):
+                        step()
+                    torch.cuda.synchronize()
+                    ms = (time.perf_counter() - t0) / reps * 1e3
+                gather_ms = sum(v[1] * v[0] for k, v in timer.summary().items() if k[0] in ("gat", "spmm")) / reps
+                rx, tx = engine.exchange.received / reps, engine.exchange.sent / reps
+                per_rank.append((rank, ms, rx, tx))
+                print("   N=%d [%s] rank %d: %7d rows, %9d + %8d (halo) edges, %7d halo rows | compute %.2f ms/step (gather passes %.2f) | "
+                      "receives %.0f MB, sends %.0f MB per step" % (world, mode, rank, part.n_own, part.local.nnz, part.halo.nnz, part.n_halo,
+                                                                     ms, gather_ms, rx / 1e6, tx / 1e6))
+                del engine, part, model, opt, racom, placed, x
+                torch.cuda.empty_cache()
+            slow = max(per_rank, key=lambda t: t[1])
+            mean = sum(t[1] for t in per_rank) / len(per_rank)
+            rx, tx = max(t[2] for t in per_rank), max(t[3] for t in per_rank)
+            print("N=%d [%s]: slowest rank %d %.2f ms, mean %.2f ms, spread %+.1f %% / %+.1f %% of the mean; ideal %.2f ms" % (
+                world, mode, slow[0], slow[1], mean, 100 * (slow[1] / mean - 1), 100 * (min(t[1] for t in per_rank) / mean - 1), single_ms / world))
+            for bw in (150e9, 300e9, 450e9):
+                wire = max(rx, tx) / bw * 1e3
+                print("      at %3.0f GB/s per direction: wire %.2f ms -> step %.2f (hidden) .. %.2f ms (exposed): speed-up %.2fx .. %.2fx" % (
+                    bw / 1e9, wire, max(slow[1], wire), slow[1] + wire, single_ms / max(slow[1], wire), single_ms / (slow[1] + wire)))
+            summary.append((world, mode, slow[1], mean, single_ms / slow[1]))
+        del full
+        torch.cuda.empty_cache()
+    print("summary, config 4 (single-GPU step %.2f ms):" % single_ms)
+    for world, mode, slow, mean, sp in summary:
+        print("   N=%d %-9s slowest rank %.2f ms (mean %.2f): %.2fx with the exchange hidden" % (world, mode, slow, mean, sp))
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "rmat27":
         return rmat27_model(int(sys.argv[2]) if len(sys.argv) > 2 else 27)
+    if len(sys.argv) > 1 and sys.argv[1] == "gat":
+        return gat_model(tuple(int(a) for a in sys.argv[2:]) or (2, 4))
     dev = torch.device("cuda:0")
     raw = synth.products_like_graph(dev, seed=0, locality=0.9, exact=True, permute_ids=True)     # bench.py's default graph
     n, nnz = raw.n_rows, raw.nnz
