@@ -116,6 +116,8 @@ SIGNATURES = {
                                   C.c_float, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dgll_hip_gemm_f32": (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _i32]),
     "dgll_hip_mm_f32": (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _i32, _vp, _i64]),
+    "dgll_hip_mm2_f32": (_i32, [_vp, _vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp, _i64, _i32, _vp, _i64, _i64, _i32, _vp, _i32, _vp, _i64,
+                                _vp, _i64]),
     "dgll_hip_grad_weight_f32_workspace": (_i64, [_i32, _i32, _i32]),
     "dgll_hip_grad_weight_f32": (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _i64, _i32]),
     "dgll_hip_transform_bf16": (_i32, [_vp, _vp, _i64, _i32, _vp, _i64, _vp, _i64, _i32, _vp, _i64, _i32, _vp, _i64, _vp,

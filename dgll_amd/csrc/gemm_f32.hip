@@ -1,16 +1,24 @@
 // gemm_f32.hip -- the dense products of the layers for fp32 tensors (the 1e-4 parity path), hand-written for gfx950.
 //
 // Reference call sites: F.mm(x, weight) gcnconv.py:30, F.matmul sageconv.py:41,72, F.mm gatconv.py:31,117 and, through
-// autograd, their gradients g.W^T and x^T.g.  Two shapes, both tall-skinny (M ~ 1e4 .. 1e6 rows, N, K <= a few hundred):
-//   * dgll_hip_mm_f32       C[M, N] = act(A[M, K] . Wt[N, K]^T + bias)      forward products and input gradients
-//     v_mfma_f32_32x32x2_f32 (fp32 in, fp32 accumulate: exact fp32 FMA arithmetic, 1/16 of the bf16 rate -- at N = K = 256 the
-//     product is matrix-core bound, about 2.5 x the HBM time).  One wavefront owns 32 rows x all N <= 256 columns; the weights
-//     are the MFMA "A" operand and the activations "B", so a lane ends up with 4 consecutive output columns of ONE row
-//     (float4 stores).  The reduction index inside a group of 8 is permuted -- lane half h takes k = 8 j + 4 h .. + 3 -- so
-//     that every lane's four MFMA inputs are one 16-byte load, for the activations and the (transposed) weights alike.
+// autograd, their gradients g.W^T and x^T.g.  Two shapes, both tall-skinny (M ~ 1e4 .. 1e6 rows, N, K <= a few hundred), both on
+// v_mfma_f32_32x32x2_f32 (fp32 in, fp32 accumulate: exact fp32 FMA arithmetic, 64 flops per cycle and SIMD = 157 TFLOP/s on 256 CUs;
+// at N = K = 256 a product is matrix-core bound, about 2.5 x its HBM time):
+//   * dgll_hip_mm2_f32 / dgll_hip_mm_f32   C[M, N] = gate(act(A1[M, K1] . W1t[N, K1]^T (+ A2[M, K2] . W2t[N, K2]^T) + addend + bias))
+//     forward products and input gradients; the two-operand form is sageConv's self + neighbour term (sageconv.py:72-75) or the
+//     layer's two input-gradient products in ONE accumulation (no stored intermediate), `gate` the ReLU mask of the layer below.
+//     A workgroup of 8 wavefronts owns 256 rows x all N <= 256 columns; the reduction runs in chunks of 32: the chunk of the weights
+//     ([N, 32]) and of the activations ([256, 32]) is fetched with coalesced 16-byte loads one chunk ahead (registers), parked in
+//     LDS (rows padded to 36 floats: conflict-free ds_read_b128) and read from there as MFMA operands -- round 5's kernel fetched
+//     every operand straight from L1 with one cache line per lane (9 loads x 64 lines per 32 MFMAs: it ran at 0.3 of the MFMA
+//     rate).  The weights are the MFMA "A" operand and the activations "B", so a lane ends up with 4 consecutive output columns
+//     of ONE row (float4 stores).  The reduction index inside a group of 8 is permuted -- lane half h takes k = 8 j + 4 h .. + 3
+//     -- so that every lane's four MFMA inputs are one 16-byte LDS read, for the activations and the (transposed) weights alike.
 //   * dgll_hip_grad_weight_f32   dW[K, N] = X[M, K]^T . G[M, N]          a long reduction into a small output
-//     split over row slabs (grid z), 64 x 64 output tiles per workgroup through LDS, fmaf in row order inside a slab, the slab
-//     partials summed in slab order by a second kernel: deterministic, no atomics.
+//     split over row slabs (grid z); inside a slab a wavefront owns up to 2 x 8 output tiles of 32 x 32 and walks the rows two at a
+//     time (one MFMA step): lanes read 32 consecutive columns of a row of X (its k-tile) and of G (each n-tile) -- coalesced 128-byte
+//     rows, fetched eight rows ahead; rows are summed in row order inside a slab, the slab partials in slab order by a second
+//     kernel: deterministic, no atomics.  (Round 5: 64 x 64 tiles through LDS with fmaf on the vector ALUs, 3 x slower.)
 #include <algorithm>
 
 #include "common.hpp"
@@ -20,125 +28,222 @@ namespace dgll {
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
 struct MmF32Args {
-    const float* A;
-    int64_t lda;
-    const float* Wt;
-    int64_t ldw;
+    const float* A1;        // [M, lda1]
+    int64_t lda1;
+    const float* W1;        // [N, ldw1]: the weight TRANSPOSED
+    int64_t ldw1;
+    int K1;
+    const float* A2;        // optional second product (nullptr: none)
+    int64_t lda2;
+    const float* W2;
+    int64_t ldw2;
+    int K2;
     float* C;
     int64_t ldc;
     int64_t M;
-    int N, K, relu;
+    int N, relu;
     const float* bias;
     const float* addend;    // optional [M, ldadd]: added before the activation
     int64_t ldadd;
-    int vec;                // 1: A / Wt rows are 16-byte aligned (float4 loads)
+    const float* gate;      // optional [M, ldgate]: outputs are zeroed where gate <= 0 (after the activation)
+    int64_t ldgate;
+    int vec1, vec2;         // 1: the operand's rows (activations AND weights) are 16-byte aligned (float4 loads)
 };
 
-__device__ __forceinline__ void load4(const float* __restrict__ p, int k, int K, bool vec, float (&v)[4]) {
-    if (vec && k + 4 <= K) {
-        const float4 t = *reinterpret_cast<const float4*>(p + k);
-        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-    } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = k + i < K ? p[k + i] : 0.0f;
-    }
+constexpr int kMmThreads = 512;          // 8 wavefronts: two per SIMD
+constexpr int kMmRows = 256;             // rows of C per workgroup pass (32 per wavefront)
+constexpr int kMmChunk = 32;             // reduction indices per LDS stage
+constexpr int kMmLd = kMmChunk + 4;      // LDS row pitch in floats: lanes of a ds_read_b128 land on distinct banks
+
+__device__ __forceinline__ float4 load4(const float* __restrict__ p, int k, int K, bool vec) {
+    if (vec && k + 4 <= K) return *reinterpret_cast<const float4*>(p + k);
+    float4 v;
+    v.x = k + 0 < K ? p[k + 0] : 0.0f;
+    v.y = k + 1 < K ? p[k + 1] : 0.0f;
+    v.z = k + 2 < K ? p[k + 2] : 0.0f;
+    v.w = k + 3 < K ? p[k + 3] : 0.0f;
+    return v;
 }
 
 template <int NT>
-__global__ __launch_bounds__(kBlock) void mm_f32_mfma_kernel(const MmF32Args a) {
+__global__ __launch_bounds__(kMmThreads) void mm_f32_mfma_kernel(const MmF32Args a) {
+    extern __shared__ __attribute__((aligned(16))) char mm_smem[];
+    float* smem = reinterpret_cast<float*>(mm_smem);
+    constexpr int WROWS = NT * 32;
+    constexpr int BUF = (WROWS + kMmRows) * kMmLd;      // floats per stage: weight chunk, then the activation chunk
+    constexpr int WIT = (WROWS + 63) / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, l32 = lane & 31;
+    const int c4 = (tid & 7) * 4, r0 = tid >> 3;        // staging: 8 lanes cover the 32 floats of a row's chunk, 64 rows per sweep
+    const int nch1 = (a.K1 + kMmChunk - 1) / kMmChunk;
+    const int nch = nch1 + (a.A2 ? (a.K2 + kMmChunk - 1) / kMmChunk : 0);
+    const bool c_vec = (a.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(a.C) & 15u) == 0;
+    {   // one pass of 256 rows per workgroup (a persistent loop made the compiler hoist the epilogue's 128 lane masks: SGPR spills)
+        const int64_t row_base = (int64_t)blockIdx.x * kMmRows;
+        f32x16_t acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+        float4 wreg[WIT], areg[4];
+        auto fetch = [&](int ch) {
+            const bool second = ch >= nch1;
+            const float* A = second ? a.A2 : a.A1;
+            const float* W = second ? a.W2 : a.W1;
+            const int64_t lda = second ? a.lda2 : a.lda1, ldw = second ? a.ldw2 : a.ldw1;
+            const int K = second ? a.K2 : a.K1;
+            const bool vec = (second ? a.vec2 : a.vec1) != 0;
+            const int k = (second ? ch - nch1 : ch) * kMmChunk + c4;
+#pragma unroll
+            for (int it = 0; it < WIT; ++it) {
+                const int n = r0 + 64 * it;
+                wreg[it] = (n < a.N && k < K) ? load4(W + (int64_t)n * ldw, k, K, vec) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int64_t r = row_base + r0 + 64 * it;
+                areg[it] = (r < a.M && k < K) ? load4(A + r * lda, k, K, vec) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+        };
+        auto stash = [&](int buf) {
+            float* b = smem + buf * BUF;
+#pragma unroll
+            for (int it = 0; it < WIT; ++it) {
+                const int n = r0 + 64 * it;
+                if (n < WROWS) *reinterpret_cast<float4*>(b + n * kMmLd + c4) = wreg[it];
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) *reinterpret_cast<float4*>(b + (WROWS + r0 + 64 * it) * kMmLd + c4) = areg[it];
+        };
+        fetch(0);
+        stash(0);
+        __syncthreads();
+        for (int ch = 0; ch < nch; ++ch) {
+            if (ch + 1 < nch) fetch(ch + 1);            // in flight while this chunk is multiplied
+            const float* b = smem + (ch & 1) * BUF;
+            const float* wp = b + l32 * kMmLd + 4 * h;
+            const float* ap = b + (WROWS + wave * 32 + l32) * kMmLd + 4 * h;
+            const bool second = ch >= nch1;
+            const int left = (second ? a.K2 - (ch - nch1) * kMmChunk : a.K1 - ch * kMmChunk);      // valid reduction indices of this chunk
+            const int steps = left >= kMmChunk ? kMmChunk / 8 : (left + 7) / 8;                     // (the rest of the chunk is zeros)
+            for (int s = 0; s < steps; ++s) {
+                const float4 av = *reinterpret_cast<const float4*>(ap + 8 * s);
+                float4 wv[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) wv[t] = *reinterpret_cast<const float4*>(wp + t * 32 * kMmLd + 8 * s);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[t].x, av.x, acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[t].y, av.y, acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[t].z, av.z, acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[t].w, av.w, acc[t], 0, 0, 0);
+            }
+            if (ch + 1 < nch) stash((ch + 1) & 1);
+            __syncthreads();      // the next chunk is complete; nobody still reads the stage that is overwritten after the NEXT multiply
+        }
+        const int64_t row = row_base + wave * 32 + l32;
+        if (row >= a.M) return;
+        // D[i][j]: j = lane % 32 = this lane's row, i = (r & 3) + 8 (r >> 2) + 4 h = the output column inside the tile
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = t * 32 + g * 8 + h * 4;
+                if (n >= a.N) continue;
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float x = acc[t][g * 4 + i];
+                    if (n + i < a.N) {
+                        if (a.addend) x += a.addend[row * a.ldadd + n + i];
+                        if (a.bias) x += a.bias[n + i];
+                        if (a.relu) x = fmaxf(x, 0.0f);
+                        if (a.gate && !(a.gate[row * a.ldgate + n + i] > 0.0f)) x = 0.0f;
+                    }
+                    v[i] = x;
+                }
+                float* o = a.C + row * a.ldc + n;
+                if (n + 4 <= a.N && c_vec)
+                    *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+                else
+                    for (int i = 0; i < 4; ++i) if (n + i < a.N) o[i] = v[i];
+            }
+        }
+    }
+}
+
+// ---- dW = X^T . G: slab partials on the matrix cores -------------------------------------------------------------------
+// One MFMA step multiplies TWO rows of the reduction: operand "A" of lane (l32, h) is X[m + h][k-tile + l32], operand "B" is
+// G[m + h][n-tile + l32]; D[i][j] accumulates dW[k-tile + i][n-tile + j].  Wavefront w of the workgroup (up to 8: 256 columns of X)
+// owns k-tile w and all NT <= 8 n-tiles (256 columns of G: the wavefronts read the same rows of G, served by L1 after the first);
+// eight rows are fetched ahead of the eight that are being multiplied.
+constexpr int kGwRows = 8;      // rows per fetch group (4 MFMA steps)
+constexpr int kGwThreads = 512;
+
+template <int NT>
+__global__ __launch_bounds__(kGwThreads) void gradw_f32_mfma_kernel(const float* __restrict__ X, int64_t ldx, const float* __restrict__ G,
+                                                                    int64_t ldg, float* __restrict__ partial, int64_t M, int K, int N,
+                                                                    int64_t rows_per_slab) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int h = lane >> 5, l32 = lane & 31;
-    const int64_t row = ((int64_t)blockIdx.x * kWavesPerBlock + wave) * 32 + l32;
-    const int64_t row_ld = row < a.M ? row : a.M - 1;
-    const float* ap = a.A + row_ld * a.lda;
+    const int k0 = blockIdx.x * (int)(blockDim.x >> 1) + wave * 32, nb = blockIdx.y * 256;      // blockDim.x / 64 tiles of 32 columns
+    if (k0 >= K) return;                                 // (no barrier in this kernel)
+    const int64_t m_begin = (int64_t)blockIdx.z * rows_per_slab;
+    const int64_t m_end = m_begin + rows_per_slab < M ? m_begin + rows_per_slab : M;
+    const bool kok = k0 + l32 < K;
+    const int kcol = kok ? k0 + l32 : 0;
+    int ncol[NT];
+    bool nok[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { ncol[t] = nb + t * 32 + l32; nok[t] = ncol[t] < N; if (!nok[t]) ncol[t] = 0; }
     f32x16_t acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-    for (int k0 = 0; k0 < a.K; k0 += 8) {
-        const int k = k0 + 4 * h;
-        float av[4], wv[NT][4];
-        load4(ap, k, a.K, a.vec != 0, av);
+    constexpr int U = kGwRows / 2;
+    float xa[2][U], gb[2][U][NT];
+    auto fetch = [&](int64_t m, int slot) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int n = t * 32 + l32;
-            if (n < a.N) load4(a.Wt + (int64_t)n * a.ldw, k, a.K, a.vec != 0, wv[t]);
-            else { wv[t][0] = wv[t][1] = wv[t][2] = wv[t][3] = 0.0f; }
+        for (int u = 0; u < U; ++u) {
+            const int64_t row = m + 2 * u + h;
+            const bool in = row < m_end;
+            const float* xr = X + (in ? row : m_begin) * ldx;
+            const float* gr = G + (in ? row : m_begin) * ldg;
+            const float v = xr[kcol];
+            xa[slot][u] = (in && kok) ? v : 0.0f;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) { const float w = gr[ncol[t]]; gb[slot][u][t] = (in && nok[t]) ? w : 0.0f; }
         }
+    };
+    auto multiply = [&](int slot) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[t][i], av[i], acc[t], 0, 0, 0);
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[slot][u], gb[slot][u][t], acc[t], 0, 0, 0);
+    };
+    if (m_begin < m_end) {
+        fetch(m_begin, 0);
+        int64_t m = m_begin;
+        for (; m + kGwRows < m_end; m += 2 * kGwRows) {     // two groups per trip: the slots alternate without a copy
+            fetch(m + kGwRows, 1);
+            multiply(0);
+            fetch(m + 2 * kGwRows, 0);                      // (past the slab's end: zeros)
+            multiply(1);
+        }
+        if (m < m_end) multiply(0);          // an odd number of groups: the last one is in slot 0
     }
-    if (row >= a.M) return;
-    // D[i][j]: j = lane % 32 = this lane's row, i = (r & 3) + 8 (r >> 2) + 4 h = the output column inside the tile
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int n = t * 32 + g * 8 + h * 4;
-            if (n >= a.N) continue;
-            float v[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float x = acc[t][g * 4 + i];
-                if (a.addend && n + i < a.N) x += a.addend[row * a.ldadd + n + i];
-                if (a.bias && n + i < a.N) x += a.bias[n + i];
-                if (a.relu) x = fmaxf(x, 0.0f);
-                v[i] = x;
-            }
-            float* o = a.C + row * a.ldc + n;
-            if (n + 4 <= a.N && (a.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(a.C) & 15u) == 0)
-                *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-            else
-                for (int i = 0; i < 4; ++i) if (n + i < a.N) o[i] = v[i];
-        }
-    }
-}
-
-// ---- dW = X^T . G: slab partials ------------------------------------------------------------------------------------
-constexpr int GT = 64, GK = 16;
-
-__global__ __launch_bounds__(kBlock) void gradw_f32_slab_kernel(const float* __restrict__ X, int64_t ldx, const float* __restrict__ G,
-                                                                int64_t ldg, float* __restrict__ partial, int64_t M, int K, int N,
-                                                                int64_t rows_per_slab) {
-    __shared__ float sX[GK][GT + 4];   // [reduction row][k column of X]
-    __shared__ float sG[GK][GT + 4];   // [reduction row][n column of G]
-    const int tx = threadIdx.x % 16, ty = threadIdx.x / 16;
-    const int k0 = blockIdx.x * GT, n0 = blockIdx.y * GT;
-    const int64_t m_begin = (int64_t)blockIdx.z * rows_per_slab;
-    const int64_t m_end = m_begin + rows_per_slab < M ? m_begin + rows_per_slab : M;
-    float acc[4][4] = {};
-    for (int64_t m0 = m_begin; m0 < m_end; m0 += GK) {
-        for (int i = threadIdx.x; i < GK * GT; i += kBlock) {
-            const int r = i / GT, c = i % GT;
-            const int64_t m = m0 + r;
-            sX[r][c] = (m < m_end && k0 + c < K) ? X[m * ldx + k0 + c] : 0.0f;
-            sG[r][c] = (m < m_end && n0 + c < N) ? G[m * ldg + n0 + c] : 0.0f;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < GK; ++r) {
-            float xv[4], gv[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { xv[i] = sX[r][ty * 4 + i]; gv[i] = sG[r][tx * 4 + i]; }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(xv[i], gv[j], acc[i][j]);
-        }
-        __syncthreads();
-    }
+    // D[i][j]: register r of lane (l32, h) holds i = (r & 3) + 8 (r >> 2) + 4 h, j = l32: 32 lanes write 32 consecutive n
     float* p = partial + (int64_t)blockIdx.z * K * N;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int k = k0 + ty * 4 + i;
-        if (k >= K) continue;
+    for (int t = 0; t < NT; ++t) {
+        if (!nok[t]) continue;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + tx * 4 + j;
-            if (n < N) p[(int64_t)k * N + n] = acc[i][j];
+        for (int r = 0; r < 16; ++r) {
+            const int k = k0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (k < K) p[(int64_t)k * N + ncol[t]] = acc[t][r];
         }
     }
 }
@@ -156,6 +261,37 @@ __global__ __launch_bounds__(kBlock) void gradw_f32_reduce_kernel(const float* _
 
 using namespace dgll;
 
+static int launch_mm_f32(void* stream, MmF32Args a) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int nt = (a.N + 31) / 32;
+    const int64_t nblocks = (a.M + kMmRows - 1) / kMmRows;
+    DGLL_REQUIRE(nblocks <= 0x7fffffff, "too many rows for one launch");
+    dim3 grid((uint32_t)nblocks);
+    const size_t lds = (size_t)2 * (nt * 32 + kMmRows) * kMmLd * sizeof(float);
+#define DGLL_MM(T)                                                                                                              \
+    {                                                                                                                           \
+        static hipError_t raised = hipFuncSetAttribute(reinterpret_cast<const void*>(&mm_f32_mfma_kernel<T>),                   \
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (T * 32 + kMmRows) * kMmLd * 4); \
+        DGLL_HIP_TRY(raised);                                                                                                   \
+        hipLaunchKernelGGL((mm_f32_mfma_kernel<T>), grid, dim3(kMmThreads), lds, s, a);                                         \
+    }
+    switch (nt) {
+        case 1: DGLL_MM(1) break;
+        case 2: DGLL_MM(2) break;
+        case 3: DGLL_MM(3) break;
+        case 4: DGLL_MM(4) break;
+        case 5: DGLL_MM(5) break;
+        case 6: DGLL_MM(6) break;
+        case 7: DGLL_MM(7) break;
+        default: DGLL_MM(8) break;
+    }
+#undef DGLL_MM
+    DGLL_HIP_TRY(hipGetLastError());
+    return DGLL_OK;
+}
+
+static inline int rows_vec(const float* p, int64_t ld) { return aligned16(p) && (ld & 3) == 0; }
+
 DGLL_API int dgll_hip_mm_f32(void* stream, const float* A, int64_t lda, const float* Wt, int64_t ldw, float* C, int64_t ldc,
                              int64_t M, int N, int K, const float* bias, int relu, const float* addend, int64_t ldadd) {
     DGLL_REQUIRE(M >= 0 && N >= 0 && K >= 0, "negative size");
@@ -164,26 +300,29 @@ DGLL_API int dgll_hip_mm_f32(void* stream, const float* A, int64_t lda, const fl
     DGLL_REQUIRE(N <= 256, "dgll_hip_mm_f32 keeps all N <= 256 output columns of a row block in accumulators (split columns on the host)");
     DGLL_REQUIRE(lda >= K && ldw >= K && ldc >= N && (!addend || ldadd >= N), "leading dimension too small");
     MmF32Args a{};
-    a.A = A; a.lda = lda; a.Wt = Wt; a.ldw = ldw; a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.relu = relu; a.bias = bias;
+    a.A1 = A; a.lda1 = lda; a.W1 = Wt; a.ldw1 = ldw; a.K1 = K; a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.relu = relu; a.bias = bias;
     a.addend = addend; a.ldadd = ldadd;
-    a.vec = aligned16(A) && aligned16(Wt) && (lda & 3) == 0 && (ldw & 3) == 0;
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    dim3 grid((uint32_t)((M + 127) / 128));
-    const int nt = (N + 31) / 32;
-#define DGLL_MM(T) hipLaunchKernelGGL((mm_f32_mfma_kernel<T>), grid, dim3(kBlock), 0, s, a)
-    switch (nt) {
-        case 1: DGLL_MM(1); break;
-        case 2: DGLL_MM(2); break;
-        case 3: DGLL_MM(3); break;
-        case 4: DGLL_MM(4); break;
-        case 5: DGLL_MM(5); break;
-        case 6: DGLL_MM(6); break;
-        case 7: DGLL_MM(7); break;
-        default: DGLL_MM(8); break;
-    }
-#undef DGLL_MM
-    DGLL_HIP_TRY(hipGetLastError());
-    return DGLL_OK;
+    a.vec1 = rows_vec(A, lda) && rows_vec(Wt, ldw);
+    return launch_mm_f32(stream, a);
+}
+
+DGLL_API int dgll_hip_mm2_f32(void* stream, const float* A1, int64_t lda1, const float* W1t, int64_t ldw1, int K1, const float* A2,
+                              int64_t lda2, const float* W2t, int64_t ldw2, int K2, float* C, int64_t ldc, int64_t M, int N,
+                              const float* bias, int relu, const float* addend, int64_t ldadd, const float* gate, int64_t ldgate) {
+    DGLL_REQUIRE(M >= 0 && N >= 0 && K1 >= 0 && K2 >= 0, "negative size");
+    if (M == 0 || N == 0) return DGLL_OK;
+    DGLL_REQUIRE(A1 && W1t && C && K1 > 0, "NULL operand");
+    DGLL_REQUIRE(!A2 || (W2t && K2 > 0), "the second product needs its weight and a reduction length");
+    DGLL_REQUIRE(N <= 256, "dgll_hip_mm2_f32 keeps all N <= 256 output columns of a row block in accumulators (split columns on the host)");
+    DGLL_REQUIRE(lda1 >= K1 && ldw1 >= K1 && ldc >= N && (!addend || ldadd >= N) && (!gate || ldgate >= N) && (!A2 || (lda2 >= K2 && ldw2 >= K2)),
+                 "leading dimension too small");
+    MmF32Args a{};
+    a.A1 = A1; a.lda1 = lda1; a.W1 = W1t; a.ldw1 = ldw1; a.K1 = K1;
+    a.A2 = A2; a.lda2 = lda2; a.W2 = W2t; a.ldw2 = ldw2; a.K2 = A2 ? K2 : 0;
+    a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.relu = relu; a.bias = bias; a.addend = addend; a.ldadd = ldadd; a.gate = gate; a.ldgate = ldgate;
+    a.vec1 = rows_vec(A1, lda1) && rows_vec(W1t, ldw1);
+    a.vec2 = A2 ? (rows_vec(A2, lda2) && rows_vec(W2t, ldw2)) : 0;
+    return launch_mm_f32(stream, a);
 }
 
 DGLL_API int64_t dgll_hip_grad_weight_f32_workspace(int K, int N, int slabs) {
@@ -196,13 +335,28 @@ DGLL_API int dgll_hip_grad_weight_f32(void* stream, const float* X, int64_t ldx,
     if (K == 0 || N == 0) return DGLL_OK;
     DGLL_REQUIRE(X && G && dW && ldx >= K && ldg >= N && lddw >= N, "bad operand");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    slabs = (int)std::max<int64_t>(1, std::min<int64_t>(slabs, (M + GK - 1) / GK));
+    slabs = (int)std::max<int64_t>(1, std::min<int64_t>(slabs, (M + kGwRows - 1) / kGwRows));
     slabs = std::min(slabs, 65535);
     DGLL_REQUIRE(workspace && workspace_bytes >= dgll_hip_grad_weight_f32_workspace(K, N, slabs), "workspace too small for the slab partials");
-    const int64_t per = ((M + slabs - 1) / slabs + GK - 1) / GK * GK;
+    const int64_t per = ((M + slabs - 1) / slabs + kGwRows - 1) / kGwRows * kGwRows;
     const int used = M > 0 ? (int)((M + per - 1) / per) : 1;
-    dim3 grid((uint32_t)((K + GT - 1) / GT), (uint32_t)((N + GT - 1) / GT), (uint32_t)used);
-    hipLaunchKernelGGL(gradw_f32_slab_kernel, grid, dim3(kBlock), 0, s, X, ldx, G, ldg, static_cast<float*>(workspace), M, K, N, per);
+    // a wavefront per tile of 32 columns of X, at most 8 per workgroup; up to 8 n-tiles (256 columns of G) per workgroup
+    const int ktiles = (K + 31) / 32;
+    const int waves = std::min(ktiles, kGwThreads / 64);
+    const int nt = (std::min(N, 256) + 31) / 32;
+    dim3 grid((uint32_t)((ktiles + waves - 1) / waves), (uint32_t)((N + 255) / 256), (uint32_t)used);
+#define DGLL_GW(T) hipLaunchKernelGGL((gradw_f32_mfma_kernel<T>), grid, dim3(64 * waves), 0, s, X, ldx, G, ldg, static_cast<float*>(workspace), M, K, N, per)
+    switch (nt) {
+        case 1: DGLL_GW(1); break;
+        case 2: DGLL_GW(2); break;
+        case 3: DGLL_GW(3); break;
+        case 4: DGLL_GW(4); break;
+        case 5: DGLL_GW(5); break;
+        case 6: DGLL_GW(6); break;
+        case 7: DGLL_GW(7); break;
+        default: DGLL_GW(8); break;
+    }
+#undef DGLL_GW
     DGLL_HIP_TRY(hipGetLastError());
     const int64_t count = (int64_t)K * N;
     hipLaunchKernelGGL(gradw_f32_reduce_kernel, dim3((uint32_t)((count + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,

@@ -274,27 +274,47 @@ def _as_rows16(x):
     return out
 
 
-def _mm_f32(a, wt, relu, bias, addend):
-    """fp32 product on dgll_hip_mm_f32 (v_mfma_f32_32x32x2_f32: exact fp32 arithmetic), 256 output columns per launch."""
+def _mm_f32(a, wt, relu, bias, addend, a2=None, wt2=None, gate=None):
+    """fp32 product(s) on dgll_hip_mm2_f32 (v_mfma_f32_32x32x2_f32: exact fp32 arithmetic), 256 output columns per launch:
+    gate(act(a . wt^T (+ a2 . wt2^T) + addend + bias)), both products in one accumulation."""
     a = a if a.stride(1) == 1 else a.contiguous()
-    wt = wt.to(torch.float32).contiguous()
+    wt = wt.to(torch.float32)
+    wt = wt if wt.stride(1) == 1 else wt.contiguous()
     m, k = a.shape
     n = wt.shape[0]
+    k2 = 0
+    if a2 is not None:
+        a2 = a2.to(torch.float32)
+        a2 = a2 if a2.stride(1) == 1 else a2.contiguous()
+        wt2 = wt2.to(torch.float32)
+        wt2 = wt2 if wt2.stride(1) == 1 else wt2.contiguous()
+        k2 = a2.shape[1]
     out = torch.empty((m, n), dtype=torch.float32, device=a.device)
     if addend is not None:
         addend = addend.to(torch.float32)
         addend = addend if addend.stride(1) == 1 else addend.contiguous()
+    if gate is not None:
+        gate = gate.to(torch.float32)
+        gate = gate if gate.stride(1) == 1 else gate.contiguous()
     if bias is not None:
         bias = bias.detach().to(torch.float32).contiguous()
     with _lib.on_device(a.device):
         stream = _lib.raw_stream(a.device)
+        end = _timed(("transform_f32", m, k, k2, n, "+".join(t for t, on in (("gate", gate is not None), ("addend", addend is not None)) if on)),
+                     a.device)
         for n0 in range(0, n, 256):
             nn = min(256, n - n0)
-            code = _lib.lib.dgll_hip_mm_f32(
-                stream, a.data_ptr(), a.stride(0), wt.data_ptr() + n0 * k * 4, k, out.data_ptr() + n0 * 4, out.stride(0), m, nn, k,
+            code = _lib.lib.dgll_hip_mm2_f32(
+                stream, a.data_ptr(), a.stride(0), wt.data_ptr() + n0 * wt.stride(0) * 4, wt.stride(0), k,
+                a2.data_ptr() if a2 is not None else None, a2.stride(0) if a2 is not None else 0,
+                wt2.data_ptr() + n0 * wt2.stride(0) * 4 if a2 is not None else None, wt2.stride(0) if a2 is not None else 0, k2,
+                out.data_ptr() + n0 * 4, out.stride(0), m, nn,
                 bias.data_ptr() + n0 * 4 if bias is not None else None, int(relu),
-                addend.data_ptr() + n0 * 4 if addend is not None else None, addend.stride(0) if addend is not None else 0)
-            _lib.check(code, "dgll_hip_mm_f32")
+                addend.data_ptr() + n0 * 4 if addend is not None else None, addend.stride(0) if addend is not None else 0,
+                gate.data_ptr() + n0 * 4 if gate is not None else None, gate.stride(0) if gate is not None else 0)
+            _lib.check(code, "dgll_hip_mm2_f32")
+        if end is not None:
+            end.record(torch.cuda.current_stream(a.device))
     return out
 
 
@@ -325,17 +345,22 @@ def mm_nt(a, wt, relu=False, bias=None, addend=None, out=None):
     return torch.cat(parts, dim=1)
 
 
-def mm2_nt(a1, wt1, a2, wt2, relu=False):
-    """act(a1 . wt1^T + a2 . wt2^T): both products accumulate in fp32 before anything is stored.  bf16 operands whose rows are
+def mm2_nt(a1, wt1, a2, wt2, relu=False, gate=None):
+    """gate(act(a1 . wt1^T + a2 . wt2^T)): both products accumulate in fp32 before anything is stored; gate: [M, N], the result is
+    zeroed where it is <= 0 (the ReLU mask of the layer below, fused for fp32 GPU tensors, a threshold pass otherwise).  bf16 operands whose rows are
     not 16-byte aligned are re-laid out once and take the two-product MFMA launch (256 output columns at a time) -- the sum
     of two separately stored bf16 products rounds the first one to 8 bits before the add, which showed as a 4-5 % relative
     error of the first layer's gradients at the Reddit shape (602-column rows; tests/test_config2_reddit_gpu.py)."""
+    if a1.is_cuda and a1.dtype == torch.float32 and a2.dtype == torch.float32:
+        return _mm_f32(a1, wt1, relu, None, None, a2=a2, wt2=wt2, gate=gate)       # one launch, one accumulation (exact fp32 FMAs)
     if not (a1.is_cuda and a1.dtype == torch.bfloat16 and a2.dtype == torch.bfloat16):
-        return mm_nt(a2, wt2, relu=relu, addend=mm_nt(a1, wt1))      # fp32: the addend stays fp32 (exact); host: torch
+        res = mm_nt(a2, wt2, relu=relu, addend=mm_nt(a1, wt1))      # mixed / host: the addend stays fp32 (exact); host: torch
+        return res if gate is None else torch.ops.aten.threshold_backward(res, gate.to(res.dtype), 0)
     a1, a2 = _as_rows16(a1), _as_rows16(a2)
     n = wt1.shape[0]
     parts = [transform_bf16(a1, wt1[n0:n0 + 256], a2, wt2[n0:n0 + 256], relu=relu) for n0 in range(0, n, 256)]
-    return parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
+    res = parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
+    return res if gate is None else torch.ops.aten.threshold_backward(res, gate.to(res.dtype), 0)
 
 
 def input_grads(g, wsd, wnd, out1=None):
@@ -433,14 +458,20 @@ def _grad_weight_f32(x, g):
     n = g.shape[1]
     if m == 0:                                   # an empty reduction (an empty tensor has no storage to point the kernel at)
         return torch.zeros((k, n), dtype=torch.float32, device=x.device)
-    slabs = max(1, min(256, -(-m // 256)))
+    # row slabs: enough workgroups (k-blocks x n-blocks x slabs) for two per CU, at least 512 rows each
+    blocks = -(-k // 256) * -(-n // 256)
+    n_cu = torch.cuda.get_device_properties(x.device).multi_processor_count
+    slabs = max(1, min(-(-2 * n_cu // blocks), -(-m // 512)))
     need = int(_lib.lib.dgll_hip_grad_weight_f32_workspace(k, n, slabs))
     ws = torch.empty(need // 4, dtype=torch.float32, device=x.device)
     out = torch.empty((k, n), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
+        end = _timed(("grad_weight_f32", m, k, 0, n, ""), x.device)
         code = _lib.lib.dgll_hip_grad_weight_f32(torch.cuda.current_stream(x.device).cuda_stream, x.data_ptr(), x.stride(0),
                                                  g.data_ptr(), g.stride(0), out.data_ptr(), out.stride(0), m, k, n, ws.data_ptr(),
                                                  need, slabs)
+        if end is not None:
+            end.record(torch.cuda.current_stream(x.device))
     _lib.check(code, "dgll_hip_grad_weight_f32")
     return out
 

@@ -99,8 +99,10 @@ class _SageGraphLayer(torch.autograd.Function):
             gws = dense.grad_weight(h, g, out=grad_slot_of(ctx.wparams[0])) if ctx.needs_input_grad[1] else None
             gwn = dense.grad_weight(agg, g, out=grad_slot_of(ctx.wparams[1])) if ctx.needs_input_grad[2] else None
         gh = None
+        f32 = g.is_cuda and g.dtype == torch.float32 and h.dtype == torch.float32      # the reference's own arithmetic (dgll/__init__.py:1)
         agg_first = (BACKWARD_ORDER != "transform-first" and ctx.needs_input_grad[0] and wsd.shape[1] <= wsd.shape[0]
-                     and dense._mfma_ok(g) and wsd.shape[0] <= 256 and _aligned(g) and (not ctx.gate_input or h.stride(1) == 1))
+                     and (f32 or (dense._mfma_ok(g) and wsd.shape[0] <= 256 and _aligned(g)))
+                     and (not ctx.gate_input or h.stride(1) == 1))
         if agg_first:
             gt, _ = graph.transpose()
             tval = gt.val
@@ -108,7 +110,10 @@ class _SageGraphLayer(torch.autograd.Function):
                 scale = graph.mean_scale_transposed()
                 tval = scale if tval is None else tval * scale
             gtg = ops.spmm_raw(gt, g, val=tval, reduce="sum")                       # A^T (scale . g): plain weighted gather
-            gh = dense.transform_bf16(g, wsd, gtg, wnd, out_gate=h if ctx.gate_input else None, gate_bits=ctx.h_bits)
+            if f32:       # both products in one fp32 accumulation, the mask applied by the epilogue (dgll_hip_mm2_f32)
+                gh = dense.mm2_nt(g, wsd, gtg, wnd, gate=h if ctx.gate_input else None)
+            else:
+                gh = dense.transform_bf16(g, wsd, gtg, wnd, out_gate=h if ctx.gate_input else None, gate_bits=ctx.h_bits)
         elif ctx.needs_input_grad[0]:
             gh, gagg = dense.input_grads(g, wsd, wnd)      # self path, neighbour path: one MFMA launch, g read once
             gt, _ = graph.transpose()
@@ -197,9 +202,7 @@ class _SageGraphLayerTransformFirst(torch.autograd.Function):
                 # g.Ws^T + gz.Wn^T and the ReLU mask of the layer below: one MFMA launch, every operand read once
                 gh = dense.transform_bf16(gm, wsd, gz, wnd, out_gate=h if ctx.gate_input else None, gate_bits=ctx.h_bits)
             else:
-                gh = dense.mm2_nt(gm, wsd, gz, wnd)
-                if ctx.gate_input:
-                    gh = torch.ops.aten.threshold_backward(gh, h, 0)
+                gh = dense.mm2_nt(gm, wsd, gz, wnd, gate=h if ctx.gate_input else None)     # (fp32: the mask rides in the epilogue)
         return gh, gws, gwn, None, None, None, None, None, None, None
 
 

@@ -387,10 +387,17 @@ int dgll_hip_gemm_f32(void* stream, const float* A, int64_t lda, const float* B,
  * dgll_hip_mm_f32:  C[M, N] = act(A[M, K] . Wt[N, K]^T + addend + bias), everything fp32, v_mfma_f32_32x32x2_f32 (fp32 inputs, fp32
  * accumulation: exact fp32 FMA arithmetic).  Wt is the weight TRANSPOSED ([N, K] row-major; for an input gradient g . W^T pass
  * Wt := W).  N <= 256 per call (split columns on the host); any alignment (16-byte aligned rows take float4 loads).
- * dgll_hip_grad_weight_f32:  dW[K, N] = X[M, K]^T . G[M, N]: the long reduction is split over `slabs` row slabs whose partials
- * (workspace: dgll_hip_grad_weight_f32_workspace bytes) are summed in slab order -- deterministic, no atomics.             */
+ * dgll_hip_mm2_f32:  C = gate(act(A1 . W1t^T + A2 . W2t^T + addend + bias)): sageConv's self + neighbour term (sageconv.py:72-75), or
+ * a layer's two input-gradient products, in ONE accumulation; A2 may be NULL (then W2t / K2 are ignored); gate (optional, [M, ldgate]):
+ * outputs are zeroed where gate <= 0 -- the ReLU mask of the layer below applied by the epilogue.  N <= 256 per call.
+ * dgll_hip_grad_weight_f32:  dW[K, N] = X[M, K]^T . G[M, N] on the same instruction: the long reduction is split over `slabs` row
+ * slabs (rows summed in order inside a slab) whose partials (workspace: dgll_hip_grad_weight_f32_workspace bytes) are summed in
+ * slab order -- deterministic, no atomics.                                                                                  */
 int dgll_hip_mm_f32(void* stream, const float* A, int64_t lda, const float* Wt, int64_t ldw, float* C, int64_t ldc,
                     int64_t M, int N, int K, const float* bias, int relu, const float* addend, int64_t ldadd);
+int dgll_hip_mm2_f32(void* stream, const float* A1, int64_t lda1, const float* W1t, int64_t ldw1, int K1, const float* A2,
+                     int64_t lda2, const float* W2t, int64_t ldw2, int K2, float* C, int64_t ldc, int64_t M, int N,
+                     const float* bias, int relu, const float* addend, int64_t ldadd, const float* gate, int64_t ldgate);
 int64_t dgll_hip_grad_weight_f32_workspace(int K, int N, int slabs);
 int dgll_hip_grad_weight_f32(void* stream, const float* X, int64_t ldx, const float* G, int64_t ldg, float* dW,
                              int64_t lddw, int64_t M, int K, int N, void* workspace, int64_t workspace_bytes, int slabs);

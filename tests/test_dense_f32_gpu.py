@@ -26,7 +26,35 @@ def test_mm_f32_matches_float64(cuda_device, m, k, n, relu):
     torch.testing.assert_close(got2.cpu().double(), big[:, 1:k + 1].cpu().double() @ wt.double().T, rtol=1e-5, atol=1e-4)
 
 
-@pytest.mark.parametrize("m,k,n", [(5000, 64, 47), (100000, 100, 256), (17, 300, 5), (1, 3, 2)])
+@pytest.mark.parametrize("m,k1,k2,n", [(3000, 256, 256, 256), (1031, 100, 100, 256), (777, 47, 47, 200), (300, 33, 7, 47), (5, 3, 260, 9)])
+@pytest.mark.parametrize("gated", [False, True])
+def test_mm2_f32_two_products_one_accumulation_and_the_gate(cuda_device, m, k1, k2, n, gated):
+    """dgll_hip_mm2_f32: gate(act(a1 . w1t^T + a2 . w2t^T)) against float64 -- sageConv's self + neighbour term (sageconv.py:72-75)
+    and the aggregate-first input gradient with the ReLU mask of the layer below in the epilogue; reduction lengths that are not
+    multiples of the 32-wide LDS chunk or of 8, unaligned rows (odd leading dimensions), row counts that are not multiples of 256."""
+    from dgll_amd import dense
+
+    torch.manual_seed(m + n)
+    a1, a2 = torch.randn(m, k1), torch.randn(m, k2)
+    w1, w2 = torch.randn(n, k1), torch.randn(n, k2)
+    gate = torch.randn(m, n) if gated else None
+    want = a1.double() @ w1.double().T + a2.double() @ w2.double().T
+    want = torch.relu(want) if not gated else want
+    if gated:
+        want = want * (gate > 0).double()
+    d = cuda_device
+    got = dense.mm2_nt(a1.to(d), w1.to(d), a2.to(d), w2.to(d), relu=not gated, gate=gate.to(d) if gated else None)
+    assert got.dtype == torch.float32 and got.shape == (m, n)
+    torch.testing.assert_close(got.cpu().double(), want, rtol=1e-5, atol=2e-4)
+    # the same through column-sliced (unaligned) views of wider buffers
+    b1, b2 = torch.randn(m, k1 + 3).to(d), torch.randn(m, k2 + 5).to(d)
+    got2 = dense.mm2_nt(b1[:, 1:k1 + 1], w1.to(d), b2[:, 3:k2 + 3], w2.to(d))
+    want2 = b1[:, 1:k1 + 1].cpu().double() @ w1.double().T + b2[:, 3:k2 + 3].cpu().double() @ w2.double().T
+    torch.testing.assert_close(got2.cpu().double(), want2, rtol=1e-5, atol=2e-4)
+    assert torch.equal(got, dense.mm2_nt(a1.to(d), w1.to(d), a2.to(d), w2.to(d), relu=not gated, gate=gate.to(d) if gated else None))
+
+
+@pytest.mark.parametrize("m,k,n", [(5000, 64, 47), (100000, 100, 256), (17, 300, 5), (1, 3, 2), (70000, 256, 256), (4099, 257, 300), (9, 31, 33)])
 def test_grad_weight_f32_matches_float64_and_is_deterministic(cuda_device, m, k, n):
     from dgll_amd import dense
 
