@@ -52,6 +52,7 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+FP32_MFMA_PEAK_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32: 64 flops / cycle / SIMD x 4 SIMDs x 256 CUs x 2.4 GHz
 LINE_LIMIT = 6000        # characters of the stdout line (the driver keeps an 8 000-character tail and parses the last line)
 FULL_RECORD = os.path.join(ROOT, "bench_full.json")
 METRIC = "aggregated edges/sec + epoch time, 3-layer GraphSAGE ogbn-products, 1/2/4/8 GPU"
@@ -507,6 +508,18 @@ def launch_tables(launches, local_rows, heads_of=None):
                                  "algorithmic_GBps": b_alg / (avg_ms * 1e-3) / 1e9,
                                  "frac_of_hbm_peak": b_alg / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                  "frac_of_streaming_ceiling_5500": b_alg / (avg_ms * 1e-3) / 1e9 / 5500.0}
+            continue
+        elif tag[0] in ("transform_f32", "grad_weight_f32"):
+            # fp32 products (the reference's own arithmetic, dgll/__init__.py:1) on v_mfma_f32_32x32x2_f32: matrix-core bound at these
+            # widths (157.3 TFLOP/s dense fp32 MFMA peak of 256 CUs at 2.4 GHz: MI355X_MICROARCH.md), bytes next to it
+            kind, m, k1, k2, n_out, extra = tag
+            flops = 2.0 * m * (k1 + k2) * n_out
+            b_alg = m * (k1 + k2 + n_out) * 4 + (m * n_out * 4 if extra else 0)
+            name = "%s M=%d K=%d%s N=%d%s" % (kind, m, k1, ("+%d" % k2) if k2 else "", n_out, (" " + extra) if extra else "")
+            dense_table[name] = {"count": cnt, "avg_ms": avg_ms, "algorithmic_bytes": b_alg, "flops": flops,
+                                 "TFLOPs": flops / (avg_ms * 1e-3) / 1e12, "frac_of_fp32_mfma_peak": flops / (avg_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                                 "algorithmic_GBps": b_alg / (avg_ms * 1e-3) / 1e9,
+                                 "frac_of_hbm_peak": b_alg / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
             continue
         else:
             continue

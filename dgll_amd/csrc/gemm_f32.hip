@@ -47,7 +47,7 @@ struct MmF32Args {
     int64_t ldadd;
     const float* gate;      // optional [M, ldgate]: outputs are zeroed where gate <= 0 (after the activation)
     int64_t ldgate;
-    int vec1, vec2;         // 1: the operand's rows (activations AND weights) are 16-byte aligned (float4 loads)
+    int vec;                // 1: every operand's rows (activations AND weights) are 16-byte aligned, pitches multiples of 4 (float4 loads)
 };
 
 constexpr int kMmThreads = 512;          // 8 wavefronts: two per SIMD
@@ -55,17 +55,34 @@ constexpr int kMmRows = 256;             // rows of C per workgroup pass (32 per
 constexpr int kMmChunk = 32;             // reduction indices per LDS stage
 constexpr int kMmLd = kMmChunk + 4;      // LDS row pitch in floats: lanes of a ds_read_b128 land on distinct banks
 
-__device__ __forceinline__ float4 load4(const float* __restrict__ p, int k, int K, bool vec) {
-    if (vec && k + 4 <= K) return *reinterpret_cast<const float4*>(p + k);
+// Four reduction indices k .. k + 3 of one row WITHOUT a branch: the address is clamped into the row (a `cond ? load : 0` becomes
+// an exec-masked branch with its own s_waitcnt -- 1 500 basic blocks in the first version of this kernel, every prefetch
+// serialized); what lies past K is cleared later, when the registers are parked in LDS (clear_past: a bit mask -- applied right
+// after the load it would make the wavefront wait for the data before the multiply it is meant to overlap).
+template <bool VEC>
+__device__ __forceinline__ float4 load4(const float* __restrict__ p, int k, int K, int ld) {
     float4 v;
-    v.x = k + 0 < K ? p[k + 0] : 0.0f;
-    v.y = k + 1 < K ? p[k + 1] : 0.0f;
-    v.z = k + 2 < K ? p[k + 2] : 0.0f;
-    v.w = k + 3 < K ? p[k + 3] : 0.0f;
+    if constexpr (VEC) {                       // rows 16-byte aligned, ld a multiple of 4 (>= K): the whole vector lies inside the pitch
+        const int kk = k < ld - 4 ? k : ld - 4;
+        v = *reinterpret_cast<const float4*>(p + kk);
+    } else {
+        const int last = K - 1;
+        v.x = p[k + 0 < last ? k + 0 : last];
+        v.y = p[k + 1 < last ? k + 1 : last];
+        v.z = p[k + 2 < last ? k + 2 : last];
+        v.w = p[k + 3 < last ? k + 3 : last];
+    }
+    return v;
+}
+__device__ __forceinline__ float4 clear_past(float4 v, int k, int K) {
+    v.x = __uint_as_float(__float_as_uint(v.x) & (k + 0 < K ? 0xffffffffu : 0u));
+    v.y = __uint_as_float(__float_as_uint(v.y) & (k + 1 < K ? 0xffffffffu : 0u));
+    v.z = __uint_as_float(__float_as_uint(v.z) & (k + 2 < K ? 0xffffffffu : 0u));
+    v.w = __uint_as_float(__float_as_uint(v.w) & (k + 3 < K ? 0xffffffffu : 0u));
     return v;
 }
 
-template <int NT>
+template <int NT, bool VEC>
 __global__ __launch_bounds__(kMmThreads) void mm_f32_mfma_kernel(const MmF32Args a) {
     extern __shared__ __attribute__((aligned(16))) char mm_smem[];
     float* smem = reinterpret_cast<float*>(mm_smem);
@@ -86,34 +103,37 @@ __global__ __launch_bounds__(kMmThreads) void mm_f32_mfma_kernel(const MmF32Args
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
         float4 wreg[WIT], areg[4];
+        // rows past M / weight rows past N are clamped to the last valid one: what they produce is never stored
         auto fetch = [&](int ch) {
             const bool second = ch >= nch1;
             const float* A = second ? a.A2 : a.A1;
             const float* W = second ? a.W2 : a.W1;
             const int64_t lda = second ? a.lda2 : a.lda1, ldw = second ? a.ldw2 : a.ldw1;
             const int K = second ? a.K2 : a.K1;
-            const bool vec = (second ? a.vec2 : a.vec1) != 0;
             const int k = (second ? ch - nch1 : ch) * kMmChunk + c4;
 #pragma unroll
             for (int it = 0; it < WIT; ++it) {
                 const int n = r0 + 64 * it;
-                wreg[it] = (n < a.N && k < K) ? load4(W + (int64_t)n * ldw, k, K, vec) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                wreg[it] = load4<VEC>(W + (int64_t)(n < a.N ? n : a.N - 1) * ldw, k, K, (int)ldw);
             }
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int64_t r = row_base + r0 + 64 * it;
-                areg[it] = (r < a.M && k < K) ? load4(A + r * lda, k, K, vec) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                areg[it] = load4<VEC>(A + (r < a.M ? r : a.M - 1) * lda, k, K, (int)lda);
             }
         };
-        auto stash = [&](int buf) {
-            float* b = smem + buf * BUF;
+        auto stash = [&](int ch) {
+            float* b = smem + (ch & 1) * BUF;
+            const bool second = ch >= nch1;
+            const int K = second ? a.K2 : a.K1;
+            const int k = (second ? ch - nch1 : ch) * kMmChunk + c4;
 #pragma unroll
             for (int it = 0; it < WIT; ++it) {
                 const int n = r0 + 64 * it;
-                if (n < WROWS) *reinterpret_cast<float4*>(b + n * kMmLd + c4) = wreg[it];
+                if (n < WROWS) *reinterpret_cast<float4*>(b + n * kMmLd + c4) = clear_past(wreg[it], k, K);
             }
 #pragma unroll
-            for (int it = 0; it < 4; ++it) *reinterpret_cast<float4*>(b + (WROWS + r0 + 64 * it) * kMmLd + c4) = areg[it];
+            for (int it = 0; it < 4; ++it) *reinterpret_cast<float4*>(b + (WROWS + r0 + 64 * it) * kMmLd + c4) = clear_past(areg[it], k, K);
         };
         fetch(0);
         stash(0);
@@ -140,7 +160,7 @@ __global__ __launch_bounds__(kMmThreads) void mm_f32_mfma_kernel(const MmF32Args
 #pragma unroll
                 for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[t].w, av.w, acc[t], 0, 0, 0);
             }
-            if (ch + 1 < nch) stash((ch + 1) & 1);
+            if (ch + 1 < nch) stash(ch + 1);
             __syncthreads();      // the next chunk is complete; nobody still reads the stage that is overwritten after the NEXT multiply
         }
         const int64_t row = row_base + wave * 32 + l32;
@@ -152,16 +172,32 @@ __global__ __launch_bounds__(kMmThreads) void mm_f32_mfma_kernel(const MmF32Args
             for (int g = 0; g < 4; ++g) {
                 const int n = t * 32 + g * 8 + h * 4;
                 if (n >= a.N) continue;
-                float v[4];
+                float v[4], ad[4] = {0.0f, 0.0f, 0.0f, 0.0f}, gt[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+                const bool whole = n + 4 <= a.N;
+                if (a.addend) {
+                    const float* q = a.addend + row * a.ldadd + n;
+                    if (whole && (a.ldadd & 3) == 0 && (reinterpret_cast<uintptr_t>(a.addend) & 15u) == 0) {
+                        const float4 t4 = *reinterpret_cast<const float4*>(q);
+                        ad[0] = t4.x; ad[1] = t4.y; ad[2] = t4.z; ad[3] = t4.w;
+                    } else {
+                        for (int i = 0; i < 4; ++i) if (n + i < a.N) ad[i] = q[i];
+                    }
+                }
+                if (a.gate) {
+                    const float* q = a.gate + row * a.ldgate + n;
+                    if (whole && (a.ldgate & 3) == 0 && (reinterpret_cast<uintptr_t>(a.gate) & 15u) == 0) {
+                        const float4 t4 = *reinterpret_cast<const float4*>(q);
+                        gt[0] = t4.x; gt[1] = t4.y; gt[2] = t4.z; gt[3] = t4.w;
+                    } else {
+                        for (int i = 0; i < 4; ++i) if (n + i < a.N) gt[i] = q[i];
+                    }
+                }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    float x = acc[t][g * 4 + i];
-                    if (n + i < a.N) {
-                        if (a.addend) x += a.addend[row * a.ldadd + n + i];
-                        if (a.bias) x += a.bias[n + i];
-                        if (a.relu) x = fmaxf(x, 0.0f);
-                        if (a.gate && !(a.gate[row * a.ldgate + n + i] > 0.0f)) x = 0.0f;
-                    }
+                    float x = acc[t][g * 4 + i] + ad[i];
+                    if (a.bias && n + i < a.N) x += a.bias[n + i];
+                    if (a.relu) x = fmaxf(x, 0.0f);
+                    if (!(gt[i] > 0.0f)) x = 0.0f;
                     v[i] = x;
                 }
                 float* o = a.C + row * a.ldc + n;
@@ -176,74 +212,109 @@ __global__ __launch_bounds__(kMmThreads) void mm_f32_mfma_kernel(const MmF32Args
 
 // ---- dW = X^T . G: slab partials on the matrix cores -------------------------------------------------------------------
 // One MFMA step multiplies TWO rows of the reduction: operand "A" of lane (l32, h) is X[m + h][k-tile + l32], operand "B" is
-// G[m + h][n-tile + l32]; D[i][j] accumulates dW[k-tile + i][n-tile + j].  Wavefront w of the workgroup (up to 8: 256 columns of X)
-// owns k-tile w and all NT <= 8 n-tiles (256 columns of G: the wavefronts read the same rows of G, served by L1 after the first);
-// eight rows are fetched ahead of the eight that are being multiplied.
-constexpr int kGwRows = 8;      // rows per fetch group (4 MFMA steps)
+// G[m + h][n-tile + l32]; D[i][j] accumulates dW[k-tile + i][n-tile + j].  Wavefront w of the 8 owns k-tile w (KTL = 8: 256 columns of
+// X per workgroup; KTL = 4: 128, wavefronts 4-7 only help with the staging) and all NT <= 8 n-tiles (256 columns of G).  Chunks of 32
+// rows of X and G are fetched one chunk ahead with coalesced 16-byte loads (registers), parked in LDS and read from there as MFMA
+// operands (consecutive lanes read consecutive floats: conflict-free); rows are summed in row order.  (The first MFMA version
+// fetched the operands straight from global memory, one dword per lane and row: 36 loads in flight per wavefront, 244 registers,
+// and slower than the fmaf kernel it replaced.)
 constexpr int kGwThreads = 512;
+constexpr int kGwRows = 32;      // rows per LDS stage (16 MFMA steps)
 
-template <int NT>
+template <int KTL, int NT, bool VEC>
 __global__ __launch_bounds__(kGwThreads) void gradw_f32_mfma_kernel(const float* __restrict__ X, int64_t ldx, const float* __restrict__ G,
                                                                     int64_t ldg, float* __restrict__ partial, int64_t M, int K, int N,
                                                                     int64_t rows_per_slab) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    extern __shared__ __attribute__((aligned(16))) char gw_smem[];
+    float* smem = reinterpret_cast<float*>(gw_smem);
+    constexpr int XW = KTL * 32, GW = NT * 32;
+    constexpr int BUF = kGwRows * (XW + GW);                      // floats per stage: the X chunk, then the G chunk
+    constexpr int XV = kGwRows * XW / 4, GV = kGwRows * GW / 4;   // 16-byte vectors per chunk
+    constexpr int XIT = (XV + kGwThreads - 1) / kGwThreads, GIT = (GV + kGwThreads - 1) / kGwThreads;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, l32 = lane & 31;
-    const int k0 = blockIdx.x * (int)(blockDim.x >> 1) + wave * 32, nb = blockIdx.y * 256;      // blockDim.x / 64 tiles of 32 columns
-    if (k0 >= K) return;                                 // (no barrier in this kernel)
+    const int kb = blockIdx.x * XW, nb = blockIdx.y * 256;
     const int64_t m_begin = (int64_t)blockIdx.z * rows_per_slab;
     const int64_t m_end = m_begin + rows_per_slab < M ? m_begin + rows_per_slab : M;
-    const bool kok = k0 + l32 < K;
-    const int kcol = kok ? k0 + l32 : 0;
-    int ncol[NT];
-    bool nok[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) { ncol[t] = nb + t * 32 + l32; nok[t] = ncol[t] < N; if (!nok[t]) ncol[t] = 0; }
+    const bool works = wave < KTL && kb + wave * 32 < K;          // this wavefront owns a k-tile
     f32x16_t acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-    constexpr int U = kGwRows / 2;
-    float xa[2][U], gb[2][U][NT];
-    auto fetch = [&](int64_t m, int slot) {
+    float4 xreg[XIT], greg[GIT];
+    // columns past K / N are clamped into the row (what they accumulate is never stored); rows past the matrix are clamped to its
+    // last row and cleared when they are parked (rows past the slab's end must contribute nothing)
+    auto fetch = [&](int64_t m) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int64_t row = m + 2 * u + h;
-            const bool in = row < m_end;
-            const float* xr = X + (in ? row : m_begin) * ldx;
-            const float* gr = G + (in ? row : m_begin) * ldg;
-            const float v = xr[kcol];
-            xa[slot][u] = (in && kok) ? v : 0.0f;
+        for (int it = 0; it < XIT; ++it) {
+            const int v = tid + it * kGwThreads;
+            const int r = v / (XW / 4), c = (v % (XW / 4)) * 4;
+            int64_t row = m + r;
+            row = row < M ? row : M - 1;
+            xreg[it] = load4<VEC>(X + row * ldx, kb + c, K, (int)ldx);
+        }
 #pragma unroll
-            for (int t = 0; t < NT; ++t) { const float w = gr[ncol[t]]; gb[slot][u][t] = (in && nok[t]) ? w : 0.0f; }
+        for (int it = 0; it < GIT; ++it) {
+            const int v = tid + it * kGwThreads;
+            const int r = v / (GW / 4), c = (v % (GW / 4)) * 4;
+            int64_t row = m + (r < kGwRows ? r : kGwRows - 1);
+            row = row < M ? row : M - 1;
+            greg[it] = load4<VEC>(G + row * ldg, nb + c, N, (int)ldg);
         }
     };
-    auto multiply = [&](int slot) {
+    auto stash = [&](int64_t m, int buf) {
+        float* b = smem + buf * BUF;
 #pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[slot][u], gb[slot][u][t], acc[t], 0, 0, 0);
-    };
-    if (m_begin < m_end) {
-        fetch(m_begin, 0);
-        int64_t m = m_begin;
-        for (; m + kGwRows < m_end; m += 2 * kGwRows) {     // two groups per trip: the slots alternate without a copy
-            fetch(m + kGwRows, 1);
-            multiply(0);
-            fetch(m + 2 * kGwRows, 0);                      // (past the slab's end: zeros)
-            multiply(1);
+        for (int it = 0; it < XIT; ++it) {
+            const int v = tid + it * kGwThreads;
+            const int r = v / (XW / 4), c = (v % (XW / 4)) * 4;
+            if (XV % kGwThreads == 0 || v < XV) *reinterpret_cast<float4*>(b + r * XW + c) = clear_past(xreg[it], 0, m + r < m_end ? 4 : 0);
         }
-        if (m < m_end) multiply(0);          // an odd number of groups: the last one is in slot 0
+#pragma unroll
+        for (int it = 0; it < GIT; ++it) {
+            const int v = tid + it * kGwThreads;
+            const int r = v / (GW / 4), c = (v % (GW / 4)) * 4;
+            if (GV % kGwThreads == 0 || v < GV) *reinterpret_cast<float4*>(b + kGwRows * XW + r * GW + c) = greg[it];
+        }
+    };
+    if (m_begin < m_end) {          // (uniform per workgroup: every wavefront takes the same barriers)
+        fetch(m_begin);
+        stash(m_begin, 0);
+        __syncthreads();
+        int buf = 0;
+        for (int64_t m = m_begin; m < m_end; m += kGwRows, buf ^= 1) {
+            const bool more = m + kGwRows < m_end;
+            if (more) fetch(m + kGwRows);
+            if (works) {
+                const float* xs = smem + buf * BUF + wave * 32 + l32;
+                const float* gs = smem + buf * BUF + kGwRows * XW + l32;
+#pragma unroll 4
+                for (int u = 0; u < kGwRows / 2; ++u) {
+                    const float xa = xs[(2 * u + h) * XW];
+                    float gb[NT];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) gb[t] = gs[(2 * u + h) * GW + t * 32];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa, gb[t], acc[t], 0, 0, 0);
+                }
+            }
+            if (more) stash(m + kGwRows, buf ^ 1);
+            __syncthreads();
+        }
     }
+    if (!works) return;
     // D[i][j]: register r of lane (l32, h) holds i = (r & 3) + 8 (r >> 2) + 4 h, j = l32: 32 lanes write 32 consecutive n
     float* p = partial + (int64_t)blockIdx.z * K * N;
+    const int k0 = kb + wave * 32;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        if (!nok[t]) continue;
+        const int n = nb + t * 32 + l32;
+        if (n >= N) continue;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int k = k0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (k < K) p[(int64_t)k * N + ncol[t]] = acc[t][r];
+            if (k < K) p[(int64_t)k * N + n] = acc[t][r];
         }
     }
 }
@@ -268,13 +339,14 @@ static int launch_mm_f32(void* stream, MmF32Args a) {
     DGLL_REQUIRE(nblocks <= 0x7fffffff, "too many rows for one launch");
     dim3 grid((uint32_t)nblocks);
     const size_t lds = (size_t)2 * (nt * 32 + kMmRows) * kMmLd * sizeof(float);
-#define DGLL_MM(T)                                                                                                              \
+#define DGLL_MM_V(T, V)                                                                                                         \
     {                                                                                                                           \
-        static hipError_t raised = hipFuncSetAttribute(reinterpret_cast<const void*>(&mm_f32_mfma_kernel<T>),                   \
+        static hipError_t raised = hipFuncSetAttribute(reinterpret_cast<const void*>(&mm_f32_mfma_kernel<T, V>),                \
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (T * 32 + kMmRows) * kMmLd * 4); \
         DGLL_HIP_TRY(raised);                                                                                                   \
-        hipLaunchKernelGGL((mm_f32_mfma_kernel<T>), grid, dim3(kMmThreads), lds, s, a);                                         \
+        hipLaunchKernelGGL((mm_f32_mfma_kernel<T, V>), grid, dim3(kMmThreads), lds, s, a);                                      \
     }
+#define DGLL_MM(T) if (a.vec) DGLL_MM_V(T, true) else DGLL_MM_V(T, false)
     switch (nt) {
         case 1: DGLL_MM(1) break;
         case 2: DGLL_MM(2) break;
@@ -286,6 +358,7 @@ static int launch_mm_f32(void* stream, MmF32Args a) {
         default: DGLL_MM(8) break;
     }
 #undef DGLL_MM
+#undef DGLL_MM_V
     DGLL_HIP_TRY(hipGetLastError());
     return DGLL_OK;
 }
@@ -302,7 +375,7 @@ DGLL_API int dgll_hip_mm_f32(void* stream, const float* A, int64_t lda, const fl
     MmF32Args a{};
     a.A1 = A; a.lda1 = lda; a.W1 = Wt; a.ldw1 = ldw; a.K1 = K; a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.relu = relu; a.bias = bias;
     a.addend = addend; a.ldadd = ldadd;
-    a.vec1 = rows_vec(A, lda) && rows_vec(Wt, ldw);
+    a.vec = rows_vec(A, lda) && rows_vec(Wt, ldw);
     return launch_mm_f32(stream, a);
 }
 
@@ -320,8 +393,7 @@ DGLL_API int dgll_hip_mm2_f32(void* stream, const float* A1, int64_t lda1, const
     a.A1 = A1; a.lda1 = lda1; a.W1 = W1t; a.ldw1 = ldw1; a.K1 = K1;
     a.A2 = A2; a.lda2 = lda2; a.W2 = W2t; a.ldw2 = ldw2; a.K2 = A2 ? K2 : 0;
     a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.relu = relu; a.bias = bias; a.addend = addend; a.ldadd = ldadd; a.gate = gate; a.ldgate = ldgate;
-    a.vec1 = rows_vec(A1, lda1) && rows_vec(W1t, ldw1);
-    a.vec2 = A2 ? (rows_vec(A2, lda2) && rows_vec(W2t, ldw2)) : 0;
+    a.vec = rows_vec(A1, lda1) && rows_vec(W1t, ldw1) && (!A2 || (rows_vec(A2, lda2) && rows_vec(W2t, ldw2)));
     return launch_mm_f32(stream, a);
 }
 
@@ -340,23 +412,35 @@ DGLL_API int dgll_hip_grad_weight_f32(void* stream, const float* X, int64_t ldx,
     DGLL_REQUIRE(workspace && workspace_bytes >= dgll_hip_grad_weight_f32_workspace(K, N, slabs), "workspace too small for the slab partials");
     const int64_t per = ((M + slabs - 1) / slabs + kGwRows - 1) / kGwRows * kGwRows;
     const int used = M > 0 ? (int)((M + per - 1) / per) : 1;
-    // a wavefront per tile of 32 columns of X, at most 8 per workgroup; up to 8 n-tiles (256 columns of G) per workgroup
-    const int ktiles = (K + 31) / 32;
-    const int waves = std::min(ktiles, kGwThreads / 64);
+    // 8 wavefronts; 256 (K > 128) or 128 columns of X and up to 256 columns of G per workgroup
+    const int ktl = K > 128 ? 8 : 4;
     const int nt = (std::min(N, 256) + 31) / 32;
-    dim3 grid((uint32_t)((ktiles + waves - 1) / waves), (uint32_t)((N + 255) / 256), (uint32_t)used);
-#define DGLL_GW(T) hipLaunchKernelGGL((gradw_f32_mfma_kernel<T>), grid, dim3(64 * waves), 0, s, X, ldx, G, ldg, static_cast<float*>(workspace), M, K, N, per)
+    const bool vec = rows_vec(X, ldx) && rows_vec(G, ldg);
+    dim3 grid((uint32_t)((K + ktl * 32 - 1) / (ktl * 32)), (uint32_t)((N + 255) / 256), (uint32_t)used);
+    const size_t lds = (size_t)2 * kGwRows * (ktl * 32 + nt * 32) * sizeof(float);
+#define DGLL_GW_V(KT, T, V)                                                                                                       \
+    {                                                                                                                             \
+        static hipError_t raised = hipFuncSetAttribute(reinterpret_cast<const void*>(&gradw_f32_mfma_kernel<KT, T, V>),           \
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kGwRows * (KT * 32 + T * 32) * 4); \
+        DGLL_HIP_TRY(raised);                                                                                                     \
+        hipLaunchKernelGGL((gradw_f32_mfma_kernel<KT, T, V>), grid, dim3(kGwThreads), lds, s, X, ldx, G, ldg,                     \
+                           static_cast<float*>(workspace), M, K, N, per);                                                         \
+    }
+#define DGLL_GW(T)                                                                                                                \
+    if (ktl == 8) { if (vec) DGLL_GW_V(8, T, true) else DGLL_GW_V(8, T, false) }                                                  \
+    else { if (vec) DGLL_GW_V(4, T, true) else DGLL_GW_V(4, T, false) }
     switch (nt) {
-        case 1: DGLL_GW(1); break;
-        case 2: DGLL_GW(2); break;
-        case 3: DGLL_GW(3); break;
-        case 4: DGLL_GW(4); break;
-        case 5: DGLL_GW(5); break;
-        case 6: DGLL_GW(6); break;
-        case 7: DGLL_GW(7); break;
-        default: DGLL_GW(8); break;
+        case 1: DGLL_GW(1) break;
+        case 2: DGLL_GW(2) break;
+        case 3: DGLL_GW(3) break;
+        case 4: DGLL_GW(4) break;
+        case 5: DGLL_GW(5) break;
+        case 6: DGLL_GW(6) break;
+        case 7: DGLL_GW(7) break;
+        default: DGLL_GW(8) break;
     }
 #undef DGLL_GW
+#undef DGLL_GW_V
     DGLL_HIP_TRY(hipGetLastError());
     const int64_t count = (int64_t)K * N;
     hipLaunchKernelGGL(gradw_f32_reduce_kernel, dim3((uint32_t)((count + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,

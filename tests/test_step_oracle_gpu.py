@@ -83,12 +83,25 @@ def test_bench_step_against_the_chained_oracle(cuda_device, flat_adam):
     ref_loss = torch.nn.functional.cross_entropy(h, labels, reduction="sum") * (1.0 / N)
     ref_loss.backward()
 
+    # layer by layer (each GPU layer fed the activation the GPU stored for the layer below): same bf16 operands, fp32 accumulation on both
+    # sides, one rounding -- the stored outputs agree except where the accumulation order decides a rounding boundary; the chained
+    # output of the three layers inherits the (rare) one-ulp differences of the layers below: measured 0.99896 identical
+    with torch.no_grad():
+        hg = x
+        for l, layer in enumerate(model.gcn):
+            hg = fused_layers.sage_graph_layer(layer, full, hg)
+            if l == 0:
+                first = float((hg.float().cpu() == acts[0].detach()).float().mean())
+                print("layer 0: %.5f of the stored outputs identical" % first)
+                assert first >= 0.999, first
+        assert torch.equal(hg, out.detach())              # the autograd run stored exactly these
     got = out.detach().float().cpu()
     ref_out = h.detach()
     equal = float((got == ref_out).float().mean())
     flips = float(((got > 0) != (ref_out > 0)).float().mean())
-    print("stored outputs identical: %.5f, ReLU gates that differ: %.1e" % (equal, flips))
-    assert equal >= 0.999 and flips <= 1e-4, (equal, flips)
+    worst = float((got - ref_out).abs().max()) / float(ref_out.abs().max())
+    print("stored outputs identical: %.5f, largest difference %.2e of the largest output, ReLU gates that differ: %.1e" % (equal, worst, flips))
+    assert equal >= 0.998 and worst <= 2.0 ** -6 and flips <= 1e-4, (equal, worst, flips)
     assert abs(float(loss.detach()) - float(ref_loss.detach())) < 2e-3 * abs(float(ref_loss.detach()))
     for l, layer in enumerate(model.gcn):
         _close("layer %d weight" % l, layer.weight.grad, ref_params[l][0].grad, 1.5e-2)
