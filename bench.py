@@ -378,7 +378,7 @@ def spmm_kernel_fragment(feat, dtype_name, weighted, extra, avg_len=None):
     return "spmm_csr_kernel<%s, %s, %d, %d, %s, 4, %s, false>" % (t, t, epv, lpr, w, e)
 
 
-def gat_kernel_fragment(heads, fo, dtype_name, kind, packed=False):
+def gat_kernel_fragment(heads, fo, dtype_name, kind, packed=False, rowscore=False):
     """gat2_kernel instantiation of a pass (kind 0 forward, 3 rows in the exact-dd form -- 1: its stored-output form --, 2 transposed rows) -- edge.hip's gat2_pick / gat2_inrow."""
     bf = "bfloat16" in dtype_name
     epv = 8 if bf else 4
@@ -396,7 +396,9 @@ def gat_kernel_fragment(heads, fo, dtype_name, kind, packed=False):
         lph <<= 1
     t = "unsigned short" if bf else "float"
     inrow = packed and heads == 1 and nh == 1 and vph < lph        # scores behind the row's last column, an idle lane to fetch them
-    return "gat2_kernel<%s, %s, %d, %d, %d, 4, %d, %s>" % (t, t, epv, nh * lph, nh, kind, "true" if inrow else "false")
+    # (last argument: the row-score form -- t_j formed from the gathered row, dgll_hip_gat_fwd_rowscore)
+    return "gat2_kernel<%s, %s, %d, %d, %d, 4, %d, %s, %s>" % (t, t, epv, nh * lph, nh, kind, "true" if inrow else "false",
+                                                               "true" if rowscore else "false")
 
 
 def load_traffic(sig, fragment):
@@ -495,8 +497,9 @@ def launch_tables(launches, local_rows, heads_of=None):
             b_alg = gat_alg_bytes(tag_nnz, local_rows, heads * fo, xb, heads)
             name = "gat %s %d heads x %d %s%s nnz=%d" % (kind, heads, fo, dt.replace("torch.", ""), (" " + packed) if packed else "", tag_nnz)
             table[name] = {"count": cnt, "avg_ms": avg_ms, "nnz": tag_nnz, "feat": heads * fo, "heads": heads, "pass": kind,
-                           "scores_in_row_padding": bool(packed),
-                           "kernel_fragment": gat_kernel_fragment(heads, fo, dt, {"fwd": 0, "bwd_rows": 3, "bwd_cols": 2}[kind], bool(packed))}
+                           "scores_in_row_padding": packed == "packed", "scores_from_gathered_rows": packed == "rowscore",
+                           "kernel_fragment": gat_kernel_fragment(heads, fo, dt, {"fwd": 0, "bwd_rows": 3, "bwd_cols": 2}[kind],
+                                                                  packed == "packed", packed == "rowscore")}
         elif tag[0] in ("transform", "transform_dual", "grad_weight"):
             kind, m, k1, k2, n_out, extra = tag
             parts = extra.split("+") if extra else []
@@ -1709,7 +1712,7 @@ def compact_other(rec):
     passes = {}
     for name, ms in (rec.get("gather_launch_ms") or {}).items():       # the three GAT passes of the hidden (8-head) layer
         for kind in ("fwd", "bwd_rows", "bwd_cols"):
-            if name.startswith("gat %s " % kind) and "packed" not in name and kind not in passes:
+            if name.startswith("gat %s " % kind) and " packed" not in name and kind not in passes:
                 passes[kind] = ms
     for kind, ms in passes.items():
         out["gat_%s_ms" % kind] = ms

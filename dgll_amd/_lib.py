@@ -89,6 +89,8 @@ SIGNATURES = {
                                      _i32, _i64, _i32, _i32, C.c_float, _i32, _vp, _sz]),
     "dgll_hip_gat_fwd_strided": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _vp, _i64, _i32, _vp, _i64, _i32, _i32,
                                         C.c_float, _i32, _vp, _sz]),
+    "dgll_hip_gat_fwd_rowscore": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i32, _vp, _i64, _i32, _i32, C.c_float, _i32,
+                                         _vp, _sz, _i32, _i32]),
     "dgll_hip_gat_bwd_rows_strided": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _i64,
                                              _vp, _i32, _vp, _i64, _i32, _i32, C.c_float, _i32, _vp, _sz]),
     "dgll_hip_gat_bwd_cols_strided": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i32, _vp, _i64, _vp, _i32, _i64,

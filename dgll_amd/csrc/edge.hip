@@ -787,7 +787,8 @@ static bool gat2_pick(const EdgeArgs& a, int* lpr, int* nh, uint32_t* grid_y) {
     while (lph < a.vph) lph <<= 1;
     if (lph > kWave) return false;
     // blocks of 4 / 8 heads are read as float4s: whole blocks, 16-byte aligned
-    const bool vec = a.heads % 4 == 0 && a.tstride % 4 == 0 && aligned16(a.T) && (!a.DD || aligned16(a.DD));
+    // (row-score form, a.T == NULL: no score row is read at all)
+    const bool vec = a.heads % 4 == 0 && (!a.T || (a.tstride % 4 == 0 && aligned16(a.T))) && (!a.DD || aligned16(a.DD));
     int n = 1;
     for (int cand = 8; cand >= 1; cand >>= 1) {
         if (cand * lph > kWave) continue;
@@ -829,12 +830,15 @@ static int gat1_pick(const EdgeArgs& a, int epv, int* lph, int* lpr, uint32_t* g
 static int gat_fwd_impl(void* stream, const dgll_csr_plan* plan, const int64_t* rowptr, const int32_t* col,
                         const void* H, int64_t ldh, const float* S, const float* T, int t_stride, const float* edge_scale, void* out,
                         int64_t ldo, int dtype, float* rowsum, float* rowmax, int64_t n_rows, int heads, int fo,
-                        float alpha, int apply_elu, int mode, void* workspace, size_t workspace_bytes, int raw, int accumulate) {
+                        float alpha, int apply_elu, int mode, void* workspace, size_t workspace_bytes, int raw, int accumulate,
+                        const float* attn2 = nullptr) {
     if (n_rows <= 0) return DGLL_OK;
     EdgeArgs a{};
     int rc = gat_common(a, rowptr, col, n_rows, heads, fo, dtype, alpha, mode, apply_elu);
     if (rc != DGLL_OK) return rc;
-    DGLL_REQUIRE(H && S && T && out && rowsum, "NULL argument");
+    DGLL_REQUIRE(H && S && (T || attn2) && out && rowsum, "NULL argument");
+    DGLL_REQUIRE(!attn2 || (!T && mode == 0 && !edge_scale), "the row-score form takes a2 INSTEAD of T (sparseGatConv's form, no attention dropout)");
+    a.attn2 = attn2;
     DGLL_REQUIRE(mode == 0 || rowmax, "mode 1 needs a rowmax output");
     const int esz = dtype == DGLL_BF16 ? 2 : 4, epv = 16 / esz;
     DGLL_REQUIRE(vec_ok(H, ldh, esz) && vec_ok(out, ldo, esz) && ldh >= a.feat && ldo >= a.feat, "H/out must be 16-byte aligned");
@@ -847,7 +851,12 @@ static int gat_fwd_impl(void* stream, const dgll_csr_plan* plan, const int64_t* 
     if (rc != DGLL_OK) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
     int lpr, nh, lph;
-    if (gat2_pick(a, &lpr, &nh, &grid.y)) {
+    if (attn2) {
+        if (!gat2_pick(a, &lpr, &nh, &grid.y) || !gat2_launch_0r(dtype, lpr, nh, grid, s, a)) {
+            set_error("no row-score GAT kernel for this head layout");
+            return DGLL_ERR_UNSUPPORTED;
+        }
+    } else if (gat2_pick(a, &lpr, &nh, &grid.y)) {
         if (!gat2_launch_0(dtype, lpr, nh, grid, s, a, gat2_inrow(a, lpr, nh, esz, a.T, nullptr))) { set_error("no second-generation GAT kernel for this head layout"); return DGLL_ERR_UNSUPPORTED; }
     } else {
         rc = gat1_pick(a, epv, &lph, &lpr, &grid.y);
@@ -885,6 +894,15 @@ DGLL_API int dgll_hip_gat_fwd_strided(void* stream, const dgll_csr_plan* plan, c
     DGLL_REQUIRE(t_stride >= heads, "t_stride must be at least heads");
     return gat_fwd_impl(stream, plan, rowptr, col, H, ldh, S, T, t_stride, nullptr, out, ldo, dtype, rowsum, nullptr, n_rows, heads,
                         fo, alpha, apply_elu, 0, workspace, workspace_bytes, 0, 0);
+}
+
+DGLL_API int dgll_hip_gat_fwd_rowscore(void* stream, const dgll_csr_plan* plan, const int64_t* rowptr, const int32_t* col,
+                                       const void* H, int64_t ldh, const float* S, const float* attn2, void* out, int64_t ldo, int dtype,
+                                       float* rowsum, int64_t n_rows, int heads, int fo, float alpha, int apply_elu, void* workspace,
+                                       size_t workspace_bytes, int raw, int accumulate) {
+    DGLL_REQUIRE(attn2, "attn2 (a2 of every head, laid out like a row of H) is required");
+    return gat_fwd_impl(stream, plan, rowptr, col, H, ldh, S, nullptr, 0, nullptr, out, ldo, dtype, rowsum, nullptr, n_rows, heads, fo,
+                        alpha, apply_elu, 0, workspace, workspace_bytes, raw, accumulate, attn2);
 }
 
 // Pass 1 of the backward (rows of A or of one column-half of A): DN, DD and grad_S.  accumulate: 0 = first (or only) launch:

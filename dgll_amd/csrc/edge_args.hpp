@@ -151,6 +151,7 @@ __device__ __forceinline__ void for_each_batch(const int32_t* __restrict__ col, 
 // 2 backward over the rows of A^T) for `nh` heads per wavefront on `lpr` lanes per row; inrow: the gathered-side scores sit
 // in the padding of the gathered rows and arrive with the gather (one head).  False: no such instantiation.
 bool gat2_launch_0(int dtype, int lpr, int nh, dim3 grid, hipStream_t s, const EdgeArgs& a, bool inrow);
+bool gat2_launch_0r(int dtype, int lpr, int nh, dim3 grid, hipStream_t s, const EdgeArgs& a);             // pass 0, scores from the gathered rows
 bool gat2_launch_1(int dtype, int lpr, int nh, dim3 grid, hipStream_t s, const EdgeArgs& a, bool inrow);
 bool gat2_launch_3(int dtype, int lpr, int nh, dim3 grid, hipStream_t s, const EdgeArgs& a, bool inrow);   // pass 1, exact-dd form alone
 bool gat2_launch_2(int dtype, int lpr, int nh, dim3 grid, hipStream_t s, const EdgeArgs& a, bool inrow);

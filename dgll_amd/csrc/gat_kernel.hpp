@@ -66,6 +66,24 @@ __device__ __forceinline__ float head_sum_c(float v) {
     return v;
 }
 
+// The same sum on the DPP path (no LDS crossbar trip) for the per-EDGE use of the row-score form: quad_perm [1,0,3,2], [2,3,0,1],
+// then row_half_mirror (lane i <-> 7 - i: the other quad of 8) and row_mirror (15 - i: the other half of 16) -- every lane of the
+// group ends up with the group's sum.  Groups of 32 / 64 lanes finish through ds_bpermute.
+template <int CTRL>
+__device__ __forceinline__ float dpp_take(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+template <int LPH>
+__device__ __forceinline__ float head_sum_dpp(float v) {
+    if constexpr (LPH >= 2) v += dpp_take<0xB1>(v);
+    if constexpr (LPH >= 4) v += dpp_take<0x4E>(v);
+    if constexpr (LPH >= 8) v += dpp_take<0x141>(v);
+    if constexpr (LPH >= 16) v += dpp_take<0x140>(v);
+    if constexpr (LPH >= 32) v += __shfl_xor(v, 16);
+    if constexpr (LPH >= 64) v += __shfl_xor(v, 32);
+    return v;
+}
+
 }  // namespace
 
 // KIND 0: forward.  KIND 1: backward over the rows of A (DN, DD, grad_S).  KIND 2: backward over the rows of A^T (grad_H, grad_T).
@@ -75,7 +93,12 @@ __device__ __forceinline__ float head_sum_c(float v) {
 // behind the row's last column WITH the row -- t_j (or {s_i, dd_i} in the transposed pass) arrives with the gather, is broadcast
 // inside the lane group, and the record phase (a dependent load per batch, the LDS hand-over) disappears: for 8-lane rows the
 // passes are bound by exactly that per-row latency chain.
-template <typename XT, typename YT, int EPV, int LPR, int NH, int U, int KIND, bool INROW = false>
+// TROW (forward and rows passes): the gathered-side score t_j = h_j . a2 is FORMED from the gathered row itself, as the reference does
+// (gatconv.py:122-125 builds the logit from the gathered rows): every lane holds its EPV columns of a2 (bf16 storage: as packed pairs
+// for v_dot2), takes the partial dot product with the row it has just gathered and sums over the head's lanes on the DPP path; each
+// lane then evaluates w_ij itself.  No score row is fetched (the FIFTH cache line per edge of the 8 x 32 bf16 layer), no
+// record phase, no LDS hand-over -- for 4 x more exponentials per edge, on a VALU that was a third busy.
+template <typename XT, typename YT, int EPV, int LPR, int NH, int U, int KIND, bool INROW = false, bool TROW = false>
 // (the narrow in-row rows pass is held at 6 wavefronts per SIMD: the exact dd_i's extra sum took it from 79 to 86 VGPRs and from 6 to
 // 5 wavefronts, 2.56 -> 2.88 ms; bounded it fits 77 registers without scratch.  The 8-head form needs 12 bytes of scratch at that bound
 // and measured no faster: it runs at 83 registers / 5 wavefronts, 6.02 -> 6.17 ms for the exactness.)
@@ -121,6 +144,20 @@ __global__ __launch_bounds__(kBlock, ((KIND == 1 || KIND == 3) && INROW && sizeo
     }
     // (Round 4, measured and dropped: requesting the NEXT item's first score rows one item ahead, behind the current row's gathers --
     // forward 5.58 -> 5.61 ms, rows pass 6.04 -> 6.15; in the transposed pass the held registers cost a wavefront of occupancy.)
+    uint32_t a2p[4] = {0u, 0u, 0u, 0u};                            // TROW: this lane's columns of a2 (idle lanes: zeros -> partial dot 0)
+    float a2f[EPV];
+#pragma unroll
+    for (int i = 0; i < EPV; ++i) a2f[i] = 0.0f;
+    if constexpr (TROW) {
+        if (col_ok) {
+#pragma unroll
+            for (int i = 0; i < EPV; ++i) a2f[i] = a.attn2[c0 + i];
+        }
+        if constexpr (BF) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a2p[q] = pack_bf16x2(a2f[2 * q], a2f[2 * q + 1]);
+        }
+    }
     WorkItem it = resolve_item(a, wave, 0);
     int col_first = 0;                                             // the item's first index batch (lane = edge), prefetched
     if (it.valid && it.b + lane < it.e) col_first = __builtin_nontemporal_load(a.col + it.b + lane);
@@ -138,6 +175,8 @@ __global__ __launch_bounds__(kBlock, ((KIND == 1 || KIND == 3) && INROW && sizeo
     // ---- wave-uniform per-row scalars of the wave's heads
     float su[NH];
     load_heads_uniform<NH>(a.S, row, a.heads, h0, su);
+    float s_mine = 0.0f;                                           // TROW: s_i of this lane's own head
+    if constexpr (TROW) s_mine = a.S[row * a.heads + head];
 
     // ---- per-row prologue of the backward passes
     float dn[EPV];                     // KIND 1: DN_i (this lane's columns)
@@ -215,7 +254,7 @@ __global__ __launch_bounds__(kBlock, ((KIND == 1 || KIND == 3) && INROW && sizeo
         }
         // -- record phase: lane = edge.  (Measured alternative for 8 heads, lane = (edge, half) so that one load instruction
         // covers 32 edges with two adjacent lanes per 32-byte score row: forward unchanged, transposed pass 6.4 -> 7.8 ms.)
-        if constexpr (!INROW) {
+        if constexpr (!INROW && !TROW) {
             float tv[NH], dv[NH];
             load_heads<NH>(a.T, col_cur, a.tstride, a.heads, h0, tv);        // idle lanes hold column 0: a valid row
             if constexpr (KIND == 2) load_heads<NH>(a.DD, col_cur, a.tstride, a.heads, h0, dv);
@@ -245,9 +284,32 @@ __global__ __launch_bounds__(kBlock, ((KIND == 1 || KIND == 3) && INROW && sizeo
                 const int idx = j + u * SLOTS + slot;
                 const int cj = __shfl(gcol, idx);
                 v[u] = IO::load(hcol + (uint64_t)(uint32_t)cj * ld32);
-                if constexpr (!INROW) {
+                if constexpr (!INROW && !TROW) {
                     rr[u] = my_rec[idx];
                     if constexpr (KIND == 2) r1[u] = my_rec1[idx];
+                }
+            }
+            if constexpr (TROW) {
+                static_assert(KIND != 2, "the transposed pass gathers DN rows: their scores cannot be formed from them");
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    float pt = 0.0f;
+                    if constexpr (BF) {
+                        const uint32_t hv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            pt = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a2p[q]), __builtin_bit_cast(bf16x2_t, hv[q]), pt, false);
+                    } else {
+                        float f[EPV];
+                        IO::unpack(v[u], f);
+#pragma unroll
+                        for (int i = 0; i < EPV; ++i) pt = fmaf(f[i], a2f[i], pt);
+                    }
+                    const float z = s_mine + head_sum_dpp<LPH>(pt);
+                    float w = __expf(a.sign * lrelu(z, a.alpha));
+                    w = (j + u * SLOTS + slot < nb) ? w : 0.0f;
+                    if constexpr (KIND == 0) rr[u] = w;
+                    if constexpr (ROWS) rr[u] = z > 0.0f ? w : -w;
                 }
             }
             if constexpr (INROW) {
@@ -408,12 +470,14 @@ __global__ __launch_bounds__(kBlock, ((KIND == 1 || KIND == 3) && INROW && sizeo
 }
 
 // ---- dispatch: (lanes per row, heads per wavefront) pairs with 1 <= LPR / NH ------------------------------------------------
-template <typename XT, typename YT, int EPV, int LPR, int KIND>
+template <typename XT, typename YT, int EPV, int LPR, int KIND, bool TROW = false>
 static bool gat2_launch_nh(const EdgeArgs& a, int nh, dim3 grid, hipStream_t s, bool inrow) {
-#define DGLL_GAT2(NHV) hipLaunchKernelGGL((gat2_kernel<XT, YT, EPV, LPR, NHV, 4, KIND>), grid, dim3(kBlock), 0, s, a); return true
+#define DGLL_GAT2(NHV) hipLaunchKernelGGL((gat2_kernel<XT, YT, EPV, LPR, NHV, 4, KIND, false, TROW>), grid, dim3(kBlock), 0, s, a); return true
     switch (nh) {
         case 1:
-            if (inrow) { hipLaunchKernelGGL((gat2_kernel<XT, YT, EPV, LPR, 1, 4, KIND, true>), grid, dim3(kBlock), 0, s, a); return true; }
+            if constexpr (!TROW) {
+                if (inrow) { hipLaunchKernelGGL((gat2_kernel<XT, YT, EPV, LPR, 1, 4, KIND, true>), grid, dim3(kBlock), 0, s, a); return true; }
+            }
             DGLL_GAT2(1);
         case 2: DGLL_GAT2(2);
         case 4: DGLL_GAT2(4);
@@ -423,22 +487,22 @@ static bool gat2_launch_nh(const EdgeArgs& a, int nh, dim3 grid, hipStream_t s, 
 #undef DGLL_GAT2
 }
 
-template <typename XT, typename YT, int EPV, int KIND>
+template <typename XT, typename YT, int EPV, int KIND, bool TROW = false>
 static bool gat2_launch_lpr(const EdgeArgs& a, int lpr, int nh, dim3 grid, hipStream_t s, bool inrow) {
     switch (lpr) {
-        case 4: return gat2_launch_nh<XT, YT, EPV, 4, KIND>(a, nh, grid, s, inrow);
-        case 8: return gat2_launch_nh<XT, YT, EPV, 8, KIND>(a, nh, grid, s, inrow);
-        case 16: return gat2_launch_nh<XT, YT, EPV, 16, KIND>(a, nh, grid, s, inrow);
-        case 32: return gat2_launch_nh<XT, YT, EPV, 32, KIND>(a, nh, grid, s, inrow);
-        case 64: return gat2_launch_nh<XT, YT, EPV, 64, KIND>(a, nh, grid, s, inrow);
+        case 4: return gat2_launch_nh<XT, YT, EPV, 4, KIND, TROW>(a, nh, grid, s, inrow);
+        case 8: return gat2_launch_nh<XT, YT, EPV, 8, KIND, TROW>(a, nh, grid, s, inrow);
+        case 16: return gat2_launch_nh<XT, YT, EPV, 16, KIND, TROW>(a, nh, grid, s, inrow);
+        case 32: return gat2_launch_nh<XT, YT, EPV, 32, KIND, TROW>(a, nh, grid, s, inrow);
+        case 64: return gat2_launch_nh<XT, YT, EPV, 64, KIND, TROW>(a, nh, grid, s, inrow);
         default: return false;
     }
 }
 
-template <int KIND>
+template <int KIND, bool TROW = false>
 static bool gat2_launch_kind(int dtype, int lpr, int nh, dim3 grid, hipStream_t s, const EdgeArgs& a, bool inrow) {
-    if (dtype == DGLL_F32) return gat2_launch_lpr<float, float, 4, KIND>(a, lpr, nh, grid, s, inrow);
-    return gat2_launch_lpr<bf16_t, bf16_t, 8, KIND>(a, lpr, nh, grid, s, inrow);
+    if (dtype == DGLL_F32) return gat2_launch_lpr<float, float, 4, KIND, TROW>(a, lpr, nh, grid, s, inrow);
+    return gat2_launch_lpr<bf16_t, bf16_t, 8, KIND, TROW>(a, lpr, nh, grid, s, inrow);
 }
 
 }  // namespace dgll

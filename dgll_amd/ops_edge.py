@@ -1,5 +1,7 @@
 """Per-edge operators of the GAT / SpecialSpmm path (C ABI: dgll_hip_sddmm_csr, dgll_hip_gat_fwd/bwd,
 dgll_hip_segment_max).  GPU only; no fallback."""
+import os
+
 import torch
 
 from . import _lib
@@ -144,8 +146,14 @@ def _empty_like_rows(n, like):
     return buf[:, :like.shape[1]] if like.stride(0) != like.shape[1] else buf
 
 
-def _gat_strided_forward(h, s, t, graph, heads, fo, alpha, apply_elu, pack_scores):
-    """Forward gather pass on dgll_hip_gat_fwd_strided.  Returns (h with aligned rows, s, t, out, rowsum, packed)."""
+ROW_SCORES = os.environ.get("DGLL_GAT_ROW_SCORES", "1") != "0"     # 0: the forward always gathers T (A/B, tests)
+
+
+def _gat_strided_forward(h, s, t, graph, heads, fo, alpha, apply_elu, pack_scores, attn2=None):
+    """Forward gather pass on dgll_hip_gat_fwd_strided.  Returns (h with aligned rows, s, t, out, rowsum, packed).
+    attn2: fp32 [heads * fo], a2 of every head laid out like a row of h (t = h . a2 per head): when the scores cannot ride in the rows'
+    padding the pass forms t_j from the row it gathers anyway instead of fetching T[j] (dgll_hip_gat_fwd_rowscore; the reference builds
+    its logit from the gathered rows too, gatconv.py:122-125)."""
     _require_cuda(h, s, t, graph.rowptr)
     dev = h.device
     h = _ready(h)
@@ -164,15 +172,23 @@ def _gat_strided_forward(h, s, t, graph, heads, fo, alpha, apply_elu, pack_score
     ws_bytes = int(_lib.lib.dgll_hip_gat_workspace_bytes(plan, heads, fo))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
     timer = _launch_timer()
-    end = timer.start(("gat", "fwd", heads, fo, str(h.dtype), graph.nnz, "packed" if packed else ""), dev) if timer else None
+    row_scores = attn2 is not None and not packed and ROW_SCORES
+    end = timer.start(("gat", "fwd", heads, fo, str(h.dtype), graph.nnz, "packed" if packed else ("rowscore" if row_scores else "")), dev) if timer else None
     with torch.cuda.device(dev):
-        code = _lib.lib.dgll_hip_gat_fwd_strided(
-            _stream(dev), plan, graph.rowptr.data_ptr(), graph.col.data_ptr(), h.data_ptr(), h.stride(0), s.data_ptr(),
-            t_gather.data_ptr(), t_gather.stride(0), out.data_ptr(), out.stride(0), _dtype_code(h), rowsum.data_ptr(),
-            graph.n_rows, heads, fo, float(alpha), int(apply_elu), ws.data_ptr() if ws is not None else None, ws_bytes)
+        if row_scores:
+            a2 = attn2.detach().to(torch.float32).contiguous()
+            code = _lib.lib.dgll_hip_gat_fwd_rowscore(
+                _stream(dev), plan, graph.rowptr.data_ptr(), graph.col.data_ptr(), h.data_ptr(), h.stride(0), s.data_ptr(),
+                a2.data_ptr(), out.data_ptr(), out.stride(0), _dtype_code(h), rowsum.data_ptr(), graph.n_rows, heads, fo, float(alpha),
+                int(apply_elu), ws.data_ptr() if ws is not None else None, ws_bytes, 0, 0)
+        else:
+            code = _lib.lib.dgll_hip_gat_fwd_strided(
+                _stream(dev), plan, graph.rowptr.data_ptr(), graph.col.data_ptr(), h.data_ptr(), h.stride(0), s.data_ptr(),
+                t_gather.data_ptr(), t_gather.stride(0), out.data_ptr(), out.stride(0), _dtype_code(h), rowsum.data_ptr(),
+                graph.n_rows, heads, fo, float(alpha), int(apply_elu), ws.data_ptr() if ws is not None else None, ws_bytes)
     if end is not None:
         end.record(torch.cuda.current_stream(dev))
-    _lib.check(code, "dgll_hip_gat_fwd_strided")
+    _lib.check(code, "dgll_hip_gat_fwd_rowscore" if row_scores else "dgll_hip_gat_fwd_strided")
     return h, s, t, out, rowsum, packed
 
 
@@ -263,8 +279,9 @@ class _GatLayerStrided(torch.autograd.Function):
         Ad = A.detach().to(h.dtype)
         st = (dense.transform_bf16(h, Ad.t(), out_dtype=torch.float32) if (dense._mfma_ok(h) and Ad.shape[1] <= 256)
               else dense.mm_nt(h, Ad.t()).float())
+        # a2 of every head laid out like a row of h (A is block-diagonal: column heads + k holds a2 of head k in rows k fo .. (k + 1) fo)
         h, s, t, out, rowsum, packed = _gat_strided_forward(h, st[:, :heads], st[:, heads:], graph, heads, fo, alpha, apply_elu,
-                                                            pack_scores)
+                                                            pack_scores, attn2=Ad[:, heads:].float().sum(1))
         ctx.graph, ctx.cfg, ctx.packed = graph, (heads, fo, float(alpha), int(apply_elu)), packed
         ctx.save_for_backward(h, Ad, s, t, out, rowsum)
         return out

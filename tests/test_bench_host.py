@@ -47,10 +47,12 @@ def test_kernel_fragments_name_the_instantiations(bench):
     assert bench.spmm_kernel_fragment(256, "torch.float32", False, False, 50.5) == "spmm_csr_kernel<float, float, 4, 64, false, 4, false, false>"
     assert bench.spmm_kernel_fragment(256, "torch.bfloat16", True, False, 50.5) == "spmm_csr_kernel<unsigned short, unsigned short, 8, 32, true, 4, false, false>"
     # 8 heads x 32 bf16: 4 lanes per head, 8 heads per wavefront; 1 head x 48 with scores in the row padding: the in-row form
-    assert bench.gat_kernel_fragment(8, 32, "torch.bfloat16", 2) == "gat2_kernel<unsigned short, unsigned short, 8, 32, 8, 4, 2, false>"
-    assert bench.gat_kernel_fragment(1, 48, "torch.bfloat16", 0, packed=True) == "gat2_kernel<unsigned short, unsigned short, 8, 8, 1, 4, 0, true>"
-    assert bench.gat_kernel_fragment(1, 48, "torch.bfloat16", 0, packed=False).endswith("0, false>")
-    assert bench.gat_kernel_fragment(3, 24, "torch.bfloat16", 1) == "gat2_kernel<unsigned short, unsigned short, 8, 8, 2, 4, 1, false>"
+    assert bench.gat_kernel_fragment(8, 32, "torch.bfloat16", 2) == "gat2_kernel<unsigned short, unsigned short, 8, 32, 8, 4, 2, false, false>"
+    assert bench.gat_kernel_fragment(1, 48, "torch.bfloat16", 0, packed=True) == "gat2_kernel<unsigned short, unsigned short, 8, 8, 1, 4, 0, true, false>"
+    assert bench.gat_kernel_fragment(1, 48, "torch.bfloat16", 0, packed=False).endswith("0, false, false>")
+    assert bench.gat_kernel_fragment(3, 24, "torch.bfloat16", 1) == "gat2_kernel<unsigned short, unsigned short, 8, 8, 2, 4, 1, false, false>"
+    # the 8-head forward in its row-score form (t_j from the gathered row: dgll_hip_gat_fwd_rowscore)
+    assert bench.gat_kernel_fragment(8, 32, "torch.bfloat16", 0, rowscore=True) == "gat2_kernel<unsigned short, unsigned short, 8, 32, 8, 4, 0, false, true>"
 
 
 def _dom(frag, ms=5.0, b_alg=65.6e9):
