@@ -236,6 +236,12 @@ class ExchangeWatchdog:
         """Whether the next exchange is watched."""
         return self.timeout > 0 and (self.mode == "always" or self.watched < self.arm_first)
 
+    def rearm(self):
+        """A NEW exchange pattern is about to make first contact (the halo mode switched, another set of buffers, a new DistGraph):
+        watch the next `arm_first` exchanges again.  Without this the "startup" mode's budget could be spent before the pattern
+        that hangs is ever used (resolve_halo_mode switches forms after the first 16 exchanges)."""
+        self.watched = 0
+
     def _die(self, phase, age):
         print("dgll_amd.dist: rank %d: exchange phase '%s' did not complete within %.0f s -- exiting (code 3); Python stacks follow" % (
             self.rank, phase, age), file=sys.stderr, flush=True)
@@ -960,6 +966,7 @@ class DistGraph:
         timings = {}
         for mode in ("recompute", "exchange"):
             self.halo_recompute = mode == "recompute"
+            self._rearm_watchdog()                        # each form's exchanges make their own first contact
             step()
             if self.device.type == "cuda":
                 torch.cuda.synchronize(self.device)
@@ -977,7 +984,13 @@ class DistGraph:
         self.halo_mode_timings = timings
         self.halo_recompute = timings["recompute"] <= timings["exchange"]
         self.halo_mode = "recompute" if self.halo_recompute else "exchange"
+        self._rearm_watchdog()
         return self.halo_mode
+
+    def _rearm_watchdog(self):
+        wd = getattr(self.exchange, "watchdog", None)      # (a stand-in transport of the modelling tools has none)
+        if wd is not None:
+            wd.rearm()
 
     def verify(self):
         """Before anything is timed: (1) cross-check the locally derived exchange lists across ranks (a mismatch would otherwise

@@ -133,7 +133,11 @@ class GraphedSampledStep:
     graph (its bias corrections are host scalars of the launch): one more launch.
 
     model: GraphSage on the GPU (standard layers: hops of a layer batched, forward_sampled's fast path); optimizer: FlatAdam (the
-    weight-gradient kernels write its gradient slots in place -- the replay refills them) or any torch optimizer.
+    weight-gradient kernels write its gradient slots in place -- the replay refills them) or any torch optimizer.  Every captured
+    set keeps the gradient tensors ITS graph writes (a FlatAdam slot is the same tensor in every set; anything else -- a torch
+    optimizer's accumulated gradients, a parameter with two producers -- lives in that graph's pool) and p.grad is bound to them
+    before the optimizer steps: without that, the replay of set k < n_sets - 1 would fill its own tensors while the optimizer read
+    the ones the LAST capture left in p.grad.
     fanouts: the sampler's, in the model's order; the outermost hop arrives reduced (Batch.last_hop_reduced)."""
 
     def __init__(self, model, optimizer, batch_size, fanouts, in_feats, n_classes, dtype=torch.bfloat16, device="cuda", warmup=2,
@@ -162,7 +166,9 @@ class GraphedSampledStep:
                 raise ValueError("rows: one bound per hop 0 .. L-1")
             self.rows = [min(int(r), cap) for r, cap in zip(rows, self.rows)]
         self._ops = ops
-        self.sets = [self._make_set(order, in_feats, n_classes, dtype, warmup) for _ in range(max(1, int(n_sets)))]
+        self.sets = []
+        for _ in range(max(1, int(n_sets))):
+            self.sets.append(self._make_set(order, in_feats, n_classes, dtype, warmup))
         first = self.sets[0]                                          # the copy path's set under the names earlier rounds used
         self.feat_all, self.features, self.agg_all, self.reduced = first.feat_all, first.features, first.agg_all, first.reduced
         self.blocks, self.labels, self.graph, self.loss = first.blocks, first.labels, first.graph, first.loss
@@ -203,10 +209,21 @@ class GraphedSampledStep:
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         st.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(st.graph, stream=side, capture_error_mode="thread_local"):
+        # one memory pool for all sets: the replays never overlap (one stream), so only the static inputs and what a set hands out
+        # (its loss, its gradient tensors -- kept alive below) need to be per set; a pool per set reserved the whole activation
+        # footprint n_sets times and took it from the feature cache
+        pool = self.sets[0].graph.pool() if getattr(self, "sets", None) else None
+        with torch.cuda.graph(st.graph, pool=pool, stream=side, capture_error_mode="thread_local"):
             st.loss = self._forward_backward(st)
         torch.cuda.synchronize(dev)
+        st.params = [p for p in self.model.parameters() if p.requires_grad]
+        st.grads = [p.grad for p in st.params]          # the tensors THIS graph's replay fills
         return st
+
+    def _bind_grads(self, st):
+        for p, g in zip(st.params, st.grads):
+            if p.grad is not g:
+                p.grad = g
 
     def _zero_grad(self):
         self.optimizer.zero_grad(set_to_none=True)
@@ -271,5 +288,6 @@ class GraphedSampledStep:
                 st = self.sets[k]
             st.graph.replay()
             self._mark_free(k)
+            self._bind_grads(st)
             self.optimizer.step()
         return st.loss

@@ -220,6 +220,10 @@ def test_exchange_watchdog_reports_the_phase_of_an_exchange_that_never_completes
     assert wd2.watched == 3
     with wd2.guard("self-test", force=True):             # the start-up self-test is watched whatever was counted before
         assert any(ph == "self-test" for ph, _p, _t, _e in wd2._pending)
+    # a new exchange pattern (halo mode switched, DistGraph.resolve_halo_mode) is watched from its own first contact again
+    assert not wd2.armed()
+    wd2.rearm()
+    assert wd2.armed() and wd2.watched == 0
     assert ddist.ExchangeWatchdog(timeout=5.0, mode="always", arm_first=0).armed()
     assert not ddist.ExchangeWatchdog(timeout=5.0, mode="off").armed()
     with pytest.raises(ValueError):

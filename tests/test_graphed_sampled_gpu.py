@@ -244,3 +244,64 @@ def test_sampled_step_gradients_written_in_place_equal_the_merged_ones(cuda_devi
     assert loss_a == loss_b and len(calls) >= 3
     for ga, gb in zip(grads_a, grads_b):
         assert float((ga - gb).abs().max()) <= 1e-6 * max(float(gb.abs().max()), 1.0)
+
+
+@pytest.mark.parametrize("optimizer", ["flat", "torch"])
+def test_every_set_steps_on_its_own_gradients(cuda_device, optimizer):
+    """with n_sets > 1 every set's graph is captured after a zero_grad(set_to_none), so p.grad ends up bound to the LAST
+    capture's tensors; a replay of an earlier set fills ITS tensors.  The step binds p.grad to the replayed set's gradient tensors
+    before the optimizer runs: training with lr > 0 through sets handed round equals the eager loop, for FlatAdam (whose slots are the
+    same tensor in every set) and for torch.optim.Adam (whose gradients live in each graph's pool)."""
+    from dgll_amd import nn as dnn, ops
+    from dgll_amd.graphs import GraphedSampledStep
+    from dgll_amd.optim import FlatAdam
+
+    dev = cuda_device
+    fanouts, batch, feats, classes = [4, 3], 48, 30, 6
+    order = list(reversed(fanouts))
+    rng = torch.Generator().manual_seed(9)
+    batches = [_batch(dev, rng, batch, order, feats, classes, fill) for fill in (1.0, 0.8, 1.0, 0.6, 1.0, 0.9, 1.0)]
+
+    def make():
+        torch.manual_seed(4)
+        model = dnn.GraphSage(feats, [32, classes], fanouts).to(dev)
+        params = list(model.parameters())
+        return model, (FlatAdam(params, lr=2e-2) if optimizer == "flat" else torch.optim.Adam(params, lr=2e-2))
+
+    model, opt = make()
+    want, grads_want = [], []
+    for b in batches:
+        loss, grads = _eager(model, opt, b, ops)
+        opt.step()
+        want.append(loss)
+        grads_want.append([g.clone() for g in grads])
+    ref_params = [p.detach().clone() for p in model.parameters()]
+
+    model, opt = make()
+    step = GraphedSampledStep(model, opt, batch, fanouts, feats, classes, device=dev, n_sets=3)
+    got = []
+    for i, b in enumerate(batches):
+        k = i % 3                                        # hand the sets round: load into set k by hand, as the loading stage would
+        st = step.sets[k]
+        if k:
+            n = [int(b.features[h].shape[0]) for h in range(len(order))]
+            for h in range(len(order)):
+                st.features[h][:n[h]].copy_(b.features[h])
+            st.reduced[:n[-1]].copy_(b.last_hop_reduced)
+            from dgll_amd.graphs import PaddedBlock
+
+            for h in range(len(order) - 1):
+                PaddedBlock.pad(st.blocks[h], b.blocks[h].rowptr, n[h + 1])
+            st.labels.fill_(-100)
+            st.labels[:n[0]].copy_(b.labels)
+            b.static_set = k
+        else:
+            b.static_set = None
+        got.append(float(step(b)))
+        for p, gw in zip(model.parameters(), grads_want[i]):       # the optimizer stepped on THIS batch's gradients
+            assert float((p.grad - gw).abs().max()) <= 5e-3 * float(gw.abs().max()) + 1e-6, (i, k)
+    assert got == pytest.approx(want, rel=5e-3)
+    for p, r in zip(model.parameters(), ref_params):
+        assert float((p.detach() - r).abs().max()) <= 2e-2 * float(r.abs().max())
+    # one pool for all sets
+    assert all(s.graph.pool() == step.sets[0].graph.pool() for s in step.sets)
