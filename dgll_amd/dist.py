@@ -738,8 +738,8 @@ class _DistSageInputLayerAll(torch.autograd.Function):
     the mask is linear in the gradient, so the sum over ranks equals the owner-side reduction of the exchange it replaces."""
 
     @staticmethod
-    def forward(ctx, ws, wn, engine, reduce, relu, grad_is_gated, placed):
-        from . import dense
+    def forward(ctx, ws, wn, engine, reduce, relu, grad_is_gated, placed, bits_box=None):
+        from . import dense, fused_layers
 
         p = engine.part
         x_all = placed[2]
@@ -748,7 +748,11 @@ class _DistSageInputLayerAll(torch.autograd.Function):
         engine.spmm(p.merged, x_all, agg_all[:p.n_own], row_scale=scale)        # this rank's rows: aggregated every step
         wsd, wnd = dense.wcast(ws, x_all), dense.wcast(wn, x_all)
         if x_all.is_cuda and dense._mfma_ok(x_all, agg_all) and ws.shape[1] <= 256:
-            out = dense.transform_bf16(x_all, wsd.t(), agg_all, wnd.t(), relu=relu)
+            if relu and bits_box is not None and fused_layers.GATE_BITS:      # sign bits of own AND halo rows: the layer above gates both
+                out, bits = dense.transform_bf16(x_all, wsd.t(), agg_all, wnd.t(), relu=relu, bits_out=True)
+                bits_box.append(bits)
+            else:
+                out = dense.transform_bf16(x_all, wsd.t(), agg_all, wnd.t(), relu=relu)
         else:
             out = dense.mm2_nt(x_all, wsd.t(), agg_all, wnd.t(), relu=relu)
         ctx.relu, ctx.grad_is_gated = relu, grad_is_gated
@@ -770,7 +774,7 @@ class _DistSageInputLayerAll(torch.autograd.Function):
         else:
             gws = dense.grad_weight(x_all, g, out=grad_slot_of(ctx.wparams[0])) if ctx.needs_input_grad[0] else None
             gwn = dense.grad_weight(agg_all, g, out=grad_slot_of(ctx.wparams[1])) if ctx.needs_input_grad[1] else None
-        return gws, gwn, None, None, None, None, None
+        return gws, gwn, None, None, None, None, None, None
 
 
 class _DistSageLayerOnAll(torch.autograd.Function):
@@ -798,13 +802,14 @@ class _DistSageLayerOnAll(torch.autograd.Function):
             out = dense.mm2_nt(h, wsd.t(), agg, wnd.t(), relu=relu)
         ctx.engine, ctx.reduce, ctx.relu = engine, reduce, relu
         ctx.grad_is_gated, ctx.gate_input = grad_is_gated, gate_input
+        ctx.h_bits = fused_layers._bits_of(h_all) if gate_input else None
         ctx.wparams = (ws, wn)
         ctx.save_for_backward(h_all, agg, wsd, wnd, out if relu else None)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        from . import dense
+        from . import dense, fused_layers
 
         h_all, agg, wsd, wnd, out = ctx.saved_tensors
         engine = ctx.engine
@@ -814,7 +819,33 @@ class _DistSageLayerOnAll(torch.autograd.Function):
         if ctx.relu and not ctx.grad_is_gated:
             g = torch.ops.aten.threshold_backward(g, out, 0)
         gh_all = None
-        if ctx.needs_input_grad[0]:
+        # The single-GPU step's backward order (fused_layers.BACKWARD_ORDER, round 5): aggregate first -- gt = merged^T (scale . g), ONE
+        # plain weighted SpMM into own + halo rows (no read-modify-write of the output, no gate operand) -- then the input gradient as
+        # MFMA launches that read the ReLU mask of the layer below as bits: gate(g.Ws^T + gt.Wn^T) on the own rows, gate(gt.Wn^T) on the
+        # halo rows (which have no self path here: their owner adds it).  Replaces (g.Wn^T)/deg, g.Ws^T, an accumulating gated SpMM
+        # over local^T and a gated SpMM over halo^T.
+        agg_first = (fused_layers.BACKWARD_ORDER != "transform-first" and ctx.needs_input_grad[0] and engine._spmm_fn is None
+                     and g.is_cuda and dense._mfma_ok(g) and fused_layers._aligned(g) and wsd.shape[1] <= wsd.shape[0] <= 256
+                     and p.merged is not None and (not ctx.gate_input or h_all.stride(1) == 1))
+        if agg_first:
+            mt = engine.transposed(p.merged)
+            tval = mt.val
+            if ctx.reduce == "mean":
+                scale = p.merged.mean_scale_transposed()
+                tval = scale if tval is None else tval * scale
+            _, gt_all = engine.alloc_rows(p.n_own + p.n_halo, g.shape[1], g.dtype)
+            engine.spmm(mt, g, gt_all, val=tval)
+            _, gh_all = engine.alloc_rows(p.n_own + p.n_halo, h_all.shape[1], h_all.dtype)
+            gate = h_all if ctx.gate_input else None
+            bits = ctx.h_bits
+            dense.transform_bf16(g, wsd, gt_all[:p.n_own], wnd, out=gh_all[:p.n_own],
+                                 out_gate=gate[:p.n_own] if gate is not None else None,
+                                 gate_bits=bits[:p.n_own] if bits is not None else None)
+            if p.n_halo:
+                dense.transform_bf16(gt_all[p.n_own:], wnd, out=gh_all[p.n_own:],
+                                     out_gate=gate[p.n_own:] if gate is not None else None,
+                                     gate_bits=bits[p.n_own:] if bits is not None else None)
+        elif ctx.needs_input_grad[0]:
             inv = p.inv_deg if ctx.reduce == "mean" else None
             if inv is not None and g.is_cuda and dense._mfma_ok(g) and wnd.shape[0] <= 256:
                 gagg = dense.transform_bf16(g, wnd, row_scale=inv)                 # (g.Wn^T) / deg in one kernel
@@ -1280,8 +1311,11 @@ class DistGraph:
                 and self.part.merged is not None and all(fused_layers.can_fuse(layers[i], True) for i in (0, 1))
                 and not layers[0].transform_first(x_local) and layers[1].hidden_dim >= layers[1].input_dim):
             relu0, relu1 = layers[0].activation is not None, layers[1].activation is not None
+            box0 = [] if relu0 else None
             h_all = _DistSageInputLayerAll.apply(layers[0].weight, layers[0].neighborAgg.weight, self, layers[0].aggr_neighbor_method,
-                                                 relu0, relu0, placed_input)          # layer 1 returns its gradient masked
+                                                 relu0, relu0, placed_input, box0)    # layer 1 returns its gradient masked
+            if box0:
+                fused_layers._tag_bits(h_all, box0[0])
             gated1 = bool(len(layers) > 2 and gates[2] and relu1)
             box = [] if relu1 else None
             h = _DistSageLayerOnAll.apply(h_all, layers[1].weight, layers[1].neighborAgg.weight, self,
