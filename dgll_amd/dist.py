@@ -639,6 +639,18 @@ class DistGatAggregate(torch.autograd.Function):
         has_halo = p.n_halo > 0
         _, out = engine.alloc_rows(p.n_own, feat, dtype)
         rowsum = torch.empty((p.n_own, heads), dtype=torch.float32, device=dev)
+        merged = halo_local and p.merged is not None and has_halo
+        if merged:
+            # own and halo rows of h / t sit in ONE buffer (the transform ran on both): ONE pass over the merged adjacency instead of a
+            # pass per column half -- the second of those re-read and re-wrote every output row (numerator, denominator) for the
+            # ~5 remote edges a row has: 551 us next to the local half's 1168 us on a rank of four
+            h_all, t_all = h_view, t_own
+            h_view, halo_h = h_all[:p.n_own], h_all[p.n_own:]
+            s_own, t_own, halo_t = s_own[:p.n_own], t_all[:p.n_own], t_all[p.n_own:]
+            oe.gat_fwd_part(p.merged, h_all, s_own, t_all, out, rowsum, heads, fo, alpha, apply_elu, raw=False, accumulate=False)
+            ctx.engine, ctx.cfg, ctx.halo_local, ctx.merged = engine, (heads, fo, alpha, apply_elu), halo_local, True
+            ctx.save_for_backward(h_all, t_all, s_own, out, rowsum)
+            return out
         if halo_local:
             h_view, halo_h = h_view[:p.n_own], h_view[p.n_own:]
             s_own, t_own, halo_t = s_own[:p.n_own], t_own[:p.n_own], t_own[p.n_own:]
@@ -656,7 +668,7 @@ class DistGatAggregate(torch.autograd.Function):
             engine.join_comm()
         if has_halo:
             oe.gat_fwd_part(p.halo, halo_h, s_own, halo_t, out, rowsum, heads, fo, alpha, apply_elu, raw=False, accumulate=True)
-        ctx.engine, ctx.cfg, ctx.halo_local = engine, (heads, fo, alpha, apply_elu), halo_local
+        ctx.engine, ctx.cfg, ctx.halo_local, ctx.merged = engine, (heads, fo, alpha, apply_elu), halo_local, False
         ctx.save_for_backward(h_view, halo_h, s_own, t_own, halo_t, out, rowsum)
         return out
 
@@ -664,11 +676,25 @@ class DistGatAggregate(torch.autograd.Function):
     def backward(ctx, g):
         from . import ops_edge as oe
 
-        h_view, halo_h, s_own, t_own, halo_t, out, rowsum = ctx.saved_tensors
         engine = ctx.engine
         heads, fo, alpha, apply_elu = ctx.cfg
         p = engine.part
         feat = heads * fo
+        if ctx.merged:      # one rows pass (declared the only launch: exact dd_i) and one transposed pass over merged^T
+            h_all, t_all, s_own, out, rowsum = ctx.saved_tensors
+            dev, dtype = h_all.device, h_all.dtype
+            _, gv = engine.rows_of(g.to(dtype))
+            _, dn = engine.alloc_rows(p.n_own, feat, dtype)
+            dd = torch.empty((p.n_own, heads), dtype=torch.float32, device=dev)
+            grad_s = torch.empty((p.n_own, heads), dtype=torch.float32, device=dev)
+            oe.gat_bwd_rows_part(p.merged, h_all, s_own, t_all, out, gv, rowsum, dn, dd, grad_s, heads, fo, alpha, apply_elu, 3)
+            _, gh_all = engine.alloc_rows(p.n_own + p.n_halo, feat, dtype)
+            gt_all = torch.empty((p.n_own + p.n_halo, heads), dtype=torch.float32, device=dev)
+            gs_all = torch.zeros((p.n_own + p.n_halo, heads), dtype=torch.float32, device=dev)   # a halo node's s is never used here
+            gs_all[:p.n_own] = grad_s
+            oe.gat_bwd_cols_part(engine.transposed(p.merged), dn, h_all, t_all, s_own, dd, gh_all, gt_all, heads, fo, alpha)
+            return gh_all, gs_all, gt_all, None, None, None, None, None, None
+        h_view, halo_h, s_own, t_own, halo_t, out, rowsum = ctx.saved_tensors
         dev, dtype = h_view.device, h_view.dtype
         _, gv = engine.rows_of(g.to(dtype))
         _, dn = engine.alloc_rows(p.n_own, feat, dtype)
@@ -828,13 +854,14 @@ class _DistSageLayerOnAll(torch.autograd.Function):
                      and g.is_cuda and dense._mfma_ok(g) and fused_layers._aligned(g) and wsd.shape[1] <= wsd.shape[0] <= 256
                      and p.merged is not None and (not ctx.gate_input or h_all.stride(1) == 1))
         if agg_first:
-            mt = engine.transposed(p.merged)
-            tval = mt.val
-            if ctx.reduce == "mean":
-                scale = p.merged.mean_scale_transposed()
-                tval = scale if tval is None else tval * scale
+            # two launches, one per column half of A: the halo half's rows are short (a remote node feeds ~3 of this rank's rows) and take
+            # the row-per-slot kernel; one launch over merged^T ran them through the wave-per-row kernel: 815 us against 500 + 300
             _, gt_all = engine.alloc_rows(p.n_own + p.n_halo, g.shape[1], g.dtype)
-            engine.spmm(mt, g, gt_all, val=tval)
+            for half, rows in ((p.local, gt_all[:p.n_own]), (p.halo, gt_all[p.n_own:])):
+                if rows.shape[0] == 0:
+                    continue
+                ht = engine.transposed(half)
+                engine.spmm(ht, g, rows, val=engine.transposed_scale(half, ctx.reduce))
             _, gh_all = engine.alloc_rows(p.n_own + p.n_halo, h_all.shape[1], h_all.dtype)
             gate = h_all if ctx.gate_input else None
             bits = ctx.h_bits
@@ -1158,6 +1185,20 @@ class DistGraph:
     def transposed(self, graph):
         return graph.transpose()[0]
 
+    def transposed_scale(self, half, reduce):
+        """Edge values of half^T for the backward of reduce_A over one column half of this rank's adjacency: 1 / deg(i) of the
+        destination row i each edge came from -- the FULL degree (part.inv_deg), not the half's -- times the half's own values; cached."""
+        key = "_dgll_tscale_" + reduce
+        val = getattr(half, key, None)
+        if val is None:
+            ht = half.transpose()[0]
+            val = ht.val
+            if reduce == "mean":
+                scale = self.part.inv_deg.to(torch.float32)[ht.col.long()]
+                val = scale if val is None else val * scale
+            setattr(half, key, val if val is not None else False)
+        return None if val is False else val
+
     class _Scope:
         def __init__(self, engine):
             self.engine = engine
@@ -1264,14 +1305,12 @@ class DistGraph:
         nn.Convolution.gatconv._fused_heads (mode 0, attention dropout inactive).  halo_local: x holds own AND halo rows
         (statically placed inputs): the transform and the scores are evaluated for both, nothing is exchanged."""
         from . import dense, ops
+        from .nn.Convolution.gatconv import pack_heads
 
         heads, fo = len(Ws), Ws[0].shape[1]
-        h = dense.linear(x, Ws[0] if heads == 1 else torch.cat(Ws, dim=1))
-        A = h.new_zeros(heads * fo, 2 * heads)
-        for k in range(heads):
-            A[k * fo:(k + 1) * fo, k] = a1s[k].to(h.dtype)
-            A[k * fo:(k + 1) * fo, heads + k] = a2s[k].to(h.dtype)
-        st = dense.skinny_linear(h, A)
+        W, A = pack_heads(Ws, a1s, a2s, fo)          # the heads' parameters as two matrices, a handful of launches each way
+        h = dense.linear(x, W)
+        st = dense.skinny_linear(h, A.to(h.dtype))
         fo_pad = ops.head_width_padded(fo, h.dtype)
         hp = h if fo_pad == fo else torch.nn.functional.pad(h.view(-1, heads, fo), (0, fo_pad - fo)).reshape(-1, heads * fo_pad)
         out = DistGatAggregate.apply(hp, st[:, :heads], st[:, heads:], self, heads, fo_pad, alpha, concat, halo_local)

@@ -33,6 +33,98 @@ def _unpad_heads(out, heads, fo, fo_pad):
     return out.view(out.shape[0], heads, fo_pad)[:, :, :fo].reshape(out.shape[0], heads * fo)
 
 
+_PACK_INDEX = {}
+
+
+def _pack_index(heads, fo, fo_pad, device):
+    """(row, column) of every element of the stacked [heads, 2 fo] attention vectors inside the block-diagonal score matrix
+    A [heads * fo_pad, 2 heads]: a1 of head k fills column k, a2 column heads + k, rows k fo_pad .. k fo_pad + fo."""
+    key = (heads, fo, fo_pad, str(device))
+    idx = _PACK_INDEX.get(key)
+    if idx is None:
+        k = F.arange(heads, device=device).repeat_interleave(2 * fo)
+        j = F.arange(2 * fo, device=device).repeat(heads)
+        second = (j >= fo).long()
+        idx = _PACK_INDEX[key] = (k * fo_pad + j - second * fo, k + second * heads)
+    return idx
+
+
+class _PackHeads(F.autograd.Function):
+    """The per-head parameters of a multi-head layer as the two matrices its launches take: W [Fin, heads * fo_pad] (every head's
+    transform side by side, gatconv.py:196's loop as one product) and the block-diagonal A [heads * fo_pad, 2 heads] (every head's
+    a1 | a2: the scores of all heads as one skinny product) -- in a handful of launches forward and backward.  Written op by op
+    (a cat, and two sliced assignments per head, each with its own cast) the assembly and its autograd took ~270 launches of a
+    few microseconds per step: 1.4 of the 29.8 ms of the products-sized SpGAT step, 1.9 of 12.1 ms on a rank of four.
+    Inputs: W_0 .. W_{h-1} [Fin, fo], then the heads' `a` parameters (any shape with 2 fo elements, a1 first).  The gradients are
+    written into the parameters' FlatAdam slots when they have them (one multi-tensor copy per parameter kind)."""
+
+    @staticmethod
+    def forward(ctx, heads, fo, fo_pad, *params):
+        Ws, As = params[:heads], params[heads:]
+        fin = Ws[0].shape[0]
+        W = Ws[0].detach() if heads == 1 else F.cat([w.detach() for w in Ws], dim=1)
+        if fo_pad != fo:
+            W = F.nn.functional.pad(W.reshape(fin, heads, fo), (0, fo_pad - fo)).reshape(fin, heads * fo_pad)
+        av = As[0].detach().reshape(1, -1) if heads == 1 else F.stack([a.detach().reshape(-1) for a in As])
+        A = F.zeros(heads * fo_pad, 2 * heads, dtype=av.dtype, device=av.device)
+        A[_pack_index(heads, fo, fo_pad, av.device)] = av.reshape(-1)
+        ctx.cfg = (heads, fo, fo_pad, fin)
+        ctx.targets = params
+        return W, A
+
+    @staticmethod
+    def backward(ctx, gW, gA):
+        from ...optim import grad_slot_of
+
+        heads, fo, fo_pad, fin = ctx.cfg
+        Ws, As = ctx.targets[:heads], ctx.targets[heads:]
+        outs = [None] * (2 * heads)
+        for base, grads, params in ((0, gW, Ws), (heads, gA, As)):
+            if grads is None or not any(ctx.needs_input_grad[3 + base + k] for k in range(heads)):
+                continue
+            if base == 0:       # [heads, Fin, fo]: every head's gradient a contiguous block
+                per = grads.reshape(fin, heads, fo_pad)[:, :, :fo].permute(1, 0, 2).contiguous()
+            else:
+                per = grads[_pack_index(heads, fo, fo_pad, grads.device)].reshape(heads, 2 * fo)
+            pieces = [per[k].view(params[k].shape) for k in range(heads)]
+            slots = [grad_slot_of(p) if ctx.needs_input_grad[3 + base + k] else None for k, p in enumerate(params)]
+            if all(sl is not None for sl in slots):
+                F._foreach_copy_(slots, pieces)           # one multi-tensor launch into the optimizer's gradient buffer
+                pieces = slots
+            else:
+                pieces = [sl.copy_(pc) if sl is not None else pc for sl, pc in zip(slots, pieces)]
+            for k in range(heads):
+                if ctx.needs_input_grad[3 + base + k]:
+                    outs[base + k] = pieces[k]
+        return (None, None, None) + tuple(outs)
+
+
+def pack_heads(Ws, a1s, a2s, fo_pad):
+    """(W [Fin, heads * fo_pad], A [heads * fo_pad, 2 heads]) of a multi-head layer (see _PackHeads).  a1s / a2s: the halves of every
+    head's `a` as the layers' _split_a() returns them -- views of the parameter, a1 first: the parameter itself is what enters the
+    autograd node (per-view slice backward passes were most of the launches this replaces).  Any other pair is packed op by op."""
+    heads, fo = len(Ws), Ws[0].shape[1]
+    bases = []
+    for a1, a2 in zip(a1s, a2s):
+        b = a1._base
+        ok = (b is not None and a2._base is b and b.numel() == 2 * fo and b.is_contiguous() and a1.stride() == (1,) and a2.stride() == (1,)
+              and a1.storage_offset() == b.storage_offset() and a2.storage_offset() == b.storage_offset() + fo)
+        if not ok:
+            bases = None
+            break
+        bases.append(b)
+    if bases is not None and all(W.shape == Ws[0].shape and W.dtype == Ws[0].dtype for W in Ws):
+        return _PackHeads.apply(heads, fo, fo_pad, *Ws, *bases)
+    if fo_pad != fo:
+        Ws = [F.nn.functional.pad(W, (0, fo_pad - fo)) for W in Ws]
+    W = (Ws[0] if heads == 1 else F.cat(Ws, dim=1))
+    A = a1s[0].new_zeros(heads * fo_pad, 2 * heads)
+    for k in range(heads):
+        A[k * fo_pad:k * fo_pad + fo, k] = a1s[k]
+        A[k * fo_pad:k * fo_pad + fo, heads + k] = a2s[k]
+    return W, A
+
+
 def _attention_dropout(graph, heads, p, training, device):
     """Per-edge, per-head multipliers of F.dropout on the attention weights (gatconv.py:37,132)."""
     if not training or p <= 0.0:
@@ -51,16 +143,11 @@ def _fused_heads(x, adj, Ws, a1s, a2s, alpha, concat, mode, dropout, training):
     fo_pad = ops.head_width_padded(fo, x.dtype, pow2=not strided)
     # The per-head padding is applied to the WEIGHTS (a [Fin, heads*fo_pad] matrix with zero columns), not to the activations:
     # the transform then writes the padded layout directly, with exact zeros, and no [N, heads*fo] matrix is copied.
-    if fo_pad != fo:
-        Ws = [F.nn.functional.pad(W, (0, fo_pad - fo)) for W in Ws]
-    W = (Ws[0] if heads == 1 else F.cat(Ws, dim=1))
-    h = dense.linear(x, W)                                                     # gatconv.py:31,117 for every head at once
     # per-node scores for every head as ONE skinny GEMM: [N, heads*fo_pad] . blockdiag(a1_k | a2_k) -> [N, 2*heads]
     # (the reference forms a[:fo].h_i + a[fo:].h_j per edge from a materialised [2*fo, E] matrix, gatconv.py:122-125)
-    A = h.new_zeros(heads * fo_pad, 2 * heads)
-    for k in range(heads):
-        A[k * fo_pad:k * fo_pad + fo, k] = a1s[k].to(h.dtype)
-        A[k * fo_pad:k * fo_pad + fo, heads + k] = a2s[k].to(h.dtype)
+    W, A = pack_heads(Ws, a1s, a2s, fo_pad)
+    h = dense.linear(x, W)                                                     # gatconv.py:31,117 for every head at once
+    A = A.to(h.dtype)
     if strided and graph.n_rows == graph.n_cols:
         # scores + aggregation as ONE autograd node (ops.gat_layer): the scores' own gradient w.r.t. h rides in the epilogue of
         # the transposed gather pass.  h is this function's own temporary (dense.linear allocates narrow rows on 128-byte

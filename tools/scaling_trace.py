@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Kernel timeline of rank 0's step at world size N (stand-in transport, see tools/scaling_model.py).  usage: scaling_trace.py [N]"""
+"""Kernel timeline of rank 0's step at world size N (stand-in transport, see tools/scaling_model.py).
+usage: scaling_trace.py [N] [sage|gat]      (gat: config 4's partitioned SpGAT step; N = 1 with gat: the single-GPU SpGAT step)"""
 import os
 import sys
 
@@ -12,13 +13,18 @@ from dgll_amd.optim import FlatAdam  # noqa: E402
 from scaling_model import NullExchange  # noqa: E402
 
 world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+workload = sys.argv[2] if len(sys.argv) > 2 else "sage"
 dev = torch.device("cuda:0")
-raw = synth.products_like_graph(dev, seed=0, locality=0.9, exact=True, permute_ids=True)
+raw = synth.products_like_graph(dev, seed=0, locality=0.9, exact=True, permute_ids=True, self_loops=workload == "gat")
 n = raw.n_rows
-perm, bounds = dpart.partition_and_order(raw, world, seed=0)
-full = dreorder.relabel(raw, perm)
+if world > 1:
+    perm, bounds = dpart.partition_and_order(raw, world, seed=0)
+    full = dreorder.relabel(raw, perm)
+else:
+    full, perm = raw.reorder(seed=0)
+    bounds = [0, n]
 del raw
-model = dnn.GraphSage(100, [256, 256, 47], None).to(dev)
+model = (dnn.SpGAT(100, 32, 47, dropout=0.0, alpha=0.2, nheads=8) if workload == "gat" else dnn.GraphSage(100, [256, 256, 47], None)).to(dev)
 params = list(model.parameters())
 opt = FlatAdam(params, lr=1e-3)
 racom = ddist.RaCoM(params, dev, flat=opt)
@@ -32,10 +38,18 @@ labels = torch.randint(0, 47, (part.n_own,), device=dev)
 placed = engine.place_input_halo(x)
 
 
+if world == 1:
+    full.plan(); full.transpose()[0].plan()
+
+
 def step():
     opt.zero_grad(set_to_none=True)
-    out = engine.sage_forward(model, x, placed)
-    loss = ops.cross_entropy(out, labels, reduction="sum", fold_relu=True) * (world / n)
+    if workload == "gat":
+        act = model.forward_activations(x, full) if world == 1 else engine.spgat_forward(model, x, placed, activations=True)
+        loss = ops.cross_entropy(act, labels, reduction="sum") * (world / n)
+    else:
+        out = model.forward_graph(full, x) if world == 1 else engine.sage_forward(model, x, placed)
+        loss = ops.cross_entropy(out, labels, reduction="sum", fold_relu=True) * (world / n)
     loss.backward()
     racom.all_reduce_and_wait()
     opt.step()
