@@ -1310,6 +1310,15 @@ class DistGraph:
         heads, fo = len(Ws), Ws[0].shape[1]
         W, A = pack_heads(Ws, a1s, a2s, fo)          # the heads' parameters as two matrices, a handful of launches each way
         h = dense.linear(x, W)
+        p = self.part
+        if (halo_local and p.merged is not None and p.n_halo > 0 and h.is_cuda and ops.head_width_padded(fo, h.dtype, pow2=False) == fo
+                and h.shape[0] == p.n_own + p.n_halo):
+            # Own and halo rows of h sit in ONE buffer (the transform ran on both): the layer is the single-GPU autograd node over the
+            # rank's merged adjacency (rows = own nodes = its first columns) -- one pass per direction instead of one per column half
+            # (the second of those re-read and re-wrote every output row for the ~5 remote edges a row has), the forward forms t_j from
+            # the gathered rows, and the scores' own gradient w.r.t. h rides in the transposed pass's epilogue instead of a
+            # [rows, 2 heads] x [2 heads, 256] product and an elementwise add over all own + halo rows.  Nothing is exchanged.
+            return ops.gat_layer(p.merged, h, A, heads, alpha, apply_elu=concat, pack_scores=False)
         st = dense.skinny_linear(h, A.to(h.dtype))
         fo_pad = ops.head_width_padded(fo, h.dtype)
         hp = h if fo_pad == fo else torch.nn.functional.pad(h.view(-1, heads, fo), (0, fo_pad - fo)).reshape(-1, heads * fo_pad)

@@ -192,7 +192,7 @@ def _gat_strided_forward(h, s, t, graph, heads, fo, alpha, apply_elu, pack_score
     return h, s, t, out, rowsum, packed
 
 
-def _gat_strided_backward(g, h, s, t, out, rowsum, graph, heads, fo, alpha, apply_elu, packed, attn=None):
+def _gat_strided_backward(g, h, s, t, out, rowsum, graph, heads, fo, alpha, apply_elu, packed, attn=None, rows_first=False):
     """Both backward gather passes (dgll_hip_gat_bwd_rows_strided, _cols_strided).  attn = (a1, a2) fp32 [heads * fo]: the
     scores are S = H.a1, T = H.a2 per head and their contribution to grad_h is added by the second pass's epilogue.
     Returns (grad_h, grad_s, grad_t)."""
@@ -216,9 +216,14 @@ def _gat_strided_backward(g, h, s, t, out, rowsum, graph, heads, fo, alpha, appl
     tag = (heads, fo, str(h.dtype), graph.nnz, "packed" if packed else "")
     wsp = ws.data_ptr() if ws is not None else None
     a1 = a2 = None
+    gs_cols = grad_s
     if attn is not None:
         if graph.n_rows != graph.n_cols:
-            raise ValueError("the score-gradient epilogue needs a square adjacency (grad_S of the rows the transposed pass owns)")
+            # a rectangular adjacency whose rows ARE its first n_rows columns (a rank's merged adjacency, dist.py: own rows, then halo
+            # rows): the transposed pass owns n_cols rows, grad_S exists for the first n_rows of them -- nobody uses a halo node's s here
+            if not rows_first or graph.n_rows > graph.n_cols:
+                raise ValueError("the score-gradient epilogue needs a square adjacency (grad_S of the rows the transposed pass owns)")
+            gs_cols = torch.zeros((graph.n_cols, heads), dtype=torch.float32, device=dev)
         a1, a2 = (v.detach().to(torch.float32).contiguous() for v in attn)
     with torch.cuda.device(dev):
         st = _stream(dev)
@@ -231,12 +236,14 @@ def _gat_strided_backward(g, h, s, t, out, rowsum, graph, heads, fo, alpha, appl
         if end is not None:
             end.record(torch.cuda.current_stream(dev))
         _lib.check(code, "dgll_hip_gat_bwd_rows_strided")
+        if gs_cols is not grad_s:
+            gs_cols[:graph.n_rows].copy_(grad_s)
         end = timer.start(("gat", "bwd_cols") + tag, dev) if timer else None
         code = _lib.lib.dgll_hip_gat_bwd_cols_strided(
             st, t_plan, gt.rowptr.data_ptr(), gt.col.data_ptr(), dn.data_ptr(), dn.stride(0), h.data_ptr(), h.stride(0),
             t.data_ptr(), sd.data_ptr(), sd.stride(0), grad_h.data_ptr(), grad_h.stride(0), grad_t.data_ptr(), _dtype_code(h),
             graph.n_cols, heads, fo, alpha, wsp, ws_bytes, a1.data_ptr() if a1 is not None else None,
-            a2.data_ptr() if a2 is not None else None, grad_s.data_ptr() if a1 is not None else None)
+            a2.data_ptr() if a2 is not None else None, gs_cols.data_ptr() if a1 is not None else None)
         if end is not None:
             end.record(torch.cuda.current_stream(dev))
         _lib.check(code, "dgll_hip_gat_bwd_cols_strided")
@@ -273,14 +280,17 @@ class _GatLayerStrided(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, h, A, graph, heads, fo, alpha, apply_elu, pack_scores):
+        """h: one row per COLUMN of `graph`; a rectangular graph's rows are its first n_rows columns (dist.py's merged adjacency)."""
         from . import dense
 
         h = _ready(h)
+        if h.shape[0] != graph.n_cols or graph.n_rows > graph.n_cols:
+            raise ValueError("gat_layer: h needs one row per column of the adjacency, whose rows are its first columns")
         Ad = A.detach().to(h.dtype)
         st = (dense.transform_bf16(h, Ad.t(), out_dtype=torch.float32) if (dense._mfma_ok(h) and Ad.shape[1] <= 256)
               else dense.mm_nt(h, Ad.t()).float())
         # a2 of every head laid out like a row of h (A is block-diagonal: column heads + k holds a2 of head k in rows k fo .. (k + 1) fo)
-        h, s, t, out, rowsum, packed = _gat_strided_forward(h, st[:, :heads], st[:, heads:], graph, heads, fo, alpha, apply_elu,
+        h, s, t, out, rowsum, packed = _gat_strided_forward(h, st[:graph.n_rows, :heads], st[:, heads:], graph, heads, fo, alpha, apply_elu,
                                                             pack_scores, attn2=Ad[:, heads:].float().sum(1))
         ctx.graph, ctx.cfg, ctx.packed = graph, (heads, fo, float(alpha), int(apply_elu)), packed
         ctx.save_for_backward(h, Ad, s, t, out, rowsum)
@@ -296,13 +306,13 @@ class _GatLayerStrided(torch.autograd.Function):
         a1 = Ad[:, :heads].float().sum(1)
         a2 = Ad[:, heads:].float().sum(1)
         grad_h, grad_s, grad_t = _gat_strided_backward(g, h, s, t, out, rowsum, ctx.graph, heads, fo, alpha, apply_elu, ctx.packed,
-                                                       attn=(a1, a2) if ctx.needs_input_grad[0] else None)
+                                                       attn=(a1, a2) if ctx.needs_input_grad[0] else None, rows_first=True)
         grad_A = None
         if ctx.needs_input_grad[1]:      # dA = H^T . [grad_S | grad_T], columns padded to a 16-byte row for the split-K kernel
             n = 2 * heads
             pad = -n % 8
             gst = torch.zeros((h.shape[0], n + pad), dtype=h.dtype, device=h.device)
-            gst[:, :heads] = grad_s
+            gst[:grad_s.shape[0], :heads] = grad_s
             gst[:, heads:n] = grad_t
             grad_A = dense.grad_weight(h, gst)[:, :n]
         return (grad_h if ctx.needs_input_grad[0] else None), grad_A, None, None, None, None, None, None
