@@ -1296,7 +1296,10 @@ def run_minibatch(args, c):
     _dl.check(_dl.lib.dgll_hip_debug_tune(12, int(args.mb_loader_blocks_per_cu)), "tune")
     if args.mb_dense_kernel == "4wave":
         _dl.check(_dl.lib.dgll_hip_debug_tune(4, 1), "tune")
-    k_threads = args.mb_sampler_threads if args.mb_sampler_threads >= 0 else max(1, min(8, (os.cpu_count() or 4) // 4))
+    # native pool (the default): the workers never take the interpreter lock, so they scale with the cores -- 16 of them draw ~1 600
+    # batches/s at the Reddit shape, well above what the GPU consumes; DGLL_NATIVE_SAMPLER_POOL=0: Python threads (8: more of those ran slower)
+    pool_on = os.environ.get("DGLL_NATIVE_SAMPLER_POOL", "1") != "0"
+    k_threads = args.mb_sampler_threads if args.mb_sampler_threads >= 0 else max(1, min(16 if pool_on else 8, (os.cpu_count() or 4) // 4))
     lock = __import__("threading").Lock()
 
     class TimedSampler(FastNeighborSampler):
@@ -1491,16 +1494,20 @@ def run_minibatch(args, c):
          "parallelism": "single GPU"})
     result.update({"loss": float(loss.detach()), "batches_per_s": steps / elapsed, "gpu_side_ms_per_batch": gpu_ms,
                    "gpu_side_ms_per_batch_p50": pct(0.5), "gpu_side_ms_per_batch_p95": pct(0.95), "gpu_side_ms_per_batch_max": per_batch[-1],
-                   "host_sampler_ms_per_batch": sampler_s / max(steps, 1) * 1e3,
+                   # per batch and sampler thread: the Python-thread path times sample_seeded around its native call; the native pool reports
+                   # its workers' own time per batch (whole epoch)
+                   "host_sampler_ms_per_batch": (getattr(pipe, "pool_stats", None) or {}).get("sample_ms_per_batch", sampler_s / max(steps, 1) * 1e3),
                    "host_sampler_threads": k_threads,
+                   "native_sampler_pool": getattr(pipe, "pool_stats", None) is not None,
                    # where the batch period goes on the host: the consumer thread's own time per batch (issuing ~110 launches through
                    # Python), the loading thread's, and what is left of the period = the consumer waiting for a batch
                    "consumer_host_ms_per_batch": busy_s / max(steps, 1) * 1e3,
                    "loader_host_ms_per_batch": loader_s / max(steps, 1) * 1e3,
                    "launch_tables_from": "%d further batches after the timed window (per-launch HIP events on)" % tail,
                    "loaded_queue_starved_s": pipe.queue._starved,
-                   "sampler_mode": ("per-batch seeds, %d native sampler threads (batch b under random.seed(batch_seed(%d, 0, b)))" % (
-                       k_threads, args.seed)) if k_threads > 0 else "one sequential stream on the interpreter's generator",
+                   "sampler_mode": ("per-batch seeds, %d %s (batch b under random.seed(batch_seed(%d, 0, b)))" % (
+                       k_threads, "native pool threads (csrc/sampler.hip: no interpreter in the producers)" if getattr(pipe, "pool_stats", None)
+                       else "Python threads around the native draw", args.seed)) if k_threads > 0 else "one sequential stream on the interpreter's generator",
                    "outermost_hop_translation": "host" if device_graph is None else "device gather from pinned positions",
                    "consumer_step": ("one HIP graph on padded static block shapes (rows per hop %s, %d of %d timed batches beyond them ran "
                                      "launch by launch) + the optimizer's launch; %d of the timed batches were written IN PLACE into one of %d "

@@ -16,8 +16,11 @@
 // specific; tests/test_sampler.py checks it against the running interpreter and against the goldens.)
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -297,5 +300,213 @@ DGLL_API int dgll_host_translate_neighbors(const int64_t* indptr, const int64_t*
             workers.emplace_back(translate, n_seeds * t / n_threads, n_seeds * (t + 1) / n_threads);
         for (auto& w : workers) w.join();
     }
+    return DGLL_OK;
+}
+
+// ---- native producer: a pool of sampler threads behind one in-order hand-over ---------------------------------------------------
+// MiniBatchPipeline(sampler_threads=K) drew batches on K PYTHON threads: the draw itself ran without the interpreter lock, but every
+// batch's bookkeeping (buffers, prefix sums, narrowing, queue hand-overs) took it, next to the loading and the consuming thread --
+// more than 8 threads made the epoch SLOWER (bench.py, Reddit shape: 782 batches/s at 8 threads, 635 at 16).  Here the K threads
+// are native: a worker claims the next batch index, waits for that batch's slot (batch i uses slot i % n_slots: slots come free in
+// order, so the earliest batch can always proceed), draws the batch under ITS OWN seed -- random.seed((base << 40) | (epoch << 20) |
+// batch), bit for bit what the Python path and the reference's loop draw -- straight into the slot's (pinned, caller-owned) buffers in
+// the layout the loading stage uploads with ONE copy: [seeds | source ids of hop 0 .. L-2 | row pointers of hop 0 .. L-1], plus the
+// outermost hop's neighbour POSITIONS narrowed to 16 / 32 bits.  Python only dequeues finished batches, in order.
+// The buffer offsets are the caller's (they are what its loading stage uses); nothing here touches the GPU or the interpreter.
+constexpr int kPoolMaxHops = 8;
+
+struct dgll_sampler_pool {
+    const int64_t* indptr = nullptr;
+    const int64_t* indices = nullptr;
+    const int64_t* train = nullptr;
+    int64_t n_train = 0, batch_size = 0, n_batches = 0;
+    int n_hops = 0;
+    int64_t fanouts[kPoolMaxHops] = {0}, setsizes[kPoolMaxHops] = {0};
+    uint64_t base_seed = 0, epoch = 0;
+    int64_t off_seeds = 0, off_src[kPoolMaxHops] = {0}, off_ptr[kPoolMaxHops] = {0}, staged_entries = 0;
+    int64_t cap[kPoolMaxHops] = {0};          // upper bound of hop h's edges for a full batch
+    int pos_bytes = 8;
+    struct Slot {
+        int64_t* staged = nullptr;
+        void* pos = nullptr;
+        int state = 0;                        // 0 free, 1 being filled, 2 ready, 3 handed out
+        int64_t batch = -1;
+        int64_t rows[kPoolMaxHops] = {0}, n_src[kPoolMaxHops] = {0};
+        double sample_ms = 0.0;
+    };
+    std::vector<Slot> slots;
+    std::vector<std::thread> workers;
+    std::mutex mu;
+    std::condition_variable cv_free, cv_ready;
+    int64_t next_batch = 0, next_out = 0;
+    bool stop = false;
+    int error = DGLL_OK;
+    std::string error_text;
+};
+
+namespace {
+void pool_worker(dgll_sampler_pool* p) {
+    const int L = p->n_hops;
+    std::vector<std::vector<int64_t>> dst(L), cnt(L);
+    std::vector<int64_t> outer;               // the outermost hop's positions as the draw leaves them (int64), narrowed afterwards
+    int64_t rows_cap = p->batch_size;
+    for (int h = 0; h < L; ++h) {
+        cnt[h].resize((size_t)rows_cap);
+        if (h + 1 < L) dst[h].resize((size_t)p->cap[h]);      // inner hops are translated to ids (the next hop's seeds): dst is scratch
+        rows_cap = p->cap[h];
+    }
+    outer.resize((size_t)p->cap[L - 1]);
+    for (;;) {
+        int64_t i;
+        dgll_sampler_pool::Slot* sl;
+        {
+            std::unique_lock<std::mutex> lk(p->mu);
+            if (p->stop || p->next_batch >= p->n_batches) return;
+            i = p->next_batch++;
+            sl = &p->slots[(size_t)(i % (int64_t)p->slots.size())];
+            p->cv_free.wait(lk, [&] { return p->stop || sl->state == 0; });
+            if (p->stop) return;
+            sl->state = 1;
+            sl->batch = i;
+        }
+        const auto t0 = std::chrono::steady_clock::now();
+        const int64_t first = i * p->batch_size;
+        const int64_t n_seeds = std::min<int64_t>(p->batch_size, p->n_train - first);
+        int64_t* st = sl->staged;
+        std::memcpy(st + p->off_seeds, p->train + first, (size_t)n_seeds * sizeof(int64_t));
+        // random.seed(int): the 32-bit little-endian words of the seed, [0] for 0 (fast_sampler._seed_key)
+        const uint64_t seed = (p->base_seed << 40) | (p->epoch << 20) | (uint64_t)i;
+        uint32_t key[2] = {(uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32)};
+        const int64_t key_len = key[1] ? 2 : 1;
+        int64_t* src[kPoolMaxHops];
+        int64_t* dstp[kPoolMaxHops];
+        int64_t* cntp[kPoolMaxHops];
+        for (int h = 0; h < L; ++h) {
+            src[h] = h + 1 < L ? st + p->off_src[h] : outer.data();
+            dstp[h] = h + 1 < L ? dst[h].data() : outer.data();       // (never written for the deferred outermost hop)
+            cntp[h] = cnt[h].data();
+        }
+        int64_t n_out[kPoolMaxHops] = {0};
+        int code = dgll_host_sample_batch_seeded(key, key_len, p->indptr, p->indices, st + p->off_seeds, n_seeds, p->fanouts, p->setsizes,
+                                                 L, src, dstp, cntp, p->cap, n_out, /*defer_last=*/1, /*max_threads=*/1);
+        if (code == DGLL_OK) {
+            int64_t rows = n_seeds;
+            for (int h = 0; h < L; ++h) {                     // row pointers of hop h: prefix sums of the kept-neighbour counts
+                int64_t* ptr = st + p->off_ptr[h];
+                int64_t acc = 0;
+                ptr[0] = 0;
+                for (int64_t r = 0; r < rows; ++r) { acc += cnt[h][(size_t)r]; ptr[r + 1] = acc; }
+                sl->rows[h] = rows;
+                sl->n_src[h] = n_out[h];
+                rows = n_out[h];
+            }
+            const int64_t n_pos = n_out[L - 1];
+            if (p->pos_bytes == 2) {
+                uint16_t* o = static_cast<uint16_t*>(sl->pos);
+                for (int64_t k = 0; k < n_pos; ++k) o[k] = (uint16_t)outer[(size_t)k];
+            } else if (p->pos_bytes == 4) {
+                uint32_t* o = static_cast<uint32_t*>(sl->pos);
+                for (int64_t k = 0; k < n_pos; ++k) o[k] = (uint32_t)outer[(size_t)k];
+            } else {
+                std::memcpy(sl->pos, outer.data(), (size_t)n_pos * sizeof(int64_t));
+            }
+        }
+        sl->sample_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        {
+            std::lock_guard<std::mutex> lk(p->mu);
+            if (code != DGLL_OK && p->error == DGLL_OK) {
+                p->error = code;
+                p->error_text = dgll_hip_last_error();
+                p->stop = true;
+            }
+            sl->state = 2;
+        }
+        p->cv_ready.notify_all();
+        if (code != DGLL_OK) { p->cv_free.notify_all(); return; }
+    }
+}
+}  // namespace
+
+DGLL_API int dgll_host_sampler_pool_create(dgll_sampler_pool** out, const int64_t* indptr, const int64_t* indices, const int64_t* train_nodes,
+                                           int64_t n_train, int64_t batch_size, const int64_t* fanouts, const int64_t* setsizes, int n_hops,
+                                           uint64_t base_seed, uint64_t epoch, int n_threads, int n_slots, int64_t* const* staged_bufs,
+                                           int64_t staged_entries, int64_t off_seeds, const int64_t* off_src, const int64_t* off_ptr,
+                                           void* const* pos_bufs, int pos_bytes) {
+    DGLL_REQUIRE(out && indptr && indices && (train_nodes || n_train == 0) && fanouts && setsizes && staged_bufs && off_src && off_ptr && pos_bufs,
+                 "NULL argument");
+    DGLL_REQUIRE(n_hops > 0 && n_hops <= kPoolMaxHops && batch_size > 0 && n_train >= 0 && n_threads > 0, "bad size");
+    DGLL_REQUIRE(n_slots >= n_threads + 1, "the pool needs more slots than threads (a finished batch holds its slot until it is released)");
+    DGLL_REQUIRE(pos_bytes == 2 || pos_bytes == 4 || pos_bytes == 8, "positions leave as 2-, 4- or 8-byte integers");
+    DGLL_REQUIRE(base_seed < (1ull << 24) && epoch < (1ull << 20), "base_seed < 2**24 and epoch < 2**20 (the seed is one 64-bit word)");
+    const int64_t n_batches = (n_train + batch_size - 1) / batch_size;
+    DGLL_REQUIRE(n_batches < (1ll << 20), "batch index must stay below 2**20 (fast_sampler.batch_seed)");
+    auto* p = new dgll_sampler_pool();
+    p->indptr = indptr; p->indices = indices; p->train = train_nodes; p->n_train = n_train; p->batch_size = batch_size;
+    p->n_batches = n_batches; p->n_hops = n_hops; p->base_seed = base_seed; p->epoch = epoch;
+    p->off_seeds = off_seeds; p->staged_entries = staged_entries; p->pos_bytes = pos_bytes;
+    int64_t rows = batch_size;
+    for (int h = 0; h < n_hops; ++h) {
+        if (fanouts[h] <= 0) { delete p; dgll::set_error("the pool needs integer fan-outs"); return DGLL_ERR_INVALID; }
+        p->fanouts[h] = fanouts[h]; p->setsizes[h] = setsizes[h];
+        p->off_src[h] = h + 1 < n_hops ? off_src[h] : 0; p->off_ptr[h] = off_ptr[h];
+        p->cap[h] = rows * fanouts[h];
+        // the caller's layout must hold the upper bounds
+        const bool fits = off_ptr[h] + rows + 1 <= staged_entries && (h + 1 == n_hops || off_src[h] + p->cap[h] <= staged_entries);
+        if (!fits || off_seeds + batch_size > staged_entries) { delete p; dgll::set_error("staged buffer layout too small for the upper bounds"); return DGLL_ERR_INVALID; }
+        rows = p->cap[h];
+    }
+    p->slots.resize((size_t)n_slots);
+    for (int k = 0; k < n_slots; ++k) {
+        if (!staged_bufs[k] || !pos_bufs[k]) { delete p; dgll::set_error("NULL slot buffer"); return DGLL_ERR_INVALID; }
+        p->slots[(size_t)k].staged = staged_bufs[k];
+        p->slots[(size_t)k].pos = pos_bufs[k];
+    }
+    for (int t = 0; t < n_threads; ++t) p->workers.emplace_back(pool_worker, p);
+    *out = p;
+    return DGLL_OK;
+}
+
+// The next batch IN ORDER (blocks until it is drawn): 0 = `out` filled (out[0] batch index, out[1] slot, out[2] hops L, out[3 .. 3+L) rows of
+// hop h, out[3+L .. 3+2L) edges of hop h, sample_ms the worker's time for it); 1 = the epoch is over; < 0 = a worker failed (the error text is
+// this thread's dgll_hip_last_error()).  One consumer thread.
+DGLL_API int dgll_host_sampler_pool_next(dgll_sampler_pool* p, int64_t* out, double* sample_ms) {
+    DGLL_REQUIRE(p && out, "NULL argument");
+    std::unique_lock<std::mutex> lk(p->mu);
+    if (p->next_out >= p->n_batches) return 1;
+    auto& sl = p->slots[(size_t)(p->next_out % (int64_t)p->slots.size())];
+    p->cv_ready.wait(lk, [&] { return p->error != DGLL_OK || p->stop || (sl.state == 2 && sl.batch == p->next_out); });
+    if (p->error != DGLL_OK) { dgll::set_error("sampler pool: " + p->error_text); return p->error; }
+    if (!(sl.state == 2 && sl.batch == p->next_out)) return 1;       // stopped before this batch was drawn
+    sl.state = 3;
+    out[0] = sl.batch; out[1] = p->next_out % (int64_t)p->slots.size(); out[2] = p->n_hops;
+    for (int h = 0; h < p->n_hops; ++h) { out[3 + h] = sl.rows[h]; out[3 + p->n_hops + h] = sl.n_src[h]; }
+    if (sample_ms) *sample_ms = sl.sample_ms;
+    p->next_out++;
+    return DGLL_OK;
+}
+
+// The slot's buffers may be overwritten (its upload has completed).
+DGLL_API int dgll_host_sampler_pool_release(dgll_sampler_pool* p, int slot) {
+    DGLL_REQUIRE(p && slot >= 0 && slot < (int)p->slots.size(), "bad slot");
+    {
+        std::lock_guard<std::mutex> lk(p->mu);
+        DGLL_REQUIRE(p->slots[(size_t)slot].state == 3, "slot was not handed out");
+        p->slots[(size_t)slot].state = 0;
+    }
+    p->cv_free.notify_all();
+    return DGLL_OK;
+}
+
+// Stops the workers (a batch in progress is finished first), joins them, frees the pool.  The slot buffers stay the caller's.
+DGLL_API int dgll_host_sampler_pool_destroy(dgll_sampler_pool* p) {
+    if (!p) return DGLL_OK;
+    {
+        std::lock_guard<std::mutex> lk(p->mu);
+        p->stop = true;
+    }
+    p->cv_free.notify_all();
+    p->cv_ready.notify_all();
+    for (auto& w : p->workers) w.join();
+    delete p;
     return DGLL_OK;
 }

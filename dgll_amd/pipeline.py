@@ -179,6 +179,146 @@ class PinnedRing:
             self._free.put((token, event))
 
 
+class _Positions:
+    """Stand-in for the outermost hop's int64 position array when the native sampler pool handed it over already narrowed (only its
+    length is ever asked for: the loading stage uploads the narrowed copy)."""
+
+    def __init__(self, n):
+        self.shape = (int(n),)
+
+    def numel(self):
+        return self.shape[0]
+
+
+class SamplerPool:
+    """K NATIVE sampler threads behind one in-order hand-over (csrc/sampler.hip: dgll_host_sampler_pool_*): every batch is drawn under
+    its own seed -- random.seed(batch_seed(base_seed, epoch, i)): the ids of the reference's loop, of oracle/sampler.py and of the
+    Python-thread path, bit for bit -- straight into one of `n_slots` pinned slot buffers in the loading stage's upload layout.
+    Python only dequeues (`next()`: blocks without the interpreter lock) and gives slots back when their uploads have completed.
+    Replaces MiniBatchPipeline's K Python sampler threads, whose per-batch bookkeeping contended for the interpreter lock with the
+    loading and the consuming thread (more than 8 of them made the epoch slower)."""
+
+    HOLD = 8        # delivered batches whose slots may be waiting for their upload (queue of 2, the loader's batch, uploads in flight)
+
+    def __init__(self, indptr, indices, train_nodes, batch_size, fanouts, base_seed, epoch, n_threads, max_degree):
+        import ctypes as C
+
+        from . import _lib
+        from .sampling.fast_sampler import FastNeighborSampler, _setsize
+
+        self._lib, self._C = _lib, C
+        order = [int(f) for f in reversed(fanouts)]              # sampling order (base_sampler.py:30-58)
+        L = self.L = len(order)
+        self.batch_size, self.order = int(batch_size), order
+        rows = [self.batch_size]
+        for f in order[:-1]:
+            rows.append(rows[-1] * f)
+        self.rows_cap = rows
+        caps = [rows[h] * order[h] for h in range(L)]
+        self.cap_outer = caps[-1]
+        off, o = {"seeds": 0, "src": [], "ptr": []}, rows[0]      # the layout of FastNeighborSampler.sample_seeded(staging=)
+        for h in range(L - 1):
+            off["src"].append(o)
+            o += caps[h]
+        for h in range(L):
+            off["ptr"].append(o)
+            o += rows[h] + 1
+        self.offsets, self.entries = off, o
+        assert o == FastNeighborSampler.staging_entries(batch_size, fanouts)
+        self.pos_dtype = torch.int16 if max_degree < (1 << 15) else (torch.int32 if max_degree < (1 << 31) else torch.int64)
+        self.n_threads = int(n_threads)
+        self.n_slots = self.n_threads + self.HOLD + 2
+        self.staged = [torch.empty(self.entries, dtype=torch.int64, pin_memory=torch.cuda.is_available()) for _ in range(self.n_slots)]
+        self.pos = [torch.empty(self.cap_outer, dtype=self.pos_dtype, pin_memory=torch.cuda.is_available()) for _ in range(self.n_slots)]
+        self._keep = (np.ascontiguousarray(indptr, dtype=np.int64), np.ascontiguousarray(indices, dtype=np.int64),
+                      np.ascontiguousarray(train_nodes.numpy() if isinstance(train_nodes, torch.Tensor) else train_nodes, dtype=np.int64))
+        self.train = torch.from_numpy(self._keep[2])
+        fan = np.array(order, dtype=np.int64)
+        sets = np.array([_setsize(f) for f in order], dtype=np.int64)
+        off_src = np.array(off["src"] + [0], dtype=np.int64)
+        off_ptr = np.array(off["ptr"], dtype=np.int64)
+        sb = (C.c_void_p * self.n_slots)(*[t.data_ptr() for t in self.staged])
+        pb = (C.c_void_p * self.n_slots)(*[t.data_ptr() for t in self.pos])
+        handle = C.c_void_p()
+        _lib.check(_lib.lib.dgll_host_sampler_pool_create(
+            C.byref(handle), self._keep[0].ctypes.data, self._keep[1].ctypes.data, self._keep[2].ctypes.data, len(self._keep[2]),
+            self.batch_size, fan.ctypes.data, sets.ctypes.data, L, int(base_seed), int(epoch), self.n_threads, self.n_slots, sb,
+            self.entries, off["seeds"], off_src.ctypes.data, off_ptr.ctypes.data, pb, self.pos[0].element_size()),
+            "dgll_host_sampler_pool_create")
+        self._handle = handle
+        self._lock = threading.Lock()
+        self._pending = []                 # (slot, [events]) of delivered batches whose uploads were issued
+        self._parts = {}                   # slot -> events released so far (a slot has two buffers: staged and positions)
+        self.delivered = self.released = 0
+        self.sample_ms = 0.0
+
+    def next(self):
+        """(batch index, slot, rows per hop, edges per hop) of the next batch in order, or None at the end of the epoch."""
+        C = self._C
+        out = (C.c_int64 * (3 + 2 * 8))()
+        ms = C.c_double(0.0)
+        self.reap(block=self.delivered - self.released >= self.HOLD)
+        code = self._lib.lib.dgll_host_sampler_pool_next(self._handle, out, C.byref(ms))
+        if code == 1:
+            return None
+        self._lib.check(code, "dgll_host_sampler_pool_next")
+        L = int(out[2])
+        self.delivered += 1
+        self.sample_ms += ms.value
+        return int(out[0]), int(out[1]), [int(out[3 + h]) for h in range(L)], [int(out[3 + L + h]) for h in range(L)]
+
+    def release_part(self, slot, event):
+        """One of the slot's two buffers (staged arrays, positions) was uploaded behind `event` (None: it will not be uploaded)."""
+        with self._lock:
+            got = self._parts.setdefault(slot, [])
+            got.append(event)
+            if len(got) == 2:
+                self._pending.append((slot, [e for e in got if e is not None]))
+                del self._parts[slot]
+
+    def reap(self, block=False):
+        """Give the slots whose uploads have completed back to the workers; block: wait until at least one came back."""
+        while True:
+            with self._lock:
+                keep, done = [], []
+                for slot, events in self._pending:
+                    (done if all(e.query() for e in events) else keep).append((slot, events))
+                self._pending = keep
+                first = keep[0] if keep else None
+            for slot, _ in done:
+                self._lib.check(self._lib.lib.dgll_host_sampler_pool_release(self._handle, slot), "dgll_host_sampler_pool_release")
+                self.released += 1
+            if done or not block:
+                return
+            if first is not None:
+                for e in first[1]:
+                    e.synchronize()
+            else:
+                time.sleep(0.0002)           # the loading stage has not issued the oldest batch's upload yet
+
+    def close(self):
+        if self._handle is not None:
+            self._lib.lib.dgll_host_sampler_pool_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+class _PoolPart:
+    """What the loading stage calls a ring (release(token, event)) for one of the two pinned buffers of a pool slot."""
+
+    def __init__(self, pool):
+        self.pool = pool
+
+    def release(self, token, event=None):
+        if token is not None:
+            self.pool.release_part(token, event)
+
+
 class Batch:
     __slots__ = ("input_nodes", "output_nodes", "subgraphs", "features", "labels", "ready", "step", "last_hop_reduced", "blocks",
                  "static_set")
@@ -291,6 +431,54 @@ class MiniBatchPipeline:
         except BaseException as exc:  # noqa: BLE001
             self._fail(exc)
             handoff.close(0)
+
+    def _pool_applicable(self):
+        dl = self.dataloader
+        s = dl.sampler
+        return (self.sampler_threads > 0 and os.environ.get("DGLL_NATIVE_SAMPLER_POOL", "1") != "0" and self.device_graph is not None
+                and self.load_stream is not None and self.hops == "sampled" and self.cache is not None and self.build_blocks
+                and getattr(s, "defer_last_hop", False) and hasattr(s, "staging_entries") and hasattr(s, "_csr")
+                and all(f is not None for f in s.fanouts) and 0 <= self.base_seed < (1 << 24) and len(dl) < (1 << 20)
+                and len(s.fanouts) <= 8)
+
+    def _sample_pool(self):
+        """Producer stage 1 on the NATIVE sampler pool (SamplerPool): this thread only dequeues finished batches, in order, wraps the
+        slot buffers as the views the loading stage expects and hands them on."""
+        from .sampling.base_sampler import sugbraph
+        from .sampling.fast_sampler import StagedBatch
+
+        pool = self._pool
+        L, off = pool.L, pool.offsets
+        try:
+            while not self._stop.is_set():
+                with rng("sample"):
+                    got = pool.next()
+                if got is None:
+                    break
+                i, slot, rows, n_src = got
+                buf = pool.staged[slot]
+                staged = StagedBatch(slot, buf.numpy(), off)
+                staged.rows = list(rows)
+                subgs = []
+                for h in range(L):
+                    ptr = buf[off["ptr"][h]:off["ptr"][h] + rows[h] + 1]
+                    if h < L - 1:
+                        sg = sugbraph(buf[off["src"][h]:off["src"][h] + n_src[h]], None, ptr)
+                    else:       # the outermost hop: positions, narrowed, in the slot's second buffer; translated on the device
+                        sg = sugbraph(_Positions(n_src[h]), None, ptr, finish=lambda: (_ for _ in ()).throw(
+                            RuntimeError("the native sampler pool hands the outermost hop over for a DEVICE-side translation")))
+                        hop_seeds = buf[off["seeds"]:off["seeds"] + rows[0]] if L == 1 else buf[off["src"][h - 1]:off["src"][h - 1] + rows[h]]
+                        sg.pending_positions = (hop_seeds, None)
+                        sg.positions_compact = (pool.pos[slot][:n_src[h]], slot)
+                    sg.max_degree = pool.order[h]
+                    sg.staged = staged
+                    subgs.insert(0, sg)
+                seeds = pool.train[i * pool.batch_size:i * pool.batch_size + rows[0]]
+                self.sampled.put((i, None, seeds, subgs))
+        except BaseException as exc:  # noqa: BLE001
+            self._fail(exc)
+        finally:
+            self.sampled.put(_DONE)
 
     def _sample_threaded(self):
         """Producer stage 1 in the per-batch-seeded mode: K workers -> OrderedHandoff -> the hand-over queue of the loader."""
@@ -746,7 +934,17 @@ class MiniBatchPipeline:
     def __iter__(self):
         self._error = None
         self._stop.clear()
-        if self.sampler_threads > 0 and self.device_graph is not None and self.load_stream is not None and self._ring is None \
+        self._pool = None
+        if self._pool_applicable():
+            dl = self.dataloader
+            indptr, indices = dl.sampler._csr(dl.Dgraph)
+            max_deg = int((self.device_graph[0][1:] - self.device_graph[0][:-1]).max())
+            n_thr = self.sampler_threads
+            self._pool = SamplerPool(indptr, indices, dl.train_nodes, dl.batch_size, dl.sampler.fanouts, self.base_seed, self.epoch, n_thr, max_deg)
+            self._staging, self._pos_ring, self._ring = _PoolPart(self._pool), _PoolPart(self._pool), None
+            if self.labels is not None and self._labels_dev is None:
+                self._labels_dev = self.labels.to(self.device)
+        elif self.sampler_threads > 0 and self.device_graph is not None and self.load_stream is not None and self._ring is None \
                 and self._pos_ring is None \
                 and getattr(self.dataloader.sampler, "defer_last_hop", False):
             cap = self.dataloader.batch_size
@@ -764,7 +962,8 @@ class MiniBatchPipeline:
                                            stop=self._stop)
                 if self.labels is not None and self._labels_dev is None:
                     self._labels_dev = self.labels.to(self.device)
-        self._thread = threading.Thread(target=self._sample_threaded if self.sampler_threads > 0 else self._sample,
+        self._thread = threading.Thread(target=self._sample_pool if self._pool is not None else
+                                        (self._sample_threaded if self.sampler_threads > 0 else self._sample),
                                         name="dgll-sample-producer", daemon=True)
         self._loader = threading.Thread(target=self._load, name="dgll-feature-loader", daemon=True)
         self._thread.start()
@@ -780,6 +979,11 @@ class MiniBatchPipeline:
                     pass
             self._thread.join()
             self._loader.join()
+            if self._pool is not None:          # stop + join the native workers; the rings of the next epoch are built afresh
+                self.pool_stats = {"threads": self._pool.n_threads, "sample_ms_per_batch": self._pool.sample_ms / max(self._pool.delivered, 1),
+                                   "batches": self._pool.delivered}
+                self._pool.close()
+                self._pool, self._staging, self._pos_ring = None, None, None
         if self._error is not None:
             raise self._error
 

@@ -375,6 +375,29 @@ int dgll_host_sample_batch_seeded(const uint32_t* key, int64_t key_len, const in
                                   int64_t* const* out_src, int64_t* const* out_dst, int64_t* const* out_counts,
                                   const int64_t* capacity, int64_t* n_out, int defer_last, int max_threads);
 
+/* ---- f1 / f2 (host code): a pool of native sampler threads behind one in-order hand-over -- the first of the reference's three
+ * queues (README.md:27-29; buffer_queues.py:22-46's sample_generator) without an interpreter in the producers.  `n_threads` workers
+ * draw the batches of one epoch -- batch i = train_nodes[i * batch_size, (i + 1) * batch_size), under
+ * random.seed((base_seed << 40) | (epoch << 20) | i): exactly dgll_host_sample_batch_seeded's ids (outermost hop left as positions) --
+ * each into slot i % n_slots of caller-owned (pinned) buffers:
+ *   staged_bufs[slot]  int64[staged_entries]: seeds at off_seeds, the source ids of hop h < n_hops - 1 at off_src[h], the row pointers
+ *                      of hop h (rows + 1 prefix sums of the kept-neighbour counts) at off_ptr[h] -- ONE upload for the loading stage;
+ *   pos_bufs[slot]     the outermost hop's neighbour POSITIONS as pos_bytes-byte (2 / 4 / 8) unsigned integers.
+ * fanouts / setsizes in SAMPLING order (the reference's reversed(fanouts)), setsizes as for dgll_host_sample_neighbors.
+ * n_slots >= n_threads + 1; base_seed < 2**24, epoch and the batch count < 2**20 (the seed is one 64-bit word).
+ * _next: the next batch IN ORDER, blocking: 0 = out[0] batch, out[1] slot, out[2] n_hops, out[3 ..) rows per hop, then edges per hop;
+ *        1 = epoch over; < 0 = a worker failed.  ONE consumer thread.   _release: the slot's uploads are complete, it may be rewritten.
+ * _destroy: stops and joins the workers.  Threading: the pool's own; the adjacency arrays are read-only and shared.               */
+typedef struct dgll_sampler_pool dgll_sampler_pool;
+int dgll_host_sampler_pool_create(dgll_sampler_pool** out, const int64_t* indptr, const int64_t* indices, const int64_t* train_nodes,
+                                  int64_t n_train, int64_t batch_size, const int64_t* fanouts, const int64_t* setsizes, int n_hops,
+                                  uint64_t base_seed, uint64_t epoch, int n_threads, int n_slots, int64_t* const* staged_bufs,
+                                  int64_t staged_entries, int64_t off_seeds, const int64_t* off_src, const int64_t* off_ptr,
+                                  void* const* pos_bufs, int pos_bytes);
+int dgll_host_sampler_pool_next(dgll_sampler_pool* pool, int64_t* out, double* sample_ms);
+int dgll_host_sampler_pool_release(dgll_sampler_pool* pool, int slot);
+int dgll_host_sampler_pool_destroy(dgll_sampler_pool* pool);
+
 /* ---- the optimizer step of the training loops as ONE launch (torch.optim.Adam's arithmetic; MQGCN.py:141-144, train_gcn.py:26) --
  * Adam over a flat fp32 parameter buffer: param/grad/exp_avg/exp_avg_sq [n]; `step` = 1, 2, ... (bias corrections formed in double
  * on the host); grad_scale multiplies the gradient first (1 / world_size of the RaCoM average, MQGCN.py:64).  Segments (optional,

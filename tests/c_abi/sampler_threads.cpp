@@ -20,6 +20,7 @@ namespace dgll {
 static thread_local std::string g_err;
 void set_error(const std::string& msg) { g_err = msg; }   // api.hip's definition, restated for the host-only build
 }  // namespace dgll
+extern "C" const char* dgll_hip_last_error(void) { return dgll::g_err.c_str(); }
 
 namespace {
 struct Graph {
@@ -136,6 +137,82 @@ int main() {
         std::memcmp(dst.data(), dst2.data(), n_out * 8) || cnt != cnt2) {
         std::fprintf(stderr, "deferred translation differs from the in-call one\n");
         return 1;
+    }
+    // the native sampler pool (what MiniBatchPipeline runs now): 6 workers, 9 slots, 40 batches of 100 seeds (the last one ragged); a
+    // consumer dequeues in order, checks every batch against the same draw made sequentially, and releases its slot two batches late
+    {
+        const int64_t bs = 100, n_train = 40 * bs - 33, L = (int64_t)fan.size();
+        const int pool_threads = 6, n_slots = 9;
+        std::vector<int64_t> train((size_t)n_train);
+        uint64_t s2 = 7;
+        for (auto& v : train) v = (int64_t)(lcg(s2) % (uint64_t)n);
+        std::vector<int64_t> ss(L), rows_cap(L), capv(L), off_src(L, 0), off_ptr(L);
+        int64_t rows = bs, o = bs;
+        for (int h = 0; h < L; ++h) { ss[h] = setsize(fan[h]); rows_cap[h] = rows; capv[h] = rows * fan[h]; rows = capv[h]; }
+        for (int h = 0; h + 1 < L; ++h) { off_src[h] = o; o += capv[h]; }
+        for (int h = 0; h < L; ++h) { off_ptr[h] = o; o += rows_cap[h] + 1; }
+        const int64_t entries = o;
+        std::vector<std::vector<int64_t>> staged(n_slots, std::vector<int64_t>((size_t)entries, -7));
+        std::vector<std::vector<uint32_t>> pos(n_slots, std::vector<uint32_t>((size_t)capv[L - 1], 0u));
+        std::vector<int64_t*> sb(n_slots);
+        std::vector<void*> pb(n_slots);
+        for (int k = 0; k < n_slots; ++k) { sb[k] = staged[k].data(); pb[k] = pos[k].data(); }
+        dgll_sampler_pool* pool = nullptr;
+        if (dgll_host_sampler_pool_create(&pool, g.indptr.data(), g.indices.data(), train.data(), n_train, bs, fan.data(), ss.data(), (int)L, 3, 1,
+                                          pool_threads, n_slots, sb.data(), entries, 0, off_src.data(), off_ptr.data(), pb.data(), 4) != DGLL_OK) {
+            std::fprintf(stderr, "pool create failed: %s\n", dgll::g_err.c_str());
+            return 2;
+        }
+        std::vector<int> held;
+        int64_t desc[3 + 16];
+        int64_t seen = 0;
+        for (;;) {
+            const int rc = dgll_host_sampler_pool_next(pool, desc, nullptr);
+            if (rc == 1) break;
+            if (rc != DGLL_OK) { std::fprintf(stderr, "pool next failed: %s\n", dgll::g_err.c_str()); return 2; }
+            const int64_t i = desc[0];
+            const int slot = (int)desc[1];
+            if (i != seen || slot != i % n_slots) { std::fprintf(stderr, "pool delivered batch %lld out of order\n", (long long)i); return 1; }
+            const int64_t first = i * bs, ns = std::min<int64_t>(bs, n_train - first);
+            std::vector<int64_t> sd(train.begin() + first, train.begin() + first + ns);
+            BatchOut want_b;
+            const uint64_t seed = (3ull << 40) | (1ull << 20) | (uint64_t)i;
+            {   // the same draw, sequentially, through the plain entry point (two-word key: the seed's low and high half)
+                std::vector<int64_t> cap2(L);
+                int64_t r = ns;
+                want_b.src.assign(L, {}); want_b.dst.assign(L, {}); want_b.cnt.assign(L, {}); want_b.n_out.assign(L, 0);
+                std::vector<int64_t*> ps(L), pd(L), pc(L);
+                for (int h = 0; h < L; ++h) {
+                    want_b.cnt[h].assign(r, 0); cap2[h] = r * fan[h]; want_b.src[h].assign(cap2[h], -1); want_b.dst[h].assign(cap2[h], -1);
+                    ps[h] = want_b.src[h].data(); pd[h] = want_b.dst[h].data(); pc[h] = want_b.cnt[h].data(); r = cap2[h];
+                }
+                const uint32_t key2[2] = {(uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32)};
+                if (dgll_host_sample_batch_seeded(key2, 2, g.indptr.data(), g.indices.data(), sd.data(), ns, fan.data(), ss.data(), (int)L, ps.data(),
+                                                  pd.data(), pc.data(), cap2.data(), want_b.n_out.data(), 1, 1) != DGLL_OK) return 2;
+            }
+            bool ok = std::memcmp(staged[slot].data(), sd.data(), (size_t)ns * 8) == 0;
+            int64_t r = ns;
+            for (int h = 0; h < L && ok; ++h) {
+                ok = desc[3 + h] == r && desc[3 + L + h] == want_b.n_out[h];
+                const int64_t* ptr = staged[slot].data() + off_ptr[h];
+                for (int64_t q = 0; q < r && ok; ++q) ok = ptr[q + 1] - ptr[q] == want_b.cnt[h][(size_t)q];
+                if (h + 1 < L) ok = ok && std::memcmp(staged[slot].data() + off_src[h], want_b.src[h].data(), (size_t)want_b.n_out[h] * 8) == 0;
+                else for (int64_t q = 0; q < want_b.n_out[h] && ok; ++q) ok = (int64_t)pos[slot][(size_t)q] == want_b.src[h][(size_t)q];
+                r = want_b.n_out[h];
+            }
+            if (!ok) { std::fprintf(stderr, "pool batch %lld differs from the sequential draw\n", (long long)i); return 1; }
+            held.push_back(slot);
+            if (held.size() > 2) { if (dgll_host_sampler_pool_release(pool, held.front()) != DGLL_OK) return 2; held.erase(held.begin()); }
+            ++seen;
+        }
+        dgll_host_sampler_pool_destroy(pool);
+        if (seen != 40) { std::fprintf(stderr, "pool delivered %lld of 40 batches\n", (long long)seen); return 1; }
+        // a pool that is destroyed while its workers still wait for slots (the consumer left early) must come down cleanly
+        if (dgll_host_sampler_pool_create(&pool, g.indptr.data(), g.indices.data(), train.data(), n_train, bs, fan.data(), ss.data(), (int)L, 3, 2,
+                                          pool_threads, n_slots, sb.data(), entries, 0, off_src.data(), off_ptr.data(), pb.data(), 4) != DGLL_OK) return 2;
+        if (dgll_host_sampler_pool_next(pool, desc, nullptr) != DGLL_OK) return 2;
+        dgll_host_sampler_pool_destroy(pool);
+        std::printf("sampler_threads: native pool, 40 batches x %d workers over %d slots, in order, equal the sequential draw\n", pool_threads, n_slots);
     }
     std::printf("sampler_threads: %d batches x %d threads equal the sequential draw; %lld edges through the helper threads\n", n_batches,
                 n_threads, (long long)n_out);

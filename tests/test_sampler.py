@@ -274,3 +274,73 @@ def test_staged_batch_holds_the_same_ids_in_one_buffer():
                 assert buf[o:o + len(sg_p.src_nodes())].tolist() == sg_p.src_nodes().tolist()
                 assert st.rows[h + 1] == len(sg_p.src_nodes())
         assert got[0].resolve().tolist() == plain[0].resolve().tolist()
+
+
+@pytest.mark.parametrize("threads", [1, 4])
+def test_native_sampler_pool_delivers_every_batch_in_order_bit_equal_to_the_reference_loop(threads):
+    """dgll_host_sampler_pool_* (pipeline.SamplerPool): K native threads draw the epoch's batches, each under
+    random.seed(batch_seed(base, epoch, i)), into pinned slot buffers in the loading stage's upload layout; Python dequeues them in
+    order.  Every batch -- seeds, the source ids and row pointers of every hop, the outermost hop's neighbours (handed over as
+    positions, here translated on the host) -- equals the reference's loop (oracle/sampler.py = base_sampler.py:45-58 +
+    dgllsampler.py:10-21) under that seed; more batches than slots (slots are reused as they are released), a ragged last batch."""
+    from dgll_amd.pipeline import SamplerPool
+    from dgll_amd.sampling.fast_sampler import batch_seed
+    from oracle import sampler as osampler
+
+    rng = np.random.default_rng(3)
+    n = 3000
+    edges = []
+    for v in range(n):
+        deg = int(min(n - 1, rng.zipf(1.3))) if v % 11 else 0
+        edges.append(rng.choice(n, size=deg, replace=False).tolist())
+    indptr = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum([len(e) for e in edges], out=indptr[1:])
+    indices = np.array([u for e in edges for u in e], dtype=np.int64)
+    fanouts = [6, 3, 9]                                   # the model's order; sampled in reversed order
+    batch, n_batches = 50, 37
+    train = torch.from_numpy(rng.integers(0, n, size=batch * n_batches - 17))
+    max_deg = int(np.diff(indptr).max())
+    pool = SamplerPool(indptr, indices, train, batch, fanouts, base_seed=5, epoch=2, n_threads=threads, max_degree=max_deg)
+    assert pool.n_slots < n_batches and pool.pos_dtype == torch.int16
+    L, off = pool.L, pool.offsets
+    seen = 0
+    try:
+        while True:
+            got = pool.next()
+            if got is None:
+                break
+            i, slot, rows, n_src = got
+            assert i == seen and slot == i % pool.n_slots
+            seeds = train[i * batch:(i + 1) * batch]
+            assert rows[0] == len(seeds)
+            random.seed(batch_seed(5, 2, i))
+            inp, outp, layers = osampler.sample(edges, seeds.tolist(), fanouts)      # layers: outermost first
+            buf = pool.staged[slot]
+            assert buf[off["seeds"]:off["seeds"] + rows[0]].tolist() == outp
+            hop_seeds = outp
+            for h in range(L):
+                src, dst = layers[L - 1 - h]
+                assert n_src[h] == len(src) and rows[h] == len(hop_seeds)
+                ptr = buf[off["ptr"][h]:off["ptr"][h] + rows[h] + 1].numpy()
+                assert ptr[0] == 0 and ptr[-1] == len(src)
+                assert np.repeat(np.array(hop_seeds), np.diff(ptr)).tolist() == dst
+                if h < L - 1:
+                    got_src = buf[off["src"][h]:off["src"][h] + n_src[h]].tolist()
+                else:                # positions inside every seed's adjacency list -> ids
+                    pos = pool.pos[slot][:n_src[h]].numpy().astype(np.int64)
+                    base = np.repeat(indptr[np.array(hop_seeds, dtype=np.int64)], np.diff(ptr))
+                    got_src = indices[base + pos].tolist()
+                assert got_src == src
+                hop_seeds = src
+            assert hop_seeds == inp
+            seen += 1
+            pool.release_part(slot, None)                 # both buffers: nothing to wait for on the host
+            pool.release_part(slot, None)
+        assert seen == n_batches and pool.next() is None and pool.delivered == n_batches
+        pool.reap()
+        assert pool.released == n_batches
+    finally:
+        pool.close()
+    # a layout that cannot hold the upper bounds is refused, and so is a seed that does not fit the 64-bit word
+    with pytest.raises(Exception):
+        SamplerPool(indptr, indices, train, batch, fanouts, base_seed=1 << 24, epoch=0, n_threads=1, max_degree=max_deg)
