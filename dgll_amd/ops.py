@@ -42,9 +42,6 @@ def alloc_features(n_rows, feat, dtype, device, pad_to=8):
     return buf[:, :feat] if ld != feat else buf
 
 
-OUT_PITCH_LINES = __import__("os").environ.get("DGLL_SPMM_OUT_PITCH_LINES", "1") != "0"     # 0: 16-byte pitch as before (A/B)
-
-
 class LaunchTimer:
     """HIP-event timing of individual kernel launches on the stream they are issued on (bench.py's roofline leg).
     Usage: `with LaunchTimer() as t: ...steps...` then t.summary() -> {tag: (count, avg_ms)}."""
@@ -94,14 +91,9 @@ def spmm_raw(graph, x, val=None, reduce="sum", bias=None, relu=False, out_dtype=
         val = val.contiguous()
     out_dtype = x.dtype if out_dtype is None else out_dtype
     if out is None:
-        # rows a little over one cache line (a 100-column bf16 aggregate: 200 bytes) get a pitch of whole 128-byte lines when that costs
-        # at most a third more address space: at a 208-byte pitch every row straddles lines at a different offset and the MFMA transform
-        # that reads it next moved 1.18 x its algorithmic bytes; the pad is never read or written
-        esz = 2 if out_dtype == torch.bfloat16 else 4
-        line = 128 // esz
-        lines = -(-feat // line)
-        pad = line if (OUT_PITCH_LINES and feat > line and feat % line and lines * line * 3 <= feat * 4) else 16 // esz
-        out = alloc_features(graph.n_rows, feat, out_dtype, x.device, pad_to=pad)
+        # (Round 6, measured and dropped: a pitch of whole 128-byte lines for rows a little over one line -- the 100-column bf16
+        # aggregate at 256 instead of 208 bytes: the MFMA transform that reads it 0.614 -> 0.618 ms, the weight gradient 0.440 -> 0.465.)
+        out = alloc_features(graph.n_rows, feat, out_dtype, x.device, pad_to=8 if out_dtype == torch.bfloat16 else 4)
     epi = (_lib.EPI_BIAS if bias is not None else 0) | (_lib.EPI_RELU if relu else 0)
     if bias is not None:
         bias = bias.detach().to(torch.float32).contiguous()

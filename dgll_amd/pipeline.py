@@ -434,7 +434,9 @@ class MiniBatchPipeline:
 
     def _pool_applicable(self):
         dl = self.dataloader
-        s = dl.sampler
+        s = getattr(dl, "sampler", None)
+        if s is None or self.sampler_threads <= 0:
+            return False
         return (self.sampler_threads > 0 and os.environ.get("DGLL_NATIVE_SAMPLER_POOL", "1") != "0" and self.device_graph is not None
                 and self.load_stream is not None and self.hops == "sampled" and self.cache is not None and self.build_blocks
                 and getattr(s, "defer_last_hop", False) and hasattr(s, "staging_entries") and hasattr(s, "_csr")
