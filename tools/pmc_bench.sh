@@ -37,6 +37,6 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
   # would run next to it and read skewed counters -- stop here instead
   if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "pmc_bench.sh: counter pass $grp overran PMC_TIMEOUT (exit $rc): remaining passes skipped" >&2; ls -la $OUT; exit $rc; fi
   f=$(find /tmp/pmc_${TAG}_$tag -name '*counter_collection.csv' | head -1)
-  [ -n "$f" ] && grep -E "Counter_Name|spmm_csr_kernel|spmm_rowslot|spmm_long_finalize|gat2_kernel|gat_long_finalize|gat_fwd_kernel|gat_bwd|gemm_bf16|gradw_" $f > $OUT/pmc_$tag.csv
+  [ -n "$f" ] && grep -E "Counter_Name|spmm_csr_kernel|spmm_csr_flat_kernel|spmm_rowslot|spmm_long_finalize|gat2_kernel|gat_long_finalize|gat_fwd_kernel|gat_bwd|gemm_bf16|gradw_" $f > $OUT/pmc_$tag.csv
 done
 ls -la $OUT
