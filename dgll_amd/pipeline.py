@@ -320,6 +320,13 @@ class _PoolPart:
 
 
 class Batch:
+    """One loaded mini-batch.  CONTRACT for batches written in place (static_set is not None, MiniBatchPipeline.use_static_sets): features,
+    last_hop_reduced, labels, blocks, input_nodes and the subgraphs' _src / indptr are VIEWS of the captured step's input set (and of
+    the loading stage's per-set scratch), not copies.  They are valid from `ready` until the step that consumes the batch has been
+    issued -- GraphedSampledStep.__call__ / .eager record the set's `free` event, and the loading stage rewrites the set behind it,
+    a few batches later.  A consumer that wants to read them afterwards (evaluation, logging, record_access) must copy what it needs
+    BEFORE calling the step, on the stream that waited for `ready`; a consumer that never calls the step on such a batch must record
+    `step.sets[b.static_set].free` itself (GraphedSampledStep._mark_free) or the set is rewritten without waiting for its reads."""
     __slots__ = ("input_nodes", "output_nodes", "subgraphs", "features", "labels", "ready", "step", "last_hop_reduced", "blocks",
                  "static_set")
 
