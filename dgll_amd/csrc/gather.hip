@@ -10,6 +10,10 @@
 // array, 16 bytes per lane, while the hit rows come from HBM; the per-batch miss count is accumulated for the
 // miss-rate log (storage.py:213-220).  HBM/PCIe-bound, no LDS, no MFMA.
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
 
 #include "common.hpp"
 
@@ -310,6 +314,43 @@ __global__ __launch_bounds__(kBlock) void gather_labels_kernel(const int64_t* __
 }
 }  // namespace dgll
 
+// Upload of a pinned (device-visible) host buffer by a KERNEL on the loading stream: 16-byte loads over PCIe, stores to HBM.
+// hipMemcpyAsync does the same through the copy engines -- but when the stream's last command is a not-yet-resolved cross-stream
+// wait (the loading stage waits for the replay that read the input set it is about to overwrite), the call BLOCKED ON THE HOST until
+// that dependency had resolved: 7-19 ms, about once in thirty batches (DGLL_LOADER_STAMPS=1), each time draining the loaded-batch queue
+// behind it.  A kernel is simply ordered behind the wait on the device.  Few workgroups: the link, not the CUs, bounds it.
+__global__ __launch_bounds__(kBlock) void upload_kernel(const char* __restrict__ src, char* __restrict__ dst, size_t bytes) {
+    const size_t vecs = bytes / 16;
+    const uint4* __restrict__ s4 = reinterpret_cast<const uint4*>(src);
+    uint4* __restrict__ d4 = reinterpret_cast<uint4*>(dst);
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < vecs; i += (size_t)gridDim.x * kBlock) d4[i] = s4[i];
+    const size_t tail = vecs * 16;
+    for (size_t i = tail + (size_t)blockIdx.x * kBlock + threadIdx.x; i < bytes; i += (size_t)gridDim.x * kBlock) dst[i] = src[i];
+}
+
+static int upload_async(hipStream_t s, void* dst, const void* src, size_t bytes) {
+    static const bool by_copy_engine = []() { const char* v = std::getenv("DGLL_LOADER_UPLOAD"); return v && std::string(v) == "memcpy"; }();
+    if (bytes == 0) return DGLL_OK;
+    const bool aligned = aligned16(dst) && aligned16(src);
+    bool visible = false;                       // only page-locked, device-mapped host memory may be read by a kernel
+    if (!by_copy_engine && aligned) {
+        hipPointerAttribute_t attr{};
+        if (hipPointerGetAttributes(&attr, src) == hipSuccess) visible = attr.type == hipMemoryTypeHost && attr.devicePointer != nullptr;
+        else (void)hipGetLastError();          // an unregistered (pageable) pointer: clear the error, take the copy engine
+    }
+    if (by_copy_engine || !aligned || !visible) {
+        DGLL_HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s));
+        return DGLL_OK;
+    }
+    const int blocks = (int)std::min<size_t>((bytes / 16 + kBlock - 1) / kBlock + 1, 128);
+    hipPointerAttribute_t attr{};
+    (void)hipPointerGetAttributes(&attr, src);
+    const char* dsrc = static_cast<const char*>(attr.devicePointer ? attr.devicePointer : src);
+    hipLaunchKernelGGL(upload_kernel, dim3(blocks), dim3(kBlock), 0, s, dsrc, static_cast<char*>(dst), bytes);
+    DGLL_HIP_TRY(hipGetLastError());
+    return DGLL_OK;
+}
+
 DGLL_API int dgll_hip_load_sampled_batch(void* stream, const dgll_batch_load* b) {
     DGLL_REQUIRE(b != nullptr, "NULL batch");
     const int L = b->n_hops;
@@ -317,9 +358,25 @@ DGLL_API int dgll_hip_load_sampled_batch(void* stream, const dgll_batch_load* b)
     DGLL_REQUIRE(b->staged_host && b->staged_dev && b->staged_entries > 0, "staging buffer");
     DGLL_REQUIRE(b->n_outer == 0 || (b->pos_host && b->pos_dev && b->ids_out && b->indptr && b->indices), "outermost hop arguments");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    DGLL_HIP_TRY(hipMemcpyAsync(b->staged_dev, b->staged_host, (size_t)b->staged_entries * 8, hipMemcpyHostToDevice, s));
-    if (b->n_outer > 0)
-        DGLL_HIP_TRY(hipMemcpyAsync(b->pos_dev, b->pos_host, (size_t)b->n_outer * (size_t)b->pos_bytes, hipMemcpyHostToDevice, s));
+    // DGLL_LOADER_STAMPS=1 (diagnostics): host time of every enqueue of this call; any that takes more than a millisecond is reported
+    static const bool stamps = std::getenv("DGLL_LOADER_STAMPS") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto stamp = [&](const char* what) {
+        if (!stamps) return;
+        const auto now = std::chrono::steady_clock::now();
+        const double ms = std::chrono::duration<double, std::milli>(now - t_prev).count();
+        if (ms > 1.0) std::fprintf(stderr, "[dgll loader] %s took %.2f ms on the host\n", what, ms);
+        t_prev = now;
+    };
+    // staged_host / pos_host must be pinned, device-visible memory (hipHostMalloc / torch pin_memory): they are read by a kernel
+    int up = upload_async(s, b->staged_dev, b->staged_host, (size_t)b->staged_entries * 8);
+    if (up != DGLL_OK) return up;
+    stamp("upload of the staged arrays");
+    if (b->n_outer > 0) {
+        up = upload_async(s, b->pos_dev, b->pos_host, (size_t)b->n_outer * (size_t)b->pos_bytes);
+        if (up != DGLL_OK) return up;
+    }
+    stamp("upload of the positions");
     const int64_t* st = b->staged_dev;
     const int64_t* ids_of[8];
     ids_of[0] = st + b->seeds_off;
@@ -329,17 +386,20 @@ DGLL_API int dgll_hip_load_sampled_batch(void* stream, const dgll_batch_load* b)
         code = dgll_hip_translate_positions(stream, b->indptr, b->indices, ids_of[L - 1], st + b->ptr_off[L - 1], b->rows[L - 1], b->pos_dev,
                                             b->pos_bytes, b->ids_out);
         if (code != DGLL_OK) return code;
+        stamp("translate launch");
     }
     for (int h = 0; h < L; ++h) {
         if (b->rows[h] <= 0 || !b->feat_out[h]) continue;
         code = dgll_hip_gather_rows_mapped(stream, b->cache, b->ldc, b->host, b->ldh, ids_of[h], b->slot, b->host_map, b->feat_out[h], b->ld_feat,
                                            b->rows[h], b->feat, b->dtype, b->miss_count);
         if (code != DGLL_OK) return code;
+        stamp("gather launch");
     }
     if (b->reduced_out && b->rows[L - 1] > 0) {
         code = dgll_hip_aggregate_rows_mapped(stream, b->cache, b->ldc, b->host, b->ldh, b->ids_out, b->slot, b->host_map, st + b->ptr_off[L - 1],
                                               b->reduced_out, b->ld_reduced, b->rows[L - 1], b->feat, b->dtype, b->reduce, b->miss_count);
         if (code != DGLL_OK) return code;
+        stamp("aggregate launch");
     }
     for (int h = 0; h + 1 < L; ++h) {
         if (!b->rowptr_out[h]) continue;
@@ -353,6 +413,7 @@ DGLL_API int dgll_hip_load_sampled_batch(void* stream, const dgll_batch_load* b)
         hipLaunchKernelGGL(gather_labels_kernel, dim3(blocks), dim3(kBlock), 0, s, b->labels, ids_of[0], b->rows[0], b->labels_out, b->labels_cap,
                            b->label_fill);
     }
+    stamp("row-pointer / label launches");
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "dgll_hip_load_sampled_batch launches");
     return DGLL_OK;

@@ -377,6 +377,7 @@ class MiniBatchPipeline:
         self._error = None
         self._stop = threading.Event()          # set when a stage failed or the consumer left: every producer winds down
         self._static_step = None                # use_static_sets(): batches are written into a captured step's input sets in place
+        self._pool = None                       # the native sampler pool of the running epoch (SamplerPool), when it applies
         self._next_set = 1
         self._native_loader = os.environ.get("DGLL_NATIVE_LOADER", "1") != "0"    # in-place loading through ONE native call per batch
         self.load_seconds, self.load_batches = 0.0, 0
@@ -971,6 +972,16 @@ class MiniBatchPipeline:
                                            stop=self._stop)
                 if self.labels is not None and self._labels_dev is None:
                     self._labels_dev = self.labels.to(self.device)
+        # Three Python threads share the interpreter lock (producer hand-over, loader, consumer) and each drops it around its native
+        # calls; a thread coming back from one waits until the holder next yields -- by default only every 5 ms.  A shorter switch
+        # interval bounds that wait (DGLL_PIPELINE_SWITCH_INTERVAL seconds, 0 = leave the interpreter's setting alone); restored at the end.
+        import sys
+
+        self._old_switch = None
+        want = float(os.environ.get("DGLL_PIPELINE_SWITCH_INTERVAL", "0.0002"))
+        if want > 0 and want < sys.getswitchinterval():
+            self._old_switch = sys.getswitchinterval()
+            sys.setswitchinterval(want)
         self._thread = threading.Thread(target=self._sample_pool if self._pool is not None else
                                         (self._sample_threaded if self.sampler_threads > 0 else self._sample),
                                         name="dgll-sample-producer", daemon=True)
@@ -988,6 +999,9 @@ class MiniBatchPipeline:
                     pass
             self._thread.join()
             self._loader.join()
+            if self._old_switch is not None:
+                sys.setswitchinterval(self._old_switch)
+                self._old_switch = None
             if self._pool is not None:          # stop + join the native workers; the rings of the next epoch are built afresh
                 self.pool_stats = {"threads": self._pool.n_threads, "sample_ms_per_batch": self._pool.sample_ms / max(self._pool.delivered, 1),
                                    "batches": self._pool.delivered}

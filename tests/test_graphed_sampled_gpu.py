@@ -147,14 +147,16 @@ def test_replay_equals_eager_at_a_fan_out_above_128(cuda_device):
             assert float((a - b_).abs().max()) <= 2e-3 * float(b_.abs().max()) + 1e-7
 
 
-@pytest.mark.parametrize("native", [True, False])
-def test_batches_written_in_place_by_the_loading_stage_replay_to_the_same_losses(cuda_device, native):
+@pytest.mark.parametrize("native,pool", [(True, True), (True, False), (False, True)])
+def test_batches_written_in_place_by_the_loading_stage_replay_to_the_same_losses(cuda_device, native, pool, monkeypatch):
     """MiniBatchPipeline.use_static_sets: the loading stage writes a batch's hop features (one cache gather per hop), the outermost
     hop's reduction, the row pointers and the labels straight into one of the captured step's input sets; the consumer replays that
     set's graph without a copy.  Same batches (per-batch seeds), parameters frozen: every in-place replay gives the loss the copy
     path gives for that batch, sets are handed round, and the launch-by-launch form on a static set agrees too."""
     import numpy as np
 
+    # pool: the sampler threads are the native pool (round 6, the default) / Python threads around the native draw (the fallback)
+    monkeypatch.setenv("DGLL_NATIVE_SAMPLER_POOL", "1" if pool else "0")
     from dgll_amd import nn as dnn, ops, synth
     from dgll_amd.cache import GraphCacheServer
     from dgll_amd.data import DGraph
@@ -197,6 +199,7 @@ def test_batches_written_in_place_by_the_loading_stage_replay_to_the_same_losses
     pipe.use_static_sets(step)
     got, used = [], []
     for i, b in enumerate(pipe):
+        assert (pipe._pool is not None) == pool
         assert b.static_set is not None and 1 <= b.static_set <= 4
         used.append(b.static_set)
         if i in (0, n_batches - 1):             # the loaded arrays themselves, against a plain lookup (first and the ragged last batch)
