@@ -228,8 +228,11 @@ class SamplerPool:
         self.pos_dtype = torch.int16 if max_degree < (1 << 15) else (torch.int32 if max_degree < (1 << 31) else torch.int64)
         self.n_threads = int(n_threads)
         self.n_slots = self.n_threads + self.HOLD + 2
-        self.staged = [torch.empty(self.entries, dtype=torch.int64, pin_memory=torch.cuda.is_available()) for _ in range(self.n_slots)]
-        self.pos = [torch.empty(self.cap_outer, dtype=self.pos_dtype, pin_memory=torch.cuda.is_available()) for _ in range(self.n_slots)]
+        # page-locked slots: the loading stage uploads them with a kernel that reads host memory (DGLL_SAMPLER_POOL_PINNED=0, tests:
+        # pageable slots -- dgll_hip_load_sampled_batch detects them and takes the copy engine)
+        pin = torch.cuda.is_available() and os.environ.get("DGLL_SAMPLER_POOL_PINNED", "1") != "0"
+        self.staged = [torch.empty(self.entries, dtype=torch.int64, pin_memory=pin) for _ in range(self.n_slots)]
+        self.pos = [torch.empty(self.cap_outer, dtype=self.pos_dtype, pin_memory=pin) for _ in range(self.n_slots)]
         self._keep = (np.ascontiguousarray(indptr, dtype=np.int64), np.ascontiguousarray(indices, dtype=np.int64),
                       np.ascontiguousarray(train_nodes.numpy() if isinstance(train_nodes, torch.Tensor) else train_nodes, dtype=np.int64))
         self.train = torch.from_numpy(self._keep[2])

@@ -147,7 +147,7 @@ def test_replay_equals_eager_at_a_fan_out_above_128(cuda_device):
             assert float((a - b_).abs().max()) <= 2e-3 * float(b_.abs().max()) + 1e-7
 
 
-@pytest.mark.parametrize("native,pool", [(True, True), (True, False), (False, True)])
+@pytest.mark.parametrize("native,pool", [(True, True), (True, False), (False, True), (True, "pageable")])
 def test_batches_written_in_place_by_the_loading_stage_replay_to_the_same_losses(cuda_device, native, pool, monkeypatch):
     """MiniBatchPipeline.use_static_sets: the loading stage writes a batch's hop features (one cache gather per hop), the outermost
     hop's reduction, the row pointers and the labels straight into one of the captured step's input sets; the consumer replays that
@@ -157,6 +157,10 @@ def test_batches_written_in_place_by_the_loading_stage_replay_to_the_same_losses
 
     # pool: the sampler threads are the native pool (round 6, the default) / Python threads around the native draw (the fallback)
     monkeypatch.setenv("DGLL_NATIVE_SAMPLER_POOL", "1" if pool else "0")
+    # "pageable": the pool's slots are ordinary host memory -- the native loading call must notice (it uploads pinned slots with a kernel
+    # that reads host memory) and take hipMemcpyAsync instead; same batches either way
+    monkeypatch.setenv("DGLL_SAMPLER_POOL_PINNED", "0" if pool == "pageable" else "1")
+    pool = bool(pool)
     from dgll_amd import nn as dnn, ops, synth
     from dgll_amd.cache import GraphCacheServer
     from dgll_amd.data import DGraph
