@@ -456,6 +456,16 @@ class _CrossEntropy(torch.autograd.Function):
             ctx.token.masked = True
         if per_row:
             grad = grad * g.to(grad.dtype).unsqueeze(1)
+        else:
+            c = z.shape[1]
+            c8 = -(-c // 8) * 8
+            if (z.dtype == torch.bfloat16 and not ctx.soft and c <= 512 and z.data_ptr() % 16 == 0 and z.stride(0) % 8 == 0
+                    and z.stride(0) >= c8 and grad.stride(0) >= c8):
+                # loss.hip's vector form (exactly these conditions, xent_impl) stores whole 16-byte vectors: the columns behind the C
+                # classes up to the next multiple of 8 are ZERO.  A consumer that needs the gradient that much wider (a layer computed on
+                # padded rows: gatconv._UnpadOneHead) may re-view this buffer instead of copying it; (columns, storage pointer,
+                # version) -- valid only for this very storage and version, as fused_layers._tag_bits
+                grad._dgll_zero_padding = (c8, grad.data_ptr(), grad._version)
         return grad, None, None, None
 
 
