@@ -34,7 +34,10 @@ class BatchLoad(C.Structure):
                 ("reduced_out", C.c_void_p), ("ld_reduced", C.c_int64), ("reduce", C.c_int),
                 ("ids_out", C.c_void_p),
                 ("rowptr_out", C.c_void_p * 8), ("rowptr_cap", C.c_int64 * 8),
-                ("labels", C.c_void_p), ("labels_out", C.c_void_p), ("labels_cap", C.c_int64), ("label_fill", C.c_int64)]
+                ("labels", C.c_void_p), ("labels_out", C.c_void_p), ("labels_cap", C.c_int64), ("label_fill", C.c_int64),
+                ("stage_map", C.c_void_p), ("stage_rows", C.c_void_p), ("ld_stage", C.c_int64), ("stage_cap", C.c_int64),
+                ("stage_list", C.c_void_p), ("stage_count", C.c_void_p), ("stage_serial", C.c_uint), ("stage_blocks", C.c_int),
+                ("upload_blocks", C.c_int)]
 
 
 class DgllHipError(RuntimeError):

@@ -10,6 +10,7 @@ Mirror of /root/reference/dgll/FeatureCache/storage.py:12-221 without its DGL (N
   * `log_miss_rate` / `get_miss_rate` (storage.py:213-220).
 Host features are kept in pinned memory so the GPU can read them (and `hipMemcpyAsync` them) without staging.
 """
+import os
 import threading
 
 import torch
@@ -19,6 +20,27 @@ from .ranges import rng
 from .ops import _dtype_code
 
 
+# Row pitches (bytes) of the pinned host store and of the HBM cache block; 1 = the rows' natural pitch (the default).  Measured, round 6
+# (tools/probes/pcie_probe.py, tools/probes/row_pitch_ab.sh): rows that start on 128-byte boundaries are gathered over PCIe at 54.5 GB/s
+# against 48.7 at the Reddit pitch of 1204 bytes, and 16-byte pitches put the outermost hop's reduction on 16-byte lanes -- but the
+# PIPELINE did not get faster at the 50 % cache (627-637 against 623-645 batches/s) and lost 10 % with everything cached (727-755
+# against 820-848: the 16-byte-lane reduction keeps four rows in flight per wavefront and takes more of the CUs from the step beside it).
+HOST_ROW_ALIGN = int(os.environ.get("DGLL_HOST_ROW_ALIGN", "1"))
+CACHE_ROW_ALIGN = int(os.environ.get("DGLL_CACHE_ROW_ALIGN", "1"))
+
+
+def _padded_rows(t, align, pin=False):
+    """[n, D] view of a zero-padded buffer whose rows start `align` bytes apart (a plain contiguous copy when they already do)."""
+    esz = t.element_size()
+    row = int(t.shape[1]) * esz
+    if align <= 1 or row % align == 0 or align % esz:
+        return t.contiguous().pin_memory() if pin else t.contiguous()
+    ld = (-(-row // align) * align) // esz
+    store = torch.zeros((int(t.shape[0]), ld), dtype=t.dtype, device=t.device, pin_memory=pin)
+    store[:, :t.shape[1]] = t
+    return store[:, :t.shape[1]]
+
+
 class GraphCacheServer:
     def __init__(self, features, node_num=None, nid_map=None, gpuid=0):
         """features: [N, D] CPU tensor (fp32 or bf16) -- the 'remote server' of storage.py:100-125.  It is pinned here.
@@ -26,7 +48,7 @@ class GraphCacheServer:
         self.gpuid = gpuid
         self.device = torch.device("cuda", gpuid)
         self.node_num = int(features.shape[0] if node_num is None else node_num)
-        self.features = features if features.is_pinned() else features.contiguous().pin_memory()
+        self.features = features if features.is_pinned() else _padded_rows(features, HOST_ROW_ALIGN, pin=True)
         self.nid_map = None if nid_map is None else nid_map.clone().detach().to(self.device)
         self.total_dim = int(features.shape[1])
         self.dims = {"features": self.total_dim}
@@ -143,7 +165,7 @@ class GraphCacheServer:
         cur = torch.cuda.current_stream(self.device)
         slot_map = torch.full((self.node_num,), -1, dtype=torch.int64, device=self.device)
         slot_map[nids] = torch.arange(rows, device=self.device)
-        block = data.to(self.device).contiguous()
+        block = _padded_rows(data.to(self.device), CACHE_ROW_ALIGN)
         flag = torch.zeros(self.node_num, dtype=torch.bool, device=self.device)
         flag[nids] = True
         ready = torch.cuda.Event()
@@ -261,7 +283,10 @@ class GraphCacheServer:
         use_map = cache is not None
         if ready is not None:
             stream.wait_event(ready)
-        counter = torch.zeros(1, dtype=torch.int64, device=self.device) if (self.log and use_map) else None
+        counter = None
+        if self.log and use_map:
+            with torch.cuda.stream(stream):          # zeroed on the stream whose kernels add to it (not on the caller's current stream)
+                counter = torch.zeros(1, dtype=torch.int64, device=self.device)
         return (cache.data_ptr() if use_map else None, cache.stride(0) if use_map else 0, self.features.data_ptr(), self.features.stride(0),
                 slot_map.data_ptr() if use_map else None, self.nid_map.data_ptr() if self.nid_map is not None else None, counter,
                 (slot_map, cache))

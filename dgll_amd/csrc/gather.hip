@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <string>
+#include <type_traits>
 
 #include "common.hpp"
 
@@ -68,6 +69,8 @@ struct AggregateArgs {
     int64_t ldc, ldh, ldo, n_rows;
     int row_bytes, mean;
     unsigned long long* miss_count;
+    // optional: rows of uncached nodes fetched into HBM beforehand (stage_misses below): stage_map[node] = (serial << 32) | staged row
+    const unsigned long long* stage_map; const void* stage_rows; int64_t ld_stage; uint32_t stage_serial, stage_cap;
 };
 
 template <typename T, int VEC> struct AggIO;
@@ -130,8 +133,14 @@ __global__ __launch_bounds__(kBlock) void aggregate_rows_kernel(const AggregateA
                     const int64_t kk = k + u < e ? k + u : e - 1;                    // the tail repeats the last neighbour (not added)
                     const int64_t node = a.idx[kk];
                     const int64_t s = a.slot ? a.slot[node] : -1;
-                    const char* src = (s >= 0) ? static_cast<const char*>(a.cache) + s * a.ldc * esz
-                                               : static_cast<const char*>(a.host) + (a.host_map ? a.host_map[node] : node) * a.ldh * esz;
+                    const char* src;
+                    if (s >= 0) src = static_cast<const char*>(a.cache) + s * a.ldc * esz;
+                    else {                                                           // (wave-uniform: one node per wavefront and slot)
+                        const unsigned long long sv = a.stage_map ? a.stage_map[node] : 0ull;
+                        if ((uint32_t)(sv >> 32) == a.stage_serial && (uint32_t)sv < a.stage_cap)
+                            src = static_cast<const char*>(a.stage_rows) + (int64_t)(uint32_t)sv * a.ld_stage * esz;
+                        else src = static_cast<const char*>(a.host) + (a.host_map ? a.host_map[node] : node) * a.ldh * esz;
+                    }
                     if (c0 == 0 && k + u < e && a.slot && s < 0) ++misses;
 #pragma unroll
                     for (int st = 0; st < STEPS; ++st) {
@@ -157,6 +166,89 @@ __global__ __launch_bounds__(kBlock) void aggregate_rows_kernel(const AggregateA
     if (a.miss_count && lane == 0 && misses) atomicAdd(a.miss_count, misses);
 }
 
+// ---- the misses of the outermost hop, fetched ahead of its reduction -------------------------------------------------------------------
+// aggregate_rows_kernel on a partly cached store mixes two kinds of reads: 98.5 % of its rows come from HBM, 1.5 % over PCIe (Reddit
+// shape, half of the nodes cached) -- and every wavefront that meets a miss sits on its CU for the link's latency.  The kernel then
+// takes as long as the link needs for the misses (0.84 ms for 46 MB), with a chip-filling grid resident next to the training step all
+// that time (the step's kernels ran 30 % slower beside it: tools/minibatch_timeline.py).  Split: (1) list_misses_kernel walks the hop's ids
+// once and gives every DISTINCT uncached node a row of a staging buffer (a claim per node in stage_map: duplicates of a batch cross the
+// link once); (2) stage_rows_kernel copies those rows from the pinned store into HBM with a SMALL grid -- one workgroup per CU already
+// saturates the link (tools/probes/pcie_probe.py); 20 workgroups here, because what slows the training step beside a zero-copy kernel is the
+// DEPTH of its read queue on the link, not the CUs it holds: at 32 workgroups and more (330 KB of reads in flight) the step's own kernels
+// ran 1.4-1.6x longer, at 16-20 hardly (profiles/r06_minibatch_stage_sweep.log); (3) the reduction reads staged rows: HBM only.
+// stage_map entries carry the batch's serial number in their upper half, so the map is never cleared.
+constexpr unsigned long long kStageClaimed = 0xffffffffull, kStageOverflow = 0xfffffffeull;
+
+constexpr int kListPerBlock = 2048;     // ids a workgroup of list_misses_kernel walks: its claims fit an LDS list, ONE counter update per workgroup
+
+__global__ __launch_bounds__(kBlock) void list_misses_kernel(const int64_t* __restrict__ idx, int64_t n, const int64_t* __restrict__ slot,
+                                                             unsigned long long* __restrict__ stage_map, uint32_t serial, uint32_t cap,
+                                                             int64_t* __restrict__ list, unsigned int* __restrict__ count) {
+    // (one atomicAdd per claim on the one counter took 0.2 ms for the 30 k claims of a Reddit batch: same-address atomics serialise)
+    __shared__ int64_t claimed[kListPerBlock];
+    __shared__ unsigned int n_claimed, base;
+    if (threadIdx.x == 0) n_claimed = 0;
+    __syncthreads();
+    const unsigned long long tag = (unsigned long long)serial << 32;
+    const int64_t lo = (int64_t)blockIdx.x * kListPerBlock, hi = lo + kListPerBlock < n ? lo + kListPerBlock : n;
+    for (int64_t k = lo + threadIdx.x; k < hi; k += kBlock) {
+        const int64_t node = idx[k];
+        if (slot[node] >= 0) continue;
+        const unsigned long long cur = __hip_atomic_load(stage_map + node, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((uint32_t)(cur >> 32) == serial) continue;                              // already claimed for this batch
+        if (atomicCAS(stage_map + node, cur, tag | kStageClaimed) != cur) continue;  // somebody else's claim came first
+        claimed[atomicAdd(&n_claimed, 1u)] = node;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) base = n_claimed ? atomicAdd(count, n_claimed) : 0u;
+    __syncthreads();
+    for (unsigned int j = threadIdx.x; j < n_claimed; j += kBlock) {
+        const unsigned int row = base + j;
+        const int64_t node = claimed[j];
+        if (row < cap) list[row] = node;
+        __hip_atomic_store(stage_map + node, tag | (row < cap ? (unsigned long long)row : kStageOverflow), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);                                // past the buffer: that node stays a zero-copy read
+    }
+}
+
+template <int VEC>   // bytes per lane and load: 16 or 4
+__global__ __launch_bounds__(kBlock) void stage_rows_kernel(const char* __restrict__ host, int64_t ldh_bytes, const int64_t* __restrict__ host_map,
+                                                            const int64_t* __restrict__ list, const unsigned int* __restrict__ count,
+                                                            uint32_t cap, char* __restrict__ stage, int64_t lds_bytes, int row_bytes) {
+    typedef typename std::conditional<VEC == 16, uint4, uint32_t>::type raw_t;
+    constexpr int STEPS = VEC == 16 ? 2 : 5, ROWS = 2;      // ROWS rows x STEPS loads of a wavefront in flight (2.5 KB at the Reddit width)
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t n = min(*count, cap);
+    for (int64_t i = ((int64_t)blockIdx.x * kWavesPerBlock + wave) * ROWS; i < n; i += (int64_t)gridDim.x * kWavesPerBlock * ROWS) {
+        const char* src[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const int64_t node = list[i + r < n ? i + r : n - 1];
+            src[r] = host + (host_map ? host_map[node] : node) * ldh_bytes;
+        }
+        for (int c0 = 0; c0 < row_bytes; c0 += STEPS * VEC * kWave) {
+            raw_t v[ROWS][STEPS];
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+                for (int st = 0; st < STEPS; ++st) {
+                    const int off = c0 + (st * kWave + lane) * VEC;
+                    if (off < row_bytes) v[r][st] = *reinterpret_cast<const raw_t*>(src[r] + off);
+                }
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) {
+                if (i + r >= n) continue;
+#pragma unroll
+                for (int st = 0; st < STEPS; ++st) {
+                    const int off = c0 + (st * kWave + lane) * VEC;
+                    if (off < row_bytes) *reinterpret_cast<raw_t*>(stage + (i + r) * lds_bytes + off) = v[r][st];
+                }
+            }
+        }
+    }
+}
+
 }  // namespace dgll
 
 using namespace dgll;
@@ -164,6 +256,12 @@ using namespace dgll;
 static int gather_rows_impl(void* stream, const void* cache, int64_t ldc, const void* host, int64_t ldh,
                             const int64_t* idx, const int64_t* slot, void* out, int64_t ldo, int64_t n, int feat,
                             int dtype, unsigned long long* miss_count, const int64_t* host_map);
+struct MissStage {      // dgll_batch_load's stage_* members
+    unsigned long long* map; void* rows; int64_t ld, cap; int64_t* list; unsigned int* count; uint32_t serial; int blocks;
+};
+static int aggregate_rows_impl(void* stream, const void* cache, int64_t ldc, const void* host, int64_t ldh, const int64_t* idx,
+                               const int64_t* slot, const int64_t* host_map, const int64_t* rowptr, void* out, int64_t ldo, int64_t n_rows,
+                               int feat, int dtype, int reduce, unsigned long long* miss_count, int64_t n_idx, const MissStage* stage);
 
 // dgll_hip_debug_tune(12, n): cap the grids of the feature-loading kernels below at n workgroups per CU (0 = their defaults, 16 and
 // 32).  They are grid-stride loops issued on a mini-batch pipeline's LOADING stream next to the training kernels: a smaller
@@ -318,7 +416,8 @@ __global__ __launch_bounds__(kBlock) void gather_labels_kernel(const int64_t* __
 // hipMemcpyAsync does the same through the copy engines -- but when the stream's last command is a not-yet-resolved cross-stream
 // wait (the loading stage waits for the replay that read the input set it is about to overwrite), the call BLOCKED ON THE HOST until
 // that dependency had resolved: 7-19 ms, about once in thirty batches (DGLL_LOADER_STAMPS=1), each time draining the loaded-batch queue
-// behind it.  A kernel is simply ordered behind the wait on the device.  Few workgroups: the link, not the CUs, bounds it.
+// behind it.  A kernel is simply ordered behind the wait on the device.  Few workgroups (16; DGLL_LOADER_UPLOAD_BLOCKS): the link, not
+// the CUs, bounds it, and a deep queue of reads on the link slows the kernels of the training step beside it (see stage_rows_kernel).
 __global__ __launch_bounds__(kBlock) void upload_kernel(const char* __restrict__ src, char* __restrict__ dst, size_t bytes) {
     const size_t vecs = bytes / 16;
     const uint4* __restrict__ s4 = reinterpret_cast<const uint4*>(src);
@@ -328,7 +427,7 @@ __global__ __launch_bounds__(kBlock) void upload_kernel(const char* __restrict__
     for (size_t i = tail + (size_t)blockIdx.x * kBlock + threadIdx.x; i < bytes; i += (size_t)gridDim.x * kBlock) dst[i] = src[i];
 }
 
-static int upload_async(hipStream_t s, void* dst, const void* src, size_t bytes) {
+static int upload_async(hipStream_t s, void* dst, const void* src, size_t bytes, int blocks_wanted = 0) {
     static const bool by_copy_engine = []() { const char* v = std::getenv("DGLL_LOADER_UPLOAD"); return v && std::string(v) == "memcpy"; }();
     if (bytes == 0) return DGLL_OK;
     const bool aligned = aligned16(dst) && aligned16(src);
@@ -342,7 +441,8 @@ static int upload_async(hipStream_t s, void* dst, const void* src, size_t bytes)
         DGLL_HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s));
         return DGLL_OK;
     }
-    const int blocks = (int)std::min<size_t>((bytes / 16 + kBlock - 1) / kBlock + 1, 128);
+    static const int max_blocks = []() { const char* v = std::getenv("DGLL_LOADER_UPLOAD_BLOCKS"); const int n = v ? std::atoi(v) : 0; return n > 0 ? n : 16; }();
+    const int blocks = (int)std::min<size_t>((bytes / 16 + kBlock - 1) / kBlock + 1, (size_t)(blocks_wanted > 0 ? blocks_wanted : max_blocks));
     hipPointerAttribute_t attr{};
     (void)hipPointerGetAttributes(&attr, src);
     const char* dsrc = static_cast<const char*>(attr.devicePointer ? attr.devicePointer : src);
@@ -369,11 +469,11 @@ DGLL_API int dgll_hip_load_sampled_batch(void* stream, const dgll_batch_load* b)
         t_prev = now;
     };
     // staged_host / pos_host must be pinned, device-visible memory (hipHostMalloc / torch pin_memory): they are read by a kernel
-    int up = upload_async(s, b->staged_dev, b->staged_host, (size_t)b->staged_entries * 8);
+    int up = upload_async(s, b->staged_dev, b->staged_host, (size_t)b->staged_entries * 8, b->upload_blocks);
     if (up != DGLL_OK) return up;
     stamp("upload of the staged arrays");
     if (b->n_outer > 0) {
-        up = upload_async(s, b->pos_dev, b->pos_host, (size_t)b->n_outer * (size_t)b->pos_bytes);
+        up = upload_async(s, b->pos_dev, b->pos_host, (size_t)b->n_outer * (size_t)b->pos_bytes, b->upload_blocks);
         if (up != DGLL_OK) return up;
     }
     stamp("upload of the positions");
@@ -396,8 +496,14 @@ DGLL_API int dgll_hip_load_sampled_batch(void* stream, const dgll_batch_load* b)
         stamp("gather launch");
     }
     if (b->reduced_out && b->rows[L - 1] > 0) {
-        code = dgll_hip_aggregate_rows_mapped(stream, b->cache, b->ldc, b->host, b->ldh, b->ids_out, b->slot, b->host_map, st + b->ptr_off[L - 1],
-                                              b->reduced_out, b->ld_reduced, b->rows[L - 1], b->feat, b->dtype, b->reduce, b->miss_count);
+        MissStage stage{reinterpret_cast<unsigned long long*>(b->stage_map), b->stage_rows, b->ld_stage, b->stage_cap, b->stage_list,
+                        b->stage_count, b->stage_serial, b->stage_blocks};
+        const bool staged = b->stage_map && b->slot && b->n_outer > 0;
+        if (staged) DGLL_REQUIRE(b->stage_rows && b->stage_list && b->stage_count && b->stage_cap > 0 && b->stage_cap < 0xfffffffell &&
+                                 b->stage_serial != 0 && b->ld_stage >= b->feat, "staging of the uncached rows: buffers, capacity, serial");
+        code = aggregate_rows_impl(stream, b->cache, b->ldc, b->host, b->ldh, b->ids_out, b->slot, b->host_map, st + b->ptr_off[L - 1],
+                                   b->reduced_out, b->ld_reduced, b->rows[L - 1], b->feat, b->dtype, b->reduce, b->miss_count, b->n_outer,
+                                   staged ? &stage : nullptr);
         if (code != DGLL_OK) return code;
         stamp("aggregate launch");
     }
@@ -460,6 +566,14 @@ DGLL_API int dgll_hip_aggregate_rows_mapped(void* stream, const void* cache, int
                                             const int64_t* idx, const int64_t* slot, const int64_t* host_map, const int64_t* rowptr,
                                             void* out, int64_t ldo, int64_t n_rows, int feat, int dtype, int reduce,
                                             unsigned long long* miss_count) {
+    return aggregate_rows_impl(stream, cache, ldc, host, ldh, idx, slot, host_map, rowptr, out, ldo, n_rows, feat, dtype, reduce, miss_count, 0,
+                               nullptr);
+}
+
+// n_idx (entries of idx) is needed with a stage only
+static int aggregate_rows_impl(void* stream, const void* cache, int64_t ldc, const void* host, int64_t ldh, const int64_t* idx,
+                               const int64_t* slot, const int64_t* host_map, const int64_t* rowptr, void* out, int64_t ldo, int64_t n_rows,
+                               int feat, int dtype, int reduce, unsigned long long* miss_count, int64_t n_idx, const MissStage* stage) {
     if (n_rows <= 0 || feat <= 0) return DGLL_OK;
     DGLL_REQUIRE(host && idx && rowptr && out, "NULL argument");
     DGLL_REQUIRE(!slot || cache, "a slot map needs a cache matrix");
@@ -474,15 +588,31 @@ DGLL_API int dgll_hip_aggregate_rows_mapped(void* stream, const void* cache, int
     auto ok = [&](const void* p, int64_t ld, int vec) {
         return !p || ((reinterpret_cast<uintptr_t>(p) % vec) == 0 && (ld * esz) % vec == 0);
     };
+    const void* srows = stage ? stage->rows : nullptr;
+    const int64_t lds = stage ? stage->ld : 0;
     // 16-byte lanes when every row of every source starts on a 16-byte boundary (the row's last vector may reach into its padding:
     // pitches are whole vectors), else 4-byte lanes; rows that are not even 4-byte granular are the caller's to fetch and reduce
-    const bool v16 = ok(cache, ldc, 16) && ok(host, ldh, 16) && ok(out, ldo, 16) && (!slot || ldc * esz >= ((a.row_bytes + 15) / 16) * 16) &&
-                     ldh * esz >= ((a.row_bytes + 15) / 16) * 16 && ldo * esz >= ((a.row_bytes + 15) / 16) * 16;
-    const bool v4 = a.row_bytes % 4 == 0 && ok(cache, ldc, 4) && ok(host, ldh, 4) && ok(out, ldo, 4);
+    const int64_t whole = ((a.row_bytes + 15) / 16) * 16;
+    const bool v16 = ok(cache, ldc, 16) && ok(host, ldh, 16) && ok(out, ldo, 16) && ok(srows, lds, 16) && (!slot || ldc * esz >= whole) &&
+                     ldh * esz >= whole && ldo * esz >= whole && (!stage || lds * esz >= whole);
+    const bool v4 = a.row_bytes % 4 == 0 && ok(cache, ldc, 4) && ok(host, ldh, 4) && ok(out, ldo, 4) && ok(srows, lds, 4);
     DGLL_REQUIRE(v16 || v4, "rows must be at least 4-byte granular (even bf16 width, 4-byte aligned pitches)");
-    if (v16) a.row_bytes = ((a.row_bytes + 15) / 16) * 16;       // whole vectors: the padding columns are summed and written too
-    const int64_t blocks = std::min<int64_t>((n_rows + kWavesPerBlock - 1) / kWavesPerBlock, 256 * (g_tune_loader_blocks_per_cu > 0 ? g_tune_loader_blocks_per_cu : 32));
+    if (v16) a.row_bytes = (int)whole;       // whole vectors: the padding columns are summed and written too
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (stage) {
+        a.stage_map = stage->map; a.stage_rows = stage->rows; a.ld_stage = stage->ld; a.stage_serial = stage->serial;
+        a.stage_cap = (uint32_t)stage->cap;
+        DGLL_HIP_TRY(hipMemsetAsync(stage->count, 0, sizeof(unsigned int), s));
+        const int64_t lb = (n_idx + kListPerBlock - 1) / kListPerBlock;
+        hipLaunchKernelGGL(list_misses_kernel, dim3((uint32_t)lb), dim3(kBlock), 0, s, idx, n_idx, slot, stage->map, stage->serial, (uint32_t)stage->cap,
+                           stage->list, stage->count);
+        const int sb = stage->blocks > 0 ? stage->blocks : 20;
+        if (v16) hipLaunchKernelGGL(stage_rows_kernel<16>, dim3(sb), dim3(kBlock), 0, s, static_cast<const char*>(host), ldh * esz, host_map,
+                                    stage->list, stage->count, (uint32_t)stage->cap, static_cast<char*>(stage->rows), lds * esz, a.row_bytes);
+        else hipLaunchKernelGGL(stage_rows_kernel<4>, dim3(sb), dim3(kBlock), 0, s, static_cast<const char*>(host), ldh * esz, host_map,
+                                stage->list, stage->count, (uint32_t)stage->cap, static_cast<char*>(stage->rows), lds * esz, a.row_bytes);
+    }
+    const int64_t blocks = std::min<int64_t>((n_rows + kWavesPerBlock - 1) / kWavesPerBlock, 256 * (g_tune_loader_blocks_per_cu > 0 ? g_tune_loader_blocks_per_cu : 32));
     if (dtype == DGLL_BF16) {
         if (v16) hipLaunchKernelGGL((aggregate_rows_kernel<bf16_t, 16>), dim3((uint32_t)blocks), dim3(kBlock), 0, s, a);
         else hipLaunchKernelGGL((aggregate_rows_kernel<bf16_t, 4>), dim3((uint32_t)blocks), dim3(kBlock), 0, s, a);

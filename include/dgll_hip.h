@@ -342,6 +342,16 @@ typedef struct dgll_batch_load {
     int64_t* ids_out;
     int64_t* rowptr_out[8]; int64_t rowptr_cap[8];
     const int64_t* labels; int64_t* labels_out; int64_t labels_cap; int64_t label_fill;
+    /* Optional (stage_map NULL, or no slot map: the uncached rows of the outermost hop are read zero-copy by its reduction): fetch them
+     * into HBM first -- every DISTINCT uncached node of the hop once, by a small grid that the link, not the CUs, bounds -- so that the
+     * reduction reads HBM only and does not hold the chip while it waits for PCIe.  stage_map: int64[n_nodes] scratch of ONE loading
+     * stream, zero-initialised once, never cleared (entries carry stage_serial, which the caller advances per call, never 0);
+     * stage_rows: [stage_cap, ld_stage] elements of the store's dtype; stage_list: int64[stage_cap]; stage_count: one device word.
+     * Nodes past stage_cap stay zero-copy reads.  stage_blocks: workgroups of the fetch (0 = 20).                                    */
+    int64_t* stage_map; void* stage_rows; int64_t ld_stage; int64_t stage_cap; int64_t* stage_list; unsigned int* stage_count;
+    unsigned int stage_serial; int stage_blocks;
+    int upload_blocks;      /* workgroups of the two uploads (0 = 16, DGLL_LOADER_UPLOAD_BLOCKS): few beside staged misses, more (128) when
+                             * nothing else uses the link                                                                          */
 } dgll_batch_load;
 int dgll_hip_load_sampled_batch(void* stream, const dgll_batch_load* batch);
 

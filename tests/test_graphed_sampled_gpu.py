@@ -224,6 +224,81 @@ def test_batches_written_in_place_by_the_loading_stage_replay_to_the_same_losses
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("streams,cap", [(1, 0), (2, 0), (1, 9)])
+def test_staged_misses_give_the_zero_copy_reduction_bit_for_bit(cuda_device, streams, cap, monkeypatch):
+    """csrc/gather.hip: list_misses_kernel + stage_rows_kernel fetch the outermost hop's DISTINCT uncached rows into HBM, the reduction
+    then reads them there.  Same rows in the same order: every batch's reduced rows equal the zero-copy form's bit for bit -- on one
+    loading stream and two alternating ones, and with a staging buffer of 9 rows (nodes past it stay zero-copy reads)."""
+    import numpy as np
+
+    from dgll_amd import nn as dnn, pipeline as pl, synth
+    from dgll_amd.cache import GraphCacheServer
+    from dgll_amd.data import DGraph
+    from dgll_amd.dataloader import DataLoader
+    from dgll_amd.graphs import GraphedSampledStep
+    from dgll_amd.optim import FlatAdam
+    from dgll_amd.sampling import FastNeighborSampler
+
+    dev = cuda_device
+    nodes, feats, classes, batch, fanouts = 12000, 50, 5, 64, [5, 3, 4]
+    g = synth.products_like_graph(dev, seed=2, n=nodes, n_undirected=nodes * 10, locality=0.0, exact=True)
+    indptr, indices = g.rowptr.cpu().numpy(), g.col.cpu().numpy().astype(np.int64)
+    x = torch.randn(nodes, feats, generator=torch.Generator().manual_seed(0)).to(torch.bfloat16)
+    labels = torch.randint(0, classes, (nodes,), generator=torch.Generator().manual_seed(1))
+    dg = DGraph.from_csr(indptr, indices, labels=labels, features=x)
+    cache = GraphCacheServer(x, gpuid=dev.index or 0)
+    cache.auto_cache(g.degrees().cpu(), capacity=nodes // 3)           # most draws of a low-degree graph miss: thousands per batch
+    cache.log = True
+    train = torch.randperm(nodes, generator=torch.Generator().manual_seed(2))[:9 * batch - 11]
+    torch.manual_seed(3)
+    model = dnn.GraphSage(feats, [16, 16, classes], fanouts).to(dev)
+    opt = FlatAdam(list(model.parameters()), lr=0.0)
+    dgraph = (torch.from_numpy(indptr).to(dev), torch.from_numpy(indices).to(dev))
+    step = GraphedSampledStep(model, opt, batch, fanouts, feats, classes, device=dev, n_sets=5)
+
+    def run(stage):
+        monkeypatch.setattr(pl, "STAGE_MISSES", stage)
+        monkeypatch.setattr(pl, "STAGE_CAP", cap)
+        monkeypatch.setenv("DGLL_LOADER_STREAMS", str(streams))
+        loader = DataLoader(dg, train, FastNeighborSampler(fanouts, defer_last_hop=True), batch_size=batch)
+        pipe = pl.MiniBatchPipeline(loader, cache=cache, labels=labels, queue_size=2, device=dev, hops="sampled", reduce_last_hop="mean",
+                                    sampler_threads=2, base_seed=5, epoch=0, device_graph=dgraph, build_blocks=True)
+        assert len(pipe._load_streams) == streams
+        pipe.use_static_sets(step)
+        out, losses = [], []
+        for b in pipe:
+            assert b.static_set is not None
+            torch.cuda.current_stream().wait_event(b.ready)
+            out.append((b.last_hop_reduced.clone(), b.input_nodes.clone()))
+            losses.append(float(step(b)))
+        torch.cuda.synchronize()
+        stages = getattr(pipe, "_miss_stages", {})
+        assert (len(stages) == streams) == stage
+        for sg in stages.values():
+            assert sg["cap"] == (cap or min(nodes - nodes // 3, batch * 5 * 3 * 4)) and sg["serial"] >= 9 // streams
+        return out, losses, stages, cache.get_miss_rate()
+
+    plain, plain_losses, _, plain_rate = run(False)
+    staged, staged_losses, stages, staged_rate = run(True)
+    assert len(plain) == len(staged) == 9
+    for (a, ids_a), (b_, ids_b) in zip(plain, staged):
+        assert torch.equal(ids_a, ids_b) and torch.equal(a, b_)
+    assert staged_losses == plain_losses
+    assert staged_rate == pytest.approx(plain_rate) and plain_rate > 0.05         # the miss log counts draws, staged or not
+    # the last batch of a stream: its distinct uncached nodes, each listed once
+    sg = next(iter(stages.values()))
+    count = int(sg["count"][0])
+    slot = cache.localid2cacheid
+    last_ids = staged[-1][1] if streams == 1 else None
+    if last_ids is not None:
+        distinct = torch.unique(last_ids[slot[last_ids] < 0])
+        assert count == int(distinct.numel())
+        listed = sg["list"][:min(count, sg["cap"])]
+        assert int(torch.unique(listed).numel()) == int(listed.numel()) and bool(torch.isin(listed, distinct).all())
+        rows = sg["rows"][:int(listed.numel()), :feats]
+        assert torch.equal(rows.cpu(), x[listed.cpu()])
+
+
 def test_sampled_step_gradients_written_in_place_equal_the_merged_ones(cuda_device):
     """ops.row_slices hands its consumers rows of ONE gradient buffer (the block's expand launch adds / writes there, the
     transform's self-path product writes there): the sampled step's parameter gradients equal the ones of the same step with that
