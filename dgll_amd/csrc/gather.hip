@@ -30,6 +30,8 @@ struct GatherArgs {
     int row_bytes;          // bytes actually copied per row
     unsigned long long* miss_count;   // optional
     const int64_t* host_map; // optional [n_nodes]: row of `host` that holds node i (local -> full-graph id, storage.py:27)
+    // optional: rows of uncached nodes fetched into HBM beforehand (stage_rows_kernel below): stage_map[node] = (serial << 32) | staged row
+    const unsigned long long* stage_map; const void* stage_rows; int64_t ld_stage; uint32_t stage_serial, stage_cap;
 };
 
 template <int VEC>  // bytes per lane per step: 16, 4 or 2
@@ -41,8 +43,14 @@ __global__ __launch_bounds__(kBlock) void gather_rows_kernel(const GatherArgs a,
     for (int64_t i = (int64_t)blockIdx.x * kWavesPerBlock + wave; i < a.n; i += (int64_t)gridDim.x * kWavesPerBlock) {
         const int64_t node = a.idx[i];
         const int64_t s = a.slot ? a.slot[node] : -1;
-        const char* src = (s >= 0) ? static_cast<const char*>(a.cache) + s * a.ldc * esz
-                                   : static_cast<const char*>(a.host) + (a.host_map ? a.host_map[node] : node) * a.ldh * esz;
+        const char* src;
+        if (s >= 0) src = static_cast<const char*>(a.cache) + s * a.ldc * esz;
+        else {
+            const unsigned long long sv = a.stage_map ? a.stage_map[node] : 0ull;
+            if ((uint32_t)(sv >> 32) == a.stage_serial && (uint32_t)sv < a.stage_cap)
+                src = static_cast<const char*>(a.stage_rows) + (int64_t)(uint32_t)sv * a.ld_stage * esz;
+            else src = static_cast<const char*>(a.host) + (a.host_map ? a.host_map[node] : node) * a.ldh * esz;
+        }
         char* dst = static_cast<char*>(a.out) + i * a.ldo * esz;
         misses += (a.slot && s < 0) ? 1 : 0;
         for (int st = 0; st < steps; ++st) {
@@ -253,15 +261,19 @@ __global__ __launch_bounds__(kBlock) void stage_rows_kernel(const char* __restri
 
 using namespace dgll;
 
+struct MissStage;
 static int gather_rows_impl(void* stream, const void* cache, int64_t ldc, const void* host, int64_t ldh,
                             const int64_t* idx, const int64_t* slot, void* out, int64_t ldo, int64_t n, int feat,
-                            int dtype, unsigned long long* miss_count, const int64_t* host_map);
+                            int dtype, unsigned long long* miss_count, const int64_t* host_map, const MissStage* stage = nullptr);
 struct MissStage {      // dgll_batch_load's stage_* members
     unsigned long long* map; void* rows; int64_t ld, cap; int64_t* list; unsigned int* count; uint32_t serial; int blocks;
 };
 static int aggregate_rows_impl(void* stream, const void* cache, int64_t ldc, const void* host, int64_t ldh, const int64_t* idx,
                                const int64_t* slot, const int64_t* host_map, const int64_t* rowptr, void* out, int64_t ldo, int64_t n_rows,
-                               int feat, int dtype, int reduce, unsigned long long* miss_count, int64_t n_idx, const MissStage* stage);
+                               int feat, int dtype, int reduce, unsigned long long* miss_count, const MissStage* stage);
+// list_misses_kernel over every id list, then stage_rows_kernel; *usable = false (nothing launched) when the rows are not 4-byte granular
+static int stage_misses(hipStream_t s, const MissStage& stage, const void* host, int64_t ldh, const int64_t* host_map, const int64_t* slot,
+                        int feat, int dtype, const int64_t* const* lists, const int64_t* counts, int n_lists, bool* usable);
 
 // dgll_hip_debug_tune(12, n): cap the grids of the feature-loading kernels below at n workgroups per CU (0 = their defaults, 16 and
 // 32).  They are grid-stride loops issued on a mini-batch pipeline's LOADING stream next to the training kernels: a smaller
@@ -488,21 +500,31 @@ DGLL_API int dgll_hip_load_sampled_batch(void* stream, const dgll_batch_load* b)
         if (code != DGLL_OK) return code;
         stamp("translate launch");
     }
+    // the uncached rows of every hop of the batch, each distinct node once, into HBM ahead of the gathers and the reduction
+    MissStage stage{reinterpret_cast<unsigned long long*>(b->stage_map), b->stage_rows, b->ld_stage, b->stage_cap, b->stage_list,
+                    b->stage_count, b->stage_serial, b->stage_blocks};
+    bool staged = b->stage_map && b->slot;
+    if (staged) {
+        DGLL_REQUIRE(b->stage_rows && b->stage_list && b->stage_count && b->stage_cap > 0 && b->stage_cap < 0xfffffffell &&
+                     b->stage_serial != 0 && b->ld_stage >= b->feat, "staging of the uncached rows: buffers, capacity, serial");
+        const int64_t* lists[9]; int64_t counts[9]; int n_lists = 0;
+        for (int h = 0; h < L; ++h)
+            if (b->rows[h] > 0 && b->feat_out[h]) { lists[n_lists] = ids_of[h]; counts[n_lists++] = b->rows[h]; }
+        if (b->reduced_out && b->rows[L - 1] > 0 && b->n_outer > 0) { lists[n_lists] = b->ids_out; counts[n_lists++] = b->n_outer; }
+        code = stage_misses(s, stage, b->host, b->ldh, b->host_map, b->slot, b->feat, b->dtype, lists, counts, n_lists, &staged);
+        if (code != DGLL_OK) return code;
+        stamp("staging launches");
+    }
     for (int h = 0; h < L; ++h) {
         if (b->rows[h] <= 0 || !b->feat_out[h]) continue;
-        code = dgll_hip_gather_rows_mapped(stream, b->cache, b->ldc, b->host, b->ldh, ids_of[h], b->slot, b->host_map, b->feat_out[h], b->ld_feat,
-                                           b->rows[h], b->feat, b->dtype, b->miss_count);
+        code = gather_rows_impl(stream, b->cache, b->ldc, b->host, b->ldh, ids_of[h], b->slot, b->feat_out[h], b->ld_feat, b->rows[h], b->feat,
+                                b->dtype, b->miss_count, b->host_map, staged ? &stage : nullptr);
         if (code != DGLL_OK) return code;
         stamp("gather launch");
     }
     if (b->reduced_out && b->rows[L - 1] > 0) {
-        MissStage stage{reinterpret_cast<unsigned long long*>(b->stage_map), b->stage_rows, b->ld_stage, b->stage_cap, b->stage_list,
-                        b->stage_count, b->stage_serial, b->stage_blocks};
-        const bool staged = b->stage_map && b->slot && b->n_outer > 0;
-        if (staged) DGLL_REQUIRE(b->stage_rows && b->stage_list && b->stage_count && b->stage_cap > 0 && b->stage_cap < 0xfffffffell &&
-                                 b->stage_serial != 0 && b->ld_stage >= b->feat, "staging of the uncached rows: buffers, capacity, serial");
         code = aggregate_rows_impl(stream, b->cache, b->ldc, b->host, b->ldh, b->ids_out, b->slot, b->host_map, st + b->ptr_off[L - 1],
-                                   b->reduced_out, b->ld_reduced, b->rows[L - 1], b->feat, b->dtype, b->reduce, b->miss_count, b->n_outer,
+                                   b->reduced_out, b->ld_reduced, b->rows[L - 1], b->feat, b->dtype, b->reduce, b->miss_count,
                                    staged ? &stage : nullptr);
         if (code != DGLL_OK) return code;
         stamp("aggregate launch");
@@ -537,9 +559,33 @@ DGLL_API int dgll_hip_gather_rows_mapped(void* stream, const void* cache, int64_
     return gather_rows_impl(stream, cache, ldc, host, ldh, idx, slot, out, ldo, n, feat, dtype, miss_count, host_map);
 }
 
+static int stage_misses(hipStream_t s, const MissStage& stage, const void* host, int64_t ldh, const int64_t* host_map, const int64_t* slot,
+                        int feat, int dtype, const int64_t* const* lists, const int64_t* counts, int n_lists, bool* usable) {
+    const int esz = dtype == DGLL_BF16 ? 2 : 4;
+    const int64_t row_bytes = (int64_t)feat * esz, whole = ((row_bytes + 15) / 16) * 16;
+    auto ok = [&](const void* p, int64_t ld, int vec) { return (reinterpret_cast<uintptr_t>(p) % vec) == 0 && (ld * esz) % vec == 0; };
+    const bool v16 = ok(host, ldh, 16) && ok(stage.rows, stage.ld, 16) && ldh * esz >= whole && stage.ld * esz >= whole;
+    const bool v4 = row_bytes % 4 == 0 && ok(host, ldh, 4) && ok(stage.rows, stage.ld, 4);
+    *usable = v16 || v4;
+    if (!*usable || n_lists == 0) { *usable = *usable && n_lists > 0; return DGLL_OK; }
+    DGLL_HIP_TRY(hipMemsetAsync(stage.count, 0, sizeof(unsigned int), s));
+    for (int i = 0; i < n_lists; ++i) {
+        const int64_t lb = (counts[i] + kListPerBlock - 1) / kListPerBlock;
+        hipLaunchKernelGGL(list_misses_kernel, dim3((uint32_t)lb), dim3(kBlock), 0, s, lists[i], counts[i], slot, stage.map, stage.serial,
+                           (uint32_t)stage.cap, stage.list, stage.count);
+    }
+    const int sb = stage.blocks > 0 ? stage.blocks : 20;
+    if (v16) hipLaunchKernelGGL(stage_rows_kernel<16>, dim3(sb), dim3(kBlock), 0, s, static_cast<const char*>(host), ldh * esz, host_map, stage.list,
+                                stage.count, (uint32_t)stage.cap, static_cast<char*>(stage.rows), stage.ld * esz, (int)whole);
+    else hipLaunchKernelGGL(stage_rows_kernel<4>, dim3(sb), dim3(kBlock), 0, s, static_cast<const char*>(host), ldh * esz, host_map, stage.list,
+                            stage.count, (uint32_t)stage.cap, static_cast<char*>(stage.rows), stage.ld * esz, (int)row_bytes);
+    DGLL_HIP_TRY(hipGetLastError());
+    return DGLL_OK;
+}
+
 static int gather_rows_impl(void* stream, const void* cache, int64_t ldc, const void* host, int64_t ldh,
                             const int64_t* idx, const int64_t* slot, void* out, int64_t ldo, int64_t n, int feat,
-                            int dtype, unsigned long long* miss_count, const int64_t* host_map) {
+                            int dtype, unsigned long long* miss_count, const int64_t* host_map, const MissStage* stage) {
     if (n <= 0 || feat <= 0) return DGLL_OK;
     DGLL_REQUIRE(host && idx && out, "NULL argument");
     DGLL_REQUIRE(!slot || cache, "a slot map needs a cache matrix");
@@ -549,9 +595,14 @@ static int gather_rows_impl(void* stream, const void* cache, int64_t ldc, const 
     GatherArgs a{};
     a.cache = cache; a.host = host; a.idx = idx; a.slot = slot; a.out = out;
     a.ldc = ldc; a.ldh = ldh; a.ldo = ldo; a.n = n; a.row_bytes = feat * esz; a.miss_count = miss_count; a.host_map = host_map;
+    if (stage) {
+        a.stage_map = stage->map; a.stage_rows = stage->rows; a.ld_stage = stage->ld; a.stage_serial = stage->serial;
+        a.stage_cap = (uint32_t)stage->cap;
+    }
     auto ok16 = [&](const void* p, int64_t ld) { return !p || (aligned16(p) && (ld * esz) % 16 == 0); };
-    const bool v16 = a.row_bytes % 16 == 0 && ok16(cache, ldc) && ok16(host, ldh) && ok16(out, ldo);
-    const bool v4 = a.row_bytes % 4 == 0 && (ldh * esz) % 4 == 0 && (ldo * esz) % 4 == 0 && (!slot || (ldc * esz) % 4 == 0);
+    const bool v16 = a.row_bytes % 16 == 0 && ok16(cache, ldc) && ok16(host, ldh) && ok16(out, ldo) && (!stage || ok16(stage->rows, stage->ld));
+    const bool v4 = a.row_bytes % 4 == 0 && (ldh * esz) % 4 == 0 && (ldo * esz) % 4 == 0 && (!slot || (ldc * esz) % 4 == 0) &&
+                    (!stage || (stage->ld * esz) % 4 == 0);
     const int64_t blocks = std::min<int64_t>((n + kWavesPerBlock - 1) / kWavesPerBlock, 256 * (g_tune_loader_blocks_per_cu > 0 ? g_tune_loader_blocks_per_cu : 16));
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (v16) hipLaunchKernelGGL(gather_rows_kernel<16>, dim3((uint32_t)blocks), dim3(kBlock), 0, s, a, esz);
@@ -566,14 +617,14 @@ DGLL_API int dgll_hip_aggregate_rows_mapped(void* stream, const void* cache, int
                                             const int64_t* idx, const int64_t* slot, const int64_t* host_map, const int64_t* rowptr,
                                             void* out, int64_t ldo, int64_t n_rows, int feat, int dtype, int reduce,
                                             unsigned long long* miss_count) {
-    return aggregate_rows_impl(stream, cache, ldc, host, ldh, idx, slot, host_map, rowptr, out, ldo, n_rows, feat, dtype, reduce, miss_count, 0,
+    return aggregate_rows_impl(stream, cache, ldc, host, ldh, idx, slot, host_map, rowptr, out, ldo, n_rows, feat, dtype, reduce, miss_count,
                                nullptr);
 }
 
-// n_idx (entries of idx) is needed with a stage only
+// stage: the uncached rows were fetched by stage_misses on this stream
 static int aggregate_rows_impl(void* stream, const void* cache, int64_t ldc, const void* host, int64_t ldh, const int64_t* idx,
                                const int64_t* slot, const int64_t* host_map, const int64_t* rowptr, void* out, int64_t ldo, int64_t n_rows,
-                               int feat, int dtype, int reduce, unsigned long long* miss_count, int64_t n_idx, const MissStage* stage) {
+                               int feat, int dtype, int reduce, unsigned long long* miss_count, const MissStage* stage) {
     if (n_rows <= 0 || feat <= 0) return DGLL_OK;
     DGLL_REQUIRE(host && idx && rowptr && out, "NULL argument");
     DGLL_REQUIRE(!slot || cache, "a slot map needs a cache matrix");
@@ -602,15 +653,6 @@ static int aggregate_rows_impl(void* stream, const void* cache, int64_t ldc, con
     if (stage) {
         a.stage_map = stage->map; a.stage_rows = stage->rows; a.ld_stage = stage->ld; a.stage_serial = stage->serial;
         a.stage_cap = (uint32_t)stage->cap;
-        DGLL_HIP_TRY(hipMemsetAsync(stage->count, 0, sizeof(unsigned int), s));
-        const int64_t lb = (n_idx + kListPerBlock - 1) / kListPerBlock;
-        hipLaunchKernelGGL(list_misses_kernel, dim3((uint32_t)lb), dim3(kBlock), 0, s, idx, n_idx, slot, stage->map, stage->serial, (uint32_t)stage->cap,
-                           stage->list, stage->count);
-        const int sb = stage->blocks > 0 ? stage->blocks : 20;
-        if (v16) hipLaunchKernelGGL(stage_rows_kernel<16>, dim3(sb), dim3(kBlock), 0, s, static_cast<const char*>(host), ldh * esz, host_map,
-                                    stage->list, stage->count, (uint32_t)stage->cap, static_cast<char*>(stage->rows), lds * esz, a.row_bytes);
-        else hipLaunchKernelGGL(stage_rows_kernel<4>, dim3(sb), dim3(kBlock), 0, s, static_cast<const char*>(host), ldh * esz, host_map,
-                                stage->list, stage->count, (uint32_t)stage->cap, static_cast<char*>(stage->rows), lds * esz, a.row_bytes);
     }
     const int64_t blocks = std::min<int64_t>((n_rows + kWavesPerBlock - 1) / kWavesPerBlock, 256 * (g_tune_loader_blocks_per_cu > 0 ? g_tune_loader_blocks_per_cu : 32));
     if (dtype == DGLL_BF16) {

@@ -942,9 +942,10 @@ class MiniBatchPipeline:
         sg = stages.get(which)
         uncached = max(int(self.cache.node_num) - int(self.cache.cached_num), 1)
         if sg is None or sg["cap"] < min(uncached, sg["cap_outer"], STAGE_CAP if STAGE_CAP > 0 else uncached):
-            cap_outer = self.dataloader.batch_size
-            for f in self.dataloader.sampler.fanouts:
-                cap_outer *= int(f)
+            cap_outer, rows = 0, self.dataloader.batch_size
+            for f in [1] + [int(f) for f in reversed(self.dataloader.sampler.fanouts)]:
+                rows *= f
+                cap_outer += rows                          # ids of all hops of a batch (seeds + every hop's sources)
             cap = min(uncached, cap_outer)                 # every distinct uncached node at most once
             if STAGE_CAP > 0:
                 cap = min(cap, STAGE_CAP)                  # nodes past it stay zero-copy reads of the reduction

@@ -226,9 +226,10 @@ def test_batches_written_in_place_by_the_loading_stage_replay_to_the_same_losses
 
 @pytest.mark.parametrize("streams,cap", [(1, 0), (2, 0), (1, 9)])
 def test_staged_misses_give_the_zero_copy_reduction_bit_for_bit(cuda_device, streams, cap, monkeypatch):
-    """csrc/gather.hip: list_misses_kernel + stage_rows_kernel fetch the outermost hop's DISTINCT uncached rows into HBM, the reduction
-    then reads them there.  Same rows in the same order: every batch's reduced rows equal the zero-copy form's bit for bit -- on one
-    loading stream and two alternating ones, and with a staging buffer of 9 rows (nodes past it stay zero-copy reads)."""
+    """csrc/gather.hip: list_misses_kernel + stage_rows_kernel fetch a batch's DISTINCT uncached rows (all hops) into HBM, the hop gathers
+    and the outermost hop's reduction then read them there.  Same rows in the same order: every batch's gathered and reduced rows equal
+    the zero-copy form's bit for bit -- on one loading stream and two alternating ones, and with a staging buffer of 9 rows (nodes past
+    it stay zero-copy reads)."""
     import numpy as np
 
     from dgll_amd import nn as dnn, pipeline as pl, synth
@@ -269,27 +270,29 @@ def test_staged_misses_give_the_zero_copy_reduction_bit_for_bit(cuda_device, str
         for b in pipe:
             assert b.static_set is not None
             torch.cuda.current_stream().wait_event(b.ready)
-            out.append((b.last_hop_reduced.clone(), b.input_nodes.clone()))
+            every = torch.cat([sg.src_nodes().to(dev) for sg in b.subgraphs] + [train[len(out) * batch:(len(out) + 1) * batch].to(dev)])
+            out.append((b.last_hop_reduced.clone(), b.input_nodes.clone(), [f.clone() for f in b.features if f is not None], every))
             losses.append(float(step(b)))
         torch.cuda.synchronize()
         stages = getattr(pipe, "_miss_stages", {})
         assert (len(stages) == streams) == stage
         for sg in stages.values():
-            assert sg["cap"] == (cap or min(nodes - nodes // 3, batch * 5 * 3 * 4)) and sg["serial"] >= 9 // streams
+            assert sg["cap"] == (cap or min(nodes - nodes // 3, batch * (1 + 4 + 12 + 60))) and sg["serial"] >= 9 // streams
         return out, losses, stages, cache.get_miss_rate()
 
     plain, plain_losses, _, plain_rate = run(False)
     staged, staged_losses, stages, staged_rate = run(True)
     assert len(plain) == len(staged) == 9
-    for (a, ids_a), (b_, ids_b) in zip(plain, staged):
+    for (a, ids_a, feats_a, _), (b_, ids_b, feats_b, _) in zip(plain, staged):
         assert torch.equal(ids_a, ids_b) and torch.equal(a, b_)
+        assert len(feats_a) == len(feats_b) == 3 and all(torch.equal(u, v) for u, v in zip(feats_a, feats_b))      # the hop gathers too
     assert staged_losses == plain_losses
     assert staged_rate == pytest.approx(plain_rate) and plain_rate > 0.05         # the miss log counts draws, staged or not
     # the last batch of a stream: its distinct uncached nodes, each listed once
     sg = next(iter(stages.values()))
     count = int(sg["count"][0])
     slot = cache.localid2cacheid
-    last_ids = staged[-1][1] if streams == 1 else None
+    last_ids = staged[-1][3] if streams == 1 else None          # every id of the batch: seeds, each hop's sources, the outermost hop
     if last_ids is not None:
         distinct = torch.unique(last_ids[slot[last_ids] < 0])
         assert count == int(distinct.numel())
