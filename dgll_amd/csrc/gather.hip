@@ -574,7 +574,11 @@ static int stage_misses(hipStream_t s, const MissStage& stage, const void* host,
         hipLaunchKernelGGL(list_misses_kernel, dim3((uint32_t)lb), dim3(kBlock), 0, s, lists[i], counts[i], slot, stage.map, stage.serial,
                            (uint32_t)stage.cap, stage.list, stage.count);
     }
-    const int sb = stage.blocks > 0 ? stage.blocks : 20;
+    // default grid: ~192 KB of reads in flight on the link (two rows, or two 2048 / 1280-byte pieces of them, per wavefront): 20 workgroups
+    // at the Reddit row of 1204 bytes -- the measured optimum (16: 744, 20: 783-795, 24: 725, 32: 630 batches/s)
+    const int64_t piece = std::min<int64_t>(v16 ? whole : row_bytes, v16 ? 2048 : 1280);
+    const int sb = stage.blocks > 0 ? stage.blocks
+                                    : (int)std::min<int64_t>(std::max<int64_t>(196608 / (2 * piece) / kWavesPerBlock, 4), 256);
     if (v16) hipLaunchKernelGGL(stage_rows_kernel<16>, dim3(sb), dim3(kBlock), 0, s, static_cast<const char*>(host), ldh * esz, host_map, stage.list,
                                 stage.count, (uint32_t)stage.cap, static_cast<char*>(stage.rows), stage.ld * esz, (int)whole);
     else hipLaunchKernelGGL(stage_rows_kernel<4>, dim3(sb), dim3(kBlock), 0, s, static_cast<const char*>(host), ldh * esz, host_map, stage.list,

@@ -347,7 +347,7 @@ typedef struct dgll_batch_load {
      * reduction reads HBM only and does not hold the chip while it waits for PCIe.  stage_map: int64[n_nodes] scratch of ONE loading
      * stream, zero-initialised once, never cleared (entries carry stage_serial, which the caller advances per call, never 0);
      * stage_rows: [stage_cap, ld_stage] elements of the store's dtype; stage_list: int64[stage_cap]; stage_count: one device word.
-     * Nodes past stage_cap stay zero-copy reads.  stage_blocks: workgroups of the fetch (0 = 20).                                    */
+     * Nodes past stage_cap stay zero-copy reads.  stage_blocks: workgroups of the fetch (0 = about 192 KB of reads in flight: 20 at 1204-byte rows).                                   */
     int64_t* stage_map; void* stage_rows; int64_t ld_stage; int64_t stage_cap; int64_t* stage_list; unsigned int* stage_count;
     unsigned int stage_serial; int stage_blocks;
     int upload_blocks;      /* workgroups of the two uploads (0 = 16, DGLL_LOADER_UPLOAD_BLOCKS): few beside staged misses, more (128) when
