@@ -898,9 +898,15 @@ DGLL_API int dgll_hip_gat_fwd_strided(void* stream, const dgll_csr_plan* plan, c
 
 DGLL_API int dgll_hip_gat_fwd_rowscore(void* stream, const dgll_csr_plan* plan, const int64_t* rowptr, const int32_t* col,
                                        const void* H, int64_t ldh, const float* S, const float* attn2, void* out, int64_t ldo, int dtype,
-                                       float* rowsum, int64_t n_rows, int heads, int fo, float alpha, int apply_elu, void* workspace,
-                                       size_t workspace_bytes, int raw, int accumulate) {
+                                       float* rowsum, int64_t n_rows, int64_t n_cols, int heads, int fo, float alpha, int apply_elu,
+                                       void* workspace, size_t workspace_bytes, int raw, int accumulate) {
     DGLL_REQUIRE(attn2, "attn2 (a2 of every head, laid out like a row of H) is required");
+    // the kernel addresses the gathered rows by 32-bit byte offsets formed with a 24-bit multiply
+    const int64_t row_bytes = ldh * (dtype == DGLL_BF16 ? 2 : 4);
+    if (n_cols <= 0 || n_cols > (1 << 24) || row_bytes >= (1 << 24) || n_cols * row_bytes > (int64_t)0xffffffffll) {
+        set_error("dgll_hip_gat_fwd_rowscore: H must have at most 2^24 rows and 4 GB (use dgll_hip_gat_fwd_strided)");
+        return DGLL_ERR_UNSUPPORTED;
+    }
     return gat_fwd_impl(stream, plan, rowptr, col, H, ldh, S, nullptr, 0, nullptr, out, ldo, dtype, rowsum, nullptr, n_rows, heads, fo,
                         alpha, apply_elu, 0, workspace, workspace_bytes, raw, accumulate, attn2);
 }

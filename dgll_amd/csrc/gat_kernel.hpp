@@ -71,7 +71,9 @@ __device__ __forceinline__ float head_sum_c(float v) {
 // group ends up with the group's sum.  Groups of 32 / 64 lanes finish through ds_bpermute.
 template <int CTRL>
 __device__ __forceinline__ float dpp_take(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+    // full row / bank masks and a permutation inside the row: every lane receives a value, `old` is never seen.  The form without an
+    // `old` operand lets the compiler fold the move into the add that follows (v_add_f32_dpp): with old = 0 it kept v_mov 0 + v_mov_dpp + v_add.
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, false));
 }
 template <int LPH>
 __device__ __forceinline__ float head_sum_dpp(float v) {
@@ -127,6 +129,7 @@ __global__ __launch_bounds__(kBlock, ((KIND == 1 || KIND == 3) && INROW && sizeo
     const XT* hcol = static_cast<const XT*>(a.H) + (col_ok ? c0 : ((INROW && hs == a.vph) ? a.feat : 0));
     const int tlane = (lane & ~(LPR - 1)) + a.vph;
     const uint32_t ld32 = (uint32_t)a.ldh;
+    const uint32_t lane_off = (uint32_t)((col_ok ? c0 : ((INROW && hs == a.vph) ? a.feat : 0)) * (int)sizeof(XT));
     const rec_t* __restrict__ my_rec = rec + hk * kRecStride;
     float* __restrict__ rec1 = rec1_all[KIND == 2 ? wave : 0];
     const float* __restrict__ my_rec1 = rec1 + hk * kRecStride;
@@ -161,6 +164,11 @@ __global__ __launch_bounds__(kBlock, ((KIND == 1 || KIND == 3) && INROW && sizeo
     WorkItem it = resolve_item(a, wave, 0);
     int col_first = 0;                                             // the item's first index batch (lane = edge), prefetched
     if (it.valid && it.b + lane < it.e) col_first = __builtin_nontemporal_load(a.col + it.b + lane);
+    // TROW: s_i of this lane's own head, requested ONE ITEM AHEAD like the index batch (read at the top of its row the load's latency
+    // stood in front of every row's gathers: the one wait the plain SpMM of the same shape does not have)
+    float s_first = 0.0f;
+    const int head_s = h0 + hk < a.heads ? h0 + hk : 0;          // the lane's head even where it holds none of its columns (fo < lanes x EPV)
+    if constexpr (TROW) { if (it.valid) s_first = a.S[it.row * a.heads + head_s]; }
   for (int r = 0; !it.done; ++r) {
     // the NEXT item's bounds and first index batch are requested before this item's gathers: a row's dependent chain
     // (row pointers -> indices -> score rows -> gathers) then starts at the score rows
@@ -169,14 +177,15 @@ __global__ __launch_bounds__(kBlock, ((KIND == 1 || KIND == 3) && INROW && sizeo
     if (r + 1 < a.rows_per_wave) nx = resolve_item(a, wave, r + 1);
     int col_next_item = 0;
     if (nx.valid && nx.b + lane < nx.e) col_next_item = __builtin_nontemporal_load(a.col + nx.b + lane);
+    float s_next = 0.0f;
+    if constexpr (TROW) { if (nx.valid) s_next = a.S[nx.row * a.heads + head_s]; }
    if (it.valid) {
     const int64_t row = it.row, b = it.b, e = it.e;
 
     // ---- wave-uniform per-row scalars of the wave's heads
     float su[NH];
     load_heads_uniform<NH>(a.S, row, a.heads, h0, su);
-    float s_mine = 0.0f;                                           // TROW: s_i of this lane's own head
-    if constexpr (TROW) s_mine = a.S[row * a.heads + head];
+    const float s_mine = s_first;                                  // TROW: s_i of this lane's own head
 
     // ---- per-row prologue of the backward passes
     float dn[EPV];                     // KIND 1: DN_i (this lane's columns)
@@ -283,7 +292,15 @@ __global__ __launch_bounds__(kBlock, ((KIND == 1 || KIND == 3) && INROW && sizeo
             for (int u = 0; u < U; ++u) {
                 const int idx = j + u * SLOTS + slot;
                 const int cj = __shfl(gcol, idx);
-                v[u] = IO::load(hcol + (uint64_t)(uint32_t)cj * ld32);
+                if constexpr (TROW) {
+                    // 32-bit byte offset from the uniform base: one full-rate v_mad_u32_u24 and the load's scalar-base form instead of
+                    // v_mad_u64_u32 + a 64-bit add per gather (forward 5.08 -> 4.95 ms; the entry point admits matrices under 4 GB and
+                    // 2^24 rows only).  The plain SpMM gains nothing from the same change: it waits for memory, this pass for its VALU.
+                    const uint32_t off = __umul24((uint32_t)cj, ld32 * (uint32_t)sizeof(XT)) + lane_off;
+                    v[u] = *reinterpret_cast<const typename IO::raw_t*>(static_cast<const char*>(a.H) + off);
+                } else {
+                    v[u] = IO::load(hcol + (uint64_t)(uint32_t)cj * ld32);
+                }
                 if constexpr (!INROW && !TROW) {
                     rr[u] = my_rec[idx];
                     if constexpr (KIND == 2) r1[u] = my_rec1[idx];
@@ -291,26 +308,53 @@ __global__ __launch_bounds__(kBlock, ((KIND == 1 || KIND == 3) && INROW && sizeo
             }
             if constexpr (TROW) {
                 static_assert(KIND != 2, "the transposed pass gathers DN rows: their scores cannot be formed from them");
+                // w = exp(sign * lrelu(z)) = exp2(z * c_neg + max(z, 0) * (c_pos - c_neg)),  c_pos = sign * log2(e), c_neg = alpha * c_pos:
+                // mul + max + fma + v_exp per (edge, head) instead of mul, compare, select, mul, mul, v_exp
+                const float c_neg = a.sign * a.alpha * 1.44269504088896341f, c_dif = a.sign * 1.44269504088896341f - c_neg;
+                auto scores = [&](auto masked) __attribute__((always_inline)) {
+                    float z[U];
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    float pt = 0.0f;
-                    if constexpr (BF) {
-                        const uint32_t hv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+                    for (int u = 0; u < U; ++u) {
+                        float pt = 0.0f;
+                        if constexpr (BF) {
+                            const uint32_t hv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
 #pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            pt = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a2p[q]), __builtin_bit_cast(bf16x2_t, hv[q]), pt, false);
-                    } else {
-                        float f[EPV];
-                        IO::unpack(v[u], f);
+                            for (int q = 0; q < 4; ++q)
+                                pt = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a2p[q]), __builtin_bit_cast(bf16x2_t, hv[q]), pt, false);
+                        } else {
+                            float f[EPV];
+                            IO::unpack(v[u], f);
 #pragma unroll
-                        for (int i = 0; i < EPV; ++i) pt = fmaf(f[i], a2f[i], pt);
+                            for (int i = 0; i < EPV; ++i) pt = fmaf(f[i], a2f[i], pt);
+                        }
+                        z[u] = s_mine + head_sum_dpp<LPH>(pt);
                     }
-                    const float z = s_mine + head_sum_dpp<LPH>(pt);
-                    float w = __expf(a.sign * lrelu(z, a.alpha));
-                    w = (j + u * SLOTS + slot < nb) ? w : 0.0f;
-                    if constexpr (KIND == 0) rr[u] = w;
-                    if constexpr (ROWS) rr[u] = z > 0.0f ? w : -w;
-                }
+                    if constexpr (LPH == 4 && U == 4) {
+                        // the head's four lanes hold the same four z: lane hs evaluates edge hs and hands w to the quad (one exponential
+                        // and one mask per lane and group instead of four; v_exp_f32 is a quarter-rate instruction)
+                        const float zs = hs == 0 ? z[0] : (hs == 1 ? z[1] : (hs == 2 ? z[2] : z[3]));
+                        float ws = __builtin_amdgcn_exp2f(fmaf(fmaxf(zs, 0.0f), c_dif, zs * c_neg));
+                        if constexpr (decltype(masked)::value) ws = (j + hs * SLOTS + slot < nb) ? ws : 0.0f;
+                        const float w4[4] = {dpp_take<0x00>(ws), dpp_take<0x55>(ws), dpp_take<0xAA>(ws), dpp_take<0xFF>(ws)};
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            if constexpr (KIND == 0) rr[u] = w4[u];
+                            if constexpr (ROWS) rr[u] = z[u] > 0.0f ? w4[u] : -w4[u];
+                        }
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            float w = __builtin_amdgcn_exp2f(fmaf(fmaxf(z[u], 0.0f), c_dif, z[u] * c_neg));
+                            if constexpr (decltype(masked)::value) w = (j + u * SLOTS + slot < nb) ? w : 0.0f;
+                            if constexpr (KIND == 0) rr[u] = w;
+                            if constexpr (ROWS) rr[u] = z[u] > 0.0f ? w : -w;
+                        }
+                    }
+                };
+                // every slot of the group holds a live edge (wave-uniform; all groups of a row but its last): no per-edge mask.  (The
+                // empty asm keeps the two forms apart: merged into selects they cost every group two per edge.)
+                if (j + SLOTS * U <= nb) scores(std::false_type{});
+                else { asm volatile(""); scores(std::true_type{}); }
             }
             if constexpr (INROW) {
 #pragma unroll
@@ -466,6 +510,7 @@ __global__ __launch_bounds__(kBlock, ((KIND == 1 || KIND == 3) && INROW && sizeo
    }
     it = nx;
     col_first = col_next_item;
+    s_first = s_next;
   }
 }
 

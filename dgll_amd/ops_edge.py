@@ -172,15 +172,17 @@ def _gat_strided_forward(h, s, t, graph, heads, fo, alpha, apply_elu, pack_score
     ws_bytes = int(_lib.lib.dgll_hip_gat_workspace_bytes(plan, heads, fo))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
     timer = _launch_timer()
-    row_scores = attn2 is not None and not packed and ROW_SCORES
+    # (the row-score kernel addresses h by 32-bit byte offsets: at most 2^24 rows and 4 GB)
+    row_scores = attn2 is not None and not packed and ROW_SCORES and h.shape[0] <= (1 << 24) and h.stride(0) * esz < (1 << 24) \
+        and h.shape[0] * h.stride(0) * esz <= 0xFFFFFFFF
     end = timer.start(("gat", "fwd", heads, fo, str(h.dtype), graph.nnz, "packed" if packed else ("rowscore" if row_scores else "")), dev) if timer else None
     with torch.cuda.device(dev):
         if row_scores:
             a2 = attn2.detach().to(torch.float32).contiguous()
             code = _lib.lib.dgll_hip_gat_fwd_rowscore(
                 _stream(dev), plan, graph.rowptr.data_ptr(), graph.col.data_ptr(), h.data_ptr(), h.stride(0), s.data_ptr(),
-                a2.data_ptr(), out.data_ptr(), out.stride(0), _dtype_code(h), rowsum.data_ptr(), graph.n_rows, heads, fo, float(alpha),
-                int(apply_elu), ws.data_ptr() if ws is not None else None, ws_bytes, 0, 0)
+                a2.data_ptr(), out.data_ptr(), out.stride(0), _dtype_code(h), rowsum.data_ptr(), graph.n_rows, int(h.shape[0]), heads, fo,
+                float(alpha), int(apply_elu), ws.data_ptr() if ws is not None else None, ws_bytes, 0, 0)
         else:
             code = _lib.lib.dgll_hip_gat_fwd_strided(
                 _stream(dev), plan, graph.rowptr.data_ptr(), graph.col.data_ptr(), h.data_ptr(), h.stride(0), s.data_ptr(),

@@ -203,11 +203,13 @@ int dgll_hip_gat_fwd_strided(void* stream, const dgll_csr_plan* plan, const int6
  * sparseGatConv itself builds its logit from the gathered rows (gatconv.py:122-125) -- no score row is fetched per edge (one cache
  * line fewer per edge than dgll_hip_gat_fwd_strided when the rows fill their lines).  attn2: fp32 [heads * fo], a2 of every head laid
  * out like a row of H (bf16 storage: rounded to bf16 for the packed dot product, as the score product of the caller rounds it).  S as
- * before ([n_rows, heads] fp32).  raw / accumulate as dgll_hip_gat_fwd_ex.  sparseGatConv's form only (exp(-leakyrelu), no dropout). */
+ * before ([n_rows, heads] fp32).  raw / accumulate as dgll_hip_gat_fwd_ex.  sparseGatConv's form only (exp(-leakyrelu), no dropout).
+ * n_cols = rows of H: the gathers use 32-bit byte offsets, so H may hold at most 2^24 rows and 4 GB (DGLL_ERR_UNSUPPORTED past
+ * that: take dgll_hip_gat_fwd_strided).                                                                                         */
 int dgll_hip_gat_fwd_rowscore(void* stream, const dgll_csr_plan* plan, const int64_t* rowptr, const int32_t* col,
                               const void* H, int64_t ldh, const float* S, const float* attn2, void* out, int64_t ldo, int dtype,
-                              float* rowsum, int64_t n_rows, int heads, int fo, float alpha, int apply_elu, void* workspace,
-                              size_t workspace_bytes, int raw, int accumulate);
+                              float* rowsum, int64_t n_rows, int64_t n_cols, int heads, int fo, float alpha, int apply_elu,
+                              void* workspace, size_t workspace_bytes, int raw, int accumulate);
 /* the two passes of dgll_hip_gat_bwd_strided one by one (rows of A: DN, {s, dd}, grad_S; then rows of A^T: grad_H, grad_T) */
 int dgll_hip_gat_bwd_rows_strided(void* stream, const dgll_csr_plan* plan, const int64_t* rowptr, const int32_t* col,
                                   const void* H, int64_t ldh, const float* S, const float* T, int t_stride,
