@@ -99,6 +99,8 @@ SIGNATURES = {
     "dgll_host_sampler_pool_destroy": (_i32, [_vp]),
     "dgll_hip_gat_fwd_rowscore": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i32, _vp, _i64, _i64, _i32, _i32, C.c_float, _i32,
                                          _vp, _sz, _i32, _i32]),
+    "dgll_hip_gat_bwd_rows_rowscore": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _i64,
+                                              _vp, _i32, _vp, _i64, _i64, _i32, _i32, C.c_float, _i32, _vp, _sz]),
     "dgll_hip_gat_bwd_rows_strided": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _i64,
                                              _vp, _i32, _vp, _i64, _i32, _i32, C.c_float, _i32, _vp, _sz]),
     "dgll_hip_gat_bwd_cols_strided": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i32, _vp, _i64, _vp, _i32, _i64,

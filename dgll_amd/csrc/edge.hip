@@ -827,6 +827,12 @@ static int gat1_pick(const EdgeArgs& a, int epv, int* lph, int* lpr, uint32_t* g
     return DGLL_OK;
 }
 
+// the row-score kernels address the gathered rows by 32-bit byte offsets formed with a 24-bit multiply
+static bool rowscore_addressable(int64_t n_cols, int64_t ldh, int dtype) {
+    const int64_t row_bytes = ldh * (dtype == DGLL_BF16 ? 2 : 4);
+    return n_cols > 0 && n_cols <= (1 << 24) && row_bytes < (1 << 24) && n_cols * row_bytes <= (int64_t)0xffffffffll;
+}
+
 static int gat_fwd_impl(void* stream, const dgll_csr_plan* plan, const int64_t* rowptr, const int32_t* col,
                         const void* H, int64_t ldh, const float* S, const float* T, int t_stride, const float* edge_scale, void* out,
                         int64_t ldo, int dtype, float* rowsum, float* rowmax, int64_t n_rows, int heads, int fo,
@@ -901,9 +907,7 @@ DGLL_API int dgll_hip_gat_fwd_rowscore(void* stream, const dgll_csr_plan* plan, 
                                        float* rowsum, int64_t n_rows, int64_t n_cols, int heads, int fo, float alpha, int apply_elu,
                                        void* workspace, size_t workspace_bytes, int raw, int accumulate) {
     DGLL_REQUIRE(attn2, "attn2 (a2 of every head, laid out like a row of H) is required");
-    // the kernel addresses the gathered rows by 32-bit byte offsets formed with a 24-bit multiply
-    const int64_t row_bytes = ldh * (dtype == DGLL_BF16 ? 2 : 4);
-    if (n_cols <= 0 || n_cols > (1 << 24) || row_bytes >= (1 << 24) || n_cols * row_bytes > (int64_t)0xffffffffll) {
+    if (!rowscore_addressable(n_cols, ldh, dtype)) {
         set_error("dgll_hip_gat_fwd_rowscore: H must have at most 2^24 rows and 4 GB (use dgll_hip_gat_fwd_strided)");
         return DGLL_ERR_UNSUPPORTED;
     }
@@ -919,12 +923,16 @@ static int gat_bwd_rows_impl(void* stream, const dgll_csr_plan* plan, const int6
                              const void* out, int64_t ldo, const void* grad_out, int64_t ldg, int dtype,
                              const float* rowsum, const float* rowmax, void* dn, int64_t ldn, float* dd, float* sd_out,
                              int sd_stride, float* grad_S, int64_t n_rows, int heads, int fo, float alpha, int apply_elu,
-                             int mode, int accumulate, void* workspace, size_t workspace_bytes, float* part3 = nullptr) {
+                             int mode, int accumulate, void* workspace, size_t workspace_bytes, float* part3 = nullptr,
+                             const float* attn2 = nullptr) {
     if (n_rows <= 0) return DGLL_OK;
     EdgeArgs a{};
     int rc = gat_common(a, rowptr, col, n_rows, heads, fo, dtype, alpha, mode, apply_elu);
     if (rc != DGLL_OK) return rc;
-    DGLL_REQUIRE(H && S && T && out && grad_out && rowsum && dn && (dd || sd_out) && grad_S, "NULL argument");
+    DGLL_REQUIRE(H && S && (T || attn2) && out && grad_out && rowsum && dn && (dd || sd_out) && grad_S, "NULL argument");
+    DGLL_REQUIRE(!attn2 || (!T && mode == 0 && !edge_scale && accumulate == 3),
+                 "the row-score form takes a2 INSTEAD of T: sparseGatConv's form, one launch over the rows (exact dd_i)");
+    a.attn2 = attn2;
     DGLL_REQUIRE(mode == 0 || rowmax, "mode 1 needs the forward's rowmax");
     const int esz = dtype == DGLL_BF16 ? 2 : 4, epv = 16 / esz;
     DGLL_REQUIRE(vec_ok(H, ldh, esz) && vec_ok(out, ldo, esz) && vec_ok(grad_out, ldg, esz) && vec_ok(dn, ldn, esz),
@@ -946,9 +954,12 @@ static int gat_bwd_rows_impl(void* stream, const dgll_csr_plan* plan, const int6
         DGLL_REQUIRE(a.exact_dd < 2 || part3, "a split exact rows pass needs the [n_rows, 3 * heads] partial-sum buffer");
         a.part3 = part3;
         a.accumulate = accumulate == 1 ? 1 : 0;
-        const bool inrow = gat2_inrow(a, lpr, nh, esz, a.T, nullptr);
-        if (!(a.exact_dd ? gat2_launch_3(dtype, lpr, nh, grid, s, a, inrow) : gat2_launch_1(dtype, lpr, nh, grid, s, a, inrow))) { set_error("no second-generation GAT kernel for this head layout"); return DGLL_ERR_UNSUPPORTED; }
+        const bool inrow = !attn2 && gat2_inrow(a, lpr, nh, esz, a.T, nullptr);
+        const bool ok = attn2 ? gat2_launch_3r(dtype, lpr, nh, grid, s, a)
+                              : (a.exact_dd ? gat2_launch_3(dtype, lpr, nh, grid, s, a, inrow) : gat2_launch_1(dtype, lpr, nh, grid, s, a, inrow));
+        if (!ok) { set_error("no second-generation GAT kernel for this head layout"); return DGLL_ERR_UNSUPPORTED; }
     } else {
+        DGLL_REQUIRE(!attn2, "the row-score form needs the second-generation kernels");
         rc = gat1_pick(a, epv, &lph, &lpr, &grid.y);
         if (rc != DGLL_OK) return rc;
         DGLL_REQUIRE(dd, "the first-generation rows pass writes dd");
@@ -1083,6 +1094,22 @@ DGLL_API int dgll_hip_gat_bwd_rows_strided(void* stream, const dgll_csr_plan* pl
     return gat_bwd_rows_impl(stream, plan, rowptr, col, H, ldh, S, T, t_stride, nullptr, out, ldo, grad_out, ldg, dtype, rowsum,
                              nullptr, dn_scratch, ldn, nullptr, sd_scratch, sd_stride, grad_S, n_rows, heads, fo, alpha,
                              apply_elu, 0, 3, workspace, workspace_bytes);      // the strided form is always the only launch over its rows
+}
+
+DGLL_API int dgll_hip_gat_bwd_rows_rowscore(void* stream, const dgll_csr_plan* plan, const int64_t* rowptr, const int32_t* col,
+                                            const void* H, int64_t ldh, const float* S, const float* attn2,
+                                            const void* out, int64_t ldo, const void* grad_out, int64_t ldg, int dtype,
+                                            const float* rowsum, void* dn_scratch, int64_t ldn, float* sd_scratch, int sd_stride,
+                                            float* grad_S, int64_t n_rows, int64_t n_cols, int heads, int fo, float alpha, int apply_elu,
+                                            void* workspace, size_t workspace_bytes) {
+    DGLL_REQUIRE(sd_scratch && sd_stride >= 2 * heads && attn2, "bad row-score arguments");
+    if (!rowscore_addressable(n_cols, ldh, dtype)) {
+        set_error("dgll_hip_gat_bwd_rows_rowscore: H must have at most 2^24 rows and 4 GB (use dgll_hip_gat_bwd_rows_strided)");
+        return DGLL_ERR_UNSUPPORTED;
+    }
+    return gat_bwd_rows_impl(stream, plan, rowptr, col, H, ldh, S, nullptr, 0, nullptr, out, ldo, grad_out, ldg, dtype, rowsum,
+                             nullptr, dn_scratch, ldn, nullptr, sd_scratch, sd_stride, grad_S, n_rows, heads, fo, alpha,
+                             apply_elu, 0, 3, workspace, workspace_bytes, nullptr, attn2);
 }
 
 DGLL_API int dgll_hip_gat_bwd_cols_strided(void* stream, const dgll_csr_plan* t_plan, const int64_t* t_rowptr,

@@ -154,6 +154,7 @@ bool gat2_launch_0(int dtype, int lpr, int nh, dim3 grid, hipStream_t s, const E
 bool gat2_launch_0r(int dtype, int lpr, int nh, dim3 grid, hipStream_t s, const EdgeArgs& a);             // pass 0, scores from the gathered rows
 bool gat2_launch_1(int dtype, int lpr, int nh, dim3 grid, hipStream_t s, const EdgeArgs& a, bool inrow);
 bool gat2_launch_3(int dtype, int lpr, int nh, dim3 grid, hipStream_t s, const EdgeArgs& a, bool inrow);   // pass 1, exact-dd form alone
+bool gat2_launch_3r(int dtype, int lpr, int nh, dim3 grid, hipStream_t s, const EdgeArgs& a);            // pass 1 exact, scores from the gathered rows
 bool gat2_launch_2(int dtype, int lpr, int nh, dim3 grid, hipStream_t s, const EdgeArgs& a, bool inrow);
 
 }  // namespace dgll

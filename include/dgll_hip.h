@@ -210,6 +210,14 @@ int dgll_hip_gat_fwd_rowscore(void* stream, const dgll_csr_plan* plan, const int
                               const void* H, int64_t ldh, const float* S, const float* attn2, void* out, int64_t ldo, int dtype,
                               float* rowsum, int64_t n_rows, int64_t n_cols, int heads, int fo, float alpha, int apply_elu,
                               void* workspace, size_t workspace_bytes, int raw, int accumulate);
+/* The rows pass of the backward in the same form (dgll_hip_gat_bwd_rows_strided with attn2 instead of T / t_stride; n_cols = rows of
+ * H, bounded as above).                                                                                                          */
+int dgll_hip_gat_bwd_rows_rowscore(void* stream, const dgll_csr_plan* plan, const int64_t* rowptr, const int32_t* col,
+                                   const void* H, int64_t ldh, const float* S, const float* attn2,
+                                   const void* out, int64_t ldo, const void* grad_out, int64_t ldg, int dtype,
+                                   const float* rowsum, void* dn_scratch, int64_t ldn, float* sd_scratch, int sd_stride,
+                                   float* grad_S, int64_t n_rows, int64_t n_cols, int heads, int fo, float alpha, int apply_elu,
+                                   void* workspace, size_t workspace_bytes);
 /* the two passes of dgll_hip_gat_bwd_strided one by one (rows of A: DN, {s, dd}, grad_S; then rows of A^T: grad_H, grad_T) */
 int dgll_hip_gat_bwd_rows_strided(void* stream, const dgll_csr_plan* plan, const int64_t* rowptr, const int32_t* col,
                                   const void* H, int64_t ldh, const float* S, const float* T, int t_stride,
