@@ -230,9 +230,10 @@ def _gat_strided_backward(g, h, s, t, out, rowsum, graph, heads, fo, alpha, appl
         a1, a2 = (v.detach().to(torch.float32).contiguous() for v in attn)
     with torch.cuda.device(dev):
         st = _stream(dev)
-        end = timer.start(("gat", "bwd_rows") + tag, dev) if timer else None
         small = h.shape[0] <= (1 << 24) and h.stride(0) * esz < (1 << 24) and h.shape[0] * h.stride(0) * esz <= 0xFFFFFFFF
-        if a2 is not None and not packed and ROW_SCORES_BWD and small:      # t_j from the gathered rows, as in the forward
+        rows_rowscore = a2 is not None and not packed and ROW_SCORES_BWD and small
+        end = timer.start(("gat", "bwd_rows") + (tag[:4] + ("rowscore",) if rows_rowscore else tag), dev) if timer else None
+        if rows_rowscore:      # t_j from the gathered rows, as in the forward
             code = _lib.lib.dgll_hip_gat_bwd_rows_rowscore(
                 st, plan, graph.rowptr.data_ptr(), graph.col.data_ptr(), h.data_ptr(), h.stride(0), s.data_ptr(), a2.data_ptr(),
                 out.data_ptr(), out.stride(0), g.data_ptr(), g.stride(0), _dtype_code(h), rowsum.data_ptr(), dn.data_ptr(), dn.stride(0),
@@ -245,7 +246,7 @@ def _gat_strided_backward(g, h, s, t, out, rowsum, graph, heads, fo, alpha, appl
                 heads, fo, alpha, apply_elu, wsp, ws_bytes)
         if end is not None:
             end.record(torch.cuda.current_stream(dev))
-        _lib.check(code, "dgll_hip_gat_bwd_rows_strided")
+        _lib.check(code, "dgll_hip_gat_bwd_rows_rowscore" if rows_rowscore else "dgll_hip_gat_bwd_rows_strided")
         if gs_cols is not grad_s:
             gs_cols[:graph.n_rows].copy_(grad_s)
         end = timer.start(("gat", "bwd_cols") + tag, dev) if timer else None
