@@ -356,7 +356,21 @@ __global__ __launch_bounds__(kBlock, ((KIND == 1 || KIND == 3) && INROW && sizeo
                 if (j + SLOTS * U <= nb) scores(std::false_type{});
                 else { asm volatile(""); scores(std::true_type{}); }
             }
-            if constexpr (INROW) {
+            if constexpr (INROW && KIND == 0 && U == 4 && LPR >= 4) {
+                // the forward as in the row-score form: w = exp2(z c_neg + max(z, 0) (c_pos - c_neg)), and ONE exponential per lane and group
+                // of four edges -- every lane of the row's group holds the same four z (t_j broadcast from the score lane): lane q of each
+                // quad evaluates edge q and hands w round the quad (one-head output layer: 2.20 -> 2.07 ms).  The two backward passes keep
+                // the per-edge form below: waiting for all four rows before any arithmetic cost them 8-14 % (2.52 -> 2.87, 2.5 -> 2.7 ms).
+                const float k_neg = a.sign * a.alpha * 1.44269504088896341f, k_dif = a.sign * 1.44269504088896341f - k_neg;
+                float z[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) z[u] = su[0] + __shfl(__uint_as_float(v[u].x), tlane);
+                const int q = lane & 3;
+                const float zs = q == 0 ? z[0] : (q == 1 ? z[1] : (q == 2 ? z[2] : z[3]));
+                float ws = __builtin_amdgcn_exp2f(fmaf(fmaxf(zs, 0.0f), k_dif, zs * k_neg));
+                ws = (j + q * SLOTS + slot < nb) ? ws : 0.0f;
+                rr[0] = dpp_take<0x00>(ws); rr[1] = dpp_take<0x55>(ws); rr[2] = dpp_take<0xAA>(ws); rr[3] = dpp_take<0xFF>(ws);
+            } else if constexpr (INROW) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const float tx = __shfl(__uint_as_float(v[u].x), tlane);       // t_j (KIND 0 / 1) or s_i (KIND 2)
