@@ -87,6 +87,70 @@ def test_gat_layer_node_equals_the_separate_nodes(cuda_device):
     assert float((gA1.float() - gA2.float())[mask].abs().max()) <= 3e-2 * float(gA2.float()[mask].abs().max())
 
 
+@pytest.mark.parametrize("heads,fo,dtype", [(8, 32, torch.bfloat16), (3, 24, torch.bfloat16), (2, 16, torch.bfloat16), (4, 32, torch.float32),
+                                            (8, 8, torch.float32), (2, 64, torch.float32), (1, 40, torch.float32)])
+def test_row_score_passes_equal_the_gathered_score_passes(cuda_device, heads, fo, dtype, monkeypatch):
+    """dgll_hip_gat_fwd_rowscore / dgll_hip_gat_bwd_rows_rowscore (t_j formed from the gathered row; 32-bit gather offsets; one
+    exponential per lane and four edges where a head has four lanes; heads that leave lanes of their group idle) against the passes
+    that gather T: same outputs and gradients, fp32 to rounding, bf16 to its storage rounding.  A rows-long row (long-row chunks)
+    rides along."""
+    from dgll_amd import ops, ops_edge
+    from dgll_amd.graph import CSRGraph
+
+    _, g0 = _graph(1 << 11, 7 + heads, cuda_device)
+    n = g0.n_rows
+    # one row of 700 edges: chunked by the plan (threshold 256), finished by the finalize kernel
+    rp, col = g0.rowptr.cpu(), g0.col.cpu()
+    extra = torch.randperm(n, generator=torch.Generator().manual_seed(1))[:700].to(col.dtype)
+    deg0 = int(rp[1] - rp[0])
+    col = torch.cat([extra, col[deg0:]])
+    rp = torch.cat([rp[:1], rp[1:] + (700 - deg0)])
+    g = CSRGraph(rp.to(cuda_device), col.to(cuda_device), None, n, n)
+    torch.manual_seed(fo)
+    h0 = (torch.randn(n, heads * fo, device=cuda_device) * 0.5).to(dtype)
+    A0 = torch.zeros(heads * fo, 2 * heads, device=cuda_device)
+    for k in range(heads):
+        A0[k * fo:(k + 1) * fo, k] = torch.randn(fo, device=cuda_device) * 0.3
+        A0[k * fo:(k + 1) * fo, heads + k] = torch.randn(fo, device=cuda_device) * 0.3
+    if dtype == torch.bfloat16:
+        A0 = A0.to(dtype).float()                    # both forms then see the same a2 (the row-score form rounds it to bf16)
+    gout = torch.randn(n, heads * fo, device=cuda_device).to(dtype)
+
+    def run(row_scores):
+        monkeypatch.setattr(ops_edge, "ROW_SCORES", row_scores)
+        monkeypatch.setattr(ops_edge, "ROW_SCORES_BWD", row_scores)
+        h, A = h0.clone().requires_grad_(), A0.clone().requires_grad_()
+        with ops.LaunchTimer() as timer:
+            out = ops.gat_layer(g, h, A, heads, 0.2, apply_elu=True)
+            gh, gA = torch.autograd.grad(out, (h, A), gout)
+        tags = [k for k in timer.summary() if k[0] == "gat"]
+        assert sum("rowscore" in k for k in tags) == (2 if row_scores else 0), tags
+        return out.float(), gh.float(), gA.float()
+
+    out_t, gh_t, gA_t = run(False)
+    out_r, gh_r, gA_r = run(True)
+    tol = 2e-2 if dtype == torch.bfloat16 else 2e-5
+    mask = A0 != 0
+    for name, a, b in (("out", out_r, out_t), ("grad_h", gh_r, gh_t), ("grad_A", gA_r[mask], gA_t[mask])):
+        assert torch.isfinite(a).all(), name
+        assert float((a - b).abs().max()) <= tol * float(b.abs().max()), (name, float((a - b).abs().max()), float(b.abs().max()))
+
+
+def test_row_score_entry_points_refuse_what_32_bit_offsets_cannot_address(cuda_device):
+    """Both row-score entry points address the gathered rows by 32-bit byte offsets: more than 2^24 rows, or more than 4 GB, is
+    DGLL_ERR_UNSUPPORTED with a message naming the form to take (checked before anything is launched: dummy pointers)."""
+    from dgll_amd import _lib
+
+    one = torch.zeros(64, device=cuda_device)
+    p = one.data_ptr()
+    # (DGLL_ERR_UNSUPPORTED = -3, include/dgll_hip.h)
+    too_many_rows = _lib.lib.dgll_hip_gat_fwd_rowscore(None, None, p, p, p, 256, p, p, p, 256, 1, p, 10, (1 << 24) + 1, 8, 32, 0.2, 1, None, 0, 0, 0)
+    assert too_many_rows == -3 and b"dgll_hip_gat_fwd_strided" in _lib.lib.dgll_hip_last_error()
+    too_large = _lib.lib.dgll_hip_gat_bwd_rows_rowscore(None, None, p, p, p, 1024, p, p, p, 1024, p, 1024, 0, p, p, 1024, p, 16, p, 10,
+                                                        (1 << 21), 8, 128, 0.2, 1, None, 0)        # 2 M rows x 4 KB = 8 GB
+    assert too_large == -3 and b"dgll_hip_gat_bwd_rows_strided" in _lib.lib.dgll_hip_last_error()
+
+
 def test_bf16_spgat_bench_configuration_against_the_storage_emulating_oracle(cuda_device):
     """The SpGAT bench configuration (8 heads x 32 -> 1 x 47, bf16, scores in the row padding, one autograd node per layer)
     against CPU autograd of the reference's formulas (gatconv.py:117-148, :194-199) with bf16 rounding applied where the GPU path
