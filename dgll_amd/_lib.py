@@ -149,6 +149,7 @@ SIGNATURES = {
     "dgll_hip_softmax_xent": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _i64, _vp, _i64, _i32]),
     "dgll_hip_softmax_xent_soft": (_i32, [_vp, _vp, _i64, _i32, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i32]),
     "dgll_hip_softmax_xent_ex": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i32, _i32]),
+    "dgll_hip_xent_reduce": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp]),
     "launch_gcn_fused_kernel": (None, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32]),
     "launch_gcn_fused_kernel_backward_optimized": (None, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32,
                                                           _i32, _i32]),

@@ -254,3 +254,38 @@ DGLL_API int dgll_hip_softmax_xent_ex(void* stream, const void* logits, int64_t 
     DGLL_REQUIRE((labels != nullptr) != (targets != nullptr) || n_rows == 0, "pass class-index labels OR probability targets");
     return xent_impl(stream, logits, ldz, dtype, labels, targets, ldt, row_loss, grad, ldg, grad_scale, n_rows, n_classes, flags);
 }
+
+// ---- the loss of a mini-batch out of its per-row losses, ONE launch -------------------------------------------------------------------
+// nn.CrossEntropyLoss(reduction='mean') over class-index targets divides by the number of targets that are not ignored.  As tensor ops
+// that is a zeroed buffer, two compares, an and, a copy, two sums and a division -- nine launches of ~4 us inside a 1.1 ms mini-batch
+// step.  One workgroup walks the rows once (fixed order: bit-reproducible) and writes {total, count, total / count, 1 / count}.
+namespace dgll {
+__global__ __launch_bounds__(kBlock) void xent_reduce_kernel(const float* __restrict__ row_loss, const int64_t* __restrict__ labels,
+                                                             int64_t n, int n_classes, float* __restrict__ out) {
+    __shared__ float part[2][kBlock];
+    float sum = 0.0f, cnt = 0.0f;
+    for (int64_t i = threadIdx.x; i < n; i += kBlock) {
+        sum += row_loss[i];
+        cnt += (!labels || (labels[i] >= 0 && labels[i] < n_classes)) ? 1.0f : 0.0f;
+    }
+    part[0][threadIdx.x] = sum; part[1][threadIdx.x] = cnt;
+    __syncthreads();
+    for (int w = kBlock / 2; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) { part[0][threadIdx.x] += part[0][threadIdx.x + w]; part[1][threadIdx.x] += part[1][threadIdx.x + w]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float total = part[0][0], count = part[1][0];
+        out[0] = total; out[1] = count; out[2] = total / count; out[3] = 1.0f / count;       // count == 0: NaN / inf, as torch
+    }
+}
+}  // namespace dgll
+
+DGLL_API int dgll_hip_xent_reduce(void* stream, const float* row_loss, const int64_t* labels, int64_t n_rows, int n_classes, float* out4) {
+    DGLL_REQUIRE(row_loss && out4 && n_rows >= 0 && n_rows <= (1 << 20), "row losses, a 4-float output, at most 2^20 rows (one workgroup)");
+    hipLaunchKernelGGL(dgll::xent_reduce_kernel, dim3(1), dim3(kBlock), 0, static_cast<hipStream_t>(stream), row_loss, labels, n_rows, n_classes,
+                       out4);
+    DGLL_HIP_TRY(hipGetLastError());
+    return DGLL_OK;
+}
+

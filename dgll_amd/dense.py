@@ -262,6 +262,24 @@ def transform_bf16_dual(a, wt1, wt2, out1=None):
     return o1, o2
 
 
+def _rows16_ok(x):
+    epv = 16 // x.element_size()
+    return x.dim() == 2 and x.stride(1) == 1 and x.stride(0) >= x.shape[1] and x.stride(0) % epv == 0 and x.data_ptr() % 16 == 0
+
+
+def _relu_backward_rows(g, out):
+    """g where out > 0 (aten::threshold_backward), ONE pass whatever g's row pitch.  A gradient whose rows already start on 16-byte
+    boundaries (the loss's: 41 classes on a 128-byte pitch) keeps that layout -- the masked copy is written into a buffer of the same
+    pitch, so the products that follow read it as it is; made dense first (`.contiguous()`) its 82-byte rows were re-laid out four times
+    (twice for the input gradients, twice for the weight gradients: five tiny launches per mini-batch step)."""
+    if g.dim() == 2 and g.stride(1) == 1 and not g.is_contiguous() and _rows16_ok(g):
+        buf = torch.empty((g.shape[0], g.stride(0)), dtype=g.dtype, device=g.device)
+        gm = buf[:, :g.shape[1]]
+        torch.ops.aten.threshold_backward.grad_input(g, out, 0, grad_input=gm)
+        return gm
+    return torch.ops.aten.threshold_backward(g.contiguous(), out, 0)
+
+
 def _as_rows16(x):
     """x with unit column stride and 16-byte aligned rows: itself when it already is, else one copy into a padded buffer."""
     epv = 16 // x.element_size()
@@ -586,8 +604,9 @@ class _SageTransform(torch.autograd.Function):
 
         h, agg, wsd, wnd, out = ctx.saved_tensors
         if ctx.relu:
-            g = torch.ops.aten.threshold_backward(g.contiguous(), out, 0)   # one vectorised pass: g where out > 0
-        g = g.contiguous()
+            g = _relu_backward_rows(g, out)   # one vectorised pass: g where out > 0
+        elif not (g.stride(1) == 1 and _rows16_ok(g)):
+            g = g.contiguous()
         if ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
             # the self path's product straight into its rows of the stacked input's gradient buffer (no copy pass afterwards)
             got = grad_dest(ctx.h_dest, h.shape, g.dtype, g.device, allow_accumulate=False) if (ctx.mfma and g.is_cuda) else None

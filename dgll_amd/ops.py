@@ -393,6 +393,9 @@ def _xent_launch(z, target, soft, row_loss, grad, scale, mask_nonpositive=False,
     _lib.check(code, "dgll_hip_softmax_xent")
 
 
+XENT_ONE_LAUNCH_ROWS = 1 << 16     # up to here the loss of a batch is finished by one workgroup (larger: the two-stage tree below)
+
+
 class _CrossEntropy(torch.autograd.Function):
     """Softmax cross-entropy, one kernel per direction (dgll_hip_softmax_xent / _soft).  The per-row losses are summed in
     two stages (a [n] -> [~sqrt n] -> scalar tree of small reductions) rather than by one large single-output reduction:
@@ -419,6 +422,19 @@ class _CrossEntropy(torch.autograd.Function):
             target = target.to(torch.int64).contiguous()
         z = logits if logits.stride(1) == 1 else logits.contiguous()
         n, c = z.shape
+        if not soft and reduction in ("mean", "sum") and 0 < n <= XENT_ONE_LAUNCH_ROWS:
+            # a mini-batch: {total, count, mean, 1 / count} by ONE native launch (dgll_hip_xent_reduce) instead of nine tensor ops
+            row_loss = torch.empty(n, dtype=torch.float32, device=z.device)
+            _xent_launch(z, target, soft, row_loss, None, None)
+            res = torch.empty(4, dtype=torch.float32, device=z.device)
+            with _lib.on_device(z.device):
+                _lib.check(_lib.lib.dgll_hip_xent_reduce(_lib.raw_stream(z.device), row_loss.data_ptr(), target.data_ptr(), n, c, res.data_ptr()),
+                           "dgll_hip_xent_reduce")
+            ctx.reduction, ctx.soft = reduction, soft
+            ctx.inv_count = res[3] if reduction == "mean" else None
+            ctx.save_for_backward(z, target, None)
+            return res[2] if reduction == "mean" else res[0]
+        ctx.inv_count = None
         store = torch.empty(-(-n // 256) * 256, dtype=torch.float32, device=z.device)   # padded for the two-stage sum
         store[n:].zero_()
         row_loss = store[:n]
@@ -444,7 +460,12 @@ class _CrossEntropy(torch.autograd.Function):
     def backward(ctx, g):
         z, target, count = ctx.saved_tensors
         per_row = ctx.reduction == "none"
-        scale = (g.float() / count if count is not None else g.float()).reshape(-1) if not per_row else None
+        if per_row:
+            scale = None
+        elif ctx.inv_count is not None:
+            scale = (g.float() * ctx.inv_count).reshape(-1)
+        else:
+            scale = (g.float() / count if count is not None else g.float()).reshape(-1)
         # rows of the gradient start on 16-byte (narrow bf16 logits: 128-byte) boundaries: the layer below gathers it and feeds
         # it to the MFMA kernels as it is, without a re-layout pass over [N, C]
         line = 128 // z.element_size()

@@ -30,6 +30,30 @@ def test_cross_entropy_matches_torch(cuda_device, dtype, classes, reduction):
     assert bool((za.grad[::13] == 0).all())
 
 
+@pytest.mark.parametrize("n", [1, 255, 65536, 65537])
+def test_cross_entropy_mean_on_both_sides_of_the_one_launch_bound(cuda_device, n):
+    """Up to ops.XENT_ONE_LAUNCH_ROWS rows the batch's {total, count, mean, 1 / count} come from ONE native launch
+    (dgll_hip_xent_reduce); above, from the two-stage tree of tensor ops: same loss and gradient as torch on both sides, ignored labels
+    counted out, and an all-ignored batch is NaN as in torch."""
+    from dgll_amd import ops
+
+    assert ops.XENT_ONE_LAUNCH_ROWS == 65536
+    torch.manual_seed(n)
+    z = torch.randn(n, 41, device=cuda_device) * 3
+    labels = torch.randint(0, 41, (n,), device=cuda_device)
+    if n > 4:
+        labels[::5] = -100
+    for reduction in ("mean", "sum"):
+        za, zr = z.clone().requires_grad_(), z.clone().requires_grad_()
+        loss = ops.cross_entropy(za, labels, reduction=reduction)
+        ref = F.cross_entropy(zr, labels, reduction=reduction)
+        torch.testing.assert_close(loss, ref, rtol=2e-5, atol=1e-5)
+        loss.backward(); ref.backward()
+        torch.testing.assert_close(za.grad, zr.grad, rtol=1e-5, atol=1e-6 * max(float(zr.grad.abs().max()), 1e-3))
+    ignored = torch.full((n,), -100, device=cuda_device)
+    assert torch.isnan(ops.cross_entropy(z, ignored)) and torch.isnan(F.cross_entropy(z, ignored))
+
+
 def test_cross_entropy_padded_rows_and_errors(cuda_device):
     from dgll_amd import ops
 

@@ -45,3 +45,23 @@ with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CPU, tor
         step()
     torch.cuda.synchronize()
 print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=45, max_name_column_width=70))
+if len(sys.argv) > 1 and sys.argv[1] == "shapes":      # every torch op that launches a kernel, with shapes and the dgll_amd line that issued it
+    import traceback
+    from torch.utils._python_dispatch import TorchDispatchMode
+
+    VIEWS = ("view", "select", "slice", "as_strided", "expand", "reshape", "t.default", "transpose", "unsqueeze", "squeeze", "detach", "alias",
+             "empty", "_unsafe_view", "permute", "narrow", "unbind", "split", "is_", "sym_", "stride", "size", "numel", "_local_scalar")
+
+    class Log(TorchDispatchMode):
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            name = str(func)
+            if not any(v in name for v in VIEWS):
+                frames = [f for f in traceback.extract_stack() if "dgll_amd" in f.filename][-2:]
+                shapes = [tuple(a.shape) for a in args if isinstance(a, torch.Tensor)]
+                print("%-34s %-44s %s" % (name.replace("aten.", ""), str(shapes)[:44],
+                                          " <- ".join("%s:%d %s" % (os.path.basename(f.filename), f.lineno, f.name) for f in reversed(frames))))
+            return func(*args, **(kwargs or {}))
+
+    with Log():
+        step()
+    torch.cuda.synchronize()
