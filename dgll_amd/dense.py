@@ -388,7 +388,8 @@ def input_grads(g, wsd, wnd, out1=None):
         if out1 is not None and (out1.dtype != torch.bfloat16 or out1.stride(0) % 8 or out1.data_ptr() % 16):
             out1 = None
         return transform_bf16_dual(g, wsd, wnd, out1=out1)
-    return mm_nt(g, wsd), mm_nt(g, wnd)
+    # (short gradients: two launches; the first product still lands in the caller's rows when the kernel can write there)
+    return input_grad(g, wsd, out=out1) if out1 is not None else mm_nt(g, wsd), mm_nt(g, wnd)
 
 
 def _rows(g):
