@@ -556,7 +556,7 @@ int dgll_hip_softmax_xent_ex(void* stream, const void* logits, int64_t ldz, int 
                              int64_t ldt, float* row_loss, void* grad, int64_t ldg, const float* grad_scale, int64_t n_rows,
                              int n_classes, int flags);
 /* The loss of a (mini-)batch out of its per-row losses in ONE launch: out4 = {sum of row_loss, number of labels in [0, n_classes)
- * (labels NULL: n_rows), their quotient -- nn.CrossEntropyLoss(reduction='mean'), train_gcn.py:27 / MQGCN.py:132 --, 1 / count (the
+ * (labels NULL: n_rows), their quotient -- nn.CrossEntropyLoss(reduction='mean'), train_gcn.py:27 / buffer_queues.py:106 --, 1 / count (the
  * scale of the gradient pass)}.  One workgroup, fixed summation order; n_rows <= 2^20.                                          */
 int dgll_hip_xent_reduce(void* stream, const float* row_loss, const int64_t* labels, int64_t n_rows, int n_classes, float* out4);
 
