@@ -387,6 +387,7 @@ class MiniBatchPipeline:
         # batch's uploads and the fetch of its uncached rows use the link while the previous batch's gathers and reduction use HBM
         n_extra = max(0, int(os.environ.get("DGLL_LOADER_STREAMS", "2")) - 1) if self.load_stream is not None else 0
         self._load_streams = [self.load_stream] + [torch.cuda.Stream(self.device) for _ in range(n_extra)]
+        self._miss_stages = {}                  # loading stream -> staging buffers of the uncached rows (_bind_miss_stage)
         self._thread = None
         self._error = None
         self._stop = threading.Event()          # set when a stage failed or the consumer left: every producer winds down
@@ -938,7 +939,7 @@ class MiniBatchPipeline:
             d.stage_map = None
             d.upload_blocks = UPLOAD_BLOCKS_ALONE        # the uploads are the link's only users: a wider grid finishes them sooner
             return
-        stages = self.__dict__.setdefault("_miss_stages", {})
+        stages = self._miss_stages
         sg = stages.get(which)
         uncached = max(int(self.cache.node_num) - int(self.cache.cached_num), 1)
         if sg is None or sg["cap"] < min(uncached, sg["cap_outer"], STAGE_CAP if STAGE_CAP > 0 else uncached):
