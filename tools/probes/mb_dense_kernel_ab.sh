@@ -1,0 +1,7 @@
+for rep in 1 2; do
+for dk in 4wave auto; do
+  for frac in 0.5 -1; do
+    timeout -k 30 400 python bench.py --full-line --workload minibatch --no-cpu-baseline --mb-cache-frac $frac --mb-dense-kernel $dk 2>/tmp/mb_err.log | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('dense $dk cache $frac', {k:round(d[k],3) for k in ('batches_per_s','gpu_side_ms_per_batch','gpu_side_ms_per_batch_p95')})" || tail -3 /tmp/mb_err.log
+  done
+done
+done
