@@ -224,12 +224,12 @@ def test_batches_written_in_place_by_the_loading_stage_replay_to_the_same_losses
     torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("streams,cap", [(1, 0), (2, 0), (1, 9)])
-def test_staged_misses_give_the_zero_copy_reduction_bit_for_bit(cuda_device, streams, cap, monkeypatch):
+@pytest.mark.parametrize("streams,cap,feats", [(1, 0, 50), (2, 0, 50), (1, 9, 50), (1, 0, 64)])
+def test_staged_misses_give_the_zero_copy_reduction_bit_for_bit(cuda_device, streams, cap, feats, monkeypatch):
     """csrc/gather.hip: list_misses_kernel + stage_rows_kernel fetch a batch's DISTINCT uncached rows (all hops) into HBM, the hop gathers
     and the outermost hop's reduction then read them there.  Same rows in the same order: every batch's gathered and reduced rows equal
     the zero-copy form's bit for bit -- on one loading stream and two alternating ones, and with a staging buffer of 9 rows (nodes past
-    it stay zero-copy reads)."""
+    it stay zero-copy reads); 64 features: rows of whole 16-byte vectors (the 16-byte-lane forms of all three kernels)."""
     import numpy as np
 
     from dgll_amd import nn as dnn, pipeline as pl, synth
@@ -241,7 +241,7 @@ def test_staged_misses_give_the_zero_copy_reduction_bit_for_bit(cuda_device, str
     from dgll_amd.sampling import FastNeighborSampler
 
     dev = cuda_device
-    nodes, feats, classes, batch, fanouts = 12000, 50, 5, 64, [5, 3, 4]
+    nodes, classes, batch, fanouts = 12000, 5, 64, [5, 3, 4]
     g = synth.products_like_graph(dev, seed=2, n=nodes, n_undirected=nodes * 10, locality=0.0, exact=True)
     indptr, indices = g.rowptr.cpu().numpy(), g.col.cpu().numpy().astype(np.int64)
     x = torch.randn(nodes, feats, generator=torch.Generator().manual_seed(0)).to(torch.bfloat16)
